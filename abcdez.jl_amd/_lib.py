@@ -1,0 +1,80 @@
+"""ctypes binding of ``libabcdez_hip.so`` (C ABI: include/abcdez_hip.h).
+
+Loading fails loudly: there is no CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .model import Model
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libabcdez_hip.so")
+
+_vp, _i64, _u32, _i32, _f64 = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_double
+_pi64, _pf64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+
+# name -> argtypes (every function returns int status unless noted)
+PROTOTYPES = {
+    "abcdez_ctx_create": [C.POINTER(Model), C.c_int, C.POINTER(_vp)],
+    "abcdez_ctx_destroy": [_vp],
+    "abcdez_ctx_set_stream": [_vp, _vp],
+    "abcdez_ctx_set_lanes": [_vp, C.c_int],
+    "abcdez_ctx_get_layout": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
+    "abcdez_sync": [_vp],
+    "abcdez_dev_alloc": [C.c_size_t, C.POINTER(_vp)],
+    "abcdez_dev_free": [_vp],
+    "abcdez_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
+    "abcdez_memcpy_d2h": [_vp, _vp, _vp, C.c_size_t],
+    "abcdez_init": [_vp, _vp, _vp, _vp, _i64, _i64],
+    "abcdez_alive_compact": [_vp, _vp, _i64, _vp, _vp, _pi64],
+    "abcdez_smc_swarm": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64,
+                         _i64, _i64, C.c_int, _u32, _pi64, _pi64],
+    "abcdez_smc_reweight": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64],
+    "abcdez_get_ess": [_vp, _vp, _i64, _pf64],
+    "abcdez_tree_sum": [_vp, _vp, _i64, _pf64],
+    "abcdez_wsample_stratified": [_vp, _vp, _i64, _u32, _vp],
+    "abcdez_smc_resample_gather": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _f64, _pf64, _pf64, _pf64],
+    "abcdez_extrema": [_vp, _vp, _i64, _pf64, _pf64],
+    "abcdez_count_gt": [_vp, _vp, _i64, _f64, _pi64],
+    "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _vp, _vp],
+    "abcdez_mc_swarm": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64, _u32,
+                        _pi64],
+    "abcdez_push_p": [_vp, _vp, _i64, _vp],
+    "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
+}
+# symbols with a non-status return type
+OTHER_SYMBOLS = ("abcdez_version", "abcdez_last_error")
+
+
+class AbcdezError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raise if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise AbcdezError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C abcdez.jl_amd/csrc`).  The population loop has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.abcdez_version.restype = C.c_int
+    lib.abcdez_last_error.restype = C.c_char_p
+    _LIB = lib
+    return lib
+
+
+def check(lib, rc: int) -> None:
+    if rc != 0:
+        msg = lib.abcdez_last_error()
+        raise AbcdezError(f"libabcdez_hip: status {rc}: {msg.decode('utf-8', 'replace') if msg else ''}")

@@ -1,0 +1,344 @@
+/*
+ * abz_api.hip -- the extern "C" surface of libabcdez_hip.so (include/abcdez_hip.h).
+ * Argument checking, context life cycle and the host ends of the scalar-returning
+ * calls; all device work is launched from the kernel files.
+ */
+#include <string.h>
+
+#include <mutex>
+
+#include "../../include/abcdez_hip.h"
+#include "abz_ctx.h"
+
+int abz_tree_sum_impl(abcdez_ctx*, const double*, int64_t, int, double*);
+int abz_reweight_impl(abcdez_ctx*, const double*, double*, uint8_t*, int64_t, double, double, double*, double*, int64_t*);
+int abz_compact_impl(abcdez_ctx*, const uint8_t*, int64_t, uint32_t*, uint32_t*, int64_t*);
+int abz_stratified_impl(abcdez_ctx*, const double*, int64_t, uint32_t, uint32_t*);
+int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t, double*, double*, int64_t*);
+int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
+int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
+int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, uint32_t*, double*);
+int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
+
+static thread_local std::string g_err;
+void abz_set_error(const std::string& msg) { g_err = msg; }
+
+#define ABZ_REQUIRE(cond, msg)      \
+  do {                              \
+    if (!(cond)) {                  \
+      abz_set_error(msg);           \
+      return -1;                    \
+    }                               \
+  } while (0)
+
+int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return 0;
+  /* growing is rare (first call per population size); it synchronises the stream */
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) ABZ_HIP_CHECK(hipFree(ctx->ws));
+  ctx->ws = nullptr; ctx->ws_bytes = 0;
+  const size_t want = abz_align(bytes + bytes / 4, 1 << 20);
+  ABZ_HIP_CHECK(hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return 0;
+}
+
+static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+/* default lane-group shape: 4 components (two 16-byte loads) per lane for the
+ * component-parallel simulator, the whole row in one thread otherwise            */
+static void default_shape(const abz_model& m, int* L, int* C) {
+  if (m.sim_id == ABZ_SIM_MVN && m.ld >= 8) { *C = 4; *L = m.ld / 4; }
+  else { *L = 1; *C = m.ld; }
+}
+
+extern "C" {
+
+int abcdez_version(void) { return 100; }
+const char* abcdez_last_error(void) { return g_err.c_str(); }
+
+int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
+  ABZ_REQUIRE(model && out, "ctx_create: null argument");
+  ABZ_REQUIRE(model->d >= 1 && model->d <= ABZ_MAX_D, "ctx_create: d out of range");
+  ABZ_REQUIRE(is_pow2(model->ld) && model->ld >= model->d && model->ld < 2 * model->d + (model->d == 1),
+              "ctx_create: ld must be the smallest power of two >= d");
+  ABZ_REQUIRE(model->abck >= 0 && model->abck <= 3, "ctx_create: unknown ABC kernel id");
+  ABZ_REQUIRE(model->sim_id >= 0 && model->sim_id <= ABZ_SIM_LV, "ctx_create: unknown simulator id");
+  ABZ_REQUIRE(model->n_data >= 0 && (model->n_data == 0 || model->data), "ctx_create: data pointer missing");
+  for (int k = 0; k < model->ld; ++k) {
+    const int fam = model->prior[k].family;
+    ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_DUNIFORM, "ctx_create: unknown prior family");
+    ABZ_REQUIRE((k < model->d) == (fam != ABZ_PRIOR_PAD), "ctx_create: prior descriptor / d mismatch");
+  }
+  switch (model->sim_id) {
+    case ABZ_SIM_NORMAL1D: ABZ_REQUIRE(model->d == 1 && model->n_data >= 1, "normal1d: needs d = 1 and one datum"); break;
+    case ABZ_SIM_MVN: ABZ_REQUIRE(model->n_data >= model->d, "mvn: needs d data values"); break;
+    case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: ABZ_REQUIRE(model->d == 1, "simulator needs d = 1"); break;
+    case ABZ_SIM_QUAD2D: case ABZ_SIM_NORMDU: ABZ_REQUIRE(model->d == 2, "simulator needs d = 2"); break;
+    case ABZ_SIM_WIENER: ABZ_REQUIRE(model->d == 2 && model->n_data >= 1, "wiener: needs d = 2 and data"); break;
+    case ABZ_SIM_LV:
+      ABZ_REQUIRE(model->d == 4 && model->n_data >= 2 && model->n_data % 2 == 0, "lv: needs d = 4 and (x,y) data");
+      ABZ_REQUIRE(model->sim_p[3] >= 1.0 && model->sim_p[3] <= 1e6, "lv: steps per observation out of range");
+      break;
+    default: break;
+  }
+  int ndev = 0;
+  ABZ_HIP_CHECK(hipGetDeviceCount(&ndev));
+  ABZ_REQUIRE(ndev > 0, "ctx_create: no HIP device visible");
+  ABZ_REQUIRE(device >= 0 && device < ndev, "ctx_create: device index out of range");
+  ABZ_HIP_CHECK(hipSetDevice(device));
+  abcdez_ctx* ctx = new abcdez_ctx();
+  ctx->device = device;
+  ctx->h_model = *model;
+  default_shape(*model, &ctx->L, &ctx->C);
+  if (model->n_data > 0) {
+    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_data, (size_t)model->n_data * 8));
+    ABZ_HIP_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));
+  }
+  ctx->h_model.data = ctx->d_data;
+  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
+  ABZ_HIP_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
+  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
+  ABZ_HIP_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
+  ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
+  *out = ctx;
+  return 0;
+}
+
+int abcdez_ctx_destroy(abcdez_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->d_scal) (void)hipFree(ctx->d_scal);
+  if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  if (ctx->d_model) (void)hipFree(ctx->d_model);
+  if (ctx->d_data) (void)hipFree(ctx->d_data);
+  delete ctx;
+  return 0;
+}
+
+int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
+  ABZ_REQUIRE(ctx, "set_stream: null context");
+  ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes) {
+  ABZ_REQUIRE(ctx, "set_lanes: null context");
+  if (lanes <= 0) { default_shape(ctx->h_model, &ctx->L, &ctx->C); return 0; }
+  const int ld = ctx->h_model.ld;
+  ABZ_REQUIRE(is_pow2(lanes) && lanes <= 16 && ld % lanes == 0, "set_lanes: lanes must be a power of two <= 16 dividing ld");
+  ABZ_REQUIRE(lanes == 1 || ctx->h_model.sim_id == ABZ_SIM_MVN, "set_lanes: this simulator needs the whole row in one thread");
+  const int C = ld / lanes;
+  ABZ_REQUIRE(lanes == 1 || C >= 2, "set_lanes: at least two components per lane");
+  ctx->L = lanes; ctx->C = C;
+  return 0;
+}
+
+int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lanes, int32_t* comps) {
+  ABZ_REQUIRE(ctx, "get_layout: null context");
+  if (ld) *ld = ctx->h_model.ld;
+  if (lanes) *lanes = ctx->L;
+  if (comps) *comps = ctx->C;
+  return 0;
+}
+
+int abcdez_sync(abcdez_ctx* ctx) {
+  ABZ_REQUIRE(ctx, "sync: null context");
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int abcdez_dev_alloc(size_t bytes, void** out) {
+  ABZ_REQUIRE(out, "dev_alloc: null argument");
+  ABZ_HIP_CHECK(hipMalloc(out, bytes ? bytes : 8));
+  return 0;
+}
+int abcdez_dev_free(void* ptr) {
+  if (ptr) ABZ_HIP_CHECK(hipFree(ptr));
+  return 0;
+}
+int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ABZ_REQUIRE(ctx && dst && src, "memcpy_h2d: null argument");
+  ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ABZ_REQUIRE(ctx && dst && src, "memcpy_d2h: null argument");
+  ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+static int read_counters(abcdez_ctx* ctx) {
+  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+#define ABZ_MAX_N 0x7FFFFFFFll /* indices are 32-bit on the device */
+
+int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
+  ABZ_REQUIRE(ctx && theta && logpi && delta, "init: null argument");
+  ABZ_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= ABZ_MAX_N, "init: range out of bounds");
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_INITBAD, 0, 8, ctx->stream));
+  int rc = abz_launch_init(ctx, theta, logpi, delta, i0, n);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  ABZ_REQUIRE(ctx->h_scal[ABZ_S_INITBAD] == 0, "init: a particle found no finite (log-prior, distance) within the retry limit");
+  return 0;
+}
+
+int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
+                         int64_t* n_alive) {
+  ABZ_REQUIRE(ctx && alive && alive_idx && arank && n_alive, "alive_compact: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact: N out of range");
+  return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive);
+}
+
+int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive, int64_t r_lo,
+                     int64_t r_hi, const double* theta, const double* logpi, const double* delta, double* ntheta,
+                     double* nlogpi, double* ndelta, double eps, double gamma0, double gamma_sigma, int64_t i0,
+                     int64_t n_local, int copy_dead, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && alive_idx && arank && theta && logpi && delta && ntheta && nlogpi && ndelta && nacc && nsim,
+              "smc_swarm: null argument");
+  /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm: alive-rank range out of bounds");
+  ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= ABZ_MAX_N, "smc_swarm: particle range out of bounds");
+  ABZ_REQUIRE(r_hi - r_lo <= n_local, "smc_swarm: more alive ranks than particles in the range");
+  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "smc_swarm: in/out arrays must differ (synchronous update)");
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NACC, 0, 16, ctx->stream));
+  int rc = abz_launch_smc_swarm(ctx, alive_idx, arank, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, theta, logpi,
+                                delta, ntheta, nlogpi, ndelta, eps, gamma0, gamma_sigma, (uint32_t)i0,
+                                (uint32_t)n_local, copy_dead, sweep);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
+  return 0;
+}
+
+int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
+                        double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
+  ABZ_REQUIRE(ctx && delta && wns && alive && wnorm && ess && n_alive, "smc_reweight: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_reweight: N out of range");
+  ABZ_REQUIRE(eps_old >= 0.0 && eps_new >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
+  return abz_reweight_impl(ctx, delta, wns, alive, N, eps_old, eps_new, wnorm, ess, n_alive);
+}
+
+int abcdez_get_ess(abcdez_ctx* ctx, const double* wns, int64_t N, double* ess) {
+  ABZ_REQUIRE(ctx && wns && ess, "get_ess: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "get_ess: N out of range");
+  double s;
+  int rc = abz_tree_sum_impl(ctx, wns, N, 1, &s);
+  if (rc) return rc;
+  *ess = 1.0 / s;
+  return 0;
+}
+
+int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out) {
+  ABZ_REQUIRE(ctx && x && out, "tree_sum: null argument");
+  ABZ_REQUIRE(n >= 1 && n <= ABZ_MAX_N, "tree_sum: n out of range");
+  return abz_tree_sum_impl(ctx, x, n, 0, out);
+}
+
+int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds) {
+  ABZ_REQUIRE(ctx && wns && inds, "wsample_stratified: null argument");
+  /* stratum index and 40 fraction bits must fit 63 bits */
+  ABZ_REQUIRE(N >= 1 && N <= (1ll << 23), "wsample_stratified: N must be <= 2^23");
+  return abz_stratified_impl(ctx, wns, N, draw, inds);
+}
+
+int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
+                               const double* theta, const double* logpi, const double* delta, double* ntheta,
+                               double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
+  ABZ_REQUIRE(ctx && inds && theta && logpi && delta && ntheta && nlogpi && ndelta && wns && alive,
+              "smc_resample_gather: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && i0 >= 0 && n_local >= 0 && i0 + n_local <= N,
+              "smc_resample_gather: range out of bounds");
+  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "smc_resample_gather: in/out arrays must differ");
+  return abz_launch_resample_gather(ctx, inds, (uint32_t)N, (uint32_t)i0, (uint32_t)n_local, theta, logpi, delta,
+                                    ntheta, nlogpi, ndelta, wns, alive);
+}
+
+int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double p, double* q,
+                          double* xj, double* xj1) {
+  ABZ_REQUIRE(ctx && delta && alive && q, "quantile_alive: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "quantile_alive: N out of range");
+  ABZ_REQUIRE(p >= 0.0 && p <= 1.0, "quantile_alive: p must be in [0, 1]");
+  int64_t n = 0, n_le;
+  double a, b;
+  int rc = abz_count_alive_impl(ctx, alive, N, &n);
+  if (rc) return rc;
+  ABZ_REQUIRE(n >= 1, "quantile_alive: no alive particles");
+  /* Julia Statistics.quantile, type 7: h = (n-1) p + 1, j = clamp(floor(h), 1, n-1), g = h - j */
+  const double h = (double)(n - 1) * p + 1.0;
+  int64_t j = (int64_t)__builtin_floor(h);
+  if (j < 1) j = 1;
+  if (j > n - 1) j = n - 1 > 1 ? n - 1 : 1;
+  const double g = h - (double)j;
+  rc = abz_select_impl(ctx, delta, alive, N, j - 1, &a, &b, &n_le);
+  if (rc) return rc;
+  if (n == 1) b = a;
+  *q = a + g * (b - a);
+  if (xj) *xj = a;
+  if (xj1) *xj1 = b;
+  return 0;
+}
+
+int abcdez_extrema(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi) {
+  ABZ_REQUIRE(ctx && delta && lo && hi, "extrema: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "extrema: N out of range");
+  return abz_extrema_impl(ctx, delta, N, lo, hi);
+}
+
+int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count) {
+  ABZ_REQUIRE(ctx && delta && count, "count_gt: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "count_gt: N out of range");
+  return abz_count_gt_impl(ctx, delta, N, thr, count);
+}
+
+int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta) {
+  ABZ_REQUIRE(ctx && delta && order && sorted_delta, "mc_rank_prepare: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
+  return abz_rank_prepare_impl(ctx, delta, N, order, sorted_delta);
+}
+
+int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N, const double* theta,
+                    const double* logpi, const double* delta, double* ntheta, double* nlogpi, double* ndelta,
+                    double eps_pop, double eps_target, double gamma0, double gamma_sigma, int64_t i0, int64_t n_local,
+                    uint32_t sweep, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && order && sorted_delta && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
+              "mc_swarm: null argument");
+  ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
+  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NACC, 0, 16, ctx->stream));
+  int rc = abz_launch_mc_swarm(ctx, order, sorted_delta, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
+                               eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
+  return 0;
+}
+
+int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) {
+  ABZ_REQUIRE(ctx && theta && out, "push_p: null argument");
+  ABZ_REQUIRE(N >= 0 && N <= ABZ_MAX_N, "push_p: N out of range");
+  return abz_launch_push_p(ctx, theta, N, out);
+}
+
+int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
+  ABZ_REQUIRE(ctx && x && y, "math_eval: null argument");
+  ABZ_REQUIRE(fn >= 0 && fn <= 6 && (y2 || (fn != 2 && fn != 6)), "math_eval: bad function id / missing second array");
+  return abz_math_eval_impl(ctx, fn, x, y, y2, n);
+}
+
+} /* extern "C" */

@@ -1,0 +1,64 @@
+/* abz_ctx.h -- internal context of libabcdez_hip.so (not part of the ABI). */
+#ifndef ABZ_CTX_H
+#define ABZ_CTX_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "abcdez_spec.h"
+
+struct abcdez_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  abz_model h_model;              /* host copy; .data points at d_data          */
+  abz_model* d_model = nullptr;
+  double* d_data = nullptr;
+  int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
+  /* device scalars + pinned host mirror */
+  unsigned long long* d_scal = nullptr;   /* 32 x u64                           */
+  unsigned long long* h_scal = nullptr;
+  /* growable workspace */
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+void abz_set_error(const std::string& msg);
+
+#define ABZ_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      abz_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+/* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
+int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
+
+static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+/* scalar slots in d_scal / h_scal */
+enum {
+  ABZ_S_NACC = 0, ABZ_S_NSIM = 1, ABZ_S_WNORM = 2, ABZ_S_SUMSQ = 3, ABZ_S_NALIVE = 4,
+  ABZ_S_MIN = 5, ABZ_S_MAX = 6, ABZ_S_COUNT = 7, ABZ_S_LASTPOS = 8, ABZ_S_SUM = 9,
+  ABZ_S_SEL_PREFIX = 10, ABZ_S_SEL_K = 11, ABZ_S_SEL_LESS = 12, ABZ_S_SEL_EQ = 13, ABZ_S_SEL_NEXT = 14,
+  ABZ_S_INITBAD = 15, ABZ_S_N = 32
+};
+
+/* kernel launchers implemented across the .hip files */
+int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
+int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
+                         const double*, const double*, const double*, double*, double*, double*,
+                         double, double, double, uint32_t, uint32_t, int, uint32_t);
+int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, const double*, const double*,
+                        const double*, double*, double*, double*, double, double, double, double,
+                        uint32_t, uint32_t, uint32_t);
+int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,
+                               const double*, const double*, double*, double*, double*, double*, uint8_t*);
+int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
+
+#endif

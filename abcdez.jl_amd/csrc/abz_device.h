@@ -1,0 +1,215 @@
+/*
+ * abz_device.h -- device-side building blocks shared by the gfx950 kernels.
+ *
+ * Thread mapping ("lane group"): L consecutive lanes of a wavefront own one
+ * particle; theta is row-major double[N][ld] with ld = L*C.  Lane j of the group
+ * owns the components k(m,c) = m*2L + 2j + c (m < C/2, c < 2), i.e. load m of the
+ * group is one contiguous run of L*16 bytes -- a whole 128-B line for L = 8.  Own
+ * rows are therefore read fully coalesced and the two DE donor rows, which are
+ * uniformly random rows of the table, are fetched as whole contiguous rows.
+ * Per-particle sums follow the canonical pairwise tree of abcdez_spec.h: level 0
+ * inside the lane, then an xor butterfly over the L lanes, then a binary tree over m.
+ */
+#ifndef ABZ_DEVICE_H
+#define ABZ_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "abcdez_spec.h"
+
+#define ABZ_BLOCK 256
+
+/* ---- component ownership ------------------------------------------------------- */
+template <int L, int C>
+struct Lay {
+  static constexpr int M = (C + 1) / 2;              /* 16-byte loads per row per lane */
+  static constexpr int LD = L * C;
+  __device__ static inline int comp(int j, int m, int c) { return C == 1 ? 0 : m * 2 * L + 2 * j + c; }
+};
+
+template <int L, int C>
+__device__ inline void load_row(const double* __restrict__ row, int j, double (&v)[C]) {
+  if constexpr (C == 1) {
+    v[0] = row[0];
+  } else {
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) {
+      const double2 t = *reinterpret_cast<const double2*>(row + m * 2 * L + 2 * j);
+      v[2 * m] = t.x; v[2 * m + 1] = t.y;
+    }
+  }
+}
+template <int L, int C>
+__device__ inline void store_row(double* __restrict__ row, int j, const double (&v)[C]) {
+  if constexpr (C == 1) {
+    row[0] = v[0];
+  } else {
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) {
+      double2 t; t.x = v[2 * m]; t.y = v[2 * m + 1];
+      *reinterpret_cast<double2*>(row + m * 2 * L + 2 * j) = t;
+    }
+  }
+}
+
+/* ---- canonical per-particle tree sum ------------------------------------------- */
+__device__ inline double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+template <int L, int C>
+__device__ inline double group_tree_sum(const double (&x)[C]) {
+  if constexpr (C == 1) {
+    return x[0];
+  } else {
+    constexpr int M = C / 2;
+    double s[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double t = x[2 * m] + x[2 * m + 1];            /* level 0: (2t, 2t+1)            */
+#pragma unroll
+      for (int off = 1; off < L; off <<= 1) t = t + shfl_xor_f64(t, off);   /* over lanes */
+      s[m] = t;
+    }
+#pragma unroll
+    for (int st = 1; st < M; st <<= 1)               /* over m                         */
+#pragma unroll
+      for (int m = 0; m + st < M; m += 2 * st) s[m] = s[m] + s[m + st];
+    return s[0];
+  }
+}
+
+/* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */
+template <int L, int C>
+__device__ inline double group_logprior(const abz_model* __restrict__ M, int j, const double (&p)[C], double (&pp)[C]) {
+  double lp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    const int k = Lay<L, C>::comp(j, q / 2, q & 1);
+    const abz_prior_dim* pd = &M->prior[k];
+    pp[q] = abz_push_p(pd, p[q]);
+    lp[q] = abz_prior_logpdf1(pd, pp[q]);
+  }
+  return group_tree_sum<L, C>(lp);
+}
+
+/* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
+template <int SIM, int L, int C>
+__device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const double (&th)[C],
+                                  uint32_t i, uint32_t epoch, uint32_t purpose) {
+  const uint64_t seed = M->seed;
+  if constexpr (SIM == ABZ_SIM_NORMAL1D) {
+    double z0, z1;
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+    const double x = abz_fma(M->sim_p[0], z0, th[0]);
+    return __builtin_fabs(x - M->data[0]);
+  } else if constexpr (SIM == ABZ_SIM_MVN) {
+    const double sg = M->sim_p[0];
+    const int d = M->d;
+    double sq[C];
+    if constexpr (C == 1) {
+      double z0, z1;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+      const double e = abz_fma(sg, z0, th[0]) - M->data[0];
+      sq[0] = e * e;
+    } else {
+#pragma unroll
+      for (int m = 0; m < C / 2; ++m) {
+        double z[2];
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose), &z[0], &z[1]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int k = Lay<L, C>::comp(j, m, c);
+          double v = 0.0;
+          if (k < d) {
+            const double e = abz_fma(sg, z[c], th[2 * m + c]) - M->data[k];
+            v = e * e;
+          }
+          sq[2 * m + c] = v;
+        }
+      }
+    }
+    return abz_sqrt(group_tree_sum<L, C>(sq));
+  } else if constexpr (SIM == ABZ_SIM_DIRAC) {
+    return __builtin_fabs((th[0] * th[0] + 1.0) - M->sim_p[0]);
+  } else if constexpr (SIM == ABZ_SIM_QUAD2D) {
+    double n1, n2;
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    const double u = abz_u01_co(abz_rng(seed, i, epoch, 1, purpose).w0);
+    const double a = (th[0] + n1 * 0.01) - th[1] * th[1];
+    const double b = (th[1] - 1.0) + n2 * 0.01;
+    const double r = 50.0 * (a * a) + b * b;
+    return (u < M->sim_p[0]) ? ABZ_INF : r;
+  } else if constexpr (SIM == ABZ_SIM_MIXTURE) {
+    double n1, n2;
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    const uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
+    const double x = th[0] + (coin ? n2 : n1 * 0.1);
+    return __builtin_fabs(x - M->sim_p[0]);
+  } else if constexpr (SIM == ABZ_SIM_NORMDU) {
+    double n1, n2;
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    const double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
+    return __builtin_fabs(x - M->sim_p[0]);
+  } else if constexpr (SIM == ABZ_SIM_WIENER) {
+    const double f = 0.95 + 0.1 * abz_u01_co(abz_rng(seed, i, epoch, 0, purpose).w0);
+    double acc = 0.0;
+    const int n = M->n_data;
+    for (int t = 0; t < n; ++t) {
+      const double dt = (double)t;
+      const double v = abz_sqrt(th[0] * th[0] * dt * dt + th[1] * th[1] * dt) * f;
+      acc += __builtin_fabs(v - M->data[t]);
+    }
+    return acc / (double)n;
+  } else if constexpr (SIM == ABZ_SIM_LV) {
+    const double a = th[0], b = th[1], c = th[2], e = th[3];
+    double x = M->sim_p[0], y = M->sim_p[1];
+    const double h = M->sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
+    const int steps = (int)M->sim_p[3];
+    const double sn = M->sim_p[4];
+    const int nobs = M->n_data / 2;
+    double acc = 0.0;
+    for (int jo = 0; jo < nobs; ++jo) {
+      double z0, z1;
+      abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), &z0, &z1);
+      const double ex = abz_fma(sn, z0, x) - M->data[2 * jo];
+      const double ey = abz_fma(sn, z1, y) - M->data[2 * jo + 1];
+      acc = abz_fma(ex, ex, acc);
+      acc = abz_fma(ey, ey, acc);
+      if (jo + 1 == nobs) break;
+      for (int s = 0; s < steps; ++s) {
+        const double k1x = x * abz_fma(-b, y, a), k1y = y * abz_fma(e, x, -c);
+        const double xa = abz_fma(h2, k1x, x), ya = abz_fma(h2, k1y, y);
+        const double k2x = xa * abz_fma(-b, ya, a), k2y = ya * abz_fma(e, xa, -c);
+        const double xb = abz_fma(h2, k2x, x), yb = abz_fma(h2, k2y, y);
+        const double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
+        const double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
+        const double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
+        x = abz_fma(h6, (k1x + 2.0 * k2x) + (2.0 * k3x + k4x), x);
+        y = abz_fma(h6, (k1y + 2.0 * k2y) + (2.0 * k3y + k4y), y);
+      }
+    }
+    return abz_sqrt(acc);
+  } else {
+    return ABZ_NAN;
+  }
+}
+
+/* ---- block-level integer counters: wave ballot -> LDS -> one global atomic per block */
+__device__ inline void block_count2(bool f0, bool f1, unsigned long long* __restrict__ out) {
+  __shared__ unsigned int s_cnt[2];
+  if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+  __syncthreads();
+  const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned int c0 = (unsigned int)__popcll(b0), c1 = (unsigned int)__popcll(b1);
+    if (c0) atomicAdd(&s_cnt[0], c0);
+    if (c1) atomicAdd(&s_cnt[1], c1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_cnt[0]) atomicAdd(&out[0], (unsigned long long)s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&out[1], (unsigned long long)s_cnt[1]);
+  }
+}
+
+#endif /* ABZ_DEVICE_H */

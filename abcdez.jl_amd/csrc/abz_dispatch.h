@@ -1,0 +1,37 @@
+/* abz_dispatch.h -- (simulator, lanes, comps-per-lane) -> template instantiation. */
+#ifndef ABZ_DISPATCH_H
+#define ABZ_DISPATCH_H
+
+#include <type_traits>
+
+#include "abz_ctx.h"
+#include "abz_device.h"
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+/* Shapes.  Component-parallel simulators (MVN) may spread a row over L lanes;
+ * the others need the whole row in one thread (L = 1, ld <= 8).                   */
+#define ABZ_FOR_EACH_SHAPE(X)                                                            \
+  X(ABZ_SIM_MVN, 1, 1) X(ABZ_SIM_MVN, 1, 2) X(ABZ_SIM_MVN, 1, 4) X(ABZ_SIM_MVN, 2, 2)    \
+  X(ABZ_SIM_MVN, 2, 4) X(ABZ_SIM_MVN, 4, 2) X(ABZ_SIM_MVN, 4, 4) X(ABZ_SIM_MVN, 8, 2)    \
+  X(ABZ_SIM_MVN, 8, 4) X(ABZ_SIM_MVN, 4, 8) X(ABZ_SIM_MVN, 16, 2) X(ABZ_SIM_MVN, 16, 4)  \
+  X(ABZ_SIM_MVN, 2, 16) X(ABZ_SIM_MVN, 1, 8)                                             \
+  X(ABZ_SIM_NORMAL1D, 1, 1) X(ABZ_SIM_DIRAC, 1, 1) X(ABZ_SIM_MIXTURE, 1, 1)              \
+  X(ABZ_SIM_QUAD2D, 1, 2) X(ABZ_SIM_NORMDU, 1, 2) X(ABZ_SIM_WIENER, 1, 2)                \
+  X(ABZ_SIM_LV, 1, 4)
+
+template <class F>
+static inline bool abz_dispatch(int sim, int L, int C, F&& f) {
+#define ABZ_X(S, LL, CC)                                   \
+  if (sim == S && L == LL && C == CC) {                    \
+    f(IC<S>{}, IC<LL>{}, IC<CC>{});                        \
+    return true;                                           \
+  }
+  ABZ_FOR_EACH_SHAPE(ABZ_X)
+#undef ABZ_X
+  return false;
+}
+
+static inline unsigned abz_grid(uint64_t threads) { return (unsigned)((threads + ABZ_BLOCK - 1) / ABZ_BLOCK); }
+
+#endif

@@ -1,0 +1,173 @@
+/*
+ * abz_mc_swarm.hip -- one greedy ABC-DE-MCMC sweep over all N particles, plus the
+ * resampling gather and push_p.
+ *
+ * abcdemc_swarm! (src/abcdez_mc.jl:5-61) with the copies of mc:140-143 fused in.
+ * The "better particle" draw s = rand((1:N)[Ds .<= Ds[i]]) (mc:23) indexes the
+ * (Ds, index)-sorted order built once per generation by abcdez_mc_rank_prepare:
+ * the candidate set is order[0 .. cnt), cnt = upper_bound(sorted_delta, Ds[i]).
+ */
+#include "abz_dispatch.h"
+
+struct McSwarmArgs {
+  const abz_model* model;
+  const uint32_t* order;
+  const double* sorted_delta;
+  const double* theta;
+  const double* logpi;
+  const double* delta;
+  double* ntheta;
+  double* nlogpi;
+  double* ndelta;
+  unsigned long long* counters;
+  double eps_pop, eps_target, gamma0, gsig;
+  uint32_t N, i0, n_local, sweep;
+};
+
+__device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <int SIM, int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a) {
+  constexpr int LD = L * C;
+  const abz_model* __restrict__ M = a.model;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_local;
+  const uint32_t i = a.i0 + (active ? grp : 0u);
+  const uint64_t seed = M->seed;
+
+  const double lpi = a.logpi[i];
+  const double di = a.delta[i];
+  const double eps = di <= a.eps_target ? a.eps_target : a.eps_pop;       /* mc:19 */
+  uint32_t s = i;
+  if (di > eps) {                                                         /* mc:20-24 */
+    const uint32_t cnt = upper_bound_f64(a.sorted_delta, a.N, di);
+    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, cnt)];
+  }
+  uint32_t ia, ib;                                                        /* mc:25-32 */
+  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.N, s, &ia, &ib);
+
+  double ti[C], ts[C], ta[C], tb[C];
+  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+  load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
+  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+
+  double z0, z1;
+  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+  const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
+  double tp[C], pp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
+
+  const double lp = group_logprior<L, C>(M, j, tp, pp);                   /* mc:41 */
+  const double w_prior = lp - lpi;                                        /* mc:42 */
+  const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
+  double mn = w_prior < 0.0 ? w_prior : 0.0;
+  if (abz_isnan(w_prior)) mn = w_prior;
+  const bool simulate = !(abz_log(u) > mn);                               /* mc:43 */
+  bool acc = false;
+  double dp = di;
+  if (simulate) {
+    dp = sim_dist<SIM, L, C>(M, j, pp, i, a.sweep, ABZ_RNG_SIM);          /* mc:45 */
+    const double thr = eps > di ? eps : di;
+    acc = dp <= thr;                                                      /* mc:54 */
+  }
+  if (active) {
+    double to[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+    if (j == 0) {
+      a.nlogpi[i] = acc ? lp : lpi;
+      a.ndelta[i] = acc ? dp : di;
+    }
+  }
+  block_count2(false, active && j == 0 && simulate, a.counters + ABZ_S_NACC);
+}
+
+int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, uint32_t N,
+                        const double* theta, const double* logpi, const double* delta, double* ntheta, double* nlogpi,
+                        double* ndelta, double eps_pop, double eps_target, double gamma0, double gsig, uint32_t i0,
+                        uint32_t n_local, uint32_t sweep) {
+  if (n_local == 0) return 0;
+  McSwarmArgs a;
+  a.model = ctx->d_model; a.order = order; a.sorted_delta = sorted_delta;
+  a.theta = theta; a.logpi = logpi; a.delta = delta;
+  a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
+  a.counters = ctx->d_scal;
+  a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
+  a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
+  bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
+    hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())), dim3(ABZ_BLOCK),
+                       0, ctx->stream, a);
+  });
+  if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) ---- */
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_kernel(
+    const uint32_t* __restrict__ inds, uint32_t N, uint32_t i0, uint32_t n, const double* __restrict__ theta,
+    const double* __restrict__ logpi, const double* __restrict__ delta, double* __restrict__ ntheta,
+    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  if (grp >= n) return;
+  const uint32_t s = i0 + grp;
+  const uint32_t src = inds[s];
+  double t[C];
+  load_row<L, C>(theta + (size_t)src * LD, j, t);
+  store_row<L, C>(ntheta + (size_t)s * LD, j, t);
+  if (j == 0) {
+    nlogpi[s] = logpi[src];
+    ndelta[s] = delta[src];
+    wns[s] = 1.0 / (double)N;
+    alive[s] = 1;
+  }
+}
+
+int abz_launch_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N, uint32_t i0, uint32_t n_local,
+                               const double* theta, const double* logpi, const double* delta, double* ntheta,
+                               double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
+  if (n_local == 0) return 0;
+  bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto, auto LL, auto CC) {
+    hipLaunchKernelGGL((resample_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())),
+                       dim3(ABZ_BLOCK), 0, ctx->stream, inds, N, i0, n_local, theta, logpi, delta, ntheta, nlogpi,
+                       ndelta, wns, alive);
+  });
+  if (!ok) { abz_set_error("resample_gather: unsupported layout"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* ---- T2 push_p over the population (result P, smc:382, mc:166) ---- */
+__global__ __launch_bounds__(ABZ_BLOCK) void push_p_kernel(const abz_model* __restrict__ M,
+                                                           const double* __restrict__ theta, uint64_t total,
+                                                           double* __restrict__ out) {
+  const uint64_t e = (uint64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (e >= total) return;
+  const int k = (int)(e % (uint64_t)M->ld);
+  out[e] = abz_push_p(&M->prior[k], theta[e]);
+}
+
+int abz_launch_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) {
+  const uint64_t total = (uint64_t)N * (uint64_t)ctx->h_model.ld;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(push_p_kernel, dim3(abz_grid(total)), dim3(ABZ_BLOCK), 0, ctx->stream, ctx->d_model, theta,
+                     total, out);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}

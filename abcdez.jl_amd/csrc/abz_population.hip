@@ -1,0 +1,615 @@
+/*
+ * abz_population.hip -- population-wide streaming passes around the sweeps:
+ *   tile-tree sums + ABC-kernel reweighting  (src/abcdez_smc.jl:59-83, :308-311, :8)
+ *   alive compaction (wave ballot / popcount prefix)   (implicit in smc:121,125)
+ *   integer cumulative weights + stratified search     (src/abcdez_smc.jl:15-56)
+ *   radix select for the eps-quantile                  (src/abcdez_smc.jl:301)
+ *   extrema / counts                                   (smc:286,364; mc:133,146,156,163)
+ * All HBM-streaming, a few bytes per particle per generation.
+ */
+#include <string.h>
+
+#include "abz_ctx.h"
+#include "abz_device.h"
+
+/* ================================================================ tile-tree sum
+ * The fixed summation tree of abcdez_spec.h.  One block = one tile of 2048.     */
+enum { LOAD_PLAIN = 0, LOAD_SQUARE = 1, LOAD_WPROD = 2, LOAD_NORMALISE = 3 };
+
+struct TileArgs {
+  const double* x;        /* PLAIN/SQUARE: input; NORMALISE: wprod                      */
+  double* partials;       /* one per tile                                              */
+  int64_t n;
+  /* reweight */
+  const double* delta;
+  double* wns;
+  uint8_t* alive;
+  double* wprod;          /* WPROD: output temp                                        */
+  const double* wnorm;    /* NORMALISE: device scalar                                  */
+  unsigned long long* n_alive;
+  double eps_old, eps_new;
+  int abck;
+};
+
+template <int MODE>
+__device__ inline double tile_elem(const TileArgs& a, int64_t k, int& n_pos) {
+  if (k >= a.n) return 0.0;
+  if constexpr (MODE == LOAD_PLAIN) {
+    return a.x[k];
+  } else if constexpr (MODE == LOAD_SQUARE) {
+    const double v = a.x[k];
+    return v * v;
+  } else if constexpr (MODE == LOAD_WPROD) {
+    /* ws[i] = exp(logpdf(K_new, D_i) - logpdf(K_old, D_i)) for alive i (smc:77-82); wprod = Wns .* ws (smc:308) */
+    double wp = 0.0;
+    if (a.alive[k]) {
+      const double d = a.delta[k];
+      const double w = abz_exp(abz_kernel_logpdf(a.abck, a.eps_new, d) - abz_kernel_logpdf(a.abck, a.eps_old, d));
+      wp = a.wns[k] * w;
+    }
+    a.wprod[k] = wp;
+    return wp;
+  } else {
+    /* Wns = wprod ./ wnorm; alive = Wns .> 0 (smc:310-311); element = Wns^2 for get_ess (smc:8) */
+    const double W = a.x[k] / *a.wnorm;
+    a.wns[k] = W;
+    a.alive[k] = (uint8_t)(W > 0.0);
+    n_pos += W > 0.0;
+    return W * W;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
+  __shared__ double s_w[4];
+  const int t = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * ABZ_TILE;
+  double e[8];
+  int c = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    e[2 * m] = tile_elem<MODE>(a, base + m * 512 + 2 * t, c);
+    e[2 * m + 1] = tile_elem<MODE>(a, base + m * 512 + 2 * t + 1, c);
+  }
+  if constexpr (MODE == LOAD_NORMALISE) {
+    /* alive count rides along (sum(alive), smc:352,357) */
+    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((t & 63) == 0 && c) atomicAdd(a.n_alive, (unsigned long long)c);
+  }
+  double s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s = s + shfl_xor_f64(s, off);
+  if ((t & 63) == 0) s_w[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) a.partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+/* sums `n` elements under MODE; leaves the result in *d_out (device).  Uses ws. */
+template <int MODE>
+static int tree_sum_device(abcdez_ctx* ctx, TileArgs a, double* d_out, double* part0, double* part1) {
+  int64_t n = a.n;
+  int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
+  a.partials = nt == 1 ? d_out : part0;
+  hipLaunchKernelGGL((tile_sum_kernel<MODE>), dim3((unsigned)nt), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+  double* cur = part0;
+  double* nxt = part1;
+  while (nt > 1) {
+    TileArgs b{};
+    b.x = cur; b.n = nt;
+    const int64_t nt2 = (nt + ABZ_TILE - 1) / ABZ_TILE;
+    b.partials = nt2 == 1 ? d_out : nxt;
+    hipLaunchKernelGGL((tile_sum_kernel<LOAD_PLAIN>), dim3((unsigned)nt2), dim3(ABZ_BLOCK), 0, ctx->stream, b);
+    nt = nt2;
+    double* t = cur; cur = nxt; nxt = t;
+  }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int read_scalars(abcdez_ctx* ctx) {
+  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+static double scal_f64(abcdez_ctx* ctx, int slot) { double v; memcpy(&v, &ctx->h_scal[slot], 8); return v; }
+
+static int partial_buffers(abcdez_ctx* ctx, int64_t n, size_t extra, double** p0, double** p1, char** rest) {
+  const size_t nt = (size_t)((n + ABZ_TILE - 1) / ABZ_TILE);
+  const size_t pb = abz_align(nt * 8 + 8);
+  int rc = abz_ws_reserve(ctx, 2 * pb + extra);
+  if (rc) return rc;
+  *p0 = (double*)ctx->ws;
+  *p1 = (double*)((char*)ctx->ws + pb);
+  if (rest) *rest = (char*)ctx->ws + 2 * pb;
+  return 0;
+}
+
+int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, double* out) {
+  double *p0, *p1;
+  int rc = partial_buffers(ctx, n, 0, &p0, &p1, nullptr);
+  if (rc) return rc;
+  TileArgs a{};
+  a.x = x; a.n = n;
+  double* d_out = (double*)(ctx->d_scal + ABZ_S_SUM);
+  rc = square ? tree_sum_device<LOAD_SQUARE>(ctx, a, d_out, p0, p1) : tree_sum_device<LOAD_PLAIN>(ctx, a, d_out, p0, p1);
+  if (rc) return rc;
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  *out = scal_f64(ctx, ABZ_S_SUM);
+  return 0;
+}
+
+int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
+                      double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
+  double *p0, *p1;
+  char* rest;
+  int rc = partial_buffers(ctx, N, abz_align((size_t)N * 8), &p0, &p1, &rest);
+  if (rc) return rc;
+  double* wprod = (double*)rest;
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NALIVE, 0, 8, ctx->stream));
+  TileArgs a{};
+  a.n = N; a.delta = delta; a.wns = wns; a.alive = alive; a.wprod = wprod;
+  a.eps_old = eps_old; a.eps_new = eps_new; a.abck = ctx->h_model.abck;
+  rc = tree_sum_device<LOAD_WPROD>(ctx, a, (double*)(ctx->d_scal + ABZ_S_WNORM), p0, p1);
+  if (rc) return rc;
+  TileArgs b{};
+  b.n = N; b.x = wprod; b.wns = wns; b.alive = alive;
+  b.wnorm = (const double*)(ctx->d_scal + ABZ_S_WNORM);
+  b.n_alive = ctx->d_scal + ABZ_S_NALIVE;
+  rc = tree_sum_device<LOAD_NORMALISE>(ctx, b, (double*)(ctx->d_scal + ABZ_S_SUMSQ), p0, p1);
+  if (rc) return rc;
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  *wnorm = scal_f64(ctx, ABZ_S_WNORM);
+  *ess = 1.0 / scal_f64(ctx, ABZ_S_SUMSQ);
+  *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
+  return 0;
+}
+
+/* ================================================================ alive compaction
+ * chunk = 1024 flags per block.  Pass 1 counts, pass 2 scans the chunk counts,
+ * pass 3 ranks each flag with wave ballot + popcount prefix and scatters.        */
+#define ABZ_CHUNK 1024
+
+__global__ __launch_bounds__(ABZ_BLOCK) void compact_count_kernel(const uint8_t* __restrict__ alive, int64_t N,
+                                                                  uint32_t* __restrict__ chunk_cnt) {
+  __shared__ uint32_t s_c;
+  if (threadIdx.x == 0) s_c = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * ABZ_CHUNK;
+  uint32_t c = 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int64_t k = base + it * ABZ_BLOCK + threadIdx.x;
+    const bool f = k < N && alive[k];
+    c += (uint32_t)__popcll(__ballot(f));
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_c, c);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s_c;
+}
+
+/* exclusive scan of up to 2^20 chunk counts by one block; total -> *total_out */
+__global__ __launch_bounds__(1024) void scan_u32_kernel(uint32_t* __restrict__ v, uint32_t n,
+                                                        unsigned long long* __restrict__ total_out) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += v[k];
+  s_part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    uint32_t add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = v[k]; v[k] = run; run += c; }
+  if (t == 1023) *total_out = s_part[1023];
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void compact_scatter_kernel(const uint8_t* __restrict__ alive, int64_t N,
+                                                                    const uint32_t* __restrict__ chunk_off,
+                                                                    uint32_t* __restrict__ alive_idx,
+                                                                    uint32_t* __restrict__ arank) {
+  __shared__ uint32_t s_wave[4];
+  const int64_t base = (int64_t)blockIdx.x * ABZ_CHUNK;
+  uint32_t run = chunk_off[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < 4; ++it) {
+    const int64_t k = base + it * ABZ_BLOCK + threadIdx.x;
+    const bool f = k < N && alive[k];
+    const unsigned long long bal = __ballot(f);
+    const uint32_t below = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (k < N) {
+      if (f) {
+        const uint32_t r = run + woff + below;
+        alive_idx[r] = (uint32_t)k;
+        arank[k] = r;
+      } else {
+        arank[k] = ABZ_DEAD;
+      }
+    }
+    run += tot;
+    __syncthreads();
+  }
+}
+
+int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
+                     int64_t* n_alive) {
+  const uint32_t nchunk = (uint32_t)((N + ABZ_CHUNK - 1) / ABZ_CHUNK);
+  int rc = abz_ws_reserve(ctx, abz_align((size_t)nchunk * 4));
+  if (rc) return rc;
+  uint32_t* cnt = (uint32_t*)ctx->ws;
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt);
+  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, nchunk, ctx->d_scal + ABZ_S_NALIVE);
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt, alive_idx,
+                     arank);
+  ABZ_HIP_CHECK(hipGetLastError());
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
+  return 0;
+}
+
+/* ================================================================ stratified resampling (smc:15-56)
+ * integer weights (abz_weight_fix) -> inclusive scan in u64 -> per-stratum search. */
+#define ABZ_SCAN_TILE 2048 /* 256 threads x 8 consecutive elements */
+
+__global__ __launch_bounds__(ABZ_BLOCK) void wfix_tile_sum_kernel(const double* __restrict__ wns, uint32_t N,
+                                                                  unsigned long long* __restrict__ tile_sum,
+                                                                  unsigned long long* __restrict__ last_pos) {
+  __shared__ unsigned long long s_w[4];
+  const uint32_t base = blockIdx.x * ABZ_SCAN_TILE + threadIdx.x * 8;
+  unsigned long long s = 0;
+  uint32_t lp1 = 0;                      /* 1 + last index with positive weight, 0 = none */
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t k = base + q;
+    if (k < N) {
+      const unsigned long long f = abz_weight_fix(wns[k], N);
+      s += f;
+      if (f) lp1 = k + 1;
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    const uint32_t o = __shfl_xor(lp1, off, 64);
+    lp1 = o > lp1 ? o : lp1;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_w[threadIdx.x >> 6] = s;
+    if (lp1) atomicMax(last_pos, (unsigned long long)lp1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long* __restrict__ v, uint32_t n) {
+  __shared__ unsigned long long s_part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+  unsigned long long s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += v[k];
+  s_part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    unsigned long long add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  unsigned long long run = t ? s_part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { const unsigned long long c = v[k]; v[k] = run; run += c; }
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void wfix_scan_kernel(const double* __restrict__ wns, uint32_t N,
+                                                              const unsigned long long* __restrict__ tile_off,
+                                                              unsigned long long* __restrict__ cum) {
+  __shared__ unsigned long long s_w[4];
+  const uint32_t base = blockIdx.x * ABZ_SCAN_TILE + threadIdx.x * 8;
+  unsigned long long f[8];
+  unsigned long long s = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t k = base + q;
+    f[q] = k < N ? abz_weight_fix(wns[k], N) : 0ull;
+    s += f[q];
+  }
+  /* inclusive scan of s over the wave */
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = s;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  unsigned long long run = tile_off[blockIdx.x] + (inc - s);
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t k = base + q;
+    run += f[q];
+    if (k < N) cum[k] = run;
+  }
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void stratified_search_kernel(const unsigned long long* __restrict__ cum,
+                                                                      uint32_t N, uint64_t seed, uint32_t draw,
+                                                                      const unsigned long long* __restrict__ last_pos,
+                                                                      uint32_t* __restrict__ inds) {
+  const uint32_t s = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (s >= N) return;
+  const uint64_t R = abz_stratum_point(seed, s, draw);
+  uint32_t lo = 0, hi = N;               /* smallest i with cum[i] > R */
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cum[mid] > R) hi = mid; else lo = mid + 1;
+  }
+  const uint32_t lp1 = (uint32_t)*last_pos;
+  const uint32_t lp = lp1 ? lp1 - 1 : 0u;
+  inds[s] = (lo >= N || lo > lp) ? lp : lo;
+}
+
+int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds) {
+  const uint32_t n = (uint32_t)N;
+  const uint32_t nt = (n + ABZ_SCAN_TILE - 1) / ABZ_SCAN_TILE;
+  const size_t tb = abz_align((size_t)nt * 8);
+  int rc = abz_ws_reserve(ctx, tb + abz_align((size_t)n * 8));
+  if (rc) return rc;
+  unsigned long long* tile = (unsigned long long*)ctx->ws;
+  unsigned long long* cum = (unsigned long long*)((char*)ctx->ws + tb);
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_LASTPOS, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(wfix_tile_sum_kernel, dim3(nt), dim3(ABZ_BLOCK), 0, ctx->stream, wns, n, tile,
+                     ctx->d_scal + ABZ_S_LASTPOS);
+  hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile, nt);
+  hipLaunchKernelGGL(wfix_scan_kernel, dim3(nt), dim3(ABZ_BLOCK), 0, ctx->stream, wns, n, tile, cum);
+  hipLaunchKernelGGL(stratified_search_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, ctx->stream,
+                     cum, n, ctx->h_model.seed, draw, ctx->d_scal + ABZ_S_LASTPOS, inds);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* ================================================================ order statistics of alive distances (smc:301)
+ * MSB-first radix select on the IEEE bit patterns (distances are >= 0, so the bit
+ * pattern order is the value order; NaN never enters the population).
+ * Digits: 11,11,11,11,11,9 bits.  Per pass: histogram of the digit among keys that
+ * match the current prefix, then a one-block scan picks the bin holding rank k.    */
+#define ABZ_SEL_BINS 2048
+
+struct SelState { unsigned long long prefix, k, less, eq, next; };
+
+__global__ __launch_bounds__(ABZ_BLOCK) void select_hist_kernel(const double* __restrict__ delta,
+                                                                const uint8_t* __restrict__ alive, int64_t N,
+                                                                const unsigned long long* __restrict__ st, int shift,
+                                                                int bits, int top, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[ABZ_SEL_BINS];
+  for (int b = threadIdx.x; b < ABZ_SEL_BINS; b += ABZ_BLOCK) s_h[b] = 0;
+  __syncthreads();
+  const unsigned long long prefix = st[0];
+  const uint32_t mask = (1u << bits) - 1u;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
+    bool f = false;
+    uint32_t bin = 0;
+    if (alive[k]) {
+      const unsigned long long key = abz_d2u(delta[k]);
+      if (top || (key >> (shift + bits)) == prefix) { f = true; bin = (uint32_t)(key >> shift) & mask; }
+    }
+    const unsigned long long bal = __ballot(f);
+    if (bal) {
+      /* clustered distances put most of a wave in one bin: aggregate that bin */
+      const int leader = __ffsll((long long)bal) - 1;
+      const uint32_t lbin = __shfl(bin, leader, 64);
+      const unsigned long long same = __ballot(f && bin == lbin);
+      if ((threadIdx.x & 63) == leader) atomicAdd(&s_h[lbin], (uint32_t)__popcll(same));
+      if (f && bin != lbin) atomicAdd(&s_h[bin], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < ABZ_SEL_BINS; b += ABZ_BLOCK)
+    if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
+}
+
+__global__ __launch_bounds__(1024) void select_pick_kernel(uint32_t* __restrict__ hist, unsigned long long* __restrict__ st,
+                                                           int bits) {
+  /* one block; thread t owns 2 bins; find bin b with cum(b-1) <= k < cum(b) */
+  __shared__ unsigned long long s_c[1024];
+  const int t = threadIdx.x;
+  const int nb = 1 << bits;
+  const uint32_t h0 = 2 * t < nb ? hist[2 * t] : 0, h1 = 2 * t + 1 < nb ? hist[2 * t + 1] : 0;
+  s_c[t] = (unsigned long long)h0 + h1;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned long long add = t >= off ? s_c[t - off] : 0;
+    __syncthreads();
+    s_c[t] += add;
+    __syncthreads();
+  }
+  const unsigned long long k = st[1];
+  const unsigned long long before = t ? s_c[t - 1] : 0;
+  if (k >= before && k < s_c[t]) {
+    int b; unsigned long long lessb;
+    if (k < before + h0) { b = 2 * t; lessb = before; } else { b = 2 * t + 1; lessb = before + h0; }
+    st[0] = (st[0] << bits) | (unsigned long long)b;
+    st[1] = k - lessb;
+    st[2] += lessb;
+    st[3] = b == 2 * t ? h0 : h1;
+  }
+  __syncthreads();
+  if (2 * t < nb) hist[2 * t] = 0;
+  if (2 * t + 1 < nb) hist[2 * t + 1] = 0;
+}
+
+/* smallest alive key strictly greater than the selected key */
+__global__ __launch_bounds__(ABZ_BLOCK) void select_next_kernel(const double* __restrict__ delta,
+                                                                const uint8_t* __restrict__ alive, int64_t N,
+                                                                unsigned long long* __restrict__ st) {
+  const unsigned long long key0 = st[0];
+  unsigned long long best = ~0ull;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
+    if (alive[k]) {
+      const unsigned long long key = abz_d2u(delta[k]);
+      if (key > key0 && key < best) best = key;
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off, 64);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(&st[4], best);
+}
+
+int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
+                    double* xk, double* xk1, int64_t* n_le) {
+  int rc = abz_ws_reserve(ctx, abz_align(ABZ_SEL_BINS * 4));
+  if (rc) return rc;
+  uint32_t* hist = (uint32_t*)ctx->ws;
+  unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
+  SelState init{0ull, (unsigned long long)k0, 0ull, 0ull, ~0ull};
+  ABZ_HIP_CHECK(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  ABZ_HIP_CHECK(hipMemsetAsync(hist, 0, ABZ_SEL_BINS * 4, ctx->stream));
+  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
+  if (grid > 2048) grid = 2048;
+  const int widths[6] = {11, 11, 11, 11, 11, 9};
+  int shift = 64;
+  for (int p = 0; p < 6; ++p) {
+    shift -= widths[p];
+    hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st, shift,
+                       widths[p], p == 0 ? 1 : 0, hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, st, widths[p]);
+  }
+  hipLaunchKernelGGL(select_next_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
+  ABZ_HIP_CHECK(hipGetLastError());
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  const unsigned long long key = ctx->h_scal[ABZ_S_SEL_PREFIX];
+  const unsigned long long less = ctx->h_scal[ABZ_S_SEL_LESS], eq = ctx->h_scal[ABZ_S_SEL_EQ];
+  const unsigned long long next = ctx->h_scal[ABZ_S_SEL_NEXT];
+  *xk = abz_u2d(key);
+  *n_le = (int64_t)(less + eq);
+  /* rank k0+1 is the same value if it is still inside the run of equal keys */
+  *xk1 = ((unsigned long long)k0 + 1 < less + eq || next == ~0ull) ? abz_u2d(key) : abz_u2d(next);
+  return 0;
+}
+
+/* ================================================================ extrema / counts (S10) */
+__device__ inline unsigned long long f64_order_key(double x) {
+  const unsigned long long u = abz_d2u(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+static inline double f64_from_order_key(unsigned long long k) {
+  return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void extrema_kernel(const double* __restrict__ delta, int64_t N,
+                                                            unsigned long long* __restrict__ mn,
+                                                            unsigned long long* __restrict__ mx) {
+  unsigned long long lo = ~0ull, hi = 0ull;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
+    const unsigned long long key = f64_order_key(delta[k]);
+    lo = key < lo ? key : lo;
+    hi = key > hi ? key : hi;
+  }
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(mn, lo); atomicMax(mx, hi); }
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void count_gt_kernel(const double* __restrict__ delta, int64_t N, double thr,
+                                                             unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) c += delta[k] > thr;
+  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void count_alive_kernel(const uint8_t* __restrict__ alive, int64_t N,
+                                                                unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) c += alive[k] != 0;
+  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+int abz_count_alive_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, int64_t* count) {
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_COUNT, 0, 8, ctx->stream));
+  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(count_alive_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N,
+                     ctx->d_scal + ABZ_S_COUNT);
+  ABZ_HIP_CHECK(hipGetLastError());
+  int rc = read_scalars(ctx);
+  if (rc) return rc;
+  *count = (int64_t)ctx->h_scal[ABZ_S_COUNT];
+  return 0;
+}
+
+int abz_extrema_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi) {
+  unsigned long long init[2] = {~0ull, 0ull};
+  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->d_scal + ABZ_S_MIN, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(extrema_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, ctx->d_scal + ABZ_S_MIN,
+                     ctx->d_scal + ABZ_S_MAX);
+  ABZ_HIP_CHECK(hipGetLastError());
+  int rc = read_scalars(ctx);
+  if (rc) return rc;
+  *lo = f64_from_order_key(ctx->h_scal[ABZ_S_MIN]);
+  *hi = f64_from_order_key(ctx->h_scal[ABZ_S_MAX]);
+  return 0;
+}
+
+int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count) {
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_COUNT, 0, 8, ctx->stream));
+  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(count_gt_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, thr,
+                     ctx->d_scal + ABZ_S_COUNT);
+  ABZ_HIP_CHECK(hipGetLastError());
+  int rc = read_scalars(ctx);
+  if (rc) return rc;
+  *count = (int64_t)ctx->h_scal[ABZ_S_COUNT];
+  return 0;
+}
+
+/* ================================================================ spec arithmetic on the device (test hook) */
+__global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const double* __restrict__ x, double* __restrict__ y,
+                                                              double* __restrict__ y2, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  switch (fn) {
+    case 0: y[i] = abz_log(x[i]); break;
+    case 1: y[i] = abz_exp(x[i]); break;
+    case 2: { double s, c; abz_sincos2pi(x[i], &s, &c); y[i] = s; y2[i] = c; break; }
+    case 3: y[i] = abz_rint(x[i]); break;
+    case 4: y[i] = abz_floor(x[i]); break;
+    case 5: y[i] = abz_sqrt(x[i]); break;
+    default: y[i] = x[i] / y2[i]; break;
+  }
+}
+int abz_math_eval_impl(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)((n + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
+                     ctx->stream, fn, x, y, y2, n);
+  ABZ_HIP_CHECK(hipGetLastError());
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}

@@ -1,0 +1,137 @@
+/*
+ * abz_smc_swarm.hip -- one DE-Metropolis sweep over the alive particles.
+ *
+ * Replaces abcdesmc_swarm! (src/abcdez_smc.jl:106-153) and the identity. copies
+ * of src/abcdez_smc.jl:337-340.  One fused kernel: donor draw -> proposal ->
+ * push_p -> prior support/log-density -> simulator -> distance -> Metropolis
+ * accept -> write generation t+1, with the acceptance/simulation counters reduced
+ * per block.  Work items are alive RANKS, so every wave is dense regardless of how
+ * many particles are dead; dead rows are carried by copy_dead_kernel only when the
+ * alive set has changed since the last sweep.
+ *
+ * HBM-bound (roofline: DESIGN.md): per update 3 rows of 8*ld bytes read (own row,
+ * two donor rows) + 16 B state + 12 B indices, one row + 16 B written.
+ */
+#include "abz_dispatch.h"
+
+struct SmcSwarmArgs {
+  const abz_model* model;
+  const uint32_t* alive_idx;
+  const uint32_t* arank;
+  const double* theta;
+  const double* logpi;
+  const double* delta;
+  double* ntheta;
+  double* nlogpi;
+  double* ndelta;
+  unsigned long long* counters; /* [ABZ_S_NACC], [ABZ_S_NSIM] */
+  double eps, gamma0, gsig;
+  uint32_t n_alive, r_lo, n_work, sweep;
+};
+
+template <int SIM, int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs a) {
+  constexpr int LD = L * C;
+  const abz_model* __restrict__ M = a.model;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+  const uint32_t i = a.alive_idx[ri];
+  const uint64_t seed = M->seed;
+
+  /* donors a, b: uniform over alive \ {i} and alive \ {i, a}  (smc:119-126) */
+  uint32_t ra, rb;
+  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.n_alive, ri, &ra, &rb);
+  const uint32_t ia = a.alive_idx[ra], ib = a.alive_idx[rb];
+
+  double ti[C], ta[C], tb[C];
+  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+  const double lpi = a.logpi[i];
+  const double dli = a.delta[i];
+
+  /* gamma = gamma0 (1 + randn gamma_sigma), one scalar for all components (smc:128) */
+  double z0, z1;
+  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+  const double g = a.gamma0 * (1.0 + z0 * a.gsig);
+
+  double tp[C], pp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+
+  const double lp = group_logprior<L, C>(M, j, tp, pp);           /* smc:134 */
+  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+  bool acc = false;
+  double dp = dli;
+  if (insupport) {
+    dp = sim_dist<SIM, L, C>(M, j, pp, i, a.sweep, ABZ_RNG_SIM);  /* smc:137 */
+    const double w = (lp - lpi) + (abz_kernel_logpdf(M->abck, a.eps, dp) - abz_kernel_logpdf(M->abck, a.eps, dli)); /* smc:140-141 */
+    acc = (0.0 <= w);
+    if (!acc) {                                                   /* smc:145 */
+      const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
+      acc = abz_log(u) < w;
+    }
+  }
+  if (active) {                                                   /* smc:146-150 + copies :337-340 */
+    double to[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+    if (j == 0) {
+      a.nlogpi[i] = acc ? lp : lpi;
+      a.ndelta[i] = acc ? dp : dli;
+    }
+  }
+  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.counters + ABZ_S_NACC);
+}
+
+/* dead rows of [i0, i0+n): carry generation t into generation t+1 (smc:337-340) */
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __restrict__ arank,
+                                                              const double* __restrict__ theta,
+                                                              const double* __restrict__ logpi,
+                                                              const double* __restrict__ delta,
+                                                              double* __restrict__ ntheta, double* __restrict__ nlogpi,
+                                                              double* __restrict__ ndelta, uint32_t i0, uint32_t n) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  if (grp >= n) return;
+  const uint32_t i = i0 + grp;
+  if (arank[i] != ABZ_DEAD) return;
+  double t[C];
+  load_row<L, C>(theta + (size_t)i * LD, j, t);
+  store_row<L, C>(ntheta + (size_t)i * LD, j, t);
+  if (j == 0) { nlogpi[i] = logpi[i]; ndelta[i] = delta[i]; }
+}
+
+int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, uint32_t n_alive,
+                         uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
+                         double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
+                         uint32_t i0, uint32_t n_local, int copy_dead, uint32_t sweep) {
+  SmcSwarmArgs a;
+  a.model = ctx->d_model; a.alive_idx = alive_idx; a.arank = arank;
+  a.theta = theta; a.logpi = logpi; a.delta = delta;
+  a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
+  a.counters = ctx->d_scal;
+  a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
+  a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
+  const int L = ctx->L, C = ctx->C;
+  bool ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
+    if (copy_dead && n_local > 0) {
+      hipLaunchKernelGGL((copy_dead_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())), dim3(ABZ_BLOCK), 0,
+                         ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local);
+    }
+    if (a.n_work > 0) {
+      hipLaunchKernelGGL((smc_swarm_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)a.n_work * LL())),
+                         dim3(ABZ_BLOCK), 0, ctx->stream, a);
+    }
+  });
+  if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}

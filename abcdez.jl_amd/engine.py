@@ -1,0 +1,344 @@
+"""Population engine: device-resident particle state + one call per reference function.
+
+``PopulationEngine`` owns the arrays the reference driver owns
+(``θs, logπ, Δs, Wns, alive`` and their ``n*`` doubles, src/abcdez_smc.jl:242-275)
+as torch tensors, shards the particles over the ranks of a ``torch.distributed``
+process group, and forwards every population-sized step to an *ops* backend:
+
+* :class:`HipOps` -- the product: ctypes calls into ``libabcdez_hip.so`` with raw
+  device pointers (torch is plumbing: memory, streams, collectives);
+* the test suite injects an oracle-backed ops object to exercise this file's host
+  logic (sharding, collectives, buffer swapping) on CPU over ``gloo``.
+
+Layout in HBM (per rank, every array FULL length N so donors can be any particle):
+``theta[2][N][ld]`` f64 row-major ping-pong, ``logpi[2][N]``, ``delta[2][N]`` f64,
+``wns[N]`` f64, ``alive[N]`` u8, ``alive_idx[N]``, ``arank[N]``, ``inds[N]`` u32,
+and for abcdemc ``order[N]`` u32 + ``sorted_delta[N]`` f64.
+
+Multi-GPU: rank r updates the contiguous index range
+[r N/G, (r+1) N/G); after every sweep the new rows / logπ / Δ of all ranks are
+exchanged with one in-place all-gather each, so the next sweep's donors come from
+the global population.  RNG counters are keyed by the global particle index, so
+results do not depend on G.  The cheap per-generation passes (quantile, reweight,
+compaction, resampling indices) run replicated on the full arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import ModelSpec
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    """ctypes -> HIP kernels.  Tensors must live on this ops' CUDA(HIP) device."""
+
+    name = "hip"
+
+    def __init__(self, spec: ModelSpec, device_index: Optional[int] = None, lanes: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.AbcdezError("no HIP device visible: the population loop runs only on the GPU (no CPU fallback)")
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        self.spec = spec
+        self._data_host = np.ascontiguousarray(spec.data, dtype=np.float64)
+        cm = spec.cstruct(self._data_host.ctypes.data if self._data_host.size else None)
+        ctx = C.c_void_p()
+        _lib.check(self.lib, self.lib.abcdez_ctx_create(C.byref(cm), device_index, C.byref(ctx)))
+        self.ctx = ctx
+        if lanes:
+            _lib.check(self.lib, self.lib.abcdez_ctx_set_lanes(self.ctx, lanes))
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib, self.lib.abcdez_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)))
+
+    def layout(self):
+        ld, L, Cc = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
+        return ld.value, L.value, Cc.value
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.abcdez_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one method per C-ABI entry point -------------------------------------------------
+    def init(self, theta, logpi, delta, i0, n):
+        _lib.check(self.lib, self.lib.abcdez_init(self.ctx, _ptr(theta), _ptr(logpi), _ptr(delta), i0, n))
+
+    def alive_compact(self, alive, alive_idx, arank) -> int:
+        n = C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_alive_compact(self.ctx, _ptr(alive), alive.numel(), _ptr(alive_idx),
+                                                           _ptr(arank), C.byref(n)))
+        return n.value
+
+    def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
+                  sweep):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_swarm(
+            self.ctx, _ptr(alive_idx), _ptr(arank), n_alive, r_lo, r_hi, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
+            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps, gamma0, gsig, i0, n_local, int(copy_dead), sweep,
+            C.byref(nacc), C.byref(nsim)))
+        return nacc.value, nsim.value
+
+    def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
+        wnorm, ess, na = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_reweight(self.ctx, _ptr(delta), _ptr(wns), _ptr(alive), delta.numel(),
+                                                          eps_old, eps_new, C.byref(wnorm), C.byref(ess), C.byref(na)))
+        return wnorm.value, ess.value, na.value
+
+    def get_ess(self, wns) -> float:
+        ess = C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_get_ess(self.ctx, _ptr(wns), wns.numel(), C.byref(ess)))
+        return ess.value
+
+    def tree_sum(self, x) -> float:
+        out = C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_tree_sum(self.ctx, _ptr(x), x.numel(), C.byref(out)))
+        return out.value
+
+    def wsample_stratified(self, wns, draw, inds):
+        _lib.check(self.lib, self.lib.abcdez_wsample_stratified(self.ctx, _ptr(wns), wns.numel(), draw, _ptr(inds)))
+
+    def smc_resample_gather(self, inds, i0, n_local, cur, nxt, wns, alive):
+        _lib.check(self.lib, self.lib.abcdez_smc_resample_gather(
+            self.ctx, _ptr(inds), inds.numel(), i0, n_local, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
+            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), _ptr(wns), _ptr(alive)))
+
+    def quantile_alive(self, delta, alive, p):
+        q, a, b = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_quantile_alive(self.ctx, _ptr(delta), _ptr(alive), delta.numel(), p,
+                                                            C.byref(q), C.byref(a), C.byref(b)))
+        return q.value, a.value, b.value
+
+    def extrema(self, delta):
+        lo, hi = C.c_double(), C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_extrema(self.ctx, _ptr(delta), delta.numel(), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def count_gt(self, delta, thr) -> int:
+        c = C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_count_gt(self.ctx, _ptr(delta), delta.numel(), thr, C.byref(c)))
+        return c.value
+
+    def mc_rank_prepare(self, delta, order, sorted_delta):
+        _lib.check(self.lib, self.lib.abcdez_mc_rank_prepare(self.ctx, _ptr(delta), delta.numel(), _ptr(order),
+                                                             _ptr(sorted_delta)))
+
+    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep) -> int:
+        nsim = C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_mc_swarm(
+            self.ctx, _ptr(order), _ptr(sorted_delta), cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
+            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep,
+            C.byref(nsim)))
+        return nsim.value
+
+    def push_p(self, theta, out):
+        _lib.check(self.lib, self.lib.abcdez_push_p(self.ctx, _ptr(theta), theta.shape[0], _ptr(out)))
+        _lib.check(self.lib, self.lib.abcdez_sync(self.ctx))
+
+    def math_eval(self, fn, x, y, y2=None):
+        _lib.check(self.lib, self.lib.abcdez_math_eval(self.ctx, fn, _ptr(x), _ptr(y), _ptr(y2), x.numel()))
+
+
+class PopulationEngine:
+    """Device-resident population + the reference's per-generation functions."""
+
+    def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0):
+        self.spec = spec
+        self.N = int(nparticles)
+        self.pg = process_group
+        if self.pg is not None:
+            import torch.distributed as dist
+
+            self.rank = dist.get_rank(self.pg)
+            self.world = dist.get_world_size(self.pg)
+        else:
+            self.rank, self.world = 0, 1
+        if self.N % self.world:
+            raise ValueError(f"nparticles ({self.N}) must be divisible by the number of ranks ({self.world})")
+        self.n_local = self.N // self.world
+        self.lo = self.rank * self.n_local
+        self.hi = self.lo + self.n_local
+        self.ops = ops if ops is not None else HipOps(spec, lanes=lanes)
+        dev = self.ops.device
+        self.device = dev
+        N, ld = self.N, spec.ld
+        f64 = dict(dtype=torch.float64, device=dev)
+        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350)
+        self.buf = [
+            (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
+            (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
+        ]
+        self.cur = 0
+        self.wns = torch.full((N,), 1.0 / N, **f64)
+        self.alive = torch.ones(N, dtype=torch.uint8, device=dev)
+        self.alive_idx = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.arank = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.inds = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.order = None
+        self.sorted_delta = None
+        self.n_alive = N
+        self.r_lo, self.r_hi = self.lo, self.hi
+        self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
+        self.draw = 0           # resampling number = RNG epoch of the stratified draws
+        self._dead_synced = True
+        self.last_inds = None
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def state(self):
+        return self.buf[self.cur]
+
+    @property
+    def other(self):
+        return self.buf[1 - self.cur]
+
+    def _swap(self):
+        self.cur = 1 - self.cur
+
+    def _allgather_state(self, bufs):
+        """exchange rows [lo, hi) of (theta, logpi, delta) -- one in-place all-gather per array"""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+
+        for t in bufs:
+            dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
+
+    def _allreduce_counts(self, *vals):
+        if self.world == 1:
+            return vals
+        import torch.distributed as dist
+
+        t = torch.tensor(vals, dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return tuple(int(v) for v in t.tolist())
+
+    # ------------------------------------------------------------------ S1
+    def init_population(self):
+        th, lp, dl = self.state
+        self.ops.init(th, lp, dl, self.lo, self.n_local)
+        self._allgather_state(self.state)
+
+    def reset_weights(self):  # smc:266-270
+        self.wns.fill_(1.0 / self.N)
+        self.alive.fill_(1)
+        self.n_alive = self.N
+        self._dead_synced = True
+
+    # ------------------------------------------------------------------ S9, S10
+    def quantile_alive(self, alpha: float) -> float:
+        return self.ops.quantile_alive(self.state[2], self.alive, alpha)[0]
+
+    def extrema(self):
+        return self.ops.extrema(self.state[2])
+
+    def count_gt(self, thr: float) -> int:
+        return self.ops.count_gt(self.state[2], thr)
+
+    # ------------------------------------------------------------------ S5, S6
+    def smc_reweight(self, eps_old: float, eps_new: float):
+        wnorm, ess, n_alive = self.ops.smc_reweight(self.state[2], self.wns, self.alive, eps_old, eps_new)
+        self.n_alive = n_alive
+        self._dead_synced = False
+        return wnorm, ess, n_alive
+
+    def get_ess(self) -> float:
+        return self.ops.get_ess(self.wns)
+
+    # ------------------------------------------------------------------ S7, S8
+    def smc_resample(self):
+        self.ops.wsample_stratified(self.wns, self.draw, self.inds)
+        self.draw += 1
+        self.ops.smc_resample_gather(self.inds, self.lo, self.n_local, self.state, self.other, self.wns, self.alive)
+        if self.world > 1:
+            self.wns.fill_(1.0 / self.N)   # the other ranks' ranges (smc:102-103)
+            self.alive.fill_(1)
+        self._allgather_state(self.other)
+        self._swap()
+        self.n_alive = self.N
+        self._dead_synced = True
+        self.last_inds = self.inds
+
+    # ------------------------------------------------------------------ alive list + S2, S3
+    def alive_compact(self) -> int:
+        n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank)
+        self.n_alive = n
+        if self.world == 1:
+            self.r_lo, self.r_hi = 0, n
+        else:
+            # alive ranks owned by this rank's index range: first alive index >= lo / >= hi
+            idx = self.alive_idx[:n]
+            bounds = torch.searchsorted(idx, torch.tensor([self.lo, self.hi], dtype=torch.int32, device=self.device))
+            self.r_lo, self.r_hi = (int(v) for v in bounds.tolist())
+        return n
+
+    def smc_swarm(self, eps: float, gamma0: float, gsig: float):
+        copy_dead = (not self._dead_synced) and self.n_alive < self.N
+        nacc, nsim = self.ops.smc_swarm(self.alive_idx, self.arank, self.n_alive, self.r_lo, self.r_hi, self.state,
+                                        self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep)
+        self.sweep += 1
+        self._dead_synced = True
+        self._allgather_state(self.other)
+        self._swap()
+        return self._allreduce_counts(nacc, nsim)
+
+    # ------------------------------------------------------------------ S4
+    def mc_rank_prepare(self):
+        if self.order is None:
+            self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+            self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        self.ops.mc_rank_prepare(self.state[2], self.order, self.sorted_delta)
+
+    def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float) -> int:
+        if self.order is None:   # converged population: the order is never consulted
+            self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+            self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        nsim = self.ops.mc_swarm(self.order, self.sorted_delta, self.state, self.other, eps_pop, eps_target, gamma0,
+                                 gsig, self.lo, self.n_local, self.sweep)
+        self.sweep += 1
+        self._allgather_state(self.other)
+        self._swap()
+        return self._allreduce_counts(nsim)[0]
+
+    # ------------------------------------------------------------------ results (smc:382-393, mc:166-171)
+    def result(self):
+        th, lp, dl = self.state
+        pushed = torch.empty_like(th)
+        self.ops.push_p(th, pushed)
+        d = self.spec.d
+        P = pushed[:, :d].cpu().numpy()
+        if d == 1 and not hasattr(self.spec.prior, "p"):
+            P = P[:, 0]                      # univariate prior -> vector of scalars
+        return {
+            "P": P,
+            "theta": th[:, :d].cpu().numpy(),  # internal (unrounded) state, mc:216-220
+            "logpi": lp.cpu().numpy(),
+            "C": dl.cpu().numpy(),
+            "Wns": self.wns.cpu().numpy(),
+            "alive": self.alive.cpu().numpy().astype(bool),
+        }
+
+
+def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0) -> PopulationEngine:
+    """The product engine: HIP kernels on the current CUDA(HIP) device."""
+    return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes)

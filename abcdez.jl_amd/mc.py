@@ -1,0 +1,68 @@
+"""Host driver ``abcdemc`` -- ABC-DE MCMC (posterior samples only).
+
+Literal restatement of the reference's host loop ``abcdemc!``
+(src/abcdez_mc.jl:102-172); the per-generation sweep ``abcdemc_swarm!``
+(src/abcdez_mc.jl:5-61) and the reductions steering it run on the device.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from types import SimpleNamespace
+
+from .model import ModelSpec
+from .priors import prior_length
+from .smc import _check, _make_engine
+
+log = logging.getLogger("abcdez_amd")
+
+
+def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
+            nparticles: int = 50, generations: int = 20, verbose: bool = True, rng: int = 1,
+            parallel: bool = True, engine=None, process_group=None):
+    """Run ABC with differential-evolution moves in an MCMC setup (src/abcdez_mc.jl:102).
+
+    Same arguments and defaults as the reference (see :func:`abcdesmc` for the
+    differences in ``dist``/``rng``/``parallel``).  Returns ``(P, C, reached_ϵ, blobs)``
+    (src/abcdez_mc.jl:171) as a namespace.
+    """
+    α = 0.0                                                   # mc:107
+    _check(0.0 <= ϵ_target, "ϵ_target must be non-negative")  # mc:108
+    _check(5 <= nparticles, "nparticles must be at least 5")  # mc:109
+    _check(1 <= generations, "generations must be at least 1")  # mc:110
+
+    spec = ModelSpec(prior, dist, seed=rng)
+    eng = _make_engine(spec, nparticles, engine, process_group)
+    if verbose:
+        log.info("Running abcdemc with engine %s: ϵ_target=%s nparticles=%d generations=%d seed=%d",
+                 type(eng).__name__, ϵ_target, nparticles, generations, spec.seed)
+
+    eng.init_population()                                     # mc:117-125 (S1)
+
+    nsims = 0                                                 # mc:128
+    γ0 = 2.38 / math.sqrt(2 * prior_length(prior))            # mc:129
+    γσ = 1e-5                                                 # mc:130
+    iters = 0
+    complete = 1 - eng.count_gt(ϵ_target) / nparticles        # mc:133
+    while iters < generations:                                # mc:134
+        iters += 1
+        ϵ_l, ϵ_h = eng.extrema()                              # mc:146
+        ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))          # mc:147
+        if ϵ_h > ϵ_target:
+            # the "better particle" set of mc:23 is only consulted while some Δ_i > ϵ
+            eng.mc_rank_prepare()
+        nsims += eng.mc_swarm(ϵ_pop, ϵ_target, γ0, γσ)        # mc:149 (S2, S4)
+        ncomplete = 1 - eng.count_gt(ϵ_target) / nparticles   # mc:156
+        if verbose and (ncomplete != complete or complete >= (nparticles - 1) / nparticles):
+            log.info("Finished run: completion=%s nsim=%d range_ϵ=%s", ncomplete, nsims, eng.extrema())
+        complete = ncomplete
+
+    conv = eng.extrema()[1] <= ϵ_target                       # mc:163
+    if verbose:
+        log.info("End: completion=%s converged=%s nsim=%d range_ϵ=%s", complete, conv, nsims, eng.extrema())
+    res = eng.result()                                        # mc:166
+    out = SimpleNamespace(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=None)
+    out.reached_eps = conv
+    out.nsims, out.updates, out.complete = nsims, generations * nparticles, complete
+    out.engine = eng
+    return out

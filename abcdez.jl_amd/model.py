@@ -1,0 +1,95 @@
+"""ctypes mirror of ``abz_model`` (csrc/abcdez_spec.h) and its builder.
+
+The model descriptor is what the reference passes around as
+``(prior, dist!, varexternal, rng)`` plus the ``ABCk`` keyword
+(src/abcdez_smc.jl:215-220, src/abcdez_mc.jl:102-104).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from .kernels import IndicatorStrict0toϵ, kernel_kind
+from .priors import PRIOR_PAD, Prior, prior_factors
+from .simulators import DeviceSimulator
+
+MAX_D = 64
+
+
+class PriorDim(C.Structure):
+    _fields_ = [
+        ("family", C.c_int32),
+        ("discrete", C.c_int32),
+        ("p0", C.c_double),
+        ("p1", C.c_double),
+        ("c0", C.c_double),
+    ]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32),
+        ("ld", C.c_int32),
+        ("sim_id", C.c_int32),
+        ("abck", C.c_int32),
+        ("seed", C.c_uint64),
+        ("n_data", C.c_int32),
+        ("reserved", C.c_int32),
+        ("sim_p", C.c_double * 8),
+        ("data", C.c_void_p),
+        ("prior", PriorDim * MAX_D),
+    ]
+
+
+def next_pow2(n: int) -> int:
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
+class ModelSpec:
+    """Host-side description; ``.cstruct(data_ptr)`` yields the C struct."""
+
+    def __init__(self, prior: Prior, sim: DeviceSimulator, ABCk=IndicatorStrict0toϵ, seed: int = 1):
+        if not isinstance(sim, DeviceSimulator):
+            raise TypeError(
+                "dist! must be a DeviceSimulator (built-in on-device simulator); arbitrary host closures "
+                "cannot run on the GPU -- see INTEGRATION.md"
+            )
+        factors = prior_factors(prior)
+        d = len(factors)
+        if d > MAX_D:
+            raise ValueError(f"length(prior) = {d} exceeds the supported maximum {MAX_D}")
+        if sim.ndim is not None and sim.ndim != d:
+            raise ValueError(f"{type(sim).__name__} needs length(prior) == {sim.ndim}, got {d}")
+        self.prior = prior
+        self.sim = sim
+        self.d = d
+        self.ld = next_pow2(d)
+        self.abck = kernel_kind(ABCk)
+        self.ABCk = ABCk
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.data = np.ascontiguousarray(np.asarray(sim.data(), dtype=np.float64))
+        self.discrete = tuple(bool(f.discrete) for f in factors)
+        self._desc = [f.descriptor() for f in factors]
+
+    def cstruct(self, data_ptr: Optional[int]) -> Model:
+        m = Model()
+        m.d, m.ld, m.sim_id, m.abck = self.d, self.ld, self.sim.sim_id, self.abck
+        m.seed = self.seed
+        m.n_data = int(self.data.size)
+        params = tuple(self.sim.params())
+        for i in range(8):
+            m.sim_p[i] = params[i] if i < len(params) else 0.0
+        m.data = data_ptr or None
+        for k in range(MAX_D):
+            if k < self.d:
+                fam, disc, p0, p1, c0 = self._desc[k]
+            else:
+                fam, disc, p0, p1, c0 = PRIOR_PAD, 0, 0.0, 0.0, 0.0
+            m.prior[k].family, m.prior[k].discrete = fam, disc
+            m.prior[k].p0, m.prior[k].p1, m.prior[k].c0 = p0, p1, c0
+        return m

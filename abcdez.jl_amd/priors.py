@@ -1,0 +1,182 @@
+"""Prior types of the drop-in: univariate distributions, ``Factored`` and ``push_p``.
+
+Host-side mirror of what ABCdeZ.jl takes from Distributions.jl plus its own
+``Factored`` (reference: src/abcdez_priors.jl:18-61) and ``push_p``
+(src/abcdez_types.jl:20-23).  The device only ever sees the per-dimension
+descriptor produced by :func:`prior_descriptor` (family id, two parameters, the
+precomputed log-normaliser and the discrete flag).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Sequence, Tuple, Union
+
+# family ids -- keep in sync with csrc/abcdez_spec.h (ABZ_PRIOR_*)
+PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM = 0, 1, 2, 3
+
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def _rint(x: float) -> float:
+    """Julia ``round(Int, x)``: ties to even (src/abcdez_types.jl:23)."""
+    return float(round(x))  # Python's round() is ties-to-even for floats
+
+
+class UnivariateDistribution:
+    """Base of the supported prior factors."""
+
+    discrete = False
+    family = PRIOR_PAD
+
+    def descriptor(self) -> Tuple[int, int, float, float, float]:
+        raise NotImplementedError
+
+    def __len__(self) -> int:  # length(prior) for a univariate prior is 1
+        return 1
+
+
+@dataclass(frozen=True)
+class Normal(UnivariateDistribution):
+    mu: float = 0.0
+    sigma: float = 1.0
+    family = PRIOR_NORMAL
+
+    def __post_init__(self):
+        if not self.sigma > 0.0:
+            raise ValueError("Normal: sigma must be positive")
+
+    def logpdf(self, x: float) -> float:
+        z = (x - self.mu) / self.sigma
+        return -0.5 * z * z + (-math.log(self.sigma) - _HALF_LOG_2PI)
+
+    def pdf(self, x: float) -> float:
+        return math.exp(self.logpdf(x))
+
+    def insupport(self, x: float) -> bool:
+        return math.isfinite(x)
+
+    def rand(self, rng) -> float:
+        return self.mu + self.sigma * rng.standard_normal()
+
+    def descriptor(self):
+        return (PRIOR_NORMAL, 0, float(self.mu), float(self.sigma), -math.log(self.sigma) - _HALF_LOG_2PI)
+
+
+@dataclass(frozen=True)
+class Uniform(UnivariateDistribution):
+    a: float = 0.0
+    b: float = 1.0
+    family = PRIOR_UNIFORM
+
+    def __post_init__(self):
+        if not self.b > self.a:
+            raise ValueError("Uniform: need a < b")
+
+    def insupport(self, x: float) -> bool:
+        return self.a <= x <= self.b  # closed support, as Distributions.Uniform
+
+    def logpdf(self, x: float) -> float:
+        return -math.log(self.b - self.a) if self.insupport(x) else -math.inf
+
+    def pdf(self, x: float) -> float:
+        return 1.0 / (self.b - self.a) if self.insupport(x) else 0.0
+
+    def rand(self, rng) -> float:
+        return self.a + (self.b - self.a) * rng.random()
+
+    def descriptor(self):
+        return (PRIOR_UNIFORM, 0, float(self.a), float(self.b), -math.log(self.b - self.a))
+
+
+@dataclass(frozen=True)
+class DiscreteUniform(UnivariateDistribution):
+    a: int = 0
+    b: int = 1
+    family = PRIOR_DUNIFORM
+    discrete = True
+
+    def __post_init__(self):
+        if not self.b >= self.a:
+            raise ValueError("DiscreteUniform: need a <= b")
+
+    def insupport(self, x) -> bool:
+        return self.a <= x <= self.b and float(x) == _rint(float(x))
+
+    def logpdf(self, x) -> float:
+        return -math.log(self.b - self.a + 1) if self.insupport(x) else -math.inf
+
+    def pdf(self, x) -> float:
+        return 1.0 / (self.b - self.a + 1) if self.insupport(x) else 0.0
+
+    def rand(self, rng) -> int:
+        return int(rng.integers(self.a, self.b + 1))
+
+    def descriptor(self):
+        return (PRIOR_DUNIFORM, 1, float(self.a), float(self.b), -math.log(self.b - self.a + 1))
+
+
+class Factored:
+    """Product of independent univariate priors (src/abcdez_priors.jl:18-21).
+
+    >>> prior = Factored(Normal(0, 1), Uniform(-1, 1))
+    """
+
+    def __init__(self, *args: UnivariateDistribution):
+        if not args:
+            raise ValueError("Factored needs at least one distribution")
+        for a in args:
+            if not isinstance(a, UnivariateDistribution):
+                raise TypeError("Factored takes univariate distributions")
+        self.p: Tuple[UnivariateDistribution, ...] = tuple(args)
+
+    def __len__(self) -> int:  # src/abcdez_priors.jl:61
+        return len(self.p)
+
+    def pdf(self, x: Sequence[float]) -> float:  # src/abcdez_priors.jl:27-33
+        s = self.p[0].pdf(x[0])
+        for i in range(1, len(self.p)):
+            s *= self.p[i].pdf(x[i])
+        return s
+
+    def logpdf(self, x: Sequence[float]) -> float:  # src/abcdez_priors.jl:40-46
+        s = self.p[0].logpdf(x[0])
+        for i in range(1, len(self.p)):
+            s += self.p[i].logpdf(x[i])
+        return s
+
+    def rand(self, rng) -> tuple:  # src/abcdez_priors.jl:53-54
+        return tuple(p.rand(rng) for p in self.p)
+
+    def __repr__(self) -> str:
+        return "Factored(" + ", ".join(repr(p) for p in self.p) + ")"
+
+
+Prior = Union[UnivariateDistribution, Factored]
+
+
+def prior_factors(prior: Prior) -> Tuple[UnivariateDistribution, ...]:
+    if isinstance(prior, Factored):
+        return prior.p
+    if isinstance(prior, UnivariateDistribution):
+        return (prior,)
+    raise TypeError(f"unsupported prior type {type(prior).__name__}; use Normal/Uniform/DiscreteUniform or Factored")
+
+
+def prior_length(prior: Prior) -> int:
+    return len(prior_factors(prior))
+
+
+def push_p(density, p):
+    """Cast parameter values to the prior's domain (src/abcdez_types.jl:20-23).
+
+    continuous -> ``float(p)``; discrete -> ``round(Int, p)`` (ties to even);
+    ``Factored`` / sequences broadcast.
+    """
+    if isinstance(density, Factored):
+        return tuple(push_p(d, v) for d, v in zip(density.p, p))
+    if isinstance(p, (tuple, list)):
+        return type(p)(push_p(density, v) for v in p)
+    if density.discrete:
+        return int(_rint(float(p)))
+    return float(p)

@@ -1,0 +1,177 @@
+"""Host driver ``abcdesmc`` -- ABC-DE SMC with evidence estimate.
+
+A literal restatement of the reference's host loop ``abcdesmc!``
+(src/abcdez_smc.jl:215-394): this side owns argument validation, the ε-schedule,
+the log-evidence accumulator, the ESS test, the ``Kmcmc`` early exit, γ0 tuning,
+history vectors and the stop criteria.  Every population-sized operation
+(the ★ rows of SURVEY.md section 8a) is one call into the engine, i.e. one C-ABI
+call into ``libabcdez_hip.so``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+
+from .kernels import IndicatorStrict0toϵ
+from .model import ModelSpec
+from .priors import prior_length
+
+log = logging.getLogger("abcdez_amd")
+
+
+def get_ess(Wns) -> float:
+    """Effective sample size ``1/sum(Wns.^2)`` (src/abcdez_smc.jl:8), host version."""
+    w = np.asarray(Wns, dtype=np.float64)
+    return 1.0 / float(np.sum(w * w))
+
+
+def quantile_type7(xj: float, xj1: float, g: float) -> float:
+    """Interpolation step of Julia's default ``quantile`` (type 7), used at smc:301."""
+    return xj + g * (xj1 - xj)
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)  # the reference raises ErrorException via error(...)
+
+
+def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group):
+    if engine is not None:
+        return engine(spec, nparticles, process_group) if callable(engine) else engine
+    from .engine import HipEngine  # fails loudly if the HIP library or the GPU is missing
+
+    return HipEngine(spec, nparticles, process_group)
+
+
+def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
+             nparticles: int = 100, α: float = 0.95, δess: float = 0.5,
+             nsims_max: int = 10 ** 7, Kmcmc: int = 3, Kmcmc_min: float = 1.0,
+             ABCk=IndicatorStrict0toϵ, facc_stop: float = 0.0, facc_min: float = 0.0, facc_tune: float = 0.975,
+             verbose: bool = True, verboseout: bool = True, rng: int = 1, parallel: bool = True,
+             engine=None, process_group=None, max_iters: int = 1_000_000):
+    """Run ABC with differential-evolution moves in an SMC setup (src/abcdez_smc.jl:215).
+
+    Same positional arguments, keywords and defaults as the reference, except:
+    ``dist`` is a :class:`~abcdez_amd.simulators.DeviceSimulator`; ``rng`` is the
+    64-bit Philox seed; ``parallel`` is ignored (the population always runs on the
+    GPU); ``varexternal`` is accepted and ignored (device simulators carry their own
+    constants).  Returns a namespace with the reference's fields
+    ``P, Wns, C, ϵ, logZ, blobs`` and, with ``verboseout``, ``ϵs, ranges_ϵ, logZs,
+    esss, faccs, γ0s, Kmcmcs`` (src/abcdez_smc.jl:388-393).
+    """
+    # ---- initialisation / validation: src/abcdez_smc.jl:223-235
+    _check(0.0 <= α < 1.0, "α must be in 0 <= α < 1")
+    _check(0.0 <= δess <= 1.0, "δess must be in 0 <= δess <= 1")
+    _check(0.0 <= facc_stop <= 1.0, "facc_stop must be in 0 <= facc_stop <= 1")
+    _check(0.0 <= facc_min <= 1.0, "facc_min must be in 0 <= facc_min <= 1")
+    _check(0.0 <= facc_tune <= 1.0, "facc_tune must be in 0 <= facc_tune <= 1")
+    _check(0.0 <= ϵ_target, "ϵ_target must be non-negative")
+    _check(1 <= Kmcmc, "Kmcmc must be at least 1")
+    _check(0.0 <= Kmcmc_min <= math.inf, "Kmcmc_min must be in 0 <= Kmcmc_min <= Inf")
+    _check(1 <= nsims_max, "nsims_max must be at least 1")
+    if not Kmcmc_min > facc_min:
+        warnings.warn("Kmcmc_min should be larger than facc_min")
+    d = prior_length(prior)
+    # guard against α = δess = 0 (the reference would divide by zero here)
+    denom = min(α, δess)
+    nparticles_min = math.ceil(3 * d / denom) if denom > 0 else 3
+    _check(nparticles_min <= nparticles, f"nparticles must be at least {nparticles_min}")
+
+    spec = ModelSpec(prior, dist, ABCk, seed=rng)
+    eng = _make_engine(spec, nparticles, engine, process_group)
+    if verbose:
+        log.info("Running abcdesmc with engine %s: ϵ_target=%s nparticles=%d α=%s δess=%s nsims_max=%d Kmcmc=%d "
+                 "Kmcmc_min=%s ABCk=%s facc_stop=%s facc_min=%s facc_tune=%s seed=%d", type(eng).__name__,
+                 ϵ_target, nparticles, α, δess, nsims_max, Kmcmc, Kmcmc_min, ABCk.__name__, facc_stop, facc_min,
+                 facc_tune, spec.seed)
+
+    # prior draws, log-prior, first distances, redraw until finite: smc:242-252 (S1)
+    eng.init_population()
+
+    ϵ = math.inf                       # smc:255
+    ϵ_k = math.inf                     # smc:256 (the kernel object is (ABCk, ϵ_k))
+    ABCk(ϵ_k)                          # ctor check, types.jl:30
+    ess_min = nparticles * δess        # smc:259
+    logZ = 0.0                         # smc:263
+    eng.reset_weights()                # Wns = 1/N, alive = true: smc:266-270
+    ess = 0.0
+    nsims = 0                          # sum(nsims), smc:274
+    facc = 1.0
+    Ki = Kmcmc
+    γ0 = 2.38 / math.sqrt(2 * d)       # smc:280
+    γσ = 1e-5                          # smc:281
+    updates = 0                        # Σ over sweeps of n_alive (the bench metric's numerator)
+
+    if verboseout:                     # smc:284-292
+        ϵs = [ϵ]
+        ranges_ϵ = [eng.extrema()]
+        logZs = [logZ]
+        esss = [eng.get_ess()]
+        faccs = [facc]
+        γ0s = [γ0]
+        Kmcmcs = [Ki]
+
+    iters = 0
+    while True:                        # smc:295
+        iters += 1
+        # new ϵ target, smc:301 (S9: the order statistics come from the device)
+        ϵ = max(min(eng.quantile_alive(α), ϵ), ϵ_target)
+        ABCk(ϵ)
+        # target weights, normalisation, alive mask: smc:305-311 (S5) and ESS smc:323 (S6)
+        wnorm, ess, n_alive = eng.smc_reweight(ϵ_k, ϵ)
+        # evidence, smc:315
+        logZ += math.log(wnorm) if wnorm > 0.0 else (-math.inf if wnorm == 0.0 else math.nan)
+        naccs = 0                      # smc:318
+        Ki = Kmcmc
+        if facc < facc_min:            # smc:320
+            γ0 *= facc_tune
+        if n_alive > 0 and ess < ess_min:   # smc:323-326 (S7, S8)
+            eng.smc_resample()
+            ess = eng.get_ess()
+            n_alive = nparticles
+        if n_alive >= 3:               # donor draws need three alive particles (smc:119-126)
+            eng.alive_compact()
+            for i in range(1, Kmcmc + 1):   # smc:336-353 (S2, S3)
+                nacc, nsim = eng.smc_swarm(ϵ, γ0, γσ)
+                naccs += nacc
+                nsims += nsim
+                updates += n_alive
+                if naccs / n_alive >= Kmcmc_min:   # smc:352
+                    Ki = i
+                    break
+        facc = naccs / (n_alive * Ki) if n_alive > 0 else math.nan   # smc:357
+        ϵ_k = ϵ                        # smc:360
+        if verboseout:                 # smc:362-370
+            ϵs.append(ϵ)
+            ranges_ϵ.append(eng.extrema())
+            logZs.append(logZ)
+            esss.append(ess)
+            faccs.append(facc)
+            γ0s.append(γ0)
+            Kmcmcs.append(Ki)
+        if verbose:                    # smc:372
+            log.info("Finished run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
+        if n_alive < 3:                # smc:375
+            warnings.warn("No alive particles")
+            break
+        if ϵ <= ϵ_target or nsims >= nsims_max or facc < facc_stop:   # smc:376
+            break
+        if iters >= max_iters:
+            break
+
+    if verbose:                        # smc:379
+        log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
+
+    res = eng.result()                 # P is push_p-cast, smc:382
+    out = SimpleNamespace(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=None)
+    out.eps = ϵ
+    out.iters, out.nsims, out.updates = iters, nsims, updates
+    out.engine = eng
+    if verboseout:
+        out.ϵs, out.ranges_ϵ, out.logZs, out.esss = ϵs, ranges_ϵ, logZs, esss
+        out.faccs, out.γ0s, out.Kmcmcs = faccs, γ0s, Kmcmcs
+    return out

@@ -1,0 +1,625 @@
+/*
+ * abcdez_oracle.c -- CPU restatement of ABCdeZ.jl's per-generation population loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product package (abcdez.jl_amd/) may
+ * import, link or call this file; it is the checker used by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg.
+ *
+ * PARITY STATUS: the reference is pure Julia; Julia is not installed in the build
+ * container and its RNG stream (task-local Xoshiro256++, forked per FLoops task) is
+ * not observable, and the reference's tests hold no seed-specific vectors
+ * (SURVEY.md section 8c).  Bit/seed-level parity with ABCdeZ.jl is therefore
+ * UNPINNED.  What IS pinned (tests/test_oracle_*.py): every exact known answer of
+ * test/runtests.jl on this path (kernel truth tables :48-108, Factored :21-36,
+ * push_p :38-46) and its statistical known answers (analytic evidences and
+ * posterior means :110-266, :321-423, Dirac :493-519, 2-d incl. Inf distances
+ * :600-624, ...), plus the resampling / driver invariants implied by
+ * src/abcdez_smc.jl:45-54 and :295-377.
+ *
+ * Two tiers:
+ *   ref_*  literal restatements (sequential fp walks, O(N) donor scans, rejection
+ *          loops, left-to-right sums) following the reference line by line, with
+ *          the Philox stream standing in for Julia's rng;
+ *   orc_*  the "spec" restatement the HIP kernels must match bit for bit: same
+ *          algorithm, but with the order-free formulations a GPU needs (rank-skip
+ *          donors, integer cumulative weights, fixed summation trees).  Tests show
+ *          ref_* and orc_* agree (exactly where the formulation is exact, in law
+ *          where only the consumption of random numbers differs).
+ *
+ * All citations are into /root/reference (ABCdeZ.jl v0.6.0).
+ * Layout: theta is row-major double[N][ld]; logpi, delta, wns are double[N];
+ * alive is uint8[N]; indices are uint32.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../abcdez.jl_amd/csrc/abcdez_spec.h"
+
+#define ORC_API __attribute__((visibility("default")))
+#define ORC_MAX_RETRY 100000u
+
+/* ---------------------------------------------------------------- thin exports of the spec math
+ * (so the tests can pin them against mpmath / the published Philox vectors)        */
+ORC_API void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  abz_u32x4 r = abz_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  memcpy(out, r.v, 16);
+}
+ORC_API void orc_math_eval(int fn, const double* x, double* y, double* y2, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    switch (fn) {
+      case 0: y[i] = abz_log(x[i]); break;
+      case 1: y[i] = abz_exp(x[i]); break;
+      case 2: abz_sincos2pi(x[i], &y[i], &y2[i]); break;
+      case 3: y[i] = abz_rint(x[i]); break;
+      case 4: y[i] = abz_floor(x[i]); break;
+      case 5: y[i] = abz_sqrt(x[i]); break;
+      default: y[i] = x[i] / (y2 ? y2[i] : 1.0); break;
+    }
+  }
+}
+ORC_API void orc_rng_words(uint64_t seed, uint32_t idx, uint32_t epoch, uint32_t sub, uint32_t purpose,
+                           uint64_t out[2]) {
+  abz_u64x2 w = abz_rng(seed, idx, epoch, sub, purpose);
+  out[0] = w.w0; out[1] = w.w1;
+}
+ORC_API void orc_normal_pairs(uint64_t seed, uint32_t purpose, int64_t n, double* z) {
+  for (int64_t i = 0; i < n; ++i) {
+    abz_normal_pair(abz_rng(seed, (uint32_t)i, 0, 0, purpose), &z[2 * i], &z[2 * i + 1]);
+  }
+}
+ORC_API double orc_kernel_pdf(int kind, double eps, double x) { return abz_kernel_pdf(kind, eps, x); }
+ORC_API double orc_kernel_logpdf(int kind, double eps, double x) { return abz_kernel_logpdf(kind, eps, x); }
+
+/* ---------------------------------------------------------------- priors (priors.jl:40-46, types.jl:20-23) */
+static void push_row(const abz_model* M, const double* th, double* out) {
+  for (int k = 0; k < M->ld; ++k) out[k] = abz_push_p(&M->prior[k], th[k]);
+}
+/* spec: pairwise tree over components */
+static double logprior_tree(const abz_model* M, const double* pushed) {
+  double t[ABZ_MAX_D];
+  for (int k = 0; k < M->ld; ++k) t[k] = abz_prior_logpdf1(&M->prior[k], pushed[k]);
+  return abz_tree_sum_small(t, M->ld);
+}
+/* literal: left-to-right sum, priors.jl:41-45 */
+static double logprior_seq(const abz_model* M, const double* pushed) {
+  double s = abz_prior_logpdf1(&M->prior[0], pushed[0]);
+  for (int k = 1; k < M->d; ++k) s += abz_prior_logpdf1(&M->prior[k], pushed[k]);
+  return s;
+}
+ORC_API void orc_push_p(const abz_model* M, const double* theta, int64_t n, double* out) {
+  for (int64_t i = 0; i < n; ++i) push_row(M, theta + i * M->ld, out + i * M->ld);
+}
+ORC_API void orc_logprior(const abz_model* M, const double* theta, int64_t n, int literal, double* out) {
+  double p[ABZ_MAX_D];
+  for (int64_t i = 0; i < n; ++i) {
+    push_row(M, theta + i * M->ld, p);
+    out[i] = literal ? logprior_seq(M, p) : logprior_tree(M, p);
+  }
+}
+
+/* ---------------------------------------------------------------- simulators = dist!(theta, ve) (smc:137, mc:45, init:10,17)
+ * theta arrives push_p-cast.  (i, epoch, purpose) address the particle's noise.    */
+static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_t epoch, uint32_t purpose) {
+  const uint64_t seed = M->seed;
+  switch (M->sim_id) {
+    case ABZ_SIM_NORMAL1D: {
+      double z0, z1;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+      double x = abz_fma(M->sim_p[0], z0, th[0]);
+      return fabs(x - M->data[0]);
+    }
+    case ABZ_SIM_MVN: {
+      double sq[ABZ_MAX_D];
+      for (int m = 0; 2 * m < M->ld; ++m) {
+        double z[2];
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)m, purpose), &z[0], &z[1]);
+        for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c) {
+          int k = 2 * m + c;
+          if (k < M->d) {
+            double e = abz_fma(M->sim_p[0], z[c], th[k]) - M->data[k];
+            sq[k] = e * e;
+          } else {
+            sq[k] = 0.0;
+          }
+        }
+      }
+      return abz_sqrt(abz_tree_sum_small(sq, M->ld));
+    }
+    case ABZ_SIM_DIRAC:
+      return fabs((th[0] * th[0] + 1.0) - M->sim_p[0]);
+    case ABZ_SIM_QUAD2D: {
+      double n1, n2;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      double u = abz_u01_co(abz_rng(seed, i, epoch, 1, purpose).w0);
+      if (u < M->sim_p[0]) return ABZ_INF;
+      double a = (th[0] + n1 * 0.01) - th[1] * th[1];
+      double b = (th[1] - 1.0) + n2 * 0.01;
+      return 50.0 * (a * a) + b * b;
+    }
+    case ABZ_SIM_MIXTURE: {
+      double n1, n2;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
+      double x = th[0] + (coin ? n2 : n1 * 0.1);
+      return fabs(x - M->sim_p[0]);
+    }
+    case ABZ_SIM_NORMDU: {
+      double n1, n2;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
+      return fabs(x - M->sim_p[0]);
+    }
+    case ABZ_SIM_WIENER: {
+      double f = 0.95 + 0.1 * abz_u01_co(abz_rng(seed, i, epoch, 0, purpose).w0);
+      double acc = 0.0;
+      for (int t = 0; t < M->n_data; ++t) {
+        double dt = (double)t;
+        double v = abz_sqrt(th[0] * th[0] * dt * dt + th[1] * th[1] * dt) * f;
+        acc += fabs(v - M->data[t]);
+      }
+      return acc / (double)M->n_data;
+    }
+    case ABZ_SIM_LV: {
+      const double a = th[0], b = th[1], c = th[2], e = th[3];
+      double x = M->sim_p[0], y = M->sim_p[1];
+      const double h = M->sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
+      const int steps = (int)M->sim_p[3];
+      const double sn = M->sim_p[4];
+      const int nobs = M->n_data / 2;
+      double acc = 0.0;
+      for (int j = 0; j < nobs; ++j) {
+        double z0, z1;
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)j, purpose), &z0, &z1);
+        double ex = abz_fma(sn, z0, x) - M->data[2 * j];
+        double ey = abz_fma(sn, z1, y) - M->data[2 * j + 1];
+        acc = abz_fma(ex, ex, acc);
+        acc = abz_fma(ey, ey, acc);
+        if (j + 1 == nobs) break;
+        for (int s = 0; s < steps; ++s) {
+          double k1x = x * abz_fma(-b, y, a), k1y = y * abz_fma(e, x, -c);
+          double xa = abz_fma(h2, k1x, x), ya = abz_fma(h2, k1y, y);
+          double k2x = xa * abz_fma(-b, ya, a), k2y = ya * abz_fma(e, xa, -c);
+          double xb = abz_fma(h2, k2x, x), yb = abz_fma(h2, k2y, y);
+          double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
+          double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
+          double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
+          x = abz_fma(h6, (k1x + 2.0 * k2x) + (2.0 * k3x + k4x), x);
+          y = abz_fma(h6, (k1y + 2.0 * k2y) + (2.0 * k3y + k4y), y);
+        }
+      }
+      return abz_sqrt(acc);
+    }
+    default:
+      return ABZ_NAN;
+  }
+}
+ORC_API double orc_sim_dist(const abz_model* M, const double* pushed, uint32_t i, uint32_t epoch, uint32_t purpose) {
+  return sim_dist(M, pushed, i, epoch, purpose);
+}
+
+/* ---------------------------------------------------------------- S1: abcde_init!  (init.jl:2-22 + prior draws smc:242-243, mc:117-118)
+ * retry 0 is the initial draw of smc:242; every redraw of init.jl:15 bumps retry.  */
+static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, double* th) {
+  for (int m = 0; 2 * m < M->ld; ++m) {
+    abz_u64x2 w = abz_rng(M->seed, i, retry, (uint32_t)m, ABZ_RNG_INIT_PRIOR);
+    double z0, z1;
+    abz_normal_pair(w, &z0, &z1);
+    th[2 * m] = abz_prior_draw1(&M->prior[2 * m], w.w0, z0);
+    if (2 * m + 1 < M->ld) th[2 * m + 1] = abz_prior_draw1(&M->prior[2 * m + 1], w.w1, z1);
+  }
+}
+/* fills rows [i0, i0+n) of the FULL arrays theta / logpi / delta */
+ORC_API int orc_init(const abz_model* M, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+  for (int64_t g = i0; g < i0 + n; ++g) {
+    uint32_t i = (uint32_t)g;
+    double* th = theta + g * M->ld;
+    double p[ABZ_MAX_D];
+    uint32_t retry = 0;
+    for (;;) {
+      draw_prior_row(M, i, retry, th);
+      push_row(M, th, p);
+      double lp = logprior_tree(M, p);
+      double dl = ABZ_NAN;
+      if (abz_isfinite(lp)) dl = sim_dist(M, p, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
+      logpi[g] = lp; delta[g] = dl;
+      if (abz_isfinite(dl) && abz_isfinite(lp)) break;                          /* init.jl:14 */
+      if (++retry >= ORC_MAX_RETRY) { bad = 1; break; }
+    }
+  }
+  return bad ? -1 : 0;
+}
+
+/* ---------------------------------------------------------------- alive list (implicit in wsample(rng, 1:N, alive), smc:121,125) */
+ORC_API int64_t orc_alive_compact(const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank) {
+  uint32_t r = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    if (alive[i]) { alive_idx[r] = (uint32_t)i; arank[i] = r; ++r; }
+    else arank[i] = ABZ_DEAD;
+  }
+  return (int64_t)r;
+}
+
+/* ---------------------------------------------------------------- S2+S3: abcdesmc_swarm!  (smc:106-153, copies smc:337-340)
+ * Spec tier.  Processes particles [i0, i0+n_local) of a population of N whose
+ * generation-t state is (theta, logpi, delta) -- all FULL arrays of N rows -- and
+ * writes generation t+1 into (ntheta, nlogpi, ndelta), also full arrays.           */
+ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,
+                           const double* theta, const double* logpi, const double* delta,
+                           double* ntheta, double* nlogpi, double* ndelta,
+                           double eps, double gamma0, double gsig,
+                           int64_t i0, int64_t n_local, uint32_t sweep,
+                           int64_t* nacc_out, int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t nacc = 0, nsim = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+  for (int64_t i = i0; i < i0 + n_local; ++i) {
+    const double* ti = theta + i * ld;
+    double* to = ntheta + i * ld;
+    /* identity. copies, smc:337-340 */
+    for (int k = 0; k < ld; ++k) to[k] = ti[k];
+    nlogpi[i] = logpi[i];
+    ndelta[i] = delta[i];
+    uint32_t ri = arank[i];
+    if (ri == ABZ_DEAD) continue;                                   /* smc:114 */
+    uint32_t ra, rb;
+    abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)n_alive, ri, &ra, &rb);
+    const double* ta = theta + (int64_t)alive_idx[ra] * ld;        /* smc:119-126 */
+    const double* tb = theta + (int64_t)alive_idx[rb] * ld;
+    double z0, z1;
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    double g = gamma0 * (1.0 + z0 * gsig);                          /* smc:128 */
+    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+    for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
+    push_row(M, tp, pp);
+    double lp = logprior_tree(M, pp);                               /* smc:134 */
+    if (lp < 0.0 && !abz_isfinite(lp) && !abz_isnan(lp)) continue;  /* smc:135 */
+    double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM);   /* smc:137 */
+    nsim += 1;                                                      /* smc:138 */
+    double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i])); /* smc:140-141 */
+    int acc = (0.0 <= w);
+    if (!acc) {                                                     /* smc:145 */
+      double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
+      acc = abz_log(u) < w;
+    }
+    if (acc) {                                                      /* smc:146-150 */
+      ndelta[i] = dp;
+      for (int k = 0; k < ld; ++k) to[k] = tp[k];
+      nlogpi[i] = lp;
+      nacc += 1;
+    }
+  }
+  *nacc_out = nacc; *nsim_out = nsim;
+}
+
+/* Literal tier of the same sweep: donors by rejection around an O(N) weighted scan
+ * exactly as wsample(rng, 1:N, alive) does it (StatsBase: t = rand*sum(w); walk the
+ * cumulative weight until cw >= t), left-to-right logpdf.  Different consumption of
+ * random numbers => equal in law only.  Used for equivalence tests and as the
+ * "reference-faithful" CPU baseline.                                               */
+static uint32_t ref_wsample_alive(const uint8_t* alive, int64_t N, int64_t n_alive, double u) {
+  double t = u * (double)n_alive;          /* rand(rng) * sum(wv) */
+  int64_t i = 0;
+  double cw = (double)alive[0];
+  while (cw < t && i < N - 1) { ++i; cw += (double)alive[i]; }
+  return (uint32_t)i;
+}
+ORC_API void ref_smc_swarm(const abz_model* M, const uint8_t* alive, int64_t N,
+                           const double* theta, const double* logpi, const double* delta,
+                           double* ntheta, double* nlogpi, double* ndelta,
+                           double eps, double gamma0, double gsig, uint32_t sweep,
+                           int64_t* nacc_out, int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t n_alive = 0;
+  for (int64_t i = 0; i < N; ++i) n_alive += alive[i];
+  int64_t nacc = 0, nsim = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nacc, nsim)
+  for (int64_t i = 0; i < N; ++i) {
+    const double* ti = theta + i * ld;
+    double* to = ntheta + i * ld;
+    for (int k = 0; k < ld; ++k) to[k] = ti[k];
+    nlogpi[i] = logpi[i];
+    ndelta[i] = delta[i];
+    if (!alive[i]) continue;
+    uint32_t att = 0;
+    int64_t a = i;
+    while (a == i) {
+      double u = abz_u01_co(abz_rng(M->seed, (uint32_t)i, sweep, att++, ABZ_RNG_DONOR).w0);
+      a = ref_wsample_alive(alive, N, n_alive, u);
+    }
+    int64_t b = a;
+    while (b == a || b == i) {
+      double u = abz_u01_co(abz_rng(M->seed, (uint32_t)i, sweep, att++, ABZ_RNG_DONOR).w0);
+      b = ref_wsample_alive(alive, N, n_alive, u);
+    }
+    const double* ta = theta + a * ld;
+    const double* tb = theta + b * ld;
+    double z0, z1;
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    double g = gamma0 * (1.0 + z0 * gsig);
+    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+    for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
+    push_row(M, tp, pp);
+    double lp = logprior_seq(M, pp);
+    if (lp < 0.0 && isinf(lp)) continue;
+    double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM);
+    nsim += 1;
+    double w = lp - logpi[i] + abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i]);
+    int acc = (0.0 <= w);
+    if (!acc) {
+      double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
+      acc = log(u) < w;
+    }
+    if (acc) {
+      ndelta[i] = dp;
+      for (int k = 0; k < ld; ++k) to[k] = tp[k];
+      nlogpi[i] = lp;
+      nacc += 1;
+    }
+  }
+  *nacc_out = nacc; *nsim_out = nsim;
+}
+
+/* ---------------------------------------------------------------- fixed summation tree (spec header, "tile tree") */
+static double tile_sum(const double* x, int64_t n) { /* n <= ABZ_TILE, missing = +0.0 */
+  double s[256];
+  for (int t = 0; t < 256; ++t) {
+    double e[8];
+    for (int m = 0; m < 4; ++m)
+      for (int c = 0; c < 2; ++c) {
+        int64_t k = (int64_t)m * 512 + 2 * t + c;
+        e[2 * m + c] = k < n ? x[k] : 0.0;
+      }
+    s[t] = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+  }
+  for (int st = 1; st < 256; st <<= 1)
+    for (int t = 0; t < 256; t += 2 * st) s[t] = s[t] + s[t + st];
+  return s[0];
+}
+ORC_API double orc_tree_sum(const double* x, int64_t n) {
+  if (n <= ABZ_TILE) return tile_sum(x, n);
+  int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
+  double* part = (double*)malloc((size_t)nt * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t t = 0; t < nt; ++t) {
+    int64_t lo = t * ABZ_TILE, len = n - lo < ABZ_TILE ? n - lo : ABZ_TILE;
+    part[t] = tile_sum(x + lo, len);
+  }
+  double r = orc_tree_sum(part, nt);
+  free(part);
+  return r;
+}
+
+/* ---------------------------------------------------------------- S5 + driver lines smc:305-311, S6 (smc:8, :323)
+ * ws[i] = exp(logpdf(K_new, D_i) - logpdf(K_old, D_i)) for alive i (smc:77-82);
+ * wprod = Wns .* ws; wnorm = sum(wprod); Wns = wprod ./ wnorm; alive = Wns .> 0.
+ * A dead particle has Wns = 0 and a stale finite ws, so its product is 0.           */
+ORC_API void orc_smc_reweight(int abck, const double* delta, double* wns, uint8_t* alive, int64_t N,
+                              double eps_old, double eps_new,
+                              double* wnorm_out, double* ess_out, int64_t* n_alive_out) {
+  double* wprod = (double*)malloc((size_t)N * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    double w = 0.0;
+    if (alive[i]) w = abz_exp(abz_kernel_logpdf(abck, eps_new, delta[i]) - abz_kernel_logpdf(abck, eps_old, delta[i]));
+    wprod[i] = alive[i] ? wns[i] * w : 0.0;
+  }
+  double wnorm = orc_tree_sum(wprod, N);
+  int64_t na = 0;
+#pragma omp parallel for schedule(static) reduction(+ : na)
+  for (int64_t i = 0; i < N; ++i) {
+    double W = wprod[i] / wnorm;
+    wns[i] = W;
+    alive[i] = (uint8_t)(W > 0.0);
+    na += alive[i];
+    wprod[i] = W * W;
+  }
+  *wnorm_out = wnorm;
+  *ess_out = 1.0 / orc_tree_sum(wprod, N);
+  *n_alive_out = na;
+  free(wprod);
+}
+ORC_API double orc_get_ess(const double* wns, int64_t N) {
+  double* sq = (double*)malloc((size_t)N * sizeof(double));
+  for (int64_t i = 0; i < N; ++i) sq[i] = wns[i] * wns[i];
+  double r = 1.0 / orc_tree_sum(sq, N);
+  free(sq);
+  return r;
+}
+/* literal: get_ess(Wns) = 1/sum(Wns.^2) and update_ws + normalisation with plain left-to-right sums */
+ORC_API double ref_get_ess(const double* wns, int64_t N) {
+  double s = 0.0;
+  for (int64_t i = 0; i < N; ++i) s += wns[i] * wns[i];
+  return 1.0 / s;
+}
+ORC_API void ref_smc_reweight(int abck, const double* delta, double* ws, double* wns, uint8_t* alive, int64_t N,
+                              double eps_old, double eps_new, double* wnorm_out) {
+  for (int64_t i = 0; i < N; ++i)
+    if (alive[i]) ws[i] = exp(abz_kernel_logpdf(abck, eps_new, delta[i]) - abz_kernel_logpdf(abck, eps_old, delta[i]));
+  double wnorm = 0.0;
+  for (int64_t i = 0; i < N; ++i) wnorm += wns[i] * ws[i];
+  for (int64_t i = 0; i < N; ++i) { wns[i] = (wns[i] * ws[i]) / wnorm; alive[i] = (uint8_t)(wns[i] > 0.0); }
+  *wnorm_out = wnorm;
+}
+
+/* ---------------------------------------------------------------- S7: wsample_stratified!  (smc:15-56) */
+/* literal: sequential fp walk, stratum bounds accumulated by + sval, r = lo + (hi-lo) u */
+ORC_API void ref_wsample_stratified(const double* weights, int64_t n, const double* u, int64_t* inds) {
+  double sval = 1.0 / (double)n;
+  double wsum = 0.0;
+  int64_t i = 0;               /* 1-based like the reference */
+  double unif0 = 0.0, unif1 = 0.0;
+  for (int64_t si = 0; si < n; ++si) {
+    unif1 = unif0 + sval;
+    double r = unif0 + (unif1 - unif0) * u[si];
+    while (r > wsum && i < n) { i += 1; wsum += weights[i - 1]; }   /* clamp: see SURVEY 3.5 */
+    unif0 = unif1;
+    inds[si] = i - 1;          /* reported 0-based */
+  }
+}
+/* spec: exact integer cumulative weights (spec header) */
+ORC_API void orc_wsample_stratified(uint64_t seed, const double* wns, int64_t N, uint32_t draw, uint32_t* inds) {
+  uint64_t* cum = (uint64_t*)malloc((size_t)N * sizeof(uint64_t));
+  uint64_t c = 0;
+  int64_t last_pos = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    uint64_t f = abz_weight_fix(wns[i], (uint32_t)N);
+    if (f) last_pos = i;
+    c += f; cum[i] = c;
+  }
+  int64_t i = 0;
+  for (int64_t s = 0; s < N; ++s) {
+    uint64_t R = abz_stratum_point(seed, (uint32_t)s, draw);
+    while (i < N - 1 && !(cum[i] > R)) ++i;
+    int64_t pick = i;
+    if (!(cum[pick] > R)) pick = last_pos;   /* total mass rounded below R */
+    if (pick > last_pos) pick = last_pos;
+    inds[s] = (uint32_t)pick;
+  }
+  free(cum);
+}
+/* the uniforms the spec draw corresponds to, for feeding the literal walk in tests */
+ORC_API void orc_stratum_uniforms(uint64_t seed, int64_t N, uint32_t draw, double* u) {
+  for (int64_t s = 0; s < N; ++s) {
+    uint64_t R = abz_stratum_point(seed, (uint32_t)s, draw);
+    u[s] = (double)(R & (((uint64_t)1 << ABZ_STRATUM_BITS) - 1)) * 0x1p-40;
+  }
+}
+
+/* ---------------------------------------------------------------- S8: abcdesmc_resample!  (smc:85-104) */
+ORC_API void orc_smc_resample_gather(const abz_model* M, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
+                                     const double* theta, const double* logpi, const double* delta,
+                                     double* ntheta, double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
+  const int ld = M->ld;
+#pragma omp parallel for schedule(static)
+  for (int64_t s = i0; s < i0 + n_local; ++s) {
+    int64_t j = inds[s];
+    memcpy(ntheta + s * ld, theta + j * ld, (size_t)ld * sizeof(double));  /* smc:96 */
+    nlogpi[s] = logpi[j];                                                  /* smc:97 */
+    ndelta[s] = delta[j];                                                  /* smc:98 */
+    wns[s] = 1.0 / (double)N;                                              /* smc:102 */
+    alive[s] = 1;                                                          /* smc:103 */
+  }
+}
+
+/* ---------------------------------------------------------------- S9: quantile(Ds[alive], alpha)  (smc:301)
+ * Statistics.quantile default = type 7: h = (n-1) p + 1; j = clamp(floor(h), 1, n-1);
+ * g = h - j; q = x_(j) + g (x_(j+1) - x_(j)).                                       */
+static int cmp_double(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return (x > y) - (x < y);
+}
+ORC_API double orc_quantile7(double xj, double xj1, double g) { return xj + g * (xj1 - xj); }
+ORC_API void orc_quantile_pos(int64_t n, double p, int64_t* j_out, double* g_out) { /* j is 1-based */
+  double h = (double)(n - 1) * p + 1.0;
+  double fl = floor(h);
+  int64_t j = (int64_t)fl;
+  if (j < 1) j = 1;
+  if (j > n - 1) j = n - 1 > 1 ? n - 1 : 1;
+  *j_out = j; *g_out = h - (double)j;
+}
+ORC_API double orc_quantile_alive(const double* delta, const uint8_t* alive, int64_t N, double p,
+                                  double* xj_out, double* xj1_out) {
+  double* v = (double*)malloc((size_t)N * sizeof(double));
+  int64_t n = 0;
+  for (int64_t i = 0; i < N; ++i) if (alive[i]) v[n++] = delta[i];
+  if (n == 0) { free(v); return ABZ_NAN; }
+  qsort(v, (size_t)n, sizeof(double), cmp_double);
+  int64_t j; double g;
+  orc_quantile_pos(n, p, &j, &g);
+  double xj = v[j - 1], xj1 = n > 1 ? v[j] : v[j - 1];
+  free(v);
+  if (xj_out) *xj_out = xj;
+  if (xj1_out) *xj1_out = xj1;
+  return orc_quantile7(xj, xj1, g);
+}
+
+/* ---------------------------------------------------------------- S10: driver reductions (smc:286,364; mc:133,146,156,163) */
+ORC_API void orc_extrema(const double* delta, int64_t N, double* lo, double* hi) {
+  double a = delta[0], b = delta[0];
+  for (int64_t i = 1; i < N; ++i) { if (delta[i] < a) a = delta[i]; if (delta[i] > b) b = delta[i]; }
+  *lo = a; *hi = b;
+}
+ORC_API int64_t orc_count_gt(const double* delta, int64_t N, double thr) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < N; ++i) c += delta[i] > thr;
+  return c;
+}
+
+/* ---------------------------------------------------------------- S4: abcdemc_swarm!  (mc:5-61)
+ * order = particle indices sorted by (delta, index); sorted_delta = delta[order].
+ * The "better particle" set {j : D_j <= D_i} (mc:23) is the first cnt entries of
+ * order, cnt = upper_bound(sorted_delta, D_i); s = order[randint(cnt)].
+ * (The reference enumerates the same set in index order; any fixed enumeration
+ * gives the same law.)                                                             */
+typedef struct { double d; uint32_t i; } orc_key;
+static int cmp_key(const void* a, const void* b) {
+  const orc_key* x = (const orc_key*)a; const orc_key* y = (const orc_key*)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, uint32_t* order, double* sorted_delta) {
+  orc_key* k = (orc_key*)malloc((size_t)N * sizeof(orc_key));
+  for (int64_t i = 0; i < N; ++i) { k[i].d = delta[i]; k[i].i = (uint32_t)i; }
+  qsort(k, (size_t)N, sizeof(orc_key), cmp_key);
+  for (int64_t i = 0; i < N; ++i) { order[i] = k[i].i; sorted_delta[i] = k[i].d; }
+  free(k);
+}
+static int64_t upper_bound_d(const double* v, int64_t n, double x) { /* #elements <= x */
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const double* sorted_delta, int64_t N,
+                          const double* theta, const double* logpi, const double* delta,
+                          double* ntheta, double* nlogpi, double* ndelta,
+                          double eps_pop, double eps_target, double gamma0, double gsig,
+                          int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t nsim = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nsim)
+  for (int64_t i = i0; i < i0 + n_local; ++i) {
+    const double* ti = theta + i * ld;
+    double* to = ntheta + i * ld;
+    for (int k = 0; k < ld; ++k) to[k] = ti[k];                         /* mc:140-143 */
+    nlogpi[i] = logpi[i];
+    ndelta[i] = delta[i];
+    double di = delta[i];
+    double eps = di <= eps_target ? eps_target : eps_pop;               /* mc:19 */
+    uint32_t s = (uint32_t)i;
+    if (di > eps) {                                                     /* mc:20-24 */
+      int64_t cnt = upper_bound_d(sorted_delta, N, di);
+      s = order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, (uint32_t)cnt)];
+    }
+    uint32_t a, b;                                                      /* mc:25-32: uniform over all N */
+    abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)N, s, &a, &b);
+    const double* ts = theta + (int64_t)s * ld;
+    const double* ta = theta + (int64_t)a * ld;
+    const double* tb = theta + (int64_t)b * ld;
+    double z0, z1;
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    double g = gamma0 * (1.0 + z0 * gsig);                              /* mc:34 */
+    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+    for (int k = 0; k < ld; ++k) tp[k] = ts[k] + (ta[k] - tb[k]) * g;
+    push_row(M, tp, pp);
+    double lp = logprior_tree(M, pp);                                   /* mc:41 */
+    double w_prior = lp - logpi[i];                                     /* mc:42 */
+    double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
+    double mn = w_prior < 0.0 ? w_prior : 0.0;                          /* min(0, w_prior); NaN -> compares false below */
+    if (abz_isnan(w_prior)) mn = w_prior;
+    if (abz_log(u) > mn) continue;                                      /* mc:43 */
+    nsim += 1;                                                          /* mc:44 */
+    double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM);       /* mc:45 */
+    double thr = eps > di ? eps : di;                                   /* max(eps, D_i) */
+    if (dp <= thr) {                                                    /* mc:54-58 */
+      ndelta[i] = dp;
+      for (int k = 0; k < ld; ++k) to[k] = tp[k];
+      nlogpi[i] = lp;
+    }
+  }
+  *nsim_out = nsim;
+}

@@ -1,0 +1,250 @@
+"""ctypes binding of the CPU oracle (oracle/abcdez_oracle*.c) + an ops backend for
+``PopulationEngine``.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+_vp, _i64, _u32, _i32, _f64, _u64 = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_double, C.c_uint64
+_pi64, _pf64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def build(force: bool = False) -> None:
+    if force or not os.path.exists(os.path.join(HERE, "liboracle.so")):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+
+
+class SmcRun(C.Structure):
+    _fields_ = [
+        ("nparticles", _i64), ("eps_target", _f64), ("alpha", _f64), ("delta_ess", _f64), ("nsims_max", _i64),
+        ("Kmcmc", _i32), ("max_iters", _i32), ("Kmcmc_min", _f64), ("facc_stop", _f64), ("facc_min", _f64),
+        ("facc_tune", _f64), ("eps", _f64), ("logZ", _f64), ("iters", _i64), ("nsims_total", _i64),
+        ("updates_total", _i64), ("n_hist", _i32), ("no_alive", _i32),
+    ]
+
+
+class McRun(C.Structure):
+    _fields_ = [
+        ("nparticles", _i64), ("generations", _i32), ("reserved", _i32), ("eps_target", _f64),
+        ("nsims_total", _i64), ("reached_eps", _i32), ("reserved2", _i32), ("complete", _f64),
+    ]
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    build()
+    name = "liboracle_fma.so" if _cpu_has_fma() and os.path.exists(os.path.join(HERE, "liboracle_fma.so")) \
+        else "liboracle.so"
+    L = C.CDLL(os.path.join(HERE, name))
+    L.orc_kernel_pdf.restype = _f64
+    L.orc_kernel_pdf.argtypes = [C.c_int, _f64, _f64]
+    L.orc_kernel_logpdf.restype = _f64
+    L.orc_kernel_logpdf.argtypes = [C.c_int, _f64, _f64]
+    L.orc_philox.argtypes = [_vp, _vp, _vp]
+    L.orc_math_eval.argtypes = [C.c_int, _vp, _vp, _vp, _i64]
+    L.orc_rng_words.argtypes = [_u64, _u32, _u32, _u32, _u32, _vp]
+    L.orc_normal_pairs.argtypes = [_u64, _u32, _i64, _vp]
+    L.orc_push_p.argtypes = [_vp, _vp, _i64, _vp]
+    L.orc_logprior.argtypes = [_vp, _vp, _i64, C.c_int, _vp]
+    L.orc_sim_dist.restype = _f64
+    L.orc_sim_dist.argtypes = [_vp, _vp, _u32, _u32, _u32]
+    L.orc_init.argtypes = [_vp, _vp, _vp, _vp, _i64, _i64]
+    L.orc_alive_compact.restype = _i64
+    L.orc_alive_compact.argtypes = [_vp, _i64, _vp, _vp]
+    L.orc_smc_swarm.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _i64, _i64, _u32,
+                                _pi64, _pi64]
+    L.ref_smc_swarm.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _pi64, _pi64]
+    L.orc_tree_sum.restype = _f64
+    L.orc_tree_sum.argtypes = [_vp, _i64]
+    L.orc_smc_reweight.argtypes = [C.c_int, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64]
+    L.orc_get_ess.restype = _f64
+    L.orc_get_ess.argtypes = [_vp, _i64]
+    L.ref_get_ess.restype = _f64
+    L.ref_get_ess.argtypes = [_vp, _i64]
+    L.ref_smc_reweight.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64]
+    L.ref_wsample_stratified.argtypes = [_vp, _i64, _vp, _vp]
+    L.orc_wsample_stratified.argtypes = [_u64, _vp, _i64, _u32, _vp]
+    L.orc_stratum_uniforms.argtypes = [_u64, _i64, _u32, _vp]
+    L.orc_smc_resample_gather.argtypes = [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.orc_quantile_alive.restype = _f64
+    L.orc_quantile_alive.argtypes = [_vp, _vp, _i64, _f64, _pf64, _pf64]
+    L.orc_extrema.argtypes = [_vp, _i64, _pf64, _pf64]
+    L.orc_count_gt.restype = _i64
+    L.orc_count_gt.argtypes = [_vp, _i64, _f64]
+    L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _vp, _vp]
+    L.orc_mc_swarm.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64,
+                               _u32, _pi64]
+    L.orc_abcdesmc.argtypes = [_vp, C.POINTER(SmcRun)] + [_vp] * 13
+    L.orc_abcdemc.argtypes = [_vp, C.POINTER(McRun), _vp, _vp, _vp]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    """pointer of a numpy array or CPU torch tensor"""
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        assert a.device.type == "cpu" and a.is_contiguous()
+        return a.data_ptr()
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+class OracleModel:
+    """keeps the C model struct (and the host data it points to) alive"""
+
+    def __init__(self, spec):
+        self.spec = spec
+        self._data = np.ascontiguousarray(spec.data, dtype=np.float64)
+        self.c = spec.cstruct(self._data.ctypes.data if self._data.size else None)
+        self.ref = C.byref(self.c)
+        self.ptr = C.addressof(self.c)
+
+
+class OracleOps:
+    """Same interface as abcdez_amd.engine.HipOps, on CPU tensors, through the oracle."""
+
+    name = "oracle"
+
+    def __init__(self, spec, device_index=None, lanes: int = 0):
+        self.L = lib()
+        self.spec = spec
+        self.m = OracleModel(spec)
+        self.device = torch.device("cpu")
+
+    def init(self, theta, logpi, delta, i0, n):
+        rc = self.L.orc_init(self.m.ptr, _p(theta), _p(logpi), _p(delta), i0, n)
+        if rc:
+            raise RuntimeError("oracle init: no finite (log-prior, distance) within the retry limit")
+
+    def alive_compact(self, alive, alive_idx, arank) -> int:
+        return self.L.orc_alive_compact(_p(alive), alive.numel(), _p(alive_idx), _p(arank))
+
+    def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
+                  sweep):
+        nacc, nsim = _i64(), _i64()
+        self.L.orc_smc_swarm(self.m.ptr, _p(alive_idx), _p(arank), n_alive, _p(cur[0]), _p(cur[1]), _p(cur[2]),
+                             _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps, gamma0, gsig, i0, n_local, sweep,
+                             C.byref(nacc), C.byref(nsim))
+        return nacc.value, nsim.value
+
+    def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
+        wnorm, ess, na = _f64(), _f64(), _i64()
+        self.L.orc_smc_reweight(self.spec.abck, _p(delta), _p(wns), _p(alive), delta.numel(), eps_old, eps_new,
+                                C.byref(wnorm), C.byref(ess), C.byref(na))
+        return wnorm.value, ess.value, na.value
+
+    def get_ess(self, wns) -> float:
+        return self.L.orc_get_ess(_p(wns), wns.numel())
+
+    def tree_sum(self, x) -> float:
+        return self.L.orc_tree_sum(_p(x), x.numel())
+
+    def wsample_stratified(self, wns, draw, inds):
+        self.L.orc_wsample_stratified(self.spec.seed, _p(wns), wns.numel(), draw, _p(inds))
+
+    def smc_resample_gather(self, inds, i0, n_local, cur, nxt, wns, alive):
+        self.L.orc_smc_resample_gather(self.m.ptr, _p(inds), inds.numel(), i0, n_local, _p(cur[0]), _p(cur[1]),
+                                       _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), _p(wns), _p(alive))
+
+    def quantile_alive(self, delta, alive, p):
+        a, b = _f64(), _f64()
+        q = self.L.orc_quantile_alive(_p(delta), _p(alive), delta.numel(), p, C.byref(a), C.byref(b))
+        return q, a.value, b.value
+
+    def extrema(self, delta):
+        lo, hi = _f64(), _f64()
+        self.L.orc_extrema(_p(delta), delta.numel(), C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def count_gt(self, delta, thr) -> int:
+        return self.L.orc_count_gt(_p(delta), delta.numel(), thr)
+
+    def mc_rank_prepare(self, delta, order, sorted_delta):
+        self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), _p(order), _p(sorted_delta))
+
+    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep) -> int:
+        nsim = _i64()
+        self.L.orc_mc_swarm(self.m.ptr, _p(order), _p(sorted_delta), cur[1].numel(), _p(cur[0]), _p(cur[1]),
+                            _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0,
+                            n_local, sweep, C.byref(nsim))
+        return nsim.value
+
+    def push_p(self, theta, out):
+        self.L.orc_push_p(self.m.ptr, _p(theta), theta.shape[0], _p(out))
+
+    def math_eval(self, fn, x, y, y2=None):
+        self.L.orc_math_eval(fn, _p(x), _p(y), _p(y2), x.numel())
+
+
+def oracle_engine(spec, nparticles, process_group=None):
+    """PopulationEngine (the product's host logic) driven by the oracle instead of the GPU."""
+    import abcdez_amd.engine as E
+
+    return E.PopulationEngine(spec, nparticles, process_group, ops=OracleOps(spec))
+
+
+def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0,
+                 facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000):
+    """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c)."""
+    L = lib()
+    m = OracleModel(spec)
+    N, ld = nparticles, spec.ld
+    R = SmcRun(nparticles=N, eps_target=eps_target, alpha=alpha, delta_ess=delta_ess, nsims_max=nsims_max,
+               Kmcmc=Kmcmc, max_iters=max_iters, Kmcmc_min=Kmcmc_min, facc_stop=facc_stop, facc_min=facc_min,
+               facc_tune=facc_tune)
+    theta = np.zeros((N, ld)); logpi = np.zeros(N); delta = np.zeros(N); wns = np.zeros(N)
+    alive = np.zeros(N, dtype=np.uint8)
+    H = max_iters + 2
+    h = [np.zeros(H) for _ in range(7)]
+    hK = np.zeros(H, dtype=np.int32)
+    rc = L.orc_abcdesmc(m.ptr, C.byref(R), _p(theta), _p(logpi), _p(delta), _p(wns), _p(alive),
+                        *[_p(a) for a in h], _p(hK))
+    if rc:
+        raise RuntimeError("oracle abcdesmc failed")
+    n = R.n_hist
+    return dict(theta=theta[:, :spec.d], logpi=logpi, C=delta, Wns=wns, alive=alive.astype(bool), eps=R.eps,
+                logZ=R.logZ, iters=R.iters, nsims=R.nsims_total, updates=R.updates_total, no_alive=bool(R.no_alive),
+                eps_hist=h[0][:n], lo_hist=h[1][:n], hi_hist=h[2][:n], logZ_hist=h[3][:n], ess_hist=h[4][:n],
+                facc_hist=h[5][:n], gamma0_hist=h[6][:n], K_hist=hK[:n])
+
+
+def run_abcdemc(spec, nparticles, eps_target, generations):
+    L = lib()
+    m = OracleModel(spec)
+    N, ld = nparticles, spec.ld
+    R = McRun(nparticles=N, generations=generations, eps_target=eps_target)
+    theta = np.zeros((N, ld)); logpi = np.zeros(N); delta = np.zeros(N)
+    rc = L.orc_abcdemc(m.ptr, C.byref(R), _p(theta), _p(logpi), _p(delta))
+    if rc:
+        raise RuntimeError("oracle abcdemc failed")
+    return dict(theta=theta[:, :spec.d], logpi=logpi, C=delta, reached_eps=bool(R.reached_eps), nsims=R.nsims_total,
+                complete=R.complete)
