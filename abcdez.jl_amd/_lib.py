@@ -23,6 +23,8 @@ PROTOTYPES = {
     "abcdez_ctx_set_lanes": [_vp, C.c_int],
     "abcdez_ctx_get_layout": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "abcdez_sync": [_vp],
+    "abcdez_ctx_set_timing": [_vp, C.c_int],
+    "abcdez_ctx_get_timing": [_vp, _pf64, _pi64, _pi64],
     "abcdez_dev_alloc": [C.c_size_t, C.POINTER(_vp)],
     "abcdez_dev_free": [_vp],
     "abcdez_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],

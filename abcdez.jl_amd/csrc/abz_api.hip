@@ -110,6 +110,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
@@ -176,6 +177,31 @@ int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes)
 static int read_counters(abcdez_ctx* ctx) {
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->ev_pending) {
+    float ms = 0.f;
+    ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->swarm_ms += (double)ms;
+    ctx->swarm_launches += 1;
+    ctx->swarm_units += ctx->ev_units;
+    ctx->ev_pending = false;
+  }
+  return 0;
+}
+
+int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
+  ABZ_REQUIRE(ctx, "set_timing: null context");
+  if (on && !ctx->ev0) {
+    ABZ_HIP_CHECK(hipEventCreate(&ctx->ev0));
+    ABZ_HIP_CHECK(hipEventCreate(&ctx->ev1));
+  }
+  ctx->timing = on != 0;
+  ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_pending = false;
+  return 0;
+}
+
+int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, int64_t* units) {
+  ABZ_REQUIRE(ctx && swarm_ms && launches && units, "get_timing: null argument");
+  *swarm_ms = ctx->swarm_ms; *launches = ctx->swarm_launches; *units = ctx->swarm_units;
   return 0;
 }
 

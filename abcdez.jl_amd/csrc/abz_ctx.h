@@ -23,6 +23,11 @@ struct abcdez_ctx {
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
+  bool timing = false, ev_pending = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double swarm_ms = 0.0;
+  long long swarm_launches = 0, swarm_units = 0, ev_units = 0;
 };
 
 void abz_set_error(const std::string& msg);

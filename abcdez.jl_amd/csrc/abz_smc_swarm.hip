@@ -127,8 +127,14 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
                          ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local);
     }
     if (a.n_work > 0) {
+      if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
       hipLaunchKernelGGL((smc_swarm_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)a.n_work * LL())),
                          dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      if (ctx->timing) {
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        ctx->ev_pending = true;
+        ctx->ev_units = a.n_work;
+      }
     }
   });
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }

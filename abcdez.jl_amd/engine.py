@@ -69,6 +69,15 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
         return ld.value, L.value, Cc.value
 
+    def set_timing(self, on: bool):
+        _lib.check(self.lib, self.lib.abcdez_ctx_set_timing(self.ctx, int(on)))
+
+    def get_timing(self):
+        """(sweep-kernel ms, launches, particle-updates) accumulated since set_timing(True)"""
+        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_ctx_get_timing(self.ctx, C.byref(ms), C.byref(n), C.byref(u)))
+        return ms.value, n.value, u.value
+
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.abcdez_ctx_destroy(self.ctx)

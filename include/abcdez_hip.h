@@ -30,36 +30,42 @@
 extern "C" {
 #endif
 
+#define ABCDEZ_API __attribute__((visibility("default")))
+
 typedef struct abcdez_ctx abcdez_ctx;
 
-int abcdez_version(void);
-const char* abcdez_last_error(void);
+ABCDEZ_API int abcdez_version(void);
+ABCDEZ_API const char* abcdez_last_error(void);
 
 /* Context = (prior, dist!, varexternal, rng, ex) of the reference signatures
  * (src/abcdez_smc.jl:106-109, src/abcdez_mc.jl:5-6, src/abcdez_init.jl:2).
  * `model->data` is a HOST pointer here; it is copied to the device.             */
-int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out);
-int abcdez_ctx_destroy(abcdez_ctx* ctx);
-int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
+ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out);
+ABCDEZ_API int abcdez_ctx_destroy(abcdez_ctx* ctx);
+ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */
-int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
-int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lanes, int32_t* comps_per_lane);
-int abcdez_sync(abcdez_ctx* ctx);
+ABCDEZ_API int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
+ABCDEZ_API int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lanes, int32_t* comps_per_lane);
+ABCDEZ_API int abcdez_sync(abcdez_ctx* ctx);
+/* HIP-event timing of the sweep kernel on the context's stream (measurement only):
+ * accumulated kernel milliseconds, launches and particle-updates since set_timing(1). */
+ABCDEZ_API int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on);
+ABCDEZ_API int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, int64_t* units);
 
 /* Device memory helpers for hosts without a GPU array package of their own. */
-int abcdez_dev_alloc(size_t bytes, void** out);
-int abcdez_dev_free(void* ptr);
-int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
-int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+ABCDEZ_API int abcdez_dev_alloc(size_t bytes, void** out);
+ABCDEZ_API int abcdez_dev_free(void* ptr);
+ABCDEZ_API int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+ABCDEZ_API int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
 /* S1  abcde_init!(prior, dist!, varexternal, thetas, logpi, Ds, nparticles, rng, ex, blobs)
  *     src/abcdez_init.jl:2-22, including the prior draws and log-priors of
  *     src/abcdez_smc.jl:242-243 / src/abcdez_mc.jl:117-118.  Fills rows [i0, i0+n).  */
-int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n);
+ABCDEZ_API int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n);
 
 /* Alive list: the index set wsample(rng, 1:N, alive) draws from (src/abcdez_smc.jl:121,125).
  * alive_idx[r] = index of the r-th alive particle; arank[i] = rank of i or 0xFFFFFFFF. */
-int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N,
+ABCDEZ_API int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N,
                          uint32_t* alive_idx, uint32_t* arank, int64_t* n_alive);
 
 /* S2+S3  abcdesmc_swarm!(prior, dist!, varexternal, alive, thetas, logpi, Ds, nthetas, nlogpi, nDs,
@@ -69,7 +75,7 @@ int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N,
  * copy_dead != 0 also carries the dead rows of the range into the n* arrays.
  * sweep = global sweep number (RNG epoch).  *nacc / *nsim = sums of the reference's
  * naccs[i] += 1 / nsims[i] += 1 over the range.                                      */
-int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,
+ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,
                      int64_t r_lo, int64_t r_hi,
                      const double* theta, const double* logpi, const double* delta,
                      double* ntheta, double* nlogpi, double* ndelta,
@@ -79,49 +85,49 @@ int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t*
 
 /* S5+S6  abcdesmc_update_ws!(ws, alive, Ds, eps_k, eps_k_new, nparticles) src/abcdez_smc.jl:59-83
  *        followed by the driver's wprod/wnorm/Wns/alive lines :308-311 and get_ess :8,:323. */
-int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N,
+ABCDEZ_API int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N,
                         double eps_old, double eps_new, double* wnorm, double* ess, int64_t* n_alive);
-int abcdez_get_ess(abcdez_ctx* ctx, const double* wns, int64_t N, double* ess);
+ABCDEZ_API int abcdez_get_ess(abcdez_ctx* ctx, const double* wns, int64_t N, double* ess);
 
 /* S7  wsample_stratified!(rng, weights, inds)  src/abcdez_smc.jl:15-56 (0-based indices).
  *     draw = resampling number (RNG epoch).                                           */
-int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds);
+ABCDEZ_API int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds);
 
 /* S8  abcdesmc_resample!(ess_inds, thetas, logpi, Ds, Wns, alive, nparticles, rng, blobs)
  *     src/abcdez_smc.jl:85-104, gathers for rows [i0, i0+n_local) into the n* arrays,
  *     Wns = 1/N and alive = true on that range.                                       */
-int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
+ABCDEZ_API int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
                                const double* theta, const double* logpi, const double* delta,
                                double* ntheta, double* nlogpi, double* ndelta, double* wns, uint8_t* alive);
 
 /* S9  quantile(Ds[alive], alpha)  src/abcdez_smc.jl:301 (Julia default, type 7).
  *     Also returns the two order statistics it interpolates.                         */
-int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double p,
+ABCDEZ_API int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double p,
                           double* q, double* xj, double* xj1);
 
 /* S10  extrema(Ds) src/abcdez_smc.jl:286,364, src/abcdez_mc.jl:146,163;
  *      sum(Ds .> eps_target) src/abcdez_mc.jl:133,156.                               */
-int abcdez_extrema(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi);
-int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count);
+ABCDEZ_API int abcdez_extrema(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi);
+ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count);
 
 /* S4  abcdemc_swarm!(prior, dist!, varexternal, thetas, logpi, Ds, nthetas, nlogpi, nDs,
  *     eps_pop, eps_target, gamma0, gamma_sigma, nparticles, nsims, rng, ex, nblobs)
  *     src/abcdez_mc.jl:5-61 plus the copies of :140-143.  rank_prepare builds the
  *     (Ds, index)-sorted order the "better particle" draw of mc:23 indexes into.     */
-int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta);
-int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N,
+ABCDEZ_API int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta);
+ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N,
                     const double* theta, const double* logpi, const double* delta,
                     double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma,
                     int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim);
 
 /* T2  push_p over the population (src/abcdez_types.jl:20-23; result P, smc:382, mc:166). */
-int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);
+ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);
 
 /* Test hooks: evaluate the spec arithmetic on the device (fn: 0 log, 1 exp, 2 sincos2pi,
  * 3 rint, 4 floor, 5 sqrt, 6 x/y2) and one simulator call per row of `pushed`.       */
-int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n);
-int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out);
+ABCDEZ_API int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n);
+ABCDEZ_API int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out);
 
 #ifdef __cplusplus
 }

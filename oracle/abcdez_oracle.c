@@ -69,6 +69,14 @@ ORC_API void orc_normal_pairs(uint64_t seed, uint32_t purpose, int64_t n, double
     abz_normal_pair(abz_rng(seed, (uint32_t)i, 0, 0, purpose), &z[2 * i], &z[2 * i + 1]);
   }
 }
+ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_t ri, uint32_t* ra, uint32_t* rb) {
+  abz_u64x2 w; w.w0 = w0; w.w1 = w1;
+  abz_donor_ranks(w, n_alive, ri, ra, rb);
+}
+ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w, n); }
+ORC_API double orc_u01(uint64_t w, int open) { return open ? abz_u01_open(w) : abz_u01_co(w); }
+ORC_API uint32_t orc_randint(uint64_t w, uint32_t n) { return abz_randint(w, n); }
+ORC_API double orc_prior_logpdf1(const abz_prior_dim* pd, double x) { return abz_prior_logpdf1(pd, x); }
 ORC_API double orc_kernel_pdf(int kind, double eps, double x) { return abz_kernel_pdf(kind, eps, x); }
 ORC_API double orc_kernel_logpdf(int kind, double eps, double x) { return abz_kernel_logpdf(kind, eps, x); }
 

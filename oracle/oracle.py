@@ -68,6 +68,13 @@ def lib():
     L.orc_kernel_logpdf.restype = _f64
     L.orc_kernel_logpdf.argtypes = [C.c_int, _f64, _f64]
     L.orc_philox.argtypes = [_vp, _vp, _vp]
+    L.orc_donor_ranks.argtypes = [_u64, _u64, _u32, _u32, _vp, _vp]
+    L.orc_weight_fix.restype = _u64
+    L.orc_weight_fix.argtypes = [_f64, _u32]
+    L.orc_u01.restype = _f64
+    L.orc_u01.argtypes = [_u64, C.c_int]
+    L.orc_randint.restype = _u32
+    L.orc_randint.argtypes = [_u64, _u32]
     L.orc_math_eval.argtypes = [C.c_int, _vp, _vp, _vp, _i64]
     L.orc_rng_words.argtypes = [_u64, _u32, _u32, _u32, _u32, _vp]
     L.orc_normal_pairs.argtypes = [_u64, _u32, _i64, _vp]

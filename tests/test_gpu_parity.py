@@ -1,0 +1,241 @@
+"""GPU parity: every C-ABI entry point of libabcdez_hip.so against the CPU oracle,
+bit for bit, on the same seeded inputs (sizes the oracle finishes in seconds)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import abcdez_amd as A
+from abcdez_amd.engine import HipOps, PopulationEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def models():
+    n32 = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(32)])
+    return {
+        "normal1d": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.3),
+        "uniform1d": (A.Uniform(-10.0, 10.0), A.Normal1D(3.0), 0.3),
+        "mvn32": (n32, A.MVNormal(tuple([1.0] * 32)), 6.0),
+        "mvn8": (A.Factored(*[A.Normal(0.0, 1.0) for _ in range(8)]), A.MVNormal(tuple([1.0] * 8)), 2.5),
+        "mvn3": (A.Factored(A.Normal(0, 1), A.Uniform(-3, 3), A.Normal(1, 2)), A.MVNormal((0.5, 0.2, 1.0)), 0.8),
+        "quad2d_inf": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.01),
+        "normdu": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.01),
+        "dirac": (A.Normal(1, 0.2), A.DiracSquare(1.5), 0.1),
+        "mixture": (A.Uniform(-10, 10), A.Mixture01(0.0), 0.01),
+    }
+
+
+def engines(name, N, seed=3, ABCk=A.IndicatorStrict0toϵ, lanes=0, oracle=None):
+    prior, sim, eps = models()[name]
+    spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes))
+    orc = oracle.oracle_engine(spec, N)
+    return spec, hip, orc, eps
+
+
+def same(a: torch.Tensor, b: torch.Tensor):
+    a = a.detach().cpu().contiguous()
+    b = b.detach().cpu().contiguous()
+    if a.dtype == torch.float64:
+        return torch.equal(a.view(torch.int64), b.view(torch.int64))
+    return torch.equal(a, b)
+
+
+def assert_state_equal(hip, orc, what=""):
+    for k, nm in enumerate(("theta", "logpi", "delta")):
+        assert same(hip.state[k], orc.state[k]), f"{what}: {nm} differs"
+    assert same(hip.wns, orc.wns), f"{what}: wns differs"
+    assert same(hip.alive, orc.alive), f"{what}: alive differs"
+
+
+# ---------------------------------------------------------------- spec arithmetic on the device
+@pytest.mark.parametrize("fn,gen", [
+    (0, "pos"), (1, "exparg"), (2, "unit"), (3, "round"), (4, "round"), (5, "pos"), (6, "pair"),
+])
+def test_math_bit_exact(oracle, fn, gen):
+    rng = np.random.default_rng(100 + fn)
+    n = 1 << 20
+    if gen == "pos":
+        x = np.exp(rng.uniform(-700, 700, n))
+        x[:8] = [0.0, 1.0, 5e-324, 2.2250738585072014e-308, np.inf, 0.5, 2.0, 1.0 - 2 ** -53]
+    elif gen == "exparg":
+        x = rng.uniform(-750, 710, n)
+        x[:6] = [0.0, -np.inf, np.inf, -745.2, 709.8, 1e-300]
+    elif gen == "unit":
+        x = rng.integers(0, 1 << 53, n).astype(np.float64) * 2.0 ** -53
+        x[:4] = [0.0, 0.125, 0.5, 1 - 2.0 ** -53]
+    elif gen == "round":
+        x = rng.uniform(-1e6, 1e6, n)
+        x[:8] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.0, 4503599627370497.0]
+    else:
+        x = rng.normal(0, 1e3, n)
+    y2in = rng.uniform(0.5, 3.0, n)
+    spec = A.ModelSpec(A.Normal(0, 1), A.Normal1D(0.0), seed=1)
+    ops = HipOps(spec)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    y2d = torch.from_numpy(y2in.copy()).cuda()
+    ops.math_eval(fn, xd, yd, y2d)
+    yh = np.zeros(n)
+    y2h = y2in.copy()
+    oracle.lib().orc_math_eval(fn, x.ctypes.data, yh.ctypes.data, y2h.ctypes.data, n)
+    assert np.array_equal(yd.cpu().numpy().view(np.int64), yh.view(np.int64))
+    if fn == 2:
+        assert np.array_equal(y2d.cpu().numpy().view(np.int64), y2h.view(np.int64))
+
+
+# ---------------------------------------------------------------- S1
+@pytest.mark.parametrize("name", list(models().keys()))
+def test_init_parity(oracle, name):
+    spec, hip, orc, _ = engines(name, 20000, oracle=oracle)
+    hip.init_population()
+    orc.init_population()
+    assert_state_equal(hip, orc, "init")
+    assert torch.isfinite(hip.state[2]).all() and torch.isfinite(hip.state[1]).all()   # init.jl:14
+
+
+# ---------------------------------------------------------------- population passes on a synthetic state
+@pytest.mark.parametrize("N", [1, 2, 777, 2048, 2049, 100003])
+@pytest.mark.parametrize("abck", A.ALL_KERNELS)
+def test_reweight_quantile_compact_parity(oracle, N, abck):
+    prior, sim, _ = models()["normal1d"]
+    spec = A.ModelSpec(prior, sim, abck, seed=5)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec))
+    orc = oracle.oracle_engine(spec, N)
+    g = torch.Generator().manual_seed(N)
+    delta = torch.rand(N, generator=g, dtype=torch.float64) * 3.0
+    delta[::7] = delta[0]          # ties
+    for e in (hip, orc):
+        e.state[2].copy_(delta)
+        e.reset_weights()
+    eps_old = math.inf
+    for alpha in (0.95, 0.5, 0.9):
+        qh, qo = hip.quantile_alive(alpha), orc.quantile_alive(alpha)
+        assert qh == qo
+        assert hip.extrema() == orc.extrema()
+        assert hip.count_gt(qh) == orc.count_gt(qo)
+        rh, ro = hip.smc_reweight(eps_old, qh), orc.smc_reweight(eps_old, qo)
+        assert rh[2] == ro[2]
+        if ro[2] == 0:
+            break
+        assert rh == ro, (rh, ro)
+        assert hip.get_ess() == orc.get_ess()
+        assert same(hip.wns, orc.wns) and same(hip.alive, orc.alive)
+        nh, no = hip.alive_compact(), orc.alive_compact()
+        assert nh == no == ro[2]
+        assert same(hip.alive_idx[:nh], orc.alive_idx[:no]) and same(hip.arank, orc.arank)
+        eps_old = qh
+
+
+@pytest.mark.parametrize("N", [5, 1000, 4096, 65537])
+def test_stratified_resample_parity(oracle, N):
+    spec, hip, orc, _ = engines("mvn8", N, oracle=oracle)
+    hip.init_population(); orc.init_population()
+    g = torch.Generator().manual_seed(N)
+    w = torch.rand(N, generator=g, dtype=torch.float64)
+    w[torch.rand(N, generator=g) < 0.4] = 0.0
+    w[0] = 1.0
+    w /= w.sum()
+    for e in (hip, orc):
+        e.wns.copy_(w)
+        e.alive.copy_((w > 0).to(torch.uint8))
+    for _ in range(2):
+        hip.smc_resample(); orc.smc_resample()
+        assert same(hip.inds, orc.inds)
+        assert_state_equal(hip, orc, "resample")
+        for e in (hip, orc):
+            e.wns.copy_(w)
+    inds = hip.inds.cpu().numpy().astype(np.int64)
+    assert (np.diff(inds) >= 0).all()                       # smc:45-54: monotone walk
+    assert (w.numpy()[inds] > 0).all()                      # zero weights never chosen
+    counts = np.bincount(inds, minlength=N)
+    expect = N * w.numpy()
+    assert (counts >= np.floor(expect) - 1).all() and (counts <= np.ceil(expect) + 1).all()
+
+
+# ---------------------------------------------------------------- S2/S3 sweeps incl. dead particles
+@pytest.mark.parametrize("name,lanes", [
+    ("normal1d", 0), ("uniform1d", 0), ("mvn32", 0), ("mvn32", 4), ("mvn32", 16), ("mvn32", 2), ("mvn8", 0),
+    ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0),
+])
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_smc_sweep_parity(oracle, name, lanes, abck):
+    N = 6000
+    spec, hip, orc, _ = engines(name, N, ABCk=abck, lanes=lanes, oracle=oracle)
+    hip.init_population(); orc.init_population()
+    d = spec.d
+    gamma0 = 2.38 / math.sqrt(2 * d)
+    eps_old = math.inf
+    for gen in range(4):
+        q = orc.quantile_alive(0.8)
+        assert hip.quantile_alive(0.8) == q
+        eps = min(q, eps_old)
+        rh, ro = hip.smc_reweight(eps_old, eps), orc.smc_reweight(eps_old, eps)
+        assert rh == ro
+        if gen == 2:
+            hip.smc_resample(); orc.smc_resample()
+            assert same(hip.inds, orc.inds)
+        assert hip.alive_compact() == orc.alive_compact()
+        for _ in range(3):
+            ch, co = hip.smc_swarm(eps, gamma0, 1e-5), orc.smc_swarm(eps, gamma0, 1e-5)
+            assert ch == co, (ch, co)                      # bit-exact accept mask => equal counters
+            assert_state_equal(hip, orc, f"{name} gen {gen}")
+        eps_old = eps
+
+
+# ---------------------------------------------------------------- S4
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac"])
+def test_mc_sweep_parity(oracle, name):
+    N = 5000
+    spec, hip, orc, eps_target = engines(name, N, oracle=oracle)
+    hip.init_population(); orc.init_population()
+    gamma0 = 2.38 / math.sqrt(2 * spec.d)
+    for gen in range(6):
+        lo, hi = orc.extrema()
+        assert hip.extrema() == (lo, hi)
+        hip.mc_rank_prepare(); orc.mc_rank_prepare()
+        assert same(hip.order, orc.order) and same(hip.sorted_delta, orc.sorted_delta)
+        eps_pop = max(eps_target, lo)
+        assert hip.mc_swarm(eps_pop, eps_target, gamma0, 1e-5) == orc.mc_swarm(eps_pop, eps_target, gamma0, 1e-5)
+        assert_state_equal(hip, orc, f"mc gen {gen}")
+
+
+# ---------------------------------------------------------------- whole drivers, product vs C restatement
+@pytest.mark.parametrize("name,N", [("normal1d", 5000), ("uniform1d", 5000), ("mvn8", 4096), ("mvn32", 8192),
+                                    ("quad2d_inf", 500), ("normdu", 100), ("dirac", 100)])
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ])
+def test_abcdesmc_end_to_end_parity(oracle, name, N, abck):
+    if name == "mvn32" and abck is not A.IndicatorStrict0toϵ:
+        pytest.skip("one kernel is enough at d=32")
+    prior, sim, eps = models()[name]
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, ABCk=abck, verbose=False, rng=11, nsims_max=10 ** 8)
+    assert type(r.engine.ops).__name__ == "HipOps"
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, abck, seed=11), N, eps, nsims_max=10 ** 8)
+    res = r.engine.result()
+    assert r.iters == c["iters"] and r.nsims == c["nsims"]
+    assert np.array_equal(np.array(r.ϵs), c["eps_hist"])          # eps schedule identical
+    assert r.logZ == c["logZ"] or (math.isnan(r.logZ) and math.isnan(c["logZ"]))
+    assert np.array_equal(np.array(r.logZs), c["logZ_hist"], equal_nan=True)
+    assert np.array_equal(np.array(r.esss), c["ess_hist"], equal_nan=True)
+    assert np.array_equal(res["theta"], c["theta"])
+    assert np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"], equal_nan=True)
+    assert np.array_equal(res["alive"], c["alive"])
+
+
+@pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
+                                         ("quad2d_inf", 500, 80)])
+def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
+    prior, sim, eps = models()[name]
+    r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=gens, verbose=False, rng=13)
+    c = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=13), N, eps, gens)
+    res = r.engine.result()
+    assert r.nsims == c["nsims"] and r.reached_ϵ == c["reached_eps"]
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"])
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+
+    g.smoke()

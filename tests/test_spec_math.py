@@ -1,0 +1,185 @@
+"""Pins the shared arithmetic spec (abcdez.jl_amd/csrc/abcdez_spec.h) against independent
+references: published Philox known-answer vectors + a pure-Python Philox, and mpmath /
+numpy for the elementary functions.  CPU only."""
+import ctypes as C
+
+import mpmath
+import numpy as np
+import pytest
+from scipy import stats
+
+M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+MASK = 0xFFFFFFFF
+
+
+def py_philox4x32_10(ctr, key):
+    """Independent restatement of Philox4x32-10 (Salmon et al., SC'11)."""
+    c = list(ctr)
+    k = list(key)
+    for _ in range(10):
+        p0 = M0 * c[0]
+        p1 = M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & MASK, (p0 >> 32) ^ c[3] ^ k[1], p0 & MASK]
+        k = [(k[0] + W0) & MASK, (k[1] + W1) & MASK]
+    return c
+
+
+def c_philox(O, ctr, key):
+    c = np.array(ctr, dtype=np.uint32)
+    k = np.array(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    O.lib().orc_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return [int(v) for v in out]
+
+
+# Random123 kat_vectors, philox4x32 10 rounds
+KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([MASK] * 4, [MASK] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+     [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expect", KAT)
+def test_philox_known_answers(oracle, ctr, key, expect):
+    assert c_philox(oracle, ctr, key) == expect
+    assert py_philox4x32_10(ctr, key) == expect
+
+
+def test_philox_vs_independent_python(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        ctr = [int(v) for v in rng.integers(0, 1 << 32, 4)]
+        key = [int(v) for v in rng.integers(0, 1 << 32, 2)]
+        assert c_philox(oracle, ctr, key) == py_philox4x32_10(ctr, key)
+
+
+def test_rng_word_packing(oracle):
+    out = np.zeros(2, dtype=np.uint64)
+    oracle.lib().orc_rng_words(0x0123456789ABCDEF, 7, 11, 3, 6, out.ctypes.data)
+    r = py_philox4x32_10([7, 11, 3, 6], [0x89ABCDEF, 0x01234567])
+    assert int(out[0]) == (r[1] << 32) | r[0] and int(out[1]) == (r[3] << 32) | r[2]
+
+
+def ulp_err(y, ref_mp):
+    """error of double y against the mpmath value, in units of ulp(y)"""
+    y = float(y)
+    if ref_mp == 0:
+        return 0.0 if y == 0 else np.inf
+    ulp = np.spacing(abs(y)) if y != 0 else 5e-324
+    return float(abs(mpmath.mpf(y) - ref_mp) / ulp)
+
+
+def eval_fn(O, fn, x, y2=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    y2 = np.zeros_like(x) if y2 is None else np.ascontiguousarray(y2, dtype=np.float64)
+    O.lib().orc_math_eval(fn, x.ctypes.data, y.ctypes.data, y2.ctypes.data, x.size)
+    return y, y2
+
+
+def test_log_accuracy(oracle):
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(0, 1, 1500), np.exp(rng.uniform(-700, 700, 1500)),
+                        1 + rng.uniform(-1e-3, 1e-3, 500), [5e-324, 2.2250738585072014e-308, 1.0, 0.5, 2.0]])
+    y, _ = eval_fn(oracle, 0, x)
+    worst = max(ulp_err(b, mpmath.log(mpmath.mpf(float(a)))) for a, b in zip(x, y))
+    assert worst < 1.0, worst
+    # bulk agreement with libm within 2 ulp
+    xb = np.exp(rng.uniform(-700, 700, 200000))
+    yb, _ = eval_fn(oracle, 0, xb)
+    assert np.max(np.abs(yb - np.log(xb)) / np.spacing(np.abs(np.log(xb)) + 1e-300)) <= 2
+    sp, _ = eval_fn(oracle, 0, np.array([0.0, -0.0, -1.0, np.inf, np.nan]))
+    assert sp[0] == -np.inf and sp[1] == -np.inf and np.isnan(sp[2]) and sp[3] == np.inf and np.isnan(sp[4])
+
+
+def test_exp_accuracy(oracle):
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-745, 709, 2500), rng.uniform(-1, 1, 1000), [0.0, 1e-20, -1e-20, 709.7, -745.0]])
+    y, _ = eval_fn(oracle, 1, x)
+    worst = max(ulp_err(b, mpmath.exp(mpmath.mpf(float(a)))) for a, b in zip(x, y) if b > 1e-300)
+    assert worst < 1.0, worst
+    sp, _ = eval_fn(oracle, 1, np.array([-np.inf, np.inf, np.nan, 710.0, -746.0, 0.0]))
+    assert sp[0] == 0.0 and sp[1] == np.inf and np.isnan(sp[2]) and sp[3] == np.inf and sp[4] == 0.0 and sp[5] == 1.0
+    sub, _ = eval_fn(oracle, 1, np.array([-740.0]))
+    assert abs(sub[0] - np.exp(-740.0)) <= 2 * 5e-324 * 2 ** 3   # subnormal range: absolute error of a few quanta
+
+
+def test_sincos2pi_accuracy(oracle):
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(4)
+    u = np.concatenate([rng.integers(0, 1 << 53, 3000).astype(np.float64) * 2.0 ** -53,
+                        [0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1 - 2.0 ** -53, 2.0 ** -53]])
+    s, c = eval_fn(oracle, 2, u)
+    for ui, si, ci in zip(u, s, c):
+        a = 2 * mpmath.pi * mpmath.mpf(float(ui))
+        # absolute error relative to 1 (values near zero crossings carry the rounding of 2 pi u)
+        assert abs(mpmath.mpf(float(si)) - mpmath.sin(a)) < 3e-16
+        assert abs(mpmath.mpf(float(ci)) - mpmath.cos(a)) < 3e-16
+    assert np.all(np.abs(s * s + c * c - 1) < 5e-16)
+    e = eval_fn(oracle, 2, np.array([0.0, 0.25, 0.5, 0.75]))
+    assert list(e[0]) == [0.0, 1.0, -0.0, -1.0] and list(e[1]) == [1.0, -0.0, -1.0, 0.0]
+
+
+def test_rint_floor_sqrt_div(oracle):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-1e6, 1e6, 100000), np.arange(-10, 10) + 0.5, [0.0, -0.0, 1e300, -1e300, 2.0 ** 52]])
+    assert np.array_equal(eval_fn(oracle, 3, x)[0], np.rint(x))         # ties to even == Julia round(Int, x)
+    assert np.array_equal(eval_fn(oracle, 4, x)[0], np.floor(x))
+    xp = np.abs(x) + 1e-300
+    assert np.array_equal(eval_fn(oracle, 5, xp)[0], np.sqrt(xp))
+    y2 = rng.uniform(0.5, 3.0, x.size)
+    assert np.array_equal(eval_fn(oracle, 6, x, y2)[0], x / y2)
+
+
+def test_uniform_conversions(oracle):
+    L = oracle.lib()
+    assert L.orc_u01(0, 1) == 2.0 ** -53 and L.orc_u01((1 << 64) - 1, 1) == 1 - 2.0 ** -53
+    assert L.orc_u01(0, 0) == 0.0 and L.orc_u01((1 << 64) - 1, 0) == 1 - 2.0 ** -53
+    assert L.orc_randint(0, 10) == 0 and L.orc_randint((1 << 64) - 1, 10) == 9
+    assert L.orc_randint(1 << 63, 10) == 5
+
+
+def test_normal_pairs_are_standard_normal(oracle):
+    n = 400000
+    z = np.zeros(2 * n)
+    oracle.lib().orc_normal_pairs(12345, 6, n, z.ctypes.data)
+    assert abs(z.mean()) < 4 / np.sqrt(2 * n)
+    assert abs(z.var() - 1) < 0.01
+    assert abs(stats.kurtosis(z)) < 0.03
+    assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01          # the two outputs of a pair are independent
+    assert np.abs(z).max() < 8.6                                   # sqrt(-2 log 2^-53)
+
+
+def test_donor_ranks_distinct_and_uniform(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(6)
+    n_alive, ri = 7, 3
+    ra, rb = C.c_uint32(), C.c_uint32()
+    cnt = np.zeros((n_alive, n_alive))
+    trials = 60000
+    for _ in range(trials):
+        w0, w1 = (int(v) for v in rng.integers(0, 1 << 64, 2, dtype=np.uint64))
+        L.orc_donor_ranks(w0, w1, n_alive, ri, C.byref(ra), C.byref(rb))
+        a, b = ra.value, rb.value
+        assert a != ri and b != ri and a != b and a < n_alive and b < n_alive     # smc:119-126
+        cnt[a, b] += 1
+    pairs = cnt[cnt > 0]
+    assert pairs.size == (n_alive - 1) * (n_alive - 2)
+    # uniform over ordered pairs (a, b), a != b, both != i: the law of the reference's rejection loops
+    assert stats.chisquare(pairs).pvalue > 1e-4
+    # smallest population the reference's loops terminate on
+    L.orc_donor_ranks(0, 0, 3, 0, C.byref(ra), C.byref(rb))
+    assert {ra.value, rb.value} == {1, 2}
+
+
+def test_weight_fix_exact_cases(oracle):
+    L = oracle.lib()
+    N = 1000
+    assert L.orc_weight_fix(0.0, N) == 0 and L.orc_weight_fix(float("nan"), N) == 0
+    assert L.orc_weight_fix(1.0 / N, N) == 1 << 40 or abs(L.orc_weight_fix(1.0 / N, N) - (1 << 40)) <= 1
+    assert L.orc_weight_fix(1.0, N) == N << 40
