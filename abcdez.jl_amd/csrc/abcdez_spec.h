@@ -109,15 +109,7 @@ ABZ_HD uint32_t abz_randint(uint64_t w, uint32_t n) { return (uint32_t)abz_mulhi
  * Argument reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)); f = m-1; s = f/(2+f);
  * log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)); degree-7 minimax R in s^2 (the
  * classic Sun/fdlibm coefficients).  < 1 ulp.                                      */
-ABZ_HD double abz_log(double x) {
-  uint64_t ux = abz_d2u(x);
-  int k = 0;
-  if ((ux << 1) == 0) return ABZ_NINF;                /* +-0            */
-  if (ux >> 63) return ABZ_NAN;                       /* negative       */
-  if ((ux >> 52) == 0x7FF) return x;                  /* +Inf / NaN     */
-  if ((ux >> 52) == 0) {                              /* subnormal      */
-    x = x * 0x1p54; ux = abz_d2u(x); k = -54;
-  }
+ABZ_HD double abz_log_core(uint64_t ux, int k) {   /* ux = bits of a positive normal double */
   /* bring mantissa into [sqrt(1/2), sqrt(2)) */
   uint32_t hx = (uint32_t)(ux >> 32);
   hx += 0x3FF00000u - 0x3FE6A09Eu;
@@ -140,6 +132,19 @@ ABZ_HD double abz_log(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   return dk * ln2_hi - ((hfsq - abz_fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
+ABZ_HD double abz_log(double x) {
+  uint64_t ux = abz_d2u(x);
+  int k = 0;
+  if ((ux << 1) == 0) return ABZ_NINF;                /* +-0            */
+  if (ux >> 63) return ABZ_NAN;                       /* negative       */
+  if ((ux >> 52) == 0x7FF) return x;                  /* +Inf / NaN     */
+  if ((ux >> 52) == 0) {                              /* subnormal      */
+    x = x * 0x1p54; ux = abz_d2u(x); k = -54;
+  }
+  return abz_log_core(ux, k);
+}
+/* same value as abz_log for positive NORMAL finite x (uniforms in [2^-53, 1)); no special cases */
+ABZ_HD double abz_log_pn(double x) { return abz_log_core(abz_d2u(x), 0); }
 
 /* ------------------------------------------------------------------ exp
  * x = k ln2 + r, |r| <= ln2/2; exp(r) = 1 + 2r/(2 - c(r)) form with the degree-5
@@ -192,19 +197,21 @@ ABZ_HD void abz_sincos2pi(double u, double* sn, double* cs) {
   C = abz_fma(C, z, -1.38888888888741095749e-03);
   C = abz_fma(C, z, 4.16666666666666019037e-02);
   double cp = abz_fma(z * z, C, abz_fma(-0.5, z, 1.0));
-  switch (n & 3) {
-    case 0: *sn = sp; *cs = cp; break;
-    case 1: *sn = cp; *cs = -sp; break;
-    case 2: *sn = -sp; *cs = -cp; break;
-    default: *sn = -cp; *cs = sp; break;
-  }
+  /* quadrant n&3: 0 (s,c)  1 (c,-s)  2 (-s,-c)  3 (-c,s); negation = sign-bit flip */
+  const int swap = n & 1;
+  const uint64_t s_neg = (uint64_t)((n >> 1) & 1) << 63;
+  const uint64_t c_neg = (uint64_t)(((n + 1) >> 1) & 1) << 63;
+  const double s0 = swap ? cp : sp;
+  const double c0 = swap ? sp : cp;
+  *sn = abz_u2d(abz_d2u(s0) ^ s_neg);
+  *cs = abz_u2d(abz_d2u(c0) ^ c_neg);
 }
 
 /* Box-Muller: one Philox block -> two independent N(0,1).  (randn, smc:128)       */
 ABZ_HD void abz_normal_pair(abz_u64x2 w, double* z0, double* z1) {
   double u1 = abz_u01_open(w.w0);
   double u2 = abz_u01_co(w.w1);
-  double r = abz_sqrt(-2.0 * abz_log(u1));
+  double r = abz_sqrt(-2.0 * abz_log_pn(u1));
   double sn, cs;
   abz_sincos2pi(u2, &sn, &cs);
   *z0 = r * cs;
@@ -232,34 +239,31 @@ ABZ_HD double abz_floor(double x) {
  * Distribution object (Factored = one per factor).                                 */
 enum {
   ABZ_PRIOR_PAD = 0,        /* padding component: value 0, logpdf 0                 */
-  ABZ_PRIOR_NORMAL = 1,     /* p0 = mu, p1 = sigma, c0 = -log(sigma) - log(2 pi)/2  */
+  ABZ_PRIOR_NORMAL = 1,     /* p0 = mu, p1 = sigma, c0 = -log(sigma) - log(2 pi)/2, c1 = 1/sigma */
   ABZ_PRIOR_UNIFORM = 2,    /* p0 = a, p1 = b (closed support), c0 = -log(b-a)      */
   ABZ_PRIOR_DUNIFORM = 3    /* p0 = a, p1 = b integers, c0 = -log(b-a+1); discrete  */
 };
 
-typedef struct {
+typedef struct {    /* 48 bytes = three 16-byte loads */
   int32_t family;
   int32_t discrete;   /* push_p rounds this component (types.jl:23) */
-  double p0, p1, c0;
+  double p0, p1, c0, c1, reserved;
 } abz_prior_dim;
 
 /* push_p for one component (types.jl:22-23) */
 ABZ_HD double abz_push_p(const abz_prior_dim* pd, double x) { return pd->discrete ? abz_rint(x) : x; }
 
-/* logpdf of one (already pushed) component */
+/* logpdf of one (already pushed) component; branch-free so a wave with mixed families
+ * does not serialise.  Normal: z = (x - mu) * (1/sigma), -z^2/2 + c0.                     */
 ABZ_HD double abz_prior_logpdf1(const abz_prior_dim* pd, double x) {
-  switch (pd->family) {
-    case ABZ_PRIOR_NORMAL: {
-      double z = (x - pd->p0) / pd->p1;
-      return abz_fma(-0.5 * z, z, pd->c0);
-    }
-    case ABZ_PRIOR_UNIFORM:
-      return (x >= pd->p0 && x <= pd->p1) ? pd->c0 : ABZ_NINF;
-    case ABZ_PRIOR_DUNIFORM:
-      return (x >= pd->p0 && x <= pd->p1 && abz_rint(x) == x) ? pd->c0 : ABZ_NINF;
-    default:
-      return 0.0;
-  }
+  const int fam = pd->family;
+  const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
+  const double z = (x - p0) * c1;
+  const double ln = abz_fma(-0.5 * z, z, c0);
+  int inr = (x >= p0) & (x <= p1);
+  if (fam == ABZ_PRIOR_DUNIFORM) inr &= (abz_rint(x) == x);
+  const double lu = inr ? c0 : ABZ_NINF;
+  return fam == ABZ_PRIOR_NORMAL ? ln : (fam == ABZ_PRIOR_PAD ? 0.0 : lu);
 }
 
 /* one prior draw for component pair (2m, 2m+1) uses one Philox block:

@@ -10,8 +10,20 @@
 
 #include "abcdez_spec.h"
 
+/* ---- the model fields the kernels touch, passed BY VALUE in the kernel arguments so they
+ * arrive through scalar loads of the kernarg segment instead of a chain of dependent
+ * global loads (the first build spent 80 % of its wave-cycles waiting on those).          */
+struct HotModel {
+  uint64_t seed;
+  const abz_prior_dim* prior;   /* device, ld entries */
+  const double* data;           /* device, n_data values */
+  double sim_p[8];
+  int32_t d, abck, n_data, reserved;
+};
+
 struct abcdez_ctx {
   int device = 0;
+  HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
   hipStream_t stream = nullptr;
   abz_model h_model;              /* host copy; .data points at d_data          */
   abz_model* d_model = nullptr;
@@ -58,7 +70,7 @@ enum {
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
                          const double*, const double*, const double*, double*, double*, double*,
-                         double, double, double, uint32_t, uint32_t, int, uint32_t);
+                         double, double, double, uint32_t, uint32_t, int, uint32_t, uint32_t);
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);

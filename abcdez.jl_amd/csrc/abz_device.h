@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "abcdez_spec.h"
+#include "abz_ctx.h"
 
 #define ABZ_BLOCK 256
 
@@ -53,6 +54,46 @@ __device__ inline void store_row(double* __restrict__ row, int j, const double (
   }
 }
 
+/* The read-mostly model tables (prior descriptors, data vector) are staged in LDS once per
+ * workgroup: every group of a block reads the same ld entries, so this turns ~10 dependent
+ * global loads per component into broadcast LDS reads and keeps them out of the VGPR budget. */
+template <int LD>
+struct ModelLds {
+  abz_prior_dim prior[LD];
+  double y[LD];
+};
+
+/* two phases so the global loads can be issued early (before the wave's dependent loads)
+ * and the LDS writes + barrier placed right before the first use */
+template <int SIM, int LD>
+struct ModelStage {
+  static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
+  static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
+  uint64_t w[NW];
+  double y;
+  __device__ inline void load(const HotModel& M) {
+    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      w[q] = t < W ? src[t] : 0ull;
+    }
+    y = 0.0;
+    if constexpr (SIM == ABZ_SIM_MVN) {
+      if ((int)threadIdx.x < LD && (int)threadIdx.x < M.d) y = M.data[threadIdx.x];
+    }
+  }
+  __device__ inline void store(ModelLds<LD>& s) const {
+    uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (t < W) dst[t] = w[q];
+    }
+    if ((int)threadIdx.x < LD) s.y[threadIdx.x] = y;
+  }
+};
+
 /* ---- canonical per-particle tree sum ------------------------------------------- */
 __device__ inline double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
@@ -80,36 +121,36 @@ __device__ inline double group_tree_sum(const double (&x)[C]) {
 
 /* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */
 template <int L, int C>
-__device__ inline double group_logprior(const abz_model* __restrict__ M, int j, const double (&p)[C], double (&pp)[C]) {
+__device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entries */, int j, const double (&p)[C],
+                                        double (&pp)[C]) {
   double lp[C];
 #pragma unroll
   for (int q = 0; q < C; ++q) {
-    const int k = Lay<L, C>::comp(j, q / 2, q & 1);
-    const abz_prior_dim* pd = &M->prior[k];
-    pp[q] = abz_push_p(pd, p[q]);
-    lp[q] = abz_prior_logpdf1(pd, pp[q]);
+    const abz_prior_dim* d = &pd[Lay<L, C>::comp(j, q / 2, q & 1)];
+    pp[q] = abz_push_p(d, p[q]);
+    lp[q] = abz_prior_logpdf1(d, pp[q]);
   }
   return group_tree_sum<L, C>(lp);
 }
 
 /* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
 template <int SIM, int L, int C>
-__device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const double (&th)[C],
+__device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C], const double* y /* LDS, ld */,
                                   uint32_t i, uint32_t epoch, uint32_t purpose) {
-  const uint64_t seed = M->seed;
+  const uint64_t seed = M.seed;
   if constexpr (SIM == ABZ_SIM_NORMAL1D) {
     double z0, z1;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
-    const double x = abz_fma(M->sim_p[0], z0, th[0]);
-    return __builtin_fabs(x - M->data[0]);
+    const double x = abz_fma(M.sim_p[0], z0, th[0]);
+    return __builtin_fabs(x - M.data[0]);
   } else if constexpr (SIM == ABZ_SIM_MVN) {
-    const double sg = M->sim_p[0];
-    const int d = M->d;
+    const double sg = M.sim_p[0];
+    const int d = M.d;
     double sq[C];
     if constexpr (C == 1) {
       double z0, z1;
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
-      const double e = abz_fma(sg, z0, th[0]) - M->data[0];
+      const double e = abz_fma(sg, z0, th[0]) - y[0];
       sq[0] = e * e;
     } else {
 #pragma unroll
@@ -121,7 +162,7 @@ __device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const 
           const int k = Lay<L, C>::comp(j, m, c);
           double v = 0.0;
           if (k < d) {
-            const double e = abz_fma(sg, z[c], th[2 * m + c]) - M->data[k];
+            const double e = abz_fma(sg, z[c], th[2 * m + c]) - y[k];
             v = e * e;
           }
           sq[2 * m + c] = v;
@@ -130,7 +171,7 @@ __device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const 
     }
     return abz_sqrt(group_tree_sum<L, C>(sq));
   } else if constexpr (SIM == ABZ_SIM_DIRAC) {
-    return __builtin_fabs((th[0] * th[0] + 1.0) - M->sim_p[0]);
+    return __builtin_fabs((th[0] * th[0] + 1.0) - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_QUAD2D) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
@@ -138,41 +179,41 @@ __device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const 
     const double a = (th[0] + n1 * 0.01) - th[1] * th[1];
     const double b = (th[1] - 1.0) + n2 * 0.01;
     const double r = 50.0 * (a * a) + b * b;
-    return (u < M->sim_p[0]) ? ABZ_INF : r;
+    return (u < M.sim_p[0]) ? ABZ_INF : r;
   } else if constexpr (SIM == ABZ_SIM_MIXTURE) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
     const uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
     const double x = th[0] + (coin ? n2 : n1 * 0.1);
-    return __builtin_fabs(x - M->sim_p[0]);
+    return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_NORMDU) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
     const double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
-    return __builtin_fabs(x - M->sim_p[0]);
+    return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_WIENER) {
     const double f = 0.95 + 0.1 * abz_u01_co(abz_rng(seed, i, epoch, 0, purpose).w0);
     double acc = 0.0;
-    const int n = M->n_data;
+    const int n = M.n_data;
     for (int t = 0; t < n; ++t) {
       const double dt = (double)t;
       const double v = abz_sqrt(th[0] * th[0] * dt * dt + th[1] * th[1] * dt) * f;
-      acc += __builtin_fabs(v - M->data[t]);
+      acc += __builtin_fabs(v - M.data[t]);
     }
     return acc / (double)n;
   } else if constexpr (SIM == ABZ_SIM_LV) {
     const double a = th[0], b = th[1], c = th[2], e = th[3];
-    double x = M->sim_p[0], y = M->sim_p[1];
-    const double h = M->sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
-    const int steps = (int)M->sim_p[3];
-    const double sn = M->sim_p[4];
-    const int nobs = M->n_data / 2;
+    double x = M.sim_p[0], y = M.sim_p[1];
+    const double h = M.sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
+    const int steps = (int)M.sim_p[3];
+    const double sn = M.sim_p[4];
+    const int nobs = M.n_data / 2;
     double acc = 0.0;
     for (int jo = 0; jo < nobs; ++jo) {
       double z0, z1;
       abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), &z0, &z1);
-      const double ex = abz_fma(sn, z0, x) - M->data[2 * jo];
-      const double ey = abz_fma(sn, z1, y) - M->data[2 * jo + 1];
+      const double ex = abz_fma(sn, z0, x) - M.data[2 * jo];
+      const double ey = abz_fma(sn, z1, y) - M.data[2 * jo + 1];
       acc = abz_fma(ex, ex, acc);
       acc = abz_fma(ey, ey, acc);
       if (jo + 1 == nobs) break;
@@ -191,6 +232,38 @@ __device__ inline double sim_dist(const abz_model* __restrict__ M, int j, const 
     return abz_sqrt(acc);
   } else {
     return ABZ_NAN;
+  }
+}
+
+/* ---- per-particle scalar draws of one sweep: donor ranks, gamma jitter, log(accept uniform).
+ * With L >= 4 lanes per particle the three Philox blocks are evaluated by lanes 0, 1, 2 of
+ * the group in ONE pass of the instruction stream (the purpose tag is the only difference),
+ * the Box-Muller radius of the jitter and the accept test share one log evaluation, and the
+ * results are broadcast inside the group.  Same values as the straightforward evaluation. */
+template <int L>
+__device__ inline void particle_draws(uint64_t seed, uint32_t i, uint32_t sweep, int j, uint32_t n_pool, uint32_t ri,
+                                      double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g,
+                                      double* log_u) {
+  if constexpr (L >= 4) {
+    const uint32_t purpose = j == 0 ? (uint32_t)ABZ_RNG_DONOR : (j == 1 ? (uint32_t)ABZ_RNG_JITTER : (uint32_t)ABZ_RNG_ACCEPT);
+    const abz_u64x2 w = abz_rng(seed, i, sweep, 0, purpose);
+    uint32_t a_, b_;
+    abz_donor_ranks(w, n_pool, ri, &a_, &b_);                 /* meaningful on lane 0 */
+    const double lg = abz_log_pn(abz_u01_open(w.w0));         /* lane 1: BM radius, lane 2: accept */
+    double sn, cs;
+    abz_sincos2pi(abz_u01_co(w.w1), &sn, &cs);
+    const double z0 = abz_sqrt(-2.0 * lg) * cs;               /* meaningful on lane 1 */
+    const double g_ = gamma0 * (1.0 + z0 * gsig);
+    *ra = __shfl(a_, 0, L);
+    *rb = __shfl(b_, 0, L);
+    *g = __shfl(g_, 1, L);
+    *log_u = __shfl(lg, 2, L);
+  } else {
+    abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), n_pool, ri, ra, rb);
+    double z0, z1;
+    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    *g = gamma0 * (1.0 + z0 * gsig);
+    *log_u = abz_log_pn(abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0));
   }
 }
 

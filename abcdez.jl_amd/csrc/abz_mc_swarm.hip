@@ -10,7 +10,7 @@
 #include "abz_dispatch.h"
 
 struct McSwarmArgs {
-  const abz_model* model;
+  HotModel hm;
   const uint32_t* order;
   const double* sorted_delta;
   const double* theta;
@@ -36,13 +36,20 @@ __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_
 template <int SIM, int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a) {
   constexpr int LD = L * C;
-  const abz_model* __restrict__ M = a.model;
+  const HotModel& M = a.hm;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
   const int j = (int)(gid % L);
   const bool active = grp < a.n_local;
   const uint32_t i = a.i0 + (active ? grp : 0u);
-  const uint64_t seed = M->seed;
+  const uint64_t seed = M.seed;
+  __shared__ ModelLds<LD> s_model;
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
+  __syncthreads();
 
   const double lpi = a.logpi[i];
   const double di = a.delta[i];
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C>(M, j, tp, pp);                   /* mc:41 */
+  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                     /* mc:41 */
   const double w_prior = lp - lpi;                                        /* mc:42 */
   const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
   double mn = w_prior < 0.0 ? w_prior : 0.0;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
   bool acc = false;
   double dp = di;
   if (simulate) {
-    dp = sim_dist<SIM, L, C>(M, j, pp, i, a.sweep, ABZ_RNG_SIM);          /* mc:45 */
+    dp = sim_dist<SIM, L, C>(M, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
     const double thr = eps > di ? eps : di;
     acc = dp <= thr;                                                      /* mc:54 */
   }
@@ -100,7 +107,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
                         uint32_t n_local, uint32_t sweep) {
   if (n_local == 0) return 0;
   McSwarmArgs a;
-  a.model = ctx->d_model; a.order = order; a.sorted_delta = sorted_delta;
+  a.hm = ctx->hot; a.order = order; a.sorted_delta = sorted_delta;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
   a.counters = ctx->d_scal;

@@ -12,6 +12,31 @@
 #include "abz_ctx.h"
 #include "abz_device.h"
 
+/* One global atomic per BLOCK (same-address atomics serialise at ~10 ns each; the first build
+ * issued one per wave and spent 0.3 ms per pass on them).                                    */
+__device__ inline unsigned long long block_sum_u64(unsigned long long v) {
+  __shared__ unsigned long long s_bs[ABZ_BLOCK / 64];
+  for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) s_bs[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = 0;
+  if (threadIdx.x == 0) for (int w = 0; w < ABZ_BLOCK / 64; ++w) t += s_bs[w];
+  return t;   /* valid on thread 0 */
+}
+__device__ inline void block_minmax_u64(unsigned long long& lo, unsigned long long& hi) {
+  __shared__ unsigned long long s_lo[ABZ_BLOCK / 64], s_hi[ABZ_BLOCK / 64];
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int w = 0; w < ABZ_BLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+}
+#define ABZ_REDUCE_GRID 512u
+
 /* ================================================================ tile-tree sum
  * The fixed summation tree of abcdez_spec.h.  One block = one tile of 2048.     */
 enum { LOAD_PLAIN = 0, LOAD_SQUARE = 1, LOAD_WPROD = 2, LOAD_NORMALISE = 3 };
@@ -73,8 +98,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
   }
   if constexpr (MODE == LOAD_NORMALISE) {
     /* alive count rides along (sum(alive), smc:352,357) */
-    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
-    if ((t & 63) == 0 && c) atomicAdd(a.n_alive, (unsigned long long)c);
+    const unsigned long long bc = block_sum_u64((unsigned long long)c);
+    if (t == 0 && bc) atomicAdd(a.n_alive, bc);
   }
   double s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
 #pragma unroll
@@ -285,12 +310,18 @@ __global__ __launch_bounds__(ABZ_BLOCK) void wfix_tile_sum_kernel(const double* 
     const uint32_t o = __shfl_xor(lp1, off, 64);
     lp1 = o > lp1 ? o : lp1;
   }
+  __shared__ uint32_t s_lp[4];
   if ((threadIdx.x & 63) == 0) {
     s_w[threadIdx.x >> 6] = s;
-    if (lp1) atomicMax(last_pos, (unsigned long long)lp1);
+    s_lp[threadIdx.x >> 6] = lp1;
   }
   __syncthreads();
-  if (threadIdx.x == 0) tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (threadIdx.x == 0) {
+    tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    uint32_t m = s_lp[0];
+    for (int w = 1; w < 4; ++w) m = s_lp[w] > m ? s_lp[w] : m;
+    if (m) atomicMax(last_pos, (unsigned long long)m);
+  }
 }
 
 __global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long* __restrict__ v, uint32_t n) {
@@ -464,11 +495,9 @@ __global__ __launch_bounds__(ABZ_BLOCK) void select_next_kernel(const double* __
       if (key > key0 && key < best) best = key;
     }
   }
-  for (int off = 32; off; off >>= 1) {
-    const unsigned long long o = __shfl_xor(best, off, 64);
-    best = o < best ? o : best;
-  }
-  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(&st[4], best);
+  unsigned long long dummy = 0;
+  block_minmax_u64(best, dummy);
+  if (threadIdx.x == 0 && best != ~0ull) atomicMin(&st[4], best);
 }
 
 int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
@@ -481,7 +510,7 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   ABZ_HIP_CHECK(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
   ABZ_HIP_CHECK(hipMemsetAsync(hist, 0, ABZ_SEL_BINS * 4, ctx->stream));
   unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > 2048) grid = 2048;
+  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
   const int widths[6] = {11, 11, 11, 11, 11, 9};
   int shift = 64;
   for (int p = 0; p < 6; ++p) {
@@ -523,12 +552,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void extrema_kernel(const double* __rest
     lo = key < lo ? key : lo;
     hi = key > hi ? key : hi;
   }
-  for (int off = 32; off; off >>= 1) {
-    const unsigned long long a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
-    lo = a < lo ? a : lo;
-    hi = b > hi ? b : hi;
-  }
-  if ((threadIdx.x & 63) == 0) { atomicMin(mn, lo); atomicMax(mx, hi); }
+  block_minmax_u64(lo, hi);
+  if (threadIdx.x == 0) { atomicMin(mn, lo); atomicMax(mx, hi); }
 }
 
 __global__ __launch_bounds__(ABZ_BLOCK) void count_gt_kernel(const double* __restrict__ delta, int64_t N, double thr,
@@ -536,8 +561,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void count_gt_kernel(const double* __res
   unsigned long long c = 0;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) c += delta[k] > thr;
-  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  c = block_sum_u64(c);
+  if (threadIdx.x == 0 && c) atomicAdd(out, c);
 }
 
 __global__ __launch_bounds__(ABZ_BLOCK) void count_alive_kernel(const uint8_t* __restrict__ alive, int64_t N,
@@ -545,14 +570,14 @@ __global__ __launch_bounds__(ABZ_BLOCK) void count_alive_kernel(const uint8_t* _
   unsigned long long c = 0;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) c += alive[k] != 0;
-  for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  c = block_sum_u64(c);
+  if (threadIdx.x == 0 && c) atomicAdd(out, c);
 }
 
 int abz_count_alive_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, int64_t* count) {
   ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_COUNT, 0, 8, ctx->stream));
   unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > 2048) grid = 2048;
+  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
   hipLaunchKernelGGL(count_alive_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N,
                      ctx->d_scal + ABZ_S_COUNT);
   ABZ_HIP_CHECK(hipGetLastError());
@@ -566,7 +591,7 @@ int abz_extrema_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo
   unsigned long long init[2] = {~0ull, 0ull};
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->d_scal + ABZ_S_MIN, init, 16, hipMemcpyHostToDevice, ctx->stream));
   unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > 2048) grid = 2048;
+  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
   hipLaunchKernelGGL(extrema_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, ctx->d_scal + ABZ_S_MIN,
                      ctx->d_scal + ABZ_S_MAX);
   ABZ_HIP_CHECK(hipGetLastError());
@@ -580,7 +605,7 @@ int abz_extrema_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo
 int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count) {
   ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_COUNT, 0, 8, ctx->stream));
   unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > 2048) grid = 2048;
+  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
   hipLaunchKernelGGL(count_gt_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, thr,
                      ctx->d_scal + ABZ_S_COUNT);
   ABZ_HIP_CHECK(hipGetLastError());

@@ -9,13 +9,16 @@
  * many particles are dead; dead rows are carried by copy_dead_kernel only when the
  * alive set has changed since the last sweep.
  *
- * HBM-bound (roofline: DESIGN.md): per update 3 rows of 8*ld bytes read (own row,
- * two donor rows) + 16 B state + 12 B indices, one row + 16 B written.
+ * HBM roofline: per update 3 rows of 8*ld bytes read (own row, two
+ * donor rows) + 16 B state + 12 B indices, one row + 16 B written.  Everything that
+ * does not depend on loaded data (prior descriptors, data vector, model scalars) is
+ * fetched before the first dependent load, so a wave waits on three memory round
+ * trips: alive_idx[rank] -> alive_idx[donor ranks] -> rows.
  */
 #include "abz_dispatch.h"
 
 struct SmcSwarmArgs {
-  const abz_model* model;
+  HotModel hm;
   const uint32_t* alive_idx;
   const uint32_t* arank;
   const double* theta;
@@ -27,53 +30,54 @@ struct SmcSwarmArgs {
   unsigned long long* counters; /* [ABZ_S_NACC], [ABZ_S_NSIM] */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
+  uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
 };
 
 template <int SIM, int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs a) {
   constexpr int LD = L * C;
-  const abz_model* __restrict__ M = a.model;
+  const HotModel& M = a.hm;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
   const int j = (int)(gid % L);
   const bool active = grp < a.n_work;
   const uint32_t ri = a.r_lo + (active ? grp : 0u);
-  const uint32_t i = a.alive_idx[ri];
-  const uint64_t seed = M->seed;
+  const uint32_t i = a.all_alive ? ri : a.alive_idx[ri];
 
-  /* donors a, b: uniform over alive \ {i} and alive \ {i, a}  (smc:119-126) */
-  uint32_t ra, rb;
-  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.n_alive, ri, &ra, &rb);
-  const uint32_t ia = a.alive_idx[ra], ib = a.alive_idx[rb];
+  __shared__ ModelLds<LD> s_model;
 
-  double ti[C], ta[C], tb[C];
+  /* own row + state */
+  double ti[C];
   load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
-  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
-  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
   const double lpi = a.logpi[i];
   const double dli = a.delta[i];
+  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
+  stage.load(M);
 
-  /* gamma = gamma0 (1 + randn gamma_sigma), one scalar for all components (smc:128) */
-  double z0, z1;
-  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
-  const double g = a.gamma0 * (1.0 + z0 * a.gsig);
+  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
+  uint32_t ra, rb;
+  double g, log_u;
+  particle_draws<L>(M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+  const uint32_t ia = a.all_alive ? ra : a.alive_idx[ra];
+  const uint32_t ib = a.all_alive ? rb : a.alive_idx[rb];
+  double ta[C], tb[C];
+  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
 
   double tp[C], pp[C];
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C>(M, j, tp, pp);           /* smc:134 */
+  stage.store(s_model);
+  __syncthreads();                                                /* model tables staged */
+  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   bool acc = false;
   double dp = dli;
   if (insupport) {
-    dp = sim_dist<SIM, L, C>(M, j, pp, i, a.sweep, ABZ_RNG_SIM);  /* smc:137 */
-    const double w = (lp - lpi) + (abz_kernel_logpdf(M->abck, a.eps, dp) - abz_kernel_logpdf(M->abck, a.eps, dli)); /* smc:140-141 */
-    acc = (0.0 <= w);
-    if (!acc) {                                                   /* smc:145 */
-      const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
-      acc = abz_log(u) < w;
-    }
+    dp = sim_dist<SIM, L, C>(M, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
+    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
   }
   if (active) {                                                   /* smc:146-150 + copies :337-340 */
     double to[C];
@@ -112,14 +116,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
 int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, uint32_t n_alive,
                          uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
-                         uint32_t i0, uint32_t n_local, int copy_dead, uint32_t sweep) {
+                         uint32_t i0, uint32_t n_local, int copy_dead, uint32_t sweep, uint32_t N_total) {
   SmcSwarmArgs a;
-  a.model = ctx->d_model; a.alive_idx = alive_idx; a.arank = arank;
+  a.hm = ctx->hot; a.alive_idx = alive_idx; a.arank = arank;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
   a.counters = ctx->d_scal;
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
+  a.all_alive = (N_total != 0 && n_alive == N_total) ? 1u : 0u;
   const int L = ctx->L, C = ctx->C;
   bool ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
     if (copy_dead && n_local > 0) {

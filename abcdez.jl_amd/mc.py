@@ -8,11 +8,10 @@ from __future__ import annotations
 
 import logging
 import math
-from types import SimpleNamespace
 
 from .model import ModelSpec
 from .priors import prior_length
-from .smc import _check, _make_engine
+from .smc import Result, _check, _make_engine
 
 log = logging.getLogger("abcdez_amd")
 
@@ -61,7 +60,7 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     if verbose:
         log.info("End: completion=%s converged=%s nsim=%d range_ϵ=%s", complete, conv, nsims, eng.extrema())
     res = eng.result()                                        # mc:166
-    out = SimpleNamespace(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=None)
+    out = Result(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=None)
     out.reached_eps = conv
     out.nsims, out.updates, out.complete = nsims, generations * nparticles, complete
     out.engine = eng

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 from .kernels import IndicatorStrict0toϵ, kernel_kind
-from .priors import PRIOR_PAD, Prior, prior_factors
+from .priors import PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
 from .simulators import DeviceSimulator
 
 MAX_D = 64
@@ -25,6 +25,8 @@ class PriorDim(C.Structure):
         ("p0", C.c_double),
         ("p1", C.c_double),
         ("c0", C.c_double),
+        ("c1", C.c_double),
+        ("reserved", C.c_double),
     ]
 
 
@@ -92,4 +94,5 @@ class ModelSpec:
                 fam, disc, p0, p1, c0 = PRIOR_PAD, 0, 0.0, 0.0, 0.0
             m.prior[k].family, m.prior[k].discrete = fam, disc
             m.prior[k].p0, m.prior[k].p1, m.prior[k].c0 = p0, p1, c0
+            m.prior[k].c1 = 1.0 / p1 if fam == PRIOR_NORMAL else 0.0
         return m

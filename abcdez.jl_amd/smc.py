@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import logging
 import math
+import unicodedata
 import warnings
 from types import SimpleNamespace
 
@@ -21,6 +22,18 @@ from .model import ModelSpec
 from .priors import prior_length
 
 log = logging.getLogger("abcdez_amd")
+
+
+class Result(SimpleNamespace):
+    """Result record with the reference's field names.  Python NFKC-normalises identifiers
+    (the reference's ``ϵ`` U+03F5 becomes ``ε`` U+03B5 in source code); string lookups such as
+    ``getattr(r, "ϵ")`` are normalised the same way so both spellings work."""
+
+    def __getattr__(self, name):
+        norm = unicodedata.normalize("NFKC", name)
+        if norm != name:
+            return getattr(self, norm)
+        raise AttributeError(name)
 
 
 def get_ess(Wns) -> float:
@@ -167,7 +180,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
         log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
 
     res = eng.result()                 # P is push_p-cast, smc:382
-    out = SimpleNamespace(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=None)
+    out = Result(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=None)
     out.eps = ϵ
     out.iters, out.nsims, out.updates = iters, nsims, updates
     out.engine = eng

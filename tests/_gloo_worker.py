@@ -1,0 +1,48 @@
+"""Worker for tests/test_distributed_gloo.py: one rank of a world_size-N gloo job.
+
+Runs the product's host drivers + PopulationEngine (sharding, per-sweep all-gathers,
+counter all-reduces) with the CPU oracle as the compute backend, and writes the result
+of rank 0 to <outdir>/result_<name>.npz."""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch.distributed as dist
+
+import abcdez_amd as A
+from oracle import oracle as O
+
+
+def cases():
+    return {
+        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, 2000),
+        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8), 2.5, 1024),
+        "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 600),
+    }
+
+
+def main():
+    outdir = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pg = dist.group.WORLD if world > 1 else None
+    for name, (prior, sim, eps, N) in cases().items():
+        r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=O.oracle_engine,
+                       process_group=pg)
+        m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=25, verbose=False, rng=22,
+                      engine=O.oracle_engine, process_group=pg)
+        res, mres = r.engine.result(), m.engine.result()
+        # every rank must hold the same full population after the all-gathers
+        np.savez(os.path.join(outdir, f"result_{name}_rank{rank}.npz"), theta=res["theta"], C=res["C"], Wns=res["Wns"],
+                 logZ=r.logZ, eps_hist=np.array(r.ϵs), nsims=r.nsims, iters=r.iters, mc_theta=mres["theta"],
+                 mc_C=mres["C"], mc_nsims=m.nsims, world=world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""Host-side contract of the drop-in: keyword validation and error behaviour of
+abcdesmc! / abcdemc! (src/abcdez_smc.jl:223-235, src/abcdez_mc.jl:107-110), defaults,
+result fields, and the C-ABI surface (library loads, exports every declared symbol, fails
+loudly without a GPU).  CPU only -- no compute call goes to the HIP library here."""
+import ctypes
+import inspect
+import math
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import abcdez_amd as A
+from abcdez_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRIOR, SIM = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0)
+
+
+def test_defaults_match_reference():
+    """src/abcdez_smc.jl:215-220, src/abcdez_mc.jl:102-104"""
+    p = inspect.signature(A.abcdesmc).parameters
+    want = dict(nparticles=100, α=0.95, δess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0, facc_stop=0.0,
+                facc_min=0.0, facc_tune=0.975, verbose=True, verboseout=True)
+    for k, v in want.items():
+        assert p[k].default == v, k
+    assert p["ABCk"].default is A.IndicatorStrict0toϵ
+    q = inspect.signature(A.abcdemc).parameters
+    assert q["nparticles"].default == 50 and q["generations"].default == 20
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(α=1.0), "α must be in 0 <= α < 1"),
+    (dict(α=-0.1), "α must be in 0 <= α < 1"),
+    (dict(δess=1.5), "δess must be in 0 <= δess <= 1"),
+    (dict(facc_stop=2.0), "facc_stop must be in"),
+    (dict(facc_min=-1.0), "facc_min must be in"),
+    (dict(facc_tune=1.1), "facc_tune must be in"),
+    (dict(Kmcmc=0), "Kmcmc must be at least 1"),
+    (dict(Kmcmc_min=-1.0), "Kmcmc_min must be in"),
+    (dict(nsims_max=0), "nsims_max must be at least 1"),
+    (dict(nparticles=5), "nparticles must be at least 6"),     # ceil(3*1/min(0.95, 0.5)) = 6, smc:234
+])
+def test_abcdesmc_rejects_bad_keywords(oracle, kw, msg):
+    with pytest.raises(ValueError, match=msg):
+        A.abcdesmc(PRIOR, SIM, 0.3, None, verbose=False, engine=oracle.oracle_engine, **kw)
+
+
+def test_abcdesmc_rejects_negative_eps_and_warns(oracle):
+    with pytest.raises(ValueError, match="ϵ_target must be non-negative"):
+        A.abcdesmc(PRIOR, SIM, -0.1, None, verbose=False, engine=oracle.oracle_engine)
+    with pytest.warns(UserWarning, match="Kmcmc_min should be larger than facc_min"):   # smc:232
+        A.abcdesmc(PRIOR, SIM, 0.3, None, verbose=False, engine=oracle.oracle_engine, Kmcmc_min=0.1, facc_min=0.2)
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(nparticles=4), "nparticles must be at least 5"),
+    (dict(generations=0), "generations must be at least 1"),
+])
+def test_abcdemc_rejects_bad_keywords(oracle, kw, msg):
+    with pytest.raises(ValueError, match=msg):
+        A.abcdemc(PRIOR, SIM, 0.3, None, verbose=False, engine=oracle.oracle_engine, **kw)
+    with pytest.raises(ValueError, match="ϵ_target must be non-negative"):
+        A.abcdemc(PRIOR, SIM, -1.0, None, verbose=False, engine=oracle.oracle_engine)
+
+
+def test_result_fields(oracle):
+    r = A.abcdesmc(PRIOR, SIM, 0.3, None, nparticles=200, verbose=False, engine=oracle.oracle_engine)
+    for f in ("P", "Wns", "C", "ϵ", "logZ", "blobs", "ϵs", "ranges_ϵ", "logZs", "esss", "faccs", "γ0s", "Kmcmcs"):
+        assert hasattr(r, f), f                                           # smc:388-393
+    assert r.P.shape == r.Wns.shape == r.C.shape == (200,)
+    assert r.ϵs[0] == math.inf and r.logZs[0] == 0.0 and r.faccs[0] == 1.0 and r.Kmcmcs[0] == 3      # smc:284-292
+    assert r.γ0s[0] == 2.38 / math.sqrt(2)                               # smc:280
+    assert abs(r.esss[0] - 200) < 1e-9
+    r2 = A.abcdesmc(PRIOR, SIM, 0.3, None, nparticles=200, verbose=False, verboseout=False, engine=oracle.oracle_engine)
+    assert not hasattr(r2, "ϵs") and r2.logZ == r.logZ
+    m = A.abcdemc(PRIOR, SIM, 0.3, None, nparticles=200, generations=5, verbose=False, engine=oracle.oracle_engine)
+    for f in ("P", "C", "reached_ϵ", "blobs"):
+        assert hasattr(m, f), f                                           # mc:171
+    f2 = A.abcdesmc(A.Factored(A.Normal(0, 1), A.Uniform(0, 1)), A.Quad2D(0.0), 5.0, None, nparticles=50, verbose=False,
+                    engine=oracle.oracle_engine)
+    assert f2.P.shape == (50, 2)
+
+
+def test_facc_tuning_and_stops(oracle):
+    r = A.abcdesmc(PRIOR, SIM, 0.3, None, nparticles=500, verbose=False, engine=oracle.oracle_engine, facc_min=0.9)
+    assert r.γ0s[-1] < r.γ0s[0]                                          # smc:320: γ0 *= facc_tune
+    r = A.abcdesmc(PRIOR, SIM, 0.0, None, nparticles=500, verbose=False, engine=oracle.oracle_engine, nsims_max=3000)
+    assert r.nsims >= 3000 and r.ϵ > 0.0                                 # smc:376: nsims_max stop
+    r = A.abcdesmc(PRIOR, SIM, 0.0, None, nparticles=500, verbose=False, engine=oracle.oracle_engine, facc_stop=0.5)
+    assert r.faccs[-1] < 0.5                                             # smc:376: facc_stop
+    r = A.abcdesmc(PRIOR, SIM, 0.3, None, nparticles=500, verbose=False, engine=oracle.oracle_engine, Kmcmc=5,
+                   Kmcmc_min=math.inf)
+    assert set(r.Kmcmcs) == {5}                                          # exactly Kmcmc sweeps (docstring smc:187-189)
+
+
+def test_non_device_simulator_is_rejected():
+    with pytest.raises(TypeError, match="DeviceSimulator"):
+        A.abcdesmc(PRIOR, lambda th, ve: (abs(th - 3), None), 0.3, None, verbose=False)
+    with pytest.raises(ValueError, match="length"):
+        A.ModelSpec(A.Factored(A.Normal(0, 1), A.Normal(0, 1)), A.Normal1D(3.0))
+    with pytest.raises(TypeError):
+        A.abcdesmc(PRIOR, SIM, 0.3, None, ABCk="indicator", verbose=False)
+
+
+# ------------------------------------------------------------------ the C-ABI library
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "abcdez_hip.h")).read()
+    return sorted(set(re.findall(r"ABCDEZ_API\s+[\w\s\*]*?\b(abcdez_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/abcdez_hip.h but not exported"
+    bound = set(_lib.PROTOTYPES) | set(_lib.OTHER_SYMBOLS)
+    assert set(names) - bound <= {"abcdez_tree_sum"} or set(names) <= bound | {"abcdez_tree_sum"}
+    assert _lib.load().abcdez_version() >= 100
+
+
+def test_header_cites_the_reference_for_every_entry_point():
+    text = open(os.path.join(ROOT, "include", "abcdez_hip.h")).read()
+    for ref in ("src/abcdez_init.jl:2-22", "src/abcdez_smc.jl:106-153", "src/abcdez_smc.jl:59-83",
+                "src/abcdez_smc.jl:15-56", "src/abcdez_smc.jl:85-104", "src/abcdez_smc.jl:301",
+                "src/abcdez_mc.jl:5-61", "src/abcdez_types.jl:20-23"):
+        assert ref in text, ref
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    """no CPU fallback: without a HIP device the default engine must raise, not compute"""
+    with pytest.raises(_lib.AbcdezError, match="no HIP device|no CPU fallback"):
+        A.abcdesmc(PRIOR, SIM, 0.3, None, nparticles=100, verbose=False)
+    with pytest.raises(_lib.AbcdezError):
+        A.abcdemc(PRIOR, SIM, 0.3, None, verbose=False)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "abcdez.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src and "oracle/" not in src.replace("the oracle/", ""), f

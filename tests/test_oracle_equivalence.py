@@ -1,0 +1,191 @@
+"""The oracle's two tiers agree: the *literal* restatements of the reference's sequential
+functions (ref_*) and the order-free *spec* formulations the GPU reproduces bit for bit
+(orc_*).  Exact where the formulation is exact, in law where only the consumption of
+random numbers differs.  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+from scipy import stats
+
+import abcdez_amd as A
+from abcdez_amd.model import ModelSpec
+
+
+def _weights(N, rng, frac_zero=0.4, equal=False):
+    w = np.ones(N) if equal else rng.random(N)
+    w[rng.random(N) < frac_zero] = 0.0
+    w[rng.integers(0, N)] = 1.0
+    return w / w.sum()
+
+
+@pytest.mark.parametrize("N", [1, 2, 5, 100, 1000, 4096, 50001])
+@pytest.mark.parametrize("equal", [False, True])
+def test_stratified_fixed_point_equals_sequential_fp_walk(oracle, N, equal):
+    """src/abcdez_smc.jl:15-56: the integer-cumsum pick equals the reference's sequential
+    floating-point walk fed with the same uniforms (a disagreement needs a stratum draw
+    within ~2^-40 of a cumulative-weight boundary)."""
+    rng = np.random.default_rng(N + equal)
+    L = oracle.lib()
+    w = _weights(N, rng, equal=equal)
+    for draw in range(3):
+        inds = np.zeros(N, dtype=np.uint32)
+        L.orc_wsample_stratified(77, w.ctypes.data, N, draw, inds.ctypes.data)
+        u = np.zeros(N)
+        L.orc_stratum_uniforms(77, N, draw, u.ctypes.data)
+        ref = np.zeros(N, dtype=np.int64)
+        L.ref_wsample_stratified(w.ctypes.data, N, u.ctypes.data, ref.ctypes.data)
+        assert np.array_equal(inds.astype(np.int64), ref)
+        # invariants implied by smc:45-54
+        assert (np.diff(ref) >= 0).all()
+        assert (w[ref] > 0).all()
+        counts = np.bincount(ref, minlength=N)
+        # a weight spanning l strata widths is hit by between floor(l)-1 and ceil(l)+1 stratum draws
+        # (SURVEY.md 8c-7 states {floor, ceil}; that is the systematic-resampling bound, not the stratified one)
+        assert (counts >= np.floor(N * w - 1e-9) - 1).all() and (counts <= np.ceil(N * w + 1e-9) + 1).all()
+        assert counts.sum() == N
+    if equal:
+        n_alive = int((w > 0).sum())
+        counts = np.bincount(ref, minlength=N)[w > 0]
+        assert counts.min() >= N // n_alive - 1 and counts.max() <= -(-N // n_alive) + 1
+
+
+def test_stratified_is_unbiased(oracle):
+    rng = np.random.default_rng(3)
+    N = 64
+    w = _weights(N, rng, frac_zero=0.3)
+    tot = np.zeros(N)
+    inds = np.zeros(N, dtype=np.uint32)
+    D = 4000
+    for draw in range(D):
+        oracle.lib().orc_wsample_stratified(5, w.ctypes.data, N, draw, inds.ctypes.data)
+        tot += np.bincount(inds, minlength=N)
+    assert np.max(np.abs(tot / D - N * w)) < 0.05
+
+
+@pytest.mark.parametrize("N", [1, 3, 2048, 2049, 100000])
+def test_tree_sum_and_ess(oracle, N):
+    rng = np.random.default_rng(N)
+    x = rng.random(N) * rng.choice([1e-8, 1.0, 1e8], N)
+    L = oracle.lib()
+    s = L.orc_tree_sum(x.ctypes.data, N)
+    assert abs(s - math.fsum(x)) <= 4e-16 * math.fsum(np.abs(x)) * max(1, math.log2(N + 1))
+    w = x / x.sum()
+    assert abs(L.orc_get_ess(w.ctypes.data, N) / L.ref_get_ess(w.ctypes.data, N) - 1) < 1e-13     # smc:8
+    # permutation inside a fixed tree is not required to be invariant; zero padding is exact
+    xp = np.concatenate([x, np.zeros(7)])
+    assert L.orc_tree_sum(xp.ctypes.data, N + 7) == s or N + 7 > 2048 >= N or (N % 2048) + 7 > 2048
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_reweight_spec_equals_literal(oracle, kind):
+    """src/abcdez_smc.jl:59-83 + :308-311"""
+    rng = np.random.default_rng(kind)
+    N = 5000
+    L = oracle.lib()
+    delta = rng.random(N) * 1.89          # alive particles lie inside the old kernel's support
+    alive0 = (rng.random(N) < 0.8).astype(np.uint8)
+    w0 = alive0 * rng.random(N)
+    w0 /= w0.sum()
+    a, wa = alive0.copy(), w0.copy()
+    wn, ess, na = C.c_double(), C.c_double(), C.c_int64()
+    L.orc_smc_reweight(kind, delta.ctypes.data, wa.ctypes.data, a.ctypes.data, N, 1.9, 1.2, C.byref(wn), C.byref(ess), C.byref(na))
+    b, wb, ws = alive0.copy(), w0.copy(), np.ones(N)
+    wn2 = C.c_double()
+    L.ref_smc_reweight(kind, delta.ctypes.data, ws.ctypes.data, wb.ctypes.data, b.ctypes.data, N, 1.9, 1.2, C.byref(wn2))
+    assert np.array_equal(a, b) and na.value == int(b.sum())
+    assert abs(wn.value / wn2.value - 1) < 1e-13
+    assert np.allclose(wa, wb, rtol=1e-13, atol=0)
+    assert abs(wa.sum() - 1) < 1e-12
+
+
+@pytest.mark.parametrize("N", [1, 2, 10, 1001])
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.95, 0.999])
+def test_quantile_is_julia_type7(oracle, N, p):
+    """Statistics.quantile default (type 7) == numpy's default 'linear' method."""
+    rng = np.random.default_rng(N)
+    d = rng.random(N)
+    alive = (rng.random(N) < 0.7).astype(np.uint8)
+    alive[0] = 1
+    a, b = C.c_double(), C.c_double()
+    q = oracle.lib().orc_quantile_alive(d.ctypes.data, alive.ctypes.data, N, p, C.byref(a), C.byref(b))
+    want = np.quantile(d[alive > 0], p)
+    assert abs(q - want) <= 4e-16 * max(1.0, abs(want))
+
+
+def test_logprior_tree_vs_left_to_right(oracle):
+    """priors.jl:40-46 sums left to right; the spec sums the same terms pairwise."""
+    prior = A.Factored(*[A.Normal(0.1 * k, 1 + 0.1 * k) for k in range(32)])
+    spec = ModelSpec(prior, A.MVNormal((1.0,) * 32))
+    rng = np.random.default_rng(0)
+    th = rng.normal(0, 2, (1000, 32))
+    m = oracle.OracleModel(spec)
+    a, b = np.zeros(1000), np.zeros(1000)
+    oracle.lib().orc_logprior(m.ptr, th.ctypes.data, 1000, 0, a.ctypes.data)
+    oracle.lib().orc_logprior(m.ptr, th.ctypes.data, 1000, 1, b.ctypes.data)
+    assert np.allclose(a, b, rtol=1e-14, atol=1e-13)
+    want = np.array([prior.logpdf(r) for r in th])
+    assert np.allclose(b, want, rtol=1e-13, atol=1e-12)
+
+
+def test_sweep_spec_equals_literal_in_law(oracle):
+    """abcdesmc_swarm! (smc:106-153): rank-skip donors + pairwise sums (spec) vs rejection
+    loops around O(N) wsample scans + left-to-right sums (literal): same acceptance rate and
+    same moments of the moved population, dead particles untouched in both."""
+    prior = A.Factored(*[A.Normal(0, 1)] * 4)
+    spec = ModelSpec(prior, A.MVNormal((1.0,) * 4), seed=9)
+    N = 20000
+    eng = oracle.oracle_engine(spec, N)
+    eng.init_population()
+    eng.reset_weights()
+    eps = eng.quantile_alive(0.6)
+    eng.smc_reweight(math.inf, eps)
+    eng.alive_compact()
+    th, lp, dl = (t.numpy().copy() for t in eng.state)
+    alive = eng.alive.numpy().copy()
+    g0 = 2.38 / math.sqrt(8)
+    L, m = oracle.lib(), oracle.OracleModel(spec)
+    acc = []
+    means = []
+    for tier in ("spec", "literal"):
+        nth, nlp, ndl = np.zeros_like(th), np.zeros_like(lp), np.zeros_like(dl)
+        nacc, nsim = C.c_int64(), C.c_int64()
+        if tier == "spec":
+            L.orc_smc_swarm(m.ptr, eng.alive_idx.data_ptr(), eng.arank.data_ptr(), eng.n_alive, th.ctypes.data,
+                            lp.ctypes.data, dl.ctypes.data, nth.ctypes.data, nlp.ctypes.data, ndl.ctypes.data, eps, g0,
+                            1e-5, 0, N, 0, C.byref(nacc), C.byref(nsim))
+        else:
+            L.ref_smc_swarm(m.ptr, alive.ctypes.data, N, th.ctypes.data, lp.ctypes.data, dl.ctypes.data,
+                            nth.ctypes.data, nlp.ctypes.data, ndl.ctypes.data, eps, g0, 1e-5, 0, C.byref(nacc),
+                            C.byref(nsim))
+        dead = alive == 0
+        assert np.array_equal(nth[dead], th[dead]) and np.array_equal(ndl[dead], dl[dead])    # smc:114
+        assert (ndl[~dead] < eps).all()                                                        # strict kernel
+        assert nsim.value == int((~dead).sum())          # Normal prior: every proposal is in support (smc:135-138)
+        acc.append(nacc.value / (~dead).sum())
+        means.append((nth[~dead].mean(0), nth[~dead].std(0)))
+    assert abs(acc[0] - acc[1]) < 0.02
+    assert np.allclose(means[0][0], means[1][0], atol=0.03) and np.allclose(means[0][1], means[1][1], atol=0.03)
+
+
+def test_literal_wsample_is_uniform_over_alive(oracle):
+    """wsample(rng, 1:N, alive) (smc:121): the O(N) cumulative scan returns the ceil(t)-th alive index."""
+    rng = np.random.default_rng(4)
+    N = 50
+    alive = (rng.random(N) < 0.5).astype(np.uint8)
+    alive[[3, 7, 20]] = 1
+    prior = A.Normal(0, 1)
+    spec = ModelSpec(prior, A.Normal1D(0.0), seed=1)
+    th = rng.normal(size=(N, 1)); lp = np.zeros(N); dl = np.full(N, 0.1)
+    # proposals: with eps = inf every alive particle moves to theta_i + gamma (theta_a - theta_b); recover (a, b)
+    # statistically: donors must be alive -> the moved values are combinations of alive rows only.
+    L, m = oracle.lib(), oracle.OracleModel(spec)
+    nth, nlp, ndl = np.zeros_like(th), np.zeros_like(lp), np.zeros_like(dl)
+    nacc, nsim = C.c_int64(), C.c_int64()
+    L.ref_smc_swarm(m.ptr, alive.ctypes.data, N, th.ctypes.data, lp.ctypes.data, dl.ctypes.data, nth.ctypes.data,
+                    nlp.ctypes.data, ndl.ctypes.data, math.inf, 1.0, 0.0, 0, C.byref(nacc), C.byref(nsim))
+    diffs = {round(float(th[a, 0] - th[b, 0]), 12) for a in np.flatnonzero(alive) for b in np.flatnonzero(alive) if a != b}
+    for i in np.flatnonzero(alive):
+        step = round(float(nth[i, 0] - th[i, 0]), 12)
+        assert step == 0.0 or step in diffs
