@@ -32,13 +32,13 @@ PROTOTYPES = {
     "abcdez_init": [_vp, _vp, _vp, _vp, _i64, _i64],
     "abcdez_alive_compact": [_vp, _vp, _i64, _vp, _vp, _pi64],
     "abcdez_smc_swarm": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64,
-                         _i64, _i64, C.c_int, _u32, _pi64, _pi64],
+                         _i64, _i64, C.c_int, _vp, _u32, _pi64, _pi64],
     "abcdez_smc_reweight": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64],
     "abcdez_get_ess": [_vp, _vp, _i64, _pf64],
     "abcdez_tree_sum": [_vp, _vp, _i64, _pf64],
     "abcdez_wsample_stratified": [_vp, _vp, _i64, _u32, _vp],
     "abcdez_smc_resample_gather": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _f64, _pf64, _pf64, _pf64],
+    "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _i64, _f64, _pf64, _pf64, _pf64],
     "abcdez_extrema": [_vp, _vp, _i64, _pf64, _pf64],
     "abcdez_count_gt": [_vp, _vp, _i64, _f64, _pi64],
     "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _vp, _vp],

@@ -20,6 +20,8 @@
 
 #include <stdint.h>
 
+#include "abcdez_tables.h"
+
 #if defined(__HIPCC__)
 #define ABZ_HD __host__ __device__ static inline
 #else
@@ -49,6 +51,12 @@ typedef struct { uint32_t v[4]; } abz_u32x4;
 #define ABZ_PHILOX_W0 0x9E3779B9u
 #define ABZ_PHILOX_W1 0xBB67AE85u
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ABZ_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)   /* one v_bitop3_b32 */
+#else
+#define ABZ_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
+
 ABZ_HD abz_u32x4 abz_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                    uint32_t k0, uint32_t k1) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -57,9 +65,9 @@ ABZ_HD abz_u32x4 abz_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
   for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)ABZ_PHILOX_M0 * c0;
     uint64_t p1 = (uint64_t)ABZ_PHILOX_M1 * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n0 = ABZ_XOR3((uint32_t)(p1 >> 32), c1, k0);
     uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n2 = ABZ_XOR3((uint32_t)(p0 >> 32), c3, k1);
     uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += ABZ_PHILOX_W0; k1 += ABZ_PHILOX_W1;
@@ -94,8 +102,13 @@ ABZ_HD abz_u64x2 abz_rng(uint64_t seed, uint32_t idx, uint32_t epoch, uint32_t s
   return o;
 }
 
-/* uniform in (0,1): (k+1/2) 2^-52, k = top 52 bits.  Never 0 or 1 -> log() finite. */
-ABZ_HD double abz_u01_open(uint64_t w) { return ((double)(w >> 12) + 0.5) * 0x1p-52; }
+/* uniform in (0,1): (k+1/2) 2^-52, k = top 52 bits.  Never 0 or 1 -> log() finite.
+ * Built as [1,2) mantissa fill minus (1 - 2^-53); the subtraction is exact.            */
+ABZ_HD double abz_u01_open(uint64_t w) {
+  return abz_u2d(0x3FF0000000000000ull | (w >> 12)) - 0x1.fffffffffffffp-1;
+}
+/* uniform in [0,1) with 52 bits: k 2^-52 (the Box-Muller angle) */
+ABZ_HD double abz_u01_52(uint64_t w) { return abz_u2d(0x3FF0000000000000ull | (w >> 12)) - 1.0; }
 /* uniform in [0,1): k 2^-53, k = top 53 bits (what Julia's rand() returns in law). */
 ABZ_HD double abz_u01_co(uint64_t w) { return (double)(w >> 11) * 0x1p-53; }
 
@@ -207,13 +220,77 @@ ABZ_HD void abz_sincos2pi(double u, double* sn, double* cs) {
   *cs = abz_u2d(abz_d2u(c0) ^ c_neg);
 }
 
+/* ------------------------------------------------------------------ table-driven log / sincos for the sampler
+ * (tables: abcdez_tables.h, generated by tools/gen_tables.py).  About half the instructions
+ * of the polynomial versions above; the sweep kernel is VALU-bound on exactly this code.   */
+static const abz_tables abz_tables_host = ABZ_TABLES_INIT;   /* host copy; kernels stage a device copy into LDS */
+
+/* log(x), x positive normal.  x = 2^k z, z in [~sqrt(1/2), ~sqrt(2)); interval i of z from the
+ * top 7 mantissa bits; r = z c_i - 1 (one fma), |r| < 3.9e-3; log z = T_i + log1p(r), Taylor to
+ * r^7.  <= 2 ulp (tests/test_spec_math.py).                                                 */
+ABZ_HD double abz_log_tab(double x, const abz_tables* T) {
+  const uint64_t ix = abz_d2u(x);
+  const uint64_t tmp = ix - ABZ_LOG_TAB_OFF;
+  const int k = (int)((int64_t)tmp >> 52);
+  const uint32_t i = (uint32_t)(tmp >> (52 - ABZ_LOG_TAB_BITS)) & (ABZ_LOG_TAB_N - 1);
+  const double z = abz_u2d(ix - (tmp & 0xFFF0000000000000ull));
+  const double* e = T->logt[i];
+  const double r = abz_fma(z, e[0], -1.0);
+  double p = 0x1.2492492492492p-3;            /*  1/7 */
+  p = abz_fma(p, r, -0x1.5555555555555p-3);   /* -1/6 */
+  p = abz_fma(p, r, 0x1.999999999999ap-3);    /*  1/5 */
+  p = abz_fma(p, r, -0.25);
+  p = abz_fma(p, r, 0x1.5555555555555p-2);    /*  1/3 */
+  p = abz_fma(p, r, -0.5);
+  const double dk = (double)k;
+  const double hi = abz_fma(dk, 6.93147180369123816490e-01, e[1]);
+  const double lo = abz_fma(dk, 1.90821492927058770002e-10, e[2]);
+  return hi + (lo + abz_fma(r * r, p, r));
+}
+
+/* sincos(2 pi u), u = k 2^-52 in [0,1).  j = round(256 u); delta = 2 pi (u - j/256), |delta| <=
+ * pi/256; Taylor to delta^7 / delta^6; rotate the table entry (sin, cos)(2 pi j / 256).     */
+ABZ_HD void abz_sincos2pi_tab(double u, const abz_tables* T, double* sn, double* cs) {
+  const double t = u * 256.0;
+  const double tr = (t + 0x1.8p52) - 0x1.8p52;          /* nearest integer, 0..256 */
+  const int j = (int)tr & (ABZ_SC_TAB_N - 1);
+  const double dl = (t - tr) * 0x1.921fb54442d18p-6;    /* 2 pi / 256 */
+  const double z = dl * dl;
+  const double ps = abz_fma(abz_fma(-0x1.a01a01a01a01ap-13, z, 0x1.1111111111111p-7), z, -0x1.5555555555555p-3);
+  const double pc = abz_fma(abz_fma(-0x1.6c16c16c16c17p-10, z, 0x1.5555555555555p-5), z, -0.5);
+  const double sd = abz_fma(dl * z, ps, dl);            /* sin(delta)     */
+  const double cm1 = z * pc;                            /* cos(delta) - 1 */
+  const double S = T->sc[j][0], C = T->sc[j][1];
+  *sn = S + abz_fma(S, cm1, C * sd);
+  *cs = C + abz_fma(-S, sd, C * cm1);
+}
+
+/* sqrt(x) for x in the normal range far from over/underflow (here: -2 log u in [2e-16, 74]).
+ * Device: v_rsq_f64 seed + the two Goldschmidt/Newton steps and two residual corrections the
+ * compiler's own correctly rounded expansion uses, minus its range scaling.  Host: sqrt().  */
+ABZ_HD double abz_sqrt_pn(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
 /* Box-Muller: one Philox block -> two independent N(0,1).  (randn, smc:128)       */
-ABZ_HD void abz_normal_pair(abz_u64x2 w, double* z0, double* z1) {
-  double u1 = abz_u01_open(w.w0);
-  double u2 = abz_u01_co(w.w1);
-  double r = abz_sqrt(-2.0 * abz_log_pn(u1));
+ABZ_HD void abz_normal_pair(abz_u64x2 w, const abz_tables* T, double* z0, double* z1) {
+  const double u1 = abz_u01_open(w.w0);
+  const double u2 = abz_u01_52(w.w1);
+  const double r = abz_sqrt_pn(-2.0 * abz_log_tab(u1, T));
   double sn, cs;
-  abz_sincos2pi(u2, &sn, &cs);
+  abz_sincos2pi_tab(u2, T, &sn, &cs);
   *z0 = r * cs;
   *z1 = r * sn;
 }

@@ -45,14 +45,26 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
   return 0;
 }
 
+int abz_cnt_reserve(abcdez_ctx* ctx, size_t nblocks) {
+  const size_t bytes = nblocks * 8;
+  if (bytes <= ctx->cnt_bytes) return 0;
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->cnt) ABZ_HIP_CHECK(hipFree(ctx->cnt));
+  ctx->cnt = nullptr; ctx->cnt_bytes = 0;
+  const size_t want = abz_align(bytes + bytes / 4, 1 << 16);
+  ABZ_HIP_CHECK(hipMalloc(&ctx->cnt, want));
+  ctx->cnt_bytes = want;
+  return 0;
+}
+
 static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
-/* default lane-group shape: up to 16 components per lane for the component-parallel
- * simulator (measured on MI355X at d = 32: 2 lanes x 16 comps runs 3.2x the rate of
- * 8 x 4 -- the per-particle scalar draws amortise over more components),
+/* default lane-group shape: 8 components (64 contiguous bytes) per lane for the
+ * component-parallel simulator -- measured best on MI355X at d = 32 (4 lanes
+ * x 8 comps 0.557 ms, 8 x 4 0.570, 2 x 16 0.625, 16 x 2 0.721 per 2.7 M-update sweep);
  * the whole row in one thread otherwise                                            */
 static void default_shape(const abz_model& m, int* L, int* C) {
-  if (m.sim_id == ABZ_SIM_MVN && m.ld > 16) { *C = 16; *L = m.ld / 16; }
+  if (m.sim_id == ABZ_SIM_MVN && m.ld > 8) { *C = 8; *L = m.ld / 8; }
   else { *L = 1; *C = m.ld; }
 }
 
@@ -102,6 +114,9 @@ int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
   ctx->h_model.data = ctx->d_data;
   ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
   ABZ_HIP_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
+  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_tables, sizeof(abz_tables)));
+  ABZ_HIP_CHECK(hipMemcpy(ctx->d_tables, &abz_tables_host, sizeof(abz_tables), hipMemcpyHostToDevice));
+  ctx->hot.tables = ctx->d_tables;
   ctx->hot.seed = model->seed;
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
@@ -120,10 +135,12 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->cnt) (void)hipFree(ctx->cnt);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->d_model) (void)hipFree(ctx->d_model);
   if (ctx->d_data) (void)hipFree(ctx->d_data);
+  if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   delete ctx;
   return 0;
 }
@@ -229,7 +246,7 @@ int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, in
 
 int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
                          int64_t* n_alive) {
-  ABZ_REQUIRE(ctx && alive && alive_idx && arank && n_alive, "alive_compact: null argument");
+  ABZ_REQUIRE(ctx && alive && alive_idx && arank, "alive_compact: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact: N out of range");
   return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive);
 }
@@ -237,7 +254,8 @@ int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint3
 int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive, int64_t r_lo,
                      int64_t r_hi, const double* theta, const double* logpi, const double* delta, double* ntheta,
                      double* nlogpi, double* ndelta, double eps, double gamma0, double gamma_sigma, int64_t i0,
-                     int64_t n_local, int copy_dead, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+                     int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep, int64_t* nacc,
+                     int64_t* nsim) {
   ABZ_REQUIRE(ctx && alive_idx && arank && theta && logpi && delta && ntheta && nlogpi && ndelta && nacc && nsim,
               "smc_swarm: null argument");
   /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
@@ -246,10 +264,9 @@ int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t*
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= ABZ_MAX_N, "smc_swarm: particle range out of bounds");
   ABZ_REQUIRE(r_hi - r_lo <= n_local, "smc_swarm: more alive ranks than particles in the range");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "smc_swarm: in/out arrays must differ (synchronous update)");
-  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NACC, 0, 16, ctx->stream));
   int rc = abz_launch_smc_swarm(ctx, alive_idx, arank, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, theta, logpi,
                                 delta, ntheta, nlogpi, ndelta, eps, gamma0, gamma_sigma, (uint32_t)i0,
-                                (uint32_t)n_local, copy_dead, sweep,
+                                (uint32_t)n_local, copy_dead, dead_synced, sweep,
                                 /* alive list is the identity iff every particle of a range starting at 0 is alive */
                                 (i0 == 0 && r_lo == 0 && r_hi == n_alive && n_alive == n_local) ? (uint32_t)n_alive : 0u);
   if (rc) return rc;
@@ -303,15 +320,17 @@ int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N,
                                     ntheta, nlogpi, ndelta, wns, alive);
 }
 
-int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double p, double* q,
-                          double* xj, double* xj1) {
+int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t n_alive_hint,
+                          double p, double* q, double* xj, double* xj1) {
   ABZ_REQUIRE(ctx && delta && alive && q, "quantile_alive: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "quantile_alive: N out of range");
   ABZ_REQUIRE(p >= 0.0 && p <= 1.0, "quantile_alive: p must be in [0, 1]");
-  int64_t n = 0, n_le;
+  int64_t n = n_alive_hint, n_le;
   double a, b;
-  int rc = abz_count_alive_impl(ctx, alive, N, &n);
+  int rc = 0;
+  if (n < 0) rc = abz_count_alive_impl(ctx, alive, N, &n);   /* the caller usually knows sum(alive) from the last reweight */
   if (rc) return rc;
+  ABZ_REQUIRE(n <= N, "quantile_alive: n_alive_hint exceeds N");
   ABZ_REQUIRE(n >= 1, "quantile_alive: no alive particles");
   /* Julia Statistics.quantile, type 7: h = (n-1) p + 1, j = clamp(floor(h), 1, n-1), g = h - j */
   const double h = (double)(n - 1) * p + 1.0;
@@ -355,7 +374,6 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
-  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NACC, 0, 16, ctx->stream));
   int rc = abz_launch_mc_swarm(ctx, order, sorted_delta, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
                                eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep);
   if (rc) return rc;
@@ -373,7 +391,7 @@ int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) 
 
 int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
   ABZ_REQUIRE(ctx && x && y, "math_eval: null argument");
-  ABZ_REQUIRE(fn >= 0 && fn <= 6 && (y2 || (fn != 2 && fn != 6)), "math_eval: bad function id / missing second array");
+  ABZ_REQUIRE(fn >= 0 && fn <= 9 && (y2 || (fn != 2 && fn != 6 && fn != 8)), "math_eval: bad function id / missing second array");
   return abz_math_eval_impl(ctx, fn, x, y, y2, n);
 }
 

@@ -17,6 +17,7 @@ struct HotModel {
   uint64_t seed;
   const abz_prior_dim* prior;   /* device, ld entries */
   const double* data;           /* device, n_data values */
+  const abz_tables* tables;     /* device copy of the sampler tables */
   double sim_p[8];
   int32_t d, abck, n_data, reserved;
 };
@@ -28,6 +29,7 @@ struct abcdez_ctx {
   abz_model h_model;              /* host copy; .data points at d_data          */
   abz_model* d_model = nullptr;
   double* d_data = nullptr;
+  abz_tables* d_tables = nullptr;
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
   /* device scalars + pinned host mirror */
   unsigned long long* d_scal = nullptr;   /* 32 x u64                           */
@@ -35,6 +37,9 @@ struct abcdez_ctx {
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  /* per-block (nacc, nsim) partials of the sweep kernels */
+  void* cnt = nullptr;
+  size_t cnt_bytes = 0;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
   bool timing = false, ev_pending = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -55,6 +60,7 @@ void abz_set_error(const std::string& msg);
 
 /* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
+int abz_cnt_reserve(abcdez_ctx* ctx, size_t nblocks);
 
 static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -70,12 +76,13 @@ enum {
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
                          const double*, const double*, const double*, double*, double*, double*,
-                         double, double, double, uint32_t, uint32_t, int, uint32_t, uint32_t);
+                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t);
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);
 int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,
                                const double*, const double*, double*, double*, double*, double*, uint8_t*);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
+int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, unsigned long long* d_out);
 
 #endif

@@ -59,6 +59,7 @@ __device__ inline void store_row(double* __restrict__ row, int j, const double (
  * global loads per component into broadcast LDS reads and keeps them out of the VGPR budget. */
 template <int LD>
 struct ModelLds {
+  abz_tables tab;              /* log / sincos tables of the sampler (8 KB) */
   abz_prior_dim prior[LD];
   double y[LD];
 };
@@ -69,9 +70,15 @@ template <int SIM, int LD>
 struct ModelStage {
   static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
   static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
+  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);   /* 16-byte pieces per thread */
+  static_assert(sizeof(abz_tables) % (16 * ABZ_BLOCK) == 0, "table size must tile the block");
   uint64_t w[NW];
+  double2 tb[NT];
   double y;
   __device__ inline void load(const HotModel& M) {
+    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
     const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -84,6 +91,9 @@ struct ModelStage {
     }
   }
   __device__ inline void store(ModelLds<LD>& s) const {
+    double2* tdst = reinterpret_cast<double2*>(&s.tab);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
     uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -135,12 +145,12 @@ __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entri
 
 /* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
 template <int SIM, int L, int C>
-__device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C], const double* y /* LDS, ld */,
-                                  uint32_t i, uint32_t epoch, uint32_t purpose) {
+__device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j, const double (&th)[C],
+                                  const double* y /* LDS, ld */, uint32_t i, uint32_t epoch, uint32_t purpose) {
   const uint64_t seed = M.seed;
   if constexpr (SIM == ABZ_SIM_NORMAL1D) {
     double z0, z1;
-    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
     const double x = abz_fma(M.sim_p[0], z0, th[0]);
     return __builtin_fabs(x - M.data[0]);
   } else if constexpr (SIM == ABZ_SIM_MVN) {
@@ -149,14 +159,14 @@ __device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C
     double sq[C];
     if constexpr (C == 1) {
       double z0, z1;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
       const double e = abz_fma(sg, z0, th[0]) - y[0];
       sq[0] = e * e;
     } else {
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) {
         double z[2];
-        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose), &z[0], &z[1]);
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose), T, &z[0], &z[1]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int k = Lay<L, C>::comp(j, m, c);
@@ -174,7 +184,7 @@ __device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C
     return __builtin_fabs((th[0] * th[0] + 1.0) - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_QUAD2D) {
     double n1, n2;
-    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
     const double u = abz_u01_co(abz_rng(seed, i, epoch, 1, purpose).w0);
     const double a = (th[0] + n1 * 0.01) - th[1] * th[1];
     const double b = (th[1] - 1.0) + n2 * 0.01;
@@ -182,13 +192,13 @@ __device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C
     return (u < M.sim_p[0]) ? ABZ_INF : r;
   } else if constexpr (SIM == ABZ_SIM_MIXTURE) {
     double n1, n2;
-    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
     const uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
     const double x = th[0] + (coin ? n2 : n1 * 0.1);
     return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_NORMDU) {
     double n1, n2;
-    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+    abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
     const double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
     return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_WIENER) {
@@ -211,7 +221,7 @@ __device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C
     double acc = 0.0;
     for (int jo = 0; jo < nobs; ++jo) {
       double z0, z1;
-      abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), &z0, &z1);
+      abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), T, &z0, &z1);
       const double ex = abz_fma(sn, z0, x) - M.data[2 * jo];
       const double ey = abz_fma(sn, z1, y) - M.data[2 * jo + 1];
       acc = abz_fma(ex, ex, acc);
@@ -241,7 +251,8 @@ __device__ inline double sim_dist(const HotModel& M, int j, const double (&th)[C
  * the Box-Muller radius of the jitter and the accept test share one log evaluation, and the
  * results are broadcast inside the group.  Same values as the straightforward evaluation. */
 template <int L>
-__device__ inline void particle_draws(uint64_t seed, uint32_t i, uint32_t sweep, int j, uint32_t n_pool, uint32_t ri,
+__device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32_t i, uint32_t sweep, int j,
+                                      uint32_t n_pool, uint32_t ri,
                                       double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g,
                                       double* log_u) {
   if constexpr (L >= 4) {
@@ -249,10 +260,10 @@ __device__ inline void particle_draws(uint64_t seed, uint32_t i, uint32_t sweep,
     const abz_u64x2 w = abz_rng(seed, i, sweep, 0, purpose);
     uint32_t a_, b_;
     abz_donor_ranks(w, n_pool, ri, &a_, &b_);                 /* meaningful on lane 0 */
-    const double lg = abz_log_pn(abz_u01_open(w.w0));         /* lane 1: BM radius, lane 2: accept */
+    const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
     double sn, cs;
-    abz_sincos2pi(abz_u01_co(w.w1), &sn, &cs);
-    const double z0 = abz_sqrt(-2.0 * lg) * cs;               /* meaningful on lane 1 */
+    abz_sincos2pi_tab(abz_u01_52(w.w1), T, &sn, &cs);
+    const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
     const double g_ = gamma0 * (1.0 + z0 * gsig);
     *ra = __shfl(a_, 0, L);
     *rb = __shfl(b_, 0, L);
@@ -261,27 +272,29 @@ __device__ inline void particle_draws(uint64_t seed, uint32_t i, uint32_t sweep,
   } else {
     abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), n_pool, ri, ra, rb);
     double z0, z1;
-    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), T, &z0, &z1);
     *g = gamma0 * (1.0 + z0 * gsig);
     *log_u = abz_log_pn(abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0));
   }
 }
 
-/* ---- block-level integer counters: wave ballot -> LDS -> one global atomic per block */
-__device__ inline void block_count2(bool f0, bool f1, unsigned long long* __restrict__ out) {
-  __shared__ unsigned int s_cnt[2];
-  if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
-  __syncthreads();
+/* ---- block-level integer counters: wave ballot -> LDS -> ONE plain store per block into a
+ * per-block partial array (no global atomics: 10^5 same-address atomics per launch were the
+ * bottleneck of the first build -- about 15 ns per block, 0.25 ms per lane of group width).
+ * abz_reduce_partials() sums the partials afterwards.                                        */
+__device__ inline void block_count2(bool f0, bool f1, uint2* __restrict__ partials) {
+  __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
   const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
   if ((threadIdx.x & 63) == 0) {
-    const unsigned int c0 = (unsigned int)__popcll(b0), c1 = (unsigned int)__popcll(b1);
-    if (c0) atomicAdd(&s_cnt[0], c0);
-    if (c1) atomicAdd(&s_cnt[1], c1);
+    s_cnt[0][threadIdx.x >> 6] = (unsigned int)__popcll(b0);
+    s_cnt[1][threadIdx.x >> 6] = (unsigned int)__popcll(b1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (s_cnt[0]) atomicAdd(&out[0], (unsigned long long)s_cnt[0]);
-    if (s_cnt[1]) atomicAdd(&out[1], (unsigned long long)s_cnt[1]);
+    uint2 v;
+    v.x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    v.y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    partials[blockIdx.x] = v;
   }
 }
 

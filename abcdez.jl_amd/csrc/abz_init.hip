@@ -36,14 +36,14 @@ __global__ __launch_bounds__(ABZ_BLOCK) void init_kernel(const HotModel M, doubl
     if constexpr (C == 1) {
       const abz_u64x2 w = abz_rng(seed, i, retry, 0, ABZ_RNG_INIT_PRIOR);
       double z0, z1;
-      abz_normal_pair(w, &z0, &z1);
+      abz_normal_pair(w, &s_model.tab, &z0, &z1);
       th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
     } else {
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) {
         const abz_u64x2 w = abz_rng(seed, i, retry, (uint32_t)(m * L + j), ABZ_RNG_INIT_PRIOR);
         double z0, z1;
-        abz_normal_pair(w, &z0, &z1);
+        abz_normal_pair(w, &s_model.tab, &z0, &z1);
         const int k = Lay<L, C>::comp(j, m, 0);
         th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
         th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void init_kernel(const HotModel M, doubl
     }
     lp = group_logprior<L, C>(pd, j, th, pp);
     dl = ABZ_NAN;
-    if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
+    if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
     if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
     if (++retry >= ABZ_MAX_RETRY) {
       if (j == 0) atomicAdd(bad, 1ull);

@@ -19,7 +19,7 @@ struct McSwarmArgs {
   double* ntheta;
   double* nlogpi;
   double* ndelta;
-  unsigned long long* counters;
+  uint2* partials;
   double eps_pop, eps_target, gamma0, gsig;
   uint32_t N, i0, n_local, sweep;
 };
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
   load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
 
   double z0, z1;
-  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
   const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
   double tp[C], pp[C];
 #pragma unroll
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
   const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
   double mn = w_prior < 0.0 ? w_prior : 0.0;
   if (abz_isnan(w_prior)) mn = w_prior;
-  const bool simulate = !(abz_log(u) > mn);                               /* mc:43 */
+  const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
   bool acc = false;
   double dp = di;
   if (simulate) {
-    dp = sim_dist<SIM, L, C>(M, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
+    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
     const double thr = eps > di ? eps : di;
     acc = dp <= thr;                                                      /* mc:54 */
   }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
       a.ndelta[i] = acc ? dp : di;
     }
   }
-  block_count2(false, active && j == 0 && simulate, a.counters + ABZ_S_NACC);
+  block_count2(false, active && j == 0 && simulate, a.partials);
 }
 
 int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, uint32_t N,
@@ -110,7 +110,9 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   a.hm = ctx->hot; a.order = order; a.sorted_delta = sorted_delta;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
-  a.counters = ctx->d_scal;
+  const unsigned nblocks = abz_grid((uint64_t)n_local * (uint64_t)ctx->L);
+  if (int rc = abz_cnt_reserve(ctx, nblocks)) return rc;
+  a.partials = (uint2*)ctx->cnt;
   a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
   bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
@@ -119,7 +121,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   });
   if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
 }
 
 /* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) ---- */

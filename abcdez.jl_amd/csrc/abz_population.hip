@@ -51,7 +51,7 @@ struct TileArgs {
   uint8_t* alive;
   double* wprod;          /* WPROD: output temp                                        */
   const double* wnorm;    /* NORMALISE: device scalar                                  */
-  unsigned long long* n_alive;
+  double* tile_alive;     /* NORMALISE: per-tile alive count (exact in f64)           */
   double eps_old, eps_new;
   int abck;
 };
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
   if constexpr (MODE == LOAD_NORMALISE) {
     /* alive count rides along (sum(alive), smc:352,357) */
     const unsigned long long bc = block_sum_u64((unsigned long long)c);
-    if (t == 0 && bc) atomicAdd(a.n_alive, bc);
+    if (t == 0) a.tile_alive[blockIdx.x] = (double)bc;
   }
   double s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
 #pragma unroll
@@ -168,10 +168,11 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
                       double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
   double *p0, *p1;
   char* rest;
-  int rc = partial_buffers(ctx, N, abz_align((size_t)N * 8), &p0, &p1, &rest);
+  const size_t ntile = (size_t)((N + ABZ_TILE - 1) / ABZ_TILE);
+  int rc = partial_buffers(ctx, N, abz_align((size_t)N * 8) + abz_align(ntile * 8), &p0, &p1, &rest);
   if (rc) return rc;
   double* wprod = (double*)rest;
-  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_NALIVE, 0, 8, ctx->stream));
+  double* tile_alive = (double*)(rest + abz_align((size_t)N * 8));
   TileArgs a{};
   a.n = N; a.delta = delta; a.wns = wns; a.alive = alive; a.wprod = wprod;
   a.eps_old = eps_old; a.eps_new = eps_new; a.abck = ctx->h_model.abck;
@@ -180,14 +181,18 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
   TileArgs b{};
   b.n = N; b.x = wprod; b.wns = wns; b.alive = alive;
   b.wnorm = (const double*)(ctx->d_scal + ABZ_S_WNORM);
-  b.n_alive = ctx->d_scal + ABZ_S_NALIVE;
+  b.tile_alive = tile_alive;
   rc = tree_sum_device<LOAD_NORMALISE>(ctx, b, (double*)(ctx->d_scal + ABZ_S_SUMSQ), p0, p1);
+  if (rc) return rc;
+  TileArgs c{};
+  c.x = tile_alive; c.n = (int64_t)ntile;      /* integers < 2^53: the f64 tree sum is exact */
+  rc = tree_sum_device<LOAD_PLAIN>(ctx, c, (double*)(ctx->d_scal + ABZ_S_NALIVE), p0, p1);
   if (rc) return rc;
   rc = read_scalars(ctx);
   if (rc) return rc;
   *wnorm = scal_f64(ctx, ABZ_S_WNORM);
   *ess = 1.0 / scal_f64(ctx, ABZ_S_SUMSQ);
-  *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
+  *n_alive = (int64_t)scal_f64(ctx, ABZ_S_NALIVE);
   return 0;
 }
 
@@ -279,6 +284,7 @@ int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t*
   hipLaunchKernelGGL(compact_scatter_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt, alive_idx,
                      arank);
   ABZ_HIP_CHECK(hipGetLastError());
+  if (!n_alive) return 0;            /* caller already knows sum(alive): stay asynchronous */
   rc = read_scalars(ctx);
   if (rc) return rc;
   *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
@@ -615,8 +621,30 @@ int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double th
   return 0;
 }
 
+/* ================================================================ per-block counter partials -> two u64 sums */
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const uint2* __restrict__ partials, uint32_t n,
+                                                               unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long s_a[16], s_b[16];
+  unsigned long long a = 0, b = 0;
+  for (uint32_t k = threadIdx.x; k < n; k += 1024) { const uint2 v = partials[k]; a += v.x; b += v.y; }
+  for (int off = 32; off; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0; b = 0;
+    for (int w = 0; w < 16; ++w) { a += s_a[w]; b += s_b[w]; }
+    out[0] = a; out[1] = b;
+  }
+}
+int abz_reduce_partials(abcdez_ctx* ctx, const void* partials, uint32_t nblocks, unsigned long long* d_out) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint2*)partials, nblocks, d_out);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 /* ================================================================ spec arithmetic on the device (test hook) */
-__global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const double* __restrict__ x, double* __restrict__ y,
+__global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_tables* __restrict__ T,
+                                                              const double* __restrict__ x, double* __restrict__ y,
                                                               double* __restrict__ y2, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -627,13 +655,16 @@ __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const doub
     case 3: y[i] = abz_rint(x[i]); break;
     case 4: y[i] = abz_floor(x[i]); break;
     case 5: y[i] = abz_sqrt(x[i]); break;
+    case 7: y[i] = abz_log_tab(x[i], T); break;
+    case 8: { double s, c; abz_sincos2pi_tab(x[i], T, &s, &c); y[i] = s; y2[i] = c; break; }
+    case 9: y[i] = abz_sqrt_pn(x[i]); break;
     default: y[i] = x[i] / y2[i]; break;
   }
 }
 int abz_math_eval_impl(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)((n + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
-                     ctx->stream, fn, x, y, y2, n);
+                     ctx->stream, fn, ctx->d_tables, x, y, y2, n);
   ABZ_HIP_CHECK(hipGetLastError());
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;

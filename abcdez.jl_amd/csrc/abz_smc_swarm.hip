@@ -27,7 +27,7 @@ struct SmcSwarmArgs {
   double* ntheta;
   double* nlogpi;
   double* ndelta;
-  unsigned long long* counters; /* [ABZ_S_NACC], [ABZ_S_NSIM] */
+  uint2* partials;              /* per-block (nacc, nsim) */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
   uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
@@ -55,9 +55,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs
   stage.load(M);
 
   /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged */
   uint32_t ra, rb;
   double g, log_u;
-  particle_draws<L>(M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+  particle_draws<L>(&s_model.tab, M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
   const uint32_t ia = a.all_alive ? ra : a.alive_idx[ra];
   const uint32_t ib = a.all_alive ? rb : a.alive_idx[rb];
   double ta[C], tb[C];
@@ -68,14 +70,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-  stage.store(s_model);
-  __syncthreads();                                                /* model tables staged */
   const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   bool acc = false;
   double dp = dli;
   if (insupport) {
-    dp = sim_dist<SIM, L, C>(M, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
     const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
     acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
   }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs
       a.ndelta[i] = acc ? dp : dli;
     }
   }
-  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.counters + ABZ_S_NACC);
+  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
 }
 
 /* dead rows of [i0, i0+n): carry generation t into generation t+1 (smc:337-340) */
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
                                                               const double* __restrict__ logpi,
                                                               const double* __restrict__ delta,
                                                               double* __restrict__ ntheta, double* __restrict__ nlogpi,
-                                                              double* __restrict__ ndelta, uint32_t i0, uint32_t n) {
+                                                              double* __restrict__ ndelta, uint32_t i0, uint32_t n,
+                                                              uint8_t* __restrict__ dead_synced) {
   constexpr int LD = L * C;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
   if (grp >= n) return;
   const uint32_t i = i0 + grp;
   if (arank[i] != ABZ_DEAD) return;
+  /* a dead row is carried once: after that both generations' arrays hold it and it never
+   * changes until the next resampling resets the flags */
+  if (dead_synced) {
+    if (dead_synced[i]) return;
+    if (j == 0) dead_synced[i] = 1;      /* read by the other lanes of the group only above, same wave */
+  }
   double t[C];
   load_row<L, C>(theta + (size_t)i * LD, j, t);
   store_row<L, C>(ntheta + (size_t)i * LD, j, t);
@@ -116,20 +123,24 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
 int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, uint32_t n_alive,
                          uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
-                         uint32_t i0, uint32_t n_local, int copy_dead, uint32_t sweep, uint32_t N_total) {
+                         uint32_t i0, uint32_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
+                         uint32_t N_total) {
   SmcSwarmArgs a;
   a.hm = ctx->hot; a.alive_idx = alive_idx; a.arank = arank;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
-  a.counters = ctx->d_scal;
+  const int L = ctx->L, C = ctx->C;
+  a.n_work = r_hi - r_lo;
+  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+  if (int rc = abz_cnt_reserve(ctx, nblocks ? nblocks : 1)) return rc;
+  a.partials = (uint2*)ctx->cnt;
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
   a.all_alive = (N_total != 0 && n_alive == N_total) ? 1u : 0u;
-  const int L = ctx->L, C = ctx->C;
   bool ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
     if (copy_dead && n_local > 0) {
       hipLaunchKernelGGL((copy_dead_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())), dim3(ABZ_BLOCK), 0,
-                         ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local);
+                         ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced);
     }
     if (a.n_work > 0) {
       if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
@@ -144,5 +155,5 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   });
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
 }

@@ -93,19 +93,23 @@ class HipOps:
     def init(self, theta, logpi, delta, i0, n):
         _lib.check(self.lib, self.lib.abcdez_init(self.ctx, _ptr(theta), _ptr(logpi), _ptr(delta), i0, n))
 
-    def alive_compact(self, alive, alive_idx, arank) -> int:
+    def alive_compact(self, alive, alive_idx, arank, n_known=None) -> int:
+        if n_known is not None:     # sum(alive) known from the reweight: no host sync
+            _lib.check(self.lib, self.lib.abcdez_alive_compact(self.ctx, _ptr(alive), alive.numel(), _ptr(alive_idx),
+                                                               _ptr(arank), None))
+            return n_known
         n = C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_alive_compact(self.ctx, _ptr(alive), alive.numel(), _ptr(alive_idx),
                                                            _ptr(arank), C.byref(n)))
         return n.value
 
     def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
-                  sweep):
+                  sweep, dead_synced=None):
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_swarm(
             self.ctx, _ptr(alive_idx), _ptr(arank), n_alive, r_lo, r_hi, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
-            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps, gamma0, gsig, i0, n_local, int(copy_dead), sweep,
-            C.byref(nacc), C.byref(nsim)))
+            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps, gamma0, gsig, i0, n_local, int(copy_dead),
+            _ptr(dead_synced), sweep, C.byref(nacc), C.byref(nsim)))
         return nacc.value, nsim.value
 
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
@@ -132,10 +136,10 @@ class HipOps:
             self.ctx, _ptr(inds), inds.numel(), i0, n_local, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
             _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), _ptr(wns), _ptr(alive)))
 
-    def quantile_alive(self, delta, alive, p):
+    def quantile_alive(self, delta, alive, p, n_alive=-1):
         q, a, b = C.c_double(), C.c_double(), C.c_double()
-        _lib.check(self.lib, self.lib.abcdez_quantile_alive(self.ctx, _ptr(delta), _ptr(alive), delta.numel(), p,
-                                                            C.byref(q), C.byref(a), C.byref(b)))
+        _lib.check(self.lib, self.lib.abcdez_quantile_alive(self.ctx, _ptr(delta), _ptr(alive), delta.numel(),
+                                                            n_alive, p, C.byref(q), C.byref(a), C.byref(b)))
         return q.value, a.value, b.value
 
     def extrema(self, delta):
@@ -207,6 +211,7 @@ class PopulationEngine:
         self.sorted_delta = None
         self.n_alive = N
         self.r_lo, self.r_hi = self.lo, self.hi
+        self.dead_synced = torch.zeros(N, dtype=torch.uint8, device=dev)   # dead rows already carried to both buffers
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
         self._dead_synced = True
@@ -253,10 +258,11 @@ class PopulationEngine:
         self.alive.fill_(1)
         self.n_alive = self.N
         self._dead_synced = True
+        self.dead_synced.zero_()
 
     # ------------------------------------------------------------------ S9, S10
     def quantile_alive(self, alpha: float) -> float:
-        return self.ops.quantile_alive(self.state[2], self.alive, alpha)[0]
+        return self.ops.quantile_alive(self.state[2], self.alive, alpha, self.n_alive)[0]
 
     def extrema(self):
         return self.ops.extrema(self.state[2])
@@ -286,11 +292,12 @@ class PopulationEngine:
         self._swap()
         self.n_alive = self.N
         self._dead_synced = True
+        self.dead_synced.zero_()
         self.last_inds = self.inds
 
     # ------------------------------------------------------------------ alive list + S2, S3
     def alive_compact(self) -> int:
-        n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank)
+        n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank, self.n_alive)
         self.n_alive = n
         if self.world == 1:
             self.r_lo, self.r_hi = 0, n
@@ -304,7 +311,8 @@ class PopulationEngine:
     def smc_swarm(self, eps: float, gamma0: float, gsig: float):
         copy_dead = (not self._dead_synced) and self.n_alive < self.N
         nacc, nsim = self.ops.smc_swarm(self.alive_idx, self.arank, self.n_alive, self.r_lo, self.r_hi, self.state,
-                                        self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep)
+                                        self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep,
+                                        self.dead_synced)
         self.sweep += 1
         self._dead_synced = True
         self._allgather_state(self.other)

@@ -64,7 +64,8 @@ ABCDEZ_API int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst_host, const void* sr
 ABCDEZ_API int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n);
 
 /* Alive list: the index set wsample(rng, 1:N, alive) draws from (src/abcdez_smc.jl:121,125).
- * alive_idx[r] = index of the r-th alive particle; arank[i] = rank of i or 0xFFFFFFFF. */
+ * alive_idx[r] = index of the r-th alive particle; arank[i] = rank of i or 0xFFFFFFFF.
+ * n_alive may be NULL (the caller knows sum(alive) from the reweight): then the call only enqueues. */
 ABCDEZ_API int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N,
                          uint32_t* alive_idx, uint32_t* arank, int64_t* n_alive);
 
@@ -72,7 +73,9 @@ ABCDEZ_API int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64
  *        eps_k_new, gamma0, gamma_sigma, nparticles, nsims, naccs, rng, ex, nblobs)
  *        src/abcdez_smc.jl:106-153 plus the identity. copies of :337-340.
  * Processes the alive particles of [i0, i0+n_local) = alive ranks [r_lo, r_hi).
- * copy_dead != 0 also carries the dead rows of the range into the n* arrays.
+ * copy_dead != 0 also carries the dead rows of the range into the n* arrays; with
+ * dead_synced != NULL (N flags, zeroed by the caller at start and after each resampling)
+ * every dead row is carried only once.
  * sweep = global sweep number (RNG epoch).  *nacc / *nsim = sums of the reference's
  * naccs[i] += 1 / nsims[i] += 1 over the range.                                      */
 ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,
@@ -80,7 +83,7 @@ ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, cons
                      const double* theta, const double* logpi, const double* delta,
                      double* ntheta, double* nlogpi, double* ndelta,
                      double eps, double gamma0, double gamma_sigma,
-                     int64_t i0, int64_t n_local, int copy_dead, uint32_t sweep,
+                     int64_t i0, int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
                      int64_t* nacc, int64_t* nsim);
 
 /* S5+S6  abcdesmc_update_ws!(ws, alive, Ds, eps_k, eps_k_new, nparticles) src/abcdez_smc.jl:59-83
@@ -102,7 +105,8 @@ ABCDEZ_API int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds,
 
 /* S9  quantile(Ds[alive], alpha)  src/abcdez_smc.jl:301 (Julia default, type 7).
  *     Also returns the two order statistics it interpolates.                         */
-ABCDEZ_API int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double p,
+ABCDEZ_API int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N,
+                          int64_t n_alive_hint /* sum(alive) if known, else -1 */, double p,
                           double* q, double* xj, double* xj1);
 
 /* S10  extrema(Ds) src/abcdez_smc.jl:286,364, src/abcdez_mc.jl:146,163;
@@ -125,7 +129,7 @@ ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const dou
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);
 
 /* Test hooks: evaluate the spec arithmetic on the device (fn: 0 log, 1 exp, 2 sincos2pi,
- * 3 rint, 4 floor, 5 sqrt, 6 x/y2) and one simulator call per row of `pushed`.       */
+ * 3 rint, 4 floor, 5 sqrt, 6 x/y2, 7 table log, 8 table sincos2pi, 9 sqrt_pn).       */
 ABCDEZ_API int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n);
 ABCDEZ_API int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out);
 

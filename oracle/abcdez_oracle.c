@@ -39,6 +39,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 #define ORC_MAX_RETRY 100000u
+#define ORC_T (&abz_tables_host)
 
 /* ---------------------------------------------------------------- thin exports of the spec math
  * (so the tests can pin them against mpmath / the published Philox vectors)        */
@@ -55,6 +56,9 @@ ORC_API void orc_math_eval(int fn, const double* x, double* y, double* y2, int64
       case 3: y[i] = abz_rint(x[i]); break;
       case 4: y[i] = abz_floor(x[i]); break;
       case 5: y[i] = abz_sqrt(x[i]); break;
+      case 7: y[i] = abz_log_tab(x[i], ORC_T); break;
+      case 8: abz_sincos2pi_tab(x[i], ORC_T, &y[i], &y2[i]); break;
+      case 9: y[i] = abz_sqrt_pn(x[i]); break;
       default: y[i] = x[i] / (y2 ? y2[i] : 1.0); break;
     }
   }
@@ -66,7 +70,7 @@ ORC_API void orc_rng_words(uint64_t seed, uint32_t idx, uint32_t epoch, uint32_t
 }
 ORC_API void orc_normal_pairs(uint64_t seed, uint32_t purpose, int64_t n, double* z) {
   for (int64_t i = 0; i < n; ++i) {
-    abz_normal_pair(abz_rng(seed, (uint32_t)i, 0, 0, purpose), &z[2 * i], &z[2 * i + 1]);
+    abz_normal_pair(abz_rng(seed, (uint32_t)i, 0, 0, purpose), ORC_T, &z[2 * i], &z[2 * i + 1]);
   }
 }
 ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_t ri, uint32_t* ra, uint32_t* rb) {
@@ -74,7 +78,7 @@ ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_
   abz_donor_ranks(w, n_alive, ri, ra, rb);
 }
 ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w, n); }
-ORC_API double orc_u01(uint64_t w, int open) { return open ? abz_u01_open(w) : abz_u01_co(w); }
+ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : (kind == 2 ? abz_u01_52(w) : abz_u01_co(w)); }
 ORC_API uint32_t orc_randint(uint64_t w, uint32_t n) { return abz_randint(w, n); }
 ORC_API double orc_prior_logpdf1(const abz_prior_dim* pd, double x) { return abz_prior_logpdf1(pd, x); }
 ORC_API double orc_kernel_pdf(int kind, double eps, double x) { return abz_kernel_pdf(kind, eps, x); }
@@ -114,7 +118,7 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
   switch (M->sim_id) {
     case ABZ_SIM_NORMAL1D: {
       double z0, z1;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &z0, &z1);
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &z0, &z1);
       double x = abz_fma(M->sim_p[0], z0, th[0]);
       return fabs(x - M->data[0]);
     }
@@ -122,7 +126,7 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       double sq[ABZ_MAX_D];
       for (int m = 0; 2 * m < M->ld; ++m) {
         double z[2];
-        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)m, purpose), &z[0], &z[1]);
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)m, purpose), ORC_T, &z[0], &z[1]);
         for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c) {
           int k = 2 * m + c;
           if (k < M->d) {
@@ -139,7 +143,7 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       return fabs((th[0] * th[0] + 1.0) - M->sim_p[0]);
     case ABZ_SIM_QUAD2D: {
       double n1, n2;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       double u = abz_u01_co(abz_rng(seed, i, epoch, 1, purpose).w0);
       if (u < M->sim_p[0]) return ABZ_INF;
       double a = (th[0] + n1 * 0.01) - th[1] * th[1];
@@ -148,14 +152,14 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
     }
     case ABZ_SIM_MIXTURE: {
       double n1, n2;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
       double x = th[0] + (coin ? n2 : n1 * 0.1);
       return fabs(x - M->sim_p[0]);
     }
     case ABZ_SIM_NORMDU: {
       double n1, n2;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), &n1, &n2);
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
       return fabs(x - M->sim_p[0]);
     }
@@ -179,7 +183,7 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       double acc = 0.0;
       for (int j = 0; j < nobs; ++j) {
         double z0, z1;
-        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)j, purpose), &z0, &z1);
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)j, purpose), ORC_T, &z0, &z1);
         double ex = abz_fma(sn, z0, x) - M->data[2 * j];
         double ey = abz_fma(sn, z1, y) - M->data[2 * j + 1];
         acc = abz_fma(ex, ex, acc);
@@ -213,7 +217,7 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
   for (int m = 0; 2 * m < M->ld; ++m) {
     abz_u64x2 w = abz_rng(M->seed, i, retry, (uint32_t)m, ABZ_RNG_INIT_PRIOR);
     double z0, z1;
-    abz_normal_pair(w, &z0, &z1);
+    abz_normal_pair(w, ORC_T, &z0, &z1);
     th[2 * m] = abz_prior_draw1(&M->prior[2 * m], w.w0, z0);
     if (2 * m + 1 < M->ld) th[2 * m + 1] = abz_prior_draw1(&M->prior[2 * m + 1], w.w1, z1);
   }
@@ -278,7 +282,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
     const double* ta = theta + (int64_t)alive_idx[ra] * ld;        /* smc:119-126 */
     const double* tb = theta + (int64_t)alive_idx[rb] * ld;
     double z0, z1;
-    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
     double g = gamma0 * (1.0 + z0 * gsig);                          /* smc:128 */
     double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
     for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
@@ -291,7 +295,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
     int acc = (0.0 <= w);
     if (!acc) {                                                     /* smc:145 */
       double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
-      acc = abz_log(u) < w;
+      acc = abz_log_tab(u, ORC_T) < w;
     }
     if (acc) {                                                      /* smc:146-150 */
       ndelta[i] = dp;
@@ -346,7 +350,7 @@ ORC_API void ref_smc_swarm(const abz_model* M, const uint8_t* alive, int64_t N,
     const double* ta = theta + a * ld;
     const double* tb = theta + b * ld;
     double z0, z1;
-    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
     double g = gamma0 * (1.0 + z0 * gsig);
     double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
     for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
@@ -609,7 +613,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const doubl
     const double* ta = theta + (int64_t)a * ld;
     const double* tb = theta + (int64_t)b * ld;
     double z0, z1;
-    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), &z0, &z1);
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
     double g = gamma0 * (1.0 + z0 * gsig);                              /* mc:34 */
     double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
     for (int k = 0; k < ld; ++k) tp[k] = ts[k] + (ta[k] - tb[k]) * g;
@@ -619,7 +623,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const doubl
     double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
     double mn = w_prior < 0.0 ? w_prior : 0.0;                          /* min(0, w_prior); NaN -> compares false below */
     if (abz_isnan(w_prior)) mn = w_prior;
-    if (abz_log(u) > mn) continue;                                      /* mc:43 */
+    if (abz_log_tab(u, ORC_T) > mn) continue;                                      /* mc:43 */
     nsim += 1;                                                          /* mc:44 */
     double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM);       /* mc:45 */
     double thr = eps > di ? eps : di;                                   /* max(eps, D_i) */

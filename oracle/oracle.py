@@ -152,11 +152,11 @@ class OracleOps:
         if rc:
             raise RuntimeError("oracle init: no finite (log-prior, distance) within the retry limit")
 
-    def alive_compact(self, alive, alive_idx, arank) -> int:
+    def alive_compact(self, alive, alive_idx, arank, n_known=None) -> int:
         return self.L.orc_alive_compact(_p(alive), alive.numel(), _p(alive_idx), _p(arank))
 
     def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
-                  sweep):
+                  sweep, dead_synced=None):
         nacc, nsim = _i64(), _i64()
         self.L.orc_smc_swarm(self.m.ptr, _p(alive_idx), _p(arank), n_alive, _p(cur[0]), _p(cur[1]), _p(cur[2]),
                              _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps, gamma0, gsig, i0, n_local, sweep,
@@ -182,7 +182,7 @@ class OracleOps:
         self.L.orc_smc_resample_gather(self.m.ptr, _p(inds), inds.numel(), i0, n_local, _p(cur[0]), _p(cur[1]),
                                        _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), _p(wns), _p(alive))
 
-    def quantile_alive(self, delta, alive, p):
+    def quantile_alive(self, delta, alive, p, n_alive=-1):
         a, b = _f64(), _f64()
         q = self.L.orc_quantile_alive(_p(delta), _p(alive), delta.numel(), p, C.byref(a), C.byref(b))
         return q, a.value, b.value

@@ -53,6 +53,7 @@ def assert_state_equal(hip, orc, what=""):
 # ---------------------------------------------------------------- spec arithmetic on the device
 @pytest.mark.parametrize("fn,gen", [
     (0, "pos"), (1, "exparg"), (2, "unit"), (3, "round"), (4, "round"), (5, "pos"), (6, "pair"),
+    (7, "posnormal"), (8, "unit52"), (9, "bmrange"),
 ])
 def test_math_bit_exact(oracle, fn, gen):
     rng = np.random.default_rng(100 + fn)
@@ -60,6 +61,16 @@ def test_math_bit_exact(oracle, fn, gen):
     if gen == "pos":
         x = np.exp(rng.uniform(-700, 700, n))
         x[:8] = [0.0, 1.0, 5e-324, 2.2250738585072014e-308, np.inf, 0.5, 2.0, 1.0 - 2 ** -53]
+    elif gen == "posnormal":
+        x = np.concatenate([np.exp(rng.uniform(-700, 700, n // 2)), (rng.integers(0, 1 << 52, n // 2) + 0.5) * 2.0 ** -52])
+        x[:6] = [1.0, 2.0 ** -53, 1 - 2.0 ** -53, 0.5, 2.2250738585072014e-308, 1.7e308]
+    elif gen == "unit52":
+        x = rng.integers(0, 1 << 52, n).astype(np.float64) * 2.0 ** -52
+        x[:4] = [0.0, 0.125, 0.5, 1 - 2.0 ** -52]
+    elif gen == "bmrange":
+        n = 1 << 24                       # sqrt_pn replaces the compiler's expansion: check it hard
+        x = np.exp(rng.uniform(-37.0, 4.4, n))     # -2 log u for u in [2^-53, 1)
+        x[:4] = [2.0 ** -52, 73.5, 1.0, 2.0]
     elif gen == "exparg":
         x = rng.uniform(-750, 710, n)
         x[:6] = [0.0, -np.inf, np.inf, -745.2, 709.8, 1e-300]
@@ -71,6 +82,7 @@ def test_math_bit_exact(oracle, fn, gen):
         x[:8] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.0, 4503599627370497.0]
     else:
         x = rng.normal(0, 1e3, n)
+    n = x.size
     y2in = rng.uniform(0.5, 3.0, n)
     spec = A.ModelSpec(A.Normal(0, 1), A.Normal1D(0.0), seed=1)
     ops = HipOps(spec)
@@ -82,8 +94,10 @@ def test_math_bit_exact(oracle, fn, gen):
     y2h = y2in.copy()
     oracle.lib().orc_math_eval(fn, x.ctypes.data, yh.ctypes.data, y2h.ctypes.data, n)
     assert np.array_equal(yd.cpu().numpy().view(np.int64), yh.view(np.int64))
-    if fn == 2:
+    if fn in (2, 8):
         assert np.array_equal(y2d.cpu().numpy().view(np.int64), y2h.view(np.int64))
+    if fn == 9:
+        assert np.array_equal(yh, np.sqrt(x))          # and both are the correctly rounded sqrt
 
 
 # ---------------------------------------------------------------- S1
@@ -157,7 +171,7 @@ def test_stratified_resample_parity(oracle, N):
 
 # ---------------------------------------------------------------- S2/S3 sweeps incl. dead particles
 @pytest.mark.parametrize("name,lanes", [
-    ("normal1d", 0), ("uniform1d", 0), ("mvn32", 0), ("mvn32", 4), ("mvn32", 16), ("mvn32", 2), ("mvn8", 0),
+    ("normal1d", 0), ("uniform1d", 0), ("mvn32", 0), ("mvn32", 4), ("mvn32", 16), ("mvn32", 8), ("mvn8", 0),
     ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0),
 ])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])

@@ -135,8 +135,53 @@ def test_rint_floor_sqrt_div(oracle):
     assert np.array_equal(eval_fn(oracle, 6, x, y2)[0], x / y2)
 
 
+def test_table_log_accuracy(oracle):
+    """abz_log_tab: the sampler's log on positive normal inputs (uniforms in [2^-53, 1))."""
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(0, 1, 3000), np.exp(rng.uniform(-36.7, 0, 2000)), 1 - np.exp(rng.uniform(-36, -1, 1500)),
+                        np.exp(rng.uniform(-700, 700, 500)),
+                        [2.0 ** -53, 1 - 2.0 ** -53, 0.5, 0.70710678118654746, 0.70710678118654757, 1.0, 2.0, 0.999, 1.001]])
+    y, _ = eval_fn(oracle, 7, x)
+    worst = max(ulp_err(b, mpmath.log(mpmath.mpf(float(a)))) for a, b in zip(x, y))
+    assert worst < 2.0, worst
+    assert eval_fn(oracle, 7, np.array([1.0]))[0][0] == 0.0
+    # agrees with the polynomial log to a couple of ulp everywhere in the sampler's domain
+    u = (rng.integers(0, 1 << 52, 200000).astype(np.float64) + 0.5) * 2.0 ** -52
+    a, _ = eval_fn(oracle, 7, u)
+    b, _ = eval_fn(oracle, 0, u)
+    assert np.max(np.abs(a - b) / np.spacing(np.abs(b))) <= 3
+
+
+def test_table_sincos_accuracy(oracle):
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(13)
+    u = np.concatenate([rng.integers(0, 1 << 52, 4000).astype(np.float64) * 2.0 ** -52,
+                        np.arange(0, 256) / 256.0, (np.arange(0, 256) + 0.5) / 256.0, [1 - 2.0 ** -52, 2.0 ** -52]])
+    s, c = eval_fn(oracle, 8, u)
+    worst = 0.0
+    for ui, si, ci in zip(u, s, c):
+        a = 2 * mpmath.pi * mpmath.mpf(float(ui))
+        worst = max(worst, float(abs(mpmath.mpf(float(si)) - mpmath.sin(a))), float(abs(mpmath.mpf(float(ci)) - mpmath.cos(a))))
+    assert worst < 2.3e-16, worst                     # absolute, i.e. ~1 ulp of values near 1
+    assert np.all(np.abs(s * s + c * c - 1) < 5e-16)
+    e = eval_fn(oracle, 8, np.array([0.0, 0.25, 0.5, 0.75]))
+    assert list(e[0]) == [0.0, 1.0, 0.0, -1.0] and list(e[1]) == [1.0, 0.0, -1.0, 0.0]
+
+
+def test_sqrt_pn_is_sqrt_on_host(oracle):
+    rng = np.random.default_rng(14)
+    x = np.exp(rng.uniform(-37, 5, 100000))
+    assert np.array_equal(eval_fn(oracle, 9, x)[0], np.sqrt(x))
+
+
 def test_uniform_conversions(oracle):
     L = oracle.lib()
+    assert L.orc_u01(0, 2) == 0.0 and L.orc_u01((1 << 64) - 1, 2) == 1 - 2.0 ** -52
+    rng = np.random.default_rng(15)
+    for w in (int(v) for v in rng.integers(0, 1 << 64, 2000, dtype=np.uint64)):
+        assert L.orc_u01(w, 1) == ((w >> 12) + 0.5) * 2.0 ** -52        # bit trick == the defining formula
+        assert L.orc_u01(w, 2) == (w >> 12) * 2.0 ** -52
     assert L.orc_u01(0, 1) == 2.0 ** -53 and L.orc_u01((1 << 64) - 1, 1) == 1 - 2.0 ** -53
     assert L.orc_u01(0, 0) == 0.0 and L.orc_u01((1 << 64) - 1, 0) == 1 - 2.0 ** -53
     assert L.orc_randint(0, 10) == 0 and L.orc_randint((1 << 64) - 1, 10) == 9
@@ -153,6 +198,7 @@ def test_normal_pairs_are_standard_normal(oracle):
     assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
     assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01          # the two outputs of a pair are independent
     assert np.abs(z).max() < 8.6                                   # sqrt(-2 log 2^-53)
+    assert stats.kstest(z[200000:400000] ** 2 + z[400000:600000] ** 2, 'chi2', args=(2,)).pvalue > 1e-3
 
 
 def test_donor_ranks_distinct_and_uniform(oracle):
