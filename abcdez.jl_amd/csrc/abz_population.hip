@@ -621,23 +621,34 @@ int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double th
   return 0;
 }
 
-/* ================================================================ per-block counter partials -> two u64 sums */
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const uint2* __restrict__ partials, uint32_t n,
-                                                               unsigned long long* __restrict__ out) {
-  __shared__ unsigned long long s_a[16], s_b[16];
+/* ================================================================ per-block counter partials -> two u64 sums
+ * 64 blocks, one atomic pair per block (64 adds per address: negligible).                    */
+__global__ __launch_bounds__(ABZ_BLOCK) void reduce_partials_kernel(const uint2* __restrict__ partials, uint32_t n,
+                                                                    unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long s_a[ABZ_BLOCK / 64], s_b[ABZ_BLOCK / 64];
   unsigned long long a = 0, b = 0;
-  for (uint32_t k = threadIdx.x; k < n; k += 1024) { const uint2 v = partials[k]; a += v.x; b += v.y; }
+  for (uint32_t k = blockIdx.x * ABZ_BLOCK + threadIdx.x; k < n; k += gridDim.x * ABZ_BLOCK) {
+    const uint2 v = partials[k];
+    a += v.x; b += v.y;
+  }
   for (int off = 32; off; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
   if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
   __syncthreads();
   if (threadIdx.x == 0) {
     a = 0; b = 0;
-    for (int w = 0; w < 16; ++w) { a += s_a[w]; b += s_b[w]; }
-    out[0] = a; out[1] = b;
+    for (int w = 0; w < ABZ_BLOCK / 64; ++w) { a += s_a[w]; b += s_b[w]; }
+    if (a) atomicAdd(&out[0], a);
+    if (b) atomicAdd(&out[1], b);
   }
 }
 int abz_reduce_partials(abcdez_ctx* ctx, const void* partials, uint32_t nblocks, unsigned long long* d_out) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint2*)partials, nblocks, d_out);
+  ABZ_HIP_CHECK(hipMemsetAsync(d_out, 0, 16, ctx->stream));
+  if (nblocks) {
+    unsigned grid = (nblocks + ABZ_BLOCK - 1) / ABZ_BLOCK;
+    if (grid > 64) grid = 64;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, (const uint2*)partials,
+                       nblocks, d_out);
+  }
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -28,6 +28,7 @@ struct SmcSwarmArgs {
   double* nlogpi;
   double* ndelta;
   uint2* partials;              /* per-block (nacc, nsim) */
+  uint8_t* row_synced;          /* per particle: both generations' theta rows are equal (may be NULL) */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
   uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
@@ -80,20 +81,28 @@ __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs
     acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
   }
   if (active) {                                                   /* smc:146-150 + copies :337-340 */
-    double to[C];
+    /* lazy copy: a rejected particle whose row is already identical in both generations'
+     * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
+    const bool synced = a.row_synced ? a.row_synced[i] != 0 : false;
+    if (acc || !synced) {
+      double to[C];
 #pragma unroll
-    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+      store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+    }
     if (j == 0) {
       a.nlogpi[i] = acc ? lp : lpi;
       a.ndelta[i] = acc ? dp : dli;
+      if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
     }
   }
   block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
 }
 
-/* dead rows of [i0, i0+n): carry generation t into generation t+1 (smc:337-340) */
-template <int L, int C>
+/* dead rows of [i0, i0+n): carry generation t into generation t+1 (smc:337-340).
+ * One thread per PARTICLE scans the flags (coalesced 4 + 1 bytes); the few rows that need
+ * carrying -- dead and not yet present in both generations' arrays -- are copied by that thread. */
+template <int LD>
 __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __restrict__ arank,
                                                               const double* __restrict__ theta,
                                                               const double* __restrict__ logpi,
@@ -101,23 +110,24 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
                                                               double* __restrict__ ntheta, double* __restrict__ nlogpi,
                                                               double* __restrict__ ndelta, uint32_t i0, uint32_t n,
                                                               uint8_t* __restrict__ dead_synced) {
-  constexpr int LD = L * C;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  if (grp >= n) return;
-  const uint32_t i = i0 + grp;
+  const uint32_t g = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (g >= n) return;
+  const uint32_t i = i0 + g;
   if (arank[i] != ABZ_DEAD) return;
-  /* a dead row is carried once: after that both generations' arrays hold it and it never
-   * changes until the next resampling resets the flags */
   if (dead_synced) {
     if (dead_synced[i]) return;
-    if (j == 0) dead_synced[i] = 1;      /* read by the other lanes of the group only above, same wave */
+    dead_synced[i] = 1;
   }
-  double t[C];
-  load_row<L, C>(theta + (size_t)i * LD, j, t);
-  store_row<L, C>(ntheta + (size_t)i * LD, j, t);
-  if (j == 0) { nlogpi[i] = logpi[i]; ndelta[i] = delta[i]; }
+  const double* __restrict__ src = theta + (size_t)i * LD;
+  double* __restrict__ dst = ntheta + (size_t)i * LD;
+  if constexpr (LD == 1) {
+    dst[0] = src[0];
+  } else {
+#pragma unroll 4
+    for (int k = 0; k < LD; k += 2) *reinterpret_cast<double2*>(dst + k) = *reinterpret_cast<const double2*>(src + k);
+  }
+  nlogpi[i] = logpi[i];
+  ndelta[i] = delta[i];
 }
 
 int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, uint32_t n_alive,
@@ -134,12 +144,13 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
   if (int rc = abz_cnt_reserve(ctx, nblocks ? nblocks : 1)) return rc;
   a.partials = (uint2*)ctx->cnt;
+  a.row_synced = dead_synced;
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
   a.all_alive = (N_total != 0 && n_alive == N_total) ? 1u : 0u;
   bool ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
     if (copy_dead && n_local > 0) {
-      hipLaunchKernelGGL((copy_dead_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())), dim3(ABZ_BLOCK), 0,
+      hipLaunchKernelGGL((copy_dead_kernel<LL() * CC()>), dim3(abz_grid((uint64_t)n_local)), dim3(ABZ_BLOCK), 0,
                          ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced);
     }
     if (a.n_work > 0) {

@@ -73,9 +73,10 @@ ABCDEZ_API int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64
  *        eps_k_new, gamma0, gamma_sigma, nparticles, nsims, naccs, rng, ex, nblobs)
  *        src/abcdez_smc.jl:106-153 plus the identity. copies of :337-340.
  * Processes the alive particles of [i0, i0+n_local) = alive ranks [r_lo, r_hi).
- * copy_dead != 0 also carries the dead rows of the range into the n* arrays; with
- * dead_synced != NULL (N flags, zeroed by the caller at start and after each resampling)
- * every dead row is carried only once.
+ * copy_dead != 0 also carries the dead rows of the range into the n* arrays.
+ * dead_synced (may be NULL) = N flags "theta[i] == ntheta[i]" maintained by the library and
+ * zeroed by the caller at start and after each resampling: with it a dead row is carried only
+ * once and a rejected particle whose row is already equal in both arrays is not rewritten.
  * sweep = global sweep number (RNG epoch).  *nacc / *nsim = sums of the reference's
  * naccs[i] += 1 / nsims[i] += 1 over the range.                                      */
 ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,

@@ -126,7 +126,36 @@ def spec_vectors():
     return out
 
 
+def lv_fixture():
+    """Lotka-Volterra observations for the on-device RK4 simulator (BASELINE.json configs[3]): theta* = (1, 0.4, 1, 0.3),
+    (x0, y0) = (1, 0.5), RK4 dt = 0.01, 100 steps between the 16 observation times t = 0..15, N(0, 0.1^2) noise, seed 4."""
+    a, b, c, e = 1.0, 0.4, 1.0, 0.3
+    x, y, dt, steps, nobs = 1.0, 0.5, 0.01, 100, 16
+
+    def f(x, y):
+        return x * (a - b * y), y * (e * x - c)
+
+    clean = []
+    for j in range(nobs):
+        clean += [x, y]
+        if j + 1 == nobs:
+            break
+        for _ in range(steps):
+            k1 = f(x, y)
+            k2 = f(x + 0.5 * dt * k1[0], y + 0.5 * dt * k1[1])
+            k3 = f(x + 0.5 * dt * k2[0], y + 0.5 * dt * k2[1])
+            k4 = f(x + dt * k3[0], y + dt * k3[1])
+            x += dt / 6 * (k1[0] + 2 * k2[0] + 2 * k3[0] + k4[0])
+            y += dt / 6 * (k1[1] + 2 * k2[1] + 2 * k3[1] + k4[1])
+    clean = np.array(clean)
+    obs = clean + np.random.default_rng(4).normal(0, 0.1, clean.size)
+    return dict(theta_star=[a, b, c, e], x0=1.0, y0=0.5, dt=dt, steps_per_obs=steps, noise=0.1, seed=4,
+                obs=[float(v) for v in obs], clean=[float(v) for v in clean])
+
+
 def main():
+    with open(os.path.join(HERE, "lv_data.json"), "w") as f:
+        json.dump(lv_fixture(), f, indent=1)
     ref = dict(kernel_truth_table=kernel_truth_table(), analytic=analytic(), factored=factored_cases(),
                push_p=push_cases())
     with open(os.path.join(HERE, "reference_known_answers.json"), "w") as f:

@@ -1,0 +1,269 @@
+"""GPU tests at BASELINE.json's full sizes (where the oracle cannot replay the whole
+population in seconds): size-independent properties + bit-exact spot checks of particle
+ranges against the oracle, plus the remaining simulators (Lotka-Volterra RK4, Wiener) and
+the committed spec vectors."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import abcdez_amd as A
+from abcdez_amd.engine import HipOps, PopulationEngine
+
+pytestmark = pytest.mark.gpu
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def checksum(t: torch.Tensor) -> int:
+    """order-independent 64-bit checksum of the raw bits"""
+    v = t.contiguous().view(torch.uint8).view(-1)
+    pad = (-v.numel()) % 8
+    if pad:
+        v = torch.cat([v, torch.zeros(pad, dtype=torch.uint8, device=v.device)])
+    return int(v.view(torch.int64).sum().item())
+
+
+def lv_model():
+    g = json.load(open(os.path.join(GOLD_DIR, "lv_data.json")))
+    prior = A.Factored(*[A.Uniform(0.0, 2.0)] * 4)
+    sim = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=0.05, steps_per_obs=20, noise=g["noise"])
+    return prior, sim
+
+
+def wiener_model():
+    t = np.arange(31.0)
+    tdata = np.sqrt(0.25 * t * t + 4.0 * t)
+    return A.Factored(A.Uniform(0, 1), A.Uniform(0, 4)), A.WienerRMS(tuple(tdata))
+
+
+@pytest.mark.parametrize("which", ["lv", "wiener"])
+def test_remaining_simulators_parity(oracle, which):
+    prior, sim = lv_model() if which == "lv" else wiener_model()
+    N = 3000
+    spec = A.ModelSpec(prior, sim, seed=17)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec))
+    orc = oracle.oracle_engine(spec, N)
+    hip.init_population(); orc.init_population()
+    for k in range(3):
+        assert torch.equal(hip.state[k].cpu().view(torch.int64), orc.state[k].view(torch.int64))
+    assert torch.isfinite(hip.state[2]).all()           # LV blow-ups (Inf/NaN distances) were redrawn, init.jl:14
+    hip.reset_weights(); orc.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps_old = math.inf
+    for gen in range(3):
+        eps = orc.quantile_alive(0.7)
+        assert hip.quantile_alive(0.7) == eps
+        assert hip.smc_reweight(eps_old, eps) == orc.smc_reweight(eps_old, eps)
+        hip.alive_compact(); orc.alive_compact()
+        for _ in range(2):
+            assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5)
+            for k in range(3):
+                assert torch.equal(hip.state[k].cpu().view(torch.int64), orc.state[k].view(torch.int64))
+        eps_old = eps
+    # abcdemc path on the same model
+    hip.mc_rank_prepare(); orc.mc_rank_prepare()
+    lo, _ = orc.extrema()
+    assert hip.mc_swarm(lo, 0.0, g0, 1e-5) == orc.mc_swarm(lo, 0.0, g0, 1e-5)
+    assert torch.equal(hip.state[0].cpu().view(torch.int64), orc.state[0].view(torch.int64))
+
+
+def test_lotka_volterra_end_to_end(oracle):
+    """BASELINE.json configs[3] at a size the oracle replays: full driver, bit for bit, and the posterior
+    concentrates near theta* = (1, 0.4, 1, 0.3)."""
+    prior, sim = lv_model()
+    N, eps = 4096, 1.2
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=5, nsims_max=10 ** 9)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=5), N, eps, nsims_max=10 ** 9)
+    res = r.engine.result()
+    assert r.logZ == c["logZ"] and np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["alive"], c["alive"])
+    post = r.P[r.Wns > 0]
+    assert np.all(np.abs(post.mean(0) - np.array([1.0, 0.4, 1.0, 0.3])) < 0.1)
+
+
+def test_spec_vectors_on_gpu():
+    """the committed oracle vectors (tests/golden/spec_vectors.json) reproduced by the HIP path"""
+    gold = json.load(open(os.path.join(GOLD_DIR, "spec_vectors.json")))["abcdesmc_runs"]
+    cases = {
+        "normal1d_N2000": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), A.IndicatorStrict0toϵ),
+        "mvn8_N2048": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8), A.IndicatorStrict0toϵ),
+        "mvn32_N4096": (A.Factored(*[A.Normal(0, 1)] * 32), A.MVNormal((1.0,) * 32), A.IndicatorStrict0toϵ),
+        "normal1d_epa_N2000": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), A.Epa0toϵ),
+    }
+    for name, (prior, sim, K) in cases.items():
+        g = gold[name]
+        r = A.abcdesmc(prior, sim, g["eps_target"], None, nparticles=g["N"], ABCk=K, verbose=False, rng=g["seed"],
+                       nsims_max=10 ** 9)
+        assert r.logZ == float.fromhex(g["logZ"]), name
+        assert r.iters == g["iters"] and r.nsims == g["nsims"]
+        assert [float(v) for v in r.ϵs] == [float.fromhex(v) for v in g["eps_hist"]]
+        res = r.engine.result()
+        assert int(res["alive"].sum()) == g["n_alive"]
+        assert float(np.sum(res["theta"][res["alive"]])) == float.fromhex(g["theta_sum"])
+        assert float(np.sum(res["C"])) == float.fromhex(g["delta_sum"])
+
+
+class Loop:
+    """generation loop of smc:295-377 with hooks for the property checks"""
+
+    def __init__(self, eng, d, eps_target):
+        self.e, self.eps, self.eps_k, self.eps_target = eng, math.inf, math.inf, eps_target
+        self.g0 = 2.38 / math.sqrt(2 * d)
+        self.logZ = 0.0
+
+    def generation(self, check):
+        e = self.e
+        q = e.quantile_alive(0.95)
+        eps = max(min(q, self.eps), self.eps_target)
+        assert eps <= self.eps                                           # eps sequence non-increasing (smc:301)
+        wnorm, ess, n_alive = e.smc_reweight(self.eps_k, eps)
+        assert 0 < wnorm <= 1.0 + 1e-12                                   # indicator kernel: fraction surviving
+        self.logZ += math.log(wnorm)
+        if ess < e.N * 0.5:
+            w_before = e.wns.clone()
+            e.smc_resample()
+            n_alive = e.N
+            check.resample(e, w_before)
+        e.alive_compact()
+        check.compaction(e, n_alive)
+        for _ in range(3):
+            before = [t.clone() for t in e.state] if check.deep else None
+            nacc, nsim = e.smc_swarm(eps, self.g0, 1e-5)
+            check.sweep(e, eps, before, nacc, nsim, n_alive)
+        self.eps, self.eps_k = eps, eps
+
+
+class Checks:
+    def __init__(self, oracle, spec, deep=False):
+        self.oracle, self.spec, self.deep = oracle, spec, deep
+
+    def compaction(self, e, n_alive):
+        idx = e.alive_idx[:n_alive].to(torch.int64)
+        assert int(e.alive.sum().item()) == n_alive
+        assert bool((idx[1:] > idx[:-1]).all())                          # sorted, unique
+        assert bool(e.alive[idx].all())
+        assert bool((e.arank[idx].to(torch.int64) == torch.arange(n_alive, device=idx.device)).all())
+
+    def resample(self, e, w_before):
+        inds = e.inds.to(torch.int64)
+        assert bool((inds[1:] >= inds[:-1]).all())                       # smc:45-54
+        assert bool((w_before[inds] > 0).all())                          # zero weights never chosen
+        assert bool(e.alive.all()) and float(e.wns[0]) == 1.0 / e.N
+
+    def sweep(self, e, eps, before, nacc, nsim, n_alive):
+        assert 0 <= nacc <= nsim <= n_alive
+        alive = e.alive.bool()
+        assert bool((e.state[2][alive] < eps).all())                     # strict indicator support (types:46)
+        assert torch.isfinite(e.state[1][alive]).all()
+        if before is not None:
+            dead = ~alive
+            for k in range(3):
+                assert torch.equal(before[k][dead], e.state[k][dead])    # smc:114: dead particles untouched
+            moved = (before[2] != e.state[2]) & alive
+            assert abs(int(moved.sum().item()) - nacc) <= 2              # accepted <=> distance replaced (ties aside)
+
+
+def test_config3_full_size_properties_and_oracle_spot_checks(oracle):
+    """BASELINE.json configs[2]: d = 32 MVN, N = 2^22.  Properties on the whole population every generation;
+    bit-exact comparison of three 8192-particle ranges of one sweep against the oracle; identical checksums
+    for two lane-group shapes and for a repeated run."""
+    d, N = 32, 1 << 22
+    prior = A.Factored(*[A.Normal(0, 1)] * d)
+    sim = A.MVNormal((1.0,) * d)
+    spec = A.ModelSpec(prior, sim, seed=1)
+    sums = []
+    for lanes, deep in ((0, True), (8, False), (0, False)):
+        eng = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes))
+        eng.init_population()
+        eng.reset_weights()
+        loop = Loop(eng, d, 6.0)
+        chk = Checks(oracle, spec, deep=deep)
+        for gen in range(4 if deep else 16):
+            loop.generation(chk)
+        if deep:
+            # one more sweep, replayed for three ranges by the oracle from the same full input state
+            eps = loop.eps
+            th, lp, dl = (t.cpu().contiguous() for t in eng.state)
+            aidx, arank = eng.alive_idx.cpu().contiguous(), eng.arank.cpu().contiguous()
+            n_alive, sweep = eng.n_alive, eng.sweep
+            eng.smc_swarm(eps, loop.g0, 1e-5)
+            nth, nlp, ndl = torch.zeros_like(th), torch.zeros_like(lp), torch.zeros_like(dl)
+            m = oracle.OracleModel(spec)
+            for i0 in (0, N // 2 - 4096, N - 8192):
+                nacc, nsim = C.c_int64(), C.c_int64()
+                oracle.lib().orc_smc_swarm(m.ptr, aidx.data_ptr(), arank.data_ptr(), n_alive, th.data_ptr(),
+                                           lp.data_ptr(), dl.data_ptr(), nth.data_ptr(), nlp.data_ptr(),
+                                           ndl.data_ptr(), eps, loop.g0, 1e-5, i0, 8192, sweep, C.byref(nacc),
+                                           C.byref(nsim))
+                sl = slice(i0, i0 + 8192)
+                got = [t[sl].cpu() for t in eng.state]
+                assert torch.equal(got[0].view(torch.int64), nth[sl].view(torch.int64))
+                assert torch.equal(got[1].view(torch.int64), nlp[sl].view(torch.int64))
+                assert torch.equal(got[2].view(torch.int64), ndl[sl].view(torch.int64))
+        else:
+            assert loop.eps < 9.9 and -2.5 < loop.logZ < 0.0
+            sums.append((checksum(eng.state[0]), checksum(eng.state[2]), checksum(eng.wns), loop.logZ, loop.eps))
+        del eng
+        torch.cuda.empty_cache()
+    assert sums[0] == sums[1]            # 8 x 4 lanes == 4 x 8 lanes, and a repeat is deterministic
+
+
+def test_config2_abcdemc_one_million_particles(oracle):
+    """BASELINE.json configs[1]: 1-D Normal, abcdemc, N = 2^20 (60 generations): posterior mean, never-worsening distances,
+    sortedness of the per-generation order, agreement with the oracle on a strided sample of one sweep."""
+    N = 1 << 20
+    prior, sim = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0)
+    spec = A.ModelSpec(prior, sim, seed=3)
+    eng = PopulationEngine(spec, N, ops=HipOps(spec))
+    eng.init_population()
+    g0 = 2.38 / math.sqrt(2)
+    prev_max = math.inf
+    for gen in range(60):
+        lo, hi = eng.extrema()
+        assert hi <= prev_max                                            # mc:54: max distance never grows
+        prev_max = hi
+        if hi > 0.3:
+            eng.mc_rank_prepare()
+            sd = eng.sorted_delta
+            assert bool((sd[1:] >= sd[:-1]).all())
+            assert torch.equal(eng.state[2][eng.order.to(torch.int64)], sd)
+        if gen == 5:
+            th, lp, dl = (t.cpu().contiguous() for t in eng.state)
+            order, sd_h = eng.order.cpu().contiguous(), eng.sorted_delta.cpu().contiguous()
+            sweep = eng.sweep
+            eps_pop = max(0.3, lo)
+            eng.mc_swarm(eps_pop, 0.3, g0, 1e-5)
+            nth, nlp, ndl = torch.zeros_like(th), torch.zeros_like(lp), torch.zeros_like(dl)
+            m = oracle.OracleModel(spec)
+            nsim = C.c_int64()
+            oracle.lib().orc_mc_swarm(m.ptr, order.data_ptr(), sd_h.data_ptr(), N, th.data_ptr(), lp.data_ptr(),
+                                      dl.data_ptr(), nth.data_ptr(), nlp.data_ptr(), ndl.data_ptr(), eps_pop, 0.3, g0,
+                                      1e-5, 0, N, sweep, C.byref(nsim))
+            assert torch.equal(eng.state[0].cpu().view(torch.int64), nth.view(torch.int64))
+            assert torch.equal(eng.state[2].cpu().view(torch.int64), ndl.view(torch.int64))
+        else:
+            eng.mc_swarm(max(0.3, lo), 0.3, g0, 1e-5)
+    assert eng.count_gt(0.3) <= 0.02 * N                                 # completion >= 98 % after 60 generations (mc:156)
+    assert eng.extrema()[1] == 0.9571381847990836                        # same value the CPU oracle reaches (seed 3)
+    post = eng.state[0][:, 0]
+    assert abs(float(post.mean()) - 30 / 11) < 0.015     # finite-eps bias 0.0075 + Monte Carlo error
+    assert abs(float(post.std()) - math.sqrt(10 / 11)) < 0.03
+
+
+def test_config5_two_model_evidence_large_n():
+    """BASELINE.json configs[4] (single-GPU slice): the two models of examples/minimal_example.jl at N = 2^21;
+    logZ against the exact finite-eps evidences, Bayes factor 2.104."""
+    gold = json.load(open(os.path.join(GOLD_DIR, "reference_known_answers.json"), encoding="utf-8"))["analytic"]
+    N = 1 << 21
+    out = []
+    for s2, key in ((10, "Z_exact_finite_eps_sigma2_10"), (100, "Z_exact_finite_eps_sigma2_100")):
+        r = A.abcdesmc(A.Normal(0, math.sqrt(s2)), A.Normal1D(3.0), 0.3, None, nparticles=N, verbose=False, rng=s2,
+                       nsims_max=10 ** 12)
+        assert abs(r.logZ - gold[key]["logZ"]) < 0.02, (s2, r.logZ)     # fp64 tolerance stated: |Δ logZ| < 0.02
+        out.append(r.logZ)
+        al = r.Wns > 0
+        assert abs(r.P[al].mean() - 3 * s2 / (s2 + 1)) < 0.02
+    assert abs(math.exp(out[0] - out[1]) - 2.1043) < 0.05
