@@ -418,16 +418,33 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 }
 
 /* ================================================================ order statistics of alive distances (smc:301)
- * MSB-first radix select on the IEEE bit patterns (distances are >= 0, so the bit
- * pattern order is the value order; NaN never enters the population).
- * Digits: 11,11,11,11,11,9 bits.  Per pass: histogram of the digit among keys that
- * match the current prefix, then a one-block scan picks the bin holding rank k.    */
+ * MSB-first radix select on the IEEE bit patterns (distances are >= 0, so the bit pattern
+ * order is the value order; NaN never enters the population).  Digits: 11,11 | 11,11,11,9 bits.
+ * The first two digits are histogrammed over the whole population (two streaming passes);
+ * a third pass compacts the keys that carry the selected 22-bit prefix (typically N/1000 of
+ * them) into a buffer and records the smallest key above that prefix; the remaining digits
+ * and the "next larger key" run on the buffer.  Per pass: wave-aggregated LDS histogram
+ * (clustered distances put most of a wave in one bin), then a one-block scan picks the bin
+ * holding rank k.                                                                            */
 #define ABZ_SEL_BINS 2048
 
-struct SelState { unsigned long long prefix, k, less, eq, next; };
+struct SelState { unsigned long long prefix, k, less, eq, next, nbuf, min_above, pad; };
 
+__device__ inline void hist_add(uint32_t* s_h, bool f, uint32_t bin) {
+  const unsigned long long bal = __ballot(f);
+  if (bal) {
+    const int leader = __ffsll((long long)bal) - 1;
+    const uint32_t lbin = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(f && bin == lbin);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&s_h[lbin], (uint32_t)__popcll(same));
+    if (f && bin != lbin) atomicAdd(&s_h[bin], 1u);
+  }
+}
+
+/* source = population (delta + alive) when buf == nullptr, else buf[0 .. st->nbuf) */
 __global__ __launch_bounds__(ABZ_BLOCK) void select_hist_kernel(const double* __restrict__ delta,
                                                                 const uint8_t* __restrict__ alive, int64_t N,
+                                                                const unsigned long long* __restrict__ buf,
                                                                 const unsigned long long* __restrict__ st, int shift,
                                                                 int bits, int top, uint32_t* __restrict__ hist) {
   __shared__ uint32_t s_h[ABZ_SEL_BINS];
@@ -435,22 +452,22 @@ __global__ __launch_bounds__(ABZ_BLOCK) void select_hist_kernel(const double* __
   __syncthreads();
   const unsigned long long prefix = st[0];
   const uint32_t mask = (1u << bits) - 1u;
+  const int64_t n = buf ? (int64_t)st[5] : N;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
-  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
-    bool f = false;
-    uint32_t bin = 0;
-    if (alive[k]) {
-      const unsigned long long key = abz_d2u(delta[k]);
-      if (top || (key >> (shift + bits)) == prefix) { f = true; bin = (uint32_t)(key >> shift) & mask; }
+  /* 4 independent loads in flight per lane; wave-uniform trip count so the ballots see whole waves */
+  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k0 - threadIdx.x % 64 < n; k0 += 4 * stride) {
+    unsigned long long key[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = k0 + u * stride;
+      ok[u] = k < n && (buf ? true : alive[k] != 0);
+      key[u] = ok[u] ? (buf ? buf[k] : abz_d2u(delta[k])) : 0ull;
     }
-    const unsigned long long bal = __ballot(f);
-    if (bal) {
-      /* clustered distances put most of a wave in one bin: aggregate that bin */
-      const int leader = __ffsll((long long)bal) - 1;
-      const uint32_t lbin = __shfl(bin, leader, 64);
-      const unsigned long long same = __ballot(f && bin == lbin);
-      if ((threadIdx.x & 63) == leader) atomicAdd(&s_h[lbin], (uint32_t)__popcll(same));
-      if (f && bin != lbin) atomicAdd(&s_h[bin], 1u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool f = ok[u] && (top || (key[u] >> (shift + bits)) == prefix);
+      hist_add(s_h, f, (uint32_t)(key[u] >> shift) & mask);
     }
   }
   __syncthreads();
@@ -488,44 +505,106 @@ __global__ __launch_bounds__(1024) void select_pick_kernel(uint32_t* __restrict_
   if (2 * t + 1 < nb) hist[2 * t + 1] = 0;
 }
 
-/* smallest alive key strictly greater than the selected key */
-__global__ __launch_bounds__(ABZ_BLOCK) void select_next_kernel(const double* __restrict__ delta,
-                                                                const uint8_t* __restrict__ alive, int64_t N,
+/* pass 3: keys with the selected 22-bit prefix -> buf; smallest key with a larger prefix -> st[6].
+ * Hits are staged in LDS and appended with ONE global atomic per flush (scattered hits would
+ * otherwise cost one returning same-address atomic per wave: 156 us for ~5000 hits).          */
+#define ABZ_SEL_CAP 4096
+__global__ __launch_bounds__(ABZ_BLOCK) void select_compact_kernel(const double* __restrict__ delta,
+                                                                   const uint8_t* __restrict__ alive, int64_t N,
+                                                                   unsigned long long* __restrict__ st, int shift,
+                                                                   unsigned long long* __restrict__ buf) {
+  __shared__ unsigned long long s_buf[ABZ_SEL_CAP];
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const unsigned long long prefix = st[0];
+  unsigned long long above = ~0ull;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  auto flush = [&]() {
+    if (threadIdx.x == 0) s_base = atomicAdd(&st[5], (unsigned long long)s_n);
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t t = threadIdx.x; t < n; t += ABZ_BLOCK) buf[s_base + t] = s_buf[t];
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+  };
+  for (int64_t base = (int64_t)blockIdx.x * ABZ_BLOCK; base < N; base += 4 * stride) {   /* block-uniform trips */
+    unsigned long long key[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t k = base + threadIdx.x + u * stride;
+      ok[u] = k < N && alive[k] != 0;
+      key[u] = ok[u] ? abz_d2u(delta[k]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long p = key[u] >> shift;
+      if (ok[u] && p > prefix && key[u] < above) above = key[u];
+      if (ok[u] && p == prefix) s_buf[atomicAdd(&s_n, 1u)] = key[u];       /* room for 4 x 256 guaranteed */
+    }
+    __syncthreads();
+    if (s_n > ABZ_SEL_CAP - 4 * ABZ_BLOCK) flush();                       /* s_n is block-uniform here */
+  }
+  if (s_n) flush();
+  unsigned long long dummy = 0;
+  block_minmax_u64(above, dummy);
+  if (threadIdx.x == 0 && above != ~0ull) atomicMin(&st[6], above);
+}
+
+/* smallest key strictly greater than the selected key: inside the buffer, else the recorded min_above */
+__global__ __launch_bounds__(ABZ_BLOCK) void select_next_kernel(const unsigned long long* __restrict__ buf,
                                                                 unsigned long long* __restrict__ st) {
   const unsigned long long key0 = st[0];
+  const int64_t n = (int64_t)st[5];
   unsigned long long best = ~0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
-  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
-    if (alive[k]) {
-      const unsigned long long key = abz_d2u(delta[k]);
-      if (key > key0 && key < best) best = key;
-    }
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < n; k += stride) {
+    const unsigned long long key = buf[k];
+    if (key > key0 && key < best) best = key;
   }
   unsigned long long dummy = 0;
   block_minmax_u64(best, dummy);
-  if (threadIdx.x == 0 && best != ~0ull) atomicMin(&st[4], best);
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && st[6] < best) best = st[6];
+    if (best != ~0ull) atomicMin(&st[4], best);
+  }
 }
 
 int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
                     double* xk, double* xk1, int64_t* n_le) {
-  int rc = abz_ws_reserve(ctx, abz_align(ABZ_SEL_BINS * 4));
+  const size_t hb = abz_align(ABZ_SEL_BINS * 4);
+  int rc = abz_ws_reserve(ctx, hb + abz_align((size_t)N * 8));
   if (rc) return rc;
   uint32_t* hist = (uint32_t*)ctx->ws;
+  unsigned long long* buf = (unsigned long long*)((char*)ctx->ws + hb);
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
-  SelState init{0ull, (unsigned long long)k0, 0ull, 0ull, ~0ull};
+  SelState init{0ull, (unsigned long long)k0, 0ull, 0ull, ~0ull, 0ull, ~0ull, 0ull};
   ABZ_HIP_CHECK(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
   ABZ_HIP_CHECK(hipMemsetAsync(hist, 0, ABZ_SEL_BINS * 4, ctx->stream));
-  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
+  unsigned grid = (unsigned)((N + 4 * ABZ_BLOCK - 1) / (4 * ABZ_BLOCK));
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
   const int widths[6] = {11, 11, 11, 11, 11, 9};
   int shift = 64;
-  for (int p = 0; p < 6; ++p) {
+  for (int p = 0; p < 2; ++p) {            /* whole population */
     shift -= widths[p];
-    hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st, shift,
-                       widths[p], p == 0 ? 1 : 0, hist);
+    hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N,
+                       (const unsigned long long*)nullptr, st, shift, widths[p], p == 0 ? 1 : 0, hist);
     hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, st, widths[p]);
   }
-  hipLaunchKernelGGL(select_next_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
+  hipLaunchKernelGGL(select_compact_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st, shift,
+                     buf);
+  const unsigned bgrid = 64;               /* buffer passes: the buffer is small */
+  for (int p = 2; p < 6; ++p) {
+    shift -= widths[p];
+    hipLaunchKernelGGL(select_hist_kernel, dim3(bgrid), dim3(ABZ_BLOCK), 0, ctx->stream, (const double*)nullptr,
+                       (const uint8_t*)nullptr, (int64_t)0, buf, st, shift, widths[p], 0, hist);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, st, widths[p]);
+  }
+  hipLaunchKernelGGL(select_next_kernel, dim3(bgrid), dim3(ABZ_BLOCK), 0, ctx->stream, buf, st);
   ABZ_HIP_CHECK(hipGetLastError());
   rc = read_scalars(ctx);
   if (rc) return rc;

@@ -27,6 +27,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic_per_update():
+    """HBM bytes per particle-update of the sweep kernel from the committed PMC passes
+    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+    separate rocprofv3 --pmc runs of this same command).  None if the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return float(json.load(f)["total_bytes_per_update"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -166,6 +177,7 @@ def main():
         avg_ms = kern_ms / max(launches, 1)
         units_per_launch = units / max(launches, 1)
         ach = (b_read + b_write) * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        tpu = measured_traffic_per_update() if (d == 32 and L == 4) else None
         out = {
             "metric": "particle-updates/sec per SMC generation",
             "value": updates / dt,
@@ -188,7 +200,9 @@ def main():
             },
             "roofline": {
                 "kernel": "smc_swarm_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": tpu * units_per_launch if tpu else None,          # bytes per launch (PMC), cf. algorithmic below
+                "algorithmic_bytes_per_launch": (b_read + b_write) * units_per_launch,
                 "bytes_per_update": b_read + b_write, "updates_per_launch": units_per_launch,
                 "avg_launch_ms": avg_ms, "launches": launches,
                 "read_only_achieved": b_read * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
