@@ -1,0 +1,88 @@
+// layout_bench.hip -- evidence for the theta layout decision.
+// Measures the DE-donor access pattern alone (N particles, d = 32 doubles each, two uniformly
+// random donors per particle, result reduced so nothing is optimised away) for
+//   (A) row-major rows  f64[N][32], 4 lanes x 8 components per particle (the shipped layout)
+//   (B) component-major f64[32][N] ("SoA"), one thread per particle
+//   (C) row-major rows staged through LDS by the whole workgroup before use
+// Build: hipcc --offload-arch=gfx950 -O3 tools/layout_bench.hip -o tools/layout_bench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+constexpr int D = 32;
+
+__device__ inline uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+// (A) 4 lanes per particle, lane j loads doubles [2j,2j+1] and [8+2j, 8+2j+1] ... (2 x 16 B per row)
+__global__ __launch_bounds__(256) void k_rows(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, i = gid >> 2; const int j = gid & 3;
+  if (i >= N) return;
+  const uint32_t a = hash32(i * 2 + 1) % N, b = hash32(i * 2 + 2) % N;
+  double acc = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2 o = *(const double2*)(th + (size_t)i * D + m * 8 + 2 * j);
+    const double2 x = *(const double2*)(th + (size_t)a * D + m * 8 + 2 * j);
+    const double2 y = *(const double2*)(th + (size_t)b * D + m * 8 + 2 * j);
+    acc += o.x + o.y + (x.x - y.x) + (x.y - y.y);
+  }
+  if (acc == 1.2345e300) out[gid] = acc;
+}
+// (B) component-major: thread per particle, component k at th[k*N + i]
+__global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t a = hash32(i * 2 + 1) % N, b = hash32(i * 2 + 2) % N;
+  double acc = 0;
+#pragma unroll 8
+  for (int k = 0; k < D; ++k) acc += th[(size_t)k * N + i] + (th[(size_t)k * N + a] - th[(size_t)k * N + b]);
+  if (acc == 1.2345e300) out[i] = acc;
+}
+// (C) rows staged in LDS: a 256-thread block handles 64 particles; 16 lanes copy one 256-B row
+__global__ __launch_bounds__(256) void k_rows_lds(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
+  __shared__ double s[3][64][D + 2];
+  const uint32_t p0 = blockIdx.x * 64;
+  for (int r = threadIdx.x >> 4; r < 64 * 3; r += 16) {      // row r of the 192 rows this block needs
+    const uint32_t p = p0 + (r % 64); const int which = r / 64;
+    if (p < N) {
+      const uint32_t src = which == 0 ? p : hash32(p * 2 + which) % N;
+      const int l = threadIdx.x & 15;
+      const double2 v = *(const double2*)(th + (size_t)src * D + 2 * l);
+      s[which][r % 64][2 * l] = v.x; s[which][r % 64][2 * l + 1] = v.y;
+    }
+  }
+  __syncthreads();
+  const uint32_t i = p0 + (threadIdx.x >> 2); const int j = threadIdx.x & 3;
+  if (i >= N) return;
+  double acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc += s[0][threadIdx.x >> 2][j * 8 + k] + (s[1][threadIdx.x >> 2][j * 8 + k] - s[2][threadIdx.x >> 2][j * 8 + k]);
+  if (acc == 1.2345e300) out[i] = acc;
+}
+
+int main() {
+  const uint32_t N = 1u << 22;
+  const size_t bytes = (size_t)N * D * 8;
+  double *th, *out;
+  CHECK(hipMalloc(&th, bytes)); CHECK(hipMalloc(&out, (size_t)N * 4 * 8));
+  CHECK(hipMemset(th, 0, bytes));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const double useful = (double)N * 3 * D * 8;     // 768 B per particle
+  auto run = [&](const char* name, auto launch) {
+    for (int w = 0; w < 3; ++w) launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    const int reps = 20;
+    for (int r = 0; r < reps; ++r) launch();
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    printf("{\"variant\": \"%s\", \"ms\": %.4f, \"useful_GBps\": %.1f, \"particles_per_s\": %.4e}\n", name, ms, useful / ms / 1e6, N / (ms * 1e-3));
+  };
+  run("A rows f64[N][32], 4 lanes x 8 comps, direct to registers", [&] { hipLaunchKernelGGL(k_rows, dim3(N * 4 / 256), dim3(256), 0, 0, th, N, out); });
+  run("B component-major f64[32][N], thread per particle", [&] { hipLaunchKernelGGL(k_soa, dim3(N / 256), dim3(256), 0, 0, th, N, out); });
+  run("C rows f64[N][32] staged through LDS per workgroup", [&] { hipLaunchKernelGGL(k_rows_lds, dim3(N / 64), dim3(256), 0, 0, th, N, out); });
+  return 0;
+}
