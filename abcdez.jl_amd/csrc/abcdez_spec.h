@@ -397,19 +397,26 @@ ABZ_HD void abz_donor_ranks(abz_u64x2 w, uint32_t n_alive, uint32_t ri, uint32_t
 /* ------------------------------------------------------------------ resampling fixed point (smc:15-56)
  * The reference walks a sequentially accumulated fp cumsum; a parallel scan cannot
  * reproduce its roundings, so the spec accumulates in exact integers:
- * total mass S = N * 2^40; weight i -> rint(W_i * N * 2^40); stratum s draws
- * R = s * 2^40 + (40 random bits); pick the smallest i with cumsum_i > R (clamped
- * to the last positive-weight index).                                              */
-#define ABZ_STRATUM_BITS 40
+ * total mass S = N * 2^b; weight i -> rint(W_i * N * 2^b); stratum s draws
+ * R = s * 2^b + (b random bits); pick the smallest i with cumsum_i > R (clamped to the last
+ * positive-weight index).  b = 40 fraction bits for N <= 2^23, fewer above so that S < 2^64
+ * (N = 2^25, an 8-GPU population of 2^22 per GPU: b = 38).                             */
+ABZ_HD int abz_stratum_bits(uint32_t n) {
+  int lg = 0;                               /* ceil(log2(n)) */
+  while (lg < 32 && ((uint64_t)1 << lg) < (uint64_t)n) ++lg;
+  return lg <= 23 ? 40 : 63 - lg;
+}
 ABZ_HD uint64_t abz_weight_fix(double w, uint32_t n) {
-  double v = w * (double)n * 0x1p40;
+  const int b = abz_stratum_bits(n);
+  double v = w * (double)n * abz_u2d((uint64_t)(1023 + b) << 52);     /* * 2^b */
   if (!(v > 0.0)) return 0;           /* zero, negative or NaN weights carry no mass */
   if (v >= 0x1p63) return (uint64_t)1 << 63;
   return (uint64_t)abz_rint(v);
 }
-ABZ_HD uint64_t abz_stratum_point(uint64_t seed, uint32_t s, uint32_t draw) {
+ABZ_HD uint64_t abz_stratum_point(uint64_t seed, uint32_t n, uint32_t s, uint32_t draw) {
+  const int b = abz_stratum_bits(n);
   abz_u64x2 w = abz_rng(seed, s, draw, 0, ABZ_RNG_STRATUM);
-  return ((uint64_t)s << ABZ_STRATUM_BITS) | (w.w0 >> (64 - ABZ_STRATUM_BITS));
+  return ((uint64_t)s << b) | (w.w0 >> (64 - b));
 }
 
 /* ------------------------------------------------------------------ canonical summation tree

@@ -303,8 +303,7 @@ int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out) {
 
 int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds) {
   ABZ_REQUIRE(ctx && wns && inds, "wsample_stratified: null argument");
-  /* stratum index and 40 fraction bits must fit 63 bits */
-  ABZ_REQUIRE(N >= 1 && N <= (1ll << 23), "wsample_stratified: N must be <= 2^23");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "wsample_stratified: N out of range");
   return abz_stratified_impl(ctx, wns, N, draw, inds);
 }
 

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void stratified_search_kernel(const unsi
                                                                       uint32_t* __restrict__ inds) {
   const uint32_t s = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   if (s >= N) return;
-  const uint64_t R = abz_stratum_point(seed, s, draw);
+  const uint64_t R = abz_stratum_point(seed, N, s, draw);
   uint32_t lo = 0, hi = N;               /* smallest i with cum[i] > R */
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;

@@ -215,6 +215,7 @@ class PopulationEngine:
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
         self._dead_synced = True
+        self._inplace_gather = True
         self.last_inds = None
 
     # ------------------------------------------------------------------ helpers
@@ -236,7 +237,14 @@ class PopulationEngine:
         import torch.distributed as dist
 
         for t in bufs:
-            dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
+            if self._inplace_gather:
+                try:
+                    dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
+                    continue
+                except RuntimeError:          # backend without a tensor all-gather for this device type
+                    self._inplace_gather = False
+            chunks = list(t.chunk(self.world, dim=0))
+            dist.all_gather(chunks, t[self.lo:self.hi].clone(), group=self.pg)
 
     def _allreduce_counts(self, *vals):
         if self.world == 1:

@@ -484,7 +484,7 @@ ORC_API void orc_wsample_stratified(uint64_t seed, const double* wns, int64_t N,
   }
   int64_t i = 0;
   for (int64_t s = 0; s < N; ++s) {
-    uint64_t R = abz_stratum_point(seed, (uint32_t)s, draw);
+    uint64_t R = abz_stratum_point(seed, (uint32_t)N, (uint32_t)s, draw);
     while (i < N - 1 && !(cum[i] > R)) ++i;
     int64_t pick = i;
     if (!(cum[pick] > R)) pick = last_pos;   /* total mass rounded below R */
@@ -496,8 +496,9 @@ ORC_API void orc_wsample_stratified(uint64_t seed, const double* wns, int64_t N,
 /* the uniforms the spec draw corresponds to, for feeding the literal walk in tests */
 ORC_API void orc_stratum_uniforms(uint64_t seed, int64_t N, uint32_t draw, double* u) {
   for (int64_t s = 0; s < N; ++s) {
-    uint64_t R = abz_stratum_point(seed, (uint32_t)s, draw);
-    u[s] = (double)(R & (((uint64_t)1 << ABZ_STRATUM_BITS) - 1)) * 0x1p-40;
+    const int b = abz_stratum_bits((uint32_t)N);
+    uint64_t R = abz_stratum_point(seed, (uint32_t)N, (uint32_t)s, draw);
+    u[s] = (double)(R & (((uint64_t)1 << b) - 1)) / (double)((uint64_t)1 << b);
   }
 }
 

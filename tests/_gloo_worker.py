@@ -27,14 +27,22 @@ def cases():
 
 def main():
     outdir = sys.argv[1]
+    mode = sys.argv[2] if len(sys.argv) > 2 else "oracle"     # "oracle": CPU tensors; "hip": the product engine on cuda:0
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pg = dist.group.WORLD if world > 1 else None
+    engine = O.oracle_engine
+    if mode == "hip":
+        import torch
+        from abcdez_amd.engine import HipEngine
+
+        torch.cuda.set_device(0)          # every rank shares the one GPU of the test box; collectives go through gloo
+        engine = HipEngine
     for name, (prior, sim, eps, N) in cases().items():
-        r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=O.oracle_engine,
+        r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
         m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=25, verbose=False, rng=22,
-                      engine=O.oracle_engine, process_group=pg)
+                      engine=engine, process_group=pg)
         res, mres = r.engine.result(), m.engine.result()
         # every rank must hold the same full population after the all-gathers
         np.savez(os.path.join(outdir, f"result_{name}_rank{rank}.npz"), theta=res["theta"], C=res["C"], Wns=res["Wns"],

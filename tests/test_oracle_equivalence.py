@@ -20,7 +20,7 @@ def _weights(N, rng, frac_zero=0.4, equal=False):
     return w / w.sum()
 
 
-@pytest.mark.parametrize("N", [1, 2, 5, 100, 1000, 4096, 50001])
+@pytest.mark.parametrize("N", [1, 2, 5, 100, 1000, 4096, 50001, (1 << 24) + 3])
 @pytest.mark.parametrize("equal", [False, True])
 def test_stratified_fixed_point_equals_sequential_fp_walk(oracle, N, equal):
     """src/abcdez_smc.jl:15-56: the integer-cumsum pick equals the reference's sequential
@@ -36,7 +36,16 @@ def test_stratified_fixed_point_equals_sequential_fp_walk(oracle, N, equal):
         L.orc_stratum_uniforms(77, N, draw, u.ctypes.data)
         ref = np.zeros(N, dtype=np.int64)
         L.ref_wsample_stratified(w.ctypes.data, N, u.ctypes.data, ref.ctypes.data)
-        assert np.array_equal(inds.astype(np.int64), ref)
+        if N <= 100000:
+            assert np.array_equal(inds.astype(np.int64), ref)
+        else:
+            # the sequential fp cumsum of 1.7e7 weights carries ~1e-10 of rounding error; a stratum draw
+            # within that distance of a boundary picks the neighbouring (positive-weight) particle
+            diff = inds.astype(np.int64) != ref
+            assert diff.mean() < 1e-3      # equal weights: 1e7 sequential additions of one value drift systematically
+            pos = np.flatnonzero(w > 0)
+            rank = np.searchsorted(pos, np.stack([inds.astype(np.int64)[diff], ref[diff]]))
+            assert (np.abs(rank[0] - rank[1]) <= 1).all()
         # invariants implied by smc:45-54
         assert (np.diff(ref) >= 0).all()
         assert (w[ref] > 0).all()
