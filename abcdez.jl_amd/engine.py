@@ -184,8 +184,10 @@ class PopulationEngine:
 
             self.rank = dist.get_rank(self.pg)
             self.world = dist.get_world_size(self.pg)
+            self._backend = str(dist.get_backend(self.pg))
         else:
             self.rank, self.world = 0, 1
+            self._backend = "none"
         if self.N % self.world:
             raise ValueError(f"nparticles ({self.N}) must be divisible by the number of ranks ({self.world})")
         self.n_local = self.N // self.world
@@ -215,7 +217,6 @@ class PopulationEngine:
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
         self._dead_synced = True
-        self._inplace_gather = True
         self.last_inds = None
 
     # ------------------------------------------------------------------ helpers
@@ -231,27 +232,30 @@ class PopulationEngine:
         self.cur = 1 - self.cur
 
     def _allgather_state(self, bufs):
-        """exchange rows [lo, hi) of (theta, logpi, delta) -- one in-place all-gather per array"""
+        """exchange rows [lo, hi) of (theta, logpi, delta) -- one all-gather per array.
+
+        RCCL ("nccl" backend): in place, straight between the device buffers over xGMI.
+        Any other backend (gloo in the CPU tests): CPU tensors in place; device tensors are
+        staged through host memory, so the path is deterministic on every rank."""
         if self.world == 1:
             return
         import torch.distributed as dist
 
+        direct = self._backend == "nccl" or self.device.type == "cpu"
         for t in bufs:
-            if self._inplace_gather:
-                try:
-                    dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
-                    continue
-                except RuntimeError:          # backend without a tensor all-gather for this device type
-                    self._inplace_gather = False
-            chunks = list(t.chunk(self.world, dim=0))
-            dist.all_gather(chunks, t[self.lo:self.hi].clone(), group=self.pg)
+            if direct:
+                dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
+            else:
+                host = torch.empty(t.shape, dtype=t.dtype)
+                dist.all_gather_into_tensor(host, t[self.lo:self.hi].cpu(), group=self.pg)
+                t.copy_(host)
 
     def _allreduce_counts(self, *vals):
         if self.world == 1:
             return vals
         import torch.distributed as dist
 
-        t = torch.tensor(vals, dtype=torch.int64, device=self.device)
+        t = torch.tensor(vals, dtype=torch.int64, device=self.device if self._backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return tuple(int(v) for v in t.tolist())
 

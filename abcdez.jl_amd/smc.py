@@ -47,6 +47,35 @@ def quantile_type7(xj: float, xj1: float, g: float) -> float:
     return xj + g * (xj1 - xj)
 
 
+def wsample_stratified(weights, rng: int = 1, draw: int = 0, engine=None):
+    """Stratified resampling indices for normalised ``weights`` (src/abcdez_smc.jl:15-56).
+
+    The reference's tests call ``ABCdeZ.wsample_stratified!(rng, weights, inds)`` directly to
+    turn a weighted population (continuous-weight kernels) into posterior samples
+    (test/runtests.jl:13-19).  Runs on the device through ``abcdez_wsample_stratified``;
+    returns 0-based indices (the reference's are 1-based).  ``r.P[wsample_stratified(r.Wns)]``
+    is the Python spelling of ``r.P[weightinds(r.Wns)]``.
+    """
+    import torch
+
+    from .priors import Normal
+    from .simulators import DiracSquare
+
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if not abs(float(w.sum()) - 1.0) < 1e-8:
+        raise ValueError("Sum of weights expected to be 1.0 (approximately)")   # test/runtests.jl:14
+    if engine is not None:
+        ops = engine.ops
+    else:
+        from .engine import HipOps
+
+        ops = HipOps(ModelSpec(Normal(0.0, 1.0), DiracSquare(1.5), seed=rng))   # only the seed matters here
+    wt = torch.from_numpy(w).to(ops.device)
+    inds = torch.zeros(w.size, dtype=torch.int32, device=ops.device)
+    ops.wsample_stratified(wt, draw, inds)
+    return inds.cpu().numpy().astype(np.int64)
+
+
 def _check(cond: bool, msg: str) -> None:
     if not cond:
         raise ValueError(msg)  # the reference raises ErrorException via error(...)

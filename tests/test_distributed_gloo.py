@@ -20,12 +20,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(world, outdir, mode="oracle"):
+def run_world(world, outdir, mode="oracle", timeout=900):
     env = dict(os.environ, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "_gloo_worker.py"), str(outdir), mode]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
 
 
@@ -74,7 +74,7 @@ def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
     ref_dir = tmp_path_factory.mktemp("ref_oracle")
     run_world(1, ref_dir, "oracle")
     hip_dir = tmp_path_factory.mktemp("hip_world2")
-    run_world(2, hip_dir, "hip")
+    run_world(2, hip_dir, "hip", timeout=240)
     for name in ("normal1d", "mvn8", "quad2d"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(2):

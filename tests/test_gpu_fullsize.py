@@ -267,3 +267,24 @@ def test_config5_two_model_evidence_large_n():
         al = r.Wns > 0
         assert abs(r.P[al].mean() - 3 * s2 / (s2 + 1)) < 0.02
     assert abs(math.exp(out[0] - out[1]) - 2.1043) < 0.05
+
+
+def test_epanechnikov_kernel_at_scale(oracle):
+    """continuous-weight kernels at scale.  Epa kernel, N = 2^20: evidence against the closed form
+    (test/runtests.jl:334-336), weighted posterior through the public wsample_stratified, and the resampling
+    indices of the continuous weights bit-identical to the oracle's."""
+    gold = json.load(open(os.path.join(GOLD_DIR, "reference_known_answers.json"), encoding="utf-8"))["analytic"]
+    N = 1 << 20
+    r = A.abcdesmc(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, None, nparticles=N, ABCk=A.Epa0toϵ, verbose=False,
+                   rng=8, nsims_max=10 ** 12)
+    Z = math.exp(r.logZ)
+    assert abs(Z / gold["Z_epa_data3"]["value"] - 1) < 0.03
+    w = r.Wns[r.Wns > 0]
+    assert w.max() > 1.5 * w.min()                                      # genuinely continuous weights
+    inds = A.wsample_stratified(r.Wns, rng=8, engine=r.engine)
+    post = r.P[inds]
+    assert abs(post.mean() - 30 / 11) < 0.02
+    ref = np.zeros(N, dtype=np.uint32)
+    wh = np.ascontiguousarray(r.Wns)
+    oracle.lib().orc_wsample_stratified(8, wh.ctypes.data, N, 0, ref.ctypes.data)
+    assert np.array_equal(inds, ref.astype(np.int64))

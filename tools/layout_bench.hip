@@ -31,6 +31,44 @@ __global__ __launch_bounds__(256) void k_rows(const double* __restrict__ th, uin
   }
   if (acc == 1.2345e300) out[gid] = acc;
 }
+// (A2) as (A) but the two donor rows are found through a random 4-byte look-up in a 16 MB index table
+//      (what the sweep does when some particles are dead: alive_idx[rank])
+__global__ __launch_bounds__(256) void k_rows_idx(const double* __restrict__ th, const uint32_t* __restrict__ idx, uint32_t N,
+                                                  double* __restrict__ out) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, i = gid >> 2; const int j = gid & 3;
+  if (i >= N) return;
+  const uint32_t a = idx[hash32(i * 2 + 1) % N], b = idx[hash32(i * 2 + 2) % N];
+  double acc = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2 o = *(const double2*)(th + (size_t)i * D + m * 8 + 2 * j);
+    const double2 x = *(const double2*)(th + (size_t)a * D + m * 8 + 2 * j);
+    const double2 y = *(const double2*)(th + (size_t)b * D + m * 8 + 2 * j);
+    acc += o.x + o.y + (x.x - y.x) + (x.y - y.y);
+  }
+  if (acc == 1.2345e300) out[gid] = acc;
+}
+// (A3) as (A) plus the sweep's writes: one 256-B row + 16 B per particle
+__global__ __launch_bounds__(256) void k_rows_rw(const double* __restrict__ th, const uint32_t* __restrict__ idx, uint32_t N,
+                                                 double* __restrict__ nth, double* __restrict__ nlp, int use_idx, int wfrac) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, i = gid >> 2; const int j = gid & 3;
+  if (i >= N) return;
+  uint32_t a = hash32(i * 2 + 1) % N, b = hash32(i * 2 + 2) % N;
+  if (use_idx) { a = idx[a]; b = idx[b]; }
+  const bool wr = (hash32(i * 7 + 3) % 100) < (uint32_t)wfrac;
+  double acc = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2 o = *(const double2*)(th + (size_t)i * D + m * 8 + 2 * j);
+    const double2 x = *(const double2*)(th + (size_t)a * D + m * 8 + 2 * j);
+    const double2 y = *(const double2*)(th + (size_t)b * D + m * 8 + 2 * j);
+    double2 r; r.x = o.x + (x.x - y.x); r.y = o.y + (x.y - y.y);
+    acc += r.x + r.y;                                   /* the reads happen whether or not the row is written */
+    if (wr) *(double2*)(nth + (size_t)i * D + m * 8 + 2 * j) = r;
+  }
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);   /* every lane's loads are live */
+  if (j == 0) { nlp[i] = acc; nlp[N + i] = 2.0; }
+}
 // (B) component-major: thread per particle, component k at th[k*N + i]
 __global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -82,6 +120,13 @@ int main() {
     printf("{\"variant\": \"%s\", \"ms\": %.4f, \"useful_GBps\": %.1f, \"particles_per_s\": %.4e}\n", name, ms, useful / ms / 1e6, N / (ms * 1e-3));
   };
   run("A rows f64[N][32], 4 lanes x 8 comps, direct to registers", [&] { hipLaunchKernelGGL(k_rows, dim3(N * 4 / 256), dim3(256), 0, 0, th, N, out); });
+  uint32_t* idx; CHECK(hipMalloc(&idx, (size_t)N * 4));
+  { std::vector<uint32_t> h(N); for (uint32_t k = 0; k < N; ++k) h[k] = k; CHECK(hipMemcpy(idx, h.data(), (size_t)N * 4, hipMemcpyHostToDevice)); }
+  double *nth, *nlp; CHECK(hipMalloc(&nth, bytes)); CHECK(hipMalloc(&nlp, (size_t)N * 16));
+  run("A2 rows + two random 4-B index look-ups (16 MB table)", [&] { hipLaunchKernelGGL(k_rows_idx, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, out); });
+  run("A3 rows, reads + all row writes + 16 B state, no index", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 0, 100); });
+  run("A4 rows, reads + 45% row writes + 16 B state, no index", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 0, 45); });
+  run("A5 rows, reads + 45% row writes + 16 B state + index look-ups", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 1, 45); });
   run("B component-major f64[32][N], thread per particle", [&] { hipLaunchKernelGGL(k_soa, dim3(N / 256), dim3(256), 0, 0, th, N, out); });
   run("C rows f64[N][32] staged through LDS per workgroup", [&] { hipLaunchKernelGGL(k_rows_lds, dim3(N / 64), dim3(256), 0, 0, th, N, out); });
   return 0;
