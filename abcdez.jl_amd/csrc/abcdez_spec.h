@@ -89,7 +89,8 @@ enum {
   ABZ_RNG_ACCEPT = 5,     /* word0 -> accept uniform                              */
   ABZ_RNG_SIM = 6,        /* simulator noise during sweeps                        */
   ABZ_RNG_BETTER = 7,     /* abcdemc "better particle" draw (mc:23)               */
-  ABZ_RNG_STRATUM = 8     /* stratified resampling uniform (smc:47)               */
+  ABZ_RNG_STRATUM = 8,    /* stratified resampling uniform (smc:47)               */
+  ABZ_RNG_INIT_AUX = 9    /* rejection samplers of the Beta / NegativeBinomial priors */
 };
 
 typedef struct { uint64_t w0, w1; } abz_u64x2;
@@ -318,7 +319,10 @@ enum {
   ABZ_PRIOR_PAD = 0,        /* padding component: value 0, logpdf 0                 */
   ABZ_PRIOR_NORMAL = 1,     /* p0 = mu, p1 = sigma, c0 = -log(sigma) - log(2 pi)/2, c1 = 1/sigma */
   ABZ_PRIOR_UNIFORM = 2,    /* p0 = a, p1 = b (closed support), c0 = -log(b-a)      */
-  ABZ_PRIOR_DUNIFORM = 3    /* p0 = a, p1 = b integers, c0 = -log(b-a+1); discrete  */
+  ABZ_PRIOR_DUNIFORM = 3,   /* p0 = a, p1 = b integers, c0 = -log(b-a+1); discrete  */
+  ABZ_PRIOR_BETA = 4,       /* p0 = alpha, p1 = beta, c0 = -log B(alpha, beta); support [0,1]       */
+  ABZ_PRIOR_NEGBIN = 5      /* p0 = r, p1 = p, c0 = r log p - lgamma(r), c1 = log(1-p); discrete k >= 0
+                               (Distributions.NegativeBinomial: failures before the r-th success)   */
 };
 
 typedef struct {    /* 48 bytes = three 16-byte loads */
@@ -330,10 +334,43 @@ typedef struct {    /* 48 bytes = three 16-byte loads */
 /* push_p for one component (types.jl:22-23) */
 ABZ_HD double abz_push_p(const abz_prior_dim* pd, double x) { return pd->discrete ? abz_rint(x) : x; }
 
+/* log Gamma(x), x > 0: shift to x >= 16 by the recurrence, then the Stirling series to x^-9
+ * (truncation 1e-16).  Error < 3e-14 max(1, |lgamma|) (tests/test_spec_math.py).              */
+ABZ_HD double abz_lgamma(double x) {
+  double prod = 1.0;
+  for (int it = 0; it < 16 && x < 16.0; ++it) { prod *= x; x += 1.0; }
+  const double xi = 1.0 / x, x2 = xi * xi;
+  double ser = 0x1.5555555555555p-4;                        /*  1/12   */
+  {
+    double t = -0x1.b951e2b18ff23p-11;                      /* -1/1188 */
+    t = abz_fma(t, x2, 0x1.3813813813814p-11);              /*  1/1680 */
+    t = abz_fma(t, x2, -0x1.a01a01a01a01ap-11);             /* -1/1260 */
+    t = abz_fma(t, x2, 0x1.6c16c16c16c17p-9);               /*  1/360  */
+    ser = abz_fma(-t, x2, ser);
+  }
+  const double lg = abz_fma(x - 0.5, abz_log(x), -x) + 0.91893853320467274178;
+  return (lg + ser * xi) - abz_log(prod);
+}
+
+/* Beta / NegativeBinomial log-densities (the Socks problem of test/runtests.jl:425-491) */
+ABZ_HD double abz_prior_logpdf_ext(const abz_prior_dim* pd, double x) {
+  if (pd->family == ABZ_PRIOR_BETA) {
+    if (!(x >= 0.0 && x <= 1.0)) return ABZ_NINF;
+    const double a1 = pd->p0 - 1.0, b1 = pd->p1 - 1.0;
+    const double t1 = a1 == 0.0 ? 0.0 : a1 * abz_log(x);
+    const double t2 = b1 == 0.0 ? 0.0 : b1 * abz_log(1.0 - x);
+    return (t1 + t2) + pd->c0;
+  }
+  /* ABZ_PRIOR_NEGBIN */
+  if (!(x >= 0.0) || abz_rint(x) != x || x > 0x1p52) return ABZ_NINF;
+  return ((abz_lgamma(x + pd->p0) - abz_lgamma(x + 1.0)) + pd->c0) + x * pd->c1;
+}
+
 /* logpdf of one (already pushed) component; branch-free so a wave with mixed families
  * does not serialise.  Normal: z = (x - mu) * (1/sigma), -z^2/2 + c0.                     */
 ABZ_HD double abz_prior_logpdf1(const abz_prior_dim* pd, double x) {
   const int fam = pd->family;
+  if (fam >= ABZ_PRIOR_BETA) return abz_prior_logpdf_ext(pd, x);
   const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
   const double z = (x - p0) * c1;
   const double ln = abz_fma(-0.5 * z, z, c0);
@@ -353,6 +390,50 @@ ABZ_HD double abz_prior_draw1(const abz_prior_dim* pd, uint64_t w, double z) {
     case ABZ_PRIOR_DUNIFORM: return pd->p0 + abz_floor(abz_u01_co(w) * (pd->p1 - pd->p0 + 1.0));
     default: return 0.0;
   }
+}
+
+/* Rejection / inversion samplers of the extended families; only the initial population uses
+ * them (smc:242, init.jl:15).  Random numbers: purpose ABZ_RNG_INIT_AUX, sub-index
+ * (component k) * 4096 + stream * 1024 + 2 * attempt (+1 for the attempt's uniform).         */
+ABZ_HD double abz_gamma_draw(double shape, uint64_t seed, uint32_t i, uint32_t retry, uint32_t base,
+                             const abz_tables* T) {
+  /* Marsaglia & Tsang (2000); shape < 1 is boosted through Gamma(shape+1) U^(1/shape) */
+  const double k = shape < 1.0 ? shape + 1.0 : shape;
+  const double d = k - 1.0 / 3.0, c = 1.0 / abz_sqrt(9.0 * d);
+  double g = d;
+  for (uint32_t a = 0; a < 500; ++a) {
+    double z0, z1;
+    abz_normal_pair(abz_rng(seed, i, retry, base + 2 * a, ABZ_RNG_INIT_AUX), T, &z0, &z1);
+    const double t = 1.0 + c * z0;
+    if (!(t > 0.0)) continue;
+    const double v = t * t * t;
+    const double u = abz_u01_open(abz_rng(seed, i, retry, base + 2 * a + 1, ABZ_RNG_INIT_AUX).w0);
+    if (abz_log_tab(u, T) < 0.5 * z0 * z0 + d - d * v + d * abz_log(v)) { g = d * v; break; }
+  }
+  if (shape < 1.0) {
+    const double u = abz_u01_open(abz_rng(seed, i, retry, base + 1001, ABZ_RNG_INIT_AUX).w0);
+    g = g * abz_exp(abz_log_tab(u, T) / shape);
+  }
+  return g;
+}
+ABZ_HD double abz_prior_draw_ext(const abz_prior_dim* pd, uint64_t seed, uint32_t i, uint32_t retry, uint32_t k,
+                                 const abz_tables* T) {
+  const uint32_t base = k * 4096u;
+  if (pd->family == ABZ_PRIOR_BETA) {
+    const double x = abz_gamma_draw(pd->p0, seed, i, retry, base, T);
+    const double y = abz_gamma_draw(pd->p1, seed, i, retry, base + 1024u, T);
+    return x / (x + y);
+  }
+  /* NegativeBinomial(r, p) by inversion: P(0) = p^r, P(k+1) = P(k) (k+r)/(k+1) (1-p) */
+  const double r = pd->p0, q = 1.0 - pd->p1;
+  const double u = abz_u01_co(abz_rng(seed, i, retry, base, ABZ_RNG_INIT_AUX).w0);
+  double P = abz_exp(r * abz_log(pd->p1)), cum = P, kk = 0.0;
+  for (int it = 0; it < 100000 && u >= cum; ++it) {
+    P = P * ((kk + r) / (kk + 1.0)) * q;
+    kk += 1.0;
+    cum += P;
+  }
+  return kk;
 }
 
 /* ------------------------------------------------------------------ ABC kernels (types.jl:26-73) */
@@ -471,7 +552,12 @@ enum {
    * step sim_p[2], sim_p[3] steps between observations, n_data/2 observation times
    * (the first at t = 0), additive N(0, sim_p[4]^2) noise on every observed value;
    * dist = sqrt(sum over the n_data values (obs - data)^2), summed in order        */
-  ABZ_SIM_LV = 7
+  ABZ_SIM_LV = 7,
+  /* "Tiny data, ABC and the socks of Karl Broman" (test/runtests.jl:427-437): theta = (n_socks, prop_pairs);
+   * n_pairs = round(prop_pairs floor(n_socks/2)), n_odd = n_socks - 2 n_pairs; pick min(n_socks, sim_p[2])
+   * socks without replacement (sequential uniform draws, Philox block t/2 word t%2 for pick t);
+   * dist = |pairs picked - sim_p[0]| + |odd socks picked - sim_p[1]|                               */
+  ABZ_SIM_SOCKS = 8
 };
 
 typedef struct abz_model {

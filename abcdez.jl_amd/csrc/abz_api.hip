@@ -6,8 +6,6 @@
 #include <stddef.h>
 #include <string.h>
 
-#include <mutex>
-
 #include "../../include/abcdez_hip.h"
 #include "abz_ctx.h"
 
@@ -79,11 +77,11 @@ int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
   ABZ_REQUIRE(is_pow2(model->ld) && model->ld >= model->d && model->ld < 2 * model->d + (model->d == 1),
               "ctx_create: ld must be the smallest power of two >= d");
   ABZ_REQUIRE(model->abck >= 0 && model->abck <= 3, "ctx_create: unknown ABC kernel id");
-  ABZ_REQUIRE(model->sim_id >= 0 && model->sim_id <= ABZ_SIM_LV, "ctx_create: unknown simulator id");
+  ABZ_REQUIRE(model->sim_id >= 0 && model->sim_id <= ABZ_SIM_SOCKS, "ctx_create: unknown simulator id");
   ABZ_REQUIRE(model->n_data >= 0 && (model->n_data == 0 || model->data), "ctx_create: data pointer missing");
   for (int k = 0; k < model->ld; ++k) {
     const int fam = model->prior[k].family;
-    ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_DUNIFORM, "ctx_create: unknown prior family");
+    ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_NEGBIN, "ctx_create: unknown prior family");
     ABZ_REQUIRE((k < model->d) == (fam != ABZ_PRIOR_PAD), "ctx_create: prior descriptor / d mismatch");
   }
   switch (model->sim_id) {
@@ -91,6 +89,9 @@ int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
     case ABZ_SIM_MVN: ABZ_REQUIRE(model->n_data >= model->d, "mvn: needs d data values"); break;
     case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: ABZ_REQUIRE(model->d == 1, "simulator needs d = 1"); break;
     case ABZ_SIM_QUAD2D: case ABZ_SIM_NORMDU: ABZ_REQUIRE(model->d == 2, "simulator needs d = 2"); break;
+    case ABZ_SIM_SOCKS:
+      ABZ_REQUIRE(model->d == 2 && model->sim_p[2] >= 1.0 && model->sim_p[2] <= 16.0, "socks: needs d = 2 and 1..16 picked socks");
+      break;
     case ABZ_SIM_WIENER: ABZ_REQUIRE(model->d == 2 && model->n_data >= 1, "wiener: needs d = 2 and data"); break;
     case ABZ_SIM_LV:
       ABZ_REQUIRE(model->d == 4 && model->n_data >= 2 && model->n_data % 2 == 0, "lv: needs d = 4 and (x,y) data");
@@ -390,7 +391,7 @@ int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) 
 
 int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
   ABZ_REQUIRE(ctx && x && y, "math_eval: null argument");
-  ABZ_REQUIRE(fn >= 0 && fn <= 9 && (y2 || (fn != 2 && fn != 6 && fn != 8)), "math_eval: bad function id / missing second array");
+  ABZ_REQUIRE(fn >= 0 && fn <= 10 && (y2 || (fn != 2 && fn != 6 && fn != 8)), "math_eval: bad function id / missing second array");
   return abz_math_eval_impl(ctx, fn, x, y, y2, n);
 }
 

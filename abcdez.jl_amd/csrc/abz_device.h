@@ -240,6 +240,31 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
       }
     }
     return abz_sqrt(acc);
+  } else if constexpr (SIM == ABZ_SIM_SOCKS) {
+    double ns = th[0];
+    if (!(ns >= 0.0)) return ABZ_NAN;
+    if (ns > 2147483647.0) ns = 2147483647.0;
+    const uint32_t n_socks = (uint32_t)ns;
+    const uint32_t n_pairs = (uint32_t)abz_rint(th[1] * abz_floor((double)n_socks * 0.5));
+    const uint32_t n_want = (uint32_t)M.sim_p[2];
+    const uint32_t m = n_socks < n_want ? n_socks : n_want;
+    uint32_t pos[16];
+    for (uint32_t t = 0; t < m; ++t) {
+      const abz_u64x2 w = abz_rng(seed, i, epoch, t >> 1, purpose);
+      uint32_t j = abz_randint((t & 1) ? w.w1 : w.w0, n_socks - t);
+      uint32_t at = 0;
+      while (at < t && j >= pos[at]) { ++j; ++at; }
+      for (uint32_t q = t; q > at; --q) pos[q] = pos[q - 1];
+      pos[at] = j;
+    }
+    uint32_t uniq = 0;
+    for (uint32_t t = 0; t < m; ++t) {
+      const uint32_t id = pos[t] < 2 * n_pairs ? pos[t] >> 1 : pos[t] - n_pairs;
+      const uint32_t idp = t ? (pos[t - 1] < 2 * n_pairs ? pos[t - 1] >> 1 : pos[t - 1] - n_pairs) : 0xFFFFFFFFu;
+      uniq += (t == 0) || (id != idp);
+    }
+    const double pairs = (double)(m - uniq), odds = (double)uniq - (double)(m - uniq);
+    return __builtin_fabs(pairs - M.sim_p[0]) + __builtin_fabs(odds - M.sim_p[1]);
   } else {
     return ABZ_NAN;
   }

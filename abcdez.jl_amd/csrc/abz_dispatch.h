@@ -15,10 +15,10 @@ template <int V> using IC = std::integral_constant<int, V>;
   X(ABZ_SIM_MVN, 1, 1) X(ABZ_SIM_MVN, 1, 2) X(ABZ_SIM_MVN, 1, 4) X(ABZ_SIM_MVN, 2, 2)    \
   X(ABZ_SIM_MVN, 2, 4) X(ABZ_SIM_MVN, 4, 2) X(ABZ_SIM_MVN, 4, 4) X(ABZ_SIM_MVN, 8, 2)    \
   X(ABZ_SIM_MVN, 8, 4) X(ABZ_SIM_MVN, 4, 8) X(ABZ_SIM_MVN, 16, 2) X(ABZ_SIM_MVN, 16, 4)  \
-  X(ABZ_SIM_MVN, 2, 16) X(ABZ_SIM_MVN, 1, 8) X(ABZ_SIM_MVN, 1, 16) X(ABZ_SIM_MVN, 4, 16) X(ABZ_SIM_MVN, 2, 8)                                          \
+  X(ABZ_SIM_MVN, 2, 16) X(ABZ_SIM_MVN, 1, 8) X(ABZ_SIM_MVN, 1, 16) X(ABZ_SIM_MVN, 4, 16) X(ABZ_SIM_MVN, 2, 8) X(ABZ_SIM_MVN, 8, 8)                                          \
   X(ABZ_SIM_NORMAL1D, 1, 1) X(ABZ_SIM_DIRAC, 1, 1) X(ABZ_SIM_MIXTURE, 1, 1)              \
   X(ABZ_SIM_QUAD2D, 1, 2) X(ABZ_SIM_NORMDU, 1, 2) X(ABZ_SIM_WIENER, 1, 2)                \
-  X(ABZ_SIM_LV, 1, 4)
+  X(ABZ_SIM_LV, 1, 4) X(ABZ_SIM_SOCKS, 1, 2)
 
 template <class F>
 static inline bool abz_dispatch(int sim, int L, int C, F&& f) {

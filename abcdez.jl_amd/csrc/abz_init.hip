@@ -38,6 +38,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void init_kernel(const HotModel M, doubl
       double z0, z1;
       abz_normal_pair(w, &s_model.tab, &z0, &z1);
       th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
+      if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_ext(&pd[0], seed, i, retry, 0u, &s_model.tab);
     } else {
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) {
@@ -47,6 +48,10 @@ __global__ __launch_bounds__(ABZ_BLOCK) void init_kernel(const HotModel M, doubl
         const int k = Lay<L, C>::comp(j, m, 0);
         th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
         th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
+        if (pd[k].family >= ABZ_PRIOR_BETA)
+          th[2 * m] = abz_prior_draw_ext(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab);
+        if (pd[k + 1].family >= ABZ_PRIOR_BETA)
+          th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
       }
     }
     lp = group_logprior<L, C>(pd, j, th, pp);

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_
     case 7: y[i] = abz_log_tab(x[i], T); break;
     case 8: { double s, c; abz_sincos2pi_tab(x[i], T, &s, &c); y[i] = s; y2[i] = c; break; }
     case 9: y[i] = abz_sqrt_pn(x[i]); break;
+    case 10: y[i] = abz_lgamma(x[i]); break;
     default: y[i] = x[i] / y2[i]; break;
   }
 }

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 from .kernels import IndicatorStrict0toϵ, kernel_kind
-from .priors import PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
+from .priors import PRIOR_NEGBIN, PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
 from .simulators import DeviceSimulator
 
 MAX_D = 64
@@ -77,6 +77,7 @@ class ModelSpec:
         self.data = np.ascontiguousarray(np.asarray(sim.data(), dtype=np.float64))
         self.discrete = tuple(bool(f.discrete) for f in factors)
         self._desc = [f.descriptor() for f in factors]
+        self._c1 = [f.c1() if f.family == PRIOR_NEGBIN else None for f in factors]
 
     def cstruct(self, data_ptr: Optional[int]) -> Model:
         m = Model()
@@ -94,5 +95,5 @@ class ModelSpec:
                 fam, disc, p0, p1, c0 = PRIOR_PAD, 0, 0.0, 0.0, 0.0
             m.prior[k].family, m.prior[k].discrete = fam, disc
             m.prior[k].p0, m.prior[k].p1, m.prior[k].c0 = p0, p1, c0
-            m.prior[k].c1 = 1.0 / p1 if fam == PRIOR_NORMAL else 0.0
+            m.prior[k].c1 = 1.0 / p1 if fam == PRIOR_NORMAL else (self._c1[k] if fam == PRIOR_NEGBIN else 0.0)
         return m

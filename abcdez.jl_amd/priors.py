@@ -13,7 +13,7 @@ from dataclasses import dataclass
 from typing import Sequence, Tuple, Union
 
 # family ids -- keep in sync with csrc/abcdez_spec.h (ABZ_PRIOR_*)
-PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM = 0, 1, 2, 3
+PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM, PRIOR_BETA, PRIOR_NEGBIN = 0, 1, 2, 3, 4, 5
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
@@ -114,6 +114,78 @@ class DiscreteUniform(UnivariateDistribution):
 
     def descriptor(self):
         return (PRIOR_DUNIFORM, 1, float(self.a), float(self.b), -math.log(self.b - self.a + 1))
+
+
+@dataclass(frozen=True)
+class Beta(UnivariateDistribution):
+    """Beta(α, β) on [0, 1] (prior of the Socks problem, test/runtests.jl:445)."""
+
+    alpha: float = 1.0
+    beta: float = 1.0
+    family = PRIOR_BETA
+
+    def __post_init__(self):
+        if not (self.alpha > 0 and self.beta > 0):
+            raise ValueError("Beta: need α, β > 0")
+
+    def _logB(self) -> float:
+        return math.lgamma(self.alpha) + math.lgamma(self.beta) - math.lgamma(self.alpha + self.beta)
+
+    def insupport(self, x: float) -> bool:
+        return 0.0 <= x <= 1.0
+
+    def logpdf(self, x: float) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        t1 = 0.0 if self.alpha == 1 else ((self.alpha - 1) * math.log(x) if x > 0 else -math.inf * (self.alpha - 1))
+        t2 = 0.0 if self.beta == 1 else ((self.beta - 1) * math.log(1 - x) if x < 1 else -math.inf * (self.beta - 1))
+        return t1 + t2 - self._logB()
+
+    def pdf(self, x: float) -> float:
+        return math.exp(self.logpdf(x))
+
+    def rand(self, rng) -> float:
+        return float(rng.beta(self.alpha, self.beta))
+
+    def descriptor(self):
+        return (PRIOR_BETA, 0, float(self.alpha), float(self.beta), -self._logB())
+
+
+@dataclass(frozen=True)
+class NegativeBinomial(UnivariateDistribution):
+    """NegativeBinomial(r, p): failures before the r-th success, real r > 0 (Distributions.jl convention;
+    prior of the Socks problem, test/runtests.jl:443-444)."""
+
+    r: float = 1.0
+    p: float = 0.5
+    family = PRIOR_NEGBIN
+    discrete = True
+
+    def __post_init__(self):
+        if not (self.r > 0 and 0 < self.p <= 1):
+            raise ValueError("NegativeBinomial: need r > 0 and 0 < p <= 1")
+
+    def insupport(self, x) -> bool:
+        return x >= 0 and float(x) == _rint(float(x))
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        k = float(x)
+        return (math.lgamma(k + self.r) - math.lgamma(k + 1) - math.lgamma(self.r) + self.r * math.log(self.p)
+                + (k * math.log1p(-self.p) if self.p < 1 else (0.0 if k == 0 else -math.inf)))
+
+    def pdf(self, x) -> float:
+        return math.exp(self.logpdf(x))
+
+    def rand(self, rng) -> int:
+        return int(rng.negative_binomial(self.r, self.p))
+
+    def descriptor(self):
+        return (PRIOR_NEGBIN, 1, float(self.r), float(self.p), self.r * math.log(self.p) - math.lgamma(self.r))
+
+    def c1(self) -> float:
+        return math.log1p(-self.p) if self.p < 1 else -math.inf
 
 
 class Factored:

@@ -12,7 +12,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Sequence, Tuple
 
-SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENER, SIM_LV = range(8)
+SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENER, SIM_LV, SIM_SOCKS = range(9)
 
 
 class DeviceSimulator:
@@ -152,3 +152,18 @@ class LotkaVolterraRK4(DeviceSimulator):
 
     def data(self):
         return self.obs
+
+
+@dataclass(frozen=True)
+class Socks(DeviceSimulator):
+    """"Tiny data, ABC and the socks of Karl Broman" (test/runtests.jl:427-437): θ = (n_socks, prop_pairs);
+    pick ``n_picked`` socks at random, count pairs and odd socks; dist = |pairs − data[0]| + |odds − data[1]|."""
+
+    pairs: float = 0.0
+    odds: float = 11.0
+    n_picked: int = 11
+    sim_id = SIM_SOCKS
+    ndim = 2
+
+    def params(self):
+        return (float(self.pairs), float(self.odds), float(self.n_picked))

@@ -59,6 +59,7 @@ ORC_API void orc_math_eval(int fn, const double* x, double* y, double* y2, int64
       case 7: y[i] = abz_log_tab(x[i], ORC_T); break;
       case 8: abz_sincos2pi_tab(x[i], ORC_T, &y[i], &y2[i]); break;
       case 9: y[i] = abz_sqrt_pn(x[i]); break;
+      case 10: y[i] = abz_lgamma(x[i]); break;
       default: y[i] = x[i] / (y2 ? y2[i] : 1.0); break;
     }
   }
@@ -203,6 +204,32 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       }
       return abz_sqrt(acc);
     }
+    case ABZ_SIM_SOCKS: {
+      double ns = th[0];
+      if (!(ns >= 0.0)) return ABZ_NAN;
+      if (ns > 2147483647.0) ns = 2147483647.0;
+      const uint32_t n_socks = (uint32_t)ns;
+      const uint32_t n_pairs = (uint32_t)abz_rint(th[1] * abz_floor((double)n_socks * 0.5));
+      const uint32_t n_want = (uint32_t)M->sim_p[2];
+      const uint32_t m = n_socks < n_want ? n_socks : n_want;
+      uint32_t pos[16];          /* picked positions, kept sorted */
+      for (uint32_t t = 0; t < m; ++t) {
+        abz_u64x2 w = abz_rng(seed, i, epoch, t >> 1, purpose);
+        uint32_t j = abz_randint((t & 1) ? w.w1 : w.w0, n_socks - t);    /* j-th not yet picked position */
+        uint32_t at = 0;
+        while (at < t && j >= pos[at]) { ++j; ++at; }
+        for (uint32_t q = t; q > at; --q) pos[q] = pos[q - 1];
+        pos[at] = j;
+      }
+      uint32_t uniq = 0;          /* sorted positions => equal sock ids are adjacent */
+      for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t id = pos[t] < 2 * n_pairs ? pos[t] >> 1 : pos[t] - n_pairs;
+        const uint32_t idp = t ? (pos[t - 1] < 2 * n_pairs ? pos[t - 1] >> 1 : pos[t - 1] - n_pairs) : 0xFFFFFFFFu;
+        uniq += (t == 0) || (id != idp);
+      }
+      const double pairs = (double)(m - uniq), odds = (double)uniq - (double)(m - uniq);
+      return fabs(pairs - M->sim_p[0]) + fabs(odds - M->sim_p[1]);
+    }
     default:
       return ABZ_NAN;
   }
@@ -220,6 +247,9 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
     abz_normal_pair(w, ORC_T, &z0, &z1);
     th[2 * m] = abz_prior_draw1(&M->prior[2 * m], w.w0, z0);
     if (2 * m + 1 < M->ld) th[2 * m + 1] = abz_prior_draw1(&M->prior[2 * m + 1], w.w1, z1);
+    for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c)
+      if (M->prior[2 * m + c].family >= ABZ_PRIOR_BETA)
+        th[2 * m + c] = abz_prior_draw_ext(&M->prior[2 * m + c], M->seed, i, retry, (uint32_t)(2 * m + c), ORC_T);
   }
 }
 /* fills rows [i0, i0+n) of the FULL arrays theta / logpi / delta */

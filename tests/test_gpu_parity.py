@@ -24,6 +24,8 @@ def models():
         "normdu": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.01),
         "dirac": (A.Normal(1, 0.2), A.DiracSquare(1.5), 0.1),
         "mixture": (A.Uniform(-10, 10), A.Mixture01(0.0), 0.01),
+        # test/runtests.jl:439-445: NegativeBinomial(mu 30, sd 15) x Beta(15, 2), rejection samplers at init
+        "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)), A.Socks(0, 11), 0.01),
     }
 
 
@@ -53,7 +55,7 @@ def assert_state_equal(hip, orc, what=""):
 # ---------------------------------------------------------------- spec arithmetic on the device
 @pytest.mark.parametrize("fn,gen", [
     (0, "pos"), (1, "exparg"), (2, "unit"), (3, "round"), (4, "round"), (5, "pos"), (6, "pair"),
-    (7, "posnormal"), (8, "unit52"), (9, "bmrange"),
+    (7, "posnormal"), (8, "unit52"), (9, "bmrange"), (10, "lgamma"),
 ])
 def test_math_bit_exact(oracle, fn, gen):
     rng = np.random.default_rng(100 + fn)
@@ -71,6 +73,8 @@ def test_math_bit_exact(oracle, fn, gen):
         n = 1 << 24                       # sqrt_pn replaces the compiler's expansion: check it hard
         x = np.exp(rng.uniform(-37.0, 4.4, n))     # -2 log u for u in [2^-53, 1)
         x[:4] = [2.0 ** -52, 73.5, 1.0, 2.0]
+    elif gen == "lgamma":
+        x = np.concatenate([rng.uniform(1e-3, 40, n // 2), np.exp(rng.uniform(0, 20, n // 2))])
     elif gen == "exparg":
         x = rng.uniform(-750, 710, n)
         x[:6] = [0.0, -np.inf, np.inf, -745.2, 709.8, 1e-300]
@@ -172,7 +176,7 @@ def test_stratified_resample_parity(oracle, N):
 # ---------------------------------------------------------------- S2/S3 sweeps incl. dead particles
 @pytest.mark.parametrize("name,lanes", [
     ("normal1d", 0), ("uniform1d", 0), ("mvn32", 0), ("mvn32", 4), ("mvn32", 16), ("mvn32", 8), ("mvn8", 0),
-    ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0),
+    ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0), ("socks", 0),
 ])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
 def test_smc_sweep_parity(oracle, name, lanes, abck):
@@ -200,7 +204,7 @@ def test_smc_sweep_parity(oracle, name, lanes, abck):
 
 
 # ---------------------------------------------------------------- S4
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac", "socks"])
 def test_mc_sweep_parity(oracle, name):
     N = 5000
     spec, hip, orc, eps_target = engines(name, N, oracle=oracle)
@@ -218,7 +222,7 @@ def test_mc_sweep_parity(oracle, name):
 
 # ---------------------------------------------------------------- whole drivers, product vs C restatement
 @pytest.mark.parametrize("name,N", [("normal1d", 5000), ("uniform1d", 5000), ("mvn8", 4096), ("mvn32", 8192),
-                                    ("quad2d_inf", 500), ("normdu", 100), ("dirac", 100)])
+                                    ("quad2d_inf", 500), ("normdu", 100), ("dirac", 100), ("socks", 3000)])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ])
 def test_abcdesmc_end_to_end_parity(oracle, name, N, abck):
     if name == "mvn32" and abck is not A.IndicatorStrict0toϵ:
@@ -271,11 +275,37 @@ def test_tiny_populations_end_to_end(oracle, N):
         assert np.array_equal(m.engine.result()["theta"], cm["theta"])
 
 
+@pytest.mark.parametrize("d", [2, 3, 5, 8, 16, 17, 40, 64])
+def test_every_row_width(oracle, d):
+    """d = 1..64 maps to ld = next power of two with zero padding (PAD prior family): every lane-group shape
+    the library picks by default, mixed prior families across the components"""
+    fams = [A.Normal(0.1 * k, 1.0 + 0.05 * k) if k % 3 else A.Uniform(-4.0, 4.0) for k in range(d)]
+    prior = A.Factored(*fams)
+    sim = A.MVNormal(tuple(0.3 + 0.01 * k for k in range(d)))
+    N = 2048
+    spec = A.ModelSpec(prior, sim, seed=d)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec))
+    orc = oracle.oracle_engine(spec, N)
+    hip.init_population(); orc.init_population()
+    assert_state_equal(hip, orc, f"init d={d}")
+    hip.reset_weights(); orc.reset_weights()
+    eps = orc.quantile_alive(0.6)
+    assert hip.quantile_alive(0.6) == eps
+    assert hip.smc_reweight(math.inf, eps) == orc.smc_reweight(math.inf, eps)
+    hip.alive_compact(); orc.alive_compact()
+    for _ in range(3):
+        assert hip.smc_swarm(eps, 2.38 / math.sqrt(2 * d), 1e-5) == orc.smc_swarm(eps, 2.38 / math.sqrt(2 * d), 1e-5)
+        assert_state_equal(hip, orc, f"sweep d={d}")
+    assert (hip.state[0][:, d:] == 0).all()                 # padding components stay exactly zero
+    hip.smc_resample(); orc.smc_resample()
+    assert_state_equal(hip, orc, f"resample d={d}")
+
+
 def test_run_that_ends_with_no_alive_particles(oracle):
     """a deterministic simulator with an unreachable target: the population dies out, the reference warns
     "No alive particles" and breaks (smc:375); GPU and oracle agree on where"""
     prior, sim = A.Normal(1, 0.2), A.DiracSquare(-5.0)      # |theta^2 + 1 + 5| >= 6 > eps
-    with pytest.warns(UserWarning, match="No alive particles") if False else __import__("contextlib").nullcontext():
+    with pytest.warns(UserWarning, match="No alive particles"):
         r = A.abcdesmc(prior, sim, 0.0, None, nparticles=200, verbose=False, rng=3, α=0.5)
     c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=3), 200, 0.0, alpha=0.5)
     assert r.iters == c["iters"]

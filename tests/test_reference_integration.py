@@ -188,3 +188,27 @@ def test_mvn_evidence_matches_noncentral_chi2(oracle):
     # eps = 2.5 is a wide tolerance: the ABC posterior mean lies between the prior mean 0 and the exact 0.5
     m = r.P[al].mean(0)
     assert (m > 0.2).all() and (m < 0.5).all()
+
+
+def _socks_prior():
+    """test/runtests.jl:439-445"""
+    prior_mu, prior_sd = 30, 15
+    prior_size = -prior_mu ** 2 / (prior_mu - prior_sd ** 2)
+    return A.Factored(A.NegativeBinomial(prior_size, prior_size / (prior_mu + prior_size)), A.Beta(15, 2))
+
+
+def test_socks_abcdemc(oracle):
+    """test/runtests.jl:425-454: NegativeBinomial x Beta prior, discrete parameter, integer distances"""
+    r = mc(oracle, _socks_prior(), A.Socks(0, 11), 0.01, nparticles=5000, generations=500, rng=14)
+    assert isaround(r.P[:, 0], 46.2) and isaround(r.P[:, 1], 0.866)
+    assert np.array_equal(r.P[:, 0], np.rint(r.P[:, 0])) and (r.P[:, 0] >= 0).all()
+    assert ((r.P[:, 1] >= 0) & (r.P[:, 1] <= 1)).all()
+    assert set(np.unique(r.C)) <= set(np.arange(0.0, 23.0))           # |pairs - 0| + |odds - 11| is an integer
+
+
+def test_socks_abcdesmc_strict_kernel(oracle):
+    """test/runtests.jl:456-491: eps = 0.01 with the strict kernel on integer distances => only exact matches survive"""
+    r = smc(oracle, _socks_prior(), A.Socks(0, 11), 0.01, nparticles=5000, ABCk=A.IndicatorStrict0toϵ, rng=15)
+    al = r.Wns > 0
+    assert isaround(r.P[al, 0], 46.2) and isaround(r.P[al, 1], 0.866)
+    assert (r.C[al] == 0).all()

@@ -229,3 +229,51 @@ def test_weight_fix_exact_cases(oracle):
     assert L.orc_weight_fix(0.0, N) == 0 and L.orc_weight_fix(float("nan"), N) == 0
     assert L.orc_weight_fix(1.0 / N, N) == 1 << 40 or abs(L.orc_weight_fix(1.0 / N, N) - (1 << 40)) <= 1
     assert L.orc_weight_fix(1.0, N) == N << 40
+
+
+def test_lgamma_accuracy(oracle):
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(0.01, 30, 2000), rng.uniform(30, 3000, 500), np.arange(1, 40, dtype=float), [1e-3, 0.5, 1.5, 4.615384615384615]])
+    y, _ = eval_fn(oracle, 10, x)
+    err = [abs(float(mpmath.mpf(float(b)) - mpmath.loggamma(mpmath.mpf(float(a))))) for a, b in zip(x, y)]
+    scale = [max(1.0, abs(float(mpmath.loggamma(mpmath.mpf(float(a)))))) for a in x]
+    assert max(e / s for e, s in zip(err, scale)) < 3e-14      # absolute for |lgamma| < 1, relative above
+
+
+def test_beta_negbin_logpdf_and_samplers(oracle):
+    """extended prior families against scipy: log-densities through the oracle's descriptor path, samplers through init"""
+    import ctypes as C
+
+    import abcdez_amd as A
+    from abcdez_amd.model import ModelSpec
+
+    nb, be = A.NegativeBinomial(4.615384615384615, 0.13333333333333333), A.Beta(15, 2)
+    L = oracle.lib()
+    L.orc_prior_logpdf1.restype = C.c_double
+    L.orc_prior_logpdf1.argtypes = [C.c_void_p, C.c_double]
+    spec = ModelSpec(A.Factored(nb, be), A.Socks(0, 11), seed=4)
+    m = oracle.OracleModel(spec)
+    pd0 = C.addressof(m.c.prior[0]); pd1 = C.addressof(m.c.prior[1])
+    for k in list(range(0, 200, 7)) + [0, 1, 2, 1000]:
+        assert abs(L.orc_prior_logpdf1(pd0, float(k)) - stats.nbinom.logpmf(k, nb.r, nb.p)) < 1e-12 * max(1, abs(stats.nbinom.logpmf(k, nb.r, nb.p)))
+        assert abs(nb.logpdf(k) - stats.nbinom.logpmf(k, nb.r, nb.p)) < 1e-11
+    assert L.orc_prior_logpdf1(pd0, -1.0) == -np.inf and L.orc_prior_logpdf1(pd0, 2.5) == -np.inf
+    for x in list(np.linspace(0.001, 0.999, 40)) + [0.5]:
+        assert abs(L.orc_prior_logpdf1(pd1, float(x)) - stats.beta.logpdf(x, 15, 2)) < 1e-12 * max(1, abs(stats.beta.logpdf(x, 15, 2)))
+        assert abs(be.logpdf(float(x)) - stats.beta.logpdf(x, 15, 2)) < 1e-11
+    assert L.orc_prior_logpdf1(pd1, 1.0001) == -np.inf and L.orc_prior_logpdf1(pd1, -0.1) == -np.inf
+    assert L.orc_prior_logpdf1(pd1, 0.0) == -np.inf               # alpha > 1: density 0 at x = 0
+    # samplers: the initial population is a sample from the prior (smc:242)
+    N = 40000
+    eng = oracle.oracle_engine(spec, N)
+    eng.init_population()
+    th = eng.state[0].numpy()
+    assert stats.kstest(th[:, 1], "beta", args=(15, 2)).pvalue > 1e-3
+    k = th[:, 0]
+    assert np.array_equal(k, np.rint(k)) and k.min() >= 0
+    assert abs(k.mean() - 30) < 0.4 and abs(k.std() - 15) < 0.4     # NegBin(mu = 30, sd = 15), test/runtests.jl:439-441
+    obs = np.bincount(k.astype(int), minlength=150)[:100]
+    exp = stats.nbinom.pmf(np.arange(100), nb.r, nb.p) * N
+    keep = exp > 20
+    assert stats.chisquare(obs[keep] * exp[keep].sum() / obs[keep].sum(), exp[keep]).pvalue > 1e-4
