@@ -191,6 +191,9 @@ def test_smc_sweep_parity(oracle, name, lanes, abck):
         assert hip.quantile_alive(0.8) == q
         eps = min(q, eps_old)
         rh, ro = hip.smc_reweight(eps_old, eps), orc.smc_reweight(eps_old, eps)
+        assert rh[2] == ro[2]
+        if ro[2] < 3:        # integer distances + strict kernel can wipe the population out (wnorm = 0 -> NaN weights)
+            break
         assert rh == ro
         if gen == 2:
             hip.smc_resample(); orc.smc_resample()
