@@ -16,7 +16,7 @@ from .kernels import (  # noqa: F401
 from .model import ModelSpec  # noqa: F401
 from .priors import Beta, DiscreteUniform, Factored, NegativeBinomial, Normal, Uniform, push_p  # noqa: F401
 from .simulators import (  # noqa: F401
-    DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, WienerRMS,
+    DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, UserSimulator, WienerRMS,
 )
 from .smc import abcdesmc, get_ess, quantile_type7, wsample_stratified  # noqa: F401
 from .mc import abcdemc  # noqa: F401

@@ -18,6 +18,7 @@ _pi64, _pf64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
 # name -> argtypes (every function returns int status unless noted)
 PROTOTYPES = {
     "abcdez_ctx_create": [C.POINTER(Model), C.c_int, C.POINTER(_vp)],
+    "abcdez_ctx_create_user": [C.POINTER(Model), C.c_char_p, C.c_int, C.POINTER(_vp)],
     "abcdez_ctx_destroy": [_vp],
     "abcdez_ctx_set_stream": [_vp, _vp],
     "abcdez_ctx_set_lanes": [_vp, C.c_int],

@@ -557,7 +557,10 @@ enum {
    * n_pairs = round(prop_pairs floor(n_socks/2)), n_odd = n_socks - 2 n_pairs; pick min(n_socks, sim_p[2])
    * socks without replacement (sequential uniform draws, Philox block t/2 word t%2 for pick t);
    * dist = |pairs picked - sim_p[0]| + |odd socks picked - sim_p[1]|                               */
-  ABZ_SIM_SOCKS = 8
+  ABZ_SIM_SOCKS = 8,
+  /* user-supplied device function compiled at run time (abcdez_ctx_create_user); the whole row lives in
+   * one thread; d <= 16                                                                             */
+  ABZ_SIM_USER = 9
 };
 
 typedef struct abz_model {

@@ -71,13 +71,15 @@ extern "C" {
 int abcdez_version(void) { return 100; }
 const char* abcdez_last_error(void) { return g_err.c_str(); }
 
-int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
+static int ctx_create_common(const abz_model* model, const char* user_source, int device, abcdez_ctx** out) {
   ABZ_REQUIRE(model && out, "ctx_create: null argument");
+  ABZ_REQUIRE((model->sim_id == ABZ_SIM_USER) == (user_source != nullptr),
+              "ctx_create: ABZ_SIM_USER needs abcdez_ctx_create_user with a source, built-in simulators abcdez_ctx_create");
   ABZ_REQUIRE(model->d >= 1 && model->d <= ABZ_MAX_D, "ctx_create: d out of range");
   ABZ_REQUIRE(is_pow2(model->ld) && model->ld >= model->d && model->ld < 2 * model->d + (model->d == 1),
               "ctx_create: ld must be the smallest power of two >= d");
   ABZ_REQUIRE(model->abck >= 0 && model->abck <= 3, "ctx_create: unknown ABC kernel id");
-  ABZ_REQUIRE(model->sim_id >= 0 && model->sim_id <= ABZ_SIM_SOCKS, "ctx_create: unknown simulator id");
+  ABZ_REQUIRE(model->sim_id >= 0 && model->sim_id <= ABZ_SIM_USER, "ctx_create: unknown simulator id");
   ABZ_REQUIRE(model->n_data >= 0 && (model->n_data == 0 || model->data), "ctx_create: data pointer missing");
   for (int k = 0; k < model->ld; ++k) {
     const int fam = model->prior[k].family;
@@ -89,6 +91,7 @@ int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
     case ABZ_SIM_MVN: ABZ_REQUIRE(model->n_data >= model->d, "mvn: needs d data values"); break;
     case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: ABZ_REQUIRE(model->d == 1, "simulator needs d = 1"); break;
     case ABZ_SIM_QUAD2D: case ABZ_SIM_NORMDU: ABZ_REQUIRE(model->d == 2, "simulator needs d = 2"); break;
+    case ABZ_SIM_USER: ABZ_REQUIRE(model->d <= 16, "user simulator: d must be <= 16 (whole row in one thread)"); break;
     case ABZ_SIM_SOCKS:
       ABZ_REQUIRE(model->d == 2 && model->sim_p[2] >= 1.0 && model->sim_p[2] <= 16.0, "socks: needs d = 2 and 1..16 picked socks");
       break;
@@ -126,14 +129,28 @@ int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
   ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
   ABZ_HIP_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
   ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
+  if (user_source) {
+    const int rc = abz_jit_build(ctx, user_source);
+    if (rc) { abcdez_ctx_destroy(ctx); return rc; }
+  }
   *out = ctx;
   return 0;
+}
+
+int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out) {
+  return ctx_create_common(model, nullptr, device, out);
+}
+
+int abcdez_ctx_create_user(const abz_model* model, const char* user_source, int device, abcdez_ctx** out) {
+  ABZ_REQUIRE(user_source, "ctx_create_user: null source");
+  return ctx_create_common(model, user_source, device, out);
 }
 
 int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  abz_jit_destroy(ctx);
   if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->cnt) (void)hipFree(ctx->cnt);

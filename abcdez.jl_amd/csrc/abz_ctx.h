@@ -9,18 +9,7 @@
 #include <string>
 
 #include "abcdez_spec.h"
-
-/* ---- the model fields the kernels touch, passed BY VALUE in the kernel arguments so they
- * arrive through scalar loads of the kernarg segment instead of a chain of dependent
- * global loads (the first build spent 80 % of its wave-cycles waiting on those).          */
-struct HotModel {
-  uint64_t seed;
-  const abz_prior_dim* prior;   /* device, ld entries */
-  const double* data;           /* device, n_data values */
-  const abz_tables* tables;     /* device copy of the sampler tables */
-  double sim_p[8];
-  int32_t d, abck, n_data, reserved;
-};
+#include "abz_hotmodel.h"
 
 struct abcdez_ctx {
   int device = 0;
@@ -37,6 +26,8 @@ struct abcdez_ctx {
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  /* hiprtc-compiled kernels of a user-supplied simulator (abz_jit.hip), else null */
+  void* user_module = nullptr;
   /* per-block (nacc, nsim) partials of the sweep kernels */
   void* cnt = nullptr;
   size_t cnt_bytes = 0;
@@ -84,5 +75,10 @@ int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t,
                                const double*, const double*, double*, double*, double*, double*, uint8_t*);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, unsigned long long* d_out);
+int abz_jit_build(abcdez_ctx*, const char* user_source);
+void abz_jit_destroy(abcdez_ctx*);
+int abz_jit_launch_init(abcdez_ctx*, double*, double*, double*, uint32_t, uint32_t, unsigned long long*);
+int abz_jit_launch_smc(abcdez_ctx*, const void* args, unsigned nblocks);
+int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned nblocks);
 
 #endif

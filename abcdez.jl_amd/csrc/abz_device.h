@@ -13,11 +13,13 @@
 #ifndef ABZ_DEVICE_H
 #define ABZ_DEVICE_H
 
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "abcdez_spec.h"
-#include "abz_ctx.h"
+#include "abz_hotmodel.h"
 
 #define ABZ_BLOCK 256
 
@@ -143,6 +145,23 @@ __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entri
   return group_tree_sum<L, C>(lp);
 }
 
+/* ---- user-supplied simulator (ABZ_SIM_USER): compiled at run time with hiprtc together with these
+ * headers (abz_jit.hip).  The user source defines abz_user_dist; randomness comes from abz_user_rng,
+ * which hands out consecutive Philox blocks of the particle's (index, epoch, purpose) stream, so a
+ * user simulator is as reproducible and launch-shape independent as the built-in ones.            */
+struct abz_user_rng {
+  uint64_t seed;
+  uint32_t i, epoch, purpose, sub;
+  const abz_tables* T;
+  __device__ inline abz_u64x2 block() { return abz_rng(seed, i, epoch, sub++, purpose); }
+  __device__ inline double uniform() { return abz_u01_co(block().w0); }              /* [0, 1)          */
+  __device__ inline uint64_t bits() { return block().w0; }
+  __device__ inline void normal_pair(double& z0, double& z1) { abz_normal_pair(block(), T, &z0, &z1); }
+  __device__ inline double normal() { double a, b; normal_pair(a, b); return a; }
+};
+__device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                                abz_user_rng& rng);
+
 /* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
 template <int SIM, int L, int C>
 __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j, const double (&th)[C],
@@ -240,6 +259,10 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
       }
     }
     return abz_sqrt(acc);
+  } else if constexpr (SIM == ABZ_SIM_USER) {
+    static_assert(L == 1, "user simulators see the whole row in one thread");
+    abz_user_rng rng{seed, i, epoch, purpose, 0u, T};
+    return abz_user_dist(th, M.d, M.data, M.n_data, M.sim_p, rng);
   } else if constexpr (SIM == ABZ_SIM_SOCKS) {
     double ns = th[0];
     if (!(ns >= 0.0)) return ABZ_NAN;

@@ -32,6 +32,23 @@ static inline bool abz_dispatch(int sim, int L, int C, F&& f) {
   return false;
 }
 
+/* simulator-independent kernels: dispatch on the lane-group shape / the row width only */
+template <class F>
+static inline bool abz_dispatch_lc(int L, int C, F&& f) {
+#define ABZ_Y(LL, CC) if (L == LL && C == CC) { f(IC<LL>{}, IC<CC>{}); return true; }
+  ABZ_Y(1, 1) ABZ_Y(1, 2) ABZ_Y(1, 4) ABZ_Y(1, 8) ABZ_Y(1, 16) ABZ_Y(2, 2) ABZ_Y(2, 4) ABZ_Y(2, 8) ABZ_Y(2, 16)
+  ABZ_Y(4, 2) ABZ_Y(4, 4) ABZ_Y(4, 8) ABZ_Y(4, 16) ABZ_Y(8, 2) ABZ_Y(8, 4) ABZ_Y(8, 8) ABZ_Y(16, 2) ABZ_Y(16, 4)
+#undef ABZ_Y
+  return false;
+}
+template <class F>
+static inline bool abz_dispatch_ld(int ld, F&& f) {
+#define ABZ_Z(V) if (ld == V) { f(IC<V>{}); return true; }
+  ABZ_Z(1) ABZ_Z(2) ABZ_Z(4) ABZ_Z(8) ABZ_Z(16) ABZ_Z(32) ABZ_Z(64)
+#undef ABZ_Z
+  return false;
+}
+
 static inline unsigned abz_grid(uint64_t threads) { return (unsigned)((threads + ABZ_BLOCK - 1) / ABZ_BLOCK); }
 
 #endif

@@ -1,0 +1,110 @@
+/*
+ * abz_jit.hip -- user-supplied simulators.
+ *
+ * The reference calls an arbitrary closure dist!(theta, ve) (src/abcdez_smc.jl:137).  The closest
+ * a GPU library can offer is a device function supplied as source text:
+ *
+ *     __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
+ *                                     const double* sim_p, abz_user_rng& rng);
+ *
+ * compiled here with hiprtc together with the very same kernel bodies the built-in simulators use
+ * (abz_kernels.h), -ffp-contract=off like the rest of the library.  theta arrives push_p-cast.
+ */
+#include <hip/hiprtc.h>
+
+#include <string>
+#include <vector>
+
+#include "abz_ctx.h"
+#include "abz_jit_sources.h"
+#include "abz_kernels.h"
+
+struct AbzUserModule {
+  hipModule_t mod = nullptr;
+  hipFunction_t f_init = nullptr, f_smc = nullptr, f_mc = nullptr;
+};
+
+#define ABZ_RTC_CHECK(expr)                                                                \
+  do {                                                                                     \
+    hiprtcResult _r = (expr);                                                              \
+    if (_r != HIPRTC_SUCCESS) {                                                            \
+      abz_set_error(std::string(#expr) + ": " + hiprtcGetErrorString(_r));                 \
+      return -4;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
+  const int C = ctx->h_model.ld;
+  std::string tu = "#include \"abz_kernels.h\"\n#line 1 \"user_simulator\"\n";
+  tu += user_source;
+  tu += "\n#line 1 \"abz_user_entry\"\n";
+  tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_init(const HotModel M, double* theta, "
+        "double* logpi, double* delta, uint32_t i0, uint32_t n, unsigned long long* bad) {\n"
+        "  init_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad);\n}\n"
+        "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc(const SmcSwarmArgs a) {\n"
+        "  smc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
+        "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_mc(const McSwarmArgs a) {\n"
+        "  mc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n";
+  hiprtcProgram prog;
+  ABZ_RTC_CHECK(hiprtcCreateProgram(&prog, tu.c_str(), "abz_user.hip", abz_jit_n_headers, (const char**)abz_jit_header_sources,
+                                    (const char**)abz_jit_header_names));
+  hipDeviceProp_t prop;
+  ABZ_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+  std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const size_t colon = arch.find(':');                 /* "gfx950:sramecc+:xnack-" -> "gfx950" */
+  if (colon != std::string::npos) arch = arch.substr(0, colon);
+  const std::string defc = "-DABZ_USER_C=" + std::to_string(C);
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", defc.c_str()};
+  const hiprtcResult cr = hiprtcCompileProgram(prog, 6, opts);
+  if (cr != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    abz_set_error("user simulator does not compile:\n" + log);
+    return -4;
+  }
+  size_t cs = 0;
+  ABZ_RTC_CHECK(hiprtcGetCodeSize(prog, &cs));
+  std::vector<char> code(cs);
+  ABZ_RTC_CHECK(hiprtcGetCode(prog, code.data()));
+  hiprtcDestroyProgram(&prog);
+  AbzUserModule* um = new AbzUserModule();
+  ABZ_HIP_CHECK(hipModuleLoadData(&um->mod, code.data()));
+  ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_init, um->mod, "abz_user_init"));
+  ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smc, um->mod, "abz_user_smc"));
+  ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_mc, um->mod, "abz_user_mc"));
+  ctx->user_module = um;
+  return 0;
+}
+
+void abz_jit_destroy(abcdez_ctx* ctx) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  if (!um) return;
+  if (um->mod) (void)hipModuleUnload(um->mod);
+  delete um;
+  ctx->user_module = nullptr;
+}
+
+int abz_jit_launch_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, uint32_t i0, uint32_t n,
+                        unsigned long long* bad) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  HotModel M = ctx->hot;
+  void* params[] = {&M, &theta, &logpi, &delta, &i0, &n, &bad};
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
+                                      params, nullptr));
+  return 0;
+}
+int abz_jit_launch_smc(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  void* params[] = {const_cast<void*>(args)};
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smc, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  return 0;
+}
+int abz_jit_launch_mc(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  void* params[] = {const_cast<void*>(args)};
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_mc, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  return 0;
+}

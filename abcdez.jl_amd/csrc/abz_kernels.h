@@ -1,0 +1,248 @@
+/*
+ * abz_kernels.h -- bodies of the simulator-dependent kernels (initial population, SMC sweep, MC sweep)
+ * as __device__ function templates.  The library instantiates them for the built-in simulators
+ * (abz_init.hip, abz_smc_swarm.hip, abz_mc_swarm.hip); abz_jit.hip compiles the same text with
+ * hiprtc around a user-supplied abz_user_dist.
+ */
+#ifndef ABZ_KERNELS_H
+#define ABZ_KERNELS_H
+
+#include "abz_device.h"
+
+/* ================================================================ S1: abcde_init! (src/abcdez_init.jl:2-22) */
+#define ABZ_MAX_RETRY 100000u
+
+template <int SIM, int L, int C>
+__device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ theta,
+                                                         double* __restrict__ logpi, double* __restrict__ delta,
+                                                         uint32_t i0, uint32_t n, unsigned long long* __restrict__ bad) {
+  constexpr int LD = L * C;
+  __shared__ ModelLds<LD> s_model;
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
+  __syncthreads();
+  const abz_prior_dim* pd = s_model.prior;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  if (grp >= n) return;                       /* whole groups leave together */
+  const uint32_t i = i0 + grp;
+  const uint64_t seed = M.seed;
+  double th[C], pp[C];
+  double lp, dl;
+  uint32_t retry = 0;
+  for (;;) {
+    if constexpr (C == 1) {
+      const abz_u64x2 w = abz_rng(seed, i, retry, 0, ABZ_RNG_INIT_PRIOR);
+      double z0, z1;
+      abz_normal_pair(w, &s_model.tab, &z0, &z1);
+      th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
+      if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_ext(&pd[0], seed, i, retry, 0u, &s_model.tab);
+    } else {
+#pragma unroll
+      for (int m = 0; m < C / 2; ++m) {
+        const abz_u64x2 w = abz_rng(seed, i, retry, (uint32_t)(m * L + j), ABZ_RNG_INIT_PRIOR);
+        double z0, z1;
+        abz_normal_pair(w, &s_model.tab, &z0, &z1);
+        const int k = Lay<L, C>::comp(j, m, 0);
+        th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
+        th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
+        if (pd[k].family >= ABZ_PRIOR_BETA)
+          th[2 * m] = abz_prior_draw_ext(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab);
+        if (pd[k + 1].family >= ABZ_PRIOR_BETA)
+          th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
+      }
+    }
+    lp = group_logprior<L, C>(pd, j, th, pp);
+    dl = ABZ_NAN;
+    if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
+    if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
+    if (++retry >= ABZ_MAX_RETRY) {
+      if (j == 0) atomicAdd(bad, 1ull);
+      break;
+    }
+  }
+  store_row<L, C>(theta + (size_t)i * LD, j, th);
+  if (j == 0) { logpi[i] = lp; delta[i] = dl; }
+}
+
+/* ================================================================ S2+S3: abcdesmc_swarm! (src/abcdez_smc.jl:106-153) */
+struct SmcSwarmArgs {
+  HotModel hm;
+  const uint32_t* alive_idx;
+  const uint32_t* arank;
+  const double* theta;
+  const double* logpi;
+  const double* delta;
+  double* ntheta;
+  double* nlogpi;
+  double* ndelta;
+  uint2* partials;              /* per-block (nacc, nsim) */
+  uint8_t* row_synced;          /* per particle: both generations' theta rows are equal (may be NULL) */
+  double eps, gamma0, gsig;
+  uint32_t n_alive, r_lo, n_work, sweep;
+  uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
+};
+
+template <int SIM, int L, int C>
+__device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
+  constexpr int LD = L * C;
+  const HotModel& M = a.hm;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+  const uint32_t i = a.all_alive ? ri : a.alive_idx[ri];
+
+  __shared__ ModelLds<LD> s_model;
+
+  /* own row + state */
+  double ti[C];
+  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+  const double lpi = a.logpi[i];
+  const double dli = a.delta[i];
+  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
+  stage.load(M);
+
+  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged */
+  uint32_t ra, rb;
+  double g, log_u;
+  particle_draws<L>(&s_model.tab, M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+  const uint32_t ia = a.all_alive ? ra : a.alive_idx[ra];
+  const uint32_t ib = a.all_alive ? rb : a.alive_idx[rb];
+  double ta[C], tb[C];
+  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+
+  double tp[C], pp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+
+  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
+  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+  bool acc = false;
+  double dp = dli;
+  if (insupport) {
+    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
+    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
+  }
+  if (active) {                                                   /* smc:146-150 + copies :337-340 */
+    /* lazy copy: a rejected particle whose row is already identical in both generations'
+     * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
+    const bool synced = a.row_synced ? a.row_synced[i] != 0 : false;
+    if (acc || !synced) {
+      double to[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+      store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+    }
+    if (j == 0) {
+      a.nlogpi[i] = acc ? lp : lpi;
+      a.ndelta[i] = acc ? dp : dli;
+      if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
+    }
+  }
+  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
+}
+
+/* ================================================================ S4: abcdemc_swarm! (src/abcdez_mc.jl:5-61) */
+struct McSwarmArgs {
+  HotModel hm;
+  const uint32_t* order;
+  const double* sorted_delta;
+  const double* theta;
+  const double* logpi;
+  const double* delta;
+  double* ntheta;
+  double* nlogpi;
+  double* ndelta;
+  uint2* partials;
+  double eps_pop, eps_target, gamma0, gsig;
+  uint32_t N, i0, n_local, sweep;
+};
+
+__device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <int SIM, int L, int C>
+__device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
+  constexpr int LD = L * C;
+  const HotModel& M = a.hm;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_local;
+  const uint32_t i = a.i0 + (active ? grp : 0u);
+  const uint64_t seed = M.seed;
+  __shared__ ModelLds<LD> s_model;
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
+  __syncthreads();
+
+  const double lpi = a.logpi[i];
+  const double di = a.delta[i];
+  const double eps = di <= a.eps_target ? a.eps_target : a.eps_pop;       /* mc:19 */
+  uint32_t s = i;
+  if (di > eps) {                                                         /* mc:20-24 */
+    const uint32_t cnt = upper_bound_f64(a.sorted_delta, a.N, di);
+    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, cnt)];
+  }
+  uint32_t ia, ib;                                                        /* mc:25-32 */
+  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.N, s, &ia, &ib);
+
+  double ti[C], ts[C], ta[C], tb[C];
+  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+  load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
+  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+
+  double z0, z1;
+  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
+  const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
+  double tp[C], pp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
+
+  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                     /* mc:41 */
+  const double w_prior = lp - lpi;                                        /* mc:42 */
+  const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
+  double mn = w_prior < 0.0 ? w_prior : 0.0;
+  if (abz_isnan(w_prior)) mn = w_prior;
+  const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
+  bool acc = false;
+  double dp = di;
+  if (simulate) {
+    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
+    const double thr = eps > di ? eps : di;
+    acc = dp <= thr;                                                      /* mc:54 */
+  }
+  if (active) {
+    double to[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+    if (j == 0) {
+      a.nlogpi[i] = acc ? lp : lpi;
+      a.ndelta[i] = acc ? dp : di;
+    }
+  }
+  block_count2(false, active && j == 0 && simulate, a.partials);
+}
+
+#endif /* ABZ_KERNELS_H */

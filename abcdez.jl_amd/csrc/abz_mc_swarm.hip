@@ -8,97 +8,11 @@
  * the candidate set is order[0 .. cnt), cnt = upper_bound(sorted_delta, Ds[i]).
  */
 #include "abz_dispatch.h"
-
-struct McSwarmArgs {
-  HotModel hm;
-  const uint32_t* order;
-  const double* sorted_delta;
-  const double* theta;
-  const double* logpi;
-  const double* delta;
-  double* ntheta;
-  double* nlogpi;
-  double* ndelta;
-  uint2* partials;
-  double eps_pop, eps_target, gamma0, gsig;
-  uint32_t N, i0, n_local, sweep;
-};
-
-__device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (v[mid] <= x) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
+#include "abz_kernels.h"
 
 template <int SIM, int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a) {
-  constexpr int LD = L * C;
-  const HotModel& M = a.hm;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_local;
-  const uint32_t i = a.i0 + (active ? grp : 0u);
-  const uint64_t seed = M.seed;
-  __shared__ ModelLds<LD> s_model;
-  {
-    ModelStage<SIM, LD> stage;
-    stage.load(M);
-    stage.store(s_model);
-  }
-  __syncthreads();
-
-  const double lpi = a.logpi[i];
-  const double di = a.delta[i];
-  const double eps = di <= a.eps_target ? a.eps_target : a.eps_pop;       /* mc:19 */
-  uint32_t s = i;
-  if (di > eps) {                                                         /* mc:20-24 */
-    const uint32_t cnt = upper_bound_f64(a.sorted_delta, a.N, di);
-    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, cnt)];
-  }
-  uint32_t ia, ib;                                                        /* mc:25-32 */
-  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.N, s, &ia, &ib);
-
-  double ti[C], ts[C], ta[C], tb[C];
-  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
-  load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
-  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
-  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
-
-  double z0, z1;
-  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
-  const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
-  double tp[C], pp[C];
-#pragma unroll
-  for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
-
-  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                     /* mc:41 */
-  const double w_prior = lp - lpi;                                        /* mc:42 */
-  const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
-  double mn = w_prior < 0.0 ? w_prior : 0.0;
-  if (abz_isnan(w_prior)) mn = w_prior;
-  const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
-  bool acc = false;
-  double dp = di;
-  if (simulate) {
-    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
-    const double thr = eps > di ? eps : di;
-    acc = dp <= thr;                                                      /* mc:54 */
-  }
-  if (active) {
-    double to[C];
-#pragma unroll
-    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
-    if (j == 0) {
-      a.nlogpi[i] = acc ? lp : lpi;
-      a.ndelta[i] = acc ? dp : di;
-    }
-  }
-  block_count2(false, active && j == 0 && simulate, a.partials);
+  mc_swarm_kernel_body<SIM, L, C>(a);
 }
 
 int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, uint32_t N,
@@ -115,10 +29,14 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   a.partials = (uint2*)ctx->cnt;
   a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
-  bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
-    hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())), dim3(ABZ_BLOCK),
-                       0, ctx->stream, a);
-  });
+  bool ok = true;
+  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+    if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
+  } else {
+    ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
+      hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+    });
+  }
   if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
   return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
@@ -152,7 +70,7 @@ int abz_launch_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N
                                const double* theta, const double* logpi, const double* delta, double* ntheta,
                                double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
   if (n_local == 0) return 0;
-  bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto, auto LL, auto CC) {
+  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     hipLaunchKernelGGL((resample_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())),
                        dim3(ABZ_BLOCK), 0, ctx->stream, inds, N, i0, n_local, theta, logpi, delta, ntheta, nlogpi,
                        ndelta, wns, alive);

@@ -16,87 +16,11 @@
  * trips: alive_idx[rank] -> alive_idx[donor ranks] -> rows.
  */
 #include "abz_dispatch.h"
-
-struct SmcSwarmArgs {
-  HotModel hm;
-  const uint32_t* alive_idx;
-  const uint32_t* arank;
-  const double* theta;
-  const double* logpi;
-  const double* delta;
-  double* ntheta;
-  double* nlogpi;
-  double* ndelta;
-  uint2* partials;              /* per-block (nacc, nsim) */
-  uint8_t* row_synced;          /* per particle: both generations' theta rows are equal (may be NULL) */
-  double eps, gamma0, gsig;
-  uint32_t n_alive, r_lo, n_work, sweep;
-  uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
-};
+#include "abz_kernels.h"
 
 template <int SIM, int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_kernel(const SmcSwarmArgs a) {
-  constexpr int LD = L * C;
-  const HotModel& M = a.hm;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_work;
-  const uint32_t ri = a.r_lo + (active ? grp : 0u);
-  const uint32_t i = a.all_alive ? ri : a.alive_idx[ri];
-
-  __shared__ ModelLds<LD> s_model;
-
-  /* own row + state */
-  double ti[C];
-  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
-  const double lpi = a.logpi[i];
-  const double dli = a.delta[i];
-  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
-  stage.load(M);
-
-  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
-  stage.store(s_model);
-  __syncthreads();                                                /* sampler + model tables staged */
-  uint32_t ra, rb;
-  double g, log_u;
-  particle_draws<L>(&s_model.tab, M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
-  const uint32_t ia = a.all_alive ? ra : a.alive_idx[ra];
-  const uint32_t ib = a.all_alive ? rb : a.alive_idx[rb];
-  double ta[C], tb[C];
-  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
-  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
-
-  double tp[C], pp[C];
-#pragma unroll
-  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
-
-  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
-  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
-  bool acc = false;
-  double dp = dli;
-  if (insupport) {
-    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
-    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
-    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
-  }
-  if (active) {                                                   /* smc:146-150 + copies :337-340 */
-    /* lazy copy: a rejected particle whose row is already identical in both generations'
-     * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
-    const bool synced = a.row_synced ? a.row_synced[i] != 0 : false;
-    if (acc || !synced) {
-      double to[C];
-#pragma unroll
-      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-      store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
-    }
-    if (j == 0) {
-      a.nlogpi[i] = acc ? lp : lpi;
-      a.ndelta[i] = acc ? dp : dli;
-      if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
-    }
-  }
-  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
+  smc_swarm_kernel_body<SIM, L, C>(a);
 }
 
 /* dead rows of [i0, i0+n): carry generation t into generation t+1 (smc:337-340).
@@ -148,22 +72,28 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
   a.all_alive = (N_total != 0 && n_alive == N_total) ? 1u : 0u;
-  bool ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
-    if (copy_dead && n_local > 0) {
-      hipLaunchKernelGGL((copy_dead_kernel<LL() * CC()>), dim3(abz_grid((uint64_t)n_local)), dim3(ABZ_BLOCK), 0,
-                         ctx->stream, arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced);
+  bool ok = true;
+  if (copy_dead && n_local > 0) {
+    ok = abz_dispatch_ld(ctx->h_model.ld, [&](auto LD) {
+      hipLaunchKernelGGL((copy_dead_kernel<LD()>), dim3(abz_grid((uint64_t)n_local)), dim3(ABZ_BLOCK), 0, ctx->stream,
+                         arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced);
+    });
+  }
+  if (ok && a.n_work > 0) {
+    if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+      if (int rc = abz_jit_launch_smc(ctx, &a, nblocks)) return rc;
+    } else {
+      ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
+        hipLaunchKernelGGL((smc_swarm_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      });
     }
-    if (a.n_work > 0) {
-      if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
-      hipLaunchKernelGGL((smc_swarm_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)a.n_work * LL())),
-                         dim3(ABZ_BLOCK), 0, ctx->stream, a);
-      if (ctx->timing) {
-        (void)hipEventRecord(ctx->ev1, ctx->stream);
-        ctx->ev_pending = true;
-        ctx->ev_units = a.n_work;
-      }
+    if (ctx->timing) {
+      (void)hipEventRecord(ctx->ev1, ctx->stream);
+      ctx->ev_pending = true;
+      ctx->ev_units = a.n_work;
     }
-  });
+  }
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
   return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);

@@ -54,7 +54,12 @@ class HipOps:
         self._data_host = np.ascontiguousarray(spec.data, dtype=np.float64)
         cm = spec.cstruct(self._data_host.ctypes.data if self._data_host.size else None)
         ctx = C.c_void_p()
-        _lib.check(self.lib, self.lib.abcdez_ctx_create(C.byref(cm), device_index, C.byref(ctx)))
+        source = getattr(spec.sim, "source", None)
+        if source is not None:      # user-supplied simulator: compiled by the library with hiprtc
+            _lib.check(self.lib, self.lib.abcdez_ctx_create_user(C.byref(cm), source.encode("utf-8"), device_index,
+                                                                 C.byref(ctx)))
+        else:
+            _lib.check(self.lib, self.lib.abcdez_ctx_create(C.byref(cm), device_index, C.byref(ctx)))
         self.ctx = ctx
         if lanes:
             _lib.check(self.lib, self.lib.abcdez_ctx_set_lanes(self.ctx, lanes))

@@ -12,7 +12,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Sequence, Tuple
 
-SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENER, SIM_LV, SIM_SOCKS = range(9)
+SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENER, SIM_LV, SIM_SOCKS, SIM_USER = range(10)
 
 
 class DeviceSimulator:
@@ -167,3 +167,34 @@ class Socks(DeviceSimulator):
 
     def params(self):
         return (float(self.pairs), float(self.odds), float(self.n_picked))
+
+
+class UserSimulator(DeviceSimulator):
+    """A simulator supplied as HIP source text -- the device counterpart of the reference's
+    ``dist!(θ, ve)`` closure.  ``source`` must define::
+
+        __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
+                                        const double* sim_p, abz_user_rng& rng);
+
+    ``theta`` arrives ``push_p``-cast; ``data`` / ``sim_p`` are the arrays given here (``varexternal``'s role);
+    ``rng.uniform()``, ``rng.normal()``, ``rng.normal_pair(z0, z1)``, ``rng.bits()`` draw from the particle's
+    counter-based stream.  Compiled with hiprtc when the engine is created (length(prior) <= 16).
+    """
+
+    sim_id = SIM_USER
+    ndim = None
+
+    def __init__(self, source: str, params: Sequence[float] = (), data: Sequence[float] = ()):
+        if "abz_user_dist" not in source:
+            raise ValueError("the source must define abz_user_dist")
+        if len(params) > 8:
+            raise ValueError("at most 8 scalar parameters (sim_p)")
+        self.source = str(source)
+        self._params = tuple(float(v) for v in params)
+        self._data = tuple(float(v) for v in data)
+
+    def params(self):
+        return self._params
+
+    def data(self):
+        return self._data

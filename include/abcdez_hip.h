@@ -41,6 +41,16 @@ ABCDEZ_API const char* abcdez_last_error(void);
  * (src/abcdez_smc.jl:106-109, src/abcdez_mc.jl:5-6, src/abcdez_init.jl:2).
  * `model->data` is a HOST pointer here; it is copied to the device.             */
 ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out);
+/* The same with a user-supplied simulator (model->sim_id == ABZ_SIM_USER, d <= 16): `user_source` is HIP
+ * source text defining
+ *     __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
+ *                                     const double* sim_p, abz_user_rng& rng);
+ * (theta push_p-cast; rng.uniform() / rng.normal() / rng.normal_pair(z0, z1) / rng.bits() hand out the
+ * particle's Philox stream).  It is compiled with hiprtc for the device's architecture together with the
+ * library's own kernel bodies; a compile error comes back as a negative status with the compiler log in
+ * abcdez_last_error().  This is the device counterpart of the reference's dist!(theta, ve) closure
+ * (src/abcdez_smc.jl:137, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17).                               */
+ABCDEZ_API int abcdez_ctx_create_user(const abz_model* model, const char* user_source, int device, abcdez_ctx** out);
 ABCDEZ_API int abcdez_ctx_destroy(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */

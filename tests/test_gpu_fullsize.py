@@ -288,3 +288,79 @@ def test_epanechnikov_kernel_at_scale(oracle):
     wh = np.ascontiguousarray(r.Wns)
     oracle.lib().orc_wsample_stratified(8, wh.ctypes.data, N, 0, ref.ctypes.data)
     assert np.array_equal(inds, ref.astype(np.int64))
+
+
+USER_NORMAL1D = """
+__device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                                abz_user_rng& rng) {
+  double z0, z1;
+  rng.normal_pair(z0, z1);
+  const double x = __builtin_fma(sim_p[0], z0, theta[0]);
+  return __builtin_fabs(x - data[0]);
+}
+"""
+USER_QUAD2D = """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  double n1, n2;
+  rng.normal_pair(n1, n2);
+  const double u = rng.uniform();
+  const double a = (th[0] + n1 * 0.01) - th[1] * th[1];
+  const double b = (th[1] - 1.0) + n2 * 0.01;
+  return (u < p[0]) ? ABZ_INF : 50.0 * (a * a) + b * b;
+}
+"""
+
+
+@pytest.mark.parametrize("which", ["normal1d", "quad2d"])
+def test_user_simulator_equals_builtin(oracle, which):
+    """a simulator supplied as HIP source (hiprtc) must reproduce the built-in simulator it restates,
+    and therefore the CPU oracle, bit for bit -- whole abcdesmc and abcdemc runs."""
+    if which == "normal1d":
+        prior, builtin, eps, N = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, 5000
+        user = A.UserSimulator(USER_NORMAL1D, params=(1.0,), data=(3.0,))
+    else:
+        prior, builtin, eps, N = A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.01, 500
+        user = A.UserSimulator(USER_QUAD2D, params=(0.5,))
+    r = A.abcdesmc(prior, user, eps, None, nparticles=N, verbose=False, rng=31)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, builtin, seed=31), N, eps)
+    res = r.engine.result()
+    assert r.logZ == c["logZ"] and r.nsims == c["nsims"]
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"])
+    m = A.abcdemc(prior, user, eps, None, nparticles=N, generations=40, verbose=False, rng=32)
+    cm = oracle.run_abcdemc(A.ModelSpec(prior, builtin, seed=32), N, eps, 40)
+    assert np.array_equal(m.engine.result()["theta"], cm["theta"])
+
+
+def test_user_simulator_compile_error_is_reported():
+    from abcdez_amd import _lib
+
+    bad = A.UserSimulator("__device__ double abz_user_dist(const double* t, int d, const double* a, int n, const double* p, "
+                          "abz_user_rng& rng) { return undefined_symbol; }")
+    with pytest.raises(_lib.AbcdezError, match="does not compile"):
+        A.abcdesmc(A.Normal(0, 1), bad, 0.3, None, nparticles=100, verbose=False)
+
+
+def test_user_simulator_new_model():
+    """a model that is NOT built in: logistic growth observed with noise; the posterior finds the rate"""
+    src = """
+    __device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+      double x = p[0], acc = 0.0;
+      for (int t = 0; t < n_data; ++t) {
+        const double e = (x + p[1] * rng.normal()) - data[t];
+        acc += e * e;
+        x += th[0] * x * (1.0 - x / th[1]);
+      }
+      return sqrt(acc / n_data);
+    }
+    """
+    r_true, K_true, x = 0.5, 10.0, 0.5
+    data = []
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        data.append(x + 0.05 * rng.normal())
+        x += r_true * x * (1 - x / K_true)
+    sim = A.UserSimulator(src, params=(0.5, 0.05), data=data)
+    prior = A.Factored(A.Uniform(0, 2), A.Uniform(1, 30))
+    r = A.abcdesmc(prior, sim, 0.15, None, nparticles=20000, verbose=False, rng=2, nsims_max=10 ** 9)
+    post = r.P[r.Wns > 0]
+    assert abs(post[:, 0].mean() - r_true) < 0.05 and abs(post[:, 1].mean() - K_true) < 0.5
