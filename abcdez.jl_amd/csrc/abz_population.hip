@@ -492,6 +492,7 @@ __global__ __launch_bounds__(1024) void select_pick_kernel(uint32_t* __restrict_
   }
   const unsigned long long k = st[1];
   const unsigned long long before = t ? s_c[t - 1] : 0;
+  if (t == 1023 && k >= s_c[1023]) st[7] = 1;        /* rank beyond the population: the caller's n_alive was wrong */
   if (k >= before && k < s_c[t]) {
     int b; unsigned long long lessb;
     if (k < before + h0) { b = 2 * t; lessb = before; } else { b = 2 * t + 1; lessb = before + h0; }
@@ -611,6 +612,10 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   const unsigned long long key = ctx->h_scal[ABZ_S_SEL_PREFIX];
   const unsigned long long less = ctx->h_scal[ABZ_S_SEL_LESS], eq = ctx->h_scal[ABZ_S_SEL_EQ];
   const unsigned long long next = ctx->h_scal[ABZ_S_SEL_NEXT];
+  if (ctx->h_scal[ABZ_S_SEL_PAD]) {
+    abz_set_error("quantile_alive: requested rank is beyond the number of alive particles (wrong n_alive_hint?)");
+    return -1;
+  }
   *xk = abz_u2d(key);
   *n_le = (int64_t)(less + eq);
   /* rank k0+1 is the same value if it is still inside the run of equal keys */

@@ -351,6 +351,12 @@ def test_c_abi_error_paths():
     assert "ϵ ≥ 0.0".encode() in lib.abcdez_last_error()                                  # types.jl:30
     q = C.c_double()
     assert lib.abcdez_quantile_alive(ops.ctx, dl.data_ptr(), eng.alive.data_ptr(), 1000, -1, 1.5, C.byref(q), None, None) != 0
+    eng.alive[::2] = 0                                  # 500 alive, but the caller claims 1000
+    assert lib.abcdez_quantile_alive(ops.ctx, dl.data_ptr(), eng.alive.data_ptr(), 1000, 1000, 0.95, C.byref(q), None, None) != 0
+    assert b"n_alive_hint" in lib.abcdez_last_error()
+    assert lib.abcdez_quantile_alive(ops.ctx, dl.data_ptr(), eng.alive.data_ptr(), 1000, 500, 0.95, C.byref(q), None, None) == 0
+    assert lib.abcdez_quantile_alive(ops.ctx, dl.data_ptr(), eng.alive.data_ptr(), 1000, -1, 0.95, C.byref(q), None, None) == 0
+    eng.alive.fill_(1)
     assert lib.abcdez_ctx_set_lanes(ops.ctx, 3) != 0
     # a bad model is refused at context creation
     bad = A.ModelSpec(prior, sim, seed=1).cstruct(None)
