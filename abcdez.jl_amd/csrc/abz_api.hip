@@ -11,7 +11,7 @@
 
 int abz_tree_sum_impl(abcdez_ctx*, const double*, int64_t, int, double*);
 int abz_reweight_impl(abcdez_ctx*, const double*, double*, uint8_t*, int64_t, double, double, double*, double*, int64_t*);
-int abz_compact_impl(abcdez_ctx*, const uint8_t*, int64_t, uint32_t*, uint32_t*, int64_t*);
+int abz_compact_impl(abcdez_ctx*, const uint8_t*, int64_t, uint32_t*, uint32_t*, int64_t*, const uint32_t*);
 int abz_stratified_impl(abcdez_ctx*, const double*, int64_t, uint32_t, uint32_t*);
 int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t, double*, double*, int64_t*);
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
@@ -266,7 +266,57 @@ int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint3
                          int64_t* n_alive) {
   ABZ_REQUIRE(ctx && alive && alive_idx && arank, "alive_compact: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact: N out of range");
-  return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive);
+  return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive, nullptr);
+}
+
+/* ---- row-store mode (single GPU): see the comment at SmcSwarmArgs::rows in abz_kernels.h ---- */
+int abcdez_alive_compact_rows(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, const uint32_t* cur_row,
+                              uint32_t* alive_row, uint32_t* arank, int64_t* n_alive) {
+  ABZ_REQUIRE(ctx && alive && cur_row && alive_row && arank, "alive_compact_rows: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact_rows: N out of range");
+  return abz_compact_impl(ctx, alive, N, alive_row, arank, n_alive, cur_row);
+}
+
+int abcdez_smc_swarm_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
+                          double* slot0, double* slot1, double* logpi, double* delta, double eps, double gamma0,
+                          double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && logpi && delta && nacc && nsim,
+              "smc_swarm_rows: null argument");
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows: the two slots / alive lists must differ");
+  int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, logpi, delta,
+                                slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
+                                alive_row_out);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
+  return 0;
+}
+
+int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row) {
+  ABZ_REQUIRE(ctx && alive_row && cur_row, "rows_commit: null argument");
+  ABZ_REQUIRE(n_alive >= 0 && n_alive <= ABZ_MAX_N, "rows_commit: n_alive out of range");
+  return abz_rows_commit_impl(ctx, alive_row, n_alive, cur_row);
+}
+
+int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* cur_row, double* slot0,
+                                    double* slot1, const double* logpi, const double* delta, double* nlogpi,
+                                    double* ndelta, double* wns, uint8_t* alive) {
+  ABZ_REQUIRE(ctx && inds && cur_row && slot0 && slot1 && logpi && delta && nlogpi && ndelta && wns && alive,
+              "smc_resample_gather_rows: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_rows: N out of range");
+  ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1, "smc_resample_gather_rows: in/out arrays must differ");
+  return abz_launch_resample_gather_rows(ctx, inds, (uint32_t)N, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns,
+                                         alive);
+}
+
+int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, const double* slot0, const double* slot1,
+                       double* out) {
+  ABZ_REQUIRE(ctx && cur_row && slot0 && slot1 && out, "rows_gather: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "rows_gather: N out of range");
+  return abz_launch_rows_gather(ctx, cur_row, (uint32_t)N, slot0, slot1, out);
 }
 
 int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive, int64_t r_lo,
@@ -286,7 +336,8 @@ int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t*
                                 delta, ntheta, nlogpi, ndelta, eps, gamma0, gamma_sigma, (uint32_t)i0,
                                 (uint32_t)n_local, copy_dead, dead_synced, sweep,
                                 /* alive list is the identity iff every particle of a range starting at 0 is alive */
-                                (i0 == 0 && r_lo == 0 && r_hi == n_alive && n_alive == n_local) ? (uint32_t)n_alive : 0u);
+                                (i0 == 0 && r_lo == 0 && r_hi == n_alive && n_alive == n_local) ? (uint32_t)n_alive : 0u,
+                                nullptr);
   if (rc) return rc;
   rc = read_counters(ctx);
   if (rc) return rc;

@@ -67,7 +67,11 @@ enum {
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
                          const double*, const double*, const double*, double*, double*, double*,
-                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t);
+                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t, uint32_t*);
+int abz_launch_resample_gather_rows(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, double*, double*, const double*,
+                                    const double*, double*, double*, double*, uint8_t*);
+int abz_launch_rows_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
+int abz_rows_commit_impl(abcdez_ctx*, const uint32_t*, int64_t, uint32_t*);
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);

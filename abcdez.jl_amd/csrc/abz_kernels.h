@@ -85,6 +85,12 @@ struct SmcSwarmArgs {
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
   uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
+  /* "row store" mode (single GPU): theta / ntheta are the two slots of a 2N-row store, alive_idx[r] holds
+   * the CURRENT row id (particle | slot << 31) of the r-th alive particle; an accepted proposal is written to
+   * the particle's other slot and its row id flips in alive_out, a rejected one writes nothing; log-prior and
+   * distance are updated in place (only their owner reads them).  No dead rows to carry, no copies.        */
+  uint32_t rows;
+  uint32_t* alive_out;
 };
 
 template <int SIM, int L, int C>
@@ -96,13 +102,14 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
   const int j = (int)(gid % L);
   const bool active = grp < a.n_work;
   const uint32_t ri = a.r_lo + (active ? grp : 0u);
-  const uint32_t i = a.all_alive ? ri : a.alive_idx[ri];
+  const uint32_t rowi = a.all_alive ? ri : a.alive_idx[ri];
+  const uint32_t i = rowi & 0x7FFFFFFFu;
 
   __shared__ ModelLds<LD> s_model;
 
   /* own row + state */
   double ti[C];
-  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+  load_row<L, C>(((rowi >> 31) ? a.ntheta : a.theta) + (size_t)i * LD, j, ti);
   const double lpi = a.logpi[i];
   const double dli = a.delta[i];
   ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
@@ -114,11 +121,11 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
   uint32_t ra, rb;
   double g, log_u;
   particle_draws<L>(&s_model.tab, M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
-  const uint32_t ia = a.all_alive ? ra : a.alive_idx[ra];
-  const uint32_t ib = a.all_alive ? rb : a.alive_idx[rb];
+  const uint32_t rowa = a.all_alive ? ra : a.alive_idx[ra];
+  const uint32_t rowb = a.all_alive ? rb : a.alive_idx[rb];
   double ta[C], tb[C];
-  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
-  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+  load_row<L, C>(((rowa >> 31) ? a.ntheta : a.theta) + (size_t)(rowa & 0x7FFFFFFFu) * LD, j, ta);
+  load_row<L, C>(((rowb >> 31) ? a.ntheta : a.theta) + (size_t)(rowb & 0x7FFFFFFFu) * LD, j, tb);
 
   double tp[C], pp[C];
 #pragma unroll
@@ -133,7 +140,13 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
     const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
     acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
   }
-  if (active) {                                                   /* smc:146-150 + copies :337-340 */
+  if (active && a.rows) {                                         /* smc:146-150, row-store mode */
+    if (acc) {
+      store_row<L, C>(((rowi >> 31) ? const_cast<double*>(a.theta) : a.ntheta) + (size_t)i * LD, j, tp);
+      if (j == 0) { a.nlogpi[i] = lp; a.ndelta[i] = dp; }
+    }
+    if (j == 0) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
+  } else if (active) {                                            /* smc:146-150 + copies :337-340 */
     /* lazy copy: a rejected particle whose row is already identical in both generations'
      * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
     const bool synced = a.row_synced ? a.row_synced[i] != 0 : false;

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(uint32_t* __restrict__ v
 __global__ __launch_bounds__(ABZ_BLOCK) void compact_scatter_kernel(const uint8_t* __restrict__ alive, int64_t N,
                                                                     const uint32_t* __restrict__ chunk_off,
                                                                     uint32_t* __restrict__ alive_idx,
-                                                                    uint32_t* __restrict__ arank) {
+                                                                    uint32_t* __restrict__ arank,
+                                                                    const uint32_t* __restrict__ cur_row) {
   __shared__ uint32_t s_wave[4];
   const int64_t base = (int64_t)blockIdx.x * ABZ_CHUNK;
   uint32_t run = chunk_off[blockIdx.x];
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void compact_scatter_kernel(const uint8_
     if (k < N) {
       if (f) {
         const uint32_t r = run + woff + below;
-        alive_idx[r] = (uint32_t)k;
+        alive_idx[r] = cur_row ? cur_row[k] : (uint32_t)k;      /* row-store mode: particle | slot << 31 */
         arank[k] = r;
       } else {
         arank[k] = ABZ_DEAD;
@@ -273,8 +274,24 @@ __global__ __launch_bounds__(ABZ_BLOCK) void compact_scatter_kernel(const uint8_
   }
 }
 
+/* row-store mode: cur_row[particle] = its current row id, from the alive list the sweeps ping-pong */
+__global__ __launch_bounds__(ABZ_BLOCK) void rows_commit_kernel(const uint32_t* __restrict__ alive_row, uint32_t n,
+                                                                uint32_t* __restrict__ cur_row) {
+  const uint32_t r = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t row = alive_row[r];
+  cur_row[row & 0x7FFFFFFFu] = row;
+}
+int abz_rows_commit_impl(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row) {
+  if (n_alive <= 0) return 0;
+  hipLaunchKernelGGL(rows_commit_kernel, dim3((unsigned)((n_alive + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
+                     ctx->stream, alive_row, (uint32_t)n_alive, cur_row);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
-                     int64_t* n_alive) {
+                     int64_t* n_alive, const uint32_t* cur_row) {
   const uint32_t nchunk = (uint32_t)((N + ABZ_CHUNK - 1) / ABZ_CHUNK);
   int rc = abz_ws_reserve(ctx, abz_align((size_t)nchunk * 4));
   if (rc) return rc;
@@ -282,7 +299,7 @@ int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t*
   hipLaunchKernelGGL(compact_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt);
   hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, nchunk, ctx->d_scal + ABZ_S_NALIVE);
   hipLaunchKernelGGL(compact_scatter_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt, alive_idx,
-                     arank);
+                     arank, cur_row);
   ABZ_HIP_CHECK(hipGetLastError());
   if (!n_alive) return 0;            /* caller already knows sum(alive): stay asynchronous */
   rc = read_scalars(ctx);

@@ -58,7 +58,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
                          uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
                          uint32_t i0, uint32_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
-                         uint32_t N_total) {
+                         uint32_t N_total, uint32_t* alive_out) {
   SmcSwarmArgs a;
   a.hm = ctx->hot; a.alive_idx = alive_idx; a.arank = arank;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
@@ -71,7 +71,9 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   a.row_synced = dead_synced;
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
-  a.all_alive = (N_total != 0 && n_alive == N_total) ? 1u : 0u;
+  a.all_alive = (N_total != 0 && n_alive == N_total && !alive_out) ? 1u : 0u;
+  a.rows = alive_out ? 1u : 0u;
+  a.alive_out = alive_out;
   bool ok = true;
   if (copy_dead && n_local > 0) {
     ok = abz_dispatch_ld(ctx->h_model.ld, [&](auto LD) {

@@ -117,6 +117,32 @@ class HipOps:
             _ptr(dead_synced), sweep, C.byref(nacc), C.byref(nsim)))
         return nacc.value, nsim.value
 
+    # ---- row-store mode (single GPU): include/abcdez_hip.h, abcdez_smc_swarm_rows ----------------
+    supports_rows = True
+
+    def alive_compact_rows(self, alive, cur_row, alive_row, arank):
+        _lib.check(self.lib, self.lib.abcdez_alive_compact_rows(self.ctx, _ptr(alive), alive.numel(), _ptr(cur_row),
+                                                                _ptr(alive_row), _ptr(arank), None))
+
+    def smc_swarm_rows(self, alive_row, alive_row_out, n_alive, slot0, slot1, logpi, delta, eps, gamma0, gsig, sweep):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_swarm_rows(
+            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta),
+            eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
+        return nacc.value, nsim.value
+
+    def rows_commit(self, alive_row, n_alive, cur_row):
+        _lib.check(self.lib, self.lib.abcdez_rows_commit(self.ctx, _ptr(alive_row), n_alive, _ptr(cur_row)))
+
+    def smc_resample_gather_rows(self, inds, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
+        _lib.check(self.lib, self.lib.abcdez_smc_resample_gather_rows(
+            self.ctx, _ptr(inds), inds.numel(), _ptr(cur_row), _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta),
+            _ptr(nlogpi), _ptr(ndelta), _ptr(wns), _ptr(alive)))
+
+    def rows_gather(self, cur_row, slot0, slot1, out):
+        _lib.check(self.lib, self.lib.abcdez_rows_gather(self.ctx, _ptr(cur_row), cur_row.numel(), _ptr(slot0),
+                                                         _ptr(slot1), _ptr(out)))
+
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
         wnorm, ess, na = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_reweight(self.ctx, _ptr(delta), _ptr(wns), _ptr(alive), delta.numel(),
@@ -180,7 +206,11 @@ class HipOps:
 class PopulationEngine:
     """Device-resident population + the reference's per-generation functions."""
 
-    def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0):
+    def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0,
+                 storage: str = "classic"):
+        """storage = "classic": two full generations' arrays, every sweep writes the next one (the reference's
+        thetas / nthetas; works sharded).  storage = "rows": single-GPU row store -- two slots per particle,
+        only accepted proposals are written (abcdez_smc_swarm_rows); abcdesmc only."""
         self.spec = spec
         self.N = int(nparticles)
         self.pg = process_group
@@ -203,12 +233,20 @@ class PopulationEngine:
         self.device = dev
         N, ld = self.N, spec.ld
         f64 = dict(dtype=torch.float64, device=dev)
-        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350)
+        self.rows_mode = storage == "rows" and self.world == 1 and getattr(self.ops, "supports_rows", False)
+        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store mode the two theta arrays
+        # are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings
         self.buf = [
             (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
             (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
         ]
         self.cur = 0
+        if self.rows_mode:
+            self.cur_row = torch.arange(N, dtype=torch.int32, device=dev)      # particle | slot << 31
+            self.alive_row = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(2)]
+            self.ar = 0
+            self._rows_dirty = False
+            self._rows_n = 0
         self.wns = torch.full((N,), 1.0 / N, **f64)
         self.alive = torch.ones(N, dtype=torch.uint8, device=dev)
         self.alive_idx = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -227,7 +265,30 @@ class PopulationEngine:
     # ------------------------------------------------------------------ helpers
     @property
     def state(self):
-        return self.buf[self.cur]
+        """(theta, logpi, delta) of the current generation.  Row-store mode gathers the current rows into a
+        fresh array (tests / results only; the hot path never calls this)."""
+        if not self.rows_mode:
+            return self.buf[self.cur]
+        self._rows_commit()
+        th = torch.empty_like(self.buf[0][0])
+        self.ops.rows_gather(self.cur_row, self.buf[0][0], self.buf[1][0], th)
+        return (th, self.buf[self.cur][1], self.buf[self.cur][2])
+
+    def _rows_commit(self):
+        if self.rows_mode and self._rows_dirty:
+            # the list was built for the alive set of the LAST compaction (a reweight may have shrunk n_alive since)
+            self.ops.rows_commit(self.alive_row[self.ar], self._rows_n, self.cur_row)
+            self._rows_dirty = False
+
+    @property
+    def delta(self):
+        return self.buf[self.cur][2]
+
+    def alive_indices(self) -> torch.Tensor:
+        """particle indices of the alive list of the last compaction (int64)"""
+        if self.rows_mode:
+            return self.alive_row[self.ar][:self._rows_n].to(torch.int64) & 0x7FFFFFFF
+        return self.alive_idx[:self.n_alive].to(torch.int64)
 
     @property
     def other(self):
@@ -266,7 +327,7 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ S1
     def init_population(self):
-        th, lp, dl = self.state
+        th, lp, dl = self.buf[self.cur]
         self.ops.init(th, lp, dl, self.lo, self.n_local)
         self._allgather_state(self.state)
 
@@ -279,17 +340,17 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ S9, S10
     def quantile_alive(self, alpha: float) -> float:
-        return self.ops.quantile_alive(self.state[2], self.alive, alpha, self.n_alive)[0]
+        return self.ops.quantile_alive(self.delta, self.alive, alpha, self.n_alive)[0]
 
     def extrema(self):
-        return self.ops.extrema(self.state[2])
+        return self.ops.extrema(self.delta)
 
     def count_gt(self, thr: float) -> int:
-        return self.ops.count_gt(self.state[2], thr)
+        return self.ops.count_gt(self.delta, thr)
 
     # ------------------------------------------------------------------ S5, S6
     def smc_reweight(self, eps_old: float, eps_new: float):
-        wnorm, ess, n_alive = self.ops.smc_reweight(self.state[2], self.wns, self.alive, eps_old, eps_new)
+        wnorm, ess, n_alive = self.ops.smc_reweight(self.delta, self.wns, self.alive, eps_old, eps_new)
         self.n_alive = n_alive
         self._dead_synced = False
         return wnorm, ess, n_alive
@@ -301,6 +362,15 @@ class PopulationEngine:
     def smc_resample(self):
         self.ops.wsample_stratified(self.wns, self.draw, self.inds)
         self.draw += 1
+        if self.rows_mode:
+            self._rows_commit()
+            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
+            self.ops.smc_resample_gather_rows(self.inds, self.cur_row, self.buf[0][0], self.buf[1][0], cur[1], cur[2],
+                                              oth[1], oth[2], self.wns, self.alive)
+            self._swap()
+            self.n_alive = self.N
+            self.last_inds = self.inds
+            return
         self.ops.smc_resample_gather(self.inds, self.lo, self.n_local, self.state, self.other, self.wns, self.alive)
         if self.world > 1:
             self.wns.fill_(1.0 / self.N)   # the other ranks' ranges (smc:102-103)
@@ -314,6 +384,11 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ alive list + S2, S3
     def alive_compact(self) -> int:
+        if self.rows_mode:
+            self._rows_commit()
+            self.ops.alive_compact_rows(self.alive, self.cur_row, self.alive_row[self.ar], self.arank)
+            self._rows_n = self.n_alive
+            return self.n_alive
         n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank, self.n_alive)
         self.n_alive = n
         if self.world == 1:
@@ -326,6 +401,15 @@ class PopulationEngine:
         return n
 
     def smc_swarm(self, eps: float, gamma0: float, gsig: float):
+        if self.rows_mode:
+            cur = self.buf[self.cur]
+            nacc, nsim = self.ops.smc_swarm_rows(self.alive_row[self.ar], self.alive_row[1 - self.ar], self.n_alive,
+                                                 self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
+                                                 self.sweep)
+            self.sweep += 1
+            self.ar = 1 - self.ar
+            self._rows_dirty = True
+            return nacc, nsim
         copy_dead = (not self._dead_synced) and self.n_alive < self.N
         nacc, nsim = self.ops.smc_swarm(self.alive_idx, self.arank, self.n_alive, self.r_lo, self.r_hi, self.state,
                                         self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep,
@@ -338,6 +422,8 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ S4
     def mc_rank_prepare(self):
+        if self.rows_mode:
+            raise RuntimeError("abcdemc needs storage='classic'")
         if self.order is None:
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
             self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
@@ -373,6 +459,8 @@ class PopulationEngine:
         }
 
 
-def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0) -> PopulationEngine:
-    """The product engine: HIP kernels on the current CUDA(HIP) device."""
-    return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes)
+def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0,
+              storage: str = "rows") -> PopulationEngine:
+    """The product engine: HIP kernels on the current CUDA(HIP) device.  Single GPU: row-store sweeps
+    (only accepted proposals are written); sharded runs fall back to the classic double buffer."""
+    return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage)

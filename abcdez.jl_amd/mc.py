@@ -31,7 +31,7 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     _check(1 <= generations, "generations must be at least 1")  # mc:110
 
     spec = ModelSpec(prior, dist, seed=rng)
-    eng = _make_engine(spec, nparticles, engine, process_group)
+    eng = _make_engine(spec, nparticles, engine, process_group, storage="classic")
     if verbose:
         log.info("Running abcdemc with engine %s: ϵ_target=%s nparticles=%d generations=%d seed=%d",
                  type(eng).__name__, ϵ_target, nparticles, generations, spec.seed)

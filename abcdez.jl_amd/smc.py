@@ -81,12 +81,12 @@ def _check(cond: bool, msg: str) -> None:
         raise ValueError(msg)  # the reference raises ErrorException via error(...)
 
 
-def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group):
+def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group, storage: str = "rows"):
     if engine is not None:
         return engine(spec, nparticles, process_group) if callable(engine) else engine
     from .engine import HipEngine  # fails loudly if the HIP library or the GPU is missing
 
-    return HipEngine(spec, nparticles, process_group)
+    return HipEngine(spec, nparticles, process_group, storage=storage)
 
 
 def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,

@@ -97,6 +97,26 @@ ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, cons
                      int64_t i0, int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
                      int64_t* nacc, int64_t* nsim);
 
+/* Row-store variant of the same sweep for a single GPU (what bench.py measures).  theta lives in a store of
+ * two slots per particle (slot0[N][ld], slot1[N][ld]); cur_row[i] = i | slot << 31 names particle i's current
+ * row, alive_row[r] the current row of the r-th alive particle.  An accepted proposal is written to the
+ * particle's other slot and its entry flips in alive_row_out; a rejected or dead particle writes nothing, and
+ * log-prior / distance are updated in place -- the identity. copies of src/abcdez_smc.jl:337-340 cost nothing.
+ * Call order per generation: alive_compact_rows -> smc_swarm_rows (ping-pong alive_row / alive_row_out)
+ * -> rows_commit (alive list -> cur_row) before the next compaction, resampling or rows_gather.          */
+ABCDEZ_API int abcdez_alive_compact_rows(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, const uint32_t* cur_row,
+                              uint32_t* alive_row, uint32_t* arank, int64_t* n_alive);
+ABCDEZ_API int abcdez_smc_swarm_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
+                          double* slot0, double* slot1, double* logpi, double* delta,
+                          double eps, double gamma0, double gamma_sigma, uint32_t sweep,
+                          int64_t* nacc, int64_t* nsim);
+ABCDEZ_API int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row);
+ABCDEZ_API int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* cur_row,
+                                    double* slot0, double* slot1, const double* logpi, const double* delta,
+                                    double* nlogpi, double* ndelta, double* wns, uint8_t* alive);
+ABCDEZ_API int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, const double* slot0,
+                       const double* slot1, double* out);
+
 /* S5+S6  abcdesmc_update_ws!(ws, alive, Ds, eps_k, eps_k_new, nparticles) src/abcdez_smc.jl:59-83
  *        followed by the driver's wprod/wnorm/Wns/alive lines :308-311 and get_ess :8,:323. */
 ABCDEZ_API int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N,

@@ -29,10 +29,10 @@ def models():
     }
 
 
-def engines(name, N, seed=3, ABCk=A.IndicatorStrict0toϵ, lanes=0, oracle=None):
+def engines(name, N, seed=3, ABCk=A.IndicatorStrict0toϵ, lanes=0, oracle=None, storage="classic"):
     prior, sim, eps = models()[name]
     spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
-    hip = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes))
+    hip = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes), storage=storage)
     orc = oracle.oracle_engine(spec, N)
     return spec, hip, orc, eps
 
@@ -179,9 +179,12 @@ def test_stratified_resample_parity(oracle, N):
     ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0), ("socks", 0),
 ])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
-def test_smc_sweep_parity(oracle, name, lanes, abck):
+@pytest.mark.parametrize("storage", ["classic", "rows"])
+def test_smc_sweep_parity(oracle, name, lanes, abck, storage):
+    """storage: the classic double buffer (what sharded runs use) and the single-GPU row store"""
     N = 6000
-    spec, hip, orc, _ = engines(name, N, ABCk=abck, lanes=lanes, oracle=oracle)
+    spec, hip, orc, _ = engines(name, N, ABCk=abck, lanes=lanes, oracle=oracle, storage=storage)
+    assert hip.rows_mode == (storage == "rows")
     hip.init_population(); orc.init_population()
     d = spec.d
     gamma0 = 2.38 / math.sqrt(2 * d)
