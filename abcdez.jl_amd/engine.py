@@ -329,7 +329,7 @@ class PopulationEngine:
     def init_population(self):
         th, lp, dl = self.buf[self.cur]
         self.ops.init(th, lp, dl, self.lo, self.n_local)
-        self._allgather_state(self.state)
+        self._allgather_state(self.buf[self.cur])
 
     def reset_weights(self):  # smc:266-270
         self.wns.fill_(1.0 / self.N)

@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--particles-per-gpu", type=int, default=1 << 22)
     p.add_argument("--dim", type=int, default=32)
     p.add_argument("--lanes", type=int, default=0, help="lanes per particle (0 = library default)")
-    p.add_argument("--cpu-particles", type=int, default=1 << 20, help="population of the CPU-oracle baseline sample")
+    p.add_argument("--cpu-particles", type=int, default=1 << 22, help="population of the CPU-oracle baseline sample")
     p.add_argument("--cpu-steps", type=int, default=10)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
