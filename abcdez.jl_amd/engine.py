@@ -256,11 +256,10 @@ class PopulationEngine:
         self.sorted_delta = None
         self.n_alive = N
         self.r_lo, self.r_hi = self.lo, self.hi
-        self.dead_synced = torch.zeros(N, dtype=torch.uint8, device=dev)   # dead rows already carried to both buffers
+        self.row_synced = torch.zeros(N, dtype=torch.uint8, device=dev)   # dead rows already carried to both buffers
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
-        self._dead_synced = True
-        self.last_inds = None
+        self._dead_carried = True
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -335,8 +334,8 @@ class PopulationEngine:
         self.wns.fill_(1.0 / self.N)
         self.alive.fill_(1)
         self.n_alive = self.N
-        self._dead_synced = True
-        self.dead_synced.zero_()
+        self._dead_carried = True
+        self.row_synced.zero_()
 
     # ------------------------------------------------------------------ S9, S10
     def quantile_alive(self, alpha: float) -> float:
@@ -352,7 +351,7 @@ class PopulationEngine:
     def smc_reweight(self, eps_old: float, eps_new: float):
         wnorm, ess, n_alive = self.ops.smc_reweight(self.delta, self.wns, self.alive, eps_old, eps_new)
         self.n_alive = n_alive
-        self._dead_synced = False
+        self._dead_carried = False
         return wnorm, ess, n_alive
 
     def get_ess(self) -> float:
@@ -369,7 +368,6 @@ class PopulationEngine:
                                               oth[1], oth[2], self.wns, self.alive)
             self._swap()
             self.n_alive = self.N
-            self.last_inds = self.inds
             return
         self.ops.smc_resample_gather(self.inds, self.lo, self.n_local, self.state, self.other, self.wns, self.alive)
         if self.world > 1:
@@ -378,9 +376,8 @@ class PopulationEngine:
         self._allgather_state(self.other)
         self._swap()
         self.n_alive = self.N
-        self._dead_synced = True
-        self.dead_synced.zero_()
-        self.last_inds = self.inds
+        self._dead_carried = True
+        self.row_synced.zero_()
 
     # ------------------------------------------------------------------ alive list + S2, S3
     def alive_compact(self) -> int:
@@ -410,12 +407,12 @@ class PopulationEngine:
             self.ar = 1 - self.ar
             self._rows_dirty = True
             return nacc, nsim
-        copy_dead = (not self._dead_synced) and self.n_alive < self.N
+        copy_dead = (not self._dead_carried) and self.n_alive < self.N
         nacc, nsim = self.ops.smc_swarm(self.alive_idx, self.arank, self.n_alive, self.r_lo, self.r_hi, self.state,
                                         self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep,
-                                        self.dead_synced)
+                                        self.row_synced)
         self.sweep += 1
-        self._dead_synced = True
+        self._dead_carried = True
         self._allgather_state(self.other)
         self._swap()
         return self._allreduce_counts(nacc, nsim)

@@ -9,7 +9,7 @@ arithmetic: csrc/abcdez_spec.h, ``ABZ_SIM_*``).  ``blob`` is always ``None``
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Sequence, Tuple
 
 SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENER, SIM_LV, SIM_SOCKS, SIM_USER = range(10)

@@ -7,7 +7,6 @@ import inspect
 import math
 import os
 import re
-import warnings
 
 import numpy as np
 import pytest

@@ -7,7 +7,6 @@ import math
 
 import numpy as np
 import pytest
-from scipy import stats
 
 import abcdez_amd as A
 from abcdez_amd.model import ModelSpec
