@@ -195,7 +195,49 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                  (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs)         # smc:388-393
 end
 
-# abcdemc! (src/abcdez_mc.jl:102-172) follows the same pattern with abcdez_extrema, abcdez_count_gt,
-# abcdez_mc_rank_prepare and abcdez_mc_swarm; see abcdez.jl_amd/mc.py for the tested host loop.
+# ---- abcdemc!: the host loop of src/abcdez_mc.jl:102-172 --------------------------------------------
+function count_gt(e, thr)                                                                                 # mc:133,156
+    c = Ref(Int64(0))
+    check(ccall((:abcdez_count_gt, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ref{Int64}), e.ctx, e.delta[e.cur], e.N, thr, c)); Int(c[])
+end
+rank_prepare!(e) = check(ccall((:abcdez_mc_rank_prepare, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                               e.ctx, e.delta[e.cur], e.N, e.order, e.sorted))                            # mc:23
+function mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                                            # mc:5-61 + :140-143
+    nsim = Ref(Int64(0)); o = other(e)
+    check(ccall((:abcdez_mc_swarm, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Float64, Float64, Float64, Float64, Int64, Int64, UInt32, Ref{Int64}),
+                e.ctx, e.order, e.sorted, e.N, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur], e.theta[o], e.logpi[o], e.delta[o],
+                ϵ_pop, ϵ_target, γ0, γσ, 0, e.N, e.sweep, nsim))
+    e.sweep += 1; e.cur = o
+    Int(nsim[])
+end
+
+function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
+                  nparticles::Int=50, generations::Int=20, verbose=true, rng::Integer=1, parallel::Bool=true)
+    α = 0.0                                                                              # mc:107
+    0.0 ≤ ϵ_target || error("ϵ_target must be non-negative")
+    5 ≤ nparticles || error("nparticles must be at least 5")
+    1 ≤ generations || error("generations must be at least 1")
+    e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, rng, nparticles)
+    init!(e)                                                                             # mc:117-125
+    nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
+    complete = 1 - count_gt(e, ϵ_target) / nparticles                                    # mc:133
+    while iters < generations                                                            # mc:134
+        iters += 1
+        ϵ_l, ϵ_h = extrema_dev(e)                                                        # mc:146
+        ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))                                     # mc:147
+        ϵ_h > ϵ_target && rank_prepare!(e)
+        nsims += mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                   # mc:149
+        ncomplete = 1 - count_gt(e, ϵ_target) / nparticles                               # mc:156
+        verbose && (ncomplete != complete || complete >= (nparticles - 1) / nparticles) &&
+            (@info "Finished run:" completion = ncomplete nsim = nsims range_ϵ = extrema_dev(e))
+        complete = ncomplete
+    end
+    conv = extrema_dev(e)[2] <= ϵ_target                                                 # mc:163
+    P, _, Δs = download(e)                                                               # mc:166
+    ccall((:abcdez_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
+    (P = P, C = Δs, reached_ϵ = conv, blobs = fill(nothing, nparticles))                # mc:171
+end
 
 end # module

@@ -33,13 +33,29 @@ def weightinds(oracle, w, seed=99):
     return inds.astype(np.int64)
 
 
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)], autouse=True)
+def backend(request):
+    """every test of this file runs twice: on the CPU oracle (-m "not gpu") and through the product's HIP engine
+    (-m gpu) -- same seeds, bit-identical populations, so the reference's tolerances hold for both"""
+    global BACKEND
+    BACKEND = request.param
+    yield request.param
+
+
+BACKEND = "oracle"
+
+
 def smc(oracle, prior, sim, eps, **kw):
     kw.setdefault("verbose", False)
+    if BACKEND == "hip":
+        return A.abcdesmc(prior, sim, eps, None, **kw)
     return A.abcdesmc(prior, sim, eps, None, engine=oracle.oracle_engine, **kw)
 
 
 def mc(oracle, prior, sim, eps, **kw):
     kw.setdefault("verbose", False)
+    if BACKEND == "hip":
+        return A.abcdemc(prior, sim, eps, None, **kw)
     return A.abcdemc(prior, sim, eps, None, engine=oracle.oracle_engine, **kw)
 
 
