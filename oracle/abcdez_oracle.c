@@ -5,16 +5,20 @@
  * import, link or call this file; it is the checker used by tests/, by
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg.
  *
- * PARITY STATUS: the reference is pure Julia; Julia is not installed in the build
- * container and its RNG stream (task-local Xoshiro256++, forked per FLoops task) is
- * not observable, and the reference's tests hold no seed-specific vectors
- * (SURVEY.md section 8c).  Bit/seed-level parity with ABCdeZ.jl is therefore
- * UNPINNED.  What IS pinned (tests/test_oracle_*.py): every exact known answer of
- * test/runtests.jl on this path (kernel truth tables :48-108, Factored :21-36,
- * push_p :38-46) and its statistical known answers (analytic evidences and
- * posterior means :110-266, :321-423, Dirac :493-519, 2-d incl. Inf distances
- * :600-624, ...), plus the resampling / driver invariants implied by
- * src/abcdez_smc.jl:45-54 and :295-377.
+ * PARITY STATUS.  PINNED against every known answer the reference's own tests hold for this path
+ * (SURVEY.md section 8c), restated as committed fixtures (tests/golden/reference_known_answers.json):
+ *   exact:        kernel truth tables test/runtests.jl:48-108, Factored :21-36, push_p :38-46
+ *                 -> tests/test_reference_known_answers.py
+ *   statistical:  all 17 integration testsets :110-624 with the reference's population sizes and
+ *                 tolerances (analytic evidences, Bayes factor, posterior means, Dirac, mixture deciles,
+ *                 Wiener, 2-d with Inf distances, mixed discrete prior, Socks)
+ *                 -> tests/test_reference_integration.py
+ *   structural:   resampling / driver invariants implied by src/abcdez_smc.jl:45-54 and :295-377
+ *                 -> tests/test_oracle_equivalence.py, tests/test_reference_integration.py
+ * NOT pinnable: seed-for-seed equality with ABCdeZ.jl.  The reference is pure Julia, Julia is not
+ * installed in the build container (nor on the GPU box), its RNG (task-local Xoshiro256++, forked per
+ * FLoops task) is not observable from here, and test/runtests.jl asserts no seed-specific value.  "Same
+ * seed, same result" is therefore defined between this oracle and the HIP kernels (shared Philox stream).
  *
  * Two tiers:
  *   ref_*  literal restatements (sequential fp walks, O(N) donor scans, rejection
