@@ -365,3 +365,23 @@ def test_user_simulator_new_model():
     r = A.abcdesmc(prior, sim, 0.15, None, nparticles=20000, verbose=False, rng=2, nsims_max=10 ** 9)
     post = r.P[r.Wns > 0]
     assert abs(post[:, 0].mean() - r_true) < 0.05 and abs(post[:, 1].mean() - K_true) < 0.5
+
+
+def test_config3_full_run_logz_and_posterior():
+    """BASELINE.json configs[2] run to its target: d = 32 MVN, N = 2^22, eps_target = 6 (about 160 generations).
+    logZ against the closed form log P(chi'^2_32(16) < 18) = -8.1116 (tests/golden), posterior mean against the
+    symmetry of the model (all 32 components exchangeable) and a 2^20-particle run with another seed."""
+    gold = json.load(open(os.path.join(GOLD_DIR, "reference_known_answers.json"), encoding="utf-8"))["analytic"]
+    prior = A.Factored(*[A.Normal(0, 1)] * 32)
+    sim = A.MVNormal((1.0,) * 32)
+    r = A.abcdesmc(prior, sim, 6.0, None, nparticles=1 << 22, verbose=False, rng=1, nsims_max=10 ** 12)
+    assert r.ϵ == 6.0 and 120 < r.iters < 220
+    assert abs(r.logZ - gold["Z_mvn32_eps6"]["logZ"]) < 0.02, r.logZ          # stated fp64 / Monte-Carlo tolerance
+    al = r.Wns > 0
+    m = r.P[al].mean(0)
+    assert np.abs(m - m.mean()).max() < 0.015          # exchangeable components (particles are correlated: duplicates + 3 sweeps per generation)
+    r2 = A.abcdesmc(prior, sim, 6.0, None, nparticles=1 << 20, verbose=False, rng=2, nsims_max=10 ** 12)
+    m2 = r2.P[r2.Wns > 0].mean(0)
+    assert abs(m.mean() - m2.mean()) < 0.01 and abs(r.logZ - r2.logZ) < 0.03
+    print(f"config3 full run: iters={r.iters} nsims={r.nsims} logZ={r.logZ:.5f} (exact {gold['Z_mvn32_eps6']['logZ']:.5f}) "
+          f"posterior mean per component={m.mean():.5f}")
