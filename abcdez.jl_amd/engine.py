@@ -307,9 +307,7 @@ class PopulationEngine:
         import torch.distributed as dist
 
         direct = self._backend == "nccl" or self.device.type == "cpu"
-        # theta rows (donors come from the global population) and distances (the replicated quantile /
-        # reweight passes); log-priors are only ever read by the rank that owns the particle
-        for t in (bufs[0], bufs[2]):
+        for t in bufs:
             if direct:
                 dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
             else:
