@@ -67,7 +67,11 @@ enum {
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
                          const double*, const double*, const double*, double*, double*, double*,
-                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t, uint32_t*);
+                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t, uint32_t*,
+                         uint8_t* acc_flag);
+int abz_launch_smc_replay(abcdez_ctx*, const uint32_t* alive_row, uint32_t* alive_out, uint32_t n_alive, uint32_t skip_lo,
+                          uint32_t skip_hi, double* slot0, double* slot1, const uint8_t* acc_flag, double gamma0,
+                          double gsig, uint32_t sweep);
 int abz_launch_resample_gather_rows(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, double*, double*, const double*,
                                     const double*, double*, double*, double*, uint8_t*);
 int abz_launch_rows_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);

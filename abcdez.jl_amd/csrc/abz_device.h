@@ -106,6 +106,22 @@ struct ModelStage {
   }
 };
 
+/* the sampler tables alone (kernels that draw but neither evaluate the prior nor simulate) */
+struct TabStage {
+  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);
+  double2 tb[NT];
+  __device__ inline void load(const HotModel& M) {
+    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+  }
+  __device__ inline void store(abz_tables& s) const {
+    double2* tdst = reinterpret_cast<double2*>(&s);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+  }
+};
+
 /* ---- canonical per-particle tree sum ------------------------------------------- */
 __device__ inline double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 

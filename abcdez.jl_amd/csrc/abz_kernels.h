@@ -91,6 +91,9 @@ struct SmcSwarmArgs {
    * distance are updated in place (only their owner reads them).  No dead rows to carry, no copies.        */
   uint32_t rows;
   uint32_t* alive_out;
+  /* sharded row store (one replica per GPU): per-PARTICLE accept flags of this sweep, the only thing the other
+   * ranks need to replay the accepted proposals on their replicas (smc_replay_kernel_body); NULL = not recorded */
+  uint8_t* acc_flag;
 };
 
 template <int SIM, int L, int C>
@@ -145,7 +148,10 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
       store_row<L, C>(((rowi >> 31) ? const_cast<double*>(a.theta) : a.ntheta) + (size_t)i * LD, j, tp);
       if (j == 0) { a.nlogpi[i] = lp; a.ndelta[i] = dp; }
     }
-    if (j == 0) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
+    if (j == 0) {
+      a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
+      if (a.acc_flag) a.acc_flag[i] = acc ? 1 : 0;
+    }
   } else if (active) {                                            /* smc:146-150 + copies :337-340 */
     /* lazy copy: a rejected particle whose row is already identical in both generations'
      * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
@@ -163,6 +169,58 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
     }
   }
   block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
+}
+
+/* ================================================================ replay of a sweep on a replica
+ * Multi-GPU row store: every rank keeps the whole population; rank r runs smc_swarm_kernel on the alive ranks of
+ * its own particles and publishes one accept flag per particle.  The accepted proposal theta_i + gamma (theta_a -
+ * theta_b) (smc:128) is a function of replicated state and of the particle's counter-based random numbers only,
+ * so the other ranks REBUILD it from their replica instead of receiving the row: 1 byte per particle crosses
+ * xGMI instead of 8 ld + 16, paid for with 3 row reads + 1 row write of local HBM per accepted particle.      */
+struct SmcReplayArgs {
+  HotModel hm;
+  const uint32_t* alive_idx;    /* current row id (particle | slot << 31) by alive rank */
+  uint32_t* alive_out;
+  const uint8_t* acc_flag;      /* by particle */
+  double* slot0;
+  double* slot1;
+  double gamma0, gsig;
+  uint32_t n_alive, skip_lo, skip_n, n_work, sweep;   /* work item w -> alive rank w (< skip_lo) or w + skip_n */
+};
+
+template <int L, int C>
+__device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t w = active ? grp : 0u;
+  const uint32_t ri = w < a.skip_lo ? w : w + a.skip_n;
+  const uint32_t rowi = a.alive_idx[ri];
+  const uint32_t i = rowi & 0x7FFFFFFFu;
+
+  __shared__ abz_tables s_tab;
+  TabStage stage;
+  stage.load(a.hm);
+  const bool acc = active && a.acc_flag[i] != 0;
+  stage.store(s_tab);
+  __syncthreads();
+  if (acc) {                                                       /* uniform over the lanes of a group */
+    uint32_t ra, rb;
+    double g, log_u;
+    particle_draws<L>(&s_tab, a.hm.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+    const uint32_t rowa = a.alive_idx[ra];
+    const uint32_t rowb = a.alive_idx[rb];
+    double ti[C], ta[C], tb[C], tp[C];
+    load_row<L, C>(((rowi >> 31) ? a.slot1 : a.slot0) + (size_t)i * LD, j, ti);
+    load_row<L, C>(((rowa >> 31) ? a.slot1 : a.slot0) + (size_t)(rowa & 0x7FFFFFFFu) * LD, j, ta);
+    load_row<L, C>(((rowb >> 31) ? a.slot1 : a.slot0) + (size_t)(rowb & 0x7FFFFFFFu) * LD, j, tb);
+#pragma unroll
+    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+    store_row<L, C>(((rowi >> 31) ? a.slot0 : a.slot1) + (size_t)i * LD, j, tp);
+  }
+  if (active && j == 0) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
 }
 
 /* ================================================================ S4: abcdemc_swarm! (src/abcdez_mc.jl:5-61) */

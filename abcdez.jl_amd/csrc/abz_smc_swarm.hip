@@ -58,7 +58,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
                          uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
                          uint32_t i0, uint32_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
-                         uint32_t N_total, uint32_t* alive_out) {
+                         uint32_t N_total, uint32_t* alive_out, uint8_t* acc_flag) {
   SmcSwarmArgs a;
   a.hm = ctx->hot; a.alive_idx = alive_idx; a.arank = arank;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
@@ -74,6 +74,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   a.all_alive = (N_total != 0 && n_alive == N_total && !alive_out) ? 1u : 0u;
   a.rows = alive_out ? 1u : 0u;
   a.alive_out = alive_out;
+  a.acc_flag = acc_flag;
   bool ok = true;
   if (copy_dead && n_local > 0) {
     ok = abz_dispatch_ld(ctx->h_model.ld, [&](auto LD) {
@@ -99,4 +100,28 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
   return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
+}
+
+/* replay of the other ranks' accepted proposals on this rank's replica (abz_kernels.h) */
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_kernel(const SmcReplayArgs a) {
+  smc_replay_kernel_body<L, C>(a);
+}
+
+int abz_launch_smc_replay(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_out, uint32_t n_alive,
+                          uint32_t skip_lo, uint32_t skip_hi, double* slot0, double* slot1, const uint8_t* acc_flag,
+                          double gamma0, double gsig, uint32_t sweep) {
+  SmcReplayArgs a;
+  a.hm = ctx->hot; a.alive_idx = alive_row; a.alive_out = alive_out; a.acc_flag = acc_flag;
+  a.slot0 = slot0; a.slot1 = slot1; a.gamma0 = gamma0; a.gsig = gsig;
+  a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_n = skip_hi - skip_lo; a.n_work = n_alive - a.skip_n; a.sweep = sweep;
+  if (a.n_work == 0) return 0;
+  const int L = ctx->L;
+  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+  bool ok = abz_dispatch_lc(L, ctx->C, [&](auto LL, auto CC) {
+    hipLaunchKernelGGL((smc_replay_kernel<LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+  });
+  if (!ok) { abz_set_error("smc_replay: unsupported layout"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
 }

@@ -16,11 +16,20 @@ Layout in HBM (per rank, every array FULL length N so donors can be any particle
 and for abcdemc ``order[N]`` u32 + ``sorted_delta[N]`` f64.
 
 Multi-GPU: rank r updates the contiguous index range
-[r N/G, (r+1) N/G); after every sweep the new rows / logπ / Δ of all ranks are
-exchanged with one in-place all-gather each, so the next sweep's donors come from
-the global population.  RNG counters are keyed by the global particle index, so
-results do not depend on G.  The cheap per-generation passes (quantile, reweight,
-compaction, resampling indices) run replicated on the full arrays.
+[r N/G, (r+1) N/G) and every rank keeps the whole population, so the next sweep's
+donors come from the global population.  RNG counters are keyed by the global
+particle index, so results do not depend on G.  The cheap per-generation passes
+(quantile, reweight, compaction, resampling indices) run replicated on the full arrays.
+
+* ``storage="classic"`` (abcdemc; abcdesmc on request): after every sweep the new
+  rows / logπ / Δ of all ranks are exchanged with one in-place all-gather each.
+* ``storage="rows"`` (abcdesmc default): the replicas exchange ONE BYTE per particle
+  and sweep -- the accept flag -- and rebuild the accepted proposals themselves
+  (``smc_replay_rows``: the proposal is a function of replicated rows and of
+  counter-based random numbers).  Distances are all-gathered once per generation
+  (quantile / reweight need them), log-priors only before a resampling, and the
+  resampling gathers run replicated.  xGMI carries 1 + 8/K bytes per particle and
+  sweep instead of 8 ld + 16.
 """
 from __future__ import annotations
 
@@ -131,6 +140,20 @@ class HipOps:
             eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
         return nacc.value, nsim.value
 
+    def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
+                             eps, gamma0, gsig, sweep):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_swarm_rows_shard(
+            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, r_lo, r_hi, _ptr(slot0), _ptr(slot1), _ptr(logpi),
+            _ptr(delta), _ptr(accepted), eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
+        return nacc.value, nsim.value
+
+    def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
+                        sweep):
+        _lib.check(self.lib, self.lib.abcdez_smc_replay_rows(
+            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, skip_lo, skip_hi, _ptr(slot0), _ptr(slot1),
+            _ptr(accepted), gamma0, gsig, sweep))
+
     def rows_commit(self, alive_row, n_alive, cur_row):
         _lib.check(self.lib, self.lib.abcdez_rows_commit(self.ctx, _ptr(alive_row), n_alive, _ptr(cur_row)))
 
@@ -209,8 +232,8 @@ class PopulationEngine:
     def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0,
                  storage: str = "classic"):
         """storage = "classic": two full generations' arrays, every sweep writes the next one (the reference's
-        thetas / nthetas; works sharded).  storage = "rows": single-GPU row store -- two slots per particle,
-        only accepted proposals are written (abcdez_smc_swarm_rows); abcdesmc only."""
+        thetas / nthetas).  storage = "rows": row store -- two slots per particle, only accepted proposals are
+        written (abcdez_smc_swarm_rows); sharded: accept-flag exchange + replay (module docstring); abcdesmc only."""
         self.spec = spec
         self.N = int(nparticles)
         self.pg = process_group
@@ -233,7 +256,8 @@ class PopulationEngine:
         self.device = dev
         N, ld = self.N, spec.ld
         f64 = dict(dtype=torch.float64, device=dev)
-        self.rows_mode = storage == "rows" and self.world == 1 and getattr(self.ops, "supports_rows", False)
+        self.rows_mode = storage == "rows" and getattr(self.ops, "supports_rows", False)
+        self.sharded_rows = self.rows_mode and self.world > 1
         # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store mode the two theta arrays
         # are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings
         self.buf = [
@@ -247,6 +271,10 @@ class PopulationEngine:
             self.ar = 0
             self._rows_dirty = False
             self._rows_n = 0
+        if self.sharded_rows:
+            self.accepted = torch.zeros(N, dtype=torch.uint8, device=dev)   # accept flags of the last sweep, by particle
+        self._delta_stale = False    # sharded row store: other ranks' distances / log-priors not yet fetched
+        self._logpi_stale = False
         self.wns = torch.full((N,), 1.0 / N, **f64)
         self.alive = torch.ones(N, dtype=torch.uint8, device=dev)
         self.alive_idx = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -269,6 +297,8 @@ class PopulationEngine:
         if not self.rows_mode:
             return self.buf[self.cur]
         self._rows_commit()
+        self._sync_delta()
+        self._sync_logpi()
         th = torch.empty_like(self.buf[0][0])
         self.ops.rows_gather(self.cur_row, self.buf[0][0], self.buf[1][0], th)
         return (th, self.buf[self.cur][1], self.buf[self.cur][2])
@@ -281,7 +311,20 @@ class PopulationEngine:
 
     @property
     def delta(self):
+        self._sync_delta()
         return self.buf[self.cur][2]
+
+    def _sync_delta(self):
+        """sharded row store: fetch the other ranks' distances (once per generation, before the first consumer)"""
+        if self._delta_stale:
+            self._allgather_state((self.buf[self.cur][2],))
+            self._delta_stale = False
+
+    def _sync_logpi(self):
+        """sharded row store: fetch the other ranks' log-priors (read by other ranks only when resampling, smc:97)"""
+        if self._logpi_stale:
+            self._allgather_state((self.buf[self.cur][1],))
+            self._logpi_stale = False
 
     def alive_indices(self) -> torch.Tensor:
         """particle indices of the alive list of the last compaction (int64)"""
@@ -297,7 +340,7 @@ class PopulationEngine:
         self.cur = 1 - self.cur
 
     def _allgather_state(self, bufs):
-        """exchange rows [lo, hi) of (theta, logpi, delta) -- one all-gather per array.
+        """exchange entries [lo, hi) of per-particle arrays (theta, logpi, delta, ...) -- one all-gather per array.
 
         RCCL ("nccl" backend): in place, straight between the device buffers over xGMI.
         Any other backend (gloo in the CPU tests): CPU tensors in place; device tensors are
@@ -363,6 +406,8 @@ class PopulationEngine:
         self.draw += 1
         if self.rows_mode:
             self._rows_commit()
+            self._sync_delta()
+            self._sync_logpi()
             cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
             self.ops.smc_resample_gather_rows(self.inds, self.cur_row, self.buf[0][0], self.buf[1][0], cur[1], cur[2],
                                               oth[1], oth[2], self.wns, self.alive)
@@ -385,6 +430,11 @@ class PopulationEngine:
             self._rows_commit()
             self.ops.alive_compact_rows(self.alive, self.cur_row, self.alive_row[self.ar], self.arank)
             self._rows_n = self.n_alive
+            if self.sharded_rows:   # alive ranks of this rank's particles: #alive below lo, #alive in [lo, hi)
+                below = self.alive[:self.lo].sum(dtype=torch.int64)
+                mine = self.alive[self.lo:self.hi].sum(dtype=torch.int64)
+                b, m = (int(v) for v in torch.stack((below, mine)).tolist())
+                self.r_lo, self.r_hi = b, b + m
             return self.n_alive
         n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank, self.n_alive)
         self.n_alive = n
@@ -398,6 +448,20 @@ class PopulationEngine:
         return n
 
     def smc_swarm(self, eps: float, gamma0: float, gsig: float):
+        if self.sharded_rows:
+            cur = self.buf[self.cur]
+            a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
+            nacc, nsim = self.ops.smc_swarm_rows_shard(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
+                                                       self.buf[1][0], cur[1], cur[2], self.accepted, eps, gamma0, gsig,
+                                                       self.sweep)
+            self._allgather_state((self.accepted,))
+            self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                     self.accepted, gamma0, gsig, self.sweep)
+            self.sweep += 1
+            self.ar = 1 - self.ar
+            self._rows_dirty = True
+            self._delta_stale = self._logpi_stale = True
+            return self._allreduce_counts(nacc, nsim)
         if self.rows_mode:
             cur = self.buf[self.cur]
             nacc, nsim = self.ops.smc_swarm_rows(self.alive_row[self.ar], self.alive_row[1 - self.ar], self.n_alive,
@@ -458,6 +522,6 @@ class PopulationEngine:
 
 def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0,
               storage: str = "rows") -> PopulationEngine:
-    """The product engine: HIP kernels on the current CUDA(HIP) device.  Single GPU: row-store sweeps
-    (only accepted proposals are written); sharded runs fall back to the classic double buffer."""
+    """The product engine: HIP kernels on the current CUDA(HIP) device.  Row-store sweeps (only accepted
+    proposals are written); sharded runs keep one replica per GPU and exchange accept flags (module docstring)."""
     return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage)

@@ -83,7 +83,13 @@ def _check(cond: bool, msg: str) -> None:
 
 def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group, storage: str = "rows"):
     if engine is not None:
-        return engine(spec, nparticles, process_group) if callable(engine) else engine
+        if not callable(engine):
+            return engine
+        import inspect
+
+        if "storage" in inspect.signature(engine).parameters:
+            return engine(spec, nparticles, process_group, storage=storage)
+        return engine(spec, nparticles, process_group)
     from .engine import HipEngine  # fails loudly if the HIP library or the GPU is missing
 
     return HipEngine(spec, nparticles, process_group, storage=storage)

@@ -227,7 +227,8 @@ def main():
                             f"(BASELINE.json configs[2]); alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
                 "sweeps": gen.sweeps - s0, "resamples": gen.resamples, "eps": gen.eps, "logZ": gen.logZ,
-                "parallelism": f"particle-shard x{world} + per-sweep all-gather" if world > 1 else "single GPU",
+                "parallelism": (f"particle-shard x{world}, replicated row store: per-sweep accept-flag all-gather + replay, "
+                                "per-generation distance all-gather") if world > 1 else "single GPU",
             },
             "roofline": {
                 "kernel": "smc_swarm_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

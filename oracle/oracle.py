@@ -100,6 +100,14 @@ def lib():
     L.orc_wsample_stratified.argtypes = [_u64, _vp, _i64, _u32, _vp]
     L.orc_stratum_uniforms.argtypes = [_u64, _i64, _u32, _vp]
     L.orc_smc_resample_gather.argtypes = [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.orc_alive_compact_rows.restype = _i64
+    L.orc_alive_compact_rows.argtypes = [_vp, _i64, _vp, _vp, _vp]
+    L.orc_rows_commit.argtypes = [_vp, _i64, _vp]
+    L.orc_rows_gather.argtypes = [_vp, _i64, C.c_int, _vp, _vp, _vp]
+    L.orc_smc_swarm_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
+                                     _pi64, _pi64]
+    L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32]
+    L.orc_smc_resample_gather_rows.argtypes = [_vp] * 2 + [_i64] + [_vp] * 9
     L.orc_quantile_alive.restype = _f64
     L.orc_quantile_alive.argtypes = [_vp, _vp, _i64, _f64, _pf64, _pf64]
     L.orc_extrema.argtypes = [_vp, _i64, _pf64, _pf64]
@@ -163,6 +171,39 @@ class OracleOps:
                              C.byref(nacc), C.byref(nsim))
         return nacc.value, nsim.value
 
+    # ---- row-store restatement (checker for the abcdez_*_rows entry points) ----
+    supports_rows = True
+
+    def alive_compact_rows(self, alive, cur_row, alive_row, arank):
+        self.L.orc_alive_compact_rows(_p(alive), alive.numel(), _p(cur_row), _p(alive_row), _p(arank))
+
+    def smc_swarm_rows(self, alive_row, alive_row_out, n_alive, slot0, slot1, logpi, delta, eps, gamma0, gsig, sweep):
+        return self.smc_swarm_rows_shard(alive_row, alive_row_out, n_alive, 0, n_alive, slot0, slot1, logpi, delta, None,
+                                         eps, gamma0, gsig, sweep)
+
+    def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
+                             eps, gamma0, gsig, sweep):
+        nacc, nsim = _i64(), _i64()
+        self.L.orc_smc_swarm_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, r_lo, r_hi, _p(slot0), _p(slot1),
+                                  _p(logpi), _p(delta), _p(accepted), eps, gamma0, gsig, sweep, C.byref(nacc),
+                                  C.byref(nsim))
+        return nacc.value, nsim.value
+
+    def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
+                        sweep):
+        self.L.orc_smc_replay_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, skip_lo, skip_hi, _p(slot0),
+                                   _p(slot1), _p(accepted), gamma0, gsig, sweep)
+
+    def rows_commit(self, alive_row, n_alive, cur_row):
+        self.L.orc_rows_commit(_p(alive_row), n_alive, _p(cur_row))
+
+    def smc_resample_gather_rows(self, inds, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
+        self.L.orc_smc_resample_gather_rows(self.m.ptr, _p(inds), inds.numel(), _p(cur_row), _p(slot0), _p(slot1),
+                                            _p(logpi), _p(delta), _p(nlogpi), _p(ndelta), _p(wns), _p(alive))
+
+    def rows_gather(self, cur_row, slot0, slot1, out):
+        self.L.orc_rows_gather(_p(cur_row), cur_row.numel(), self.spec.ld, _p(slot0), _p(slot1), _p(out))
+
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
         wnorm, ess, na = _f64(), _f64(), _i64()
         self.L.orc_smc_reweight(self.spec.abck, _p(delta), _p(wns), _p(alive), delta.numel(), eps_old, eps_new,
@@ -212,11 +253,11 @@ class OracleOps:
         self.L.orc_math_eval(fn, _p(x), _p(y), _p(y2), x.numel())
 
 
-def oracle_engine(spec, nparticles, process_group=None):
+def oracle_engine(spec, nparticles, process_group=None, storage="classic"):
     """PopulationEngine (the product's host logic) driven by the oracle instead of the GPU."""
     import abcdez_amd.engine as E
 
-    return E.PopulationEngine(spec, nparticles, process_group, ops=OracleOps(spec))
+    return E.PopulationEngine(spec, nparticles, process_group, ops=OracleOps(spec), storage=storage)
 
 
 def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0,

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 (and 4) gloo jobs through the same PopulationEngine the
-GPU path uses (contiguous particle shards, in-place all-gather of the new rows / logπ / Δ after
-every sweep, integer counter all-reduce), with the oracle as compute backend.  The RNG is
+GPU path uses (contiguous particle shards; row store: accept-flag all-gather + replay on the
+replicas, distances once per generation; classic storage: in-place all-gather of the new rows /
+logπ / Δ after every sweep; integer counter all-reduce), with the oracle as compute backend.  The RNG is
 keyed by the global particle index, so any world size must reproduce the single-process
 run bit for bit."""
 import os
@@ -46,8 +47,13 @@ def test_sharded_run_equals_single_process(runs, name, world):
     for rank in range(world):
         got = np.load(os.path.join(runs[world], f"result_{name}_rank{rank}.npz"))
         assert int(got["world"]) == world
-        for k in ("theta", "C", "Wns", "eps_hist", "mc_theta", "mc_C"):
+        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C",
+                  "classic_logpi", "classic_Wns"):
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, world, rank, k)
+        # the two storages are the same algorithm
+        for k in ("theta", "C", "Wns", "logpi"):
+            assert np.array_equal(got[k], got["classic_" + k], equal_nan=True), (name, world, rank, k)
+        assert float(got["logZ"]) == float(got["classic_logZ"]) and int(got["nsims"]) == int(got["classic_nsims"])
         assert float(ref["logZ"]) == float(got["logZ"])
         assert int(ref["nsims"]) == int(got["nsims"]) and int(ref["iters"]) == int(got["iters"])
         assert int(ref["mc_nsims"]) == int(got["mc_nsims"])
@@ -79,6 +85,6 @@ def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(2):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
-            for k in ("theta", "C", "Wns", "eps_hist", "mc_theta", "mc_C"):
+            for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):
                 assert np.array_equal(ref[k], got[k], equal_nan=True), (name, rank, k)
             assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])

@@ -209,6 +209,69 @@ def test_smc_sweep_parity(oracle, name, lanes, abck, storage):
         eps_old = eps
 
 
+# ---------------------------------------------------------------- sharded row store: shard sweep + replay on replicas
+@pytest.mark.parametrize("name,lanes", [("normal1d", 0), ("mvn32", 0), ("mvn32", 8), ("mvn8", 0), ("mvn3", 0),
+                                        ("quad2d_inf", 0), ("normdu", 0), ("socks", 0)])
+def test_shard_sweep_and_replay_parity(oracle, name, lanes):
+    """Three replicas of one population on the one GPU, each sweeping its own third of the alive ranks
+    (abcdez_smc_swarm_rows_shard) and replaying the other two thirds from the merged accept flags
+    (abcdez_smc_replay_rows): every replica must end bit-identical to the oracle's full sweep."""
+    N, G = 6000, 3
+    spec, hip, orc, _ = engines(name, N, lanes=lanes, oracle=oracle, storage="rows")
+    hip.init_population(); orc.init_population()
+    gamma0 = 2.38 / math.sqrt(2 * spec.d)
+    eps = orc.quantile_alive(0.7)
+    assert hip.quantile_alive(0.7) == eps
+    assert hip.smc_reweight(math.inf, eps) == orc.smc_reweight(math.inf, eps)
+    n = orc.alive_compact()
+    assert hip.alive_compact() == n and n >= 3
+    ops = hip.ops
+    a_in = hip.alive_row[hip.ar]
+    cuts = [0, n // 5, n // 5 + n // 2, n]                        # uneven alive-rank ranges
+    pcut = [0] + [int(a_in[c].item() & 0x7FFFFFFF) for c in cuts[1:-1]] + [N]    # the particles they start at
+    for sweep in range(3):
+        reps = []
+        for r in range(G):
+            rep = dict(s0=hip.buf[0][0].clone(), s1=hip.buf[1][0].clone(), lp=hip.buf[hip.cur][1].clone(),
+                       dl=hip.buf[hip.cur][2].clone(), out=torch.zeros_like(a_in),
+                       acc=torch.full((N,), 7, dtype=torch.uint8, device=a_in.device))
+            rep["cnt"] = ops.smc_swarm_rows_shard(a_in, rep["out"], n, cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"],
+                                                  rep["dl"], rep["acc"], eps, gamma0, 1e-5, hip.sweep)
+            reps.append(rep)
+        flags = torch.zeros(N, dtype=torch.uint8, device=a_in.device)           # the all-gather of the accept flags
+        for r in range(G):
+            flags[pcut[r]:pcut[r + 1]] = reps[r]["acc"][pcut[r]:pcut[r + 1]]
+        for r in range(G):
+            ops.smc_replay_rows(a_in, reps[r]["out"], n, cuts[r], cuts[r + 1], reps[r]["s0"], reps[r]["s1"], flags,
+                                gamma0, 1e-5, hip.sweep)
+        co = orc.smc_swarm(eps, gamma0, 1e-5)
+        assert (sum(rep["cnt"][0] for rep in reps), sum(rep["cnt"][1] for rep in reps)) == co
+        th_o, lp_o, dl_o = orc.state
+        alive = orc.alive.bool()
+        assert int(flags[alive.to(flags.device)].sum()) == co[0]
+        for r in range(G):
+            rep = reps[r]
+            assert same(rep["out"], reps[0]["out"])                           # identical alive lists everywhere
+            cur_row = hip.cur_row.clone()
+            ops.rows_commit(rep["out"], n, cur_row)
+            th = torch.empty_like(rep["s0"])
+            ops.rows_gather(cur_row, rep["s0"], rep["s1"], th)
+            assert same(th, th_o), f"{name} sweep {sweep} replica {r}: theta differs"
+            assert same(rep["lp"][pcut[r]:pcut[r + 1]], lp_o[pcut[r]:pcut[r + 1]])   # owners hold logpi / delta
+            assert same(rep["dl"][pcut[r]:pcut[r + 1]], dl_o[pcut[r]:pcut[r + 1]])
+        # carry replica 0 (completed with the owners' log-priors / distances) into the engine for the next sweep
+        hip.buf[0][0].copy_(reps[0]["s0"]); hip.buf[1][0].copy_(reps[0]["s1"])
+        for r in range(G):
+            hip.buf[hip.cur][1][pcut[r]:pcut[r + 1]] = reps[r]["lp"][pcut[r]:pcut[r + 1]]
+            hip.buf[hip.cur][2][pcut[r]:pcut[r + 1]] = reps[r]["dl"][pcut[r]:pcut[r + 1]]
+        hip.alive_row[1 - hip.ar].copy_(reps[0]["out"])
+        hip.ar = 1 - hip.ar
+        hip._rows_dirty = True
+        hip.sweep += 1
+        a_in = hip.alive_row[hip.ar]
+    assert_state_equal(hip, orc, name)
+
+
 # ---------------------------------------------------------------- S4
 @pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac", "socks"])
 def test_mc_sweep_parity(oracle, name):
