@@ -39,7 +39,7 @@ PROTOTYPES = {
     "abcdez_rows_commit": [_vp, _vp, _i64, _vp],
     "abcdez_smc_swarm_rows_shard": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
                                     _pi64, _pi64],
-    "abcdez_smc_replay_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32],
+    "abcdez_smc_replay_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
     "abcdez_smc_resample_gather_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_rows_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
     "abcdez_smc_reweight": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64],

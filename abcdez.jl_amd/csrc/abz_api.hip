@@ -301,15 +301,16 @@ int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint
                                 int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta,
                                 uint8_t* accepted, double eps, double gamma0, double gamma_sigma, uint32_t sweep,
                                 int64_t* nacc, int64_t* nsim) {
-  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && logpi && delta && accepted && nacc && nsim,
+  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && logpi && delta && accepted,
               "smc_swarm_rows_shard: null argument");
+  ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_rows_shard: pass both counters or neither");
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_rows_shard: alive-rank range out of bounds");
   ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows_shard: the two slots / alive lists must differ");
   int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, logpi,
                                 delta, slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
                                 alive_row_out, accepted);
-  if (rc) return rc;
+  if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_rows reports totals) */
   rc = read_counters(ctx);
   if (rc) return rc;
   *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
@@ -319,13 +320,20 @@ int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint
 
 int abcdez_smc_replay_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
                            int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                           double gamma0, double gamma_sigma, uint32_t sweep) {
-  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && accepted, "smc_replay_rows: null argument");
+                           double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && accepted && nacc && nsim,
+              "smc_replay_rows: null argument");
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_rows: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_rows: alive-rank range out of bounds");
   ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_replay_rows: the two slots / alive lists must differ");
-  return abz_launch_smc_replay(ctx, alive_row, alive_row_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi,
-                               slot0, slot1, accepted, gamma0, gamma_sigma, sweep);
+  int rc = abz_launch_smc_replay(ctx, alive_row, alive_row_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi,
+                                 slot0, slot1, accepted, gamma0, gamma_sigma, sweep);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nacc = (int64_t)ctx->h_scal[ABZ_S_RACC];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_RSIM];
+  return 0;
 }
 
 int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row) {

@@ -60,7 +60,9 @@ enum {
   ABZ_S_NACC = 0, ABZ_S_NSIM = 1, ABZ_S_WNORM = 2, ABZ_S_SUMSQ = 3, ABZ_S_NALIVE = 4,
   ABZ_S_MIN = 5, ABZ_S_MAX = 6, ABZ_S_COUNT = 7, ABZ_S_LASTPOS = 8, ABZ_S_SUM = 9,
   ABZ_S_SEL_PREFIX = 10, ABZ_S_SEL_K = 11, ABZ_S_SEL_LESS = 12, ABZ_S_SEL_EQ = 13, ABZ_S_SEL_NEXT = 14,
-  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_ABOVE = 16, ABZ_S_SEL_PAD = 17, ABZ_S_INITBAD = 18, ABZ_S_N = 32
+  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_ABOVE = 16, ABZ_S_SEL_PAD = 17, ABZ_S_INITBAD = 18,
+  ABZ_S_RACC = 19, ABZ_S_RSIM = 20,      /* counters of the replayed ranks (sharded row store) */
+  ABZ_S_N = 32
 };
 
 /* kernel launchers implemented across the .hip files */

@@ -91,8 +91,9 @@ struct SmcSwarmArgs {
    * distance are updated in place (only their owner reads them).  No dead rows to carry, no copies.        */
   uint32_t rows;
   uint32_t* alive_out;
-  /* sharded row store (one replica per GPU): per-PARTICLE accept flags of this sweep, the only thing the other
-   * ranks need to replay the accepted proposals on their replicas (smc_replay_kernel_body); NULL = not recorded */
+  /* sharded row store (one replica per GPU): per-PARTICLE flags of this sweep (bit 0 accepted, bit 1 simulated),
+   * the only thing the other ranks need to replay the accepted proposals on their replicas and to know the
+   * sweep's global counters (smc_replay_kernel_body); NULL = not recorded */
   uint8_t* acc_flag;
 };
 
@@ -150,7 +151,7 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
     }
     if (j == 0) {
       a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
-      if (a.acc_flag) a.acc_flag[i] = acc ? 1 : 0;
+      if (a.acc_flag) a.acc_flag[i] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
     }
   } else if (active) {                                            /* smc:146-150 + copies :337-340 */
     /* lazy copy: a rejected particle whose row is already identical in both generations'
@@ -181,32 +182,74 @@ struct SmcReplayArgs {
   HotModel hm;
   const uint32_t* alive_idx;    /* current row id (particle | slot << 31) by alive rank */
   uint32_t* alive_out;
-  const uint8_t* acc_flag;      /* by particle */
+  const uint8_t* acc_flag;      /* by particle: bit 0 accepted, bit 1 simulated (proposal inside the prior support) */
   double* slot0;
   double* slot1;
+  uint2* partials;              /* per-block (nacc, nsim) over the block's alive ranks (own ones included) */
   double gamma0, gsig;
-  uint32_t n_alive, skip_lo, skip_n, n_work, sweep;   /* work item w -> alive rank w (< skip_lo) or w + skip_n */
+  uint32_t n_alive, skip_lo, skip_hi, sweep;          /* ranks [skip_lo, skip_hi) are this rank's own: counted only */
 };
 
+#define ABZ_REPLAY_PER 8                                  /* alive ranks per thread in the scan phase */
+#define ABZ_REPLAY_CHUNK (ABZ_BLOCK * ABZ_REPLAY_PER)     /* alive ranks per block */
+
+/* Two phases per block.  Scan: the block reads the flags of ABZ_REPLAY_CHUNK consecutive alive ranks (coalesced),
+ * completes alive_out for all of them, counts, and compacts the ACCEPTED ones into an LDS list (wave ballot +
+ * one LDS atomic per wave).  Rebuild: the lane groups walk that list densely, so every wave of the expensive
+ * part (3 row reads, 1 row write) is full although only ~1 in 4-5 particles was accepted.                     */
 template <int L, int C>
 __device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
   constexpr int LD = L * C;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_work;
-  const uint32_t w = active ? grp : 0u;
-  const uint32_t ri = w < a.skip_lo ? w : w + a.skip_n;
-  const uint32_t rowi = a.alive_idx[ri];
-  const uint32_t i = rowi & 0x7FFFFFFFu;
-
   __shared__ abz_tables s_tab;
+  __shared__ uint2 s_list[ABZ_REPLAY_CHUNK];              /* (alive rank, current row id) of the accepted */
+  __shared__ unsigned int s_n;
+  __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
+
   TabStage stage;
   stage.load(a.hm);
-  const bool acc = active && a.acc_flag[i] != 0;
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+
+  const uint32_t base = blockIdx.x * (uint32_t)ABZ_REPLAY_CHUNK;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned int wacc = 0u, wsim = 0u;                      /* wave-uniform counters */
+#pragma unroll
+  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
+    const uint32_t w = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
+    const bool active = w < a.n_alive;
+    const uint32_t ri = active ? w : 0u;
+    const bool foreign = active && !(ri >= a.skip_lo && ri < a.skip_hi);
+    const uint32_t rowi = a.alive_idx[ri];
+    const unsigned f = active ? (unsigned)a.acc_flag[rowi & 0x7FFFFFFFu] : 0u;
+    wacc += (unsigned)__popcll(__ballot((f & 1u) != 0u));
+    wsim += (unsigned)__popcll(__ballot((f & 2u) != 0u));
+    const bool acc = foreign && (f & 1u) != 0u;
+    if (foreign) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
+    const unsigned long long m = __ballot(acc);
+    const unsigned cnt = (unsigned)__popcll(m);
+    unsigned int at = 0u;
+    if (lane == 0u && cnt) at = atomicAdd(&s_n, cnt);
+    at = __shfl(at, 0, 64);
+    if (acc) {
+      uint2 e; e.x = ri; e.y = rowi;
+      s_list[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
+  }
+  if (lane == 0u) { s_cnt[0][threadIdx.x >> 6] = wacc; s_cnt[1][threadIdx.x >> 6] = wsim; }
   stage.store(s_tab);
   __syncthreads();
-  if (acc) {                                                       /* uniform over the lanes of a group */
+  if (threadIdx.x == 0) {
+    uint2 v;
+    v.x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    v.y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    a.partials[blockIdx.x] = v;
+  }
+
+  const unsigned n = s_n;
+  const int j = (int)(threadIdx.x % L);
+  for (unsigned t = threadIdx.x / L; t < n; t += ABZ_BLOCK / L) {   /* uniform over the lanes of a group */
+    const uint2 e = s_list[t];
+    const uint32_t ri = e.x, rowi = e.y, i = rowi & 0x7FFFFFFFu;
     uint32_t ra, rb;
     double g, log_u;
     particle_draws<L>(&s_tab, a.hm.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
@@ -217,10 +260,9 @@ __device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
     load_row<L, C>(((rowa >> 31) ? a.slot1 : a.slot0) + (size_t)(rowa & 0x7FFFFFFFu) * LD, j, ta);
     load_row<L, C>(((rowb >> 31) ? a.slot1 : a.slot0) + (size_t)(rowb & 0x7FFFFFFFu) * LD, j, tb);
 #pragma unroll
-    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
     store_row<L, C>(((rowi >> 31) ? a.slot0 : a.slot1) + (size_t)i * LD, j, tp);
   }
-  if (active && j == 0) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
 }
 
 /* ================================================================ S4: abcdemc_swarm! (src/abcdez_mc.jl:5-61) */

@@ -114,14 +114,14 @@ int abz_launch_smc_replay(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* 
   SmcReplayArgs a;
   a.hm = ctx->hot; a.alive_idx = alive_row; a.alive_out = alive_out; a.acc_flag = acc_flag;
   a.slot0 = slot0; a.slot1 = slot1; a.gamma0 = gamma0; a.gsig = gsig;
-  a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_n = skip_hi - skip_lo; a.n_work = n_alive - a.skip_n; a.sweep = sweep;
-  if (a.n_work == 0) return 0;
-  const int L = ctx->L;
-  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
-  bool ok = abz_dispatch_lc(L, ctx->C, [&](auto LL, auto CC) {
+  a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_hi = skip_hi; a.sweep = sweep;
+  const unsigned nblocks = (unsigned)(((uint64_t)n_alive + ABZ_REPLAY_CHUNK - 1) / ABZ_REPLAY_CHUNK);
+  if (int rc = abz_cnt_reserve(ctx, nblocks)) return rc;
+  a.partials = (uint2*)ctx->cnt;
+  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     hipLaunchKernelGGL((smc_replay_kernel<LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
   });
   if (!ok) { abz_set_error("smc_replay: unsupported layout"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_RACC);
 }

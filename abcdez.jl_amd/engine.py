@@ -141,18 +141,23 @@ class HipOps:
         return nacc.value, nsim.value
 
     def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
-                             eps, gamma0, gsig, sweep):
+                             eps, gamma0, gsig, sweep, want_counts=True):
+        """want_counts=False: no host synchronisation (the replay reports the other ranks' counters, the flags
+        carry this rank's)"""
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_swarm_rows_shard(
             self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, r_lo, r_hi, _ptr(slot0), _ptr(slot1), _ptr(logpi),
-            _ptr(delta), _ptr(accepted), eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
-        return nacc.value, nsim.value
+            _ptr(delta), _ptr(accepted), eps, gamma0, gsig, sweep, C.byref(nacc) if want_counts else None,
+            C.byref(nsim) if want_counts else None))
+        return (nacc.value, nsim.value) if want_counts else None
 
     def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
                         sweep):
+        nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_replay_rows(
             self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, skip_lo, skip_hi, _ptr(slot0), _ptr(slot1),
-            _ptr(accepted), gamma0, gsig, sweep))
+            _ptr(accepted), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
+        return nacc.value, nsim.value
 
     def rows_commit(self, alive_row, n_alive, cur_row):
         _lib.check(self.lib, self.lib.abcdez_rows_commit(self.ctx, _ptr(alive_row), n_alive, _ptr(cur_row)))
@@ -451,17 +456,16 @@ class PopulationEngine:
         if self.sharded_rows:
             cur = self.buf[self.cur]
             a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
-            nacc, nsim = self.ops.smc_swarm_rows_shard(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
-                                                       self.buf[1][0], cur[1], cur[2], self.accepted, eps, gamma0, gsig,
-                                                       self.sweep)
-            self._allgather_state((self.accepted,))
-            self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
-                                     self.accepted, gamma0, gsig, self.sweep)
+            self.ops.smc_swarm_rows_shard(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                          cur[1], cur[2], self.accepted, eps, gamma0, gsig, self.sweep, want_counts=False)
+            self._allgather_state((self.accepted,))          # 1 byte per particle: accepted | simulated << 1
+            counts = self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
+                                              self.buf[1][0], self.accepted, gamma0, gsig, self.sweep)
             self.sweep += 1
             self.ar = 1 - self.ar
             self._rows_dirty = True
             self._delta_stale = self._logpi_stale = True
-            return self._allreduce_counts(nacc, nsim)
+            return counts                                    # global (nacc, nsim), counted from the flags
         if self.rows_mode:
             cur = self.buf[self.cur]
             nacc, nsim = self.ops.smc_swarm_rows(self.alive_row[self.ar], self.alive_row[1 - self.ar], self.n_alive,

@@ -114,10 +114,12 @@ ABCDEZ_API int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, in
 
 /* Sharded row store (one process per GPU).  Every rank keeps a full replica of the store.
  * Rank r runs the sweep on the alive ranks [r_lo, r_hi) of its own particles (src/abcdez_smc.jl:106-153 restricted
- * to that range) and records accepted[i] in {0, 1} for each of them; after an all-gather of the accepted flags
- * (1 byte per particle -- the only per-sweep traffic besides two counters) every rank calls smc_replay_rows, which
- * rebuilds the accepted proposals theta_i + gamma (theta_a - theta_b) (smc:128) of all alive ranks OUTSIDE
- * [skip_lo, skip_hi) from its replica and the particles' counter-based random numbers and completes alive_row_out.
+ * to that range) and records accepted[i] = (accepted ? 1 : 0) | (simulated ? 2 : 0) for each of them (nacc / nsim
+ * may both be NULL: no host synchronisation); after an all-gather of the flags (1 byte per particle -- the only
+ * per-sweep traffic) every rank calls smc_replay_rows, which rebuilds the accepted proposals theta_i + gamma
+ * (theta_a - theta_b) (smc:128) of all alive ranks OUTSIDE [skip_lo, skip_hi) from its replica and the particles'
+ * counter-based random numbers, completes alive_row_out, and returns in nacc / nsim the sweep's GLOBAL counters
+ * (sum(naccs), sum(nsims) of smc:138,149,352, counted from the flags of all alive ranks -- no all-reduce).
  * Log-priors and distances stay with their owner between the sweeps (the host all-gathers distances once per
  * generation for the quantile / reweight, log-priors before a resampling).                                   */
 ABCDEZ_API int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out,
@@ -126,7 +128,7 @@ ABCDEZ_API int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* aliv
                           uint32_t sweep, int64_t* nacc, int64_t* nsim);
 ABCDEZ_API int abcdez_smc_replay_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
                           int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                          double gamma0, double gamma_sigma, uint32_t sweep);
+                          double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim);
 ABCDEZ_API int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* cur_row,
                                     double* slot0, double* slot1, const double* logpi, const double* delta,
                                     double* nlogpi, double* ndelta, double* wns, uint8_t* alive);

@@ -608,10 +608,11 @@ ORC_API void orc_smc_swarm_rows(const abz_model* M, const uint32_t* alive_row, u
     rows_proposal(M, alive_row, n_alive, slot0, slot1, (uint32_t)r, gamma0, gsig, sweep, tp);
     push_row(M, tp, pp);
     const double lp = logprior_tree(M, pp);                                          /* smc:134 */
-    int acc = 0;
+    int acc = 0, simulated = 0;
     if (!(lp < 0.0 && !abz_isfinite(lp) && !abz_isnan(lp))) {                        /* smc:135 */
       const double dp = sim_dist(M, pp, i, sweep, ABZ_RNG_SIM);                      /* smc:137 */
       nsim += 1;
+      simulated = 1;
       const double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i]));
       acc = (0.0 <= w);
       if (!acc) acc = abz_log_tab(abz_u01_open(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T) < w;  /* smc:145 */
@@ -623,7 +624,7 @@ ORC_API void orc_smc_swarm_rows(const abz_model* M, const uint32_t* alive_row, u
       }
     }
     alive_out[r] = acc ? (rowi ^ 0x80000000u) : rowi;
-    if (accepted) accepted[i] = (uint8_t)acc;
+    if (accepted) accepted[i] = (uint8_t)(acc | (simulated << 1));
   }
   *nacc_out = nacc; *nsim_out = nsim;
 }
@@ -631,13 +632,16 @@ ORC_API void orc_smc_swarm_rows(const abz_model* M, const uint32_t* alive_row, u
 /* what a replica does for the alive ranks it does not own: rebuild the accepted proposals from the flags */
 ORC_API void orc_smc_replay_rows(const abz_model* M, const uint32_t* alive_row, uint32_t* alive_out, int64_t n_alive,
                                  int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                                 double gamma0, double gsig, uint32_t sweep) {
+                                 double gamma0, double gsig, uint32_t sweep, int64_t* nacc_out, int64_t* nsim_out) {
   const int ld = M->ld;
-#pragma omp parallel for schedule(static)
+  int64_t nacc = 0, nsim = 0;                /* the sweep's global counters (flags: bit 0 accepted, bit 1 simulated) */
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
   for (int64_t r = 0; r < n_alive; ++r) {
-    if (r >= skip_lo && r < skip_hi) continue;
     const uint32_t rowi = alive_row[r], i = rowi & 0x7FFFFFFFu;
-    if (accepted[i]) {
+    nacc += accepted[i] & 1;
+    nsim += (accepted[i] >> 1) & 1;
+    if (r >= skip_lo && r < skip_hi) continue;
+    if (accepted[i] & 1) {
       double tp[ABZ_MAX_D];
       rows_proposal(M, alive_row, n_alive, slot0, slot1, (uint32_t)r, gamma0, gsig, sweep, tp);
       double* to = (double*)(ORC_ROW(slot0, slot1, rowi ^ 0x80000000u, ld));
@@ -647,6 +651,7 @@ ORC_API void orc_smc_replay_rows(const abz_model* M, const uint32_t* alive_row, 
       alive_out[r] = rowi;
     }
   }
+  *nacc_out = nacc; *nsim_out = nsim;
 }
 
 ORC_API void orc_smc_resample_gather_rows(const abz_model* M, const uint32_t* inds, int64_t N, uint32_t* cur_row,

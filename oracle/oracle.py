@@ -106,7 +106,7 @@ def lib():
     L.orc_rows_gather.argtypes = [_vp, _i64, C.c_int, _vp, _vp, _vp]
     L.orc_smc_swarm_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
                                      _pi64, _pi64]
-    L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32]
+    L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64]
     L.orc_smc_resample_gather_rows.argtypes = [_vp] * 2 + [_i64] + [_vp] * 9
     L.orc_quantile_alive.restype = _f64
     L.orc_quantile_alive.argtypes = [_vp, _vp, _i64, _f64, _pf64, _pf64]
@@ -182,7 +182,7 @@ class OracleOps:
                                          eps, gamma0, gsig, sweep)
 
     def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
-                             eps, gamma0, gsig, sweep):
+                             eps, gamma0, gsig, sweep, want_counts=True):
         nacc, nsim = _i64(), _i64()
         self.L.orc_smc_swarm_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, r_lo, r_hi, _p(slot0), _p(slot1),
                                   _p(logpi), _p(delta), _p(accepted), eps, gamma0, gsig, sweep, C.byref(nacc),
@@ -191,8 +191,10 @@ class OracleOps:
 
     def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
                         sweep):
+        nacc, nsim = _i64(), _i64()
         self.L.orc_smc_replay_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, skip_lo, skip_hi, _p(slot0),
-                                   _p(slot1), _p(accepted), gamma0, gsig, sweep)
+                                   _p(slot1), _p(accepted), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
+        return nacc.value, nsim.value
 
     def rows_commit(self, alive_row, n_alive, cur_row):
         self.L.orc_rows_commit(_p(alive_row), n_alive, _p(cur_row))

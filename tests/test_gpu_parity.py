@@ -241,14 +241,14 @@ def test_shard_sweep_and_replay_parity(oracle, name, lanes):
         flags = torch.zeros(N, dtype=torch.uint8, device=a_in.device)           # the all-gather of the accept flags
         for r in range(G):
             flags[pcut[r]:pcut[r + 1]] = reps[r]["acc"][pcut[r]:pcut[r + 1]]
-        for r in range(G):
-            ops.smc_replay_rows(a_in, reps[r]["out"], n, cuts[r], cuts[r + 1], reps[r]["s0"], reps[r]["s1"], flags,
-                                gamma0, 1e-5, hip.sweep)
         co = orc.smc_swarm(eps, gamma0, 1e-5)
+        for r in range(G):          # every replica learns the sweep's global counters from the flags
+            assert ops.smc_replay_rows(a_in, reps[r]["out"], n, cuts[r], cuts[r + 1], reps[r]["s0"], reps[r]["s1"], flags,
+                                       gamma0, 1e-5, hip.sweep) == co
         assert (sum(rep["cnt"][0] for rep in reps), sum(rep["cnt"][1] for rep in reps)) == co
         th_o, lp_o, dl_o = orc.state
-        alive = orc.alive.bool()
-        assert int(flags[alive.to(flags.device)].sum()) == co[0]
+        alive = orc.alive.bool().to(flags.device)
+        assert int((flags[alive] & 1).sum()) == co[0] and int((flags[alive] >> 1).sum()) == co[1]
         for r in range(G):
             rep = reps[r]
             assert same(rep["out"], reps[0]["out"])                           # identical alive lists everywhere

@@ -71,8 +71,8 @@ def main():
             torch.cuda.synchronize()
             t_sw.append(ev[0].elapsed_time(ev[1]))
             t_rp.append(ev[1].elapsed_time(ev[2]))
-        assert torch.equal(a_out, cout)                      # shard + replay == the full sweep
-        acc_remote = int(flags.sum().item()) - int((a_out[:r_hi] != a_in[:r_hi]).sum().item())
+        assert torch.equal(a_out[:n], cout[:n])                    # shard + replay == the full sweep
+        acc_remote = int((flags & 1).sum().item()) - int((a_out[:r_hi] != a_in[:r_hi]).sum().item())
         rp = min(t_rp)
         print(json.dumps({
             "gpus_emulated": G, "particles_total": N, "n_alive": n, "acceptance": nacc / n,
