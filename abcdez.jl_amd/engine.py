@@ -235,10 +235,12 @@ class PopulationEngine:
     """Device-resident population + the reference's per-generation functions."""
 
     def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0,
-                 storage: str = "classic"):
+                 storage: str = "classic", force_collectives: bool = False):
         """storage = "classic": two full generations' arrays, every sweep writes the next one (the reference's
         thetas / nthetas).  storage = "rows": row store -- two slots per particle, only accepted proposals are
-        written (abcdez_smc_swarm_rows); sharded: accept-flag exchange + replay (module docstring); abcdesmc only."""
+        written (abcdez_smc_swarm_rows); sharded: accept-flag exchange + replay (module docstring); abcdesmc only.
+        force_collectives: take the sharded code path (collectives, shard sweep + replay) even in a group of ONE
+        rank -- lets a single-GPU box exercise the RCCL calls (tests)."""
         self.spec = spec
         self.N = int(nparticles)
         self.pg = process_group
@@ -262,7 +264,8 @@ class PopulationEngine:
         N, ld = self.N, spec.ld
         f64 = dict(dtype=torch.float64, device=dev)
         self.rows_mode = storage == "rows" and getattr(self.ops, "supports_rows", False)
-        self.sharded_rows = self.rows_mode and self.world > 1
+        self._collectives = self.world > 1 or (force_collectives and self.pg is not None)
+        self.sharded_rows = self.rows_mode and self._collectives
         # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store mode the two theta arrays
         # are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings
         self.buf = [
@@ -350,7 +353,7 @@ class PopulationEngine:
         RCCL ("nccl" backend): in place, straight between the device buffers over xGMI.
         Any other backend (gloo in the CPU tests): CPU tensors in place; device tensors are
         staged through host memory, so the path is deterministic on every rank."""
-        if self.world == 1:
+        if not self._collectives:
             return
         import torch.distributed as dist
 
@@ -364,7 +367,7 @@ class PopulationEngine:
                 t.copy_(host)
 
     def _allreduce_counts(self, *vals):
-        if self.world == 1:
+        if not self._collectives:
             return vals
         import torch.distributed as dist
 
@@ -420,7 +423,7 @@ class PopulationEngine:
             self.n_alive = self.N
             return
         self.ops.smc_resample_gather(self.inds, self.lo, self.n_local, self.state, self.other, self.wns, self.alive)
-        if self.world > 1:
+        if self._collectives:
             self.wns.fill_(1.0 / self.N)   # the other ranks' ranges (smc:102-103)
             self.alive.fill_(1)
         self._allgather_state(self.other)
@@ -525,7 +528,8 @@ class PopulationEngine:
 
 
 def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0,
-              storage: str = "rows") -> PopulationEngine:
+              storage: str = "rows", force_collectives: bool = False) -> PopulationEngine:
     """The product engine: HIP kernels on the current CUDA(HIP) device.  Row-store sweeps (only accepted
     proposals are written); sharded runs keep one replica per GPU and exchange accept flags (module docstring)."""
-    return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage)
+    return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage,
+                            force_collectives=force_collectives)

@@ -28,10 +28,20 @@ def cases():
 def main():
     outdir = sys.argv[1]
     mode = sys.argv[2] if len(sys.argv) > 2 else "oracle"     # "oracle": CPU tensors; "hip": the product engine on cuda:0
-    dist.init_process_group("gloo")
+    # "rccl1": the product engine in a ONE-rank RCCL group with the sharded code path forced on, so that a
+    # single-GPU box runs the real collectives (in-place all_gather_into_tensor on device slices) end to end
+    dist.init_process_group("nccl" if mode == "rccl1" else "gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    pg = dist.group.WORLD if world > 1 else None
+    pg = dist.group.WORLD if (world > 1 or mode == "rccl1") else None
     engine = O.oracle_engine
+    if mode == "rccl1":
+        import functools
+
+        import torch
+        from abcdez_amd.engine import HipEngine
+
+        torch.cuda.set_device(0)
+        engine = functools.partial(HipEngine, force_collectives=True)
     if mode == "hip":
         import torch
         from abcdez_amd.engine import HipEngine
@@ -45,7 +55,7 @@ def main():
         # default storage: row store; sharded = accept-flag exchange + replay on the replicas
         r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
-        assert r.engine.rows_mode and r.engine.sharded_rows == (world > 1)
+        assert r.engine.rows_mode and r.engine.sharded_rows == (world > 1 or mode == "rccl1")
         c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=classic,
                        process_group=pg)
         assert not c.engine.rows_mode

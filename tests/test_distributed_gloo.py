@@ -88,3 +88,20 @@ def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
             for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):
                 assert np.array_equal(ref[k], got[k], equal_nan=True), (name, rank, k)
             assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
+
+
+@pytest.mark.gpu
+def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
+    """The sharded code path (flag all-gather + replay, per-generation distance all-gather, classic row
+    all-gathers, counter all-reduce) over the real RCCL backend in a group of one rank -- all a single-GPU box
+    can run of `nccl` -- must reproduce the single-process CPU-oracle result bit for bit."""
+    ref_dir = tmp_path_factory.mktemp("ref_oracle_rccl")
+    run_world(1, ref_dir, "oracle")
+    hip_dir = tmp_path_factory.mktemp("hip_rccl1")
+    run_world(1, hip_dir, "rccl1", timeout=240)
+    for name in ("normal1d", "mvn8", "quad2d"):
+        ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
+        got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
+        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
+        assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
