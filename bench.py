@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--cpu-particles", type=int, default=1 << 22, help="population of the CPU-oracle baseline sample")
     p.add_argument("--cpu-steps", type=int, default=10)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-collectives", action="store_true",
+                   help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
 
 
@@ -164,8 +166,10 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     d = args.dim
@@ -174,7 +178,7 @@ def main():
     eps_target = 6.0 * math.sqrt(d / 32.0)
     N = args.particles_per_gpu * world
     spec = A.ModelSpec(prior, sim, seed=1)
-    eng = HipEngine(spec, N, pg, lanes=args.lanes)
+    eng = HipEngine(spec, N, pg, lanes=args.lanes, force_collectives=args.force_collectives)
     ld, L, C = eng.ops.layout()
     eng.init_population()
     eng.reset_weights()
@@ -243,8 +247,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline_reference_faithful"], out["cpu_baseline"] = cpu_baseline(args, prior, sim, eps_target)
+        try:                      # RCCL's start-up banner sits in libc's stdio buffer: push it out BEFORE the result line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.barrier()
         dist.destroy_process_group()
 
