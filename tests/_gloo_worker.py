@@ -22,6 +22,10 @@ def cases():
         "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, 2000),
         "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8), 2.5, 1024),
         "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 600),
+        # BASELINE.json configs[3] in miniature: Lotka-Volterra RK4, 4 x Uniform(0, 2) prior, 8 observations
+        "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
+               A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6),
+                                  dt=0.05, steps_per_obs=10), 1.2, 512),
     }
 
 

@@ -40,7 +40,7 @@ def runs(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "lv"])
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_run_equals_single_process(runs, name, world):
     ref = np.load(os.path.join(runs[1], f"result_{name}_rank0.npz"))
@@ -81,7 +81,7 @@ def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
     run_world(1, ref_dir, "oracle")
     hip_dir = tmp_path_factory.mktemp("hip_world2")
     run_world(2, hip_dir, "hip", timeout=240)
-    for name in ("normal1d", "mvn8", "quad2d"):
+    for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(2):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
@@ -99,7 +99,7 @@ def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
     run_world(1, ref_dir, "oracle")
     hip_dir = tmp_path_factory.mktemp("hip_rccl1")
     run_world(1, hip_dir, "rccl1", timeout=240)
-    for name in ("normal1d", "mvn8", "quad2d"):
+    for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
         for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):

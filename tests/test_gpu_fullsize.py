@@ -212,6 +212,57 @@ def test_config3_full_size_properties_and_oracle_spot_checks(oracle):
     assert sums[0] == sums[1]            # 8 x 4 lanes, classic double buffer == 4 x 8 lanes, row store
 
 
+def test_config3_full_size_shard_sweep_plus_replay_equals_full_sweep():
+    """The multi-GPU row-store path at BASELINE.json configs[2] size (d = 32, N = 2^22), as rank 1 of 4 sees it:
+    sweeping only its own alive ranks and replaying the others' accepted proposals from the flag bytes must
+    leave the replica exactly as the full sweep does (new alive list, every current row, the sweep counters),
+    for three consecutive sweeps of a generation."""
+    d, N, G, rank = 32, 1 << 22, 4, 1
+    prior = A.Factored(*[A.Normal(0, 1)] * d)
+    spec = A.ModelSpec(prior, A.MVNormal((1.0,) * d), seed=1)
+    e = PopulationEngine(spec, N, ops=HipOps(spec), storage="rows")
+    e.init_population()
+    e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * d)
+    eps = math.inf
+    for _ in range(3):
+        eps = min(e.quantile_alive(0.95), eps)
+        e.smc_reweight(math.inf, eps)
+        e.alive_compact()
+        for _ in range(2):
+            e.smc_swarm(eps, g0, 1e-5)
+    eps = min(e.quantile_alive(0.95), eps)
+    e.smc_reweight(math.inf, eps)
+    n = e.alive_compact()
+    assert n < N
+    ops = e.ops
+    r_lo, r_hi = rank * n // G, (rank + 1) * n // G
+    full = dict(s0=e.buf[0][0].clone(), s1=e.buf[1][0].clone(), lp=e.buf[e.cur][1].clone(), dl=e.buf[e.cur][2].clone())
+    mine = dict(s0=e.buf[0][0], s1=e.buf[1][0], lp=e.buf[e.cur][1], dl=e.buf[e.cur][2])
+    a_full = [e.alive_row[e.ar].clone(), torch.zeros_like(e.alive_row[0])]
+    a_mine = [e.alive_row[e.ar].clone(), torch.zeros_like(e.alive_row[0])]
+    flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    scratch = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    for k in range(3):
+        sweep = e.sweep + k
+        cnt = ops.smc_swarm_rows_shard(a_full[0], a_full[1], n, 0, n, full["s0"], full["s1"], full["lp"], full["dl"], flags,
+                                       eps, g0, 1e-5, sweep)
+        assert ops.smc_swarm_rows_shard(a_mine[0], a_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], mine["lp"], mine["dl"],
+                                        scratch, eps, g0, 1e-5, sweep, want_counts=False) is None
+        own = a_mine[0][r_lo:r_hi].to(torch.int64) & 0x7FFFFFFF
+        assert torch.equal(scratch[own], flags[own])                          # the owner's flags
+        assert ops.smc_replay_rows(a_mine[0], a_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], flags, g0, 1e-5,
+                                   sweep) == cnt                              # global counters from the flags
+        assert 0.05 * n < cnt[0] < 0.6 * n and cnt[1] == n                    # Normal prior: every proposal simulated
+        assert torch.equal(a_mine[1][:n], a_full[1][:n])
+        for key in ("s0", "s1"):                                              # both slots: current AND previous rows
+            assert checksum(mine[key]) == checksum(full[key])
+        assert torch.equal(mine["dl"][own], full["dl"][own]) and torch.equal(mine["lp"][own], full["lp"][own])
+        # next sweep: the other owners' distances / log-priors arrive by all-gather in the real job
+        mine["dl"].copy_(full["dl"]); mine["lp"].copy_(full["lp"])
+        a_full.reverse(); a_mine.reverse()
+
+
 def test_config2_abcdemc_one_million_particles(oracle):
     """BASELINE.json configs[1]: 1-D Normal, abcdemc, N = 2^20 (60 generations): posterior mean, never-worsening distances,
     sortedness of the per-generation order, agreement with the oracle on a strided sample of one sweep."""
