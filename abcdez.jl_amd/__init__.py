@@ -18,7 +18,7 @@ from .priors import Beta, DiscreteUniform, Factored, NegativeBinomial, Normal, U
 from .simulators import (  # noqa: F401
     DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, UserSimulator, WienerRMS,
 )
-from .smc import abcdesmc, get_ess, quantile_type7, wsample_stratified  # noqa: F401
+from .smc import abcdesmc, get_ess, load_checkpoint, quantile_type7, save_checkpoint, wsample_stratified  # noqa: F401
 from .mc import abcdemc  # noqa: F401
 
 __version__ = "0.1.0"

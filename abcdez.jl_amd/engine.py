@@ -508,6 +508,43 @@ class PopulationEngine:
         self._swap()
         return self._allreduce_counts(nsim)[0]
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def download_state(self) -> dict:
+        """Everything a later run needs to continue this one bit for bit: the population arrays the reference
+        driver owns (thetas, logpi, Ds, Wns, alive; smc:242-270) and the two RNG epochs.  Host numpy arrays."""
+        th, lp, dl = self.state
+        return {
+            "theta": th.cpu().numpy().copy(), "logpi": lp.cpu().numpy().copy(), "delta": dl.cpu().numpy().copy(),
+            "wns": self.wns.cpu().numpy().copy(), "alive": self.alive.cpu().numpy().copy(),
+            "sweep": int(self.sweep), "draw": int(self.draw), "N": self.N, "ld": int(th.shape[1]),
+            "seed": int(self.spec.seed),
+        }
+
+    def upload_state(self, st: dict):
+        """Inverse of :meth:`download_state` (every rank uploads the full arrays)."""
+        th = torch.as_tensor(np.ascontiguousarray(st["theta"], dtype=np.float64))
+        if tuple(th.shape) != tuple(self.buf[0][0].shape):
+            raise ValueError(f"checkpoint holds a population of shape {tuple(th.shape)}, "
+                             f"the engine expects {tuple(self.buf[0][0].shape)}")
+        if int(st.get("seed", self.spec.seed)) != int(self.spec.seed):
+            raise ValueError("checkpoint was written with a different seed: the run would not continue its own stream")
+        self.cur = 0
+        cur = self.buf[0]
+        cur[0].copy_(th)
+        cur[1].copy_(torch.as_tensor(np.ascontiguousarray(st["logpi"], dtype=np.float64)))
+        cur[2].copy_(torch.as_tensor(np.ascontiguousarray(st["delta"], dtype=np.float64)))
+        self.wns.copy_(torch.as_tensor(np.ascontiguousarray(st["wns"], dtype=np.float64)))
+        self.alive.copy_(torch.as_tensor(np.ascontiguousarray(st["alive"], dtype=np.uint8)))
+        self.n_alive = int(self.alive.sum().item())
+        self.sweep, self.draw = int(st["sweep"]), int(st["draw"])
+        if self.rows_mode:                       # every particle's current row is slot 0 again
+            self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
+            self._rows_dirty = False
+            self._rows_n = 0
+        self._delta_stale = self._logpi_stale = False
+        self._dead_carried = False
+        self.row_synced.zero_()
+
     # ------------------------------------------------------------------ results (smc:382-393, mc:166-171)
     def result(self):
         th, lp, dl = self.state

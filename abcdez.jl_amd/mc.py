@@ -11,19 +11,20 @@ import math
 
 from .model import ModelSpec
 from .priors import prior_length
-from .smc import Result, _check, _make_engine
+from .smc import Result, _check, _make_engine, load_checkpoint
 
 log = logging.getLogger("abcdez_amd")
 
 
 def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
             nparticles: int = 50, generations: int = 20, verbose: bool = True, rng: int = 1,
-            parallel: bool = True, engine=None, process_group=None):
+            parallel: bool = True, engine=None, process_group=None, resume=None):
     """Run ABC with differential-evolution moves in an MCMC setup (src/abcdez_mc.jl:102).
 
     Same arguments and defaults as the reference (see :func:`abcdesmc` for the
     differences in ``dist``/``rng``/``parallel``).  Returns ``(P, C, reached_ϵ, blobs)``
-    (src/abcdez_mc.jl:171) as a namespace.
+    (src/abcdez_mc.jl:171) as a namespace.  ``resume=result.checkpoint()`` (or a file written by
+    ``save_checkpoint``) continues an earlier run up to ``generations`` in total, bit for bit.
     """
     α = 0.0                                                   # mc:107
     _check(0.0 <= ϵ_target, "ϵ_target must be non-negative")  # mc:108
@@ -36,12 +37,17 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
         log.info("Running abcdemc with engine %s: ϵ_target=%s nparticles=%d generations=%d seed=%d",
                  type(eng).__name__, ϵ_target, nparticles, generations, spec.seed)
 
-    eng.init_population()                                     # mc:117-125 (S1)
-
-    nsims = 0                                                 # mc:128
+    if resume is None:
+        eng.init_population()                                 # mc:117-125 (S1)
+        nsims = 0                                             # mc:128
+        iters = 0
+    else:
+        ck = load_checkpoint(resume) if isinstance(resume, (str, bytes)) or hasattr(resume, "__fspath__") else resume
+        _check(ck.get("kind") == "abcdemc", "resume: not an abcdemc checkpoint")
+        eng.upload_state(ck["state"])
+        nsims, iters = int(ck["host"]["nsims"]), int(ck["host"]["iters"])
     γ0 = 2.38 / math.sqrt(2 * prior_length(prior))            # mc:129
     γσ = 1e-5                                                 # mc:130
-    iters = 0
     complete = 1 - eng.count_gt(ϵ_target) / nparticles        # mc:133
     while iters < generations:                                # mc:134
         iters += 1
@@ -64,4 +70,6 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     out.reached_eps = conv
     out.nsims, out.updates, out.complete = nsims, generations * nparticles, complete
     out.engine = eng
+    out.checkpoint = lambda: {"kind": "abcdemc", "state": eng.download_state(),
+                              "host": {"nsims": nsims, "iters": iters}, "history": None}
     return out

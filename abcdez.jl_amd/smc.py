@@ -36,6 +36,27 @@ class Result(SimpleNamespace):
         raise AttributeError(name)
 
 
+def save_checkpoint(path, ckpt: dict) -> None:
+    """Write a checkpoint dict (``result.checkpoint()``) to ``path`` (numpy ``.npz``; scalars and histories as JSON)."""
+    import json
+
+    arrays = {k: v for k, v in ckpt["state"].items() if isinstance(v, np.ndarray)}
+    meta = {"kind": ckpt["kind"], "host": ckpt["host"], "history": ckpt.get("history"),
+            "state": {k: v for k, v in ckpt["state"].items() if not isinstance(v, np.ndarray)}}
+    with open(path, "wb") as f:      # np.savez on a file object: no ".npz" appended to the name
+        np.savez(f, __meta__=np.frombuffer(json.dumps(meta).encode("utf-8"), dtype=np.uint8), **arrays)
+
+
+def load_checkpoint(path) -> dict:
+    import json
+
+    with np.load(path) as z:
+        meta = json.loads(bytes(z["__meta__"]).decode("utf-8"))
+        state = {k: z[k] for k in z.files if k != "__meta__"}
+    state.update(meta["state"])
+    return {"kind": meta["kind"], "state": state, "host": meta["host"], "history": meta.get("history")}
+
+
 def get_ess(Wns) -> float:
     """Effective sample size ``1/sum(Wns.^2)`` (src/abcdez_smc.jl:8), host version."""
     w = np.asarray(Wns, dtype=np.float64)
@@ -100,7 +121,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
              nsims_max: int = 10 ** 7, Kmcmc: int = 3, Kmcmc_min: float = 1.0,
              ABCk=IndicatorStrict0toϵ, facc_stop: float = 0.0, facc_min: float = 0.0, facc_tune: float = 0.975,
              verbose: bool = True, verboseout: bool = True, rng: int = 1, parallel: bool = True,
-             engine=None, process_group=None, max_iters: int = 1_000_000):
+             engine=None, process_group=None, max_iters: int = 1_000_000, resume=None):
     """Run ABC with differential-evolution moves in an SMC setup (src/abcdez_smc.jl:215).
 
     Same positional arguments, keywords and defaults as the reference, except:
@@ -110,6 +131,11 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
     constants).  Returns a namespace with the reference's fields
     ``P, Wns, C, ϵ, logZ, blobs`` and, with ``verboseout``, ``ϵs, ranges_ϵ, logZs,
     esss, faccs, γ0s, Kmcmcs`` (src/abcdez_smc.jl:388-393).
+
+    Checkpoint / resume: ``max_iters`` stops the loop after that many generations (in total); the result's
+    ``checkpoint()`` returns the population and the host loop's variables, and ``resume=<that dict>`` (or the
+    path of a file written by :func:`save_checkpoint`) continues the run.  All randomness is counter-based,
+    so a resumed run reproduces the uninterrupted one bit for bit.
     """
     # ---- initialisation / validation: src/abcdez_smc.jl:223-235
     _check(0.0 <= α < 1.0, "α must be in 0 <= α < 1")
@@ -137,34 +163,47 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
                  ϵ_target, nparticles, α, δess, nsims_max, Kmcmc, Kmcmc_min, ABCk.__name__, facc_stop, facc_min,
                  facc_tune, spec.seed)
 
-    # prior draws, log-prior, first distances, redraw until finite: smc:242-252 (S1)
-    eng.init_population()
-
-    ϵ = math.inf                       # smc:255
-    ϵ_k = math.inf                     # smc:256 (the kernel object is (ABCk, ϵ_k))
-    ABCk(ϵ_k)                          # ctor check, types.jl:30
     ess_min = nparticles * δess        # smc:259
-    logZ = 0.0                         # smc:263
-    eng.reset_weights()                # Wns = 1/N, alive = true: smc:266-270
-    ess = 0.0
-    nsims = 0                          # sum(nsims), smc:274
-    facc = 1.0
-    Ki = Kmcmc
-    γ0 = 2.38 / math.sqrt(2 * d)       # smc:280
     γσ = 1e-5                          # smc:281
-    updates = 0                        # Σ over sweeps of n_alive (the bench metric's numerator)
+    if resume is None:
+        # prior draws, log-prior, first distances, redraw until finite: smc:242-252 (S1)
+        eng.init_population()
 
-    if verboseout:                     # smc:284-292
-        ϵs = [ϵ]
-        ranges_ϵ = [eng.extrema()]
-        logZs = [logZ]
-        esss = [eng.get_ess()]
-        faccs = [facc]
-        γ0s = [γ0]
-        Kmcmcs = [Ki]
+        ϵ = math.inf                       # smc:255
+        ϵ_k = math.inf                     # smc:256 (the kernel object is (ABCk, ϵ_k))
+        ABCk(ϵ_k)                          # ctor check, types.jl:30
+        logZ = 0.0                         # smc:263
+        eng.reset_weights()                # Wns = 1/N, alive = true: smc:266-270
+        ess = 0.0
+        nsims = 0                          # sum(nsims), smc:274
+        facc = 1.0
+        Ki = Kmcmc
+        γ0 = 2.38 / math.sqrt(2 * d)       # smc:280
+        updates = 0                        # Σ over sweeps of n_alive (the bench metric's numerator)
+        iters = 0
 
-    iters = 0
-    while True:                        # smc:295
+        if verboseout:                     # smc:284-292
+            ϵs = [ϵ]
+            ranges_ϵ = [eng.extrema()]
+            logZs = [logZ]
+            esss = [eng.get_ess()]
+            faccs = [facc]
+            γ0s = [γ0]
+            Kmcmcs = [Ki]
+    else:
+        ck = load_checkpoint(resume) if isinstance(resume, (str, bytes)) or hasattr(resume, "__fspath__") else resume
+        _check(ck.get("kind") == "abcdesmc", "resume: not an abcdesmc checkpoint")
+        eng.upload_state(ck["state"])
+        h = ck["host"]
+        ϵ, ϵ_k, logZ, ess, facc, γ0 = (float(h[k]) for k in ("eps", "eps_k", "logZ", "ess", "facc", "gamma0"))
+        nsims, Ki, updates, iters = (int(h[k]) for k in ("nsims", "Ki", "updates", "iters"))
+        if verboseout:
+            hist = ck.get("history") or {}
+            ϵs, logZs, esss, faccs, γ0s = (list(map(float, hist.get(k, []))) for k in ("eps", "logZ", "ess", "facc", "gamma0"))
+            ranges_ϵ = [tuple(map(float, r)) for r in hist.get("ranges", [])]
+            Kmcmcs = [int(v) for v in hist.get("Kmcmc", [])]
+
+    while iters < max_iters:           # smc:295
         iters += 1
         # new ϵ target, smc:301 (S9: the order statistics come from the device)
         ϵ = max(min(eng.quantile_alive(α), ϵ), ϵ_target)
@@ -208,8 +247,6 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             break
         if ϵ <= ϵ_target or nsims >= nsims_max or facc < facc_stop:   # smc:376
             break
-        if iters >= max_iters:
-            break
 
     if verbose:                        # smc:379
         log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
@@ -219,6 +256,10 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
     out.eps = ϵ
     out.iters, out.nsims, out.updates = iters, nsims, updates
     out.engine = eng
+    host = dict(eps=ϵ, eps_k=ϵ_k, logZ=logZ, ess=ess, facc=facc, gamma0=γ0, nsims=nsims, Ki=Ki, updates=updates, iters=iters)
+    history = dict(eps=list(ϵs), logZ=list(logZs), ess=list(esss), facc=list(faccs), gamma0=list(γ0s),
+                   ranges=[tuple(r) for r in ranges_ϵ], Kmcmc=list(Kmcmcs)) if verboseout else None
+    out.checkpoint = lambda: {"kind": "abcdesmc", "state": eng.download_state(), "host": dict(host), "history": history}
     if verboseout:
         out.ϵs, out.ranges_ϵ, out.logZs, out.esss = ϵs, ranges_ϵ, logZs, esss
         out.faccs, out.γ0s, out.Kmcmcs = faccs, γ0s, Kmcmcs

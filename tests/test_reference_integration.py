@@ -228,3 +228,43 @@ def test_socks_abcdesmc_strict_kernel(oracle):
     al = r.Wns > 0
     assert isaround(r.P[al, 0], 46.2) and isaround(r.P[al, 1], 0.866)
     assert (r.C[al] == 0).all()
+
+
+# ---------------------------------------------------------------- checkpoint / resume
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_abcdesmc_resume_reproduces_the_uninterrupted_run(oracle, tmp_path, abck):
+    """Stop after 7 generations, write the checkpoint to disk, continue in a fresh engine: population, weights,
+    evidence and every history entry equal the uninterrupted run bit for bit (the randomness is counter-based)."""
+    prior = A.Factored(*[A.Normal(0.0, 1.0)] * 8)
+    sim = A.MVNormal((1.0,) * 8)
+    kw = dict(nparticles=1500, rng=17, ABCk=abck, facc_min=0.3)
+    full = smc(oracle, prior, sim, 2.4, **kw)
+    part = smc(oracle, prior, sim, 2.4, max_iters=7, **kw)
+    assert part.iters == 7 < full.iters
+    path = tmp_path / "smc.ckpt"
+    A.save_checkpoint(path, part.checkpoint())
+    rest = smc(oracle, prior, sim, 2.4, resume=path, **kw)
+    assert rest.iters == full.iters and rest.nsims == full.nsims and rest.updates == full.updates
+    assert rest.logZ == full.logZ and rest.ϵ == full.ϵ
+    for a, b in ((rest.P, full.P), (rest.Wns, full.Wns), (rest.C, full.C)):
+        assert np.array_equal(a, b, equal_nan=True)
+    for name in ("ϵs", "logZs", "esss", "faccs", "γ0s", "Kmcmcs", "ranges_ϵ"):
+        assert list(getattr(rest, name)) == list(getattr(full, name)), name
+    # in-memory dict works too, and a checkpoint of the wrong kind / seed is refused
+    again = smc(oracle, prior, sim, 2.4, resume=part.checkpoint(), **kw)
+    assert again.logZ == full.logZ
+    with pytest.raises(ValueError, match="different seed"):
+        smc(oracle, prior, sim, 2.4, resume=part.checkpoint(), **dict(kw, rng=18))
+    with pytest.raises(ValueError, match="not an abcdemc checkpoint"):
+        mc(oracle, prior, sim, 2.4, nparticles=1500, rng=17, resume=part.checkpoint())
+
+
+def test_abcdemc_resume_reproduces_the_uninterrupted_run(oracle, tmp_path):
+    prior, sim = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0)
+    full = mc(oracle, prior, sim, 0.3, nparticles=800, generations=30, rng=5)
+    part = mc(oracle, prior, sim, 0.3, nparticles=800, generations=11, rng=5)
+    path = tmp_path / "mc.ckpt"
+    A.save_checkpoint(path, part.checkpoint())
+    rest = mc(oracle, prior, sim, 0.3, nparticles=800, generations=30, rng=5, resume=A.load_checkpoint(path))
+    assert rest.nsims == full.nsims and rest.reached_ϵ == full.reached_ϵ
+    assert np.array_equal(rest.P, full.P) and np.array_equal(rest.C, full.C)
