@@ -37,6 +37,9 @@ PROTOTYPES = {
     "abcdez_alive_compact_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _pi64],
     "abcdez_smc_swarm_rows": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _pi64, _pi64],
     "abcdez_rows_commit": [_vp, _vp, _i64, _vp],
+    "abcdez_ctx_set_stamps": [_vp, _vp, _vp],
+    "abcdez_blob_width": [_vp, _vp],
+    "abcdez_blob_eval": [_vp, _vp, _vp, _i64, _vp, _vp],
     "abcdez_smc_swarm_rows_shard": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
                                     _pi64, _pi64],
     "abcdez_smc_replay_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],

@@ -563,6 +563,31 @@ enum {
   ABZ_SIM_USER = 9
 };
 
+/* ---- blobs (second return value of dist!, src/abcdez_smc.jl:137,148; docs/src/index.md:298-324).
+ * A blob here is the simulated data behind a particle's current distance.  It is a pure function of the
+ * (push_p-cast) parameters and of the random numbers of ONE simulator call, and those are addressed by
+ * (origin particle, epoch, init-or-sweep) -- so the population carries that 8-byte STAMP with each distance
+ * (set on accept / at init, gathered on resampling exactly like Ds and blobs in smc:96-99) and the blobs are
+ * rebuilt from the stamps when the result is read.  The rebuilt distance must equal the stored one bit for bit. */
+#define ABZ_MAX_BLOB 64
+#define ABZ_STAMP_INIT 0x8000000000000000ull
+ABZ_HD uint64_t abz_stamp(uint32_t origin, uint32_t epoch, int init) {
+  return (uint64_t)origin | ((uint64_t)(epoch & 0x7FFFFFFFu) << 32) | (init ? ABZ_STAMP_INIT : 0ull);
+}
+ABZ_HD uint32_t abz_stamp_origin(uint64_t st) { return (uint32_t)st; }
+ABZ_HD uint32_t abz_stamp_epoch(uint64_t st) { return (uint32_t)(st >> 32) & 0x7FFFFFFFu; }
+ABZ_HD int abz_stamp_is_init(uint64_t st) { return (int)(st >> 63); }
+/* doubles per blob of the built-in simulators: the simulated datum / data vector (-1: declared by the user) */
+ABZ_HD int abz_sim_blob_size(int sim_id, int d, int n_data) {
+  switch (sim_id) {
+    case ABZ_SIM_NORMAL1D: case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: case ABZ_SIM_NORMDU: return 1;
+    case ABZ_SIM_QUAD2D: case ABZ_SIM_SOCKS: return 2;
+    case ABZ_SIM_MVN: return d;
+    case ABZ_SIM_WIENER: case ABZ_SIM_LV: return n_data;
+    default: return -1;
+  }
+}
+
 typedef struct abz_model {
   int32_t d;        /* length(prior)                                               */
   int32_t ld;       /* row stride of theta in doubles: smallest power of two >= d  */
@@ -570,7 +595,7 @@ typedef struct abz_model {
   int32_t abck;     /* ABZ_K_*  (ABCk keyword, smc:218)                            */
   uint64_t seed;    /* Philox key                                                  */
   int32_t n_data;
-  int32_t reserved;
+  int32_t n_blob;   /* doubles per blob (0 = blobs off); must equal abz_sim_blob_size() for the built-in simulators */
   double sim_p[8];
   const double* data; /* n_data doubles: host memory for the oracle, device memory for the HIP library */
   abz_prior_dim prior[ABZ_MAX_D]; /* entries d..ld-1 are ABZ_PRIOR_PAD             */

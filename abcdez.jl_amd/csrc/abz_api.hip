@@ -102,6 +102,11 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
       break;
     default: break;
   }
+  /* blobs: off (0), or exactly the simulated data of the built-in simulator / the size the user source declares */
+  ABZ_REQUIRE(model->n_blob >= 0 && model->n_blob <= ABZ_MAX_BLOB, "model: n_blob must be in 0..64");
+  if (model->n_blob > 0 && model->sim_id != ABZ_SIM_USER)
+    ABZ_REQUIRE(model->n_blob == abz_sim_blob_size(model->sim_id, model->d, model->n_data),
+                "model: n_blob does not match the simulated data of this simulator");
   int ndev = 0;
   ABZ_HIP_CHECK(hipGetDeviceCount(&ndev));
   ABZ_REQUIRE(ndev > 0, "ctx_create: no HIP device visible");
@@ -125,7 +130,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
   for (int q = 0; q < 8; ++q) ctx->hot.sim_p[q] = model->sim_p[q];
-  ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.reserved = 0;
+  ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.n_blob = model->n_blob;
   ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
   ABZ_HIP_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
   ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
@@ -249,6 +254,31 @@ int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, 
 }
 
 #define ABZ_MAX_N 0x7FFFFFFFll /* indices are 32-bit on the device */
+
+/* ---- blobs (second return value of dist!): stamps carried with the distances, data rebuilt on demand ---- */
+int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_nxt) {
+  ABZ_REQUIRE(ctx, "set_stamps: null context");
+  ABZ_REQUIRE((stamp_cur == nullptr) == (stamp_nxt == nullptr), "set_stamps: pass both arrays or neither");
+  ABZ_REQUIRE(stamp_cur == nullptr || stamp_cur != stamp_nxt, "set_stamps: the two arrays must differ");
+  ABZ_REQUIRE(stamp_cur == nullptr || ctx->h_model.n_blob > 0, "set_stamps: the model was created with n_blob = 0");
+  ctx->stamp_cur = stamp_cur; ctx->stamp_nxt = stamp_nxt;
+  return 0;
+}
+
+int abcdez_blob_width(abcdez_ctx* ctx, int32_t* width) {
+  ABZ_REQUIRE(ctx && width, "blob_width: null argument");
+  *width = ctx->h_model.sim_id == ABZ_SIM_MVN ? ctx->h_model.ld : ctx->h_model.n_blob;
+  return 0;
+}
+
+int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
+                     double* delta_out) {
+  ABZ_REQUIRE(ctx && theta && stamp && blob && delta_out, "blob_eval: null argument");
+  ABZ_REQUIRE(ctx->h_model.n_blob > 0, "blob_eval: the model was created with n_blob = 0");
+  ABZ_REQUIRE(N >= 0 && N <= ABZ_MAX_N, "blob_eval: N out of range");
+  const uint32_t nbw = (uint32_t)(ctx->h_model.sim_id == ABZ_SIM_MVN ? ctx->h_model.ld : ctx->h_model.n_blob);
+  return abz_launch_blob_eval(ctx, theta, stamp, N, blob, delta_out, nbw);
+}
 
 int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
   ABZ_REQUIRE(ctx && theta && logpi && delta, "init: null argument");

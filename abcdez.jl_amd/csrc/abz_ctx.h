@@ -31,6 +31,10 @@ struct abcdez_ctx {
   /* per-block (nacc, nsim) partials of the sweep kernels */
   void* cnt = nullptr;
   size_t cnt_bytes = 0;
+  /* blob stamps of the current / next generation (abcdez_ctx_set_stamps); null = blobs off.  The launchers that
+   * take (logpi, nlogpi)-style pairs use (stamp_cur, stamp_nxt) alongside; row-store calls update stamp_cur in place */
+  uint64_t* stamp_cur = nullptr;
+  uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
   bool timing = false, ev_pending = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -87,7 +91,11 @@ int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, unsigned long long* d_out);
 int abz_jit_build(abcdez_ctx*, const char* user_source);
 void abz_jit_destroy(abcdez_ctx*);
-int abz_jit_launch_init(abcdez_ctx*, double*, double*, double*, uint32_t, uint32_t, unsigned long long*);
+int abz_jit_launch_init(abcdez_ctx*, double*, double*, double*, uint32_t, uint32_t, unsigned long long*, uint64_t* stamp);
+int abz_jit_launch_blob(abcdez_ctx*, const double* theta, const uint64_t* stamp, uint32_t n, double* blob,
+                        double* delta_out, uint32_t nbw);
+int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp, int64_t n, double* blob,
+                         double* delta_out, uint32_t nbw);
 int abz_jit_launch_smc(abcdez_ctx*, const void* args, unsigned nblocks);
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned nblocks);
 

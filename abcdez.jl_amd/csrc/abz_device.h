@@ -179,14 +179,21 @@ __device__ double abz_user_dist(const double* theta, int d, const double* data, 
                                 abz_user_rng& rng);
 
 /* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
-template <int SIM, int L, int C>
+/* BLOB = true additionally writes the simulated data behind the distance to blob[] (this lane's C entries in
+ * row layout for L > 1, the whole blob for L = 1); only abz_blob_eval instantiates it -- the sweeps never do. */
+__device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                              abz_user_rng& rng, double* blob, int n_blob);
+
+template <int SIM, int L, int C, bool BLOB = false>
 __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j, const double (&th)[C],
-                                  const double* y /* LDS, ld */, uint32_t i, uint32_t epoch, uint32_t purpose) {
+                                  const double* y /* LDS, ld */, uint32_t i, uint32_t epoch, uint32_t purpose,
+                                  double* blob = nullptr) {
   const uint64_t seed = M.seed;
   if constexpr (SIM == ABZ_SIM_NORMAL1D) {
     double z0, z1;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
     const double x = abz_fma(M.sim_p[0], z0, th[0]);
+    if constexpr (BLOB) blob[0] = x;
     return __builtin_fabs(x - M.data[0]);
   } else if constexpr (SIM == ABZ_SIM_MVN) {
     const double sg = M.sim_p[0];
@@ -195,7 +202,9 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     if constexpr (C == 1) {
       double z0, z1;
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
-      const double e = abz_fma(sg, z0, th[0]) - y[0];
+      const double x = abz_fma(sg, z0, th[0]);
+      if constexpr (BLOB) blob[0] = x;
+      const double e = x - y[0];
       sq[0] = e * e;
     } else {
 #pragma unroll
@@ -206,8 +215,11 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
         for (int c = 0; c < 2; ++c) {
           const int k = Lay<L, C>::comp(j, m, c);
           double v = 0.0;
+          if constexpr (BLOB) blob[2 * m + c] = 0.0;
           if (k < d) {
-            const double e = abz_fma(sg, z[c], th[2 * m + c]) - y[k];
+            const double x = abz_fma(sg, z[c], th[2 * m + c]);
+            if constexpr (BLOB) blob[2 * m + c] = x;
+            const double e = x - y[k];
             v = e * e;
           }
           sq[2 * m + c] = v;
@@ -216,7 +228,9 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     }
     return abz_sqrt(group_tree_sum<L, C>(sq));
   } else if constexpr (SIM == ABZ_SIM_DIRAC) {
-    return __builtin_fabs((th[0] * th[0] + 1.0) - M.sim_p[0]);
+    const double x = th[0] * th[0] + 1.0;
+    if constexpr (BLOB) blob[0] = x;
+    return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_QUAD2D) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
@@ -224,17 +238,20 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     const double a = (th[0] + n1 * 0.01) - th[1] * th[1];
     const double b = (th[1] - 1.0) + n2 * 0.01;
     const double r = 50.0 * (a * a) + b * b;
+    if constexpr (BLOB) { blob[0] = a; blob[1] = b; }
     return (u < M.sim_p[0]) ? ABZ_INF : r;
   } else if constexpr (SIM == ABZ_SIM_MIXTURE) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
     const uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
     const double x = th[0] + (coin ? n2 : n1 * 0.1);
+    if constexpr (BLOB) blob[0] = x;
     return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_NORMDU) {
     double n1, n2;
     abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &n1, &n2);
     const double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
+    if constexpr (BLOB) blob[0] = x;
     return __builtin_fabs(x - M.sim_p[0]);
   } else if constexpr (SIM == ABZ_SIM_WIENER) {
     const double f = 0.95 + 0.1 * abz_u01_co(abz_rng(seed, i, epoch, 0, purpose).w0);
@@ -243,6 +260,7 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     for (int t = 0; t < n; ++t) {
       const double dt = (double)t;
       const double v = abz_sqrt(th[0] * th[0] * dt * dt + th[1] * th[1] * dt) * f;
+      if constexpr (BLOB) { if (t < ABZ_MAX_BLOB) blob[t] = v; }
       acc += __builtin_fabs(v - M.data[t]);
     }
     return acc / (double)n;
@@ -257,8 +275,10 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     for (int jo = 0; jo < nobs; ++jo) {
       double z0, z1;
       abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), T, &z0, &z1);
-      const double ex = abz_fma(sn, z0, x) - M.data[2 * jo];
-      const double ey = abz_fma(sn, z1, y) - M.data[2 * jo + 1];
+      const double ox = abz_fma(sn, z0, x), oy = abz_fma(sn, z1, y);
+      if constexpr (BLOB) { if (2 * jo + 1 < ABZ_MAX_BLOB) { blob[2 * jo] = ox; blob[2 * jo + 1] = oy; } }
+      const double ex = ox - M.data[2 * jo];
+      const double ey = oy - M.data[2 * jo + 1];
       acc = abz_fma(ex, ex, acc);
       acc = abz_fma(ey, ey, acc);
       if (jo + 1 == nobs) break;
@@ -278,6 +298,12 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
   } else if constexpr (SIM == ABZ_SIM_USER) {
     static_assert(L == 1, "user simulators see the whole row in one thread");
     abz_user_rng rng{seed, i, epoch, purpose, 0u, T};
+#ifdef ABZ_USER_HAS_BLOB
+    if constexpr (BLOB) {       /* the user's blob function re-runs the simulation on a fresh copy of the same stream */
+      abz_user_rng rng2{seed, i, epoch, purpose, 0u, T};
+      abz_user_blob(th, M.d, M.data, M.n_data, M.sim_p, rng2, blob, M.n_blob);
+    }
+#endif
     return abz_user_dist(th, M.d, M.data, M.n_data, M.sim_p, rng);
   } else if constexpr (SIM == ABZ_SIM_SOCKS) {
     double ns = th[0];
@@ -303,6 +329,7 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
       uniq += (t == 0) || (id != idp);
     }
     const double pairs = (double)(m - uniq), odds = (double)uniq - (double)(m - uniq);
+    if constexpr (BLOB) { blob[0] = pairs; blob[1] = odds; }
     return __builtin_fabs(pairs - M.sim_p[0]) + __builtin_fabs(odds - M.sim_p[1]);
   } else {
     return ABZ_NAN;

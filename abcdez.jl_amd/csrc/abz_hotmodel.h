@@ -14,7 +14,7 @@ struct HotModel {
   const double* data;           /* device, n_data values */
   const abz_tables* tables;     /* device copy of the sampler tables */
   double sim_p[8];
-  int32_t d, abck, n_data, reserved;
+  int32_t d, abck, n_data, n_blob;
 };
 
 #endif

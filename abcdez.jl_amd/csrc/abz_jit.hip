@@ -21,7 +21,7 @@
 
 struct AbzUserModule {
   hipModule_t mod = nullptr;
-  hipFunction_t f_init = nullptr, f_smc = nullptr, f_mc = nullptr;
+  hipFunction_t f_init = nullptr, f_smc = nullptr, f_mc = nullptr, f_blob = nullptr;
 };
 
 #define ABZ_RTC_CHECK(expr)                                                                \
@@ -39,12 +39,17 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   tu += user_source;
   tu += "\n#line 1 \"abz_user_entry\"\n";
   tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_init(const HotModel M, double* theta, "
-        "double* logpi, double* delta, uint32_t i0, uint32_t n, unsigned long long* bad) {\n"
-        "  init_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad);\n}\n"
+        "double* logpi, double* delta, uint32_t i0, uint32_t n, unsigned long long* bad, uint64_t* stamp) {\n"
+        "  init_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad, stamp);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc(const SmcSwarmArgs a) {\n"
         "  smc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_mc(const McSwarmArgs a) {\n"
         "  mc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n";
+  const bool has_blob = ctx->h_model.n_blob > 0;     /* then the source must also define abz_user_blob */
+  if (has_blob)
+    tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_blob_eval(const HotModel M, const double* theta, "
+          "const uint64_t* stamp, uint32_t n, double* blob, double* delta_out, uint32_t nbw) {\n"
+          "  blob_eval_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, stamp, n, blob, delta_out, nbw);\n}\n";
   hiprtcProgram prog;
   ABZ_RTC_CHECK(hiprtcCreateProgram(&prog, tu.c_str(), "abz_user.hip", abz_jit_n_headers, (const char**)abz_jit_header_sources,
                                     (const char**)abz_jit_header_names));
@@ -54,8 +59,9 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   const size_t colon = arch.find(':');                 /* "gfx950:sramecc+:xnack-" -> "gfx950" */
   if (colon != std::string::npos) arch = arch.substr(0, colon);
   const std::string defc = "-DABZ_USER_C=" + std::to_string(C);
-  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", defc.c_str()};
-  const hiprtcResult cr = hiprtcCompileProgram(prog, 6, opts);
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", defc.c_str(),
+                        "-DABZ_USER_HAS_BLOB=1"};
+  const hiprtcResult cr = hiprtcCompileProgram(prog, has_blob ? 7 : 6, opts);
   if (cr != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
@@ -75,6 +81,7 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_init, um->mod, "abz_user_init"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smc, um->mod, "abz_user_smc"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_mc, um->mod, "abz_user_mc"));
+  if (has_blob) ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_blob, um->mod, "abz_user_blob_eval"));
   ctx->user_module = um;
   return 0;
 }
@@ -88,11 +95,21 @@ void abz_jit_destroy(abcdez_ctx* ctx) {
 }
 
 int abz_jit_launch_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, uint32_t i0, uint32_t n,
-                        unsigned long long* bad) {
+                        unsigned long long* bad, uint64_t* stamp) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   HotModel M = ctx->hot;
-  void* params[] = {&M, &theta, &logpi, &delta, &i0, &n, &bad};
+  void* params[] = {&M, &theta, &logpi, &delta, &i0, &n, &bad, &stamp};
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
+                                      params, nullptr));
+  return 0;
+}
+int abz_jit_launch_blob(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp, uint32_t n, double* blob,
+                        double* delta_out, uint32_t nbw) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  if (!um || !um->f_blob) { abz_set_error("blob_eval: the user simulator was built without blobs (n_blob = 0)"); return -3; }
+  HotModel M = ctx->hot;
+  void* params[] = {&M, &theta, &stamp, &n, &blob, &delta_out, &nbw};
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_blob, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
                                       params, nullptr));
   return 0;
 }

@@ -15,7 +15,8 @@
 template <int SIM, int L, int C>
 __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ theta,
                                                          double* __restrict__ logpi, double* __restrict__ delta,
-                                                         uint32_t i0, uint32_t n, unsigned long long* __restrict__ bad) {
+                                                         uint32_t i0, uint32_t n, unsigned long long* __restrict__ bad,
+                                                         uint64_t* __restrict__ stamp = nullptr) {
   constexpr int LD = L * C;
   __shared__ ModelLds<LD> s_model;
   {
@@ -66,7 +67,10 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
     }
   }
   store_row<L, C>(theta + (size_t)i * LD, j, th);
-  if (j == 0) { logpi[i] = lp; delta[i] = dl; }
+  if (j == 0) {
+    logpi[i] = lp; delta[i] = dl;
+    if (stamp) stamp[i] = abz_stamp(i, retry, 1);              /* which simulator call made this distance (blobs) */
+  }
 }
 
 /* ================================================================ S2+S3: abcdesmc_swarm! (src/abcdez_smc.jl:106-153) */
@@ -95,6 +99,9 @@ struct SmcSwarmArgs {
    * the only thing the other ranks need to replay the accepted proposals on their replicas and to know the
    * sweep's global counters (smc_replay_kernel_body); NULL = not recorded */
   uint8_t* acc_flag;
+  /* blob stamps (abcdez_spec.h, abz_stamp): carried like the distances; both NULL when blobs are off */
+  const uint64_t* stamp;
+  uint64_t* nstamp;
 };
 
 template <int SIM, int L, int C>
@@ -147,7 +154,10 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
   if (active && a.rows) {                                         /* smc:146-150, row-store mode */
     if (acc) {
       store_row<L, C>(((rowi >> 31) ? const_cast<double*>(a.theta) : a.ntheta) + (size_t)i * LD, j, tp);
-      if (j == 0) { a.nlogpi[i] = lp; a.ndelta[i] = dp; }
+      if (j == 0) {
+        a.nlogpi[i] = lp; a.ndelta[i] = dp;
+        if (a.nstamp) a.nstamp[i] = abz_stamp(i, a.sweep, 0);
+      }
     }
     if (j == 0) {
       a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
@@ -166,6 +176,7 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
     if (j == 0) {
       a.nlogpi[i] = acc ? lp : lpi;
       a.ndelta[i] = acc ? dp : dli;
+      if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
       if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
     }
   }
@@ -279,6 +290,8 @@ struct McSwarmArgs {
   uint2* partials;
   double eps_pop, eps_target, gamma0, gsig;
   uint32_t N, i0, n_local, sweep;
+  const uint64_t* stamp;        /* blob stamps, both NULL when blobs are off */
+  uint64_t* nstamp;
 };
 
 __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
@@ -353,9 +366,59 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
     if (j == 0) {
       a.nlogpi[i] = acc ? lp : lpi;
       a.ndelta[i] = acc ? dp : di;
+      if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
     }
   }
   block_count2(false, active && j == 0 && simulate, a.partials);
+}
+
+/* ================================================================ blobs: the second return value of dist! (smc:137,148)
+ * Rebuilt when the result is read: particle s re-runs the ONE simulator call its stamp names (origin particle,
+ * epoch, init-or-sweep stream) on its current push_p-cast parameters and writes the simulated data to blob[s][:].
+ * delta_out[s] is the distance of that re-run -- it must equal the stored distance bit for bit (checked by the
+ * host).  theta: dense current rows [n][LD]; blob rows are nbw doubles wide (LD for the MVN simulator, whose blob
+ * is laid out like a theta row; n_blob otherwise).                                                           */
+template <int SIM>
+struct BlobLocal {
+  static constexpr int N = (SIM == ABZ_SIM_WIENER || SIM == ABZ_SIM_LV || SIM == ABZ_SIM_USER) ? ABZ_MAX_BLOB : 2;
+};
+
+template <int SIM, int L, int C>
+__device__ inline void blob_eval_kernel_body(const HotModel& M, const double* __restrict__ theta,
+                                             const uint64_t* __restrict__ stamp, uint32_t n,
+                                             double* __restrict__ blob, double* __restrict__ delta_out, uint32_t nbw) {
+  constexpr int LD = L * C;
+  __shared__ ModelLds<LD> s_model;
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
+  __syncthreads();
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t s = gid / L;
+  const int j = (int)(gid % L);
+  if (s >= n) return;                         /* whole groups leave together */
+  double th[C], pp[C];
+  load_row<L, C>(theta + (size_t)s * LD, j, th);
+  (void)group_logprior<L, C>(s_model.prior, j, th, pp);        /* push_p (types.jl:20-23) */
+  const uint64_t st = stamp[s];
+  const uint32_t purpose = abz_stamp_is_init(st) ? (uint32_t)ABZ_RNG_INIT_SIM : (uint32_t)ABZ_RNG_SIM;
+  if constexpr (SIM == ABZ_SIM_MVN) {
+    double b[C];
+    const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
+                                                abz_stamp_epoch(st), purpose, b);
+    store_row<L, C>(blob + (size_t)s * nbw, j, b);             /* nbw == LD */
+    if (j == 0) delta_out[s] = dl;
+  } else {
+    static_assert(SIM == ABZ_SIM_MVN || L == 1, "only the MVN simulator spreads a row over lanes");
+    double b[BlobLocal<SIM>::N];
+    const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
+                                                abz_stamp_epoch(st), purpose, b);
+    const int nb = M.n_blob < BlobLocal<SIM>::N ? M.n_blob : BlobLocal<SIM>::N;
+    for (int q = 0; q < nb; ++q) blob[(size_t)s * nbw + q] = b[q];
+    delta_out[s] = dl;
+  }
 }
 
 #endif /* ABZ_KERNELS_H */

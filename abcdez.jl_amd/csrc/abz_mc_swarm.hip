@@ -29,6 +29,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   a.partials = (uint2*)ctx->cnt;
   a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
+  a.stamp = ctx->stamp_cur; a.nstamp = ctx->stamp_cur ? ctx->stamp_nxt : nullptr;      /* blob stamps */
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
@@ -47,7 +48,8 @@ template <int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_kernel(
     const uint32_t* __restrict__ inds, uint32_t N, uint32_t i0, uint32_t n, const double* __restrict__ theta,
     const double* __restrict__ logpi, const double* __restrict__ delta, double* __restrict__ ntheta,
-    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive) {
+    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive,
+    const uint64_t* __restrict__ stamp, uint64_t* __restrict__ nstamp) {
   constexpr int LD = L * C;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_kernel(
   if (j == 0) {
     nlogpi[s] = logpi[src];
     ndelta[s] = delta[src];
+    if (nstamp) nstamp[s] = stamp[src];                          /* blobs .= blobs[inds], smc:99 */
     wns[s] = 1.0 / (double)N;
     alive[s] = 1;
   }
@@ -73,7 +76,7 @@ int abz_launch_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N
   bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     hipLaunchKernelGGL((resample_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())),
                        dim3(ABZ_BLOCK), 0, ctx->stream, inds, N, i0, n_local, theta, logpi, delta, ntheta, nlogpi,
-                       ndelta, wns, alive);
+                       ndelta, wns, alive, (const uint64_t*)ctx->stamp_cur, ctx->stamp_cur ? ctx->stamp_nxt : nullptr);
   });
   if (!ok) { abz_set_error("resample_gather: unsupported layout"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
@@ -86,7 +89,8 @@ template <int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_rows_kernel(
     const uint32_t* __restrict__ inds, uint32_t N, const uint32_t* __restrict__ cur_row, double* __restrict__ slot0,
     double* __restrict__ slot1, const double* __restrict__ logpi, const double* __restrict__ delta,
-    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive) {
+    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive,
+    const uint64_t* __restrict__ stamp, uint64_t* __restrict__ nstamp) {
   constexpr int LD = L * C;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t s = gid / L;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_rows_kernel(
   if (j == 0) {
     nlogpi[s] = logpi[src];
     ndelta[s] = delta[src];
+    if (nstamp) nstamp[s] = stamp[src];                          /* blobs .= blobs[inds], smc:99 */
     wns[s] = 1.0 / (double)N;
     alive[s] = 1;
   }
@@ -129,7 +134,8 @@ int abz_launch_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, uint3
                                     double* ndelta, double* wns, uint8_t* alive) {
   bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     hipLaunchKernelGGL((resample_gather_rows_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)N * LL())), dim3(ABZ_BLOCK), 0,
-                       ctx->stream, inds, N, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive);
+                       ctx->stream, inds, N, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive,
+                       (const uint64_t*)ctx->stamp_cur, ctx->stamp_cur ? ctx->stamp_nxt : nullptr);
   });
   if (!ok) { abz_set_error("resample_gather_rows: unsupported layout"); return -3; }
   hipLaunchKernelGGL(rows_flip_kernel, dim3(abz_grid(N)), dim3(ABZ_BLOCK), 0, ctx->stream, cur_row, N);

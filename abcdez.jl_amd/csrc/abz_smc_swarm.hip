@@ -33,7 +33,9 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
                                                               const double* __restrict__ delta,
                                                               double* __restrict__ ntheta, double* __restrict__ nlogpi,
                                                               double* __restrict__ ndelta, uint32_t i0, uint32_t n,
-                                                              uint8_t* __restrict__ dead_synced) {
+                                                              uint8_t* __restrict__ dead_synced,
+                                                              const uint64_t* __restrict__ stamp,
+                                                              uint64_t* __restrict__ nstamp) {
   const uint32_t g = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   if (g >= n) return;
   const uint32_t i = i0 + g;
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void copy_dead_kernel(const uint32_t* __
   }
   nlogpi[i] = logpi[i];
   ndelta[i] = delta[i];
+  if (nstamp) nstamp[i] = stamp[i];
 }
 
 int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, uint32_t n_alive,
@@ -75,11 +78,15 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   a.rows = alive_out ? 1u : 0u;
   a.alive_out = alive_out;
   a.acc_flag = acc_flag;
+  /* blob stamps: the row store updates them in place (like logpi / delta), the double buffer writes the next array */
+  a.stamp = ctx->stamp_cur;
+  a.nstamp = ctx->stamp_cur ? (alive_out ? ctx->stamp_cur : ctx->stamp_nxt) : nullptr;
   bool ok = true;
   if (copy_dead && n_local > 0) {
     ok = abz_dispatch_ld(ctx->h_model.ld, [&](auto LD) {
       hipLaunchKernelGGL((copy_dead_kernel<LD()>), dim3(abz_grid((uint64_t)n_local)), dim3(ABZ_BLOCK), 0, ctx->stream,
-                         arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced);
+                         arank, theta, logpi, delta, ntheta, nlogpi, ndelta, i0, n_local, dead_synced,
+                         (const uint64_t*)a.stamp, a.nstamp);
     });
   }
   if (ok && a.n_work > 0) {

@@ -227,6 +227,20 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_push_p(self.ctx, _ptr(theta), theta.shape[0], _ptr(out)))
         _lib.check(self.lib, self.lib.abcdez_sync(self.ctx))
 
+    # ---- blobs: stamps carried with the distances, simulated data rebuilt on demand (include/abcdez_hip.h) ----
+    def set_stamps(self, cur, nxt):
+        _lib.check(self.lib, self.lib.abcdez_ctx_set_stamps(self.ctx, _ptr(cur), _ptr(nxt)))
+
+    def blob_width(self) -> int:
+        w = C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_blob_width(self.ctx, C.byref(w)))
+        return w.value
+
+    def blob_eval(self, theta, stamp, blob, delta_out):
+        _lib.check(self.lib, self.lib.abcdez_blob_eval(self.ctx, _ptr(theta), _ptr(stamp), theta.shape[0], _ptr(blob),
+                                                       _ptr(delta_out)))
+        _lib.check(self.lib, self.lib.abcdez_sync(self.ctx))
+
     def math_eval(self, fn, x, y, y2=None):
         _lib.check(self.lib, self.lib.abcdez_math_eval(self.ctx, fn, _ptr(x), _ptr(y), _ptr(y2), x.numel()))
 
@@ -281,6 +295,9 @@ class PopulationEngine:
             self._rows_n = 0
         if self.sharded_rows:
             self.accepted = torch.zeros(N, dtype=torch.uint8, device=dev)   # accept flags of the last sweep, by particle
+        # blobs (spec.n_blob > 0): one stamp per particle, ping-ponging with (logpi, delta)
+        self.blob_on = getattr(spec, "n_blob", 0) > 0
+        self.stamp = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)] if self.blob_on else None
         self._delta_stale = False    # sharded row store: other ranks' distances / log-priors not yet fetched
         self._logpi_stale = False
         self.wns = torch.full((N,), 1.0 / N, **f64)
@@ -329,10 +346,18 @@ class PopulationEngine:
             self._delta_stale = False
 
     def _sync_logpi(self):
-        """sharded row store: fetch the other ranks' log-priors (read by other ranks only when resampling, smc:97)"""
+        """sharded row store: fetch the other ranks' log-priors and blob stamps (read by other ranks only when
+        resampling, smc:97,99)"""
         if self._logpi_stale:
-            self._allgather_state((self.buf[self.cur][1],))
+            self._allgather_state((self.buf[self.cur][1],) + ((self.stamp[self.cur],) if self.blob_on else ()))
             self._logpi_stale = False
+
+    def _bind_stamps(self):
+        """blobs: tell the ops which stamp arrays belong to the current / next generation"""
+        if self.blob_on:
+            self.ops.set_stamps(self.stamp[self.cur], self.stamp[1 - self.cur])
+        else:
+            self.ops.set_stamps(None, None)
 
     def alive_indices(self) -> torch.Tensor:
         """particle indices of the alive list of the last compaction (int64)"""
@@ -378,8 +403,9 @@ class PopulationEngine:
     # ------------------------------------------------------------------ S1
     def init_population(self):
         th, lp, dl = self.buf[self.cur]
+        self._bind_stamps()
         self.ops.init(th, lp, dl, self.lo, self.n_local)
-        self._allgather_state(self.buf[self.cur])
+        self._allgather_state(self.buf[self.cur] + ((self.stamp[self.cur],) if self.blob_on else ()))
 
     def reset_weights(self):  # smc:266-270
         self.wns.fill_(1.0 / self.N)
@@ -412,6 +438,7 @@ class PopulationEngine:
     def smc_resample(self):
         self.ops.wsample_stratified(self.wns, self.draw, self.inds)
         self.draw += 1
+        self._bind_stamps()
         if self.rows_mode:
             self._rows_commit()
             self._sync_delta()
@@ -426,7 +453,7 @@ class PopulationEngine:
         if self._collectives:
             self.wns.fill_(1.0 / self.N)   # the other ranks' ranges (smc:102-103)
             self.alive.fill_(1)
-        self._allgather_state(self.other)
+        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
         self._swap()
         self.n_alive = self.N
         self._dead_carried = True
@@ -456,6 +483,7 @@ class PopulationEngine:
         return n
 
     def smc_swarm(self, eps: float, gamma0: float, gsig: float):
+        self._bind_stamps()
         if self.sharded_rows:
             cur = self.buf[self.cur]
             a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
@@ -484,7 +512,7 @@ class PopulationEngine:
                                         self.row_synced)
         self.sweep += 1
         self._dead_carried = True
-        self._allgather_state(self.other)
+        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
         self._swap()
         return self._allreduce_counts(nacc, nsim)
 
@@ -501,10 +529,11 @@ class PopulationEngine:
         if self.order is None:   # converged population: the order is never consulted
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
             self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        self._bind_stamps()
         nsim = self.ops.mc_swarm(self.order, self.sorted_delta, self.state, self.other, eps_pop, eps_target, gamma0,
                                  gsig, self.lo, self.n_local, self.sweep)
         self.sweep += 1
-        self._allgather_state(self.other)
+        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
         self._swap()
         return self._allreduce_counts(nsim)[0]
 
@@ -513,7 +542,9 @@ class PopulationEngine:
         """Everything a later run needs to continue this one bit for bit: the population arrays the reference
         driver owns (thetas, logpi, Ds, Wns, alive; smc:242-270) and the two RNG epochs.  Host numpy arrays."""
         th, lp, dl = self.state
+        extra = {"stamp": self.stamp[self.cur].cpu().numpy().copy()} if self.blob_on else {}
         return {
+            **extra,
             "theta": th.cpu().numpy().copy(), "logpi": lp.cpu().numpy().copy(), "delta": dl.cpu().numpy().copy(),
             "wns": self.wns.cpu().numpy().copy(), "alive": self.alive.cpu().numpy().copy(),
             "sweep": int(self.sweep), "draw": int(self.draw), "N": self.N, "ld": int(th.shape[1]),
@@ -537,6 +568,10 @@ class PopulationEngine:
         self.alive.copy_(torch.as_tensor(np.ascontiguousarray(st["alive"], dtype=np.uint8)))
         self.n_alive = int(self.alive.sum().item())
         self.sweep, self.draw = int(st["sweep"]), int(st["draw"])
+        if self.blob_on:
+            if "stamp" not in st:
+                raise ValueError("checkpoint was written without blobs")
+            self.stamp[0].copy_(torch.as_tensor(np.ascontiguousarray(st["stamp"], dtype=np.int64)))
         if self.rows_mode:                       # every particle's current row is slot 0 again
             self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
             self._rows_dirty = False
@@ -554,7 +589,21 @@ class PopulationEngine:
         P = pushed[:, :d].cpu().numpy()
         if d == 1 and not hasattr(self.spec.prior, "p"):
             P = P[:, 0]                      # univariate prior -> vector of scalars
+        blobs = None
+        if self.blob_on:
+            # rebuild the simulated data behind every particle's distance from its stamp; the re-run's distance
+            # must be the stored one, bit for bit
+            nb = self.spec.n_blob
+            out = torch.zeros((self.N, self.ops.blob_width()), dtype=torch.float64, device=self.device)
+            redo = torch.empty_like(dl)
+            self.ops.blob_eval(th, self.stamp[self.cur], out, redo)
+            if not torch.equal(redo.view(torch.int64), dl.view(torch.int64)):
+                raise RuntimeError("blobs: a re-run simulation does not reproduce the stored distance")
+            blobs = out[:, :nb].cpu().numpy()
+            if nb == 1:
+                blobs = blobs[:, 0]
         return {
+            "blobs": blobs,
             "P": P,
             "theta": th[:, :d].cpu().numpy(),  # internal (unrounded) state, mc:216-220
             "logpi": lp.cpu().numpy(),

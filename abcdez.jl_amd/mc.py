@@ -66,7 +66,7 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     if verbose:
         log.info("End: completion=%s converged=%s nsim=%d range_ϵ=%s", complete, conv, nsims, eng.extrema())
     res = eng.result()                                        # mc:166
-    out = Result(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=None)
+    out = Result(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=res.get("blobs"))
     out.reached_eps = conv
     out.nsims, out.updates, out.complete = nsims, generations * nparticles, complete
     out.engine = eng

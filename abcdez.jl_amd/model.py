@@ -38,7 +38,7 @@ class Model(C.Structure):
         ("abck", C.c_int32),
         ("seed", C.c_uint64),
         ("n_data", C.c_int32),
-        ("reserved", C.c_int32),
+        ("n_blob", C.c_int32),
         ("sim_p", C.c_double * 8),
         ("data", C.c_void_p),
         ("prior", PriorDim * MAX_D),
@@ -75,6 +75,9 @@ class ModelSpec:
         self.ABCk = ABCk
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.data = np.ascontiguousarray(np.asarray(sim.data(), dtype=np.float64))
+        self.n_blob = int(sim.blob_size(d)) if getattr(sim, "blobs", False) else 0     # doubles per blob, 0 = off
+        if self.n_blob > 64:
+            raise ValueError(f"blobs of {self.n_blob} doubles exceed the supported maximum 64")
         self.discrete = tuple(bool(f.discrete) for f in factors)
         self._desc = [f.descriptor() for f in factors]
         self._c1 = [f.c1() if f.family == PRIOR_NEGBIN else None for f in factors]
@@ -84,6 +87,7 @@ class ModelSpec:
         m.d, m.ld, m.sim_id, m.abck = self.d, self.ld, self.sim.sim_id, self.abck
         m.seed = self.seed
         m.n_data = int(self.data.size)
+        m.n_blob = self.n_blob
         params = tuple(self.sim.params())
         for i in range(8):
             m.sim_p[i] = params[i] if i < len(params) else 0.0

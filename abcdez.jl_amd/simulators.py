@@ -4,8 +4,14 @@ The reference calls an arbitrary Julia closure ``dist!(θ, ve) -> (d, blob)``
 (src/abcdez_smc.jl:137, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17).  A closure
 cannot run on the GPU, so the drop-in dispatches on a :class:`DeviceSimulator`
 marker that selects one of the built-in on-device simulators (ids and exact
-arithmetic: csrc/abcdez_spec.h, ``ABZ_SIM_*``).  ``blob`` is always ``None``
-(component 20).
+arithmetic: csrc/abcdez_spec.h, ``ABZ_SIM_*``).
+
+``blob`` -- the second return value, "arbitrary data stored to each particle, e.g. the actual
+simulation output" (docs/src/index.md:298-324) -- is ``None`` by default, as in every reference
+test.  ``blobs=True`` on a simulator makes the result's ``blobs`` the simulated data behind each
+particle's final distance (one row of ``blob_size`` doubles per particle): the population carries
+an 8-byte stamp naming the simulator call that produced the distance and the data are rebuilt
+from it when the result is read (include/abcdez_hip.h, ``abcdez_blob_eval``).
 """
 from __future__ import annotations
 
@@ -18,6 +24,11 @@ SIM_NORMAL1D, SIM_MVN, SIM_DIRAC, SIM_QUAD2D, SIM_MIXTURE, SIM_NORMDU, SIM_WIENE
 class DeviceSimulator:
     sim_id = -1
     ndim = None  # required length(prior), None = any
+    blobs = False
+
+    def blob_size(self, d: int) -> int:
+        """doubles per blob when ``blobs`` is on (abz_sim_blob_size, csrc/abcdez_spec.h)"""
+        return 1
 
     def params(self) -> Tuple[float, ...]:
         return ()
@@ -32,6 +43,7 @@ class Normal1D(DeviceSimulator):
 
     data_value: float
     sigma: float = 1.0
+    blobs: bool = False            # blob = the simulated x
     sim_id = SIM_NORMAL1D
     ndim = 1
 
@@ -48,7 +60,11 @@ class MVNormal(DeviceSimulator):
 
     y: Tuple[float, ...]
     sigma: float = 1.0
+    blobs: bool = False            # blob = the simulated vector x
     sim_id = SIM_MVN
+
+    def blob_size(self, d):
+        return d
 
     def __post_init__(self):
         object.__setattr__(self, "y", tuple(float(v) for v in self.y))
@@ -66,6 +82,7 @@ class DiracSquare(DeviceSimulator):
     """deterministic dist = |θ² + 1 − target|  (test/runtests.jl:495-497)."""
 
     target: float = 1.5
+    blobs: bool = False            # blob = θ² + 1
     sim_id = SIM_DIRAC
     ndim = 1
 
@@ -78,8 +95,12 @@ class Quad2D(DeviceSimulator):
     """50(x + 0.01n₁ − y²)² + (y − 1 + 0.01n₂)², +Inf with prob ``p_inf`` (test/runtests.jl:603,614)."""
 
     p_inf: float = 0.0
+    blobs: bool = False            # blob = the two residuals (x + 0.01n₁ − y², y − 1 + 0.01n₂)
     sim_id = SIM_QUAD2D
     ndim = 2
+
+    def blob_size(self, d):
+        return 2
 
     def params(self):
         return (float(self.p_inf),)
@@ -90,6 +111,7 @@ class Mixture01(DeviceSimulator):
     """x = θ + (coin ? 0.1n₁ : n₂); dist = |x − target|  (test/runtests.jl:582-583)."""
 
     target: float = 0.0
+    blobs: bool = False            # blob = the simulated x
     sim_id = SIM_MIXTURE
     ndim = 1
 
@@ -102,6 +124,7 @@ class NormalTimesDU(DeviceSimulator):
     """x = (n² + du)(n + 0.01n₁); dist = |x − target|  (test/runtests.jl:524-525)."""
 
     target: float = 5.5
+    blobs: bool = False            # blob = the simulated x
     sim_id = SIM_NORMDU
     ndim = 2
 
@@ -114,8 +137,12 @@ class WienerRMS(DeviceSimulator):
     """rms_t = sqrt(μ²t² + σ²t)(0.95 + 0.1u), t = 0..len(tdata)−1; mean |rms − tdata|  (test/runtests.jl:537-546)."""
 
     tdata: Tuple[float, ...]
+    blobs: bool = False            # blob = the simulated rms_t series
     sim_id = SIM_WIENER
     ndim = 2
+
+    def blob_size(self, d):
+        return len(self.tdata)
 
     def __post_init__(self):
         object.__setattr__(self, "tdata", tuple(float(v) for v in self.tdata))
@@ -139,8 +166,12 @@ class LotkaVolterraRK4(DeviceSimulator):
     dt: float = 0.01
     steps_per_obs: int = 100
     noise: float = 0.1
+    blobs: bool = False            # blob = the noisy observations (x0, y0, x1, y1, ...)
     sim_id = SIM_LV
     ndim = 4
+
+    def blob_size(self, d):
+        return len(self.obs)
 
     def __post_init__(self):
         object.__setattr__(self, "obs", tuple(float(v) for v in self.obs))
@@ -162,8 +193,12 @@ class Socks(DeviceSimulator):
     pairs: float = 0.0
     odds: float = 11.0
     n_picked: int = 11
+    blobs: bool = False            # blob = (pairs, odd socks) of the simulated pick
     sim_id = SIM_SOCKS
     ndim = 2
+
+    def blob_size(self, d):
+        return 2
 
     def params(self):
         return (float(self.pairs), float(self.odds), float(self.n_picked))
@@ -179,19 +214,36 @@ class UserSimulator(DeviceSimulator):
     ``theta`` arrives ``push_p``-cast; ``data`` / ``sim_p`` are the arrays given here (``varexternal``'s role);
     ``rng.uniform()``, ``rng.normal()``, ``rng.normal_pair(z0, z1)``, ``rng.bits()`` draw from the particle's
     counter-based stream.  Compiled with hiprtc when the engine is created (length(prior) <= 16).
+
+    Blobs: with ``n_blob`` > 0 the source must also define::
+
+        __device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data,
+                                      const double* sim_p, abz_user_rng& rng, double* blob, int n_blob);
+
+    which receives a fresh copy of the SAME random stream as the ``abz_user_dist`` call that produced the particle's
+    distance, so it can repeat the simulation and write its output to ``blob[0 .. n_blob)``.
     """
 
     sim_id = SIM_USER
     ndim = None
 
-    def __init__(self, source: str, params: Sequence[float] = (), data: Sequence[float] = ()):
+    def __init__(self, source: str, params: Sequence[float] = (), data: Sequence[float] = (), n_blob: int = 0):
         if "abz_user_dist" not in source:
             raise ValueError("the source must define abz_user_dist")
+        if not 0 <= int(n_blob) <= 64:
+            raise ValueError("n_blob must be in 0..64")
+        if n_blob and "abz_user_blob" not in source:
+            raise ValueError("n_blob > 0: the source must define abz_user_blob")
+        self.n_blob = int(n_blob)
+        self.blobs = self.n_blob > 0
         if len(params) > 8:
             raise ValueError("at most 8 scalar parameters (sim_p)")
         self.source = str(source)
         self._params = tuple(float(v) for v in params)
         self._data = tuple(float(v) for v in data)
+
+    def blob_size(self, d):
+        return self.n_blob
 
     def params(self):
         return self._params

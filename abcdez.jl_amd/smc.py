@@ -252,7 +252,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
         log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
 
     res = eng.result()                 # P is push_p-cast, smc:382
-    out = Result(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=None)
+    out = Result(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=res.get("blobs"))
     out.eps = ϵ
     out.iters, out.nsims, out.updates = iters, nsims, updates
     out.engine = eng

@@ -73,6 +73,21 @@ ABCDEZ_API int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst_host, const void* sr
  *     src/abcdez_smc.jl:242-243 / src/abcdez_mc.jl:117-118.  Fills rows [i0, i0+n).  */
 ABCDEZ_API int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n);
 
+/* Blobs -- the second return value of dist!(theta, ve) -> (d, blob) (src/abcdez_smc.jl:137,148, src/abcdez_mc.jl:45,
+ * docs/src/index.md:298-324), here: the simulated data behind a particle's current distance (model.n_blob doubles).
+ * The population does not store them.  It carries an 8-byte STAMP per particle next to the distance -- (origin
+ * particle, RNG epoch, init-or-sweep stream) of the simulator call that produced it (abz_stamp, abcdez_spec.h) --
+ * written at init and on every accept, copied / gathered exactly like Ds and blobs in the reference (smc:99,
+ * 337-340).  abcdez_ctx_set_stamps names the stamp arrays of the current and the next generation (u64[N] each;
+ * the (logpi, nlogpi)-style entry points use them alongside, the row-store ones update stamp_cur in place; NULL,
+ * NULL = off).  abcdez_blob_eval re-runs that one simulator call for each of N particles on dense current rows
+ * theta[N][ld] and writes blob[N][width] (abcdez_blob_width: ld for the MVN simulator, n_blob otherwise) and the
+ * distance of the re-run, which must equal the stored distance bit for bit.                                    */
+ABCDEZ_API int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_nxt);
+ABCDEZ_API int abcdez_blob_width(abcdez_ctx* ctx, int32_t* width);
+ABCDEZ_API int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
+                     double* delta_out);
+
 /* Alive list: the index set wsample(rng, 1:N, alive) draws from (src/abcdez_smc.jl:121,125).
  * alive_idx[r] = index of the r-th alive particle; arank[i] = rank of i or 0xFFFFFFFF.
  * n_alive may be NULL (the caller knows sum(alive) from the reweight): then the call only enqueues. */

@@ -118,13 +118,15 @@ ORC_API void orc_logprior(const abz_model* M, const double* theta, int64_t n, in
 
 /* ---------------------------------------------------------------- simulators = dist!(theta, ve) (smc:137, mc:45, init:10,17)
  * theta arrives push_p-cast.  (i, epoch, purpose) address the particle's noise.    */
-static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_t epoch, uint32_t purpose) {
+/* blob (may be NULL): the simulated data behind the distance -- the second return value of dist! */
+static double sim_dist_b(const abz_model* M, const double* th, uint32_t i, uint32_t epoch, uint32_t purpose, double* blob) {
   const uint64_t seed = M->seed;
   switch (M->sim_id) {
     case ABZ_SIM_NORMAL1D: {
       double z0, z1;
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &z0, &z1);
       double x = abz_fma(M->sim_p[0], z0, th[0]);
+      if (blob) blob[0] = x;
       return fabs(x - M->data[0]);
     }
     case ABZ_SIM_MVN: {
@@ -135,7 +137,9 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
         for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c) {
           int k = 2 * m + c;
           if (k < M->d) {
-            double e = abz_fma(M->sim_p[0], z[c], th[k]) - M->data[k];
+            double x = abz_fma(M->sim_p[0], z[c], th[k]);
+            if (blob) blob[k] = x;
+            double e = x - M->data[k];
             sq[k] = e * e;
           } else {
             sq[k] = 0.0;
@@ -144,15 +148,19 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       }
       return abz_sqrt(abz_tree_sum_small(sq, M->ld));
     }
-    case ABZ_SIM_DIRAC:
-      return fabs((th[0] * th[0] + 1.0) - M->sim_p[0]);
+    case ABZ_SIM_DIRAC: {
+      double x = th[0] * th[0] + 1.0;
+      if (blob) blob[0] = x;
+      return fabs(x - M->sim_p[0]);
+    }
     case ABZ_SIM_QUAD2D: {
       double n1, n2;
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       double u = abz_u01_co(abz_rng(seed, i, epoch, 1, purpose).w0);
-      if (u < M->sim_p[0]) return ABZ_INF;
       double a = (th[0] + n1 * 0.01) - th[1] * th[1];
       double b = (th[1] - 1.0) + n2 * 0.01;
+      if (blob) { blob[0] = a; blob[1] = b; }
+      if (u < M->sim_p[0]) return ABZ_INF;
       return 50.0 * (a * a) + b * b;
     }
     case ABZ_SIM_MIXTURE: {
@@ -160,12 +168,14 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       uint64_t coin = abz_rng(seed, i, epoch, 1, purpose).w0 >> 63;
       double x = th[0] + (coin ? n2 : n1 * 0.1);
+      if (blob) blob[0] = x;
       return fabs(x - M->sim_p[0]);
     }
     case ABZ_SIM_NORMDU: {
       double n1, n2;
       abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), ORC_T, &n1, &n2);
       double x = (th[0] * th[0] + th[1]) * (th[0] + n1 * 0.01);
+      if (blob) blob[0] = x;
       return fabs(x - M->sim_p[0]);
     }
     case ABZ_SIM_WIENER: {
@@ -174,6 +184,7 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       for (int t = 0; t < M->n_data; ++t) {
         double dt = (double)t;
         double v = abz_sqrt(th[0] * th[0] * dt * dt + th[1] * th[1] * dt) * f;
+        if (blob && t < ABZ_MAX_BLOB) blob[t] = v;
         acc += fabs(v - M->data[t]);
       }
       return acc / (double)M->n_data;
@@ -189,8 +200,10 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
       for (int j = 0; j < nobs; ++j) {
         double z0, z1;
         abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)j, purpose), ORC_T, &z0, &z1);
-        double ex = abz_fma(sn, z0, x) - M->data[2 * j];
-        double ey = abz_fma(sn, z1, y) - M->data[2 * j + 1];
+        double ox = abz_fma(sn, z0, x), oy = abz_fma(sn, z1, y);
+        if (blob && 2 * j + 1 < ABZ_MAX_BLOB) { blob[2 * j] = ox; blob[2 * j + 1] = oy; }
+        double ex = ox - M->data[2 * j];
+        double ey = oy - M->data[2 * j + 1];
         acc = abz_fma(ex, ex, acc);
         acc = abz_fma(ey, ey, acc);
         if (j + 1 == nobs) break;
@@ -232,14 +245,39 @@ static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_
         uniq += (t == 0) || (id != idp);
       }
       const double pairs = (double)(m - uniq), odds = (double)uniq - (double)(m - uniq);
+      if (blob) { blob[0] = pairs; blob[1] = odds; }
       return fabs(pairs - M->sim_p[0]) + fabs(odds - M->sim_p[1]);
     }
     default:
       return ABZ_NAN;
   }
 }
+static double sim_dist(const abz_model* M, const double* th, uint32_t i, uint32_t epoch, uint32_t purpose) {
+  return sim_dist_b(M, th, i, epoch, purpose, NULL);
+}
 ORC_API double orc_sim_dist(const abz_model* M, const double* pushed, uint32_t i, uint32_t epoch, uint32_t purpose) {
   return sim_dist(M, pushed, i, epoch, purpose);
+}
+
+/* ---------------------------------------------------------------- blobs: stamps carried with the distances (abz_stamp,
+ * abcdez_spec.h) and the rebuild of the simulated data from them.  The stamp arrays of the current / next
+ * generation are bound once per call sequence (the checker's counterpart of abcdez_ctx_set_stamps).            */
+static uint64_t* g_stamp_cur = NULL;
+static uint64_t* g_stamp_nxt = NULL;
+ORC_API void orc_set_stamps(uint64_t* cur, uint64_t* nxt) { g_stamp_cur = cur; g_stamp_nxt = nxt; }
+
+ORC_API void orc_blob_eval(const abz_model* M, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
+                           int nbw, double* delta_out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t s = 0; s < N; ++s) {
+    double p[ABZ_MAX_D], b[ABZ_MAX_BLOB];
+    for (int q = 0; q < ABZ_MAX_BLOB; ++q) b[q] = 0.0;
+    push_row(M, theta + s * M->ld, p);
+    const uint64_t st = stamp[s];
+    delta_out[s] = sim_dist_b(M, p, abz_stamp_origin(st), abz_stamp_epoch(st),
+                              abz_stamp_is_init(st) ? ABZ_RNG_INIT_SIM : ABZ_RNG_SIM, b);
+    for (int q = 0; q < nbw; ++q) blob[s * nbw + q] = q < ABZ_MAX_BLOB ? b[q] : 0.0;
+  }
 }
 
 /* ---------------------------------------------------------------- S1: abcde_init!  (init.jl:2-22 + prior draws smc:242-243, mc:117-118)
@@ -275,6 +313,7 @@ ORC_API int orc_init(const abz_model* M, double* theta, double* logpi, double* d
       if (abz_isfinite(dl) && abz_isfinite(lp)) break;                          /* init.jl:14 */
       if (++retry >= ORC_MAX_RETRY) { bad = 1; break; }
     }
+    if (g_stamp_cur) g_stamp_cur[g] = abz_stamp(i, retry, 1);
   }
   return bad ? -1 : 0;
 }
@@ -309,6 +348,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
     for (int k = 0; k < ld; ++k) to[k] = ti[k];
     nlogpi[i] = logpi[i];
     ndelta[i] = delta[i];
+    if (g_stamp_nxt) g_stamp_nxt[i] = g_stamp_cur[i];               /* nblobs = identity.(blobs), smc:340 */
     uint32_t ri = arank[i];
     if (ri == ABZ_DEAD) continue;                                   /* smc:114 */
     uint32_t ra, rb;
@@ -335,6 +375,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
       ndelta[i] = dp;
       for (int k = 0; k < ld; ++k) to[k] = tp[k];
       nlogpi[i] = lp;
+      if (g_stamp_nxt) g_stamp_nxt[i] = abz_stamp((uint32_t)i, sweep, 0);   /* nblobs[i] = blob, smc:148 */
       nacc += 1;
     }
   }
@@ -547,6 +588,7 @@ ORC_API void orc_smc_resample_gather(const abz_model* M, const uint32_t* inds, i
     memcpy(ntheta + s * ld, theta + j * ld, (size_t)ld * sizeof(double));  /* smc:96 */
     nlogpi[s] = logpi[j];                                                  /* smc:97 */
     ndelta[s] = delta[j];                                                  /* smc:98 */
+    if (g_stamp_nxt) g_stamp_nxt[s] = g_stamp_cur[j];                      /* smc:99 */
     wns[s] = 1.0 / (double)N;                                              /* smc:102 */
     alive[s] = 1;                                                          /* smc:103 */
   }
@@ -620,6 +662,7 @@ ORC_API void orc_smc_swarm_rows(const abz_model* M, const uint32_t* alive_row, u
         double* to = (double*)(ORC_ROW(slot0, slot1, rowi ^ 0x80000000u, ld));
         for (int k = 0; k < ld; ++k) to[k] = tp[k];
         logpi[i] = lp; delta[i] = dp;
+        if (g_stamp_cur) g_stamp_cur[i] = abz_stamp(i, sweep, 0);
         nacc += 1;
       }
     }
@@ -665,6 +708,7 @@ ORC_API void orc_smc_resample_gather_rows(const abz_model* M, const uint32_t* in
            (size_t)ld * sizeof(double));                                   /* smc:96 */
     nlogpi[s] = logpi[j];                                                  /* smc:97 */
     ndelta[s] = delta[j];                                                  /* smc:98 */
+    if (g_stamp_nxt) g_stamp_nxt[s] = g_stamp_cur[j];                      /* smc:99 */
     wns[s] = 1.0 / (double)N;                                              /* smc:102 */
     alive[s] = 1;                                                          /* smc:103 */
   }
@@ -754,6 +798,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const doubl
     for (int k = 0; k < ld; ++k) to[k] = ti[k];                         /* mc:140-143 */
     nlogpi[i] = logpi[i];
     ndelta[i] = delta[i];
+    if (g_stamp_nxt) g_stamp_nxt[i] = g_stamp_cur[i];
     double di = delta[i];
     double eps = di <= eps_target ? eps_target : eps_pop;               /* mc:19 */
     uint32_t s = (uint32_t)i;
@@ -785,6 +830,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const doubl
       ndelta[i] = dp;
       for (int k = 0; k < ld; ++k) to[k] = tp[k];
       nlogpi[i] = lp;
+      if (g_stamp_nxt) g_stamp_nxt[i] = abz_stamp((uint32_t)i, sweep, 0);
     }
   }
   *nsim_out = nsim;

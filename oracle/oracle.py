@@ -108,6 +108,8 @@ def lib():
                                      _pi64, _pi64]
     L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64]
     L.orc_smc_resample_gather_rows.argtypes = [_vp] * 2 + [_i64] + [_vp] * 9
+    L.orc_set_stamps.argtypes = [_vp, _vp]
+    L.orc_blob_eval.argtypes = [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]
     L.orc_quantile_alive.restype = _f64
     L.orc_quantile_alive.argtypes = [_vp, _vp, _i64, _f64, _pf64, _pf64]
     L.orc_extrema.argtypes = [_vp, _i64, _pf64, _pf64]
@@ -250,6 +252,16 @@ class OracleOps:
 
     def push_p(self, theta, out):
         self.L.orc_push_p(self.m.ptr, _p(theta), theta.shape[0], _p(out))
+
+    # ---- blobs ----
+    def set_stamps(self, cur, nxt):
+        self.L.orc_set_stamps(_p(cur), _p(nxt))
+
+    def blob_width(self) -> int:
+        return self.spec.ld if self.spec.sim.sim_id == 1 else self.spec.n_blob      # ABZ_SIM_MVN: laid out like a row
+
+    def blob_eval(self, theta, stamp, blob, delta_out):
+        self.L.orc_blob_eval(self.m.ptr, _p(theta), _p(stamp), theta.shape[0], _p(blob), blob.shape[1], _p(delta_out))
 
     def math_eval(self, fn, x, y, y2=None):
         self.L.orc_math_eval(fn, _p(x), _p(y), _p(y2), x.numel())

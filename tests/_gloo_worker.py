@@ -19,13 +19,13 @@ from oracle import oracle as O
 
 def cases():
     return {
-        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, 2000),
-        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8), 2.5, 1024),
+        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 2000),     # blobs: stamps travel too
+        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8, blobs=True), 2.5, 1024),
         "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 600),
         # BASELINE.json configs[3] in miniature: Lotka-Volterra RK4, 4 x Uniform(0, 2) prior, 8 observations
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6),
-                                  dt=0.05, steps_per_obs=10), 1.2, 512),
+                                  dt=0.05, steps_per_obs=10, blobs=True), 1.2, 512),
     }
 
 
@@ -72,7 +72,8 @@ def main():
                  logZ=r.logZ, eps_hist=np.array(r.ϵs), nsims=r.nsims, iters=r.iters, mc_theta=mres["theta"],
                  mc_C=mres["C"], mc_nsims=m.nsims, world=world, logpi=res["logpi"], classic_theta=cres["theta"],
                  classic_C=cres["C"], classic_logpi=cres["logpi"], classic_Wns=cres["Wns"], classic_logZ=c.logZ,
-                 classic_nsims=c.nsims)
+                 classic_nsims=c.nsims, **({"blobs": res["blobs"], "classic_blobs": cres["blobs"], "mc_blobs": mres["blobs"]}
+                                           if res["blobs"] is not None else {}))
     dist.barrier()
     dist.destroy_process_group()
 

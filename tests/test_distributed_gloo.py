@@ -50,6 +50,10 @@ def test_sharded_run_equals_single_process(runs, name, world):
         for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C",
                   "classic_logpi", "classic_Wns"):
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, world, rank, k)
+        if "blobs" in ref.files:        # blob stamps: all-gathered with the rows (classic) / before resampling (row store)
+            assert ref["blobs"].shape[0] == ref["C"].shape[0]
+            for k in ("blobs", "classic_blobs", "mc_blobs"):
+                assert np.array_equal(ref[k], got[k]), (name, world, rank, k)
         # the two storages are the same algorithm
         for k in ("theta", "C", "Wns", "logpi"):
             assert np.array_equal(got[k], got["classic_" + k], equal_nan=True), (name, world, rank, k)
@@ -85,7 +89,8 @@ def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(2):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
-            for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):
+            for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C") + \
+                    (("blobs", "classic_blobs", "mc_blobs") if "blobs" in ref.files else ()):
                 assert np.array_equal(ref[k], got[k], equal_nan=True), (name, rank, k)
             assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
 
@@ -102,6 +107,7 @@ def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
     for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
-        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C"):
+        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C") + \
+                (("blobs", "classic_blobs", "mc_blobs") if "blobs" in ref.files else ()):
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
         assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])

@@ -383,6 +383,30 @@ def test_user_simulator_equals_builtin(oracle, which):
     assert np.array_equal(m.engine.result()["theta"], cm["theta"])
 
 
+def test_user_simulator_with_blobs(oracle):
+    """a user simulator that also defines abz_user_blob: its blobs equal the built-in Normal1D simulator's"""
+    src = """
+    __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                                    abz_user_rng& rng) {
+      double z0, z1; rng.normal_pair(z0, z1);
+      return __builtin_fabs(__builtin_fma(sim_p[0], z0, theta[0]) - data[0]);
+    }
+    __device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                                  abz_user_rng& rng, double* blob, int n_blob) {
+      double z0, z1; rng.normal_pair(z0, z1);
+      blob[0] = __builtin_fma(sim_p[0], z0, theta[0]);
+    }
+    """
+    prior = A.Normal(0.0, math.sqrt(10.0))
+    u = A.abcdesmc(prior, A.UserSimulator(src, params=(1.0,), data=(3.0,), n_blob=1), 0.3, None, nparticles=3000,
+                   verbose=False, rng=4)
+    b = A.abcdesmc(prior, A.Normal1D(3.0, blobs=True), 0.3, None, nparticles=3000, verbose=False, rng=4)
+    assert np.array_equal(u.C, b.C) and np.array_equal(u.blobs, b.blobs)
+    assert np.array_equal(np.abs(u.blobs - 3.0), u.C)
+    with pytest.raises(ValueError, match="abz_user_blob"):
+        A.UserSimulator("__device__ double abz_user_dist(){return 0;}", n_blob=2)
+
+
 def test_user_simulator_compile_error_is_reported():
     from abcdez_amd import _lib
 

@@ -433,3 +433,33 @@ def test_c_abi_error_paths():
         _lib.check(lib, -1)
     # the context still works after the errors
     assert swarm() == 0
+
+
+# ---------------------------------------------------------------- blobs: stamps + rebuild, product vs C restatement
+@pytest.mark.parametrize("name,N", [("normal1d", 4000), ("mvn8", 3000), ("mvn32", 4096), ("mvn3", 1500), ("quad2d_inf", 500),
+                                    ("normdu", 300), ("dirac", 200), ("mixture", 1500), ("socks", 3000)])
+@pytest.mark.parametrize("storage", ["rows", "classic"])
+def test_blobs_parity(oracle, name, N, storage):
+    """blobs=True: the stamps the HIP kernels carry and the data abcdez_blob_eval rebuilds from them equal the
+    oracle's bit for bit, for both storages and for abcdemc; the rebuilt distances equal the stored ones (checked
+    inside engine.result())."""
+    import dataclasses
+    prior, sim, eps = models()[name]
+    sim = dataclasses.replace(sim, blobs=True)
+
+    def hip_engine(spec, n, pg):
+        return PopulationEngine(spec, n, pg, ops=HipOps(spec), storage=storage)
+
+    def orc_engine(spec, n, pg):
+        return oracle.oracle_engine(spec, n, pg, storage="classic")
+
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8, engine=hip_engine)
+    c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8, engine=orc_engine)
+    assert r.engine.rows_mode == (storage == "rows") and r.blobs is not None
+    assert r.iters == c.iters and np.array_equal(r.C, c.C, equal_nan=True)
+    assert np.array_equal(r.blobs, c.blobs, equal_nan=True)
+    assert same(r.engine.stamp[r.engine.cur], c.engine.stamp[c.engine.cur])
+    if storage == "classic":
+        m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=hip_engine)
+        mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=orc_engine)
+        assert np.array_equal(m.C, mo.C) and np.array_equal(m.blobs, mo.blobs)

@@ -268,3 +268,56 @@ def test_abcdemc_resume_reproduces_the_uninterrupted_run(oracle, tmp_path):
     rest = mc(oracle, prior, sim, 0.3, nparticles=800, generations=30, rng=5, resume=A.load_checkpoint(path))
     assert rest.nsims == full.nsims and rest.reached_ϵ == full.reached_ϵ
     assert np.array_equal(rest.P, full.P) and np.array_equal(rest.C, full.C)
+
+
+# ---------------------------------------------------------------- blobs (second return value of dist!, docs/src/index.md:298-324)
+def _blob_cases():
+    lv_obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09)
+    wien = tuple(math.sqrt(0.25 * t * t + 4.0 * t) for t in range(8))
+    return {
+        # name: (prior, simulator with blobs on, eps, N, distance recomputed from the blob)
+        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 1500, lambda b: np.abs(b - 3.0)),
+        "mvn5": (A.Factored(*[A.Normal(0, 1)] * 5), A.MVNormal((1.0,) * 5, blobs=True), 1.6, 1200,
+                 lambda b: np.sqrt(((b - 1.0) ** 2).sum(1))),
+        "dirac": (A.Normal(1, 0.2), A.DiracSquare(1.5, blobs=True), 0.1, 400, lambda b: np.abs(b - 1.5)),
+        "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.0, blobs=True), 0.05, 600,
+                   lambda b: 50.0 * b[:, 0] ** 2 + b[:, 1] ** 2),
+        "mixture": (A.Uniform(-10, 10), A.Mixture01(0.0, blobs=True), 0.05, 800, lambda b: np.abs(b - 0.0)),
+        "normdu": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5, blobs=True), 0.05, 400,
+                   lambda b: np.abs(b - 5.5)),
+        "wiener": (A.Factored(A.Uniform(-2, 2), A.Uniform(0, 4)), A.WienerRMS(wien, blobs=True), 0.3, 600,
+                   lambda b: np.abs(b - np.array(wien)).sum(1) / len(wien)),
+        "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4), A.LotkaVolterraRK4(lv_obs, dt=0.05, steps_per_obs=10, blobs=True),
+               1.0, 400, lambda b: np.sqrt(((b - np.array(lv_obs)) ** 2).sum(1))),
+        "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)),
+                  A.Socks(0, 11, blobs=True), 2.5, 800, lambda b: np.abs(b[:, 0] - 0.0) + np.abs(b[:, 1] - 11.0)),
+    }
+
+
+@pytest.mark.parametrize("name", list(_blob_cases().keys()))
+def test_blobs_are_the_simulated_data_behind_every_distance(oracle, name):
+    """`blobs=True`: r.blobs[i] is the simulation output whose distance to the data is r.C[i] (docs/src/index.md:
+    298-324: "blobs could record the actual simulation output"), through init, accepts, rejections and resampling."""
+    prior, sim, eps, N, dist = _blob_cases()[name]
+    r = smc(oracle, prior, sim, eps, nparticles=N, rng=9)
+    assert r.iters > 3 and r.blobs is not None and r.blobs.shape[0] == N
+    exact = name in ("normal1d", "dirac", "mixture", "normdu", "socks")
+    d = dist(r.blobs)
+    assert np.array_equal(d, r.C) if exact else np.allclose(d, r.C, rtol=1e-13, atol=0)
+    assert len(np.unique(r.C)) > 1 or name in ("socks",)
+    m = mc(oracle, prior, sim, eps, nparticles=max(N // 4, 50), generations=15, rng=9)
+    d = dist(m.blobs)
+    assert np.array_equal(d, m.C) if exact else np.allclose(d, m.C, rtol=1e-13, atol=0)
+
+
+def test_blobs_default_off_and_checkpointed(oracle, tmp_path):
+    prior, sim_on, eps, N, dist = _blob_cases()["mvn5"]
+    off = smc(oracle, prior, A.MVNormal((1.0,) * 5), eps, nparticles=N, rng=9)
+    assert off.blobs is None                                                   # as in every reference test
+    on = smc(oracle, prior, sim_on, eps, nparticles=N, rng=9)
+    assert np.array_equal(on.P, off.P) and on.logZ == off.logZ                 # recording blobs changes nothing else
+    part = smc(oracle, prior, sim_on, eps, nparticles=N, rng=9, max_iters=6)
+    path = tmp_path / "blob.ckpt"
+    A.save_checkpoint(path, part.checkpoint())
+    rest = smc(oracle, prior, sim_on, eps, nparticles=N, rng=9, resume=path)
+    assert np.array_equal(rest.blobs, on.blobs) and np.array_equal(rest.C, on.C)
