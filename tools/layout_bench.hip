@@ -69,6 +69,35 @@ __global__ __launch_bounds__(256) void k_rows_rw(const double* __restrict__ th, 
   acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);   /* every lane's loads are live */
   if (j == 0) { nlp[i] = acc; nlp[N + i] = 2.0; }
 }
+// (A6) the row store's pattern (what bench.py's kernel does): own row + two donors found through the alive list, the
+//      accepted fraction written to the particle's OTHER slot, 16 B of state read always and rewritten in place only
+//      on accept, 4 B of new alive list per particle
+__global__ __launch_bounds__(256) void k_rows_store(const double* __restrict__ th, const uint32_t* __restrict__ idx, uint32_t N,
+                                                    double* __restrict__ nth, double* __restrict__ st, uint32_t* __restrict__ aout,
+                                                    int wfrac, int use_idx, int flags = 3) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, r = gid >> 2; const int j = gid & 3;
+  if (r >= N) return;
+  const uint32_t i = use_idx ? idx[r] : r;
+  uint32_t a = hash32(r * 2 + 1) % N, b = hash32(r * 2 + 2) % N;
+  if (use_idx) { a = idx[a]; b = idx[b]; }
+  const bool wr = (hash32(r * 7 + 3) % 100) < (uint32_t)wfrac;
+  double acc = (flags & 1) ? st[i] + st[N + i] : 0.0;      /* flags bit 0: read the 16 B of state */
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2 o = *(const double2*)(th + (size_t)i * D + m * 8 + 2 * j);
+    const double2 x = *(const double2*)(th + (size_t)a * D + m * 8 + 2 * j);
+    const double2 y = *(const double2*)(th + (size_t)b * D + m * 8 + 2 * j);
+    double2 v; v.x = o.x + (x.x - y.x); v.y = o.y + (x.y - y.y);
+    acc += v.x + v.y;
+    if (wr) *(double2*)(nth + (size_t)i * D + m * 8 + 2 * j) = v;
+  }
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+  if (j == 0) {
+    if (wr) { st[i] = acc * 1e-300; st[N + i] = 2.0; }
+    if (flags & 2) aout[r] = wr ? (i | 0x80000000u) : i;    /* flags bit 1: write the 4-B alive-list entry */
+    else if (acc == 1.2345e300) aout[r] = 1u;
+  }
+}
 // (B) component-major: thread per particle, component k at th[k*N + i]
 __global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -127,6 +156,16 @@ int main() {
   run("A3 rows, reads + all row writes + 16 B state, no index", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 0, 100); });
   run("A4 rows, reads + 45% row writes + 16 B state, no index", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 0, 45); });
   run("A5 rows, reads + 45% row writes + 16 B state + index look-ups", [&] { hipLaunchKernelGGL(k_rows_rw, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, 1, 45); });
+  uint32_t* aout; CHECK(hipMalloc(&aout, (size_t)N * 4));
+  CHECK(hipMemset(nlp, 0, (size_t)N * 16));
+  run("A6 row store: reads + index look-ups + 25% rows written to the other slot, state in place on accept, 4 B alive list", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 25, 1); });
+  run("A7 row store, 20% accepted", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 20, 1); });
+  run("A8 row store, 0% accepted (reads + look-ups + 4 B alive list only)", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 1); });
+  run("A9 row store, 25% accepted, NO index look-ups (physically compacted population)", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 25, 0); });
+  run("A10 row store, 0% accepted, NO index look-ups", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 0); });
+  run("A11 as A10 without the 4-B alive-list write", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 0, 1); });
+  run("A12 as A10 without the 16-B state read", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 0, 2); });
+  run("A13 as A6 (25% accepted, look-ups) without the 4-B alive-list write", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 25, 1, 1); });
   run("B component-major f64[32][N], thread per particle", [&] { hipLaunchKernelGGL(k_soa, dim3(N / 256), dim3(256), 0, 0, th, N, out); });
   run("C rows f64[N][32] staged through LDS per workgroup", [&] { hipLaunchKernelGGL(k_rows_lds, dim3(N / 64), dim3(256), 0, 0, th, N, out); });
   return 0;
