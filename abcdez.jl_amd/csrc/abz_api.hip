@@ -299,7 +299,7 @@ int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint3
   return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive, nullptr);
 }
 
-/* ---- row-store mode (single GPU): see the comment at SmcSwarmArgs::rows in abz_kernels.h ---- */
+/* ---- row-store mode: see the comment at SmcSwarmArgs::rows in abz_kernels.h ---- */
 int abcdez_alive_compact_rows(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, const uint32_t* cur_row,
                               uint32_t* alive_row, uint32_t* arank, int64_t* n_alive) {
   ABZ_REQUIRE(ctx && alive && cur_row && alive_row && arank, "alive_compact_rows: null argument");

@@ -89,7 +89,7 @@ struct SmcSwarmArgs {
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
   uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
-  /* "row store" mode (single GPU): theta / ntheta are the two slots of a 2N-row store, alive_idx[r] holds
+  /* "row store" mode (one replica per GPU): theta / ntheta are the two slots of a 2N-row store, alive_idx[r] holds
    * the CURRENT row id (particle | slot << 31) of the r-th alive particle; an accepted proposal is written to
    * the particle's other slot and its row id flips in alive_out, a rejected one writes nothing; log-prior and
    * distance are updated in place (only their owner reads them).  No dead rows to carry, no copies.        */

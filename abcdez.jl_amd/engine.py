@@ -126,7 +126,7 @@ class HipOps:
             _ptr(dead_synced), sweep, C.byref(nacc), C.byref(nsim)))
         return nacc.value, nsim.value
 
-    # ---- row-store mode (single GPU): include/abcdez_hip.h, abcdez_smc_swarm_rows ----------------
+    # ---- row-store mode: include/abcdez_hip.h, abcdez_smc_swarm_rows (+ _shard / replay for sharded runs) ----
     supports_rows = True
 
     def alive_compact_rows(self, alive, cur_row, alive_row, arank):

@@ -112,7 +112,7 @@ ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, cons
                      int64_t i0, int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
                      int64_t* nacc, int64_t* nsim);
 
-/* Row-store variant of the same sweep for a single GPU (what bench.py measures).  theta lives in a store of
+/* Row-store variant of the same sweep (what bench.py measures; sharded runs: the _shard / replay pair below).  theta lives in a store of
  * two slots per particle (slot0[N][ld], slot1[N][ld]); cur_row[i] = i | slot << 31 names particle i's current
  * row, alive_row[r] the current row of the r-th alive particle.  An accepted proposal is written to the
  * particle's other slot and its entry flips in alive_row_out; a rejected or dead particle writes nothing, and

@@ -181,7 +181,7 @@ def test_stratified_resample_parity(oracle, N):
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
 @pytest.mark.parametrize("storage", ["classic", "rows"])
 def test_smc_sweep_parity(oracle, name, lanes, abck, storage):
-    """storage: the classic double buffer (what sharded runs use) and the single-GPU row store"""
+    """storage: the classic double buffer (abcdemc, abcdesmc on request) and the row store (abcdesmc default)"""
     N = 6000
     spec, hip, orc, _ = engines(name, N, ABCk=abck, lanes=lanes, oracle=oracle, storage=storage)
     assert hip.rows_mode == (storage == "rows")
