@@ -298,6 +298,7 @@ class PopulationEngine:
         # blobs (spec.n_blob > 0): one stamp per particle, ping-ponging with (logpi, delta)
         self.blob_on = getattr(spec, "n_blob", 0) > 0
         self.stamp = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)] if self.blob_on else None
+        self._prof = None            # optional event timing of the sharded sweep's phases (enable_phase_timing)
         self._delta_stale = False    # sharded row store: other ranks' distances / log-priors not yet fetched
         self._logpi_stale = False
         self.wns = torch.full((N,), 1.0 / N, **f64)
@@ -342,8 +343,34 @@ class PopulationEngine:
     def _sync_delta(self):
         """sharded row store: fetch the other ranks' distances (once per generation, before the first consumer)"""
         if self._delta_stale:
+            self._mark("delta_allgather", 0)
             self._allgather_state((self.buf[self.cur][2],))
+            self._mark("delta_allgather", 1)
             self._delta_stale = False
+
+    # ---- optional phase timing of the sharded row-store sweep (bench.py's multi-GPU breakdown) ----
+    def enable_phase_timing(self):
+        """record device events around the phases of every sharded sweep: own shard sweep, flag all-gather, replay,
+        and the per-generation distance all-gather (device tensors only)"""
+        self._prof = {} if self.device.type == "cuda" else None
+
+    def _mark(self, phase, end):
+        if self._prof is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._prof.setdefault(phase, []).append(ev)
+
+    def phase_timing(self) -> dict:
+        """{phase: (count, total ms)} since enable_phase_timing()"""
+        if not self._prof:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for phase, evs in self._prof.items():
+            pairs = list(zip(evs[0::2], evs[1::2]))
+            out[phase] = (len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
+        return out
 
     def _sync_logpi(self):
         """sharded row store: fetch the other ranks' log-priors and blob stamps (read by other ranks only when
@@ -487,11 +514,17 @@ class PopulationEngine:
         if self.sharded_rows:
             cur = self.buf[self.cur]
             a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
+            self._mark("own_sweep", 0)
             self.ops.smc_swarm_rows_shard(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
                                           cur[1], cur[2], self.accepted, eps, gamma0, gsig, self.sweep, want_counts=False)
+            self._mark("own_sweep", 1)
+            self._mark("flag_allgather", 0)
             self._allgather_state((self.accepted,))          # 1 byte per particle: accepted | simulated << 1
+            self._mark("flag_allgather", 1)
+            self._mark("replay", 0)
             counts = self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
                                               self.buf[1][0], self.accepted, gamma0, gsig, self.sweep)
+            self._mark("replay", 1)
             self.sweep += 1
             self.ar = 1 - self.ar
             self._rows_dirty = True

@@ -205,6 +205,15 @@ def main():
         dt = float(t.item())
     updates = gen.updates - u0          # global particle-updates (all ranks)
     kern_ms, launches, units = eng.ops.get_timing()   # this rank's sweep kernel
+    sweeps_timed, resamples_timed = gen.sweeps - s0, gen.resamples
+    phases = {}
+    if eng.sharded_rows:
+        # device-event breakdown of the sharded sweep, taken on three EXTRA generations after the timed region
+        # (recording eight events per sweep would cost the timed loop several percent)
+        eng.enable_phase_timing()
+        for _ in range(3):
+            gen.step()
+        phases = eng.phase_timing()
 
     if rank == 0:
         # algorithmic bytes per particle-update: reads 24 ld + 17, writes 8 ld + 16
@@ -230,7 +239,7 @@ def main():
                 "workload": f"abcdesmc d={d} MVN simulator + Euclidean distance, {args.particles_per_gpu} particles/GPU "
                             f"(BASELINE.json configs[2]); alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
-                "sweeps": gen.sweeps - s0, "resamples": gen.resamples, "eps": gen.eps, "logZ": gen.logZ,
+                "sweeps": sweeps_timed, "resamples": resamples_timed, "eps": gen.eps, "logZ": gen.logZ,
                 "parallelism": (f"particle-shard x{world}, replicated row store: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
@@ -245,6 +254,8 @@ def main():
                 "kernel_updates_per_s": units_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
             },
         }
+        if eng.sharded_rows:    # rank 0's device-event breakdown of the sharded sweep
+            out["sharded_phases_ms"] = {k: {"calls": c, "avg_ms": (t / c if c else 0.0)} for k, (c, t) in phases.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline_reference_faithful"], out["cpu_baseline"] = cpu_baseline(args, prior, sim, eps_target)
         try:                      # RCCL's start-up banner sits in libc's stdio buffer: push it out BEFORE the result line
