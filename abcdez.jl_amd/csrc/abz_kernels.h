@@ -224,14 +224,25 @@ __device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
   const uint32_t base = blockIdx.x * (uint32_t)ABZ_REPLAY_CHUNK;
   const unsigned lane = threadIdx.x & 63u;
   unsigned int wacc = 0u, wsim = 0u;                      /* wave-uniform counters */
+  /* all row ids first, then all flag bytes: two batches of independent loads instead of eight dependent pairs */
+  uint32_t rowv[ABZ_REPLAY_PER];
+  unsigned fv[ABZ_REPLAY_PER];
 #pragma unroll
   for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
     const uint32_t w = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
-    const bool active = w < a.n_alive;
-    const uint32_t ri = active ? w : 0u;
-    const bool foreign = active && !(ri >= a.skip_lo && ri < a.skip_hi);
-    const uint32_t rowi = a.alive_idx[ri];
-    const unsigned f = active ? (unsigned)a.acc_flag[rowi & 0x7FFFFFFFu] : 0u;
+    rowv[k] = a.alive_idx[w < a.n_alive ? w : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
+    const uint32_t w = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
+    fv[k] = w < a.n_alive ? (unsigned)a.acc_flag[rowv[k] & 0x7FFFFFFFu] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
+    const uint32_t ri = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
+    const bool foreign = ri < a.n_alive && !(ri >= a.skip_lo && ri < a.skip_hi);
+    const uint32_t rowi = rowv[k];
+    const unsigned f = fv[k];
     wacc += (unsigned)__popcll(__ballot((f & 1u) != 0u));
     wsim += (unsigned)__popcll(__ballot((f & 2u) != 0u));
     const bool acc = foreign && (f & 1u) != 0u;
