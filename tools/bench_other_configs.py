@@ -6,7 +6,7 @@ import abcdez_amd as A
 from abcdez_amd.engine import HipEngine
 def t_mc(N=1<<20, gens=100):
     spec=A.ModelSpec(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), seed=3)
-    e=HipEngine(spec,N); e.init_population(); g0=2.38/math.sqrt(2)
+    e=HipEngine(spec,N,storage="classic"); e.init_population(); g0=2.38/math.sqrt(2)
     def gen():
         lo,hi=e.extrema()
         if hi>0.3: e.mc_rank_prepare()

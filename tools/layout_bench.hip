@@ -98,6 +98,33 @@ __global__ __launch_bounds__(256) void k_rows_store(const double* __restrict__ t
     else if (acc == 1.2345e300) aout[r] = 1u;
   }
 }
+// (A14) as (A6) but the two slots of a particle are ADJACENT in memory (store[N][2][32]): the accepted row is written
+//       512 bytes-aligned next to the own row that was just read (same DRAM page) instead of 1 GiB away
+__global__ __launch_bounds__(256) void k_rows_store_il(const double* __restrict__ st2, const uint32_t* __restrict__ idx, uint32_t N,
+                                                       double* __restrict__ wr2, double* __restrict__ st, uint32_t* __restrict__ aout,
+                                                       int wfrac) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, r = gid >> 2; const int j = gid & 3;
+  if (r >= N) return;
+  const uint32_t i = idx[r];
+  const uint32_t a = idx[hash32(r * 2 + 1) % N], b = idx[hash32(r * 2 + 2) % N];
+  const uint32_t si = hash32(i * 5 + 1) & 1u, sa = hash32(a * 5 + 1) & 1u, sb = hash32(b * 5 + 1) & 1u;   /* current slots */
+  const bool wr = (hash32(r * 7 + 3) % 100) < (uint32_t)wfrac;
+  double acc = st[i] + st[N + i];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double2 o = *(const double2*)(st2 + ((size_t)i * 2 + si) * D + m * 8 + 2 * j);
+    const double2 x = *(const double2*)(st2 + ((size_t)a * 2 + sa) * D + m * 8 + 2 * j);
+    const double2 y = *(const double2*)(st2 + ((size_t)b * 2 + sb) * D + m * 8 + 2 * j);
+    double2 v; v.x = o.x + (x.x - y.x); v.y = o.y + (x.y - y.y);
+    acc += v.x + v.y;
+    if (wr) *(double2*)(wr2 + ((size_t)i * 2 + (si ^ 1u)) * D + m * 8 + 2 * j) = v;
+  }
+  acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+  if (j == 0) {
+    if (wr) { st[i] = acc * 1e-300; st[N + i] = 2.0; }
+    aout[r] = wr ? (i | 0x80000000u) : i;
+  }
+}
 // (B) component-major: thread per particle, component k at th[k*N + i]
 __global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -166,6 +193,12 @@ int main() {
   run("A11 as A10 without the 4-B alive-list write", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 0, 1); });
   run("A12 as A10 without the 16-B state read", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 0, 0, 2); });
   run("A13 as A6 (25% accepted, look-ups) without the 4-B alive-list write", [&] { hipLaunchKernelGGL(k_rows_store, dim3(N * 4 / 256), dim3(256), 0, 0, th, idx, N, nth, nlp, aout, 25, 1, 1); });
+  {
+    double* st2; CHECK(hipMalloc(&st2, 2 * bytes)); CHECK(hipMemset(st2, 0, 2 * bytes));
+    run("A14 as A6 (25% accepted) with the two slots of a particle adjacent in memory (store[N][2][32])", [&] { hipLaunchKernelGGL(k_rows_store_il, dim3(N * 4 / 256), dim3(256), 0, 0, st2, idx, N, st2, nlp, aout, 25); });
+    run("A15 as A14 with 0% accepted", [&] { hipLaunchKernelGGL(k_rows_store_il, dim3(N * 4 / 256), dim3(256), 0, 0, st2, idx, N, st2, nlp, aout, 0); });
+    CHECK(hipFree(st2));
+  }
   run("B component-major f64[32][N], thread per particle", [&] { hipLaunchKernelGGL(k_soa, dim3(N / 256), dim3(256), 0, 0, th, N, out); });
   run("C rows f64[N][32] staged through LDS per workgroup", [&] { hipLaunchKernelGGL(k_rows_lds, dim3(N / 64), dim3(256), 0, 0, th, N, out); });
   return 0;
