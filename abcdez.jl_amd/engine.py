@@ -298,6 +298,7 @@ class PopulationEngine:
         # blobs (spec.n_blob > 0): one stamp per particle, ping-ponging with (logpi, delta)
         self.blob_on = getattr(spec, "n_blob", 0) > 0
         self.stamp = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)] if self.blob_on else None
+        self._delta_work = None      # sharded row store: distance all-gather in flight (overlapped with the last replay)
         self._prof = None            # optional event timing of the sharded sweep's phases (enable_phase_timing)
         self._delta_stale = False    # sharded row store: other ranks' distances / log-priors not yet fetched
         self._logpi_stale = False
@@ -342,11 +343,26 @@ class PopulationEngine:
 
     def _sync_delta(self):
         """sharded row store: fetch the other ranks' distances (once per generation, before the first consumer)"""
+        if self._delta_work is not None:          # started behind the generation's last replay: just join it
+            self._mark("delta_allgather_wait", 0)
+            self._delta_work.wait()
+            self._delta_work = None
+            self._mark("delta_allgather_wait", 1)
+            self._delta_stale = False
         if self._delta_stale:
             self._mark("delta_allgather", 0)
             self._allgather_state((self.buf[self.cur][2],))
             self._mark("delta_allgather", 1)
             self._delta_stale = False
+
+    def _start_delta_allgather(self):
+        """sharded row store, last sweep of a generation: the owners' distances are final once the shard sweep has
+        run, so their all-gather goes out on the collective stream while this rank replays the other shards."""
+        import torch.distributed as dist
+
+        if self._backend == "nccl" or self.device.type == "cpu":
+            t = self.buf[self.cur][2]
+            self._delta_work = dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg, async_op=True)
 
     # ---- optional phase timing of the sharded row-store sweep (bench.py's multi-GPU breakdown) ----
     def enable_phase_timing(self):
@@ -509,7 +525,9 @@ class PopulationEngine:
             self.r_lo, self.r_hi = (int(v) for v in bounds.tolist())
         return n
 
-    def smc_swarm(self, eps: float, gamma0: float, gsig: float):
+    def smc_swarm(self, eps: float, gamma0: float, gsig: float, last: bool = False):
+        """last: no further sweep follows in this generation (the driver's i == Kmcmc) -- lets a sharded run start
+        the per-generation distance exchange early; has no effect on results"""
         self._bind_stamps()
         if self.sharded_rows:
             cur = self.buf[self.cur]
@@ -521,6 +539,8 @@ class PopulationEngine:
             self._mark("flag_allgather", 0)
             self._allgather_state((self.accepted,))          # 1 byte per particle: accepted | simulated << 1
             self._mark("flag_allgather", 1)
+            if last:
+                self._start_delta_allgather()
             self._mark("replay", 0)
             counts = self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
                                               self.buf[1][0], self.accepted, gamma0, gsig, self.sweep)
@@ -586,6 +606,9 @@ class PopulationEngine:
 
     def upload_state(self, st: dict):
         """Inverse of :meth:`download_state` (every rank uploads the full arrays)."""
+        if self._delta_work is not None:
+            self._delta_work.wait()
+            self._delta_work = None
         th = torch.as_tensor(np.ascontiguousarray(st["theta"], dtype=np.float64))
         if tuple(th.shape) != tuple(self.buf[0][0].shape):
             raise ValueError(f"checkpoint holds a population of shape {tuple(th.shape)}, "

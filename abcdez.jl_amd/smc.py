@@ -223,7 +223,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
         if n_alive >= 3:               # donor draws need three alive particles (smc:119-126)
             eng.alive_compact()
             for i in range(1, Kmcmc + 1):   # smc:336-353 (S2, S3)
-                nacc, nsim = eng.smc_swarm(ϵ, γ0, γσ)
+                nacc, nsim = eng.smc_swarm(ϵ, γ0, γσ, last=(i == Kmcmc))
                 naccs += nacc
                 nsims += nsim
                 updates += n_alive

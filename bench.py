@@ -81,8 +81,8 @@ class Generation:
             self.resamples += 1
         e.alive_compact()
         naccs = 0
-        for _ in range(self.Kmcmc):                                                        # smc:336-353
-            nacc, nsim = e.smc_swarm(self.eps, self.gamma0, 1e-5)
+        for i in range(1, self.Kmcmc + 1):                                                 # smc:336-353
+            nacc, nsim = e.smc_swarm(self.eps, self.gamma0, 1e-5, last=(i == self.Kmcmc))
             naccs += nacc
             self.nsims += nsim
             self.updates += n_alive
