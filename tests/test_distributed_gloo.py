@@ -76,18 +76,19 @@ def test_uneven_shard_is_rejected(oracle):
 
 
 @pytest.mark.gpu
-def test_sharded_hip_engine_two_ranks_one_gpu(tmp_path_factory):
-    """The product engine (HIP kernels) sharded over 2 ranks that share the single GPU of the test box,
-    collectives over gloo: exercises i0 > 0, alive-rank sub-ranges, the in-place all-gathers on device
-    tensors and the counter all-reduce -- everything of the N > 1 path except RCCL itself -- and must
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
+    """The product engine (HIP kernels) sharded over 2 / 4 ranks that share the single GPU of the test box,
+    collectives over gloo: exercises i0 > 0, alive-rank sub-ranges, shard sweep + flag exchange + replay, the in-place
+    all-gathers on device tensors and the counters -- everything of the N > 1 path except RCCL itself -- and must
     reproduce the single-process CPU-oracle result bit for bit."""
     ref_dir = tmp_path_factory.mktemp("ref_oracle")
     run_world(1, ref_dir, "oracle")
-    hip_dir = tmp_path_factory.mktemp("hip_world2")
-    run_world(2, hip_dir, "hip", timeout=240)
+    hip_dir = tmp_path_factory.mktemp(f"hip_world{world}")
+    run_world(world, hip_dir, "hip", timeout=300)
     for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
-        for rank in range(2):
+        for rank in range(world):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
             for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C") + \
                     (("blobs", "classic_blobs", "mc_blobs") if "blobs" in ref.files else ()):
