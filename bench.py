@@ -251,6 +251,7 @@ def main():
                 "bytes_per_update": b_read + b_write, "updates_per_launch": units_per_launch,
                 "avg_launch_ms": avg_ms, "launches": launches,
                 "read_only_achieved": b_read * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                "read_only_frac": b_read * units_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
                 "kernel_updates_per_s": units_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
             },
         }
