@@ -77,6 +77,10 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C abcdez.jl_amd/csrc`).  The population loop has no CPU fallback."
         )
+    # torch (device memory, streams, collectives) bundles its own HIP runtime: it has to be the first one loaded,
+    # so that this library binds to the same runtime instead of bringing a second one into the process
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
