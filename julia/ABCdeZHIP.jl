@@ -28,7 +28,7 @@ end
 struct AbzModel
     d::Int32; ld::Int32; sim_id::Int32; abck::Int32
     seed::UInt64
-    n_data::Int32; reserved::Int32
+    n_data::Int32; n_blob::Int32          # n_blob = 0: blobs off (abcdez_blob_eval not bound by this shim)
     sim_p::NTuple{8,Float64}
     data::Ptr{Float64}
     prior::NTuple{64,AbzPriorDim}
