@@ -530,6 +530,9 @@ class PopulationEngine:
         the per-generation distance exchange early; has no effect on results"""
         self._bind_stamps()
         if self.sharded_rows:
+            if self._delta_work is not None:      # a caller swept again after announcing the last sweep: that
+                self._delta_work.wait()           # exchange is obsolete (the stale flag stays set)
+                self._delta_work = None
             cur = self.buf[self.cur]
             a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
             self._mark("own_sweep", 0)
