@@ -463,3 +463,58 @@ def test_blobs_parity(oracle, name, N, storage):
         m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=hip_engine)
         mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=orc_engine)
         assert np.array_equal(m.C, mo.C) and np.array_equal(m.blobs, mo.blobs)
+
+
+# ---------------------------------------------------------------- randomized models: every d, mixed prior families
+def _random_model(seed):
+    rng = np.random.default_rng(seed)
+    d = int(rng.integers(1, 33))
+    fams = []
+    for _ in range(d):
+        k = int(rng.integers(0, 5))
+        if k == 0:
+            fams.append(A.Normal(float(rng.normal(0.5, 1.0)), float(rng.uniform(0.3, 2.0))))
+        elif k == 1:
+            a = float(rng.uniform(-3, 1))
+            fams.append(A.Uniform(a, a + float(rng.uniform(1.0, 5.0))))
+        elif k == 2:
+            a = int(rng.integers(-3, 2))
+            fams.append(A.DiscreteUniform(a, a + int(rng.integers(1, 6))))
+        elif k == 3:
+            fams.append(A.Beta(float(rng.uniform(0.6, 4.0)), float(rng.uniform(0.6, 4.0))))
+        else:
+            fams.append(A.NegativeBinomial(float(rng.uniform(0.7, 6.0)), float(rng.uniform(0.2, 0.8))))
+    prior = fams[0] if d == 1 and rng.random() < 0.5 else A.Factored(*fams)
+    y = tuple(float(v) for v in rng.normal(1.0, 0.5, d))
+    kern = [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ][int(rng.integers(0, 4))]
+    return d, prior, A.MVNormal(y, sigma=float(rng.uniform(0.5, 1.5)), blobs=bool(rng.random() < 0.5)), kern
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_models_end_to_end_parity(oracle, seed):
+    """40 seeded random models -- length(prior) 1..32 (every lane-group shape), all five prior families mixed, all
+    four ABC kernels, blobs on or off -- through the complete abcdesmc driver (row store) and a few abcdemc
+    generations (double buffer): HIP == oracle bit for bit."""
+    d, prior, sim, kern = _random_model(1000 + seed)
+    N = max(64, int(math.ceil(3 * d / 0.5)) + 40) * 8
+    rng = np.random.default_rng(seed)
+    # a target the population reaches in a handful of generations: the 30 % quantile of the initial distances
+    probe = oracle.oracle_engine(A.ModelSpec(prior, sim, kern, seed=seed + 1), N)
+    probe.init_population()
+    eps = probe.quantile_alive(0.3)
+    kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, nsims_max=10 ** 8, max_iters=25,
+              Kmcmc=int(rng.integers(1, 5)), α=float(rng.uniform(0.5, 0.95)), δess=float(rng.uniform(0.2, 0.8)))
+    r = A.abcdesmc(prior, sim, eps, None, **kw)
+    c = A.abcdesmc(prior, sim, eps, None, engine=oracle.oracle_engine, **kw)
+    assert type(r.engine.ops).__name__ == "HipOps" and r.engine.rows_mode
+    assert r.iters == c.iters and r.nsims == c.nsims
+    assert r.logZ == c.logZ or (math.isnan(r.logZ) and math.isnan(c.logZ))
+    assert list(r.ϵs) == list(c.ϵs) and np.array_equal(np.array(r.esss), np.array(c.esss), equal_nan=True)
+    for k in ("P", "Wns", "C"):
+        assert np.array_equal(getattr(r, k), getattr(c, k), equal_nan=True), (seed, d, k)
+    if sim.blobs:
+        assert np.array_equal(r.blobs, c.blobs, equal_nan=True)
+    m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=6, verbose=False, rng=seed + 2)
+    mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=6, verbose=False, rng=seed + 2,
+                   engine=oracle.oracle_engine)
+    assert m.nsims == mo.nsims and np.array_equal(m.P, mo.P) and np.array_equal(m.C, mo.C)
