@@ -433,6 +433,40 @@ def test_c_abi_error_paths():
         _lib.check(lib, -1)
     # the context still works after the errors
     assert swarm() == 0
+    # row store / sharded / blob entry points
+    rows = PopulationEngine(spec, 1000, ops=ops, storage="rows")
+    rows.init_population()
+    rows.alive_compact()
+    a_in, a_out = rows.alive_row[rows.ar], rows.alive_row[1 - rows.ar]
+    s0, s1, rlp, rdl = rows.buf[0][0], rows.buf[1][0], rows.buf[0][1], rows.buf[0][2]
+    flags = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+
+    def shard(r_lo=0, r_hi=1000, out=a_out, acc=flags):
+        return lib.abcdez_smc_swarm_rows_shard(ops.ctx, a_in.data_ptr(), out.data_ptr(), 1000, r_lo, r_hi, s0.data_ptr(),
+                                               s1.data_ptr(), rlp.data_ptr(), rdl.data_ptr(),
+                                               acc.data_ptr() if acc is not None else None, 5.0, 0.5, 1e-5, 0,
+                                               C.byref(nacc), C.byref(nsim))
+
+    assert shard() == 0
+    assert shard(r_lo=7, r_hi=3) != 0 and b"rank range" in lib.abcdez_last_error()
+    assert shard(out=a_in) != 0 and b"must differ" in lib.abcdez_last_error()
+    assert shard(acc=None) != 0 and b"null" in lib.abcdez_last_error()
+    assert lib.abcdez_smc_replay_rows(ops.ctx, a_in.data_ptr(), a_out.data_ptr(), 1000, 0, 1001, s0.data_ptr(), s1.data_ptr(),
+                                      flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) != 0
+    assert lib.abcdez_smc_replay_rows(ops.ctx, a_in.data_ptr(), a_out.data_ptr(), 1000, 0, 1000, s0.data_ptr(), s1.data_ptr(),
+                                      flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) == 0
+    assert nacc.value == int((flags & 1).sum()) and nsim.value == 1000        # everything is this rank's: counted only
+    st = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), st.data_ptr()) != 0
+    assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), None) != 0
+    st2 = torch.zeros_like(st)
+    assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), st2.data_ptr()) != 0 and b"n_blob = 0" in lib.abcdez_last_error()
+    assert lib.abcdez_blob_eval(ops.ctx, s0.data_ptr(), st.data_ptr(), 1000, s1.data_ptr(), rdl.data_ptr()) != 0
+    assert lib.abcdez_ctx_set_stamps(ops.ctx, None, None) == 0
+    host_data = np.ascontiguousarray(spec.data, dtype=np.float64)
+    badblob = A.ModelSpec(prior, sim, seed=1).cstruct(host_data.ctypes.data)
+    badblob.n_blob = 5                                                          # the MVN simulator's blob is d = 8 doubles
+    assert lib.abcdez_ctx_create(C.byref(badblob), 0, C.byref(ctx)) != 0 and b"n_blob" in lib.abcdez_last_error()
 
 
 # ---------------------------------------------------------------- blobs: stamps + rebuild, product vs C restatement
