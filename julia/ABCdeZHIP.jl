@@ -81,6 +81,12 @@ other(e) = 3 - e.cur
 # ---- one ccall per reference function (include/abcdez_hip.h) --------------------------------
 init!(e) = check(ccall((:abcdez_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
                        e.ctx, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur], 0, e.N))                    # init.jl:2-22
+function reset_weights!(e)                                                                                # smc:266-270: Wns = 1/N, alive = true
+    w = fill(1.0 / e.N, e.N); a = ones(UInt8, e.N)
+    check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, e.wns, w, 8e.N))
+    check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, e.alive, a, e.N))
+    e.n_alive = e.N; e.dead_synced = true
+end
 function extrema_dev(e)                                                                                   # smc:286,364
     lo = Ref(0.0); hi = Ref(0.0)
     check(ccall((:abcdez_extrema, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Float64}), e.ctx, e.delta[e.cur], e.N, lo, hi))
@@ -156,6 +162,7 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
 
     e = Engine(prior, dist!, ABCk, rng, nparticles)
     init!(e)                                                                            # smc:242-252
+    reset_weights!(e)                                                                   # smc:266-270
     ϵ = Inf; ϵ_k = Inf; logZ = 0.0; ess = 0.0; nsims = 0; facc = 1.0; Ki = Kmcmc        # smc:255-276
     ess_min = nparticles * δess
     γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5                                      # smc:280-281
