@@ -1,0 +1,228 @@
+"""The call sequence of julia/ABCdeZHIP.jl, transliterated to raw ctypes: NO torch tensors, no engine.py -- device
+memory from abcdez_dev_alloc, transfers with abcdez_memcpy_*, one C call per reference function in the order the
+shim issues them (classic double buffer, abcdez_smc_swarm / abcdez_mc_swarm).  Julia is not available to run the
+shim itself; this pins what it relies on -- argument order and types of every entry point it binds, library-side
+defaults, the need to initialise Wns / alive -- against the oracle's complete drivers, bit for bit."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import abcdez_amd as A
+from abcdez_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+class ShimEngine:
+    """mutable struct Engine of julia/ABCdeZHIP.jl"""
+
+    def __init__(self, prior, sim, ABCk, seed, N):
+        self.lib = _lib.load()
+        self.spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
+        self._data = np.ascontiguousarray(self.spec.data, dtype=np.float64)
+        m = self.spec.cstruct(self._data.ctypes.data if self._data.size else None)
+        ctx = C.c_void_p()
+        self.ck(self.lib.abcdez_ctx_create(C.byref(m), 0, C.byref(ctx)))
+        self.ctx, self.N, self.ld, self.d = ctx, N, self.spec.ld, self.spec.d
+        al = self.devalloc
+        self.theta = [al(8 * N * self.ld) for _ in range(2)]
+        self.logpi = [al(8 * N) for _ in range(2)]
+        self.delta = [al(8 * N) for _ in range(2)]
+        self.wns, self.alive, self.alive_idx, self.arank, self.inds = al(8 * N), al(N), al(4 * N), al(4 * N), al(4 * N)
+        self.order, self.sorted = al(4 * N), al(8 * N)
+        self.cur, self.sweep, self.draw, self.n_alive, self.dead_synced = 0, 0, 0, N, True
+
+    def ck(self, rc):
+        assert rc == 0, self.lib.abcdez_last_error()
+
+    def devalloc(self, nbytes):
+        p = C.c_void_p()
+        self.ck(self.lib.abcdez_dev_alloc(nbytes, C.byref(p)))
+        return p
+
+    @property
+    def other(self):
+        return 1 - self.cur
+
+    def init(self):
+        self.ck(self.lib.abcdez_init(self.ctx, self.theta[self.cur], self.logpi[self.cur], self.delta[self.cur], 0, self.N))
+
+    def reset_weights(self):
+        w = np.full(self.N, 1.0 / self.N)
+        a = np.ones(self.N, dtype=np.uint8)
+        self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.wns, w.ctypes.data, 8 * self.N))
+        self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.alive, a.ctypes.data, self.N))
+        self.n_alive, self.dead_synced = self.N, True
+
+    def extrema(self):
+        lo, hi = C.c_double(), C.c_double()
+        self.ck(self.lib.abcdez_extrema(self.ctx, self.delta[self.cur], self.N, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def quantile_alive(self, alpha):
+        q = C.c_double()
+        self.ck(self.lib.abcdez_quantile_alive(self.ctx, self.delta[self.cur], self.alive, self.N, self.n_alive, alpha,
+                                               C.byref(q), None, None))
+        return q.value
+
+    def reweight(self, eps_old, eps_new):
+        wn, es, na = C.c_double(), C.c_double(), C.c_int64()
+        self.ck(self.lib.abcdez_smc_reweight(self.ctx, self.delta[self.cur], self.wns, self.alive, self.N, eps_old, eps_new,
+                                             C.byref(wn), C.byref(es), C.byref(na)))
+        self.n_alive, self.dead_synced = na.value, False
+        return wn.value, es.value, na.value
+
+    def get_ess(self):
+        e = C.c_double()
+        self.ck(self.lib.abcdez_get_ess(self.ctx, self.wns, self.N, C.byref(e)))
+        return e.value
+
+    def resample(self):
+        self.ck(self.lib.abcdez_wsample_stratified(self.ctx, self.wns, self.N, self.draw, self.inds))
+        self.draw += 1
+        o = self.other
+        self.ck(self.lib.abcdez_smc_resample_gather(self.ctx, self.inds, self.N, 0, self.N, self.theta[self.cur],
+                                                    self.logpi[self.cur], self.delta[self.cur], self.theta[o], self.logpi[o],
+                                                    self.delta[o], self.wns, self.alive))
+        self.cur, self.n_alive, self.dead_synced = o, self.N, True
+
+    def compact(self):
+        na = C.c_int64()
+        self.ck(self.lib.abcdez_alive_compact(self.ctx, self.alive, self.N, self.alive_idx, self.arank, C.byref(na)))
+        self.n_alive = na.value
+
+    def smc_swarm(self, eps, g0, gs):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        o = self.other
+        self.ck(self.lib.abcdez_smc_swarm(self.ctx, self.alive_idx, self.arank, self.n_alive, 0, self.n_alive,
+                                          self.theta[self.cur], self.logpi[self.cur], self.delta[self.cur], self.theta[o],
+                                          self.logpi[o], self.delta[o], eps, g0, gs, 0, self.N,
+                                          1 if (not self.dead_synced and self.n_alive < self.N) else 0, None, self.sweep,
+                                          C.byref(nacc), C.byref(nsim)))
+        self.sweep += 1
+        self.dead_synced, self.cur = True, o
+        return nacc.value, nsim.value
+
+    def count_gt(self, thr):
+        c = C.c_int64()
+        self.ck(self.lib.abcdez_count_gt(self.ctx, self.delta[self.cur], self.N, thr, C.byref(c)))
+        return c.value
+
+    def rank_prepare(self):
+        self.ck(self.lib.abcdez_mc_rank_prepare(self.ctx, self.delta[self.cur], self.N, self.order, self.sorted))
+
+    def mc_swarm(self, eps_pop, eps_target, g0, gs):
+        nsim = C.c_int64()
+        o = self.other
+        self.ck(self.lib.abcdez_mc_swarm(self.ctx, self.order, self.sorted, self.N, self.theta[self.cur], self.logpi[self.cur],
+                                         self.delta[self.cur], self.theta[o], self.logpi[o], self.delta[o], eps_pop,
+                                         eps_target, g0, gs, 0, self.N, self.sweep, C.byref(nsim)))
+        self.sweep += 1
+        self.cur = o
+        return nsim.value
+
+    def download(self):
+        th = np.empty((self.N, self.ld))
+        pushed = self.devalloc(8 * self.N * self.ld)
+        self.ck(self.lib.abcdez_push_p(self.ctx, self.theta[self.cur], self.N, pushed))
+        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, th.ctypes.data, pushed, th.nbytes))
+        dl, w = np.empty(self.N), np.empty(self.N)
+        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, dl.ctypes.data, self.delta[self.cur], 8 * self.N))
+        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, w.ctypes.data, self.wns, 8 * self.N))
+        self.lib.abcdez_dev_free(pushed)
+        return th[:, :self.d], w, dl
+
+    def close(self):
+        for p in self.theta + self.logpi + self.delta + [self.wns, self.alive, self.alive_idx, self.arank, self.inds, self.order,
+                                                         self.sorted]:
+            self.lib.abcdez_dev_free(p)
+        self.lib.abcdez_ctx_destroy(self.ctx)
+
+
+def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, alpha=0.95, dess=0.5, Kmcmc=3, Kmcmc_min=1.0,
+                  nsims_max=10 ** 7):
+    """function abcdesmc!(prior, dist!::DeviceSimulator, ...) of the shim"""
+    e = ShimEngine(prior, sim, ABCk, seed, N)
+    e.init()
+    e.reset_weights()
+    eps = eps_k = math.inf
+    logZ, nsims, facc, Ki, iters = 0.0, 0, 1.0, Kmcmc, 0
+    g0, gs = 2.38 / math.sqrt(2 * e.d), 1e-5
+    eps_hist = [eps]
+    while True:
+        iters += 1
+        eps = max(min(e.quantile_alive(alpha), eps), eps_target)
+        wnorm, ess, n_alive = e.reweight(eps_k, eps)
+        logZ += math.log(wnorm)
+        naccs, Ki = 0, Kmcmc
+        if n_alive > 0 and ess < N * dess:
+            e.resample()
+            ess = e.get_ess()
+            n_alive = N
+        if n_alive >= 3:
+            e.compact()
+            for i in range(1, Kmcmc + 1):
+                nacc, nsim = e.smc_swarm(eps, g0, gs)
+                naccs += nacc
+                nsims += nsim
+                if naccs / n_alive >= Kmcmc_min:
+                    Ki = i
+                    break
+        facc = naccs / (n_alive * Ki)
+        eps_k = eps
+        eps_hist.append(eps)
+        if n_alive < 3 or eps <= eps_target or nsims >= nsims_max:
+            break
+    P, W, D = e.download()
+    e.close()
+    return dict(P=P, Wns=W, C=D, logZ=logZ, iters=iters, nsims=nsims, eps_hist=eps_hist)
+
+
+def shim_abcdemc(prior, sim, eps_target, N, seed, generations):
+    e = ShimEngine(prior, sim, A.IndicatorStrict0toϵ, seed, N)
+    e.init()
+    nsims, g0, gs = 0, 2.38 / math.sqrt(2 * e.d), 1e-5
+    for _ in range(generations):
+        lo, hi = e.extrema()
+        eps_pop = max(eps_target, lo)
+        if hi > eps_target:
+            e.rank_prepare()
+        nsims += e.mc_swarm(eps_pop, eps_target, g0, gs)
+        e.count_gt(eps_target)
+    conv = e.extrema()[1] <= eps_target
+    P, _, D = e.download()
+    e.close()
+    return dict(P=P, C=D, nsims=nsims, reached=conv)
+
+
+CASES = {
+    "normal1d": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.3, 3000),
+    "mvn8": (A.Factored(*[A.Normal(0.0, 1.0)] * 8), A.MVNormal((1.0,) * 8), 2.5, 2048),
+    "mixed": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.05, 400),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_shim_call_sequence_abcdesmc(oracle, name):
+    prior, sim, eps, N = CASES[name]
+    got = shim_abcdesmc(prior, sim, eps, N, seed=31)
+    ref = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=31), N, eps)
+    assert got["iters"] == ref["iters"] and got["nsims"] == ref["nsims"] and got["logZ"] == ref["logZ"]
+    assert np.array_equal(np.array(got["eps_hist"]), ref["eps_hist"])
+    assert np.array_equal(got["C"], ref["C"]) and np.array_equal(got["Wns"], ref["Wns"])
+    m = oracle.OracleModel(A.ModelSpec(prior, sim, seed=31))
+    th = np.ascontiguousarray(np.pad(ref["theta"], ((0, 0), (0, A.ModelSpec(prior, sim).ld - ref["theta"].shape[1]))))
+    out = np.empty_like(th)
+    oracle.lib().orc_push_p(m.ptr, th.ctypes.data, N, out.ctypes.data)
+    assert np.array_equal(got["P"], out[:, :ref["theta"].shape[1]])                    # P is push_p-cast (smc:382)
+
+
+@pytest.mark.parametrize("name", ["normal1d", "mvn8"])
+def test_shim_call_sequence_abcdemc(oracle, name):
+    prior, sim, eps, N = CASES[name]
+    got = shim_abcdemc(prior, sim, eps, N, seed=32, generations=30)
+    ref = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=32), N, eps, 30)
+    assert got["nsims"] == ref["nsims"] and got["reached"] == ref["reached_eps"]
+    assert np.array_equal(got["C"], ref["C"]) and np.array_equal(got["P"], ref["theta"])
