@@ -278,6 +278,7 @@ def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_
                  facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000):
     """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c)."""
     L = lib()
+    L.orc_set_stamps(None, None)      # the C drivers carry no blobs: unbind stamp arrays an earlier engine left behind
     m = OracleModel(spec)
     N, ld = nparticles, spec.ld
     R = SmcRun(nparticles=N, eps_target=eps_target, alpha=alpha, delta_ess=delta_ess, nsims_max=nsims_max,
@@ -301,6 +302,7 @@ def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_
 
 def run_abcdemc(spec, nparticles, eps_target, generations):
     L = lib()
+    L.orc_set_stamps(None, None)      # as in run_abcdesmc
     m = OracleModel(spec)
     N, ld = nparticles, spec.ld
     R = McRun(nparticles=N, generations=generations, eps_target=eps_target)

@@ -197,3 +197,18 @@ def test_literal_wsample_is_uniform_over_alive(oracle):
     for i in np.flatnonzero(alive):
         step = round(float(nth[i, 0] - th[i, 0]), 12)
         assert step == 0.0 or step in diffs
+
+
+def test_c_drivers_unbind_blob_stamps_of_an_earlier_engine(oracle):
+    """The oracle binds the blob stamp arrays of a run in two globals (orc_set_stamps).  The complete C drivers carry
+    no blobs: they must not write through a binding an earlier, blob-recording engine left behind (arrays that may
+    be freed by then -- this crashed the GPU suite when a driver call followed a blobs=True model)."""
+    prior = A.Normal(0.0, math.sqrt(10.0))
+    a = np.full(64, 0xABCDEF, dtype=np.uint64)
+    b = np.full(64, 0x123456, dtype=np.uint64)
+    oracle.lib().orc_set_stamps(a.ctypes.data, b.ctypes.data)        # what a blobs=True engine leaves bound
+    r1 = oracle.run_abcdesmc(ModelSpec(prior, A.Normal1D(3.0), seed=31), 64, 0.3)
+    m1 = oracle.run_abcdemc(ModelSpec(prior, A.Normal1D(3.0), seed=32), 64, 0.3, 10)
+    assert (a == 0xABCDEF).all() and (b == 0x123456).all()
+    r2 = oracle.run_abcdesmc(ModelSpec(prior, A.Normal1D(3.0), seed=31), 64, 0.3)
+    assert r1["logZ"] == r2["logZ"] and np.array_equal(r1["C"], r2["C"]) and m1["nsims"] > 0
