@@ -159,6 +159,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->cnt) (void)hipFree(ctx->cnt);
+  if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->d_model) (void)hipFree(ctx->d_model);

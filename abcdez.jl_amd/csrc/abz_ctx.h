@@ -28,6 +28,12 @@ struct abcdez_ctx {
   size_t ws_bytes = 0;
   /* hiprtc-compiled kernels of a user-supplied simulator (abz_jit.hip), else null */
   void* user_module = nullptr;
+  /* quantile select: its own histogram (left zeroed by every call) and the arrays the device-side window belongs to */
+  uint32_t* sel_hist = nullptr;
+  bool sel_clean = false;
+  const void* sel_delta = nullptr;
+  const void* sel_alive = nullptr;
+  int64_t sel_N = 0;
   /* per-block (nacc, nsim) partials of the sweep kernels */
   void* cnt = nullptr;
   size_t cnt_bytes = 0;
@@ -63,9 +69,14 @@ static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / 
 enum {
   ABZ_S_NACC = 0, ABZ_S_NSIM = 1, ABZ_S_WNORM = 2, ABZ_S_SUMSQ = 3, ABZ_S_NALIVE = 4,
   ABZ_S_MIN = 5, ABZ_S_MAX = 6, ABZ_S_COUNT = 7, ABZ_S_LASTPOS = 8, ABZ_S_SUM = 9,
+  /* state of the quantile select (abz_population.hip): result (key of the rank, #keys below, #equal, next larger key),
+   * per-call accumulators (buffer fill, smallest key above the selected bin, min / max alive key) and the binning
+   * window [HLO, HHI] carried from call to call; PAD = error flag */
   ABZ_S_SEL_PREFIX = 10, ABZ_S_SEL_K = 11, ABZ_S_SEL_LESS = 12, ABZ_S_SEL_EQ = 13, ABZ_S_SEL_NEXT = 14,
-  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_ABOVE = 16, ABZ_S_SEL_PAD = 17, ABZ_S_INITBAD = 18,
-  ABZ_S_RACC = 19, ABZ_S_RSIM = 20,      /* counters of the replayed ranks (sharded row store) */
+  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_ABOVE = 16, ABZ_S_SEL_PAD = 17, ABZ_S_SEL_KMIN = 18, ABZ_S_SEL_KMAX = 19,
+  ABZ_S_SEL_HLO = 20, ABZ_S_SEL_HHI = 21, ABZ_S_SEL_END = 22,
+  ABZ_S_INITBAD = 22,
+  ABZ_S_RACC = 23, ABZ_S_RSIM = 24,      /* counters of the replayed ranks (sharded row store) */
   ABZ_S_N = 32
 };
 

@@ -435,17 +435,30 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 }
 
 /* ================================================================ order statistics of alive distances (smc:301)
- * MSB-first radix select on the IEEE bit patterns (distances are >= 0, so the bit pattern
- * order is the value order; NaN never enters the population).  Digits: 11,11 | 11,11,11,9 bits.
- * The first two digits are histogrammed over the whole population (two streaming passes);
- * a third pass compacts the keys that carry the selected 22-bit prefix (typically N/1000 of
- * them) into a buffer and records the smallest key above that prefix; the remaining digits
- * and the "next larger key" run on the buffer.  Per pass: wave-aggregated LDS histogram
- * (clustered distances put most of a wave in one bin), then a one-block scan picks the bin
- * holding rank k.                                                                            */
-#define ABZ_SEL_BINS 2048
-
-struct SelState { unsigned long long prefix, k, less, eq, next, nbuf, min_above, pad; };
+ * Exact selection of the rank-k alive distance and of the next larger one, on the IEEE bit
+ * patterns (distances are >= 0, so the u64 pattern order is the value order; NaN never enters
+ * the population; +Inf is just the largest key).
+ *
+ *   pass 1  qs_hist_kernel     2048-bin histogram of  (key - klo) >> shift  (clamped: any
+ *                              monotone binning is correct, a good one is fast) + min/max key
+ *   pass 2  qs_compact_kernel  every block scans the histogram for the bin holding rank k,
+ *                              keys of that bin -> buffer (LDS-staged, one atomic per flush),
+ *                              smallest key of any higher bin -> `above`
+ *   finish  qs_final_kernel    ONE block narrows the buffer by 11 key bits per round until
+ *                              <= 1024 candidates remain, ranks those in LDS; leaves the
+ *                              device state ready for the next call (histogram zeroed,
+ *                              accumulators reset) and the next call's binning window.
+ *
+ * The window [klo, khi] lives on the device: the finish kernel sets it to [smallest alive key
+ * seen, key of rank k+1] -- in the driver's loop the next call's alive distances all lie below
+ * this call's quantile (smc:301-311), so the 2048 bins resolve exactly the range that is left.
+ * A stale window only costs time (clamped bins grow, the finish kernel works longer).  When the
+ * arrays change (first call, after a resampling's buffer swap) a min/max pass seeds the window.
+ * Two population passes, 3 launches, no memset / upload; replaces a 6-digit MSB radix select
+ * (3 passes, 14 launches).                                                                      */
+#define ABZ_QS_BINS 2048
+#define ABZ_QS_HBLOCK 1024          /* pass 1: 2 fat blocks per CU -> fewer flushes of the 2048 bins */
+#define ABZ_QS_CAP 4096
 
 __device__ inline void hist_add(uint32_t* s_h, bool f, uint32_t bin) {
   const unsigned long long bal = __ballot(f);
@@ -458,179 +471,325 @@ __device__ inline void hist_add(uint32_t* s_h, bool f, uint32_t bin) {
   }
 }
 
-/* source = population (delta + alive) when buf == nullptr, else buf[0 .. st->nbuf) */
-__global__ __launch_bounds__(ABZ_BLOCK) void select_hist_kernel(const double* __restrict__ delta,
-                                                                const uint8_t* __restrict__ alive, int64_t N,
-                                                                const unsigned long long* __restrict__ buf,
-                                                                const unsigned long long* __restrict__ st, int shift,
-                                                                int bits, int top, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t s_h[ABZ_SEL_BINS];
-  for (int b = threadIdx.x; b < ABZ_SEL_BINS; b += ABZ_BLOCK) s_h[b] = 0;
-  __syncthreads();
-  const unsigned long long prefix = st[0];
-  const uint32_t mask = (1u << bits) - 1u;
-  const int64_t n = buf ? (int64_t)st[5] : N;
+__device__ inline int qs_shift(unsigned long long klo, unsigned long long khi) {
+  if (khi <= klo) return 0;
+  const int bl = 64 - __clzll((long long)(khi - klo));      /* khi - klo < 2^bl */
+  return bl > 11 ? bl - 11 : 0;                             /* (khi - klo) >> shift < 2048 */
+}
+__device__ inline uint32_t qs_bin(unsigned long long key, unsigned long long klo, int shift) {
+  if (key <= klo) return 0u;
+  const unsigned long long b = (key - klo) >> shift;
+  return b < ABZ_QS_BINS ? (uint32_t)b : ABZ_QS_BINS - 1u;
+}
+
+/* window seed: min / max alive key -> st[HLO], st[HHI] (preset to ~0 / 0 by the host) */
+__global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __restrict__ delta,
+                                                              const uint8_t* __restrict__ alive, int64_t N,
+                                                              unsigned long long* __restrict__ st) {
+  unsigned long long lo = ~0ull, hi = 0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
-  /* 4 independent loads in flight per lane; wave-uniform trip count so the ballots see whole waves */
-  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k0 - threadIdx.x % 64 < n; k0 += 4 * stride) {
-    unsigned long long key[4];
-    bool ok[4];
+  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
+    const unsigned long long key = abz_d2u(delta[k]);
+    if (alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
+  }
+  block_minmax_u64(lo, hi);
+  if (threadIdx.x == 0 && lo <= hi) {
+    atomicMin(&st[ABZ_S_SEL_HLO - ABZ_S_SEL_PREFIX], lo);
+    atomicMax(&st[ABZ_S_SEL_HHI - ABZ_S_SEL_PREFIX], hi);
+  }
+}
+
+#define QS(slot) st[(slot) - ABZ_S_SEL_PREFIX]
+
+__global__ __launch_bounds__(ABZ_QS_HBLOCK) void qs_hist_kernel(const double* __restrict__ delta,
+                                                                const uint8_t* __restrict__ alive, int64_t N,
+                                                                unsigned long long* __restrict__ st,
+                                                                uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[ABZ_QS_BINS];
+  __shared__ unsigned long long s_lo[ABZ_QS_HBLOCK / 64], s_hi[ABZ_QS_HBLOCK / 64];
+  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_HBLOCK) s_h[b] = 0;
+  const unsigned long long klo = QS(ABZ_S_SEL_HLO);
+  const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
+  __syncthreads();
+  unsigned long long lo = ~0ull, hi = 0ull;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_HBLOCK;
+  /* 8 independent (distance, flag) loads in flight per lane; wave-uniform trip count so the ballots see whole waves */
+  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_HBLOCK + threadIdx.x; k0 - (threadIdx.x & 63) < N; k0 += 8 * stride) {
+    unsigned long long key[8];
+    uint8_t al[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int64_t k = k0 + u * stride;
-      ok[u] = k < n && (buf ? true : alive[k] != 0);
-      key[u] = ok[u] ? (buf ? buf[k] : abz_d2u(delta[k])) : 0ull;
+      const bool in = k < N;
+      key[u] = in ? abz_d2u(delta[k]) : 0ull;
+      al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool f = ok[u] && (top || (key[u] >> (shift + bits)) == prefix);
-      hist_add(s_h, f, (uint32_t)(key[u] >> shift) & mask);
+    for (int u = 0; u < 8; ++u) {
+      const bool f = al[u] != 0;
+      hist_add(s_h, f, qs_bin(key[u], klo, shift));
+      if (f) { lo = key[u] < lo ? key[u] : lo; hi = key[u] > hi ? key[u] : hi; }
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < ABZ_SEL_BINS; b += ABZ_BLOCK)
+  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_HBLOCK)
     if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < ABZ_QS_HBLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
+    if (lo <= hi) { atomicMin(&QS(ABZ_S_SEL_KMIN), lo); atomicMax(&QS(ABZ_S_SEL_KMAX), hi); }
+  }
 }
 
-__global__ __launch_bounds__(1024) void select_pick_kernel(uint32_t* __restrict__ hist, unsigned long long* __restrict__ st,
-                                                           int bits) {
-  /* one block; thread t owns 2 bins; find bin b with cum(b-1) <= k < cum(b) */
-  __shared__ unsigned long long s_c[1024];
-  const int t = threadIdx.x;
-  const int nb = 1 << bits;
-  const uint32_t h0 = 2 * t < nb ? hist[2 * t] : 0, h1 = 2 * t + 1 < nb ? hist[2 * t + 1] : 0;
-  s_c[t] = (unsigned long long)h0 + h1;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    unsigned long long add = t >= off ? s_c[t - off] : 0;
-    __syncthreads();
-    s_c[t] += add;
-    __syncthreads();
-  }
-  const unsigned long long k = st[1];
-  const unsigned long long before = t ? s_c[t - 1] : 0;
-  if (t == 1023 && k >= s_c[1023]) st[7] = 1;        /* rank beyond the population: the caller's n_alive was wrong */
-  if (k >= before && k < s_c[t]) {
-    int b; unsigned long long lessb;
-    if (k < before + h0) { b = 2 * t; lessb = before; } else { b = 2 * t + 1; lessb = before + h0; }
-    st[0] = (st[0] << bits) | (unsigned long long)b;
-    st[1] = k - lessb;
-    st[2] += lessb;
-    st[3] = b == 2 * t ? h0 : h1;
-  }
-  __syncthreads();
-  if (2 * t < nb) hist[2 * t] = 0;
-  if (2 * t + 1 < nb) hist[2 * t + 1] = 0;
-}
-
-/* pass 3: keys with the selected 22-bit prefix -> buf; smallest key with a larger prefix -> st[6].
- * Hits are staged in LDS and appended with ONE global atomic per flush (scattered hits would
- * otherwise cost one returning same-address atomic per wave: 156 us for ~5000 hits).          */
-#define ABZ_SEL_CAP 4096
-__global__ __launch_bounds__(ABZ_BLOCK) void select_compact_kernel(const double* __restrict__ delta,
-                                                                   const uint8_t* __restrict__ alive, int64_t N,
-                                                                   unsigned long long* __restrict__ st, int shift,
-                                                                   unsigned long long* __restrict__ buf) {
-  __shared__ unsigned long long s_buf[ABZ_SEL_CAP];
-  __shared__ uint32_t s_n;
+/* pass 2.  Every block finds the bin of rank k0 itself (2048 counters from L2: cheaper than a launch). */
+__global__ __launch_bounds__(ABZ_BLOCK) void qs_compact_kernel(const double* __restrict__ delta,
+                                                               const uint8_t* __restrict__ alive, int64_t N,
+                                                               unsigned long long k0, const uint32_t* __restrict__ hist,
+                                                               unsigned long long* __restrict__ st,
+                                                               unsigned long long* __restrict__ buf) {
+  __shared__ unsigned long long s_buf[ABZ_QS_CAP];
+  __shared__ unsigned long long s_wsum[ABZ_BLOCK / 64];
+  __shared__ uint32_t s_n, s_bin;
   __shared__ unsigned long long s_base;
-  if (threadIdx.x == 0) s_n = 0;
+  const int t = threadIdx.x;
+  constexpr int PER = ABZ_QS_BINS / ABZ_BLOCK;         /* 8 consecutive bins per thread */
+  uint32_t h[PER];
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { h[j] = hist[t * PER + j]; mine += h[j]; }
+  unsigned long long incl = mine;                      /* inclusive scan over the block */
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long v = __shfl_up(incl, off, 64);
+    if ((t & 63) >= off) incl += v;
+  }
+  if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+  if (t == 0) { s_n = 0; s_bin = 0xFFFFFFFFu; }
   __syncthreads();
-  const unsigned long long prefix = st[0];
+  unsigned long long before = incl - mine;
+  for (int w = 0; w < (t >> 6); ++w) before += s_wsum[w];
+  if (k0 >= before && k0 < before + mine) {            /* exactly one thread, if k0 < total */
+    unsigned long long c = before;
+    int j = 0;
+    while (k0 >= c + h[j]) { c += h[j]; ++j; }
+    s_bin = (uint32_t)(t * PER + j);
+    if (blockIdx.x == 0) { QS(ABZ_S_SEL_K) = k0 - c; QS(ABZ_S_SEL_LESS) = c; QS(ABZ_S_SEL_PAD) = 0; }
+  }
+  if (blockIdx.x == 0 && t == ABZ_BLOCK - 1 && k0 >= before + mine) QS(ABZ_S_SEL_PAD) = 1;   /* rank beyond the population */
+  __syncthreads();
+  const uint32_t sel = s_bin;
+  if (sel == 0xFFFFFFFFu) return;
+  const unsigned long long klo = QS(ABZ_S_SEL_HLO);
+  const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
   unsigned long long above = ~0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   auto flush = [&]() {
-    if (threadIdx.x == 0) s_base = atomicAdd(&st[5], (unsigned long long)s_n);
+    if (t == 0) s_base = atomicAdd(&QS(ABZ_S_SEL_NBUF), (unsigned long long)s_n);
     __syncthreads();
     const uint32_t n = s_n;
-    for (uint32_t t = threadIdx.x; t < n; t += ABZ_BLOCK) buf[s_base + t] = s_buf[t];
+    for (uint32_t q = t; q < n; q += ABZ_BLOCK) buf[s_base + q] = s_buf[q];
     __syncthreads();
-    if (threadIdx.x == 0) s_n = 0;
+    if (t == 0) s_n = 0;
     __syncthreads();
   };
-  for (int64_t base = (int64_t)blockIdx.x * ABZ_BLOCK; base < N; base += 4 * stride) {   /* block-uniform trips */
-    unsigned long long key[4];
-    bool ok[4];
+  for (int64_t base = (int64_t)blockIdx.x * ABZ_BLOCK; base < N; base += 8 * stride) {     /* block-uniform trips */
+    unsigned long long key[8];
+    uint8_t al[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t k = base + threadIdx.x + u * stride;
-      ok[u] = k < N && alive[k] != 0;
-      key[u] = ok[u] ? abz_d2u(delta[k]) : 0ull;
+    for (int u = 0; u < 8; ++u) {
+      const int64_t k = base + t + u * stride;
+      const bool in = k < N;
+      key[u] = in ? abz_d2u(delta[k]) : 0ull;
+      al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned long long p = key[u] >> shift;
-      if (ok[u] && p > prefix && key[u] < above) above = key[u];
-      if (ok[u] && p == prefix) s_buf[atomicAdd(&s_n, 1u)] = key[u];       /* room for 4 x 256 guaranteed */
+    for (int u = 0; u < 8; ++u) {
+      if (!al[u]) continue;
+      const uint32_t b = qs_bin(key[u], klo, shift);
+      if (b > sel && key[u] < above) above = key[u];
+      if (b == sel) s_buf[atomicAdd(&s_n, 1u)] = key[u];                    /* room for 8 x 256 guaranteed */
     }
     __syncthreads();
-    if (s_n > ABZ_SEL_CAP - 4 * ABZ_BLOCK) flush();                       /* s_n is block-uniform here */
+    if (s_n > ABZ_QS_CAP - 8 * ABZ_BLOCK) flush();                          /* s_n is block-uniform here */
   }
   if (s_n) flush();
   unsigned long long dummy = 0;
   block_minmax_u64(above, dummy);
-  if (threadIdx.x == 0 && above != ~0ull) atomicMin(&st[6], above);
+  if (t == 0 && above != ~0ull) atomicMin(&QS(ABZ_S_SEL_ABOVE), above);
 }
 
-/* smallest key strictly greater than the selected key: inside the buffer, else the recorded min_above */
-__global__ __launch_bounds__(ABZ_BLOCK) void select_next_kernel(const unsigned long long* __restrict__ buf,
-                                                                unsigned long long* __restrict__ st) {
-  const unsigned long long key0 = st[0];
-  const int64_t n = (int64_t)st[5];
-  unsigned long long best = ~0ull;
-  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
-  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < n; k += stride) {
-    const unsigned long long key = buf[k];
-    if (key > key0 && key < best) best = key;
+/* one block of 1024: sum / min / max over the block, result broadcast to every thread */
+__device__ inline void qs_block_reduce(unsigned long long& cnt, unsigned long long& mn, unsigned long long& mx,
+                                       unsigned long long* s_red) {
+  for (int off = 32; off; off >>= 1) {
+    cnt += __shfl_xor(cnt, off, 64);
+    const unsigned long long a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
   }
-  unsigned long long dummy = 0;
-  block_minmax_u64(best, dummy);
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0 && st[6] < best) best = st[6];
-    if (best != ~0ull) atomicMin(&st[4], best);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();                                    /* s_red may still be read from the previous round */
+  if ((threadIdx.x & 63) == 0) { s_red[3 * w] = cnt; s_red[3 * w + 1] = mn; s_red[3 * w + 2] = mx; }
+  __syncthreads();
+  cnt = 0; mn = ~0ull; mx = 0ull;
+  for (int q = 0; q < 16; ++q) {
+    cnt += s_red[3 * q];
+    mn = s_red[3 * q + 1] < mn ? s_red[3 * q + 1] : mn;
+    mx = s_red[3 * q + 2] > mx ? s_red[3 * q + 2] : mx;
   }
 }
+
+__global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long* __restrict__ buf,
+                                                        unsigned long long* __restrict__ st, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[ABZ_QS_BINS];
+  __shared__ unsigned long long s_cand[1024];
+  __shared__ unsigned long long s_red[48];
+  __shared__ unsigned long long s_pick[4];            /* bin | key, count before it, (rank branch) hit flag, #equal */
+  __shared__ uint32_t s_n;
+  const int t = threadIdx.x;
+  for (int b = t; b < ABZ_QS_BINS; b += 1024) hist[b] = 0;               /* ready for the next call */
+  const bool bad = QS(ABZ_S_SEL_PAD) != 0;
+  const int64_t n = bad ? 0 : (int64_t)QS(ABZ_S_SEL_NBUF);
+  unsigned long long k = QS(ABZ_S_SEL_K), less = QS(ABZ_S_SEL_LESS);
+  unsigned long long lo = 0ull, hi = ~0ull, key = 0ull, eq = 0ull;
+  bool found = false;
+  for (int round = 0; round < 16 && !bad; ++round) {
+    unsigned long long cnt = 0, mn = ~0ull, mx = 0ull;
+    for (int64_t i = t; i < n; i += 1024) {
+      const unsigned long long x = buf[i];
+      if (x >= lo && x <= hi) { ++cnt; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    }
+    qs_block_reduce(cnt, mn, mx, s_red);
+    if (cnt == 0) break;                               /* cannot happen for k < count; reported as an error below */
+    if (mn == mx) { key = mn; eq = cnt; found = true; break; }
+    if (cnt <= 1024) {
+      if (t == 0) s_n = 0;
+      __syncthreads();
+      for (int64_t i = t; i < n; i += 1024) {
+        const unsigned long long x = buf[i];
+        if (x >= lo && x <= hi) s_cand[atomicAdd(&s_n, 1u)] = x;
+      }
+      if (t == 0) s_pick[2] = 0;
+      __syncthreads();
+      if (t < (int)cnt) {
+        const unsigned long long me = s_cand[t];
+        unsigned long long l = 0, e = 0;
+        for (int j = 0; j < (int)cnt; ++j) { const unsigned long long c = s_cand[j]; l += c < me; e += c == me; }
+        if (l <= k && k < l + e) { s_pick[0] = me; s_pick[1] = l; s_pick[3] = e; s_pick[2] = 1; }   /* equal keys write equal values */
+      }
+      __syncthreads();
+      if (s_pick[2]) { key = s_pick[0]; less += s_pick[1]; eq = s_pick[3]; found = true; }
+      break;
+    }
+    /* narrow: 2048 sub-bins of [mn, mx] */
+    const int bl = 64 - __clzll((long long)(mx - mn));
+    const int s = bl > 11 ? bl - 11 : 0;
+    for (int b = t; b < ABZ_QS_BINS; b += 1024) s_h[b] = 0;
+    __syncthreads();
+    for (int64_t i = t; i < n; i += 1024) {
+      const unsigned long long x = buf[i];
+      if (x >= lo && x <= hi) atomicAdd(&s_h[(uint32_t)((x - mn) >> s)], 1u);
+    }
+    __syncthreads();
+    const uint32_t h0 = s_h[2 * t], h1 = s_h[2 * t + 1];
+    unsigned long long mine = (unsigned long long)h0 + h1, incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long v = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += v;
+    }
+    if ((t & 63) == 63) s_red[t >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) before += s_red[w];
+    if (k >= before && k < before + mine) {
+      if (k < before + h0) { s_pick[0] = 2 * t; s_pick[1] = before; } else { s_pick[0] = 2 * t + 1; s_pick[1] = before + h0; }
+    }
+    __syncthreads();
+    const unsigned long long b = s_pick[0];
+    less += s_pick[1];
+    k -= s_pick[1];
+    lo = mn + (b << s);
+    hi = lo + ((1ull << s) - 1ull);
+    __syncthreads();
+  }
+  /* smallest key strictly greater than the selected one: in the buffer, else the smallest key of a higher bin */
+  unsigned long long nxt = ~0ull, dc = 0, dm = 0;
+  if (found)
+    for (int64_t i = t; i < n; i += 1024) {
+      const unsigned long long x = buf[i];
+      if (x > key && x < nxt) nxt = x;
+    }
+  qs_block_reduce(dc, nxt, dm, s_red);
+  if (t == 0) {
+    const unsigned long long above = QS(ABZ_S_SEL_ABOVE);
+    if (above < nxt) nxt = above;
+    QS(ABZ_S_SEL_PREFIX) = key;
+    QS(ABZ_S_SEL_LESS) = less;
+    QS(ABZ_S_SEL_EQ) = eq;
+    QS(ABZ_S_SEL_NEXT) = nxt;
+    if (!found) QS(ABZ_S_SEL_PAD) = bad ? 1 : 2;
+    /* window of the next call: [smallest alive key seen, key of the next rank] */
+    const unsigned long long kmin = QS(ABZ_S_SEL_KMIN);
+    if (found) {
+      QS(ABZ_S_SEL_HLO) = kmin <= key ? kmin : key;
+      QS(ABZ_S_SEL_HHI) = nxt != ~0ull ? nxt : key;
+    }
+    QS(ABZ_S_SEL_NBUF) = 0;
+    QS(ABZ_S_SEL_ABOVE) = ~0ull;
+    QS(ABZ_S_SEL_KMIN) = ~0ull;
+    QS(ABZ_S_SEL_KMAX) = 0ull;
+  }
+}
+#undef QS
 
 int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
                     double* xk, double* xk1, int64_t* n_le) {
-  const size_t hb = abz_align(ABZ_SEL_BINS * 4);
-  int rc = abz_ws_reserve(ctx, hb + abz_align((size_t)N * 8));
+  int rc = abz_ws_reserve(ctx, abz_align((size_t)N * 8));
   if (rc) return rc;
-  uint32_t* hist = (uint32_t*)ctx->ws;
-  unsigned long long* buf = (unsigned long long*)((char*)ctx->ws + hb);
+  unsigned long long* buf = (unsigned long long*)ctx->ws;
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
-  SelState init{0ull, (unsigned long long)k0, 0ull, 0ull, ~0ull, 0ull, ~0ull, 0ull};
-  ABZ_HIP_CHECK(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  ABZ_HIP_CHECK(hipMemsetAsync(hist, 0, ABZ_SEL_BINS * 4, ctx->stream));
-  unsigned grid = (unsigned)((N + 4 * ABZ_BLOCK - 1) / (4 * ABZ_BLOCK));
-  if (grid > 1024) grid = 1024;
-  if (grid < 1) grid = 1;
-  const int widths[6] = {11, 11, 11, 11, 11, 9};
-  int shift = 64;
-  for (int p = 0; p < 2; ++p) {            /* whole population */
-    shift -= widths[p];
-    hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N,
-                       (const unsigned long long*)nullptr, st, shift, widths[p], p == 0 ? 1 : 0, hist);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, st, widths[p]);
+  if (!ctx->sel_hist) {
+    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, ABZ_QS_BINS * 4));
+    ctx->sel_clean = false;
   }
-  hipLaunchKernelGGL(select_compact_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st, shift,
-                     buf);
-  const unsigned bgrid = 64;               /* buffer passes: the buffer is small */
-  for (int p = 2; p < 6; ++p) {
-    shift -= widths[p];
-    hipLaunchKernelGGL(select_hist_kernel, dim3(bgrid), dim3(ABZ_BLOCK), 0, ctx->stream, (const double*)nullptr,
-                       (const uint8_t*)nullptr, (int64_t)0, buf, st, shift, widths[p], 0, hist);
-    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, st, widths[p]);
+  const bool reseed = !ctx->sel_clean || ctx->sel_delta != delta || ctx->sel_alive != alive || ctx->sel_N != N;
+  unsigned pgrid = (unsigned)((N + 8 * ABZ_BLOCK - 1) / (8 * ABZ_BLOCK));
+  if (pgrid > 1024) pgrid = 1024;
+  if (reseed) {
+    /* device state of the select from scratch + window from a min / max pass */
+    unsigned long long init[ABZ_S_SEL_END - ABZ_S_SEL_PREFIX] = {0};
+    init[ABZ_S_SEL_ABOVE - ABZ_S_SEL_PREFIX] = ~0ull;
+    init[ABZ_S_SEL_KMIN - ABZ_S_SEL_PREFIX] = ~0ull;
+    init[ABZ_S_SEL_HLO - ABZ_S_SEL_PREFIX] = ~0ull;
+    ABZ_HIP_CHECK(hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->sel_hist, 0, ABZ_QS_BINS * 4, ctx->stream));
+    hipLaunchKernelGGL(qs_minmax_kernel, dim3(pgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
   }
-  hipLaunchKernelGGL(select_next_kernel, dim3(bgrid), dim3(ABZ_BLOCK), 0, ctx->stream, buf, st);
+  ctx->sel_clean = false;
+  unsigned hgrid = (unsigned)((N + 8 * ABZ_QS_HBLOCK - 1) / (8 * ABZ_QS_HBLOCK));
+  if (hgrid > 512) hgrid = 512;
+  hipLaunchKernelGGL(qs_hist_kernel, dim3(hgrid), dim3(ABZ_QS_HBLOCK), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist);
+  hipLaunchKernelGGL(qs_compact_kernel, dim3(pgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N,
+                     (unsigned long long)k0, ctx->sel_hist, st, buf);
+  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist);
   ABZ_HIP_CHECK(hipGetLastError());
   rc = read_scalars(ctx);
   if (rc) return rc;
+  ctx->sel_clean = true;
+  ctx->sel_delta = delta; ctx->sel_alive = alive; ctx->sel_N = N;
   const unsigned long long key = ctx->h_scal[ABZ_S_SEL_PREFIX];
   const unsigned long long less = ctx->h_scal[ABZ_S_SEL_LESS], eq = ctx->h_scal[ABZ_S_SEL_EQ];
   const unsigned long long next = ctx->h_scal[ABZ_S_SEL_NEXT];
   if (ctx->h_scal[ABZ_S_SEL_PAD]) {
-    abz_set_error("quantile_alive: requested rank is beyond the number of alive particles (wrong n_alive_hint?)");
+    ctx->sel_clean = false;
+    abz_set_error(ctx->h_scal[ABZ_S_SEL_PAD] == 1
+                      ? "quantile_alive: requested rank is beyond the number of alive particles (wrong n_alive_hint?)"
+                      : "quantile_alive: internal selection error");
     return -1;
   }
   *xk = abz_u2d(key);

@@ -147,6 +147,73 @@ def test_reweight_quantile_compact_parity(oracle, N, abck):
         eps_old = qh
 
 
+def _quantile_inputs(shape, N, rng):
+    if shape == "uniform":
+        return rng.random(N) * 3.0
+    if shape == "clustered":            # the annealed population: a narrow band below the last epsilon
+        return 9.0 + rng.random(N) ** 0.25 * 0.04
+    if shape == "heavy":                # 20 octaves and infinite distances (2-D test of runtests.jl:246-318)
+        d = np.exp(rng.normal(0.0, 5.0, N))
+        d[rng.random(N) < 0.1] = np.inf
+        return d
+    if shape == "equal":
+        return np.full(N, 2.5)
+    if shape == "few":                  # discrete distances (Socks, DiracSquare): long runs of equal keys
+        return rng.integers(0, 5, N).astype(np.float64)
+    if shape == "zeros_and_tiny":
+        d = rng.random(N) * 1e-300
+        d[::3] = 0.0
+        return d
+    raise KeyError(shape)
+
+
+@pytest.mark.parametrize("shape", ["uniform", "clustered", "heavy", "equal", "few", "zeros_and_tiny"])
+@pytest.mark.parametrize("N", [3, 1000, 70001, 1 << 20])
+def test_quantile_select_exact_on_any_distribution(oracle, shape, N):
+    """smc:301.  The select bins the IEEE keys in a window carried over from the previous call: fresh windows, windows
+    that fit (driver order: quantile -> reweight), stale windows (new data behind the same pointers, larger p than
+    before) all give the exact order statistics -- checked against numpy's sort and the oracle's quantile."""
+    rng = np.random.default_rng(N + len(shape))
+    spec = A.ModelSpec(A.Normal(0, 1), A.Normal1D(0.0), seed=1)
+    ops = HipOps(spec)
+    delta = torch.zeros(N, dtype=torch.float64, device="cuda")
+    alive = torch.ones(N, dtype=torch.uint8, device="cuda")
+
+    def check(d, a, p, hint):
+        delta.copy_(torch.from_numpy(d))
+        alive.copy_(torch.from_numpy(a))
+        got = ops.quantile_alive(delta, alive, p, hint)
+        x = np.sort(d[a != 0])
+        n = x.size
+        h = (n - 1) * p + 1.0
+        j = min(max(int(math.floor(h)), 1), max(n - 1, 1))
+        xj, xj1 = x[j - 1], x[min(j, n - 1)]
+        assert got[1] == xj and got[2] == xj1, (shape, N, p, got, xj, xj1)
+        ref = oracle.lib().orc_quantile_alive(d.ctypes.data, a.ctypes.data, N, p, None, None)
+        assert got[0] == ref or (math.isnan(got[0]) and math.isnan(ref))       # inf - inf at the top of "heavy"
+
+    d = _quantile_inputs(shape, N, rng)
+    a = np.ones(N, dtype=np.uint8)
+    check(d, a, 0.95, N)                                  # first call: window from the min / max pass
+    for p in (0.95, 0.5, 0.99, 0.0, 1.0):                 # driver order: the survivors of the last quantile
+        x = d[a != 0]
+        if x.size < 3:
+            break
+        q = np.quantile(x, 0.9)
+        a = (a != 0) & (d < q) if (d[a != 0] < q).sum() >= 3 else a
+        a = a.astype(np.uint8)
+        check(d, a, p, int(a.sum()))
+        check(d, a, p, -1)                                # alive count not known to the caller
+    a = np.ones(N, dtype=np.uint8)
+    check(d, a, 0.97, N)                                  # stale window: everything is alive again
+    for other in ("heavy", "clustered", "uniform"):       # stale window: unrelated data behind the same pointers
+        d2 = _quantile_inputs(other, N, rng)
+        a2 = (rng.random(N) < 0.7).astype(np.uint8)
+        a2[:3] = 1
+        check(d2, a2, 0.95, int(a2.sum()))
+        check(d2, a2, 0.05, int(a2.sum()))
+
+
 @pytest.mark.parametrize("N", [5, 1000, 4096, 65537])
 def test_stratified_resample_parity(oracle, N):
     spec, hip, orc, _ = engines("mvn8", N, oracle=oracle)
