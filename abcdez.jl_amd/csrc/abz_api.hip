@@ -226,6 +226,7 @@ int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes)
 static int read_counters(abcdez_ctx* ctx) {
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  abz_fold_counters(ctx);
   if (ctx->ev_pending) {
     float ms = 0.f;
     ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

@@ -21,7 +21,7 @@ struct abcdez_ctx {
   abz_tables* d_tables = nullptr;
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
   /* device scalars + pinned host mirror */
-  unsigned long long* d_scal = nullptr;   /* 32 x u64                           */
+  unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
   unsigned long long* h_scal = nullptr;
   /* growable workspace */
   void* ws = nullptr;
@@ -70,14 +70,19 @@ enum {
   ABZ_S_NACC = 0, ABZ_S_NSIM = 1, ABZ_S_WNORM = 2, ABZ_S_SUMSQ = 3, ABZ_S_NALIVE = 4,
   ABZ_S_MIN = 5, ABZ_S_MAX = 6, ABZ_S_COUNT = 7, ABZ_S_LASTPOS = 8, ABZ_S_SUM = 9,
   /* state of the quantile select (abz_population.hip): result (key of the rank, #keys below, #equal, next larger key),
-   * per-call accumulators (buffer fill, smallest key above the selected bin, min / max alive key) and the binning
-   * window [HLO, HHI] carried from call to call; PAD = error flag */
+   * rank inside the selected bin, that bin, buffer fill (reset by every call), error flag, and the binning window [HLO, HHI]
+   * carried from call to call */
   ABZ_S_SEL_PREFIX = 10, ABZ_S_SEL_K = 11, ABZ_S_SEL_LESS = 12, ABZ_S_SEL_EQ = 13, ABZ_S_SEL_NEXT = 14,
-  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_ABOVE = 16, ABZ_S_SEL_PAD = 17, ABZ_S_SEL_KMIN = 18, ABZ_S_SEL_KMAX = 19,
-  ABZ_S_SEL_HLO = 20, ABZ_S_SEL_HHI = 21, ABZ_S_SEL_END = 22,
-  ABZ_S_INITBAD = 22,
-  ABZ_S_RACC = 23, ABZ_S_RSIM = 24,      /* counters of the replayed ranks (sharded row store) */
-  ABZ_S_N = 32
+  ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_PAD = 16, ABZ_S_SEL_HLO = 17, ABZ_S_SEL_HHI = 18, ABZ_S_SEL_BIN = 19,
+  ABZ_S_SEL_END = 20,
+  ABZ_S_INITBAD = 20,
+  ABZ_S_RACC = 21, ABZ_S_RSIM = 22,      /* counters of the replayed ranks (sharded row store) */
+  ABZ_S_SCALARS = 32,
+  /* (nacc, nsim) partial pairs of the sweep / replay kernels' blocks, summed by the host after the read-back:
+   * ABZ_CNT_PARTS pairs for the sweep (-> ABZ_S_NACC / NSIM), then as many for the replay (-> ABZ_S_RACC / RSIM) */
+  ABZ_CNT_PARTS = 16,
+  ABZ_S_PART_SWEEP = ABZ_S_SCALARS, ABZ_S_PART_REPLAY = ABZ_S_PART_SWEEP + 2 * ABZ_CNT_PARTS,
+  ABZ_S_N = ABZ_S_PART_REPLAY + 2 * ABZ_CNT_PARTS
 };
 
 /* kernel launchers implemented across the .hip files */
@@ -99,7 +104,8 @@ int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, c
 int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,
                                const double*, const double*, double*, double*, double*, double*, uint8_t*);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
-int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, unsigned long long* d_out);
+int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, int part_slot);
+void abz_fold_counters(abcdez_ctx*);
 int abz_jit_build(abcdez_ctx*, const char* user_source);
 void abz_jit_destroy(abcdez_ctx*);
 int abz_jit_launch_init(abcdez_ctx*, double*, double*, double*, uint32_t, uint32_t, unsigned long long*, uint64_t* stamp);

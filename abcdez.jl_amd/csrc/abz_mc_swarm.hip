@@ -40,7 +40,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   }
   if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_SWEEP);
 }
 
 /* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) ---- */

@@ -457,19 +457,10 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
  * Two population passes, 3 launches, no memset / upload; replaces a 6-digit MSB radix select
  * (3 passes, 14 launches).                                                                      */
 #define ABZ_QS_BINS 2048
-#define ABZ_QS_HBLOCK 1024          /* pass 1: 2 fat blocks per CU -> fewer flushes of the 2048 bins */
-#define ABZ_QS_CAP 4096
-
-__device__ inline void hist_add(uint32_t* s_h, bool f, uint32_t bin) {
-  const unsigned long long bal = __ballot(f);
-  if (bal) {
-    const int leader = __ffsll((long long)bal) - 1;
-    const uint32_t lbin = __shfl(bin, leader, 64);
-    const unsigned long long same = __ballot(f && bin == lbin);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&s_h[lbin], (uint32_t)__popcll(same));
-    if (f && bin != lbin) atomicAdd(&s_h[bin], 1u);
-  }
-}
+#define ABZ_QS_FAT 1024             /* passes 1 / 2: one fat block per CU -> few histogram flushes, few append atomics */
+#define ABZ_QS_GRID 256
+#define ABZ_QS_CAP 6144
+#define ABZ_QS_LDSKEYS 4096
 
 __device__ inline int qs_shift(unsigned long long klo, unsigned long long khi) {
   if (khi <= klo) return 0;
@@ -482,6 +473,15 @@ __device__ inline uint32_t qs_bin(unsigned long long key, unsigned long long klo
   return b < ABZ_QS_BINS ? (uint32_t)b : ABZ_QS_BINS - 1u;
 }
 
+/* 2048 sub-bins of the selected bin `sel` (again clamped and monotone): 11 more key bits */
+__device__ inline uint32_t qs_sub(unsigned long long key, unsigned long long base, int s2) {
+  if (key <= base) return 0u;
+  const unsigned long long b = (key - base) >> s2;
+  return b < ABZ_QS_BINS ? (uint32_t)b : ABZ_QS_BINS - 1u;
+}
+
+#define QS(slot) st[(slot) - ABZ_S_SEL_PREFIX]
+
 /* window seed: min / max alive key -> st[HLO], st[HHI] (preset to ~0 / 0 by the host) */
 __global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __restrict__ delta,
                                                               const uint8_t* __restrict__ alive, int64_t N,
@@ -493,28 +493,34 @@ __global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __re
     if (alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
   }
   block_minmax_u64(lo, hi);
-  if (threadIdx.x == 0 && lo <= hi) {
-    atomicMin(&st[ABZ_S_SEL_HLO - ABZ_S_SEL_PREFIX], lo);
-    atomicMax(&st[ABZ_S_SEL_HHI - ABZ_S_SEL_PREFIX], hi);
-  }
+  if (threadIdx.x == 0 && lo <= hi) { atomicMin(&QS(ABZ_S_SEL_HLO), lo); atomicMax(&QS(ABZ_S_SEL_HHI), hi); }
 }
 
-#define QS(slot) st[(slot) - ABZ_S_SEL_PREFIX]
+/* min over a fat block; valid on thread 0 */
+__device__ inline unsigned long long qs_fat_min(unsigned long long v, unsigned long long* s_w) {
+  for (int off = 32; off; off >>= 1) { const unsigned long long a = __shfl_xor(v, off, 64); v = a < v ? a : v; }
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) for (int w = 1; w < ABZ_QS_FAT / 64; ++w) v = s_w[w] < v ? s_w[w] : v;
+  return v;
+}
 
-__global__ __launch_bounds__(ABZ_QS_HBLOCK) void qs_hist_kernel(const double* __restrict__ delta,
-                                                                const uint8_t* __restrict__ alive, int64_t N,
-                                                                unsigned long long* __restrict__ st,
-                                                                uint32_t* __restrict__ hist) {
+/* pass 1: histogram of the alive keys in the window's bins; smallest alive key per block -> bmin[block] */
+__global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __restrict__ delta,
+                                                             const uint8_t* __restrict__ alive, int64_t N,
+                                                             const unsigned long long* __restrict__ st,
+                                                             uint32_t* __restrict__ hist,
+                                                             unsigned long long* __restrict__ bmin) {
   __shared__ uint32_t s_h[ABZ_QS_BINS];
-  __shared__ unsigned long long s_lo[ABZ_QS_HBLOCK / 64], s_hi[ABZ_QS_HBLOCK / 64];
-  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_HBLOCK) s_h[b] = 0;
+  __shared__ unsigned long long s_w[ABZ_QS_FAT / 64];
+  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_FAT) s_h[b] = 0;
   const unsigned long long klo = QS(ABZ_S_SEL_HLO);
   const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
   __syncthreads();
-  unsigned long long lo = ~0ull, hi = 0ull;
-  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_HBLOCK;
-  /* 8 independent (distance, flag) loads in flight per lane; wave-uniform trip count so the ballots see whole waves */
-  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_HBLOCK + threadIdx.x; k0 - (threadIdx.x & 63) < N; k0 += 8 * stride) {
+  unsigned long long lo = ~0ull;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
+  /* 8 independent (distance, flag) loads in flight per lane */
+  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x; k0 < N; k0 += 8 * stride) {
     unsigned long long key[8];
     uint8_t al[8];
 #pragma unroll
@@ -525,102 +531,108 @@ __global__ __launch_bounds__(ABZ_QS_HBLOCK) void qs_hist_kernel(const double* __
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool f = al[u] != 0;
-      hist_add(s_h, f, qs_bin(key[u], klo, shift));
-      if (f) { lo = key[u] < lo ? key[u] : lo; hi = key[u] > hi ? key[u] : hi; }
-    }
+    for (int u = 0; u < 8; ++u)
+      if (al[u]) {
+        atomicAdd(&s_h[qs_bin(key[u], klo, shift)], 1u);
+        lo = key[u] < lo ? key[u] : lo;
+      }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_HBLOCK)
+  for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_FAT)
     if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
-  for (int off = 32; off; off >>= 1) {
-    const unsigned long long a = __shfl_xor(lo, off, 64), b = __shfl_xor(hi, off, 64);
-    lo = a < lo ? a : lo;
-    hi = b > hi ? b : hi;
-  }
-  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < ABZ_QS_HBLOCK / 64; ++w) { lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; }
-    if (lo <= hi) { atomicMin(&QS(ABZ_S_SEL_KMIN), lo); atomicMax(&QS(ABZ_S_SEL_KMAX), hi); }
-  }
+  lo = qs_fat_min(lo, s_w);
+  if (threadIdx.x == 0) bmin[blockIdx.x] = lo;
 }
 
-/* pass 2.  Every block finds the bin of rank k0 itself (2048 counters from L2: cheaper than a launch). */
-__global__ __launch_bounds__(ABZ_BLOCK) void qs_compact_kernel(const double* __restrict__ delta,
-                                                               const uint8_t* __restrict__ alive, int64_t N,
-                                                               unsigned long long k0, const uint32_t* __restrict__ hist,
-                                                               unsigned long long* __restrict__ st,
-                                                               unsigned long long* __restrict__ buf) {
+/* pass 2.  Every block finds the bin of rank k0 itself (2048 counters from L2: cheaper than a launch); keys of that
+ * bin are staged in LDS and appended with one returning atomic per flush (same-address returning atomics cost ~30 ns
+ * each, serialised: hence one fat block per CU); smallest key of a higher bin -> babove[block].                     */
+__global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __restrict__ delta,
+                                                                const uint8_t* __restrict__ alive, int64_t N,
+                                                                unsigned long long k0, const uint32_t* __restrict__ hist,
+                                                                unsigned long long* __restrict__ st,
+                                                                unsigned long long* __restrict__ buf,
+                                                                unsigned long long* __restrict__ babove,
+                                                                uint32_t* __restrict__ hist2) {
   __shared__ unsigned long long s_buf[ABZ_QS_CAP];
-  __shared__ unsigned long long s_wsum[ABZ_BLOCK / 64];
+  __shared__ uint32_t s_h2[ABZ_QS_BINS];
+  __shared__ unsigned long long s_w[ABZ_QS_FAT / 64];
   __shared__ uint32_t s_n, s_bin;
   __shared__ unsigned long long s_base;
   const int t = threadIdx.x;
-  constexpr int PER = ABZ_QS_BINS / ABZ_BLOCK;         /* 8 consecutive bins per thread */
-  uint32_t h[PER];
-  unsigned long long mine = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) { h[j] = hist[t * PER + j]; mine += h[j]; }
+  const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];      /* 2 consecutive bins per thread */
+  const unsigned long long mine = (unsigned long long)h0 + h1;
   unsigned long long incl = mine;                      /* inclusive scan over the block */
   for (int off = 1; off < 64; off <<= 1) {
     const unsigned long long v = __shfl_up(incl, off, 64);
     if ((t & 63) >= off) incl += v;
   }
-  if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+  if ((t & 63) == 63) s_w[t >> 6] = incl;
   if (t == 0) { s_n = 0; s_bin = 0xFFFFFFFFu; }
+  s_h2[2 * t] = 0; s_h2[2 * t + 1] = 0;
   __syncthreads();
   unsigned long long before = incl - mine;
-  for (int w = 0; w < (t >> 6); ++w) before += s_wsum[w];
+  for (int w = 0; w < (t >> 6); ++w) before += s_w[w];
   if (k0 >= before && k0 < before + mine) {            /* exactly one thread, if k0 < total */
-    unsigned long long c = before;
-    int j = 0;
-    while (k0 >= c + h[j]) { c += h[j]; ++j; }
-    s_bin = (uint32_t)(t * PER + j);
-    if (blockIdx.x == 0) { QS(ABZ_S_SEL_K) = k0 - c; QS(ABZ_S_SEL_LESS) = c; QS(ABZ_S_SEL_PAD) = 0; }
+    const bool first = k0 < before + h0;
+    s_bin = (uint32_t)(2 * t + (first ? 0 : 1));
+    if (blockIdx.x == 0) {
+      QS(ABZ_S_SEL_BIN) = (unsigned long long)(2 * t + (first ? 0 : 1));
+      QS(ABZ_S_SEL_K) = k0 - (first ? before : before + h0);
+      QS(ABZ_S_SEL_LESS) = first ? before : before + h0;
+      QS(ABZ_S_SEL_PAD) = 0;
+    }
   }
-  if (blockIdx.x == 0 && t == ABZ_BLOCK - 1 && k0 >= before + mine) QS(ABZ_S_SEL_PAD) = 1;   /* rank beyond the population */
+  if (blockIdx.x == 0 && t == ABZ_QS_FAT - 1 && k0 >= before + mine) QS(ABZ_S_SEL_PAD) = 1;   /* rank beyond the population */
   __syncthreads();
   const uint32_t sel = s_bin;
-  if (sel == 0xFFFFFFFFu) return;
+  if (sel == 0xFFFFFFFFu) {
+    if (t == 0) babove[blockIdx.x] = ~0ull;
+    return;
+  }
   const unsigned long long klo = QS(ABZ_S_SEL_HLO);
   const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
+  const unsigned long long base2 = klo + ((unsigned long long)sel << shift);
+  const int s2 = shift > 11 ? shift - 11 : 0;
   unsigned long long above = ~0ull;
-  const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
+  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
   auto flush = [&]() {
     if (t == 0) s_base = atomicAdd(&QS(ABZ_S_SEL_NBUF), (unsigned long long)s_n);
     __syncthreads();
     const uint32_t n = s_n;
-    for (uint32_t q = t; q < n; q += ABZ_BLOCK) buf[s_base + q] = s_buf[q];
+    for (uint32_t q = t; q < n; q += ABZ_QS_FAT) buf[s_base + q] = s_buf[q];
     __syncthreads();
     if (t == 0) s_n = 0;
     __syncthreads();
   };
-  for (int64_t base = (int64_t)blockIdx.x * ABZ_BLOCK; base < N; base += 8 * stride) {     /* block-uniform trips */
-    unsigned long long key[8];
-    uint8_t al[8];
+  for (int64_t base = (int64_t)blockIdx.x * ABZ_QS_FAT; base < N; base += 4 * stride) {     /* block-uniform trips */
+    unsigned long long key[4];
+    uint8_t al[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int64_t k = base + t + u * stride;
       const bool in = k < N;
       key[u] = in ? abz_d2u(delta[k]) : 0ull;
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       if (!al[u]) continue;
       const uint32_t b = qs_bin(key[u], klo, shift);
       if (b > sel && key[u] < above) above = key[u];
-      if (b == sel) s_buf[atomicAdd(&s_n, 1u)] = key[u];                    /* room for 8 x 256 guaranteed */
+      if (b == sel) {
+        s_buf[atomicAdd(&s_n, 1u)] = key[u];                                /* room for 4 x 1024 guaranteed */
+        atomicAdd(&s_h2[qs_sub(key[u], base2, s2)], 1u);
+      }
     }
     __syncthreads();
-    if (s_n > ABZ_QS_CAP - 8 * ABZ_BLOCK) flush();                          /* s_n is block-uniform here */
+    if (s_n > ABZ_QS_CAP - 4 * ABZ_QS_FAT) flush();                         /* s_n is block-uniform here */
   }
   if (s_n) flush();
-  unsigned long long dummy = 0;
-  block_minmax_u64(above, dummy);
-  if (t == 0 && above != ~0ull) atomicMin(&QS(ABZ_S_SEL_ABOVE), above);
+  if (s_h2[2 * t]) atomicAdd(&hist2[2 * t], s_h2[2 * t]);
+  if (s_h2[2 * t + 1]) atomicAdd(&hist2[2 * t + 1], s_h2[2 * t + 1]);
+  above = qs_fat_min(above, s_w);
+  if (t == 0) babove[blockIdx.x] = above;
 }
 
 /* one block of 1024: sum / min / max over the block, result broadcast to every thread */
@@ -644,37 +656,98 @@ __device__ inline void qs_block_reduce(unsigned long long& cnt, unsigned long lo
   }
 }
 
+/* finish: rank k of the buffered bin, starting from the sub-histogram pass 2 took of it.  Rounds over the candidates (in LDS when they fit): count / min / max; all
+ * equal -> done; <= 64 left -> rank them against each other; else 2048 sub-bins of [min, max], keep the one holding
+ * the rank.  Every round strips 11 bits off the key range.                                                          */
 __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long* __restrict__ buf,
-                                                        unsigned long long* __restrict__ st, uint32_t* __restrict__ hist) {
+                                                        unsigned long long* __restrict__ st, uint32_t* __restrict__ hist,
+                                                        const unsigned long long* __restrict__ bmin,
+                                                        const unsigned long long* __restrict__ babove, int nblk,
+                                                        uint32_t* __restrict__ hist2) {
   __shared__ uint32_t s_h[ABZ_QS_BINS];
-  __shared__ unsigned long long s_cand[1024];
+  __shared__ unsigned long long s_keys[ABZ_QS_LDSKEYS];
+  __shared__ unsigned long long s_cand[64];
   __shared__ unsigned long long s_red[48];
   __shared__ unsigned long long s_pick[4];            /* bin | key, count before it, (rank branch) hit flag, #equal */
   __shared__ uint32_t s_n;
   const int t = threadIdx.x;
   for (int b = t; b < ABZ_QS_BINS; b += 1024) hist[b] = 0;               /* ready for the next call */
+  const uint32_t g0 = hist2[2 * t], g1 = hist2[2 * t + 1];
+  hist2[2 * t] = 0; hist2[2 * t + 1] = 0;
   const bool bad = QS(ABZ_S_SEL_PAD) != 0;
   const int64_t n = bad ? 0 : (int64_t)QS(ABZ_S_SEL_NBUF);
   unsigned long long k = QS(ABZ_S_SEL_K), less = QS(ABZ_S_SEL_LESS);
+  unsigned long long above = ~0ull, kmin = ~0ull;
+  for (int b = t; b < nblk; b += 1024) {
+    const unsigned long long a = babove[b], m = bmin[b];
+    above = a < above ? a : above;
+    kmin = m < kmin ? m : kmin;
+  }
   unsigned long long lo = 0ull, hi = ~0ull, key = 0ull, eq = 0ull;
+  if (t == 0) s_n = 0;
   bool found = false;
+  if (!bad) {                                          /* sub-bin of the rank: 11 key bits without touching a key */
+    unsigned long long mine = (unsigned long long)g0 + g1, incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long v = __shfl_up(incl, off, 64);
+      if ((t & 63) >= off) incl += v;
+    }
+    if ((t & 63) == 63) s_red[t >> 6] = incl;
+    __syncthreads();
+    unsigned long long before = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) before += s_red[w];
+    if (k >= before && k < before + mine) {
+      if (k < before + g0) { s_pick[0] = 2 * t; s_pick[1] = before; } else { s_pick[0] = 2 * t + 1; s_pick[1] = before + g0; }
+    }
+    __syncthreads();
+    const unsigned long long b2 = s_pick[0];
+    less += s_pick[1];
+    k -= s_pick[1];
+    const unsigned long long klo = QS(ABZ_S_SEL_HLO);
+    const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
+    const unsigned long long base2 = klo + (QS(ABZ_S_SEL_BIN) << shift);
+    const int s2 = shift > 11 ? shift - 11 : 0;
+    lo = b2 == 0 ? 0ull : base2 + (b2 << s2);
+    hi = b2 == ABZ_QS_BINS - 1 ? ~0ull : base2 + ((b2 + 1) << s2) - 1ull;
+  }
+  __syncthreads();
+  /* the one pass over the buffer in global memory: the sub-bin's keys -> LDS (normally a handful), smallest key
+   * beyond the sub-bin -> `above`.  Should they not fit, the rounds below read the whole buffer instead.        */
+  for (int64_t i0 = t; i0 < n; i0 += 4 * 1024) {
+    unsigned long long x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = i0 + u * 1024 < n ? buf[i0 + u * 1024] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * 1024 >= n) continue;
+      if (x[u] > hi) above = x[u] < above ? x[u] : above;
+      if (x[u] >= lo && x[u] <= hi) {
+        const uint32_t q = atomicAdd(&s_n, 1u);
+        if (q < ABZ_QS_LDSKEYS) s_keys[q] = x[u];
+      }
+    }
+  }
+  __syncthreads();
+  const bool in_lds = s_n <= ABZ_QS_LDSKEYS;
+  const unsigned long long* keys = in_lds ? s_keys : buf;
+  const int64_t nk = in_lds ? (int64_t)s_n : n;
+  __syncthreads();
   for (int round = 0; round < 16 && !bad; ++round) {
     unsigned long long cnt = 0, mn = ~0ull, mx = 0ull;
-    for (int64_t i = t; i < n; i += 1024) {
-      const unsigned long long x = buf[i];
+    for (int64_t i = t; i < nk; i += 1024) {
+      const unsigned long long x = keys[i];
       if (x >= lo && x <= hi) { ++cnt; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
     }
     qs_block_reduce(cnt, mn, mx, s_red);
     if (cnt == 0) break;                               /* cannot happen for k < count; reported as an error below */
     if (mn == mx) { key = mn; eq = cnt; found = true; break; }
-    if (cnt <= 1024) {
-      if (t == 0) s_n = 0;
+    if (cnt <= 64) {
+      if (t == 0) { s_n = 0; s_pick[2] = 0; }
       __syncthreads();
-      for (int64_t i = t; i < n; i += 1024) {
-        const unsigned long long x = buf[i];
+      for (int64_t i = t; i < nk; i += 1024) {
+        const unsigned long long x = keys[i];
         if (x >= lo && x <= hi) s_cand[atomicAdd(&s_n, 1u)] = x;
       }
-      if (t == 0) s_pick[2] = 0;
       __syncthreads();
       if (t < (int)cnt) {
         const unsigned long long me = s_cand[t];
@@ -691,8 +764,8 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     const int s = bl > 11 ? bl - 11 : 0;
     for (int b = t; b < ABZ_QS_BINS; b += 1024) s_h[b] = 0;
     __syncthreads();
-    for (int64_t i = t; i < n; i += 1024) {
-      const unsigned long long x = buf[i];
+    for (int64_t i = t; i < nk; i += 1024) {
+      const unsigned long long x = keys[i];
       if (x >= lo && x <= hi) atomicAdd(&s_h[(uint32_t)((x - mn) >> s)], 1u);
     }
     __syncthreads();
@@ -718,31 +791,26 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     __syncthreads();
   }
   /* smallest key strictly greater than the selected one: in the buffer, else the smallest key of a higher bin */
-  unsigned long long nxt = ~0ull, dc = 0, dm = 0;
+  unsigned long long nxt = above, dc = 0;
   if (found)
-    for (int64_t i = t; i < n; i += 1024) {
-      const unsigned long long x = buf[i];
+    for (int64_t i = t; i < nk; i += 1024) {
+      const unsigned long long x = keys[i];
       if (x > key && x < nxt) nxt = x;
     }
+  unsigned long long dm = 0, d0 = 0, d1 = 0;
   qs_block_reduce(dc, nxt, dm, s_red);
+  qs_block_reduce(d0, kmin, d1, s_red);
   if (t == 0) {
-    const unsigned long long above = QS(ABZ_S_SEL_ABOVE);
-    if (above < nxt) nxt = above;
     QS(ABZ_S_SEL_PREFIX) = key;
     QS(ABZ_S_SEL_LESS) = less;
     QS(ABZ_S_SEL_EQ) = eq;
     QS(ABZ_S_SEL_NEXT) = nxt;
     if (!found) QS(ABZ_S_SEL_PAD) = bad ? 1 : 2;
-    /* window of the next call: [smallest alive key seen, key of the next rank] */
-    const unsigned long long kmin = QS(ABZ_S_SEL_KMIN);
-    if (found) {
+    if (found) {       /* window of the next call: [smallest alive key seen, key of the next rank] */
       QS(ABZ_S_SEL_HLO) = kmin <= key ? kmin : key;
       QS(ABZ_S_SEL_HHI) = nxt != ~0ull ? nxt : key;
     }
     QS(ABZ_S_SEL_NBUF) = 0;
-    QS(ABZ_S_SEL_ABOVE) = ~0ull;
-    QS(ABZ_S_SEL_KMIN) = ~0ull;
-    QS(ABZ_S_SEL_KMAX) = 0ull;
   }
 }
 #undef QS
@@ -753,30 +821,32 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   if (rc) return rc;
   unsigned long long* buf = (unsigned long long*)ctx->ws;
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
-  if (!ctx->sel_hist) {
-    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, ABZ_QS_BINS * 4));
+  if (!ctx->sel_hist) {        /* histogram + sub-histogram (left zeroed by every call) + per-block minima of the two passes */
+    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, 2 * ABZ_QS_BINS * 4 + 2 * ABZ_QS_GRID * 8));
     ctx->sel_clean = false;
   }
+  uint32_t* hist2 = ctx->sel_hist + ABZ_QS_BINS;
+  unsigned long long* bmin = (unsigned long long*)(ctx->sel_hist + 2 * ABZ_QS_BINS);
+  unsigned long long* babove = bmin + ABZ_QS_GRID;
   const bool reseed = !ctx->sel_clean || ctx->sel_delta != delta || ctx->sel_alive != alive || ctx->sel_N != N;
-  unsigned pgrid = (unsigned)((N + 8 * ABZ_BLOCK - 1) / (8 * ABZ_BLOCK));
-  if (pgrid > 1024) pgrid = 1024;
   if (reseed) {
     /* device state of the select from scratch + window from a min / max pass */
     unsigned long long init[ABZ_S_SEL_END - ABZ_S_SEL_PREFIX] = {0};
-    init[ABZ_S_SEL_ABOVE - ABZ_S_SEL_PREFIX] = ~0ull;
-    init[ABZ_S_SEL_KMIN - ABZ_S_SEL_PREFIX] = ~0ull;
     init[ABZ_S_SEL_HLO - ABZ_S_SEL_PREFIX] = ~0ull;
     ABZ_HIP_CHECK(hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    ABZ_HIP_CHECK(hipMemsetAsync(ctx->sel_hist, 0, ABZ_QS_BINS * 4, ctx->stream));
-    hipLaunchKernelGGL(qs_minmax_kernel, dim3(pgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->sel_hist, 0, 2 * ABZ_QS_BINS * 4, ctx->stream));
+    unsigned mgrid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
+    if (mgrid > ABZ_REDUCE_GRID) mgrid = ABZ_REDUCE_GRID;
+    hipLaunchKernelGGL(qs_minmax_kernel, dim3(mgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
   }
   ctx->sel_clean = false;
-  unsigned hgrid = (unsigned)((N + 8 * ABZ_QS_HBLOCK - 1) / (8 * ABZ_QS_HBLOCK));
-  if (hgrid > 512) hgrid = 512;
-  hipLaunchKernelGGL(qs_hist_kernel, dim3(hgrid), dim3(ABZ_QS_HBLOCK), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist);
-  hipLaunchKernelGGL(qs_compact_kernel, dim3(pgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N,
-                     (unsigned long long)k0, ctx->sel_hist, st, buf);
-  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist);
+  unsigned grid = (unsigned)((N + 8 * ABZ_QS_FAT - 1) / (8 * ABZ_QS_FAT));
+  if (grid > ABZ_QS_GRID) grid = ABZ_QS_GRID;
+  hipLaunchKernelGGL(qs_hist_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist, bmin);
+  hipLaunchKernelGGL(qs_compact_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N,
+                     (unsigned long long)k0, ctx->sel_hist, st, buf, babove, hist2);
+  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist, bmin, babove, (int)grid,
+                     hist2);
   ABZ_HIP_CHECK(hipGetLastError());
   rc = read_scalars(ctx);
   if (rc) return rc;
@@ -882,7 +952,9 @@ int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double th
 }
 
 /* ================================================================ per-block counter partials -> two u64 sums
- * 64 blocks, one atomic pair per block (64 adds per address: negligible).                    */
+ * ABZ_CNT_PARTS blocks sum the (nacc, nsim) pairs the sweep's blocks stored and leave one pair each in the scalar
+ * area; the host adds them after the read-back it does anyway.  No atomics, so nothing has to be zeroed first
+ * (memset + atomic version: one more launch per sweep; a single summing block: 21 us for 46 K pairs).            */
 __global__ __launch_bounds__(ABZ_BLOCK) void reduce_partials_kernel(const uint2* __restrict__ partials, uint32_t n,
                                                                     unsigned long long* __restrict__ out) {
   __shared__ unsigned long long s_a[ABZ_BLOCK / 64], s_b[ABZ_BLOCK / 64];
@@ -897,20 +969,25 @@ __global__ __launch_bounds__(ABZ_BLOCK) void reduce_partials_kernel(const uint2*
   if (threadIdx.x == 0) {
     a = 0; b = 0;
     for (int w = 0; w < ABZ_BLOCK / 64; ++w) { a += s_a[w]; b += s_b[w]; }
-    if (a) atomicAdd(&out[0], a);
-    if (b) atomicAdd(&out[1], b);
+    out[2 * blockIdx.x] = a;
+    out[2 * blockIdx.x + 1] = b;
   }
 }
-int abz_reduce_partials(abcdez_ctx* ctx, const void* partials, uint32_t nblocks, unsigned long long* d_out) {
-  ABZ_HIP_CHECK(hipMemsetAsync(d_out, 0, 16, ctx->stream));
-  if (nblocks) {
-    unsigned grid = (nblocks + ABZ_BLOCK - 1) / ABZ_BLOCK;
-    if (grid > 64) grid = 64;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, (const uint2*)partials,
-                       nblocks, d_out);
-  }
+int abz_reduce_partials(abcdez_ctx* ctx, const void* partials, uint32_t nblocks, int part_slot) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ABZ_CNT_PARTS), dim3(ABZ_BLOCK), 0, ctx->stream, (const uint2*)partials,
+                     nblocks, ctx->d_scal + part_slot);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
+}
+/* after a read-back of the scalar area: NACC / NSIM and RACC / RSIM from their partial pairs */
+void abz_fold_counters(abcdez_ctx* ctx) {
+  const int slot[2] = {ABZ_S_PART_SWEEP, ABZ_S_PART_REPLAY}, dst[2] = {ABZ_S_NACC, ABZ_S_RACC};
+  for (int q = 0; q < 2; ++q) {
+    unsigned long long a = 0, b = 0;
+    for (int k = 0; k < ABZ_CNT_PARTS; ++k) { a += ctx->h_scal[slot[q] + 2 * k]; b += ctx->h_scal[slot[q] + 2 * k + 1]; }
+    ctx->h_scal[dst[q]] = a;
+    ctx->h_scal[dst[q] + 1] = b;
+  }
 }
 
 /* ================================================================ spec arithmetic on the device (test hook) */

@@ -106,7 +106,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   }
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_NACC);
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_SWEEP);
 }
 
 /* replay of the other ranks' accepted proposals on this rank's replica (abz_kernels.h) */
@@ -130,5 +130,5 @@ int abz_launch_smc_replay(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* 
   });
   if (!ok) { abz_set_error("smc_replay: unsupported layout"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ctx->d_scal + ABZ_S_RACC);
+  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_REPLAY);
 }
