@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where a generation's time goes: kernels vs idle gaps, from a rocprofv3 --kernel-trace csv.
 
-    python tools/timeline_gaps.py <kt_kernel_trace.csv> [marker kernel, default qs_hist_kernel] [generation index from the end]
+    python tools/timeline_gaps.py <kt_kernel_trace.csv> [marker kernel, default qs_hist_kernel] [generation index from the end] [lanes]
+
+With `lanes` (threads per particle of the sweep kernel) the sweep launches are listed with their alive count and rate.
 
 Generations are cut at the marker kernel (the first launch of every quantile).  Prints the launches of one
 steady-state generation (offset, duration, idle gap before it) and the averages over all complete generations
@@ -19,10 +21,13 @@ def main():
     path = sys.argv[1]
     marker = sys.argv[2] if len(sys.argv) > 2 else "qs_hist_kernel"
     which = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    rows = []
+    rows, sweeps = [], []
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+            if "smc_swarm_kernel" in r["Kernel_Name"]:
+                grid = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
+                sweeps.append((grid, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     cuts = [i for i, r in enumerate(rows) if marker in r[2]]
     gens = [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
@@ -51,6 +56,15 @@ def main():
         print(f"\n{n} generations: {tot / n:.1f} us each, kernels {busy / n:.1f} us, idle {(tot - busy) / n:.1f} us")
         for k, v in sorted(per.items(), key=lambda kv: -kv[1]):
             print(f"  {k:46s} {v / n:8.1f} us")
+
+
+    if sweeps and len(sys.argv) > 4:
+        # sweep kernel: rate against the number of alive particles (threads / lanes per particle)
+        lanes = int(sys.argv[4])
+        print("\nsweep launches: alive particles, us, updates/s, alive rows MB")
+        for grid, ns in sweeps:
+            n = grid // lanes
+            print(f"  {n:9d} {ns / 1e3:8.1f} {n / (ns * 1e-9):.3e} {n * 256 / 1e6:8.0f}")
 
 
 if __name__ == "__main__":
