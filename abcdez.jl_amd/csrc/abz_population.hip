@@ -554,6 +554,8 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
                                                                 unsigned long long* __restrict__ buf,
                                                                 unsigned long long* __restrict__ babove,
                                                                 uint32_t* __restrict__ hist2) {
+  /* babove[0 .. grid): smallest key above the bin; [grid .. 2 grid): smallest, [2 grid .. 3 grid): ~largest key IN the
+   * bin (stored complemented, so that one min-reduction serves all three) */
   __shared__ unsigned long long s_buf[ABZ_QS_CAP];
   __shared__ uint32_t s_h2[ABZ_QS_BINS];
   __shared__ unsigned long long s_w[ABZ_QS_FAT / 64];
@@ -587,14 +589,14 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   __syncthreads();
   const uint32_t sel = s_bin;
   if (sel == 0xFFFFFFFFu) {
-    if (t == 0) babove[blockIdx.x] = ~0ull;
+    if (t == 0) { babove[blockIdx.x] = ~0ull; babove[gridDim.x + blockIdx.x] = ~0ull; babove[2 * gridDim.x + blockIdx.x] = ~0ull; }
     return;
   }
   const unsigned long long klo = QS(ABZ_S_SEL_HLO);
   const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
   const unsigned long long base2 = klo + ((unsigned long long)sel << shift);
   const int s2 = shift > 11 ? shift - 11 : 0;
-  unsigned long long above = ~0ull;
+  unsigned long long above = ~0ull, inmin = ~0ull, inmaxc = ~0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
   auto flush = [&]() {
     if (t == 0) s_base = atomicAdd(&QS(ABZ_S_SEL_NBUF), (unsigned long long)s_n);
@@ -623,6 +625,8 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
       if (b == sel) {
         s_buf[atomicAdd(&s_n, 1u)] = key[u];                                /* room for 4 x 1024 guaranteed */
         atomicAdd(&s_h2[qs_sub(key[u], base2, s2)], 1u);
+        inmin = key[u] < inmin ? key[u] : inmin;
+        inmaxc = ~key[u] < inmaxc ? ~key[u] : inmaxc;
       }
     }
     __syncthreads();
@@ -633,6 +637,12 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   if (s_h2[2 * t + 1]) atomicAdd(&hist2[2 * t + 1], s_h2[2 * t + 1]);
   above = qs_fat_min(above, s_w);
   if (t == 0) babove[blockIdx.x] = above;
+  __syncthreads();
+  inmin = qs_fat_min(inmin, s_w);
+  if (t == 0) babove[gridDim.x + blockIdx.x] = inmin;
+  __syncthreads();
+  inmaxc = qs_fat_min(inmaxc, s_w);
+  if (t == 0) babove[2 * gridDim.x + blockIdx.x] = inmaxc;
 }
 
 /* one block of 1024: sum / min / max over the block, result broadcast to every thread */
@@ -678,15 +688,25 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   const int64_t n = bad ? 0 : (int64_t)QS(ABZ_S_SEL_NBUF);
   unsigned long long k = QS(ABZ_S_SEL_K), less = QS(ABZ_S_SEL_LESS);
   unsigned long long above = ~0ull, kmin = ~0ull;
+  unsigned long long binmin = ~0ull, binmax = 0ull;       /* smallest / largest key of the selected bin */
   for (int b = t; b < nblk; b += 1024) {
-    const unsigned long long a = babove[b], m = bmin[b];
+    const unsigned long long a = babove[b], m = bmin[b], i0 = babove[nblk + b], i1 = babove[2 * nblk + b];
     above = a < above ? a : above;
     kmin = m < kmin ? m : kmin;
+    binmin = i0 < binmin ? i0 : binmin;
+    binmax = ~i1 > binmax ? ~i1 : binmax;
   }
   unsigned long long lo = 0ull, hi = ~0ull, key = 0ull, eq = 0ull;
   if (t == 0) s_n = 0;
   bool found = false;
-  if (!bad) {                                          /* sub-bin of the rank: 11 key bits without touching a key */
+  {
+    unsigned long long dcnt = 0;
+    qs_block_reduce(dcnt, binmin, binmax, s_red);
+  }
+  /* the whole bin is one key value (tied / discrete distances): nothing to search, the buffer is not even read */
+  const bool one_value = !bad && n > 0 && binmin == binmax;
+  if (one_value) { key = binmin; eq = (unsigned long long)n; found = true; }
+  if (!bad && !one_value) {                            /* sub-bin of the rank: 11 key bits without touching a key */
     unsigned long long mine = (unsigned long long)g0 + g1, incl = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned long long v = __shfl_up(incl, off, 64);
@@ -713,7 +733,8 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   __syncthreads();
   /* the one pass over the buffer in global memory: the sub-bin's keys -> LDS (normally a handful), smallest key
    * beyond the sub-bin -> `above`.  Should they not fit, the rounds below read the whole buffer instead.        */
-  for (int64_t i0 = t; i0 < n; i0 += 4 * 1024) {
+  unsigned long long cmin = ~0ull, cmax = 0ull;
+  for (int64_t i0 = t; i0 < (one_value ? 0 : n); i0 += 4 * 1024) {
     unsigned long long x[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) x[u] = i0 + u * 1024 < n ? buf[i0 + u * 1024] : 0ull;
@@ -724,15 +745,23 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
       if (x[u] >= lo && x[u] <= hi) {
         const uint32_t q = atomicAdd(&s_n, 1u);
         if (q < ABZ_QS_LDSKEYS) s_keys[q] = x[u];
+        cmin = x[u] < cmin ? x[u] : cmin;
+        cmax = x[u] > cmax ? x[u] : cmax;
       }
     }
   }
-  __syncthreads();
+  {
+    unsigned long long dcnt = 0;
+    qs_block_reduce(dcnt, cmin, cmax, s_red);      /* (its barriers also publish s_n and s_keys) */
+  }
+  /* the sub-bin is one key value (an atom of a discrete distance among others): done, however many copies there are */
+  const bool one_cand = !bad && !one_value && s_n > 0 && cmin == cmax;
+  if (one_cand) { key = cmin; eq = (unsigned long long)s_n; found = true; }
   const bool in_lds = s_n <= ABZ_QS_LDSKEYS;
   const unsigned long long* keys = in_lds ? s_keys : buf;
   const int64_t nk = in_lds ? (int64_t)s_n : n;
   __syncthreads();
-  for (int round = 0; round < 16 && !bad; ++round) {
+  for (int round = 0; round < 16 && !bad && !one_value && !one_cand; ++round) {
     unsigned long long cnt = 0, mn = ~0ull, mx = 0ull;
     for (int64_t i = t; i < nk; i += 1024) {
       const unsigned long long x = keys[i];
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   }
   /* smallest key strictly greater than the selected one: in the buffer, else the smallest key of a higher bin */
   unsigned long long nxt = above, dc = 0;
-  if (found)
+  if (found && !one_value && !one_cand)
     for (int64_t i = t; i < nk; i += 1024) {
       const unsigned long long x = keys[i];
       if (x > key && x < nxt) nxt = x;
@@ -822,7 +851,7 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   unsigned long long* buf = (unsigned long long*)ctx->ws;
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
   if (!ctx->sel_hist) {        /* histogram + sub-histogram (left zeroed by every call) + per-block minima of the two passes */
-    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, 2 * ABZ_QS_BINS * 4 + 2 * ABZ_QS_GRID * 8));
+    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, 2 * ABZ_QS_BINS * 4 + 4 * ABZ_QS_GRID * 8));
     ctx->sel_clean = false;
   }
   uint32_t* hist2 = ctx->sel_hist + ABZ_QS_BINS;
