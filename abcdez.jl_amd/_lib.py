@@ -58,6 +58,7 @@ PROTOTYPES = {
                         _pi64],
     "abcdez_push_p": [_vp, _vp, _i64, _vp],
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
+    "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
 # symbols with a non-status return type
 OTHER_SYMBOLS = ("abcdez_version", "abcdez_last_error")

@@ -19,6 +19,7 @@ int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
 int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, uint32_t*, double*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
+int abz_draws_eval_impl(abcdez_ctx*, int, uint32_t, uint32_t, uint32_t, uint32_t, double, double, uint32_t*, uint32_t*, double*, double*);
 
 static thread_local std::string g_err;
 void abz_set_error(const std::string& msg) { g_err = msg; }
@@ -532,8 +533,16 @@ int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) 
 
 int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
   ABZ_REQUIRE(ctx && x && y, "math_eval: null argument");
-  ABZ_REQUIRE(fn >= 0 && fn <= 10 && (y2 || (fn != 2 && fn != 6 && fn != 8)), "math_eval: bad function id / missing second array");
+  ABZ_REQUIRE(fn >= 0 && fn <= 11 && (y2 || (fn != 2 && fn != 6 && fn != 8 && fn != 11)), "math_eval: bad function id / missing second array");
   return abz_math_eval_impl(ctx, fn, x, y, y2, n);
+}
+
+int abcdez_draws_eval(abcdez_ctx* ctx, int lanes, int64_t i0, int64_t n, int64_t n_pool, uint32_t sweep, double gamma0,
+                      double gamma_sigma, uint32_t* ra, uint32_t* rb, double* gamma, double* log_u) {
+  ABZ_REQUIRE(ctx && ra && rb && gamma && log_u, "draws_eval: null argument");
+  ABZ_REQUIRE(i0 >= 0 && n >= 0 && n_pool >= 3 && i0 + n <= n_pool && n_pool <= ABZ_MAX_N, "draws_eval: range out of bounds");
+  return abz_draws_eval_impl(ctx, lanes, (uint32_t)i0, (uint32_t)n, (uint32_t)n_pool, sweep, gamma0, gamma_sigma, ra, rb,
+                             gamma, log_u);
 }
 
 } /* extern "C" */

@@ -1021,6 +1021,7 @@ void abz_fold_counters(abcdez_ctx* ctx) {
 
 /* ================================================================ spec arithmetic on the device (test hook) */
 __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_tables* __restrict__ T,
+                                                              const abz_model* __restrict__ M,
                                                               const double* __restrict__ x, double* __restrict__ y,
                                                               double* __restrict__ y2, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x;
@@ -1036,13 +1037,59 @@ __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_
     case 8: { double s, c; abz_sincos2pi_tab(x[i], T, &s, &c); y[i] = s; y2[i] = c; break; }
     case 9: y[i] = abz_sqrt_pn(x[i]); break;
     case 10: y[i] = abz_lgamma(x[i]); break;
+    case 11: y[i] = abz_prior_logpdf1(&M->prior[(int)y2[i]], x[i]); break;   /* log-density of prior factor y2[i] at x[i] */
     default: y[i] = x[i] / y2[i]; break;
   }
 }
 int abz_math_eval_impl(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)((n + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
-                     ctx->stream, fn, ctx->d_tables, x, y, y2, n);
+                     ctx->stream, fn, ctx->d_tables, ctx->d_model, x, y, y2, n);
+  ABZ_HIP_CHECK(hipGetLastError());
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+/* ================================================================ per-particle scalar draws of a sweep (test hook)
+ * Runs particle_draws<L> (abz_device.h) -- the code the sweep / replay kernels call -- for particles
+ * [i0, i0+n) with alive rank = particle index in a pool of n_pool, for any lane-group width L, so that the
+ * tests can check bit for bit that (donor ranks, gamma, log u) do not depend on the lane shape (smc:119-128,145). */
+template <int L>
+__global__ __launch_bounds__(ABZ_BLOCK) void draws_eval_kernel(const HotModel M, uint32_t i0, uint32_t n, uint32_t n_pool,
+                                                               uint32_t sweep, double gamma0, double gsig,
+                                                               uint32_t* __restrict__ ra, uint32_t* __restrict__ rb,
+                                                               double* __restrict__ g, double* __restrict__ log_u) {
+  __shared__ abz_tables s_tab;
+  {
+    TabStage st;
+    st.load(M);
+    st.store(s_tab);
+  }
+  __syncthreads();
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < n;                       /* inactive groups still take part in the group shuffles */
+  const uint32_t i = i0 + (active ? grp : 0u);
+  uint32_t a, b;
+  double gg, lu;
+  particle_draws<L>(&s_tab, M.seed, i, sweep, j, n_pool, i, gamma0, gsig, &a, &b, &gg, &lu);
+  if (active && j == 0) { ra[grp] = a; rb[grp] = b; g[grp] = gg; log_u[grp] = lu; }
+}
+int abz_draws_eval_impl(abcdez_ctx* ctx, int lanes, uint32_t i0, uint32_t n, uint32_t n_pool, uint32_t sweep,
+                        double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g, double* log_u) {
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)(((uint64_t)n * (uint64_t)lanes + ABZ_BLOCK - 1) / ABZ_BLOCK);
+#define ABZ_DRAWS(LL)                                                                                                    \
+  case LL:                                                                                                               \
+    hipLaunchKernelGGL((draws_eval_kernel<LL>), dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, ctx->hot, i0, n, n_pool,    \
+                       sweep, gamma0, gsig, ra, rb, g, log_u);                                                           \
+    break;
+  switch (lanes) {
+    ABZ_DRAWS(1) ABZ_DRAWS(2) ABZ_DRAWS(4) ABZ_DRAWS(8) ABZ_DRAWS(16)
+    default: abz_set_error("draws_eval: lanes must be 1, 2, 4, 8 or 16"); return -1;
+  }
+#undef ABZ_DRAWS
   ABZ_HIP_CHECK(hipGetLastError());
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;

@@ -244,6 +244,11 @@ class HipOps:
     def math_eval(self, fn, x, y, y2=None):
         _lib.check(self.lib, self.lib.abcdez_math_eval(self.ctx, fn, _ptr(x), _ptr(y), _ptr(y2), x.numel()))
 
+    def draws_eval(self, lanes, i0, n_pool, sweep, gamma0, gsig, ra, rb, g, log_u):
+        """test hook: the sweep kernels' per-particle draws for a lane-group width of ``lanes``"""
+        _lib.check(self.lib, self.lib.abcdez_draws_eval(self.ctx, lanes, i0, ra.numel(), n_pool, sweep, gamma0, gsig,
+                                                        _ptr(ra), _ptr(rb), _ptr(g), _ptr(log_u)))
+
 
 class PopulationEngine:
     """Device-resident population + the reference's per-generation functions."""

@@ -1,14 +1,14 @@
 """The four unnormalised ABC kernels (reference: src/abcdez_types.jl:26-73).
 
 Host-side value types; the device evaluates the same truth table from the kernel id
-(csrc/abcdez_spec.h, ``abz_kernel_*``).  ``ABCk`` keyword of :func:`abcdesmc` takes
+(include/abcdez_spec.h, ``abz_kernel_*``).  ``ABCk`` keyword of :func:`abcdesmc` takes
 one of these classes, exactly like the reference (src/abcdez_smc.jl:218).
 """
 from __future__ import annotations
 
 import math
 
-# ids -- keep in sync with csrc/abcdez_spec.h (ABZ_K_*)
+# ids -- keep in sync with include/abcdez_spec.h (ABZ_K_*)
 K_INDICATOR, K_INDICATOR_STRICT, K_EPA, K_EPA_STRICT = 0, 1, 2, 3
 
 

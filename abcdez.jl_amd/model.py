@@ -1,4 +1,4 @@
-"""ctypes mirror of ``abz_model`` (csrc/abcdez_spec.h) and its builder.
+"""ctypes mirror of ``abz_model`` (include/abcdez_spec.h) and its builder.
 
 The model descriptor is what the reference passes around as
 ``(prior, dist!, varexternal, rng)`` plus the ``ABCk`` keyword

@@ -12,7 +12,7 @@ import math
 from dataclasses import dataclass
 from typing import Sequence, Tuple, Union
 
-# family ids -- keep in sync with csrc/abcdez_spec.h (ABZ_PRIOR_*)
+# family ids -- keep in sync with include/abcdez_spec.h (ABZ_PRIOR_*)
 PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM, PRIOR_BETA, PRIOR_NEGBIN = 0, 1, 2, 3, 4, 5
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)

@@ -4,7 +4,7 @@ The reference calls an arbitrary Julia closure ``dist!(θ, ve) -> (d, blob)``
 (src/abcdez_smc.jl:137, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17).  A closure
 cannot run on the GPU, so the drop-in dispatches on a :class:`DeviceSimulator`
 marker that selects one of the built-in on-device simulators (ids and exact
-arithmetic: csrc/abcdez_spec.h, ``ABZ_SIM_*``).
+arithmetic: include/abcdez_spec.h, ``ABZ_SIM_*``).
 
 ``blob`` -- the second return value, "arbitrary data stored to each particle, e.g. the actual
 simulation output" (docs/src/index.md:298-324) -- is ``None`` by default, as in every reference
@@ -27,7 +27,7 @@ class DeviceSimulator:
     blobs = False
 
     def blob_size(self, d: int) -> int:
-        """doubles per blob when ``blobs`` is on (abz_sim_blob_size, csrc/abcdez_spec.h)"""
+        """doubles per blob when ``blobs`` is on (abz_sim_blob_size, include/abcdez_spec.h)"""
         return 1
 
     def params(self) -> Tuple[float, ...]:

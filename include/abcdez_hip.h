@@ -193,9 +193,17 @@ ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const dou
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);
 
 /* Test hooks: evaluate the spec arithmetic on the device (fn: 0 log, 1 exp, 2 sincos2pi,
- * 3 rint, 4 floor, 5 sqrt, 6 x/y2, 7 table log, 8 table sincos2pi, 9 sqrt_pn).       */
+ * 3 rint, 4 floor, 5 sqrt, 6 x/y2, 7 table log, 8 table sincos2pi, 9 sqrt_pn, 10 lgamma,
+ * 11 log-density of the context's prior factor (int)y2[i] at x[i], src/abcdez_priors.jl:41-45). */
 ABCDEZ_API int abcdez_math_eval(abcdez_ctx* ctx, int fn, const double* x, double* y, double* y2, int64_t n);
 ABCDEZ_API int abcdez_tree_sum(abcdez_ctx* ctx, const double* x, int64_t n, double* out);
+/* Test hook: the per-particle scalar draws of one sweep -- donor ranks (src/abcdez_smc.jl:119-126), gamma =
+ * gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) of the accept test (smc:145) -- of particles [i0, i0+n) with
+ * alive rank = index in a pool of n_pool, evaluated by the sweep kernels' own routine for a lane-group width of
+ * `lanes` (1, 2, 4, 8, 16).  The results must not depend on `lanes`.                                      */
+ABCDEZ_API int abcdez_draws_eval(abcdez_ctx* ctx, int lanes, int64_t i0, int64_t n, int64_t n_pool, uint32_t sweep,
+                                 double gamma0, double gamma_sigma, uint32_t* ra, uint32_t* rb, double* gamma,
+                                 double* log_u);
 
 #ifdef __cplusplus
 }

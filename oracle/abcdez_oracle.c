@@ -39,7 +39,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../abcdez.jl_amd/csrc/abcdez_spec.h"
+#include "../include/abcdez_spec.h"
 
 #define ORC_API __attribute__((visibility("default")))
 #define ORC_MAX_RETRY 100000u
@@ -81,6 +81,20 @@ ORC_API void orc_normal_pairs(uint64_t seed, uint32_t purpose, int64_t n, double
 ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_t ri, uint32_t* ra, uint32_t* rb) {
   abz_u64x2 w; w.w0 = w0; w.w1 = w1;
   abz_donor_ranks(w, n_alive, ri, ra, rb);
+}
+/* the per-particle scalar draws of one sweep, straightforward evaluation (checker of abcdez_draws_eval):
+ * donors smc:119-126, gamma smc:128, log(rand) smc:145; alive rank of particle i = i in a pool of n_pool */
+ORC_API void orc_particle_draws(uint64_t seed, int64_t i0, int64_t n, int64_t n_pool, uint32_t sweep, double gamma0,
+                                double gsig, uint32_t* ra, uint32_t* rb, double* g, double* log_u) {
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < n; ++k) {
+    const uint32_t i = (uint32_t)(i0 + k);
+    abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)n_pool, i, &ra[k], &rb[k]);
+    double z0, z1;
+    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
+    g[k] = gamma0 * (1.0 + z0 * gsig);
+    log_u[k] = abz_log_tab(abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T);
+  }
 }
 ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w, n); }
 ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : (kind == 2 ? abz_u01_52(w) : abz_u01_co(w)); }

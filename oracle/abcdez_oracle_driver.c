@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../abcdez.jl_amd/csrc/abcdez_spec.h"
+#include "../include/abcdez_spec.h"
 
 #define ORC_API __attribute__((visibility("default")))
 

@@ -76,6 +76,7 @@ def lib():
     L.orc_randint.restype = _u32
     L.orc_randint.argtypes = [_u64, _u32]
     L.orc_math_eval.argtypes = [C.c_int, _vp, _vp, _vp, _i64]
+    L.orc_particle_draws.argtypes = [_u64, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp]
     L.orc_rng_words.argtypes = [_u64, _u32, _u32, _u32, _u32, _vp]
     L.orc_normal_pairs.argtypes = [_u64, _u32, _i64, _vp]
     L.orc_push_p.argtypes = [_vp, _vp, _i64, _vp]
@@ -265,6 +266,10 @@ class OracleOps:
 
     def math_eval(self, fn, x, y, y2=None):
         self.L.orc_math_eval(fn, _p(x), _p(y), _p(y2), x.numel())
+
+    def draws_eval(self, lanes, i0, n_pool, sweep, gamma0, gsig, ra, rb, g, log_u):
+        self.L.orc_particle_draws(self.spec.seed, i0, ra.numel(), n_pool, sweep, gamma0, gsig, _p(ra), _p(rb), _p(g),
+                                  _p(log_u))
 
 
 def oracle_engine(spec, nparticles, process_group=None, storage="classic"):

@@ -30,7 +30,10 @@ def checksum(t: torch.Tensor) -> int:
 def lv_model():
     g = json.load(open(os.path.join(GOLD_DIR, "lv_data.json")))
     prior = A.Factored(*[A.Uniform(0.0, 2.0)] * 4)
-    sim = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=0.05, steps_per_obs=20, noise=g["noise"])
+    # the fixture's own resolution = BASELINE.json configs[3] / SURVEY.md 8d-4: RK4 dt = 0.01, 100 steps between the
+    # 16 observation times (T = 15, 1500 steps per particle-update)
+    sim = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=g["dt"], steps_per_obs=g["steps_per_obs"],
+                             noise=g["noise"])
     return prior, sim
 
 
@@ -82,6 +85,65 @@ def test_lotka_volterra_end_to_end(oracle):
     assert r.logZ == c["logZ"] and np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["alive"], c["alive"])
     post = r.P[r.Wns > 0]
     assert np.all(np.abs(post.mean(0) - np.array([1.0, 0.4, 1.0, 0.3])) < 0.1)
+
+
+def test_config4_lotka_volterra_full_size_properties_and_oracle_spot_checks(oracle):
+    """BASELINE.json configs[3] at its stated workload on one GPU: Lotka-Volterra RK4, dt = 0.01, 1500 steps per
+    particle-update, N = 2^20.  Whole-population properties every generation; one more sweep replayed bit for bit
+    by the oracle for three 4096-particle ranges from the same full input state; the initial population's first
+    and last 2048 particles (prior draws, redraws of blown-up trajectories, first distances) against the oracle."""
+    prior, sim = lv_model()
+    assert sim.dt == 0.01 and sim.steps_per_obs == 100 and len(sim.obs) == 32
+    N, d = 1 << 20, 4
+    spec = A.ModelSpec(prior, sim, seed=11)
+    eng = PopulationEngine(spec, N, ops=HipOps(spec), storage="classic")
+    eng.init_population()
+    th0, lp0, dl0 = (t.cpu() for t in eng.state)
+    assert torch.isfinite(dl0).all() and torch.isfinite(lp0).all()                       # init.jl:14
+    assert bool(((th0[:, :d] >= 0.0) & (th0[:, :d] <= 2.0)).all())                      # Uniform(0, 2) support
+    m = oracle.OracleModel(spec)
+    for i0 in (0, N - 2048):
+        oth, olp, odl = torch.zeros_like(th0), torch.zeros_like(lp0), torch.zeros_like(dl0)
+        assert oracle.lib().orc_init(m.ptr, oth.data_ptr(), olp.data_ptr(), odl.data_ptr(), i0, 2048) == 0
+        sl = slice(i0, i0 + 2048)
+        assert torch.equal(oth[sl].view(torch.int64), th0[sl].view(torch.int64))
+        assert torch.equal(odl[sl].view(torch.int64), dl0[sl].view(torch.int64))
+        assert torch.equal(olp[sl].view(torch.int64), lp0[sl].view(torch.int64))
+    eng.reset_weights()
+    loop = Loop(eng, d, 1.0)
+    chk = Checks(oracle, spec, deep=True)
+    for gen in range(3):
+        loop.generation(chk)
+    assert loop.eps < float(dl0.max())
+    eps = loop.eps
+    th, lp, dl = (t.cpu().contiguous() for t in eng.state)
+    aidx, arank = eng.alive_idx.cpu().contiguous(), eng.arank.cpu().contiguous()
+    n_alive, sweep = eng.n_alive, eng.sweep
+    nacc_all, nsim_all = eng.smc_swarm(eps, loop.g0, 1e-5)
+    assert 0 < nacc_all <= nsim_all <= n_alive and nsim_all < n_alive                   # bounded prior: some proposals fall outside
+    nth, nlp, ndl = torch.zeros_like(th), torch.zeros_like(lp), torch.zeros_like(dl)
+    for i0 in (0, N // 2 - 2048, N - 4096):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        oracle.lib().orc_smc_swarm(m.ptr, aidx.data_ptr(), arank.data_ptr(), n_alive, th.data_ptr(), lp.data_ptr(),
+                                   dl.data_ptr(), nth.data_ptr(), nlp.data_ptr(), ndl.data_ptr(), eps, loop.g0, 1e-5,
+                                   i0, 4096, sweep, C.byref(nacc), C.byref(nsim))
+        sl = slice(i0, i0 + 4096)
+        got = [t[sl].cpu() for t in eng.state]
+        assert torch.equal(got[0].view(torch.int64), nth[sl].view(torch.int64))
+        assert torch.equal(got[1].view(torch.int64), nlp[sl].view(torch.int64))
+        assert torch.equal(got[2].view(torch.int64), ndl[sl].view(torch.int64))
+        assert nacc.value == int((got[2] != dl[sl]).sum()) or abs(nacc.value - int((got[2] != dl[sl]).sum())) <= 1
+    # the row store (the default storage of abcdesmc) gives the same population as the double buffer
+    e2 = PopulationEngine(spec, N, ops=HipOps(spec), storage="rows")
+    e2.init_population()
+    e2.reset_weights()
+    l2 = Loop(e2, d, 1.0)
+    for gen in range(3):
+        l2.generation(Checks(oracle, spec, deep=False))
+    e2.smc_swarm(l2.eps, l2.g0, 1e-5)
+    assert l2.eps == loop.eps and l2.logZ == loop.logZ
+    for k in range(3):
+        assert checksum(e2.state[k]) == checksum(eng.state[k])
 
 
 def test_spec_vectors_on_gpu():

@@ -1,4 +1,4 @@
-"""Pins the shared arithmetic spec (abcdez.jl_amd/csrc/abcdez_spec.h) against independent
+"""Pins the shared arithmetic spec (include/abcdez_spec.h) against independent
 references: published Philox known-answer vectors + a pure-Python Philox, and mpmath /
 numpy for the elementary functions.  CPU only."""
 import ctypes as C
