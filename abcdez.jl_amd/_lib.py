@@ -53,9 +53,9 @@ PROTOTYPES = {
     "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _i64, _f64, _pf64, _pf64, _pf64],
     "abcdez_extrema": [_vp, _vp, _i64, _pf64, _pf64],
     "abcdez_count_gt": [_vp, _vp, _i64, _f64, _pi64],
-    "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _vp, _vp],
+    "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _f64, _f64, _vp, _vp],
     "abcdez_mc_swarm": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64, _u32,
-                        _pi64],
+                        _pi64, _pi64, _pf64, _pf64],
     "abcdez_push_p": [_vp, _vp, _i64, _vp],
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],

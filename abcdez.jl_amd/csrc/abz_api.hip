@@ -17,7 +17,7 @@ int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
 int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
-int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, uint32_t*, double*);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_draws_eval_impl(abcdez_ctx*, int, uint32_t, uint32_t, uint32_t, uint32_t, double, double, uint32_t*, uint32_t*, double*, double*);
 
@@ -41,18 +41,6 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
   const size_t want = abz_align(bytes + bytes / 4, 1 << 20);
   ABZ_HIP_CHECK(hipMalloc(&ctx->ws, want));
   ctx->ws_bytes = want;
-  return 0;
-}
-
-int abz_cnt_reserve(abcdez_ctx* ctx, size_t nblocks) {
-  const size_t bytes = nblocks * 8;
-  if (bytes <= ctx->cnt_bytes) return 0;
-  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  if (ctx->cnt) ABZ_HIP_CHECK(hipFree(ctx->cnt));
-  ctx->cnt = nullptr; ctx->cnt_bytes = 0;
-  const size_t want = abz_align(bytes + bytes / 4, 1 << 16);
-  ABZ_HIP_CHECK(hipMalloc(&ctx->cnt, want));
-  ctx->cnt_bytes = want;
   return 0;
 }
 
@@ -134,6 +122,11 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.n_blob = model->n_blob;
   ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
   ABZ_HIP_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
+  {   /* both min / max banks start empty: (min key, max key) = (~0, 0) */
+    unsigned long long mm[2 * ABZ_MMSLOTS * 2];
+    for (int k = 0; k < 2 * ABZ_MMSLOTS * 2; ++k) mm[k] = (k & 1) ? 0ull : ~0ull;
+    ABZ_HIP_CHECK(hipMemcpy(ctx->d_scal + ABZ_S_MM0, mm, sizeof(mm), hipMemcpyHostToDevice));
+  }
   ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
   if (user_source) {
     const int rc = abz_jit_build(ctx, user_source);
@@ -159,7 +152,6 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   abz_jit_destroy(ctx);
   if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
   if (ctx->ws) (void)hipFree(ctx->ws);
-  if (ctx->cnt) (void)hipFree(ctx->cnt);
   if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
@@ -319,7 +311,7 @@ int abcdez_smc_swarm_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* 
   ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows: the two slots / alive lists must differ");
   int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, logpi, delta,
                                 slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
-                                alive_row_out, nullptr);
+                                alive_row_out, nullptr, 1);
   if (rc) return rc;
   rc = read_counters(ctx);
   if (rc) return rc;
@@ -342,7 +334,7 @@ int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint
   ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows_shard: the two slots / alive lists must differ");
   int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, logpi,
                                 delta, slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
-                                alive_row_out, accepted);
+                                alive_row_out, accepted, nacc != nullptr);
   if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_rows reports totals) */
   rc = read_counters(ctx);
   if (rc) return rc;
@@ -411,7 +403,7 @@ int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t*
                                 (uint32_t)n_local, copy_dead, dead_synced, sweep,
                                 /* alive list is the identity iff every particle of a range starting at 0 is alive */
                                 (i0 == 0 && r_lo == 0 && r_hi == n_alive && n_alive == n_local) ? (uint32_t)n_alive : 0u,
-                                nullptr, nullptr);
+                                nullptr, nullptr, 1);
   if (rc) return rc;
   rc = read_counters(ctx);
   if (rc) return rc;
@@ -501,16 +493,18 @@ int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr,
   return abz_count_gt_impl(ctx, delta, N, thr, count);
 }
 
-int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta) {
+int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
+                           uint32_t* order, double* sorted_delta) {
   ABZ_REQUIRE(ctx && delta && order && sorted_delta, "mc_rank_prepare: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
-  return abz_rank_prepare_impl(ctx, delta, N, order, sorted_delta);
+  ABZ_REQUIRE(eps_pop == eps_pop, "mc_rank_prepare: eps_pop is NaN");
+  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta);
 }
 
 int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N, const double* theta,
                     const double* logpi, const double* delta, double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma, int64_t i0, int64_t n_local,
-                    uint32_t sweep, int64_t* nsim) {
+                    uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax) {
   ABZ_REQUIRE(ctx && order && sorted_delta && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
               "mc_swarm: null argument");
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
@@ -519,9 +513,18 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted
   int rc = abz_launch_mc_swarm(ctx, order, sorted_delta, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
                                eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep);
   if (rc) return rc;
+  const int bank = ctx->mm_bank;
+  if (n_local > 0) ctx->mm_bank = 1 - bank;          /* the kernel reset the other bank for the next sweep */
   rc = read_counters(ctx);
   if (rc) return rc;
-  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_COUNT];
+  if (n_above_target) *n_above_target = (int64_t)ctx->h_scal[ABZ_S_MCGT];
+  if (dmin || dmax) {
+    double lo = ABZ_INF, hi = ABZ_NINF;
+    if (n_local > 0) abz_fold_minmax(ctx, bank, &lo, &hi);
+    if (dmin) *dmin = lo;
+    if (dmax) *dmax = hi;
+  }
   return 0;
 }
 

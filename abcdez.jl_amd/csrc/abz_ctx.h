@@ -34,9 +34,10 @@ struct abcdez_ctx {
   const void* sel_delta = nullptr;
   const void* sel_alive = nullptr;
   int64_t sel_N = 0;
-  /* per-block (nacc, nsim) partials of the sweep kernels */
-  void* cnt = nullptr;
-  size_t cnt_bytes = 0;
+  /* running totals of the cumulative counter slots at the last read-back (ABZ_S_CSLOT0), by counter class */
+  unsigned long long cnt_prev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  /* min / max slot bank the NEXT abcdemc sweep reduces into (the sweep resets the other one) */
+  int mm_bank = 0;
   /* blob stamps of the current / next generation (abcdez_ctx_set_stamps); null = blobs off.  The launchers that
    * take (logpi, nlogpi)-style pairs use (stamp_cur, stamp_nxt) alongside; row-store calls update stamp_cur in place */
   uint64_t* stamp_cur = nullptr;
@@ -61,7 +62,6 @@ void abz_set_error(const std::string& msg);
 
 /* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
-int abz_cnt_reserve(abcdez_ctx* ctx, size_t nblocks);
 
 static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -77,12 +77,17 @@ enum {
   ABZ_S_SEL_END = 20,
   ABZ_S_INITBAD = 20,
   ABZ_S_RACC = 21, ABZ_S_RSIM = 22,      /* counters of the replayed ranks (sharded row store) */
+  ABZ_S_MCGT = 23, ABZ_S_MCMIN = 24, ABZ_S_MCMAX = 25,   /* abcdemc sweep: #(Ds > eps_target), extrema of the new distances */
   ABZ_S_SCALARS = 32,
-  /* (nacc, nsim) partial pairs of the sweep / replay kernels' blocks, summed by the host after the read-back:
-   * ABZ_CNT_PARTS pairs for the sweep (-> ABZ_S_NACC / NSIM), then as many for the replay (-> ABZ_S_RACC / RSIM) */
-  ABZ_CNT_PARTS = 16,
-  ABZ_S_PART_SWEEP = ABZ_S_SCALARS, ABZ_S_PART_REPLAY = ABZ_S_PART_SWEEP + 2 * ABZ_CNT_PARTS,
-  ABZ_S_N = ABZ_S_PART_REPLAY + 2 * ABZ_CNT_PARTS
+  /* Sweep counters (smc:138,150,352; mc:44,156): every block of a sweep / replay kernel ADDS its counts to one of
+   * ABZ_CSLOTS slots (one 64-byte line each, chosen by block index; agent-scope atomics, fire and forget).  The
+   * slots are cumulative -- never zeroed -- and the host takes differences of their totals between read-backs, so
+   * a sweep costs no memset, no reduction launch and no second pass (abz_device.h: block_count2).              */
+  ABZ_S_CSLOT0 = ABZ_S_SCALARS,
+  /* min / max of the distances an abcdemc sweep leaves (mc:146,163): two banks of ABZ_MMSLOTS (min key, max key)
+   * pairs; a sweep reduces into one bank and resets the other for its successor                                */
+  ABZ_S_MM0 = ABZ_S_CSLOT0 + ABZ_CSLOTS * ABZ_CSTRIDE,
+  ABZ_S_N = ABZ_S_MM0 + 2 * ABZ_MMSLOTS * 2
 };
 
 /* kernel launchers implemented across the .hip files */
@@ -90,7 +95,7 @@ int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
                          const double*, const double*, const double*, double*, double*, double*,
                          double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t, uint32_t*,
-                         uint8_t* acc_flag);
+                         uint8_t* acc_flag, int want_counts);
 int abz_launch_smc_replay(abcdez_ctx*, const uint32_t* alive_row, uint32_t* alive_out, uint32_t n_alive, uint32_t skip_lo,
                           uint32_t skip_hi, double* slot0, double* slot1, const uint8_t* acc_flag, double gamma0,
                           double gsig, uint32_t sweep);
@@ -104,8 +109,8 @@ int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, c
 int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,
                                const double*, const double*, double*, double*, double*, double*, uint8_t*);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
-int abz_reduce_partials(abcdez_ctx*, const void* partials, uint32_t nblocks, int part_slot);
 void abz_fold_counters(abcdez_ctx*);
+void abz_fold_minmax(abcdez_ctx*, int bank, double* lo, double* hi);
 int abz_jit_build(abcdez_ctx*, const char* user_source);
 void abz_jit_destroy(abcdez_ctx*);
 int abz_jit_launch_init(abcdez_ctx*, double*, double*, double*, uint32_t, uint32_t, unsigned long long*, uint64_t* stamp);

@@ -371,11 +371,11 @@ __device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32
   }
 }
 
-/* ---- block-level integer counters: wave ballot -> LDS -> ONE plain store per block into a
- * per-block partial array (no global atomics: 10^5 same-address atomics per launch were the
- * bottleneck of the first build -- about 15 ns per block, 0.25 ms per lane of group width).
- * abz_reduce_partials() sums the partials afterwards.                                        */
-__device__ inline void block_count2(bool f0, bool f1, uint2* __restrict__ partials) {
+/* ---- block-level integer counters: wave ballot -> LDS -> two agent-scope atomic ADDS per block into one of
+ * ABZ_CSLOTS cumulative slots (abz_hotmodel.h).  Same-address atomics serialise (10^5 of them on ONE address per
+ * launch were the bottleneck of the first build, ~15 ns each); spread over 256 lines they overlap the kernel, and
+ * because the slots are cumulative nothing has to be zeroed or reduced by another launch.                      */
+__device__ inline void block_count2(bool f0, bool f1, unsigned long long* __restrict__ cslots, uint32_t cls) {
   __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
   const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
   if ((threadIdx.x & 63) == 0) {
@@ -384,11 +384,18 @@ __device__ inline void block_count2(bool f0, bool f1, uint2* __restrict__ partia
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint2 v;
-    v.x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-    v.y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
-    partials[blockIdx.x] = v;
+    const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const unsigned long long y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    unsigned long long* s = cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE + cls;
+    if (x) (void)__hip_atomic_fetch_add(s, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (y) (void)__hip_atomic_fetch_add(s + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+/* order-preserving u64 image of a double (negative values, -0.0 included, sort below the positive ones) */
+__device__ inline unsigned long long f64_order_key(double x) {
+  const unsigned long long u = abz_d2u(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
 #endif /* ABZ_DEVICE_H */

@@ -17,4 +17,17 @@ struct HotModel {
   int32_t d, abck, n_data, n_blob;
 };
 
+/* cumulative sweep-counter slots (abz_ctx.h, ABZ_S_CSLOT0): ABZ_CSLOTS slots of ABZ_CSTRIDE u64 (one 64-B line);
+ * inside a slot: counter classes */
+#define ABZ_CSLOTS 256
+#define ABZ_CSTRIDE 8
+#define ABZ_C_NACC 0      /* sweep: accepted (smc:150)                     */
+#define ABZ_C_NSIM 1      /* sweep: simulated (smc:138, mc:44)             */
+#define ABZ_C_RACC 2      /* replay: accepted / simulated over all alive ranks */
+#define ABZ_C_RSIM 3
+#define ABZ_C_MCGT 4      /* abcdemc sweep: new distances > eps_target (mc:156) */
+#define ABZ_C_MCSIM 5     /* abcdemc sweep: simulated (mc:44)                   */
+#define ABZ_C_DISCARD 6   /* sweeps whose caller wants no counters         */
+#define ABZ_MMSLOTS 64
+
 #endif

@@ -84,7 +84,8 @@ struct SmcSwarmArgs {
   double* ntheta;
   double* nlogpi;
   double* ndelta;
-  uint2* partials;              /* per-block (nacc, nsim) */
+  unsigned long long* cslots;   /* cumulative counter slots; (nacc, nsim) go to classes c_cls, c_cls + 1 */
+  uint32_t c_cls;
   uint8_t* row_synced;          /* per particle: both generations' theta rows are equal (may be NULL) */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep;
@@ -180,7 +181,7 @@ __device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
       if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
     }
   }
-  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.partials);
+  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.cslots, a.c_cls);
 }
 
 /* ================================================================ replay of a sweep on a replica
@@ -196,7 +197,8 @@ struct SmcReplayArgs {
   const uint8_t* acc_flag;      /* by particle: bit 0 accepted, bit 1 simulated (proposal inside the prior support) */
   double* slot0;
   double* slot1;
-  uint2* partials;              /* per-block (nacc, nsim) over the block's alive ranks (own ones included) */
+  unsigned long long* cslots;   /* cumulative counter slots: (nacc, nsim) over the block's alive ranks (own ones included)
+                                   go to classes ABZ_C_RACC, ABZ_C_RSIM */
   double gamma0, gsig;
   uint32_t n_alive, skip_lo, skip_hi, sweep;          /* ranks [skip_lo, skip_hi) are this rank's own: counted only */
 };
@@ -261,10 +263,11 @@ __device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
   stage.store(s_tab);
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint2 v;
-    v.x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-    v.y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
-    a.partials[blockIdx.x] = v;
+    const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const unsigned long long y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    unsigned long long* s = a.cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE;
+    if (x) (void)__hip_atomic_fetch_add(s + ABZ_C_RACC, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (y) (void)__hip_atomic_fetch_add(s + ABZ_C_RSIM, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   const unsigned n = s_n;
@@ -298,7 +301,9 @@ struct McSwarmArgs {
   double* ntheta;
   double* nlogpi;
   double* ndelta;
-  uint2* partials;
+  unsigned long long* cslots;   /* cumulative counter slots: #(new Ds > eps_target) -> ABZ_C_MCGT, nsim -> ABZ_C_MCSIM */
+  unsigned long long* mm_cur;   /* [ABZ_MMSLOTS][2] (min key, max key) of the new distances: this sweep's bank ... */
+  unsigned long long* mm_nxt;   /* ... and the bank it resets for its successor */
   double eps_pop, eps_target, gamma0, gsig;
   uint32_t N, i0, n_local, sweep;
   const uint64_t* stamp;        /* blob stamps, both NULL when blobs are off */
@@ -380,7 +385,31 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
       if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
     }
   }
-  block_count2(false, active && j == 0 && simulate, a.partials);
+  /* driver reductions of the generation this sweep leaves behind, folded in (mc:146,156,163): #(Ds > eps_target) and
+   * extrema(Ds) over this call's particles */
+  const double dn = acc ? dp : di;
+  const bool lead = active && j == 0;
+  block_count2(lead && dn > a.eps_target, lead && simulate, a.cslots, ABZ_C_MCGT);   /* (MCGT, MCSIM) */
+  {
+    __shared__ unsigned long long s_mm[2][ABZ_BLOCK / 64];
+    unsigned long long lo = lead ? f64_order_key(dn) : ~0ull, hi = lead ? f64_order_key(dn) : 0ull;
+    for (int off = 32; off; off >>= 1) {
+      const unsigned long long x = __shfl_xor(lo, off, 64), y = __shfl_xor(hi, off, 64);
+      lo = x < lo ? x : lo;
+      hi = y > hi ? y : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = lo; s_mm[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < ABZ_BLOCK / 64; ++w) { lo = s_mm[0][w] < lo ? s_mm[0][w] : lo; hi = s_mm[1][w] > hi ? s_mm[1][w] : hi; }
+      unsigned long long* m = a.mm_cur + (size_t)(blockIdx.x & (ABZ_MMSLOTS - 1)) * 2;
+      if (lo != ~0ull) {
+        (void)__hip_atomic_fetch_min(m, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_max(m + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * ABZ_MMSLOTS) a.mm_nxt[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;
+  }
 }
 
 /* ================================================================ blobs: the second return value of dist! (smc:137,148)

@@ -25,12 +25,14 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
   const unsigned nblocks = abz_grid((uint64_t)n_local * (uint64_t)ctx->L);
-  if (int rc = abz_cnt_reserve(ctx, nblocks)) return rc;
-  a.partials = (uint2*)ctx->cnt;
+  a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
+  a.mm_cur = ctx->d_scal + ABZ_S_MM0 + (size_t)ctx->mm_bank * 2 * ABZ_MMSLOTS;
+  a.mm_nxt = ctx->d_scal + ABZ_S_MM0 + (size_t)(1 - ctx->mm_bank) * 2 * ABZ_MMSLOTS;
   a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
   a.stamp = ctx->stamp_cur; a.nstamp = ctx->stamp_cur ? ctx->stamp_nxt : nullptr;      /* blob stamps */
   bool ok = true;
+  if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
   } else {
@@ -38,9 +40,14 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* so
       hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
     });
   }
+  if (ctx->timing) {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->ev_pending = true;
+    ctx->ev_units = n_local;
+  }
   if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_SWEEP);
+  return 0;
 }
 
 /* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) ---- */

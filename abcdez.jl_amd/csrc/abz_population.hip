@@ -131,8 +131,8 @@ static int tree_sum_device(abcdez_ctx* ctx, TileArgs a, double* d_out, double* p
   return 0;
 }
 
-static int read_scalars(abcdez_ctx* ctx) {
-  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
+static int read_scalars(abcdez_ctx* ctx) {        /* the plain scalars only; the counter slots are read by abz_api.hip */
+  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_SCALARS * 8, hipMemcpyDeviceToHost, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -899,10 +899,6 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
 }
 
 /* ================================================================ extrema / counts (S10) */
-__device__ inline unsigned long long f64_order_key(double x) {
-  const unsigned long long u = abz_d2u(x);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
 static inline double f64_from_order_key(unsigned long long k) {
   return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
 }
@@ -980,43 +976,29 @@ int abz_count_gt_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double th
   return 0;
 }
 
-/* ================================================================ per-block counter partials -> two u64 sums
- * ABZ_CNT_PARTS blocks sum the (nacc, nsim) pairs the sweep's blocks stored and leave one pair each in the scalar
- * area; the host adds them after the read-back it does anyway.  No atomics, so nothing has to be zeroed first
- * (memset + atomic version: one more launch per sweep; a single summing block: 21 us for 46 K pairs).            */
-__global__ __launch_bounds__(ABZ_BLOCK) void reduce_partials_kernel(const uint2* __restrict__ partials, uint32_t n,
-                                                                    unsigned long long* __restrict__ out) {
-  __shared__ unsigned long long s_a[ABZ_BLOCK / 64], s_b[ABZ_BLOCK / 64];
-  unsigned long long a = 0, b = 0;
-  for (uint32_t k = blockIdx.x * ABZ_BLOCK + threadIdx.x; k < n; k += gridDim.x * ABZ_BLOCK) {
-    const uint2 v = partials[k];
-    a += v.x; b += v.y;
-  }
-  for (int off = 32; off; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    a = 0; b = 0;
-    for (int w = 0; w < ABZ_BLOCK / 64; ++w) { a += s_a[w]; b += s_b[w]; }
-    out[2 * blockIdx.x] = a;
-    out[2 * blockIdx.x + 1] = b;
-  }
-}
-int abz_reduce_partials(abcdez_ctx* ctx, const void* partials, uint32_t nblocks, int part_slot) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ABZ_CNT_PARTS), dim3(ABZ_BLOCK), 0, ctx->stream, (const uint2*)partials,
-                     nblocks, ctx->d_scal + part_slot);
-  ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-/* after a read-back of the scalar area: NACC / NSIM and RACC / RSIM from their partial pairs */
+/* ================================================================ sweep counters: cumulative slots -> per-call counts
+ * After a read-back of the whole scalar area: totals of the counter classes over the ABZ_CSLOTS slots; what a call
+ * reports is the growth since the previous read-back (abz_ctx.h, ABZ_S_CSLOT0).  Also folds the abcdemc sweep's
+ * min / max bank.                                                                                             */
 void abz_fold_counters(abcdez_ctx* ctx) {
-  const int slot[2] = {ABZ_S_PART_SWEEP, ABZ_S_PART_REPLAY}, dst[2] = {ABZ_S_NACC, ABZ_S_RACC};
-  for (int q = 0; q < 2; ++q) {
-    unsigned long long a = 0, b = 0;
-    for (int k = 0; k < ABZ_CNT_PARTS; ++k) { a += ctx->h_scal[slot[q] + 2 * k]; b += ctx->h_scal[slot[q] + 2 * k + 1]; }
-    ctx->h_scal[dst[q]] = a;
-    ctx->h_scal[dst[q] + 1] = b;
-  }
+  unsigned long long tot[ABZ_CSTRIDE] = {0};
+  for (int k = 0; k < ABZ_CSLOTS; ++k)
+    for (int c = 0; c < ABZ_CSTRIDE; ++c) tot[c] += ctx->h_scal[ABZ_S_CSLOT0 + k * ABZ_CSTRIDE + c];
+  ctx->h_scal[ABZ_S_NACC] = tot[ABZ_C_NACC] - ctx->cnt_prev[ABZ_C_NACC];
+  ctx->h_scal[ABZ_S_NSIM] = tot[ABZ_C_NSIM] - ctx->cnt_prev[ABZ_C_NSIM];
+  ctx->h_scal[ABZ_S_RACC] = tot[ABZ_C_RACC] - ctx->cnt_prev[ABZ_C_RACC];
+  ctx->h_scal[ABZ_S_RSIM] = tot[ABZ_C_RSIM] - ctx->cnt_prev[ABZ_C_RSIM];
+  ctx->h_scal[ABZ_S_MCGT] = tot[ABZ_C_MCGT] - ctx->cnt_prev[ABZ_C_MCGT];
+  ctx->h_scal[ABZ_S_COUNT] = tot[ABZ_C_MCSIM] - ctx->cnt_prev[ABZ_C_MCSIM];
+  for (int c = 0; c < ABZ_CSTRIDE; ++c) ctx->cnt_prev[c] = tot[c];
+}
+/* extrema of the distances the LAST abcdemc sweep left, from the bank it reduced into */
+void abz_fold_minmax(abcdez_ctx* ctx, int bank, double* lo, double* hi) {
+  unsigned long long mn = ~0ull, mx = 0ull;
+  const unsigned long long* m = ctx->h_scal + ABZ_S_MM0 + (size_t)bank * 2 * ABZ_MMSLOTS;
+  for (int k = 0; k < ABZ_MMSLOTS; ++k) { mn = m[2 * k] < mn ? m[2 * k] : mn; mx = m[2 * k + 1] > mx ? m[2 * k + 1] : mx; }
+  *lo = f64_from_order_key(mn);
+  *hi = f64_from_order_key(mx);
 }
 
 /* ================================================================ spec arithmetic on the device (test hook) */

@@ -61,7 +61,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
                          uint32_t r_lo, uint32_t r_hi, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, double eps, double gamma0, double gsig,
                          uint32_t i0, uint32_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
-                         uint32_t N_total, uint32_t* alive_out, uint8_t* acc_flag) {
+                         uint32_t N_total, uint32_t* alive_out, uint8_t* acc_flag, int want_counts) {
   SmcSwarmArgs a;
   a.hm = ctx->hot; a.alive_idx = alive_idx; a.arank = arank;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
@@ -69,8 +69,8 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   const int L = ctx->L, C = ctx->C;
   a.n_work = r_hi - r_lo;
   const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
-  if (int rc = abz_cnt_reserve(ctx, nblocks ? nblocks : 1)) return rc;
-  a.partials = (uint2*)ctx->cnt;
+  a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
+  a.c_cls = want_counts ? ABZ_C_NACC : ABZ_C_DISCARD;
   a.row_synced = dead_synced;
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
@@ -106,7 +106,7 @@ int abz_launch_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint3
   }
   if (!ok) { abz_set_error("smc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_SWEEP);
+  return 0;
 }
 
 /* replay of the other ranks' accepted proposals on this rank's replica (abz_kernels.h) */
@@ -123,12 +123,11 @@ int abz_launch_smc_replay(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* 
   a.slot0 = slot0; a.slot1 = slot1; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_hi = skip_hi; a.sweep = sweep;
   const unsigned nblocks = (unsigned)(((uint64_t)n_alive + ABZ_REPLAY_CHUNK - 1) / ABZ_REPLAY_CHUNK);
-  if (int rc = abz_cnt_reserve(ctx, nblocks)) return rc;
-  a.partials = (uint2*)ctx->cnt;
+  a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
   bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     hipLaunchKernelGGL((smc_replay_kernel<LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
   });
   if (!ok) { abz_set_error("smc_replay: unsupported layout"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
-  return abz_reduce_partials(ctx, ctx->cnt, nblocks, ABZ_S_PART_REPLAY);
+  return 0;
 }

@@ -1,51 +1,220 @@
 /*
- * abz_sort.hip -- (distance, index)-sorted order for abcdemc's "better particle" draw
- * (src/abcdez_mc.jl:23).  A plain library sort: rocPRIM's stable LSD radix sort on the
- * order-preserving bit pattern of the distance with the particle index as payload,
- * so ties keep index order.
+ * abz_sort.hip -- the enumeration abcdemc's "better particle" draw indexes into
+ * (s = rand(rng, (1:N)[Ds .<= Ds[i]]), src/abcdez_mc.jl:23).
+ *
+ * order[0 .. nA)  : the particles with Ds <= eps_pop, in index order (they belong to the candidate set of EVERY
+ *                   particle that draws -- a draw happens only for Ds[i] > eps_pop, mc:19-20 -- so their relative
+ *                   order is immaterial and a stable partition is enough);
+ * order[nA .. N)  : the others sorted by (Ds, index);
+ * sorted_delta[p] = max(Ds[order[p]], eps_pop): non-decreasing, so the candidate set of particle i is
+ *                   order[0 .. upper_bound(sorted_delta, Ds[i])) exactly as in the reference's mask.
+ *
+ * Hand-written for this path instead of a library sort of 64-bit keys:
+ *   1. every particle gets a 24-bit BUCKET id: 0 for Ds <= eps_pop, else 1 + ((key - key(eps_pop) - 1) >> shift),
+ *      clamped -- a monotone binning of the order-preserving bit pattern over the window (eps_pop, max Ds] the
+ *      driver already knows (mc:146); at N = 2^20 a bucket holds 0.06 particles on average;
+ *   2. a stable LSD radix sort of (bucket, index) pairs, three passes of 8 bits; one wavefront owns a tile and ranks
+ *      its elements with ballots (no atomics anywhere, so the result is deterministic);
+ *   3. a fix-up pass puts the few buckets that hold more than one distinct distance into (Ds, index) order.
+ * Any binning is correct (the fix-up sorts whatever shares a bucket); a fitting one is fast.
  */
 #include <hip/hip_runtime.h>
-#include <cstring>
-#include <rocprim/rocprim.hpp>
+#include <string.h>
 
 #include "abz_ctx.h"
 #include "abz_device.h"
 
-__global__ __launch_bounds__(ABZ_BLOCK) void sort_keys_kernel(const double* __restrict__ delta, uint32_t n,
-                                                              unsigned long long* __restrict__ keys,
-                                                              uint32_t* __restrict__ vals) {
-  const uint32_t i = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long u = abz_d2u(delta[i]);
-  keys[i] = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-  vals[i] = i;
-}
-__global__ __launch_bounds__(ABZ_BLOCK) void sort_unkey_kernel(const unsigned long long* __restrict__ keys, uint32_t n,
-                                                               double* __restrict__ sorted) {
-  const uint32_t i = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = keys[i];
-  sorted[i] = (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
+#define MCR_BITS 24
+#define MCR_ROUND 64                    /* one wave-round */
+#define MCR_WAVES (ABZ_BLOCK / 64)
+
+__device__ inline uint32_t mcr_bucket(double d, unsigned long long klo, int shift) {
+  const unsigned long long key = f64_order_key(d);
+  if (key <= klo) return 0u;
+  const unsigned long long t = (key - klo - 1ull) >> shift;
+  return t < (1ull << MCR_BITS) - 2ull ? (uint32_t)t + 1u : (1u << MCR_BITS) - 1u;
 }
 
-int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta) {
+/* tile histogram of one 8-bit digit.  PASS 0 also makes the (bucket, index) pairs from the distances.
+ * table[digit * ntiles + tile]; one wave per tile of `rounds` x 64 consecutive elements.                 */
+template <int PASS>
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const double* __restrict__ delta, uint32_t n,
+                                                             unsigned long long klo, int shift,
+                                                             uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                             uint32_t* __restrict__ table, uint32_t ntiles,
+                                                             uint32_t rounds) {
+  __shared__ uint32_t s_h[MCR_WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
+  for (int b = lane; b < 256; b += 64) s_h[wave][b] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  if (tile < ntiles) {
+    const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint64_t i = base + (uint64_t)r * MCR_ROUND + lane;
+      if (i < n) {
+        uint32_t k;
+        if constexpr (PASS == 0) {
+          k = mcr_bucket(delta[i], klo, shift);
+          key[i] = k;
+          val[i] = (uint32_t)i;
+        } else {
+          k = key[i];
+        }
+        atomicAdd(&s_h[wave][(k >> (8 * PASS)) & 255u], 1u);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (tile < ntiles)
+    for (int b = lane; b < 256; b += 64) table[(size_t)b * ntiles + tile] = s_h[wave][b];
+}
+
+/* exclusive scan of the table (digit-major) by one block */
+__global__ __launch_bounds__(1024) void mcr_scan_kernel(uint32_t* __restrict__ v, uint32_t n) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += v[k];
+  s_part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = v[k]; v[k] = run; run += c; }
+}
+
+/* stable scatter of one digit.  The wave walks its tile in index order, 64 elements per round; lanes holding the
+ * same digit find each other with 8 ballots, take consecutive slots behind the digit's running offset (LDS, private
+ * to the wave) and the last of them advances it.  LAST: the pairs end as order[] / bucket[] and the clamped
+ * distance of every position is gathered.                                                               */
+template <int PASS, bool LAST>
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* __restrict__ key_in,
+                                                                const uint32_t* __restrict__ val_in, uint32_t n,
+                                                                const uint32_t* __restrict__ table, uint32_t ntiles,
+                                                                uint32_t rounds, uint32_t* __restrict__ key_out,
+                                                                uint32_t* __restrict__ val_out,
+                                                                const double* __restrict__ delta, double eps_pop,
+                                                                double* __restrict__ sorted_delta) {
+  __shared__ uint32_t s_run[MCR_WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
+  if (tile >= ntiles) return;                         /* whole waves leave; no block-level barrier below */
+  volatile uint32_t* run = s_run[wave];
+  for (int b = lane; b < 256; b += 64) run[b] = table[(size_t)b * ntiles + tile];
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint64_t i = base + (uint64_t)r * MCR_ROUND + lane;
+    const bool valid = i < n;
+    const uint32_t k = valid ? key_in[i] : 0u;
+    const uint32_t v = valid ? val_in[i] : 0u;
+    const uint32_t d = (k >> (8 * PASS)) & 255u;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long bal = __ballot(one);
+      same &= one ? bal : ~bal;
+    }
+    const uint32_t rank = (uint32_t)__popcll(same & below), cnt = (uint32_t)__popcll(same);
+    const uint32_t pos = run[d] + rank;               /* every lane of the group reads before its last lane writes */
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      key_out[pos] = k;
+      val_out[pos] = v;
+      if constexpr (LAST) {
+        const double x = delta[v];
+        sorted_delta[pos] = k == 0u ? eps_pop : x;
+      }
+      if (rank + 1u == cnt) run[d] = pos + 1u;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+/* buckets holding several particles: put them into (Ds, index) order.  One thread per run start; runs of one
+ * element (nearly all) and runs of equal distances (atoms of a discrete distance: the stable sort already left them
+ * in index order) cost one pass over the run; bucket 0 (Ds <= eps_pop) keeps its index order by definition.   */
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __restrict__ bucket, uint32_t n,
+                                                              uint32_t* __restrict__ order,
+                                                              double* __restrict__ sorted_delta) {
+  const uint32_t p = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t b = bucket[p];
+  if (b == 0u || (p > 0u && bucket[p - 1u] == b)) return;
+  uint32_t e = p + 1u;
+  while (e < n && bucket[e] == b) ++e;
+  for (uint32_t q = p + 1u; q < e; ++q) {             /* insertion sort: linear on sorted input */
+    const double x = sorted_delta[q];
+    const uint32_t ix = order[q];
+    uint32_t at = q;
+    while (at > p) {
+      const double y = sorted_delta[at - 1u];
+      const uint32_t iy = order[at - 1u];
+      if (y < x || (y == x && iy < ix)) break;
+      sorted_delta[at] = y;
+      order[at] = iy;
+      --at;
+    }
+    if (at != q) { sorted_delta[at] = x; order[at] = ix; }
+  }
+}
+
+static inline unsigned long long host_order_key(double x) {
+  unsigned long long u;
+  memcpy(&u, &x, 8);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
+                          uint32_t* order, double* sorted_delta) {
   const uint32_t n = (uint32_t)N;
-  size_t temp_bytes = 0;
-  ABZ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned long long*)nullptr,
-                                          (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0,
-                                          64, ctx->stream));
-  const size_t kb = abz_align((size_t)n * 8), vb = abz_align((size_t)n * 4);
-  int rc = abz_ws_reserve(ctx, 2 * kb + vb + abz_align(temp_bytes));
+  /* window of the binning: (eps_pop, dmax_hint] in key space -> 2^24 - 2 buckets */
+  const unsigned long long klo = host_order_key(eps_pop);
+  unsigned long long khi = host_order_key(dmax_hint);
+  if (!(dmax_hint > eps_pop)) khi = klo + 1ull;          /* also catches a NaN hint */
+  const unsigned long long range = khi - klo;
+  int bits = 0;
+  while (bits < 64 && (range >> bits) != 0ull) ++bits;   /* range < 2^bits */
+  const int shift = bits > MCR_BITS ? bits - MCR_BITS : 0;
+  /* one wave per tile; at most 2048 tiles so that one block scans the table */
+  uint32_t rounds = 32;
+  while ((uint64_t)rounds * MCR_ROUND * 2048ull < (uint64_t)n) rounds *= 2;
+  const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
+  const size_t pb = abz_align((size_t)n * 4), tb = abz_align((size_t)256 * ntiles * 4);
+  int rc = abz_ws_reserve(ctx, 3 * pb + tb);
   if (rc) return rc;
-  char* p = (char*)ctx->ws;
-  unsigned long long* keys_in = (unsigned long long*)p; p += kb;
-  unsigned long long* keys_out = (unsigned long long*)p; p += kb;
-  uint32_t* vals_in = (uint32_t*)p; p += vb;
-  void* temp = p;
-  const unsigned grid = (n + ABZ_BLOCK - 1) / ABZ_BLOCK;
-  hipLaunchKernelGGL(sort_keys_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, n, keys_in, vals_in);
-  ABZ_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, order, n, 0, 64, ctx->stream));
-  hipLaunchKernelGGL(sort_unkey_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, keys_out, n, sorted_delta);
+  char* w = (char*)ctx->ws;
+  uint32_t* keyA = (uint32_t*)w; w += pb;
+  uint32_t* valA = (uint32_t*)w; w += pb;
+  uint32_t* keyB = (uint32_t*)w; w += pb;
+  uint32_t* table = (uint32_t*)w;
+  uint32_t* valB = order;                                /* pass 0 -> (keyB, order), pass 1 -> (keyA, valA), pass 2 -> (keyB, order) */
+  const unsigned grid = (ntiles + MCR_WAVES - 1) / MCR_WAVES;
+  const uint32_t tn = 256u * ntiles;
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(1), dim3(1024), 0, st, table, tn);
+  hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, ntiles, rounds,
+                     keyB, valB, delta, eps_pop, sorted_delta);
+  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyB, valB, table, ntiles, rounds);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(1), dim3(1024), 0, st, table, tn);
+  hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyB, valB, n, table, ntiles, rounds,
+                     keyA, valA, delta, eps_pop, sorted_delta);
+  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(1), dim3(1024), 0, st, table, tn);
+  hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, ntiles, rounds,
+                     keyB, order, delta, eps_pop, sorted_delta);
+  hipLaunchKernelGGL(mcr_fixup_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, st, keyB, n, order,
+                     sorted_delta);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

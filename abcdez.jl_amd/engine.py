@@ -211,17 +211,19 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_count_gt(self.ctx, _ptr(delta), delta.numel(), thr, C.byref(c)))
         return c.value
 
-    def mc_rank_prepare(self, delta, order, sorted_delta):
-        _lib.check(self.lib, self.lib.abcdez_mc_rank_prepare(self.ctx, _ptr(delta), delta.numel(), _ptr(order),
-                                                             _ptr(sorted_delta)))
+    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta):
+        """asynchronous: no host synchronisation"""
+        _lib.check(self.lib, self.lib.abcdez_mc_rank_prepare(self.ctx, _ptr(delta), delta.numel(), eps_pop, dmax_hint,
+                                                             _ptr(order), _ptr(sorted_delta)))
 
-    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep) -> int:
-        nsim = C.c_int64()
+    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep):
+        """-> (nsim, #(new Ds > eps_target), min, max of the new Ds) over particles [i0, i0+n_local): ONE host sync"""
+        nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self.lib, self.lib.abcdez_mc_swarm(
             self.ctx, _ptr(order), _ptr(sorted_delta), cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
             _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep,
-            C.byref(nsim)))
-        return nsim.value
+            C.byref(nsim), C.byref(ngt), C.byref(lo), C.byref(hi)))
+        return nsim.value, ngt.value, lo.value, hi.value
 
     def push_p(self, theta, out):
         _lib.check(self.lib, self.lib.abcdez_push_p(self.ctx, _ptr(theta), theta.shape[0], _ptr(out)))
@@ -450,6 +452,16 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ S1
     def init_population(self):
+        if self._delta_work is not None:
+            self._delta_work.wait()
+            self._delta_work = None
+        if self.rows_mode:       # a fresh population lives in slot `cur` of every particle (also when an engine is re-used)
+            self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
+            if self.cur:
+                self.cur_row.bitwise_or_(-(1 << 31))
+            self._rows_dirty = False
+            self._rows_n = 0
+        self._delta_stale = self._logpi_stale = False
         th, lp, dl = self.buf[self.cur]
         self._bind_stamps()
         self.ops.init(th, lp, dl, self.lo, self.n_local)
@@ -578,25 +590,41 @@ class PopulationEngine:
         return self._allreduce_counts(nacc, nsim)
 
     # ------------------------------------------------------------------ S4
-    def mc_rank_prepare(self):
+    def mc_rank_prepare(self, eps_pop: float = None, dmax_hint: float = None):
+        """the enumeration of mc:23 for the current distances: particles with Ds <= eps_pop in index order, then the
+        others by (Ds, index).  eps_pop / dmax_hint default to the values of mc:146-147 with eps_target = 0 (one
+        extrema pass); the driver passes what it already knows.  No host synchronisation on the HIP path."""
         if self.rows_mode:
             raise RuntimeError("abcdemc needs storage='classic'")
         if self.order is None:
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
             self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
-        self.ops.mc_rank_prepare(self.state[2], self.order, self.sorted_delta)
+        if eps_pop is None or dmax_hint is None:
+            lo, hi = self.extrema()
+            eps_pop = lo if eps_pop is None else eps_pop
+            dmax_hint = hi if dmax_hint is None else dmax_hint
+        self.ops.mc_rank_prepare(self.state[2], eps_pop, dmax_hint, self.order, self.sorted_delta)
 
-    def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float) -> int:
+    def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float):
+        """one sweep of abcdemc_swarm! -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the generation it leaves
+        (mc:149,156,146,163), global over all ranks"""
         if self.order is None:   # converged population: the order is never consulted
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
             self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
         self._bind_stamps()
-        nsim = self.ops.mc_swarm(self.order, self.sorted_delta, self.state, self.other, eps_pop, eps_target, gamma0,
-                                 gsig, self.lo, self.n_local, self.sweep)
+        nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.sorted_delta, self.state, self.other, eps_pop, eps_target,
+                                              gamma0, gsig, self.lo, self.n_local, self.sweep)
         self.sweep += 1
         self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
         self._swap()
-        return self._allreduce_counts(nsim)[0]
+        nsim, ngt = self._allreduce_counts(nsim, ngt)
+        if self._collectives:
+            import torch.distributed as dist
+
+            t = torch.tensor([lo, -hi], dtype=torch.float64, device=self.device if self._backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+            lo, hi = float(t[0]), -float(t[1])
+        return nsim, ngt, lo, hi
 
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY.md 8f-4)
     def download_state(self) -> dict:

@@ -49,22 +49,24 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     γ0 = 2.38 / math.sqrt(2 * prior_length(prior))            # mc:129
     γσ = 1e-5                                                 # mc:130
     complete = 1 - eng.count_gt(ϵ_target) / nparticles        # mc:133
+    ϵ_l, ϵ_h = eng.extrema()                                  # mc:146, first generation; afterwards the sweep reports them
     while iters < generations:                                # mc:134
         iters += 1
-        ϵ_l, ϵ_h = eng.extrema()                              # mc:146
         ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))          # mc:147
         if ϵ_h > ϵ_target:
             # the "better particle" set of mc:23 is only consulted while some Δ_i > ϵ
-            eng.mc_rank_prepare()
-        nsims += eng.mc_swarm(ϵ_pop, ϵ_target, γ0, γσ)        # mc:149 (S2, S4)
-        ncomplete = 1 - eng.count_gt(ϵ_target) / nparticles   # mc:156
+            eng.mc_rank_prepare(ϵ_pop, ϵ_h)
+        # mc:149 (S2, S4); the reductions of mc:156 and of the next generation's mc:146 ride along: one host sync
+        nsim, n_above, ϵ_l, ϵ_h = eng.mc_swarm(ϵ_pop, ϵ_target, γ0, γσ)
+        nsims += nsim
+        ncomplete = 1 - n_above / nparticles                  # mc:156
         if verbose and (ncomplete != complete or complete >= (nparticles - 1) / nparticles):
-            log.info("Finished run: completion=%s nsim=%d range_ϵ=%s", ncomplete, nsims, eng.extrema())
+            log.info("Finished run: completion=%s nsim=%d range_ϵ=%s", ncomplete, nsims, (ϵ_l, ϵ_h))
         complete = ncomplete
 
-    conv = eng.extrema()[1] <= ϵ_target                       # mc:163
+    conv = ϵ_h <= ϵ_target                                    # mc:163
     if verbose:
-        log.info("End: completion=%s converged=%s nsim=%d range_ϵ=%s", complete, conv, nsims, eng.extrema())
+        log.info("End: completion=%s converged=%s nsim=%d range_ϵ=%s", complete, conv, nsims, (ϵ_l, ϵ_h))
     res = eng.result()                                        # mc:166
     out = Result(P=res["P"], C=res["C"], reached_ϵ=conv, blobs=res.get("blobs"))
     out.reached_eps = conv

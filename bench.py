@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-updates/s of the abcdesmc population loop on MI355X.
+"""bench.py -- particle-updates/s of the ABC-DE population loop on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-d = 32 MVN simulator (prior 32 x N(0,1), x = theta + z, y = 1-vector, Euclidean
-distance), abcdesmc with alpha = 0.95, delta_ess = 0.5, Kmcmc = 3, IndicatorStrict,
-2^22 particles per GPU (weak scaling).  One *step* = one SMC generation of the
-reference's main loop (src/abcdez_smc.jl:295-377): eps-quantile, reweight, (resample),
-alive compaction and up to Kmcmc DE-Metropolis sweeps.  One particle-update = one alive
+Default workload = BASELINE.json configs[2], the configuration the metric is quoted on:
+d = 32 MVN simulator (prior 32 x N(0,1), x = theta + z, y = 1-vector, Euclidean distance),
+abcdesmc with alpha = 0.95, delta_ess = 0.5, Kmcmc = 3, IndicatorStrict, 2^22 particles per GPU
+(weak scaling).  One *step* = one SMC generation of the reference's main loop
+(src/abcdez_smc.jl:295-377): eps-quantile, reweight, (resample), alive compaction, up to Kmcmc
+DE-Metropolis sweeps and the extrema(Ds) of the history (smc:364).  One particle-update = one alive
 particle through one sweep.  State is resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config smc32|mc1d|lv|evidence1d]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE
-JSON line.
+The other single-GPU configurations of BASELINE.json print the same JSON shape:
+    mc1d        configs[1]: 1-D Normal, abcdemc, 2^20 particles (step = one generation, mc:134-161)
+    lv          configs[3]: Lotka-Volterra RK4 (dt 0.01, 1500 steps per update), abcdesmc, 2^20 particles
+    evidence1d  configs[4]: the two models of examples/minimal_example.jl, abcdesmc, 2^23 particles
+
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -24,31 +28,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming, 5.5-5.8 random rows)
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (FMA = 2 flop): half the 157.3 TFLOP/s fp32 vector rate of the guide
+PROFILE_TAG = "r02"
 
 
-def measured_traffic_per_update():
-    """HBM bytes per particle-update of the sweep kernel from the committed PMC passes
-    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
-    separate rocprofv3 --pmc runs of this same command).  None if the file is absent."""
+def profile_json(name):
+    """a committed measurement under profiles/ (PMC traffic, access-pattern ceiling); None if absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            return float(json.load(f)["total_bytes_per_update"])
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--particles-per-gpu", type=int, default=1 << 22)
-    p.add_argument("--dim", type=int, default=32)
+    p.add_argument("--steps", type=int, default=None)
+    p.add_argument("--warmup", type=int, default=None)
+    p.add_argument("--config", default="smc32", choices=sorted(CONFIGS))
+    p.add_argument("--particles-per-gpu", type=int, default=None)
+    p.add_argument("--dim", type=int, default=32, help="smc32 only")
     p.add_argument("--lanes", type=int, default=0, help="lanes per particle (0 = library default)")
-    p.add_argument("--cpu-particles", type=int, default=1 << 22, help="population of the CPU-oracle baseline sample")
-    p.add_argument("--cpu-steps", type=int, default=10)
+    p.add_argument("--cpu-particles", type=int, default=None, help="population of the CPU-oracle baseline sample")
+    p.add_argument("--cpu-steps", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-whole-run", action="store_true")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -68,7 +74,10 @@ class Generation:
         self.updates = 0
         self.sweeps = 0
         self.nsims = 0
+        self.naccs = 0
         self.resamples = 0
+        self.generations = 0
+        self.range = (0.0, math.inf)
 
     def step(self):
         e = self.e
@@ -89,10 +98,94 @@ class Generation:
             self.sweeps += 1
             if naccs / n_alive >= self.Kmcmc_min:
                 break
+        self.naccs += naccs
         self.eps_k = self.eps
+        self.range = e.extrema()                                                           # smc:364 (verboseout default)
+        self.generations += 1
+
+    def done(self):
+        return self.eps <= self.eps_target                                                 # smc:376
 
 
-def cpu_baseline_faithful(spec, d, eps_target, cores, n=1 << 16, sweeps=3):
+class McGeneration:
+    """abcdemc!'s generation loop body (mc:134-161): rank pass while unconverged, one sweep, driver reductions."""
+
+    def __init__(self, eng, d, eps_target):
+        self.e, self.eps_target = eng, eps_target
+        self.gamma0 = 2.38 / math.sqrt(2 * d)
+        self.lo, self.hi = eng.extrema()                                                   # mc:146 (first generation)
+        self.updates = self.sweeps = self.nsims = self.generations = self.ranked = 0
+        self.complete = 0.0
+
+    def step(self):
+        e = self.e
+        eps_pop = max(self.eps_target, self.lo)                                            # mc:147 (alpha = 0)
+        if self.hi > self.eps_target:
+            e.mc_rank_prepare(eps_pop, self.hi)                                            # mc:23's candidate sets
+            self.ranked += 1
+        nsim, n_above, self.lo, self.hi = e.mc_swarm(eps_pop, self.eps_target, self.gamma0, 1e-5)   # mc:149,156,146
+        self.nsims += nsim
+        self.updates += e.N
+        self.sweeps += 1
+        self.generations += 1
+        self.complete = 1 - n_above / e.N
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+def lv_fixture():
+    with open(os.path.join(ROOT, "tests", "golden", "lv_data.json")) as f:
+        return json.load(f)
+
+
+def cfg_smc32(A, args):
+    d = args.dim
+    prior = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(d)])
+    sim = A.MVNormal(tuple([1.0] * d))
+    return dict(kind="smc", prior=prior, sim=sim, d=d, eps_target=6.0 * math.sqrt(d / 32.0), ppg=1 << 22, steps=20, warmup=5,
+                cpu_particles=1 << 22, cpu_steps=10, storage="rows",
+                workload=f"abcdesmc d={d} MVN simulator + Euclidean distance (BASELINE.json configs[2]); "
+                         "alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
+                exact_logZ=-8.111642 if d == 32 else None)
+
+
+def cfg_mc1d(A, args):
+    return dict(kind="mc", prior=A.Normal(0.0, math.sqrt(10.0)), sim=A.Normal1D(3.0), d=1, eps_target=0.3, ppg=1 << 20,
+                steps=100, warmup=0, cpu_particles=1 << 20, cpu_steps=8, storage="classic",
+                workload="abcdemc 1-D Normal simulator, data 3, eps 0.3 (BASELINE.json configs[1]); steps = the run's "
+                         "generations from the initial population on (rank pass while unconverged + one fused sweep)",
+                exact_logZ=None)
+
+
+def cfg_lv(A, args):
+    g = lv_fixture()
+    sim = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=g["dt"], steps_per_obs=g["steps_per_obs"],
+                             noise=g["noise"])
+    return dict(kind="smc", prior=A.Factored(*[A.Uniform(0.0, 2.0)] * 4), sim=sim, d=4, eps_target=1.0, ppg=1 << 20, steps=12,
+                warmup=3, cpu_particles=1 << 15, cpu_steps=6, storage="rows",
+                workload="abcdesmc Lotka-Volterra RK4 on device, dt 0.01 x 1500 steps per particle-update, 16 noisy (x, y) "
+                         "observations, Euclidean distance (BASELINE.json configs[3]); alpha=0.95 Kmcmc=3",
+                exact_logZ=None)
+
+
+def cfg_evidence1d(A, args):
+    return dict(kind="smc", prior=A.Normal(0.0, math.sqrt(10.0)), sim=A.Normal1D(3.0), d=1, eps_target=0.3, ppg=1 << 23,
+                steps=12, warmup=3, cpu_particles=1 << 21, cpu_steps=6, storage="rows",
+                workload="abcdesmc two-model evidence of examples/minimal_example.jl (BASELINE.json configs[4]); timed: "
+                         "generations of model 1 (prior N(0, sqrt 10)); both models then run to eps 0.3",
+                exact_logZ=-3.038051357)
+
+
+CONFIGS = {"smc32": cfg_smc32, "mc1d": cfg_mc1d, "lv": cfg_lv, "evidence1d": cfg_evidence1d}
+
+
+def make_loop(cfg, eng):
+    if cfg["kind"] == "mc":
+        return McGeneration(eng, cfg["d"], cfg["eps_target"])
+    return Generation(eng, cfg["d"], cfg["eps_target"])
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline_faithful(spec, d, cores, n=1 << 16, sweeps=3):
     """The LITERAL restatement of abcdesmc_swarm! (oracle ref_smc_swarm: donors by rejection around the O(N)
     scan of wsample(rng, 1:N, alive), src/abcdez_smc.jl:119-126) at a size where its O(N^2) sweep still
     finishes in seconds -- documents the wall the reference hits long before 4 M particles."""
@@ -122,41 +215,122 @@ def cpu_baseline_faithful(spec, d, eps_target, cores, n=1 << 16, sweeps=3):
                       f"cost per update grows linearly with the population"}
 
 
-def cpu_baseline(args, prior, sim, eps_target):
-    """The oracle (a C port of the reference algorithm, OpenMP) on a bounded sample of the workload."""
-    import abcdez_amd as A
+def cpu_baseline(A, args, cfg):
+    """The oracle (a C port of the reference algorithm, OpenMP) on a bounded sample of the same workload."""
     from oracle import oracle as O
 
-    spec = A.ModelSpec(prior, sim, seed=1)
-    eng = O.oracle_engine(spec, args.cpu_particles)
+    n = args.cpu_particles or cfg["cpu_particles"]
+    steps = args.cpu_steps or cfg["cpu_steps"]
+    spec = A.ModelSpec(cfg["prior"], cfg["sim"], seed=1)
+    eng = O.oracle_engine(spec, n)
     eng.init_population()
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    if cfg["kind"] == "mc":
+        g = make_loop(cfg, eng)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.step()
+        dt = time.perf_counter() - t0
+        return None, {"value": g.updates / dt, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+                      "sample": f"the first {steps} generations of the same abcdemc run at {n} particles "
+                                f"(oracle/abcdez_oracle.c: qsort rank pass + OpenMP sweep, {dt:.1f} s)"}
     eng.reset_weights()
-    g = Generation(eng, args.dim, eps_target)
+    g = make_loop(cfg, eng)
     g.step()                                  # untimed warm-up generation
     u0 = g.updates
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         g.step()
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    faithful = cpu_baseline_faithful(spec, args.dim, eps_target, cores)
+    faithful = cpu_baseline_faithful(spec, cfg["d"], cores) if args.config == "smc32" else None
     return faithful, {
-        "value": (g.updates - u0) / dt,
-        "unit": "particle-updates/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{args.cpu_steps} generations of the same d={args.dim} MVN abcdesmc workload at "
-                  f"{args.cpu_particles} particles (oracle/abcdez_oracle.c, OpenMP, {dt:.1f} s)",
+        "value": (g.updates - u0) / dt, "unit": "particle-updates/s", "cores": cores, "kind": "port",
+        "sample": f"{steps} generations of the same workload at {n} particles (oracle/abcdez_oracle.c, OpenMP, {dt:.1f} s)",
     }
 
 
+# ---------------------------------------------------------------------------------------------- roofline
+def lv_flops_per_update(sim):
+    """fp64 flops of one Lotka-Volterra particle-update (abz_device.h sim_dist<ABZ_SIM_LV>): per RK4 step 16 fma
+    (2 flop) + 12 mul + 6 add = 50 flop in 34 VALU instructions; per observation 2 fma (noise) + 2 sub + 2 fma
+    (squared error) = 10 flop, Box-Muller pair not counted."""
+    nobs = len(sim.obs) // 2
+    return (nobs - 1) * sim.steps_per_obs * 50 + nobs * 10
+
+
+def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
+    avg_ms = kern_ms / max(launches, 1)
+    upl = units / max(launches, 1)
+    rate = upl / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+    if args_config == "lv":
+        fl = lv_flops_per_update(cfg["sim"])
+        ach = fl * rate / 1e12
+        return {"kernel": "smc_swarm_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per update; the row traffic "
+                        "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl,
+                "rk4_steps_per_s": rate * (len(cfg["sim"].obs) // 2 - 1) * cfg["sim"].steps_per_obs,
+                "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches, "kernel_updates_per_s": rate}
+    d = cfg["d"]
+    if kind == "mc":
+        # SURVEY.md 8d uses the same per-update figure for both drivers (d = 1: 41 B read, 24 B written); the abcdemc sweep
+        # really reads one row more (the base particle of mc:23) and 12 B of the enumeration
+        b_read, b_write, kernel = 24 * ld + 17, 8 * ld + 16, "mc_swarm_kernel"
+        b_moved = 32 * ld + 16 + 12 + b_write
+    else:
+        b_read, b_write, kernel = 24 * ld + 17, 8 * ld + 16, "smc_swarm_kernel"
+        # what the row store has to move per update: the reads, an accepted row + its log-prior / distance, the
+        # 4-byte entry of the next alive list
+        b_moved = b_read + acc_rate * b_write + 4
+    to_gbs = lambda b: b * rate / 1e9
+    ach = to_gbs(b_read)
+    out = {
+        "kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "frac_is": "HBM-READ fraction of north_star / SURVEY.md 8d: (24 ld + 17) B read per update x updates per launch "
+                   "/ average launch time / 8 TB/s",
+        "bytes_read_per_update": b_read, "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches,
+        "kernel_updates_per_s": rate,
+        "total_bytes_frac": to_gbs(b_read + b_write) / HBM_PEAK_GBS,
+        "total_bytes_note": f"SURVEY.md 8d total-bytes variant: {b_read + b_write} B per update, charging every update a full "
+                            "row write (the double-buffered reference layout)",
+        "moved_bytes_per_update": b_moved, "moved_bytes_frac": to_gbs(b_moved) / HBM_PEAK_GBS,
+        "acceptance_rate": acc_rate,
+    }
+    tr = profile_json(f"{PROFILE_TAG}_hbm_traffic_{args_config}.json")
+    if tr and tr.get("ld") == ld:
+        out["traffic"] = tr["total_bytes_per_update"] * upl
+        out["traffic_source"] = (f"NOT measured in this run: {tr['total_bytes_per_update']:.1f} B per update (FETCH_SIZE x2 + "
+                                 f"WRITE_SIZE, separate rocprofv3 --pmc passes of this command, profiles/{PROFILE_TAG}_hbm_traffic_"
+                                 f"{args_config}.json) x this run's updates per launch")
+        out["traffic_over_moved_bytes"] = tr["total_bytes_per_update"] / b_moved
+    else:
+        out["traffic"] = None
+    pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json") if args_config == "smc32" and ld == 32 else None
+    if pc:
+        out["pattern_ceiling"] = {"updates_per_s": pc["updates_per_s"], "read_frac": pc["updates_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
+                                  "source": pc.get("source", f"profiles/{PROFILE_TAG}_pattern_ceiling.json"),
+                                  "what": "the sweep's memory-access pattern with all arithmetic removed (tools/layout_bench.hip), "
+                                          "same population; the exact algorithm cannot run faster on this part"}
+    return out
+
+
+args_config = "smc32"
+
+
 def main():
+    global args_config
     args = parse()
+    args_config = args.config
     import torch
     import torch.distributed as dist
 
     import abcdez_amd as A
     from abcdez_amd.engine import HipEngine
+
+    cfg = CONFIGS[args.config](A, args)
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    warmup = args.warmup if args.warmup is not None else cfg["warmup"]
+    ppg = args.particles_per_gpu or cfg["ppg"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,30 +346,28 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         pg = dist.group.WORLD
 
-    d = args.dim
-    prior = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(d)])
-    sim = A.MVNormal(tuple([1.0] * d))
-    eps_target = 6.0 * math.sqrt(d / 32.0)
-    N = args.particles_per_gpu * world
-    spec = A.ModelSpec(prior, sim, seed=1)
-    eng = HipEngine(spec, N, pg, lanes=args.lanes, force_collectives=args.force_collectives)
+    d = cfg["d"]
+    N = ppg * world
+    spec = A.ModelSpec(cfg["prior"], cfg["sim"], seed=1)
+    eng = HipEngine(spec, N, pg, lanes=args.lanes, storage=cfg["storage"], force_collectives=args.force_collectives)
     ld, L, C = eng.ops.layout()
     eng.init_population()
-    eng.reset_weights()
-    gen = Generation(eng, d, eps_target)
+    if cfg["kind"] == "smc":
+        eng.reset_weights()
+    gen = make_loop(cfg, eng)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         gen.step()
     eng.ops.set_timing(True)
-    u0, s0 = gen.updates, gen.sweeps
+    u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         gen.step()
     barrier()
     dt = time.perf_counter() - t0
@@ -205,7 +377,10 @@ def main():
         dt = float(t.item())
     updates = gen.updates - u0          # global particle-updates (all ranks)
     kern_ms, launches, units = eng.ops.get_timing()   # this rank's sweep kernel
-    sweeps_timed, resamples_timed = gen.sweeps - s0, gen.resamples
+    eng.ops.set_timing(False)
+    window = dict(sweeps=gen.sweeps - s0, resamples=getattr(gen, "resamples", 0) - r0,
+                  eps=getattr(gen, "eps", None), logZ=getattr(gen, "logZ", None))
+    acc_rate = (gen.naccs - a0) / max(updates, 1) if cfg["kind"] == "smc" else 0.0
     phases = {}
     if eng.sharded_rows:
         # device-event breakdown of the sharded sweep, taken on three EXTRA generations after the timed region
@@ -215,50 +390,71 @@ def main():
             gen.step()
         phases = eng.phase_timing()
 
+    # ---- the whole run next to the window: from a fresh population to eps_target (device-resident, no result download)
+    whole = None
+    if cfg["kind"] == "smc" and not args.no_whole_run and not eng.sharded_rows:
+        whole = {}
+        models = [("model", cfg["prior"])] if args.config != "evidence1d" else \
+            [("model1_prior_N(0,sqrt10)", cfg["prior"]), ("model2_prior_N(0,sqrt100)", A.Normal(0.0, math.sqrt(100.0)))]
+        for name, prior in models:
+            e2 = eng
+            if prior is not cfg["prior"]:
+                e2 = HipEngine(A.ModelSpec(prior, cfg["sim"], seed=1), N, pg, lanes=args.lanes, storage=cfg["storage"])
+            barrier()
+            t1 = time.perf_counter()
+            e2.init_population()
+            e2.reset_weights()
+            g2 = Generation(e2, d, cfg["eps_target"])
+            while not g2.done() and g2.generations < 5000:
+                g2.step()
+            barrier()
+            dtw = time.perf_counter() - t1
+            whole[name] = {"generations": g2.generations, "sweeps": g2.sweeps, "updates": g2.updates, "seconds": dtw,
+                           "value": g2.updates / dtw, "logZ": g2.logZ, "eps": g2.eps, "resamples": g2.resamples,
+                           "includes": "abcde_init! + every generation down to eps_target; not the result download"}
+        if args.config == "evidence1d":
+            z1, z2 = whole[models[0][0]]["logZ"], whole[models[1][0]]["logZ"]
+            whole["bayes_factor"] = math.exp(z1 - z2)
+            whole["exact"] = {"logZ1": -3.038051357, "logZ2": -3.782014144, "bayes_factor": 2.1043}
+        elif cfg["exact_logZ"] is not None:
+            whole["model"]["logZ_exact"] = cfg["exact_logZ"]
+
     if rank == 0:
-        # algorithmic bytes per particle-update: reads 24 ld + 17, writes 8 ld + 16
-        b_read, b_write = 24 * ld + 17, 8 * ld + 16
-        avg_ms = kern_ms / max(launches, 1)
-        units_per_launch = units / max(launches, 1)
-        ach = (b_read + b_write) * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        tpu = measured_traffic_per_update() if (d == 32 and L == 4) else None
         out = {
-            "metric": "particle-updates/sec per SMC generation",
+            "metric": "particle-updates/sec per SMC generation" if cfg["kind"] == "smc" else "particle-updates/sec per abcdemc generation",
             "value": updates / dt,
             "unit": "particle-updates/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"abcdesmc d={d} MVN simulator + Euclidean distance, {args.particles_per_gpu} particles/GPU "
-                            f"(BASELINE.json configs[2]); alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
+                "workload": f"{cfg['workload']}; {ppg} particles/GPU", "name": args.config,
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
-                "sweeps": sweeps_timed, "resamples": resamples_timed, "eps": gen.eps, "logZ": gen.logZ,
+                "timed_window": window,
+                "step_includes": ("quantile, reweight, resample when ESS < N/2, alive compaction, <= Kmcmc sweeps with "
+                                  "their counter read-backs, extrema(Ds) (smc:301-364)") if cfg["kind"] == "smc" else
+                                 "rank pass (while max Ds > eps_target), one sweep with nsim / completion / extrema folded in (mc:140-161)",
                 "parallelism": (f"particle-shard x{world}, replicated row store: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
-            "roofline": {
-                "kernel": "smc_swarm_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "traffic": tpu * units_per_launch if tpu else None,          # bytes per launch (PMC), cf. algorithmic below
-                "algorithmic_bytes_per_launch": (b_read + b_write) * units_per_launch,
-                "bytes_per_update": b_read + b_write, "updates_per_launch": units_per_launch,
-                "avg_launch_ms": avg_ms, "launches": launches,
-                "read_only_achieved": b_read * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                "read_only_frac": b_read * units_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_ms > 0 else 0.0,
-                "kernel_updates_per_s": units_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0,
-            },
+            "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate),
         }
+        if cfg["kind"] == "mc":
+            out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
+        if whole is not None:
+            out["whole_run"] = whole
         if eng.sharded_rows:    # rank 0's device-event breakdown of the sharded sweep
             out["sharded_phases_ms"] = {k: {"calls": c, "avg_ms": (t / c if c else 0.0)} for k, (c, t) in phases.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline_reference_faithful"], out["cpu_baseline"] = cpu_baseline(args, prior, sim, eps_target)
+            faithful, out["cpu_baseline"] = cpu_baseline(A, args, cfg)
+            if faithful:
+                out["cpu_baseline_reference_faithful"] = faithful
         try:                      # RCCL's start-up banner sits in libc's stdio buffer: push it out BEFORE the result line
             import ctypes
             ctypes.CDLL(None).fflush(None)

@@ -180,14 +180,23 @@ ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, 
 
 /* S4  abcdemc_swarm!(prior, dist!, varexternal, thetas, logpi, Ds, nthetas, nlogpi, nDs,
  *     eps_pop, eps_target, gamma0, gamma_sigma, nparticles, nsims, rng, ex, nblobs)
- *     src/abcdez_mc.jl:5-61 plus the copies of :140-143.  rank_prepare builds the
- *     (Ds, index)-sorted order the "better particle" draw of mc:23 indexes into.     */
-ABCDEZ_API int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, uint32_t* order, double* sorted_delta);
+ *     src/abcdez_mc.jl:5-61 plus the copies of :140-143.
+ *     rank_prepare builds the enumeration the "better particle" draw of mc:23 indexes into -- the particles with
+ *     Ds <= eps_pop in index order, then the others sorted by (Ds, index); sorted_delta[p] = max(Ds[order[p]], eps_pop)
+ *     -- with hand-written kernels (bucket ids over the window (eps_pop, dmax_hint], stable LSD radix passes, fix-up
+ *     of shared buckets).  dmax_hint: maximum(Ds) as the driver knows it from mc:146; it only shapes the binning,
+ *     any value gives the same result.  Asynchronous (no host synchronisation).
+ *     mc_swarm also returns the reductions the driver takes of the generation it leaves behind, over the
+ *     particles [i0, i0+n_local): n_above_target = sum(nDs .> eps_target) (mc:156), (dmin, dmax) = extrema(nDs)
+ *     (mc:146,163) -- any of the three pointers may be NULL.                                                    */
+ABCDEZ_API int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
+                           uint32_t* order, double* sorted_delta);
 ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N,
                     const double* theta, const double* logpi, const double* delta,
                     double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma,
-                    int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim);
+                    int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim, int64_t* n_above_target,
+                    double* dmin, double* dmax);
 
 /* T2  push_p over the population (src/abcdez_types.jl:20-23; result P, smc:382, mc:166). */
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);

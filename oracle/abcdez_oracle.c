@@ -729,6 +729,191 @@ ORC_API void orc_smc_resample_gather_rows(const abz_model* M, const uint32_t* in
   for (int64_t s = 0; s < N; ++s) cur_row[s] ^= 0x80000000u;
 }
 
+/* ---------------------------------------------------------------- packed population: alive particles form a prefix
+ * SPEC (deviation from the reference's "a particle keeps its index for life"): after every
+ * reweight that kills particles the population is PARTITIONED -- the k-th dead position below n_new (the new number
+ * of alive particles) swaps its whole state with the k-th alive position at or above n_new -- so that the alive
+ * particles are the positions [0, n_alive).  Everything is keyed by position (random numbers, donor ranks, summation
+ * trees, strata).  The reference's algorithm is symmetric under relabelling of the particles (smc:106-153 treats
+ * every alive index alike; results are exchangeable), so the law of every output is unchanged; what the device gains
+ * is that "alive rank r" IS "position r": no alive list, no index look-ups in front of the donor rows.
+ * n_prev = length of the alive prefix before the reweight.  Returns n_new.                                       */
+ORC_API int64_t orc_smc_partition(const abz_model* M, int64_t n_prev, uint8_t* alive, double* theta, double* logpi,
+                                  double* delta, double* wns) {
+  const int ld = M->ld;
+  int64_t n_new = 0;
+  for (int64_t p = 0; p < n_prev; ++p) n_new += alive[p] != 0;
+  int64_t h = 0, f = n_new;
+  double tmp[ABZ_MAX_D];
+  for (;;) {
+    while (h < n_new && alive[h]) ++h;
+    while (f < n_prev && !alive[f]) ++f;
+    if (h >= n_new || f >= n_prev) break;
+    memcpy(tmp, theta + h * ld, (size_t)ld * 8);
+    memcpy(theta + h * ld, theta + f * ld, (size_t)ld * 8);
+    memcpy(theta + f * ld, tmp, (size_t)ld * 8);
+    double t;
+    t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
+    t = delta[h]; delta[h] = delta[f]; delta[f] = t;
+    t = wns[h]; wns[h] = wns[f]; wns[f] = t;
+    alive[h] = 1; alive[f] = 0;
+    if (g_stamp_cur) { uint64_t u = g_stamp_cur[h]; g_stamp_cur[h] = g_stamp_cur[f]; g_stamp_cur[f] = u; }
+    ++h; ++f;
+  }
+  return n_new;
+}
+
+/* The same population in the device's storage: two row slots per position (slot0[N][ld], slot1[N][ld]) and one bit
+ * per position naming the current one (bits, 32 positions per word, position p = bit p % 32 of word p / 32).  An
+ * accepted proposal goes to the position's OTHER slot and its bit flips in bits_out; log-prior and distance are
+ * updated in place.  Checker for abcdez_smc_partition / abcdez_smc_swarm_packed / abcdez_smc_replay_packed /
+ * abcdez_smc_resample_gather_packed / abcdez_packed_gather (include/abcdez_hip.h).                               */
+#define ORC_PBIT(bits, p) (((bits)[(p) >> 5] >> ((p) & 31)) & 1u)
+#define ORC_PROW(slot0, slot1, bit, p, ld) ((bit) ? (slot1) : (slot0)) + (int64_t)(p) * (ld)
+
+ORC_API int64_t orc_packed_partition(const abz_model* M, int64_t N, int64_t n_prev, uint8_t* alive, const uint32_t* bits,
+                                     uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta,
+                                     double* wns) {
+  const int ld = M->ld;
+  int64_t n_new = 0;
+  for (int64_t p = 0; p < n_prev; ++p) n_new += alive[p] != 0;
+  int64_t h = 0, f = n_new;
+  double tmp[ABZ_MAX_D];
+  for (;;) {
+    while (h < n_new && alive[h]) ++h;
+    while (f < n_prev && !alive[f]) ++f;
+    if (h >= n_new || f >= n_prev) break;
+    double* rh = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, h), h, ld));     /* contents swap, bits stay */
+    double* rf = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, f), f, ld));
+    memcpy(tmp, rh, (size_t)ld * 8); memcpy(rh, rf, (size_t)ld * 8); memcpy(rf, tmp, (size_t)ld * 8);
+    double t;
+    t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
+    t = delta[h]; delta[h] = delta[f]; delta[f] = t;
+    t = wns[h]; wns[h] = wns[f]; wns[f] = t;
+    alive[h] = 1; alive[f] = 0;
+    if (g_stamp_cur) { uint64_t u = g_stamp_cur[h]; g_stamp_cur[h] = g_stamp_cur[f]; g_stamp_cur[f] = u; }
+    ++h; ++f;
+  }
+  for (int64_t w = 0; w < (N + 31) / 32; ++w) bits_other[w] = bits[w];   /* both bit arrays agree outside the sweeps */
+  return n_new;
+}
+
+ORC_API void orc_packed_gather(const uint32_t* bits, int64_t N, int ld, const double* slot0, const double* slot1, double* out) {
+  for (int64_t p = 0; p < N; ++p) memcpy(out + p * ld, ORC_PROW(slot0, slot1, ORC_PBIT(bits, p), p, ld), (size_t)ld * 8);
+}
+
+/* the proposal of position r (alive rank r): smc:119-128 */
+static void packed_proposal(const abz_model* M, const uint32_t* bits, int64_t n_alive, const double* slot0,
+                            const double* slot1, uint32_t r, double gamma0, double gsig, uint32_t sweep, double* tp) {
+  const int ld = M->ld;
+  uint32_t ra, rb;
+  abz_donor_ranks(abz_rng(M->seed, r, sweep, 0, ABZ_RNG_DONOR), (uint32_t)n_alive, r, &ra, &rb);
+  const double* ti = ORC_PROW(slot0, slot1, ORC_PBIT(bits, r), r, ld);
+  const double* ta = ORC_PROW(slot0, slot1, ORC_PBIT(bits, ra), ra, ld);
+  const double* tb = ORC_PROW(slot0, slot1, ORC_PBIT(bits, rb), rb, ld);
+  double z0, z1;
+  abz_normal_pair(abz_rng(M->seed, r, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
+  const double g = gamma0 * (1.0 + z0 * gsig);
+  for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
+}
+
+/* positions [r_lo, r_hi) of the alive prefix [0, n_alive); flags[p]: bit 0 accepted, bit 1 simulated (may be NULL).
+ * bits_out gets the new bit of every position in [r_lo, r_hi); r_lo and r_hi must be multiples of 32 or the ends of
+ * the prefix so that no word is shared with another caller.                                                    */
+ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
+                                  int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta,
+                                  uint8_t* flags, double eps, double gamma0, double gsig, uint32_t sweep,
+                                  int64_t* nacc_out, int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t nacc = 0, nsim = 0;
+  uint8_t* acc_tmp = (uint8_t*)calloc((size_t)(r_hi - r_lo) + 1, 1);
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+  for (int64_t r = r_lo; r < r_hi; ++r) {
+    const uint32_t i = (uint32_t)r;
+    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+    packed_proposal(M, bits, n_alive, slot0, slot1, i, gamma0, gsig, sweep, tp);
+    push_row(M, tp, pp);
+    const double lp = logprior_tree(M, pp);                                          /* smc:134 */
+    int acc = 0, simulated = 0;
+    if (!(lp < 0.0 && !abz_isfinite(lp) && !abz_isnan(lp))) {                        /* smc:135 */
+      const double dp = sim_dist(M, pp, i, sweep, ABZ_RNG_SIM);                      /* smc:137 */
+      nsim += 1;
+      simulated = 1;
+      const double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i]));
+      acc = (0.0 <= w);
+      if (!acc) acc = abz_log_tab(abz_u01_open(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T) < w;  /* smc:145 */
+      if (acc) {                                                                     /* smc:146-150 */
+        double* to = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, i) ^ 1u, i, ld));
+        for (int k = 0; k < ld; ++k) to[k] = tp[k];
+        logpi[i] = lp; delta[i] = dp;
+        if (g_stamp_cur) g_stamp_cur[i] = abz_stamp(i, sweep, 0);
+        nacc += 1;
+      }
+    }
+    acc_tmp[r - r_lo] = (uint8_t)acc;
+    if (flags) flags[i] = (uint8_t)(acc | (simulated << 1));
+  }
+  for (int64_t r = r_lo; r < r_hi; ++r) {          /* sequential: several positions share a word */
+    const uint32_t m = 1u << (r & 31);
+    const uint32_t cur = bits[r >> 5] & m;
+    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | (acc_tmp[r - r_lo] ? (cur ^ m) : cur);
+  }
+  free(acc_tmp);
+  *nacc_out = nacc; *nsim_out = nsim;
+}
+
+/* what a replica does for the positions it does not own: rebuild the accepted proposals (and their log-priors)
+ * from the flags; counts both flag bits over the whole alive prefix */
+ORC_API void orc_smc_replay_packed(const abz_model* M, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
+                                   int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, double* logpi,
+                                   const uint8_t* flags, double gamma0, double gsig, uint32_t sweep, int64_t* nacc_out,
+                                   int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t nacc = 0, nsim = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+  for (int64_t r = 0; r < n_alive; ++r) {
+    nacc += flags[r] & 1;
+    nsim += (flags[r] >> 1) & 1;
+    if (r >= skip_lo && r < skip_hi) continue;
+    if (flags[r] & 1) {
+      double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+      packed_proposal(M, bits, n_alive, slot0, slot1, (uint32_t)r, gamma0, gsig, sweep, tp);
+      double* to = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, r) ^ 1u, r, ld));
+      for (int k = 0; k < ld; ++k) to[k] = tp[k];
+      push_row(M, tp, pp);
+      logpi[r] = logprior_tree(M, pp);              /* the owner stored the same value (smc:147) */
+    }
+  }
+  for (int64_t r = 0; r < n_alive; ++r) {
+    if (r >= skip_lo && r < skip_hi) continue;
+    const uint32_t m = 1u << (r & 31);
+    const uint32_t cur = bits[r >> 5] & m;
+    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | ((flags[r] & 1) ? (cur ^ m) : cur);
+  }
+  *nacc_out = nacc; *nsim_out = nsim;
+}
+
+/* S8 on the packed store: source = current row of inds[s], destination = the OTHER slot of s (never a current row);
+ * afterwards every bit flips -- in both bit arrays */
+ORC_API void orc_smc_resample_gather_packed(const abz_model* M, const uint32_t* inds, int64_t N, uint32_t* bits,
+                                            uint32_t* bits_other, double* slot0, double* slot1, const double* logpi,
+                                            const double* delta, double* nlogpi, double* ndelta, double* wns,
+                                            uint8_t* alive) {
+  const int ld = M->ld;
+#pragma omp parallel for schedule(static)
+  for (int64_t s = 0; s < N; ++s) {
+    const int64_t j = inds[s];
+    memcpy((double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, s) ^ 1u, s, ld)), ORC_PROW(slot0, slot1, ORC_PBIT(bits, j), j, ld),
+           (size_t)ld * sizeof(double));                                   /* smc:96 */
+    nlogpi[s] = logpi[j];                                                  /* smc:97 */
+    ndelta[s] = delta[j];                                                  /* smc:98 */
+    if (g_stamp_nxt) g_stamp_nxt[s] = g_stamp_cur[j];                      /* smc:99 */
+    wns[s] = 1.0 / (double)N;                                              /* smc:102 */
+    alive[s] = 1;                                                          /* smc:103 */
+  }
+  for (int64_t w = 0; w < (N + 31) / 32; ++w) { bits[w] = ~bits[w]; bits_other[w] = bits[w]; }
+}
+
 /* ---------------------------------------------------------------- S9: quantile(Ds[alive], alpha)  (smc:301)
  * Statistics.quantile default = type 7: h = (n-1) p + 1; j = clamp(floor(h), 1, n-1);
  * g = h - j; q = x_(j) + g (x_(j+1) - x_(j)).                                       */
@@ -786,11 +971,18 @@ static int cmp_key(const void* a, const void* b) {
   if (x->d > y->d) return 1;
   return (x->i > y->i) - (x->i < y->i);
 }
-ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, uint32_t* order, double* sorted_delta) {
+/* order = [particles with Ds <= eps_pop, in index order] ++ [the others sorted by (Ds, index)];
+ * sorted_delta[p] = max(Ds[order[p]], eps_pop) (non-decreasing).  A draw (mc:20-24) happens only for Ds[i] > eps_pop,
+ * and every particle of the first block then belongs to the candidate set {j : Ds[j] <= Ds[i]}, so the first block
+ * needs no sorting: the enumeration differs from "all sorted" only inside that block -- same set, same law.      */
+ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, double eps_pop, uint32_t* order, double* sorted_delta) {
   orc_key* k = (orc_key*)malloc((size_t)N * sizeof(orc_key));
-  for (int64_t i = 0; i < N; ++i) { k[i].d = delta[i]; k[i].i = (uint32_t)i; }
-  qsort(k, (size_t)N, sizeof(orc_key), cmp_key);
-  for (int64_t i = 0; i < N; ++i) { order[i] = k[i].i; sorted_delta[i] = k[i].d; }
+  int64_t nA = 0, nB = 0;
+  for (int64_t i = 0; i < N; ++i)
+    if (delta[i] <= eps_pop) { order[nA] = (uint32_t)i; sorted_delta[nA] = eps_pop; ++nA; }
+    else { k[nB].d = delta[i]; k[nB].i = (uint32_t)i; ++nB; }
+  qsort(k, (size_t)nB, sizeof(orc_key), cmp_key);
+  for (int64_t i = 0; i < nB; ++i) { order[nA + i] = k[i].i; sorted_delta[nA + i] = k[i].d; }
   free(k);
 }
 static int64_t upper_bound_d(const double* v, int64_t n, double x) { /* #elements <= x */

@@ -18,6 +18,7 @@
 
 int orc_init(const abz_model*, double*, double*, double*, int64_t, int64_t);
 int64_t orc_alive_compact(const uint8_t*, int64_t, uint32_t*, uint32_t*);
+int64_t orc_smc_partition(const abz_model*, int64_t, uint8_t*, double*, double*, double*, double*);
 void orc_smc_swarm(const abz_model*, const uint32_t*, const uint32_t*, int64_t, const double*, const double*,
                    const double*, double*, double*, double*, double, double, double, int64_t, int64_t, uint32_t,
                    int64_t*, int64_t*);
@@ -29,7 +30,7 @@ void orc_smc_resample_gather(const abz_model*, const uint32_t*, int64_t, int64_t
 double orc_quantile_alive(const double*, const uint8_t*, int64_t, double, double*, double*);
 void orc_extrema(const double*, int64_t, double*, double*);
 int64_t orc_count_gt(const double*, int64_t, double);
-void orc_mc_rank_prepare(const double*, int64_t, uint32_t*, double*);
+void orc_mc_rank_prepare(const double*, int64_t, double, uint32_t*, double*);
 void orc_mc_swarm(const abz_model*, const uint32_t*, const double*, int64_t, const double*, const double*,
                   const double*, double*, double*, double*, double, double, double, double, int64_t, int64_t,
                   uint32_t, int64_t*);
@@ -57,6 +58,8 @@ typedef struct {
   double eps, logZ;
   int64_t iters, nsims_total, updates_total; /* updates = sum over sweeps of n_alive */
   int32_t n_hist, no_alive;
+  /* in: 1 = packed population (abcdez_oracle.c, orc_smc_partition): alive particles are kept as a prefix */
+  int32_t packed, reserved;
 } orc_smc_run;
 
 /* Outputs: theta[N][ld] (unpushed internal state), logpi, delta (= r.C), wns, alive;
@@ -84,6 +87,7 @@ ORC_API int orc_abcdesmc(const abz_model* M, orc_smc_run* R,
   int64_t nsims_total = 0, updates = 0, iters = 0;
   uint32_t sweep = 0, draw = 0;
   int nh = 0, no_alive = 0;
+  int64_t n_prev = N;                 /* packed: length of the alive prefix */
   if (rc == 0) {
     double lo, hi; orc_extrema(cur.delta, N, &lo, &hi);             /* smc:284-292 */
     h_eps[nh] = eps; h_lo[nh] = lo; h_hi[nh] = hi; h_logZ[nh] = logZ; h_ess[nh] = orc_get_ess(wns, N);
@@ -106,9 +110,14 @@ ORC_API int orc_abcdesmc(const abz_model* M, orc_smc_run* R,
       pop_swap(&cur, &nxt);
       ess = orc_get_ess(wns, N);
       n_alive = N;
+      n_prev = N;
+    }
+    if (R->packed && n_alive < n_prev) {
+      orc_smc_partition(M, n_prev, alive, cur.theta, cur.logpi, cur.delta, wns);
+      n_prev = n_alive;
     }
     if (n_alive >= 3) {                /* the reference's donor loops need 3 alive (smc:119-126) */
-      orc_alive_compact(alive, N, alive_idx, arank);
+      orc_alive_compact(alive, N, alive_idx, arank);   /* packed: the identity over [0, n_alive) */
       for (int k = 1; k <= R->Kmcmc; ++k) {                         /* smc:336-353 */
         int64_t nacc, nsim;
         orc_smc_swarm(M, alive_idx, arank, n_alive, cur.theta, cur.logpi, cur.delta,
@@ -165,7 +174,7 @@ ORC_API int orc_abcdemc(const abz_model* M, orc_mc_run* R, double* theta_out, do
     double lo, hi;
     orc_extrema(cur.delta, N, &lo, &hi);                            /* mc:146 */
     double eps_pop = fmax(R->eps_target, lo + 0.0 * (hi - lo));     /* mc:147, alpha = 0 (mc:107) */
-    if (hi > R->eps_target) orc_mc_rank_prepare(cur.delta, N, order, sorted);   /* only consulted when D_i > eps */
+    if (hi > R->eps_target) orc_mc_rank_prepare(cur.delta, N, eps_pop, order, sorted);   /* only consulted when D_i > eps */
     int64_t nsim;
     orc_mc_swarm(M, order, sorted, N, cur.theta, cur.logpi, cur.delta, nxt.theta, nxt.logpi, nxt.delta,
                  eps_pop, R->eps_target, gamma0, gsig, 0, N, (uint32_t)it, &nsim);           /* mc:149 */

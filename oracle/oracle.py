@@ -41,7 +41,7 @@ class SmcRun(C.Structure):
         ("nparticles", _i64), ("eps_target", _f64), ("alpha", _f64), ("delta_ess", _f64), ("nsims_max", _i64),
         ("Kmcmc", _i32), ("max_iters", _i32), ("Kmcmc_min", _f64), ("facc_stop", _f64), ("facc_min", _f64),
         ("facc_tune", _f64), ("eps", _f64), ("logZ", _f64), ("iters", _i64), ("nsims_total", _i64),
-        ("updates_total", _i64), ("n_hist", _i32), ("no_alive", _i32),
+        ("updates_total", _i64), ("n_hist", _i32), ("no_alive", _i32), ("packed", _i32), ("reserved", _i32),
     ]
 
 
@@ -109,6 +109,15 @@ def lib():
                                      _pi64, _pi64]
     L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64]
     L.orc_smc_resample_gather_rows.argtypes = [_vp] * 2 + [_i64] + [_vp] * 9
+    L.orc_smc_partition.restype = _i64
+    L.orc_smc_partition.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp]
+    L.orc_packed_partition.restype = _i64
+    L.orc_packed_partition.argtypes = [_vp, _i64, _i64] + [_vp] * 8
+    L.orc_packed_gather.argtypes = [_vp, _i64, C.c_int, _vp, _vp, _vp]
+    L.orc_smc_swarm_packed.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
+                                       _pi64, _pi64]
+    L.orc_smc_replay_packed.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64]
+    L.orc_smc_resample_gather_packed.argtypes = [_vp, _vp, _i64] + [_vp] * 10
     L.orc_set_stamps.argtypes = [_vp, _vp]
     L.orc_blob_eval.argtypes = [_vp, _vp, _vp, _i64, _vp, C.c_int, _vp]
     L.orc_quantile_alive.restype = _f64
@@ -116,7 +125,7 @@ def lib():
     L.orc_extrema.argtypes = [_vp, _i64, _pf64, _pf64]
     L.orc_count_gt.restype = _i64
     L.orc_count_gt.argtypes = [_vp, _i64, _f64]
-    L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _vp, _vp]
+    L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _f64, _vp, _vp]
     L.orc_mc_swarm.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64,
                                _u32, _pi64]
     L.orc_abcdesmc.argtypes = [_vp, C.POINTER(SmcRun)] + [_vp] * 13
@@ -209,6 +218,34 @@ class OracleOps:
     def rows_gather(self, cur_row, slot0, slot1, out):
         self.L.orc_rows_gather(_p(cur_row), cur_row.numel(), self.spec.ld, _p(slot0), _p(slot1), _p(out))
 
+    # ---- packed store (checker for the abcdez_*_packed entry points) ----
+    supports_packed = True
+
+    def smc_partition(self, n_prev, n_new, alive, bits, bits_other, slot0, slot1, logpi, delta, wns):
+        got = self.L.orc_packed_partition(self.m.ptr, alive.numel(), n_prev, _p(alive), _p(bits), _p(bits_other), _p(slot0),
+                                          _p(slot1), _p(logpi), _p(delta), _p(wns))
+        assert got == n_new, (got, n_new)
+
+    def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
+                         sweep, want_counts=True):
+        nacc, nsim = _i64(), _i64()
+        self.L.orc_smc_swarm_packed(self.m.ptr, _p(bits), _p(bits_out), n_alive, r_lo, r_hi, _p(slot0), _p(slot1),
+                                    _p(logpi), _p(delta), _p(flags), eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
+        return nacc.value, nsim.value
+
+    def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
+        nacc, nsim = _i64(), _i64()
+        self.L.orc_smc_replay_packed(self.m.ptr, _p(bits), _p(bits_out), n_alive, skip_lo, skip_hi, _p(slot0), _p(slot1),
+                                     _p(logpi), _p(flags), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
+        return nacc.value, nsim.value
+
+    def smc_resample_gather_packed(self, inds, bits, bits_other, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
+        self.L.orc_smc_resample_gather_packed(self.m.ptr, _p(inds), inds.numel(), _p(bits), _p(bits_other), _p(slot0),
+                                              _p(slot1), _p(logpi), _p(delta), _p(nlogpi), _p(ndelta), _p(wns), _p(alive))
+
+    def packed_gather(self, bits, slot0, slot1, out):
+        self.L.orc_packed_gather(_p(bits), out.shape[0], self.spec.ld, _p(slot0), _p(slot1), _p(out))
+
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
         wnorm, ess, na = _f64(), _f64(), _i64()
         self.L.orc_smc_reweight(self.spec.abck, _p(delta), _p(wns), _p(alive), delta.numel(), eps_old, eps_new,
@@ -241,15 +278,18 @@ class OracleOps:
     def count_gt(self, delta, thr) -> int:
         return self.L.orc_count_gt(_p(delta), delta.numel(), thr)
 
-    def mc_rank_prepare(self, delta, order, sorted_delta):
-        self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), _p(order), _p(sorted_delta))
+    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta):
+        self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), eps_pop, _p(order), _p(sorted_delta))
 
     def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep) -> int:
         nsim = _i64()
         self.L.orc_mc_swarm(self.m.ptr, _p(order), _p(sorted_delta), cur[1].numel(), _p(cur[0]), _p(cur[1]),
                             _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0,
                             n_local, sweep, C.byref(nsim))
-        return nsim.value
+        nd = nxt[2][i0:i0 + n_local]            # the driver reductions of the new generation, over this call's particles
+        if n_local == 0:
+            return nsim.value, 0, float("inf"), float("-inf")
+        return nsim.value, int((nd > eps_target).sum()), float(nd.min()), float(nd.max())
 
     def push_p(self, theta, out):
         self.L.orc_push_p(self.m.ptr, _p(theta), theta.shape[0], _p(out))
@@ -280,7 +320,7 @@ def oracle_engine(spec, nparticles, process_group=None, storage="classic"):
 
 
 def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0,
-                 facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000):
+                 facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000, packed=False):
     """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c)."""
     L = lib()
     L.orc_set_stamps(None, None)      # the C drivers carry no blobs: unbind stamp arrays an earlier engine left behind
@@ -288,7 +328,7 @@ def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_
     N, ld = nparticles, spec.ld
     R = SmcRun(nparticles=N, eps_target=eps_target, alpha=alpha, delta_ess=delta_ess, nsims_max=nsims_max,
                Kmcmc=Kmcmc, max_iters=max_iters, Kmcmc_min=Kmcmc_min, facc_stop=facc_stop, facc_min=facc_min,
-               facc_tune=facc_tune)
+               facc_tune=facc_tune, packed=int(packed))
     theta = np.zeros((N, ld)); logpi = np.zeros(N); delta = np.zeros(N); wns = np.zeros(N)
     alive = np.zeros(N, dtype=np.uint8)
     H = max_iters + 2

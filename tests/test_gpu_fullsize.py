@@ -68,8 +68,9 @@ def test_remaining_simulators_parity(oracle, which):
                 assert torch.equal(hip.state[k].cpu().view(torch.int64), orc.state[k].view(torch.int64))
         eps_old = eps
     # abcdemc path on the same model
-    hip.mc_rank_prepare(); orc.mc_rank_prepare()
-    lo, _ = orc.extrema()
+    lo, hi = orc.extrema()
+    hip.mc_rank_prepare(lo, hi); orc.mc_rank_prepare(lo, hi)
+    assert torch.equal(hip.order.cpu(), orc.order)
     assert hip.mc_swarm(lo, 0.0, g0, 1e-5) == orc.mc_swarm(lo, 0.0, g0, 1e-5)
     assert torch.equal(hip.state[0].cpu().view(torch.int64), orc.state[0].view(torch.int64))
 
@@ -340,10 +341,19 @@ def test_config2_abcdemc_one_million_particles(oracle):
         assert hi <= prev_max                                            # mc:54: max distance never grows
         prev_max = hi
         if hi > 0.3:
-            eng.mc_rank_prepare()
+            eps_pop = max(0.3, lo)
+            eng.mc_rank_prepare(eps_pop, hi)
             sd = eng.sorted_delta
             assert bool((sd[1:] >= sd[:-1]).all())
-            assert torch.equal(eng.state[2][eng.order.to(torch.int64)], sd)
+            assert torch.equal(eng.state[2][eng.order.to(torch.int64)].clamp_min(eps_pop), sd)
+            assert torch.equal(eng.order.to(torch.int64).sort().values, torch.arange(N, device="cuda"))   # a permutation
+            n_a = int((eng.state[2] <= eps_pop).sum())
+            head = eng.order[:n_a].to(torch.int64)
+            assert bool((head[1:] > head[:-1]).all()) and bool((eng.state[2][head] <= eps_pop).all())       # first block: index order
+            if gen in (0, 5, 30):              # the whole enumeration against the oracle's (stable partition + qsort)
+                oo, os_ = torch.zeros(N, dtype=torch.int32), torch.zeros(N, dtype=torch.float64)
+                oracle.OracleOps(spec).mc_rank_prepare(eng.state[2].cpu(), eps_pop, hi, oo, os_)
+                assert torch.equal(eng.order.cpu(), oo) and torch.equal(sd.cpu().view(torch.int64), os_.view(torch.int64))
         if gen == 5:
             th, lp, dl = (t.cpu().contiguous() for t in eng.state)
             order, sd_h = eng.order.cpu().contiguous(), eng.sorted_delta.cpu().contiguous()
@@ -359,9 +369,10 @@ def test_config2_abcdemc_one_million_particles(oracle):
             assert torch.equal(eng.state[0].cpu().view(torch.int64), nth.view(torch.int64))
             assert torch.equal(eng.state[2].cpu().view(torch.int64), ndl.view(torch.int64))
         else:
-            eng.mc_swarm(max(0.3, lo), 0.3, g0, 1e-5)
+            nsim_g, n_above, lo_g, hi_g = eng.mc_swarm(max(0.3, lo), 0.3, g0, 1e-5)
+            assert (lo_g, hi_g) == eng.extrema() and n_above == eng.count_gt(0.3)      # reductions folded into the sweep
     assert eng.count_gt(0.3) <= 0.02 * N                                 # completion >= 98 % after 60 generations (mc:156)
-    assert eng.extrema()[1] == 0.9571381847990836                        # same value the CPU oracle reaches (seed 3)
+    assert eng.extrema()[1] == 1.0790868611451696                        # same value the CPU oracle reaches (seed 3; oracle.run_abcdemc)
     post = eng.state[0][:, 0]
     assert abs(float(post.mean()) - 30 / 11) < 0.015     # finite-eps bias 0.0075 + Monte Carlo error
     assert abs(float(post.std()) - math.sqrt(10 / 11)) < 0.03

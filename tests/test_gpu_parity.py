@@ -349,10 +349,15 @@ def test_mc_sweep_parity(oracle, name):
     for gen in range(6):
         lo, hi = orc.extrema()
         assert hip.extrema() == (lo, hi)
-        hip.mc_rank_prepare(); orc.mc_rank_prepare()
-        assert same(hip.order, orc.order) and same(hip.sorted_delta, orc.sorted_delta)
         eps_pop = max(eps_target, lo)
-        assert hip.mc_swarm(eps_pop, eps_target, gamma0, 1e-5) == orc.mc_swarm(eps_pop, eps_target, gamma0, 1e-5)
+        # a hint that is too small, exact, or far too large only changes the binning, never the result
+        hip.mc_rank_prepare(eps_pop, (0.5 * hi, hi, 1e6 * hi + 1.0)[gen % 3]); orc.mc_rank_prepare(eps_pop, hi)
+        assert same(hip.order, orc.order) and same(hip.sorted_delta, orc.sorted_delta)
+        sd = orc.sorted_delta
+        assert bool((sd[1:] >= sd[:-1]).all())                      # upper_bound(sorted_delta, Ds[i]) is well defined
+        got, want = hip.mc_swarm(eps_pop, eps_target, gamma0, 1e-5), orc.mc_swarm(eps_pop, eps_target, gamma0, 1e-5)
+        assert got == want                                          # (nsim, #(Ds > eps_target), min Ds, max Ds)
+        assert got[1:] == (orc.count_gt(eps_target),) + orc.extrema()   # the folded-in reductions: mc:156, mc:146
         assert_state_equal(hip, orc, f"mc gen {gen}")
 
 

@@ -110,18 +110,20 @@ class ShimEngine:
         self.ck(self.lib.abcdez_count_gt(self.ctx, self.delta[self.cur], self.N, thr, C.byref(c)))
         return c.value
 
-    def rank_prepare(self):
-        self.ck(self.lib.abcdez_mc_rank_prepare(self.ctx, self.delta[self.cur], self.N, self.order, self.sorted))
+    def rank_prepare(self, eps_pop, dmax):
+        self.ck(self.lib.abcdez_mc_rank_prepare(self.ctx, self.delta[self.cur], self.N, eps_pop, dmax, self.order,
+                                                self.sorted))
 
     def mc_swarm(self, eps_pop, eps_target, g0, gs):
-        nsim = C.c_int64()
+        nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         o = self.other
         self.ck(self.lib.abcdez_mc_swarm(self.ctx, self.order, self.sorted, self.N, self.theta[self.cur], self.logpi[self.cur],
                                          self.delta[self.cur], self.theta[o], self.logpi[o], self.delta[o], eps_pop,
-                                         eps_target, g0, gs, 0, self.N, self.sweep, C.byref(nsim)))
+                                         eps_target, g0, gs, 0, self.N, self.sweep, C.byref(nsim), C.byref(ngt),
+                                         C.byref(lo), C.byref(hi)))
         self.sweep += 1
         self.cur = o
-        return nsim.value
+        return nsim.value, ngt.value, lo.value, hi.value
 
     def download(self):
         th = np.empty((self.N, self.ld))
@@ -184,14 +186,15 @@ def shim_abcdemc(prior, sim, eps_target, N, seed, generations):
     e = ShimEngine(prior, sim, A.IndicatorStrict0toϵ, seed, N)
     e.init()
     nsims, g0, gs = 0, 2.38 / math.sqrt(2 * e.d), 1e-5
+    lo, hi = e.extrema()
     for _ in range(generations):
-        lo, hi = e.extrema()
         eps_pop = max(eps_target, lo)
         if hi > eps_target:
-            e.rank_prepare()
-        nsims += e.mc_swarm(eps_pop, eps_target, g0, gs)
-        e.count_gt(eps_target)
-    conv = e.extrema()[1] <= eps_target
+            e.rank_prepare(eps_pop, hi)
+        nsim, n_above, lo, hi = e.mc_swarm(eps_pop, eps_target, g0, gs)
+        nsims += nsim
+        assert n_above == e.count_gt(eps_target) and (lo, hi) == e.extrema()
+    conv = hi <= eps_target
     P, _, D = e.download()
     e.close()
     return dict(P=P, C=D, nsims=nsims, reached=conv)

@@ -212,3 +212,34 @@ def test_c_drivers_unbind_blob_stamps_of_an_earlier_engine(oracle):
     assert (a == 0xABCDEF).all() and (b == 0x123456).all()
     r2 = oracle.run_abcdesmc(ModelSpec(prior, A.Normal1D(3.0), seed=31), 64, 0.3)
     assert r1["logZ"] == r2["logZ"] and np.array_equal(r1["C"], r2["C"]) and m1["nsims"] > 0
+
+
+@pytest.mark.parametrize("kind", ["continuous", "ties", "all_converged"])
+def test_mc_better_particle_enumeration_is_the_reference_mask(oracle, kind):
+    """abcdemc_swarm! draws s = rand(rng, (1:N)[Ds .<= Ds[i]]) (src/abcdez_mc.jl:23).  The spec enumerates that set as
+    order[0 .. cnt), cnt = upper_bound(sorted_delta, Ds[i]), with order = (particles with Ds <= eps_pop in index
+    order) ++ (the others by (Ds, index)).  For every particle that draws (Ds[i] > eps_pop, mc:19-20) the enumerated
+    set must be exactly the reference's mask -- hence the same law for any fixed enumeration."""
+    rng = np.random.default_rng(7)
+    N = 3000
+    if kind == "continuous":
+        d = np.abs(rng.normal(3.0, 2.0, N))
+    elif kind == "ties":
+        d = rng.integers(0, 12, N).astype(np.float64)           # integer distances as in the Socks problem
+    else:
+        d = rng.uniform(0.0, 0.29, N)
+    eps_target = 0.3
+    eps_pop = max(eps_target, float(d.min()))
+    order = np.zeros(N, dtype=np.uint32)
+    sd = np.zeros(N)
+    oracle.lib().orc_mc_rank_prepare(d.ctypes.data, N, eps_pop, order.ctypes.data, sd.ctypes.data)
+    assert np.array_equal(np.sort(order), np.arange(N))                       # a permutation
+    assert np.all(sd[1:] >= sd[:-1])                                          # upper_bound is well defined
+    assert np.array_equal(sd, np.maximum(d[order], eps_pop))
+    n_a = int((d <= eps_pop).sum())
+    assert np.all(np.diff(order[:n_a].astype(np.int64)) > 0) and np.all(d[order[:n_a]] <= eps_pop)
+    tail = order[n_a:].astype(np.int64)
+    assert np.all((d[tail][1:] > d[tail][:-1]) | ((d[tail][1:] == d[tail][:-1]) & (tail[1:] > tail[:-1])))
+    for i in np.flatnonzero(d > eps_pop)[:400]:
+        cnt = int(np.searchsorted(sd, d[i], side="right"))
+        assert set(order[:cnt].tolist()) == set(np.flatnonzero(d <= d[i]).tolist())
