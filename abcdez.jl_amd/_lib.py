@@ -45,6 +45,11 @@ PROTOTYPES = {
     "abcdez_smc_replay_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
     "abcdez_smc_resample_gather_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_rows_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "abcdez_smc_partition": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "abcdez_smc_swarm_packed": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _pi64, _pi64],
+    "abcdez_smc_replay_packed": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
+    "abcdez_smc_resample_gather_packed": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "abcdez_packed_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
     "abcdez_smc_reweight": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64],
     "abcdez_get_ess": [_vp, _vp, _i64, _pf64],
     "abcdez_tree_sum": [_vp, _vp, _i64, _pf64],

@@ -19,6 +19,11 @@ int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
 int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
+int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*);
+int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int);
+int abz_launch_smc_replay_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, const uint8_t*, double, double, uint32_t);
+int abz_launch_resample_gather_packed(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, double*, double*, const double*, const double*, double*, double*, double*, uint8_t*);
+int abz_launch_packed_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
 int abz_draws_eval_impl(abcdez_ctx*, int, uint32_t, uint32_t, uint32_t, uint32_t, double, double, uint32_t*, uint32_t*, double*, double*);
 
 static thread_local std::string g_err;
@@ -249,6 +254,7 @@ int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, 
 }
 
 #define ABZ_MAX_N 0x7FFFFFFFll /* indices are 32-bit on the device */
+#define ABZ_PACKED_ALIGN 2048    /* = ABZ_REPLAY_CHUNK: sub-ranges of the packed prefix own whole blocks / bitmap words */
 
 /* ---- blobs (second return value of dist!): stamps carried with the distances, data rebuilt on demand ---- */
 int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_nxt) {
@@ -383,6 +389,76 @@ int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, cons
   ABZ_REQUIRE(ctx && cur_row && slot0 && slot1 && out, "rows_gather: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "rows_gather: N out of range");
   return abz_launch_rows_gather(ctx, cur_row, (uint32_t)N, slot0, slot1, out);
+}
+
+/* ---- packed population: see the comment at SmcPackedArgs in abz_kernels.h ---- */
+int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
+                         uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
+  ABZ_REQUIRE(ctx && alive && bits && bits_other && slot0 && slot1 && logpi && delta && wns, "smc_partition: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 0 <= n_new && n_new <= n_prev && n_prev <= N, "smc_partition: need 0 <= n_new <= n_prev <= N");
+  ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_partition: the two bit arrays / slots must differ");
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_PART_ERR, 0, 8, ctx->stream));
+  return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns);
+}
+
+int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive, int64_t r_lo,
+                            int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags,
+                            double eps, double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && delta, "smc_swarm_packed: null argument");
+  ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_packed: pass both counters or neither");
+  /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_packed: position range out of bounds");
+  ABZ_REQUIRE(r_lo % ABZ_PACKED_ALIGN == 0 && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
+              "smc_swarm_packed: a sub-range must start and end at multiples of 2048 positions (or at n_alive)");
+  ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_swarm_packed: the two slots / bit arrays must differ");
+  int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
+                                       logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr);
+  if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_packed reports totals) */
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
+  ABZ_REQUIRE(ctx->h_scal[ABZ_S_PART_ERR] == 0, "smc_partition: the alive flags did not describe a prefix of length n_prev");
+  return 0;
+}
+
+int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive, int64_t skip_lo,
+                             int64_t skip_hi, double* slot0, double* slot1, double* logpi, const uint8_t* flags,
+                             double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
+  ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags && nacc && nsim, "smc_replay_packed: null argument");
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
+  ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
+  ABZ_REQUIRE(skip_lo % ABZ_PACKED_ALIGN == 0 && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
+              "smc_replay_packed: the own range must start and end at multiples of 2048 positions (or at n_alive)");
+  ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_replay_packed: the two slots / bit arrays must differ");
+  int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0,
+                                        slot1, logpi, flags, gamma0, gamma_sigma, sweep);
+  if (rc) return rc;
+  rc = read_counters(ctx);
+  if (rc) return rc;
+  *nacc = (int64_t)ctx->h_scal[ABZ_S_RACC];
+  *nsim = (int64_t)ctx->h_scal[ABZ_S_RSIM];
+  return 0;
+}
+
+int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* bits, uint32_t* bits_other,
+                                      double* slot0, double* slot1, const double* logpi, const double* delta,
+                                      double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
+  ABZ_REQUIRE(ctx && inds && bits && bits_other && slot0 && slot1 && logpi && delta && nlogpi && ndelta && wns && alive,
+              "smc_resample_gather_packed: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_packed: N out of range");
+  ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1 && bits != bits_other,
+              "smc_resample_gather_packed: in/out arrays must differ");
+  return abz_launch_resample_gather_packed(ctx, inds, (uint32_t)N, bits, bits_other, slot0, slot1, logpi, delta, nlogpi,
+                                           ndelta, wns, alive);
+}
+
+int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const double* slot0, const double* slot1,
+                         double* out) {
+  ABZ_REQUIRE(ctx && bits && slot0 && slot1 && out, "packed_gather: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "packed_gather: N out of range");
+  return abz_launch_packed_gather(ctx, bits, (uint32_t)N, slot0, slot1, out);
 }
 
 int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive, int64_t r_lo,

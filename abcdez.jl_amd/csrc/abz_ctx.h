@@ -77,7 +77,8 @@ enum {
   ABZ_S_SEL_END = 20,
   ABZ_S_INITBAD = 20,
   ABZ_S_RACC = 21, ABZ_S_RSIM = 22,      /* counters of the replayed ranks (sharded row store) */
-  ABZ_S_MCGT = 23, ABZ_S_MCMIN = 24, ABZ_S_MCMAX = 25,   /* abcdemc sweep: #(Ds > eps_target), extrema of the new distances */
+  ABZ_S_MCGT = 23, ABZ_S_MCMIN = 24, ABZ_S_MCMAX = 25,
+  ABZ_S_PART_H = 26, ABZ_S_PART_F = 27, ABZ_S_PART_ERR = 28,   /* partition: #holes, #fillers (must agree), error flag */   /* abcdemc sweep: #(Ds > eps_target), extrema of the new distances */
   ABZ_S_SCALARS = 32,
   /* Sweep counters (smc:138,150,352; mc:44,156): every block of a sweep / replay kernel ADDS its counts to one of
    * ABZ_CSLOTS slots (one 64-byte line each, chosen by block index; agent-scope atomics, fire and forget).  The
@@ -120,5 +121,6 @@ int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp
                          double* delta_out, uint32_t nbw);
 int abz_jit_launch_smc(abcdez_ctx*, const void* args, unsigned nblocks);
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned nblocks);
+int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
 
 #endif

@@ -9,6 +9,9 @@
 
 #include "abz_device.h"
 
+#define ABZ_REPLAY_PER 8                                  /* alive ranks per thread in the scan phase of the replay kernels */
+#define ABZ_REPLAY_CHUNK (ABZ_BLOCK * ABZ_REPLAY_PER)     /* alive ranks per block */
+
 /* ================================================================ S1: abcde_init! (src/abcdez_init.jl:2-22) */
 #define ABZ_MAX_RETRY 100000u
 
@@ -203,8 +206,6 @@ struct SmcReplayArgs {
   uint32_t n_alive, skip_lo, skip_hi, sweep;          /* ranks [skip_lo, skip_hi) are this rank's own: counted only */
 };
 
-#define ABZ_REPLAY_PER 8                                  /* alive ranks per thread in the scan phase */
-#define ABZ_REPLAY_CHUNK (ABZ_BLOCK * ABZ_REPLAY_PER)     /* alive ranks per block */
 
 /* Two phases per block.  Scan: the block reads the flags of ABZ_REPLAY_CHUNK consecutive alive ranks (coalesced),
  * completes alive_out for all of them, counts, and compacts the ACCEPTED ones into an LDS list (wave ballot +
@@ -287,6 +288,194 @@ __device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
     store_row<L, C>(((rowi >> 31) ? a.slot0 : a.slot1) + (size_t)i * LD, j, tp);
+  }
+}
+
+/* ================================================================ S2+S3 on the PACKED population
+ * The alive particles are the positions [0, n_alive) (abcdez_smc_partition keeps them a prefix), so "alive rank r" is
+ * "position r": the own row streams in, the two donors are addressed directly, and the only indirection left is ONE
+ * BIT per position -- which of its two row slots is current -- in a bitmap of N / 8 bytes (512 KB at N = 2^22: resident
+ * in every XCD's L2, so the donor look-ups cost no HBM / Infinity-Cache traffic).  An accepted proposal is written to
+ * the position's other slot and its bit flips in bits_out (the sweep is synchronous: donors read bits / rows of the
+ * generation before, smc:337-350); a rejected one writes nothing; log-prior and distance are updated in place.      */
+struct SmcPackedArgs {
+  HotModel hm;
+  const uint32_t* bits;         /* current slot of every position, 32 positions per word */
+  uint32_t* bits_out;
+  double* slot0;
+  double* slot1;
+  double* logpi;                /* in place */
+  double* delta;
+  unsigned long long* cslots;   /* cumulative counter slots; (nacc, nsim) go to classes c_cls, c_cls + 1 */
+  uint8_t* flags;               /* per position: bit 0 accepted, bit 1 simulated (sharded runs; may be NULL) */
+  uint64_t* stamp;              /* blob stamps, in place; NULL when blobs are off */
+  double eps, gamma0, gsig;
+  uint32_t n_alive, r_lo, n_work, sweep, c_cls;
+};
+
+__device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
+
+template <int SIM, int L, int C>
+__device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
+  constexpr int LD = L * C;
+  constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
+  static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
+  const HotModel& M = a.hm;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+
+  __shared__ ModelLds<LD> s_model;
+  __shared__ uint32_t s_acc[PB / 32];
+
+  /* own row + state */
+  const uint32_t bi = packed_bit(a.bits, ri);
+  double ti[C];
+  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+  const double lpi = a.logpi[ri];
+  const double dli = a.delta[ri];
+  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
+  stage.load(M);
+  if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
+
+  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged */
+  uint32_t ra, rb;
+  double g, log_u;
+  particle_draws<L>(&s_model.tab, M.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+  const uint32_t ba = packed_bit(a.bits, ra), bb = packed_bit(a.bits, rb);
+  double ta[C], tb[C];
+  load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+  load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+
+  double tp[C], pp[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+
+  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
+  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+  bool acc = false;
+  double dp = dli;
+  if (insupport) {
+    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
+    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
+  }
+  acc = acc && active;
+  if (acc) {                                                      /* smc:146-150 */
+    store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
+    if (j == 0) {
+      a.logpi[ri] = lp; a.delta[ri] = dp;
+      if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
+      atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+    }
+  }
+  if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
+  block_count2(j == 0 && acc, active && j == 0 && insupport, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
+  if (threadIdx.x < PB / 32) {
+    const uint32_t w = (a.r_lo + blockIdx.x * PB) / 32u + threadIdx.x;
+    if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
+  }
+}
+
+/* replay of a packed sweep on a replica (multi-GPU): every rank keeps the whole population, rank r sweeps a range of
+ * positions and publishes one flag byte per position; the accepted proposal theta_i + gamma (theta_a - theta_b)
+ * (smc:128) is a function of replicated rows and of the position's counter-based random numbers, so the other ranks
+ * REBUILD it -- and its log-prior -- from their replica instead of receiving the row.  The ranges [skip_lo, skip_hi)
+ * are multiples of ABZ_REPLAY_CHUNK, so a block is either all own (counted only) or all foreign.              */
+struct SmcReplayPackedArgs {
+  HotModel hm;
+  const uint32_t* bits;
+  uint32_t* bits_out;
+  const uint8_t* flags;         /* by position: bit 0 accepted, bit 1 simulated */
+  double* slot0;
+  double* slot1;
+  double* logpi;
+  uint64_t* stamp;              /* blob stamps (in place), NULL when blobs are off */
+  unsigned long long* cslots;   /* (nacc, nsim) over ALL positions of the prefix -> ABZ_C_RACC, ABZ_C_RSIM */
+  double gamma0, gsig;
+  uint32_t n_alive, skip_lo, skip_hi, sweep;
+};
+
+template <int L, int C>
+__device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
+  constexpr int LD = L * C;
+  __shared__ ModelLds<LD> s_model;
+  __shared__ uint32_t s_list[ABZ_REPLAY_CHUNK];           /* accepted foreign positions of this block */
+  __shared__ unsigned int s_n;
+  __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
+
+  ModelStage<-1, LD> stage;                               /* sampler tables + prior descriptors (no simulator data) */
+  stage.load(a.hm);
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+
+  const uint32_t base = blockIdx.x * (uint32_t)ABZ_REPLAY_CHUNK;
+  const unsigned lane = threadIdx.x & 63u;
+  const bool foreign_blk = !(base >= a.skip_lo && base < a.skip_hi);
+  unsigned int wacc = 0u, wsim = 0u;                      /* wave-uniform counters */
+  unsigned fv[ABZ_REPLAY_PER];
+#pragma unroll
+  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
+    const uint32_t r = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
+    fv[k] = r < a.n_alive ? (unsigned)a.flags[r] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
+    const uint32_t r = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
+    const unsigned f = fv[k];
+    wacc += (unsigned)__popcll(__ballot((f & 1u) != 0u));
+    wsim += (unsigned)__popcll(__ballot((f & 2u) != 0u));
+    const bool acc = foreign_blk && (f & 1u) != 0u;
+    const unsigned long long m = __ballot(acc);
+    if (foreign_blk && lane == 0u) {                      /* the wave's 64 positions = two words of the bitmap */
+      const uint32_t w = (r - lane) >> 5;
+      if (w * 32u < a.n_alive) a.bits_out[w] = a.bits[w] ^ (uint32_t)m;
+      if ((w + 1u) * 32u < a.n_alive) a.bits_out[w + 1u] = a.bits[w + 1u] ^ (uint32_t)(m >> 32);
+    }
+    const unsigned cnt = (unsigned)__popcll(m);
+    unsigned int at = 0u;
+    if (lane == 0u && cnt) at = atomicAdd(&s_n, cnt);
+    at = __shfl(at, 0, 64);
+    if (acc) s_list[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = r;
+  }
+  if (lane == 0u) { s_cnt[0][threadIdx.x >> 6] = wacc; s_cnt[1][threadIdx.x >> 6] = wsim; }
+  stage.store(s_model);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const unsigned long long y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    unsigned long long* s = a.cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE;
+    if (x) (void)__hip_atomic_fetch_add(s + ABZ_C_RACC, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (y) (void)__hip_atomic_fetch_add(s + ABZ_C_RSIM, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  const unsigned n = s_n;
+  const int j = (int)(threadIdx.x % L);
+  for (unsigned t = threadIdx.x / L; t < ((n + ABZ_BLOCK / L - 1) / (ABZ_BLOCK / L)) * (ABZ_BLOCK / L); t += ABZ_BLOCK / L) {
+    const bool on = t < n;                                /* whole groups idle together; shuffles stay converged */
+    const uint32_t ri = s_list[on ? t : 0u];
+    uint32_t ra, rb;
+    double g, log_u;
+    particle_draws<L>(&s_model.tab, a.hm.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+    const uint32_t bi = packed_bit(a.bits, ri), ba = packed_bit(a.bits, ra), bb = packed_bit(a.bits, rb);
+    double ti[C], ta[C], tb[C], tp[C], pp[C];
+    load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+    load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+    load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+#pragma unroll
+    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
+    const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                       /* what the owner stored, smc:147 */
+    if (on) {
+      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
+      if (j == 0) {
+        a.logpi[ri] = lp;
+        if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
+      }
+    }
   }
 }
 

@@ -160,6 +160,78 @@ int abz_launch_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, uint32_t N,
   return 0;
 }
 
+/* ---- packed store: the same gathers; source = current row of inds[s], destination = the OTHER slot of s (never a
+ * current row, so no source is overwritten); bits_flip_kernel then flips every bit, in both bit arrays.          */
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_packed_kernel(
+    const uint32_t* __restrict__ inds, uint32_t N, const uint32_t* __restrict__ bits, double* __restrict__ slot0,
+    double* __restrict__ slot1, const double* __restrict__ logpi, const double* __restrict__ delta,
+    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive,
+    const uint64_t* __restrict__ stamp, uint64_t* __restrict__ nstamp) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t s = gid / L;
+  const int j = (int)(gid % L);
+  if (s >= N) return;
+  const uint32_t src = inds[s];
+  const uint32_t bs = (bits[src >> 5] >> (src & 31u)) & 1u, bd = ((bits[s >> 5] >> (s & 31u)) & 1u) ^ 1u;
+  double t[C];
+  load_row<L, C>((bs ? slot1 : slot0) + (size_t)src * LD, j, t);
+  store_row<L, C>((bd ? slot1 : slot0) + (size_t)s * LD, j, t);
+  if (j == 0) {
+    nlogpi[s] = logpi[src];
+    ndelta[s] = delta[src];
+    if (nstamp) nstamp[s] = stamp[src];                          /* blobs .= blobs[inds], smc:99 */
+    wns[s] = 1.0 / (double)N;
+    alive[s] = 1;
+  }
+}
+__global__ __launch_bounds__(ABZ_BLOCK) void bits_flip_kernel(uint32_t* __restrict__ bits, uint32_t* __restrict__ other,
+                                                              uint32_t nwords) {
+  const uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  if (w < nwords) { const uint32_t v = ~bits[w]; bits[w] = v; other[w] = v; }
+}
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void packed_gather_kernel(const uint32_t* __restrict__ bits, uint32_t N,
+                                                                  const double* __restrict__ slot0,
+                                                                  const double* __restrict__ slot1,
+                                                                  double* __restrict__ out) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t s = gid / L;
+  const int j = (int)(gid % L);
+  if (s >= N) return;
+  const uint32_t b = (bits[s >> 5] >> (s & 31u)) & 1u;
+  double t[C];
+  load_row<L, C>((b ? slot1 : slot0) + (size_t)s * LD, j, t);
+  store_row<L, C>(out + (size_t)s * LD, j, t);
+}
+
+int abz_launch_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N, uint32_t* bits, uint32_t* bits_other,
+                                      double* slot0, double* slot1, const double* logpi, const double* delta, double* nlogpi,
+                                      double* ndelta, double* wns, uint8_t* alive) {
+  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
+    hipLaunchKernelGGL((resample_gather_packed_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)N * LL())), dim3(ABZ_BLOCK), 0,
+                       ctx->stream, inds, N, (const uint32_t*)bits, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive,
+                       (const uint64_t*)ctx->stamp_cur, ctx->stamp_cur ? ctx->stamp_nxt : nullptr);
+  });
+  if (!ok) { abz_set_error("resample_gather_packed: unsupported layout"); return -3; }
+  const uint32_t nwords = (N + 31u) / 32u;
+  hipLaunchKernelGGL(bits_flip_kernel, dim3(abz_grid(nwords)), dim3(ABZ_BLOCK), 0, ctx->stream, bits, bits_other, nwords);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int abz_launch_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, uint32_t N, const double* slot0, const double* slot1,
+                             double* out) {
+  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
+    hipLaunchKernelGGL((packed_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)N * LL())), dim3(ABZ_BLOCK), 0, ctx->stream,
+                       bits, N, slot0, slot1, out);
+  });
+  if (!ok) { abz_set_error("packed_gather: unsupported layout"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 /* ---- T2 push_p over the population (result P, smc:382, mc:166) ---- */
 __global__ __launch_bounds__(ABZ_BLOCK) void push_p_kernel(const abz_model* __restrict__ M,
                                                            const double* __restrict__ theta, uint64_t total,

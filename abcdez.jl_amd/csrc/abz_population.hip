@@ -11,6 +11,7 @@
 
 #include "abz_ctx.h"
 #include "abz_device.h"
+#include "abz_dispatch.h"
 
 /* One global atomic per BLOCK (same-address atomics serialise at ~10 ns each; the first build
  * issued one per wave and spent 0.3 ms per pass on them).                                    */
@@ -305,6 +306,152 @@ int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t*
   rc = read_scalars(ctx);
   if (rc) return rc;
   *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
+  return 0;
+}
+
+/* ================================================================ partition of the packed population
+ * After a reweight the alive flags of the prefix [0, n_prev) have holes; n_new = sum(alive) is known to the host.
+ * The k-th dead position below n_new ("hole") swaps its state with the k-th alive position at or above n_new
+ * ("filler"): afterwards the alive particles are the positions [0, n_new).  About 5 % of the prefix moves per
+ * generation at alpha = 0.95 (each hole costs two row reads and two row writes).
+ *   part_count   per 1024-chunk: #holes, #fillers                     (wave ballots)
+ *   part_scan    exclusive scans of both count arrays (two blocks), totals -> scalar area
+ *   part_list    the two position lists in ascending order (ballot prefix inside the chunk) + bit-array sync
+ *   part_swap    lane group k swaps rows / log-prior / distance / weight / flag / stamp of (hole_k, filler_k)     */
+__global__ __launch_bounds__(ABZ_BLOCK) void part_count_kernel(const uint8_t* __restrict__ alive, uint32_t n_prev,
+                                                               uint32_t n_new, uint32_t* __restrict__ cnt, uint32_t nchunk) {
+  __shared__ uint32_t s_c[2];
+  if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * ABZ_CHUNK;
+  uint32_t h = 0, f = 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t k = base + it * ABZ_BLOCK + threadIdx.x;
+    const bool in = k < n_prev;
+    const bool al = in && alive[k];
+    h += (uint32_t)__popcll(__ballot(in && !al && k < n_new));
+    f += (uint32_t)__popcll(__ballot(al && k >= n_new));
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_c[0], h); atomicAdd(&s_c[1], f); }
+  __syncthreads();
+  if (threadIdx.x < 2) cnt[threadIdx.x * nchunk + blockIdx.x] = s_c[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void part_scan_kernel(uint32_t* __restrict__ cnt, uint32_t nchunk,
+                                                         unsigned long long* __restrict__ totals) {
+  __shared__ uint32_t s_part[1024];
+  uint32_t* v = cnt + (size_t)blockIdx.x * nchunk;
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (nchunk + 1023) / 1024;
+  const uint32_t lo = t * per < nchunk ? t * per : nchunk, hi = lo + per < nchunk ? lo + per : nchunk;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += v[k];
+  s_part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = v[k]; v[k] = run; run += c; }
+  if (t == 1023) totals[blockIdx.x] = s_part[1023];
+}
+
+__global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __restrict__ alive, uint32_t n_prev,
+                                                              uint32_t n_new, const uint32_t* __restrict__ off,
+                                                              uint32_t nchunk, uint32_t* __restrict__ holes,
+                                                              uint32_t* __restrict__ fillers,
+                                                              const uint32_t* __restrict__ bits,
+                                                              uint32_t* __restrict__ bits_other, uint32_t nwords) {
+  __shared__ uint32_t s_wave[2][4];
+  /* both bit arrays must agree wherever no sweep writes: positions that just left the prefix keep the bit of the
+   * CURRENT array (their last sweep may have flipped it) */
+  for (uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x; w < nwords; w += gridDim.x * ABZ_BLOCK) bits_other[w] = bits[w];
+  const uint32_t base = blockIdx.x * ABZ_CHUNK;
+  uint32_t run_h = off[blockIdx.x], run_f = off[nchunk + blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t k = base + it * ABZ_BLOCK + threadIdx.x;
+    const bool in = k < n_prev;
+    const bool al = in && alive[k];
+    const bool is_h = in && !al && k < n_new, is_f = al && k >= n_new;
+    const unsigned long long bh = __ballot(is_h), bf = __ballot(is_f);
+    if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll(bh); s_wave[1][wave] = (uint32_t)__popcll(bf); }
+    __syncthreads();
+    uint32_t wh = 0, wf = 0;
+    for (int w = 0; w < wave; ++w) { wh += s_wave[0][w]; wf += s_wave[1][w]; }
+    if (is_h) holes[run_h + wh + (uint32_t)__popcll(bh & below)] = k;
+    if (is_f) fillers[run_f + wf + (uint32_t)__popcll(bf & below)] = k;
+    run_h += s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3];
+    run_f += s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
+    __syncthreads();
+  }
+}
+
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void part_swap_kernel(const uint32_t* __restrict__ holes,
+                                                              const uint32_t* __restrict__ fillers,
+                                                              const unsigned long long* __restrict__ totals,
+                                                              const uint32_t* __restrict__ bits, double* __restrict__ slot0,
+                                                              double* __restrict__ slot1, double* __restrict__ logpi,
+                                                              double* __restrict__ delta, double* __restrict__ wns,
+                                                              uint8_t* __restrict__ alive, uint64_t* __restrict__ stamp,
+                                                              unsigned long long* __restrict__ err) {
+  constexpr int LD = L * C;
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t k = gid / L;
+  const int j = (int)(gid % L);
+  const uint32_t m = (uint32_t)totals[0];
+  if (gid == 0 && totals[0] != totals[1]) *err = 1ull;          /* the flags do not describe a prefix of length n_prev */
+  if (k >= m || totals[0] != totals[1]) return;
+  const uint32_t h = holes[k], f = fillers[k];
+  double* rh = ((bits[h >> 5] >> (h & 31u)) & 1u ? slot1 : slot0) + (size_t)h * LD;
+  double* rf = ((bits[f >> 5] >> (f & 31u)) & 1u ? slot1 : slot0) + (size_t)f * LD;
+  double a[C], b[C];
+  load_row<L, C>(rh, j, a);
+  load_row<L, C>(rf, j, b);
+  store_row<L, C>(rh, j, b);
+  store_row<L, C>(rf, j, a);
+  if (j == 0) {
+    double t;
+    t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
+    t = delta[h]; delta[h] = delta[f]; delta[f] = t;
+    t = wns[h]; wns[h] = wns[f]; wns[f] = t;
+    alive[h] = 1; alive[f] = 0;
+    if (stamp) { const uint64_t u = stamp[h]; stamp[h] = stamp[f]; stamp[f] = u; }
+  }
+}
+
+int abz_partition_impl(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
+                       uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
+  const uint32_t np = (uint32_t)n_prev, nn = (uint32_t)n_new;
+  const uint32_t nchunk = (np + ABZ_CHUNK - 1) / ABZ_CHUNK;
+  const uint32_t bound = nn < np - nn ? nn : np - nn;             /* #swaps <= min(#dead, #alive) */
+  const size_t cb = abz_align((size_t)2 * nchunk * 4), lb = abz_align((size_t)(bound + 1) * 4);
+  int rc = abz_ws_reserve(ctx, cb + 2 * lb);
+  if (rc) return rc;
+  uint32_t* cnt = (uint32_t*)ctx->ws;
+  uint32_t* holes = (uint32_t*)((char*)ctx->ws + cb);
+  uint32_t* fillers = (uint32_t*)((char*)ctx->ws + cb + lb);
+  unsigned long long* totals = ctx->d_scal + ABZ_S_PART_H;
+  const uint32_t nwords = (uint32_t)((N + 31) / 32);
+  hipLaunchKernelGGL(part_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk);
+  hipLaunchKernelGGL(part_scan_kernel, dim3(2), dim3(1024), 0, ctx->stream, cnt, nchunk, totals);
+  hipLaunchKernelGGL(part_list_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk, holes, fillers,
+                     bits, bits_other, nwords);
+  if (bound > 0) {
+    bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
+      hipLaunchKernelGGL((part_swap_kernel<LL(), CC()>), dim3((unsigned)(((uint64_t)bound * LL() + ABZ_BLOCK - 1) / ABZ_BLOCK)),
+                         dim3(ABZ_BLOCK), 0, ctx->stream, holes, fillers, totals, bits, slot0, slot1, logpi, delta, wns, alive,
+                         ctx->stamp_cur, ctx->d_scal + ABZ_S_PART_ERR);
+    });
+    if (!ok) { abz_set_error("smc_partition: unsupported layout"); return -3; }
+  }
+  ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
 

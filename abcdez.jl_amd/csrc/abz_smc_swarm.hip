@@ -131,3 +131,64 @@ int abz_launch_smc_replay(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* 
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
+/* ================================================================ packed population (abz_kernels.h) */
+template <int SIM, int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_packed_kernel(const SmcPackedArgs a) {
+  smc_swarm_packed_body<SIM, L, C>(a);
+}
+template <int L, int C>
+__global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcReplayPackedArgs a) {
+  smc_replay_packed_body<L, C>(a);
+}
+
+int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, uint32_t n_alive, uint32_t r_lo,
+                                uint32_t r_hi, double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags,
+                                double eps, double gamma0, double gsig, uint32_t sweep, int want_counts) {
+  SmcPackedArgs a;
+  a.hm = ctx->hot; a.bits = bits; a.bits_out = bits_out; a.slot0 = slot0; a.slot1 = slot1; a.logpi = logpi; a.delta = delta;
+  a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
+  a.c_cls = want_counts ? ABZ_C_NACC : ABZ_C_DISCARD;
+  a.flags = flags; a.stamp = ctx->stamp_cur;
+  a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
+  a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
+  if (a.n_work == 0) return 0;
+  const int L = ctx->L, C = ctx->C;
+  if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
+  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+  if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  bool ok = true;
+  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+    if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+  } else {
+    ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
+      if constexpr (LL() <= 8)
+        hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+    });
+  }
+  if (ctx->timing) {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->ev_pending = true;
+    ctx->ev_units = a.n_work;
+  }
+  if (!ok) { abz_set_error("smc_swarm_packed: no kernel for this (simulator, ld, lanes) combination"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int abz_launch_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, uint32_t n_alive,
+                                 uint32_t skip_lo, uint32_t skip_hi, double* slot0, double* slot1, double* logpi,
+                                 const uint8_t* flags, double gamma0, double gsig, uint32_t sweep) {
+  SmcReplayPackedArgs a;
+  a.hm = ctx->hot; a.bits = bits; a.bits_out = bits_out; a.flags = flags; a.slot0 = slot0; a.slot1 = slot1; a.logpi = logpi;
+  a.stamp = ctx->stamp_cur;
+  a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
+  a.gamma0 = gamma0; a.gsig = gsig; a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_hi = skip_hi; a.sweep = sweep;
+  const unsigned nblocks = (unsigned)(((uint64_t)n_alive + ABZ_REPLAY_CHUNK - 1) / ABZ_REPLAY_CHUNK);
+  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
+    hipLaunchKernelGGL((smc_replay_packed_kernel<LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+  });
+  if (!ok) { abz_set_error("smc_replay_packed: unsupported layout"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}

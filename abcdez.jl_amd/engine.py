@@ -42,6 +42,8 @@ import torch
 from . import _lib
 from .model import ModelSpec
 
+PACKED_ALIGN = 2048      # sub-ranges of the packed prefix start / end at multiples of this (include/abcdez_hip.h)
+
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
@@ -171,6 +173,40 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_rows_gather(self.ctx, _ptr(cur_row), cur_row.numel(), _ptr(slot0),
                                                          _ptr(slot1), _ptr(out)))
 
+    # ---- packed population: include/abcdez_hip.h, abcdez_smc_partition / abcdez_smc_swarm_packed / ... ----
+    supports_packed = True
+
+    def smc_partition(self, n_prev, n_new, alive, bits, bits_other, slot0, slot1, logpi, delta, wns):
+        _lib.check(self.lib, self.lib.abcdez_smc_partition(self.ctx, _ptr(alive), alive.numel(), n_prev, n_new, _ptr(bits),
+                                                           _ptr(bits_other), _ptr(slot0), _ptr(slot1), _ptr(logpi),
+                                                           _ptr(delta), _ptr(wns)))
+
+    def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
+                         sweep, want_counts=True):
+        """want_counts=False: no host synchronisation (the replay reports the sweep's global counters)"""
+        nacc, nsim = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_swarm_packed(
+            self.ctx, _ptr(bits), _ptr(bits_out), n_alive, r_lo, r_hi, _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta),
+            _ptr(flags), eps, gamma0, gsig, sweep, C.byref(nacc) if want_counts else None,
+            C.byref(nsim) if want_counts else None))
+        return (nacc.value, nsim.value) if want_counts else None
+
+    def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
+        nacc, nsim = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_replay_packed(
+            self.ctx, _ptr(bits), _ptr(bits_out), n_alive, skip_lo, skip_hi, _ptr(slot0), _ptr(slot1), _ptr(logpi),
+            _ptr(flags), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
+        return nacc.value, nsim.value
+
+    def smc_resample_gather_packed(self, inds, bits, bits_other, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
+        _lib.check(self.lib, self.lib.abcdez_smc_resample_gather_packed(
+            self.ctx, _ptr(inds), inds.numel(), _ptr(bits), _ptr(bits_other), _ptr(slot0), _ptr(slot1), _ptr(logpi),
+            _ptr(delta), _ptr(nlogpi), _ptr(ndelta), _ptr(wns), _ptr(alive)))
+
+    def packed_gather(self, bits, slot0, slot1, out):
+        _lib.check(self.lib, self.lib.abcdez_packed_gather(self.ctx, _ptr(bits), out.shape[0], _ptr(slot0), _ptr(slot1),
+                                                           _ptr(out)))
+
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
         wnorm, ess, na = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_reweight(self.ctx, _ptr(delta), _ptr(wns), _ptr(alive), delta.numel(),
@@ -285,15 +321,26 @@ class PopulationEngine:
         N, ld = self.N, spec.ld
         f64 = dict(dtype=torch.float64, device=dev)
         self.rows_mode = storage == "rows" and getattr(self.ops, "supports_rows", False)
+        self.packed = storage == "packed" and getattr(self.ops, "supports_packed", False)
+        if storage == "packed" and not self.packed:
+            raise ValueError("this ops backend has no packed storage")
         self._collectives = self.world > 1 or (force_collectives and self.pg is not None)
         self.sharded_rows = self.rows_mode and self._collectives
-        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store mode the two theta arrays
-        # are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings
-        self.buf = [
-            (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
-            (torch.zeros((N, ld), **f64), torch.zeros(N, **f64), torch.zeros(N, **f64)),
-        ]
+        self.sharded_packed = self.packed and self._collectives
+        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store / packed mode the two theta
+        # arrays are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings.
+        # Sharded packed runs exchange [r_lo, r_lo + chunk) pieces of the per-position arrays: room for G chunks.
+        self._npad = N + (self.world * PACKED_ALIGN if self.sharded_packed else 0)
+        self._full = [(torch.zeros(self._npad, **f64), torch.zeros(self._npad, **f64)) for _ in range(2)]
+        self.buf = [(torch.zeros((N, ld), **f64), self._full[k][0][:N], self._full[k][1][:N]) for k in range(2)]
         self.cur = 0
+        if self.packed:
+            nw = (N + 31) // 32
+            self.bits = [torch.zeros(nw, dtype=torch.int32, device=dev) for _ in range(2)]   # current slot of every position
+            self.bc = 0
+            self.n_prev = N                 # length of the alive prefix
+            self.flags = torch.zeros(self._npad, dtype=torch.uint8, device=dev) if self.sharded_packed else None
+            self.chunk = 0
         if self.rows_mode:
             self.cur_row = torch.arange(N, dtype=torch.int32, device=dev)      # particle | slot << 31
             self.alive_row = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -328,6 +375,11 @@ class PopulationEngine:
     def state(self):
         """(theta, logpi, delta) of the current generation.  Row-store mode gathers the current rows into a
         fresh array (tests / results only; the hot path never calls this)."""
+        if self.packed:
+            self._sync_delta()
+            th = torch.empty_like(self.buf[0][0])
+            self.ops.packed_gather(self.bits[self.bc], self.buf[0][0], self.buf[1][0], th)
+            return (th, self.buf[self.cur][1], self.buf[self.cur][2])
         if not self.rows_mode:
             return self.buf[self.cur]
         self._rows_commit()
@@ -358,7 +410,10 @@ class PopulationEngine:
             self._delta_stale = False
         if self._delta_stale:
             self._mark("delta_allgather", 0)
-            self._allgather_state((self.buf[self.cur][2],))
+            if self.sharded_packed:
+                self._allgather_chunks(self._full[self.cur][1])
+            else:
+                self._allgather_state((self.buf[self.cur][2],))
             self._mark("delta_allgather", 1)
             self._delta_stale = False
 
@@ -368,6 +423,12 @@ class PopulationEngine:
         import torch.distributed as dist
 
         if self._backend == "nccl" or self.device.type == "cpu":
+            if self.sharded_packed:
+                t = self._full[self.cur][1]
+                self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
+                                                               t[self.rank * self.chunk:(self.rank + 1) * self.chunk],
+                                                               group=self.pg, async_op=True)
+                return
             t = self.buf[self.cur][2]
             self._delta_work = dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg, async_op=True)
 
@@ -411,6 +472,8 @@ class PopulationEngine:
 
     def alive_indices(self) -> torch.Tensor:
         """particle indices of the alive list of the last compaction (int64)"""
+        if self.packed:
+            return torch.arange(self.n_prev, dtype=torch.int64, device=self.device)
         if self.rows_mode:
             return self.alive_row[self.ar][:self._rows_n].to(torch.int64) & 0x7FFFFFFF
         return self.alive_idx[:self.n_alive].to(torch.int64)
@@ -441,6 +504,19 @@ class PopulationEngine:
                 dist.all_gather_into_tensor(host, t[self.lo:self.hi].cpu(), group=self.pg)
                 t.copy_(host)
 
+    def _allgather_chunks(self, t):
+        """sharded packed runs: rank r owns the positions [r chunk, (r + 1) chunk) of the prefix (chunk = a multiple of
+        PACKED_ALIGN covering n_alive / G); exchange those pieces of a per-position array of length >= G chunk"""
+        import torch.distributed as dist
+
+        c, g = self.chunk, self.world
+        if self._backend == "nccl" or self.device.type == "cpu":
+            dist.all_gather_into_tensor(t[:g * c], t[self.rank * c:(self.rank + 1) * c], group=self.pg)
+        else:
+            host = torch.empty(g * c, dtype=t.dtype)
+            dist.all_gather_into_tensor(host, t[self.rank * c:(self.rank + 1) * c].cpu(), group=self.pg)
+            t[:g * c].copy_(host)
+
     def _allreduce_counts(self, *vals):
         if not self._collectives:
             return vals
@@ -461,6 +537,10 @@ class PopulationEngine:
                 self.cur_row.bitwise_or_(-(1 << 31))
             self._rows_dirty = False
             self._rows_n = 0
+        if self.packed:          # a fresh population lives in slot `cur` of every position
+            for b in self.bits:
+                b.fill_(-1 if self.cur else 0)
+            self.n_prev = self.N
         self._delta_stale = self._logpi_stale = False
         th, lp, dl = self.buf[self.cur]
         self._bind_stamps()
@@ -471,11 +551,16 @@ class PopulationEngine:
         self.wns.fill_(1.0 / self.N)
         self.alive.fill_(1)
         self.n_alive = self.N
+        if self.packed:
+            self.n_prev = self.N
         self._dead_carried = True
         self.row_synced.zero_()
 
     # ------------------------------------------------------------------ S9, S10
     def quantile_alive(self, alpha: float) -> float:
+        if self.packed:      # the alive particles are the prefix [0, n_prev): the dead tail is not even read
+            n = self.n_prev
+            return self.ops.quantile_alive(self.delta[:n], self.alive[:n], alpha, self.n_alive)[0]
         return self.ops.quantile_alive(self.delta, self.alive, alpha, self.n_alive)[0]
 
     def extrema(self):
@@ -486,6 +571,12 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ S5, S6
     def smc_reweight(self, eps_old: float, eps_new: float):
+        if self.packed:
+            # prefix only: the dead tail has weight +0.0 and contributes exact zeros to the fixed summation trees
+            n = self.n_prev
+            wnorm, ess, n_alive = self.ops.smc_reweight(self.delta[:n], self.wns[:n], self.alive[:n], eps_old, eps_new)
+            self.n_alive = n_alive
+            return wnorm, ess, n_alive
         wnorm, ess, n_alive = self.ops.smc_reweight(self.delta, self.wns, self.alive, eps_old, eps_new)
         self.n_alive = n_alive
         self._dead_carried = False
@@ -499,6 +590,14 @@ class PopulationEngine:
         self.ops.wsample_stratified(self.wns, self.draw, self.inds)
         self.draw += 1
         self._bind_stamps()
+        if self.packed:
+            self._sync_delta()
+            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
+            self.ops.smc_resample_gather_packed(self.inds, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0],
+                                                self.buf[1][0], cur[1], cur[2], oth[1], oth[2], self.wns, self.alive)
+            self._swap()
+            self.n_alive = self.n_prev = self.N
+            return
         if self.rows_mode:
             self._rows_commit()
             self._sync_delta()
@@ -521,6 +620,23 @@ class PopulationEngine:
 
     # ------------------------------------------------------------------ alive list + S2, S3
     def alive_compact(self) -> int:
+        if self.packed:
+            # no alive list: the population is partitioned so that the alive particles are the positions [0, n_alive)
+            if self.n_alive < self.n_prev:
+                self._sync_delta()
+                cur = self.buf[self.cur]
+                self._bind_stamps()
+                self.ops.smc_partition(self.n_prev, self.n_alive, self.alive, self.bits[self.bc], self.bits[1 - self.bc],
+                                       self.buf[0][0], self.buf[1][0], cur[1], cur[2], self.wns)
+                self.n_prev = self.n_alive
+            if self.sharded_packed:     # positions [r_lo, r_hi) of the prefix are this rank's for the coming sweeps
+                per = -(-self.n_alive // self.world)
+                self.chunk = -(-per // PACKED_ALIGN) * PACKED_ALIGN
+                self.r_lo = min(self.rank * self.chunk, self.n_alive)
+                self.r_hi = min(self.r_lo + self.chunk, self.n_alive)
+            else:
+                self.r_lo, self.r_hi = 0, self.n_alive
+            return self.n_alive
         if self.rows_mode:
             self._rows_commit()
             self.ops.alive_compact_rows(self.alive, self.cur_row, self.alive_row[self.ar], self.arank)
@@ -546,6 +662,35 @@ class PopulationEngine:
         """last: no further sweep follows in this generation (the driver's i == Kmcmc) -- lets a sharded run start
         the per-generation distance exchange early; has no effect on results"""
         self._bind_stamps()
+        if self.packed:
+            cur = self.buf[self.cur]
+            b_in, b_out = self.bits[self.bc], self.bits[1 - self.bc]
+            if not self.sharded_packed:
+                counts = self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, 0, self.n_alive, self.buf[0][0],
+                                                   self.buf[1][0], cur[1], cur[2], None, eps, gamma0, gsig, self.sweep)
+                self.sweep += 1
+                self.bc = 1 - self.bc
+                return counts
+            if self._delta_work is not None:      # a caller swept again after announcing the last sweep
+                self._delta_work.wait()
+                self._delta_work = None
+            self._mark("own_sweep", 0)
+            self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                      cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep, want_counts=False)
+            self._mark("own_sweep", 1)
+            self._mark("flag_allgather", 0)
+            self._allgather_chunks(self.flags)               # 1 byte per position: accepted | simulated << 1
+            self._mark("flag_allgather", 1)
+            if last:
+                self._start_delta_allgather()
+            self._mark("replay", 0)
+            counts = self.ops.smc_replay_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
+                                                self.buf[1][0], cur[1], self.flags, gamma0, gsig, self.sweep)
+            self._mark("replay", 1)
+            self.sweep += 1
+            self.bc = 1 - self.bc
+            self._delta_stale = True
+            return counts                                    # global (nacc, nsim), counted from the flags
         if self.sharded_rows:
             if self._delta_work is not None:      # a caller swept again after announcing the last sweep: that
                 self._delta_work.wait()           # exchange is obsolete (the stale flag stays set)
@@ -594,7 +739,7 @@ class PopulationEngine:
         """the enumeration of mc:23 for the current distances: particles with Ds <= eps_pop in index order, then the
         others by (Ds, index).  eps_pop / dmax_hint default to the values of mc:146-147 with eps_target = 0 (one
         extrema pass); the driver passes what it already knows.  No host synchronisation on the HIP path."""
-        if self.rows_mode:
+        if self.rows_mode or self.packed:
             raise RuntimeError("abcdemc needs storage='classic'")
         if self.order is None:
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
@@ -664,6 +809,12 @@ class PopulationEngine:
             if "stamp" not in st:
                 raise ValueError("checkpoint was written without blobs")
             self.stamp[0].copy_(torch.as_tensor(np.ascontiguousarray(st["stamp"], dtype=np.int64)))
+        if self.packed:                          # every position's current row is slot 0 again
+            for b in self.bits:
+                b.zero_()
+            self.n_prev = self.n_alive
+            if not bool(self.alive[:self.n_alive].all()):
+                raise ValueError("checkpoint of a packed population must have its alive particles in front")
         if self.rows_mode:                       # every particle's current row is slot 0 again
             self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
             self._rows_dirty = False

@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-whole-run", action="store_true")
+    p.add_argument("--storage", default=None, choices=["rows", "packed"], help="abcdesmc storage (default: the config's)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -328,6 +329,8 @@ def main():
     from abcdez_amd.engine import HipEngine
 
     cfg = CONFIGS[args.config](A, args)
+    if args.storage and cfg["kind"] == "smc":
+        cfg["storage"] = args.storage
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
     ppg = args.particles_per_gpu or cfg["ppg"]

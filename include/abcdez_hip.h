@@ -150,6 +150,48 @@ ABCDEZ_API int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* 
 ABCDEZ_API int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, const double* slot0,
                        const double* slot1, double* out);
 
+/* ---- Packed population (abcdesmc's default storage).
+ * After every reweight that kills particles the population is PARTITIONED so that the alive particles are the
+ * positions [0, n_alive): the k-th dead position below n_new swaps its whole state with the k-th alive position at or
+ * above it (the reference's algorithm is symmetric under relabelling of the particles, src/abcdez_smc.jl:106-153, so
+ * the law of every output is unchanged; everything -- random numbers, donor ranks, summation trees -- is keyed by
+ * position).  "Alive rank r" then IS "position r": the sweeps need no alive list and no index look-up in front of the
+ * donor rows.  Rows live in two slots per position (slot0[N][ld], slot1[N][ld]); one bit per position (bits, 32
+ * positions per uint32 word, N/32 words rounded up) names the current slot.  An accepted proposal is written to the
+ * position's other slot and its bit flips in bits_out; a rejected one writes nothing; log-prior and distance are
+ * updated in place (the copies of smc:337-340 disappear).  The two bit arrays ping-pong with the sweeps and agree
+ * wherever no sweep writes.
+ *
+ * smc_partition: alive[0 .. n_prev) holds the flags after the reweight, n_new = sum(alive) (the reweight's n_alive).
+ *   Swaps rows / log-prior / distance / weight / flag / blob stamp; copies bits to bits_other.  Asynchronous.
+ * smc_swarm_packed: S2+S3 for the positions [r_lo, r_hi) of the prefix [0, n_alive) (one GPU: 0, n_alive; sharded: a
+ *   sub-range whose ends are multiples of 2048 or n_alive).  flags (may be NULL): per position, bit 0 accepted, bit 1
+ *   simulated.  nacc = nsim = NULL: no counters and no host synchronisation.
+ * smc_replay_packed: what a replica does for the positions of the OTHER ranks after the flag exchange: rebuilds the
+ *   accepted proposals theta_i + gamma (theta_a - theta_b) (smc:128) and their log-priors from its own rows and the
+ *   positions' counter-based random numbers, completes bits_out, and returns sum(naccs), sum(nsims) over the WHOLE
+ *   prefix from the flags.  One byte per particle and sweep crosses xGMI instead of 8 ld + 16.
+ * smc_resample_gather_packed: S8; source = current row of inds[s], destination = the other slot of s; afterwards
+ *   every bit is flipped in both bit arrays; nlogpi / ndelta receive the gathered log-priors / distances.
+ * packed_gather: the current rows as one dense array out[N][ld] (results, checkpoints).                          */
+ABCDEZ_API int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new,
+                                    const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1,
+                                    double* logpi, double* delta, double* wns);
+ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
+                                       int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi,
+                                       double* delta, uint8_t* flags, double eps, double gamma0, double gamma_sigma,
+                                       uint32_t sweep, int64_t* nacc, int64_t* nsim);
+ABCDEZ_API int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
+                                        int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, double* logpi,
+                                        const uint8_t* flags, double gamma0, double gamma_sigma, uint32_t sweep,
+                                        int64_t* nacc, int64_t* nsim);
+ABCDEZ_API int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* bits,
+                                                 uint32_t* bits_other, double* slot0, double* slot1, const double* logpi,
+                                                 const double* delta, double* nlogpi, double* ndelta, double* wns,
+                                                 uint8_t* alive);
+ABCDEZ_API int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const double* slot0,
+                                    const double* slot1, double* out);
+
 /* S5+S6  abcdesmc_update_ws!(ws, alive, Ds, eps_k, eps_k_new, nparticles) src/abcdez_smc.jl:59-83
  *        followed by the driver's wprod/wnorm/Wns/alive lines :308-311 and get_ess :8,:323. */
 ABCDEZ_API int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N,

@@ -882,6 +882,7 @@ ORC_API void orc_smc_replay_packed(const abz_model* M, const uint32_t* bits, uin
       for (int k = 0; k < ld; ++k) to[k] = tp[k];
       push_row(M, tp, pp);
       logpi[r] = logprior_tree(M, pp);              /* the owner stored the same value (smc:147) */
+      if (g_stamp_cur) g_stamp_cur[r] = abz_stamp((uint32_t)r, sweep, 0);
     }
   }
   for (int64_t r = 0; r < n_alive; ++r) {

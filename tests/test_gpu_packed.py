@@ -1,0 +1,182 @@
+"""GPU parity of the PACKED population (abcdez_smc_partition / _swarm_packed / _replay_packed /
+_resample_gather_packed / abcdez_packed_gather) against the oracle's restatement, bit for bit."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import abcdez_amd as A
+from abcdez_amd.engine import PACKED_ALIGN, HipOps, PopulationEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def models():
+    return {
+        "normal1d": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.3),
+        "uniform1d": (A.Uniform(-10.0, 10.0), A.Normal1D(3.0), 0.3),
+        "mvn32": (A.Factored(*[A.Normal(0.0, 1.0) for _ in range(32)]), A.MVNormal(tuple([1.0] * 32)), 6.0),
+        "mvn8": (A.Factored(*[A.Normal(0.0, 1.0) for _ in range(8)]), A.MVNormal(tuple([1.0] * 8)), 2.5),
+        "mvn3": (A.Factored(A.Normal(0, 1), A.Uniform(-3, 3), A.Normal(1, 2)), A.MVNormal((0.5, 0.2, 1.0)), 0.8),
+        "quad2d_inf": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.01),
+        "normdu": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.01),
+        "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)), A.Socks(0, 11), 0.01),
+    }
+
+
+def same(a, b):
+    a, b = a.detach().cpu().contiguous(), b.detach().cpu().contiguous()
+    if a.dtype == torch.float64:
+        return torch.equal(a.view(torch.int64), b.view(torch.int64))
+    return torch.equal(a, b)
+
+
+def assert_equal(hip, orc, what):
+    for k, nm in enumerate(("theta", "logpi", "delta")):
+        assert same(hip.state[k], orc.state[k]), f"{what}: {nm} differs"
+    assert same(hip.wns, orc.wns) and same(hip.alive, orc.alive), f"{what}: weights / flags differ"
+    assert same(hip.bits[hip.bc], orc.bits[orc.bc]), f"{what}: slot bits differ"
+    assert same(hip.buf[0][0], orc.buf[0][0]) and same(hip.buf[1][0], orc.buf[1][0]), f"{what}: a slot array differs"
+
+
+@pytest.mark.parametrize("name", list(models()))
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_packed_generations_parity(oracle, name, abck):
+    """every step of several generations -- quantile, reweight on the prefix, resampling when the ESS drops,
+    partition, three sweeps -- leaves the packed device population equal to the oracle's, both slot arrays and
+    the slot bits included"""
+    prior, sim, eps_target = models()[name]
+    N = 10007 if name != "mvn32" else 6151
+    spec = A.ModelSpec(prior, sim, abck, seed=5)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    orc = PopulationEngine(spec, N, ops=oracle.OracleOps(spec), storage="packed")
+    for e in (hip, orc):
+        e.init_population()
+        e.reset_weights()
+    assert_equal(hip, orc, "init")
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps, eps_k, resampled = math.inf, math.inf, 0
+    for gen in range(14):
+        q = orc.quantile_alive(0.8)
+        assert hip.quantile_alive(0.8) == q
+        eps = max(min(q, eps), eps_target)
+        rw = orc.smc_reweight(eps_k, eps)
+        assert hip.smc_reweight(eps_k, eps) == rw
+        n_alive = rw[2]
+        if rw[1] < 0.5 * N:
+            hip.smc_resample(); orc.smc_resample()
+            assert same(hip.inds, orc.inds)
+            assert_equal(hip, orc, f"gen {gen} resample")
+            resampled += 1
+            n_alive = N
+        if n_alive < 3:
+            break
+        assert hip.alive_compact() == orc.alive_compact() == n_alive
+        assert bool(hip.alive[:n_alive].all()) and not bool(hip.alive[n_alive:].any())      # the alive particles are a prefix
+        assert_equal(hip, orc, f"gen {gen} partition")
+        for k in range(3):
+            assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5), f"gen {gen} sweep {k}"
+            assert_equal(hip, orc, f"gen {gen} sweep {k}")
+        assert hip.extrema() == orc.extrema()
+        eps_k = eps
+    assert resampled >= 1
+
+
+@pytest.mark.parametrize("name,N", [("normal1d", 5000), ("uniform1d", 5000), ("mvn8", 4096), ("mvn32", 8192),
+                                    ("quad2d_inf", 500), ("normdu", 100), ("socks", 3000)])
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ])
+def test_packed_abcdesmc_end_to_end(oracle, name, N, abck):
+    """the whole driver on the packed device population == the C restatement of the driver with orc_smc_partition"""
+    if name == "mvn32" and abck is not A.IndicatorStrict0toϵ:
+        pytest.skip("one kernel is enough at d=32")
+    prior, sim, eps = models()[name]
+    fac = lambda spec, n, pg, storage="packed": PopulationEngine(spec, n, pg, ops=HipOps(spec), storage="packed")
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, ABCk=abck, verbose=False, rng=11, nsims_max=10 ** 8, engine=fac)
+    assert r.engine.packed and type(r.engine.ops).__name__ == "HipOps"
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, abck, seed=11), N, eps, nsims_max=10 ** 8, packed=True)
+    res = r.engine.result()
+    assert r.iters == c["iters"] and r.nsims == c["nsims"]
+    assert np.array_equal(np.array(r.ϵs), c["eps_hist"])
+    assert r.logZ == c["logZ"] or (math.isnan(r.logZ) and math.isnan(c["logZ"]))
+    for k in ("theta", "C", "Wns", "alive"):
+        assert np.array_equal(res[k], c[k]), k
+
+
+@pytest.mark.parametrize("d,shapes", [(32, (2, 4, 8)), (16, (1, 2, 4, 8)), (8, (1, 2, 4))])
+def test_packed_lane_shapes(oracle, d, shapes):
+    prior = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(d)])
+    spec = A.ModelSpec(prior, A.MVNormal(tuple([1.0] * d)), seed=5)
+    N = 1 << 14
+
+    def run(ops):
+        e = PopulationEngine(spec, N, ops=ops, storage="packed")
+        e.init_population(); e.reset_weights()
+        eps, eps_k, out = math.inf, math.inf, []
+        for _ in range(7):
+            eps = min(e.quantile_alive(0.85), eps)
+            _, ess, _ = e.smc_reweight(eps_k, eps)
+            if ess < 0.5 * N:
+                e.smc_resample()
+            e.alive_compact()
+            out += [e.smc_swarm(eps, 2.38 / math.sqrt(2 * d), 1e-5) for _ in range(2)]
+            eps_k = eps
+        return out, [t.cpu() for t in e.state], e.wns.cpu()
+
+    ref = run(oracle.OracleOps(spec))
+    for lanes in shapes:
+        got = run(HipOps(spec, lanes=lanes))
+        assert got[0] == ref[0], lanes
+        for a, b in zip(got[1] + [got[2]], ref[1] + [ref[2]]):
+            assert same(a, b), lanes
+
+
+@pytest.mark.parametrize("name", ["mvn32", "mvn3", "normal1d"])
+def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
+    """what the ranks of a sharded run do, on one GPU: every "rank" sweeps its sub-range of the prefix on its own
+    replica (flags out, no counters), the flags are merged, every rank replays the others' accepted proposals;
+    all replicas must then equal the population one full sweep leaves -- rows of both slots, slot bits, log-priors
+    -- and the replay's counters are the full sweep's"""
+    prior, sim, eps_target = models()[name]
+    N, G = 3 * PACKED_ALIGN * 4 + 777, 3
+    spec = A.ModelSpec(prior, sim, seed=9)
+    e = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    e.init_population(); e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps = e.quantile_alive(0.7)
+    e.smc_reweight(math.inf, eps)
+    n = e.alive_compact()
+    ops = e.ops
+    chunk = -(-(-(-n // G)) // PACKED_ALIGN) * PACKED_ALIGN
+    cuts = [min(r * chunk, n) for r in range(G + 1)]
+    cur = e.buf[e.cur]
+
+    def replica():
+        return dict(s0=e.buf[0][0].clone(), s1=e.buf[1][0].clone(), lp=cur[1].clone(), dl=cur[2].clone(),
+                    b=[e.bits[e.bc].clone(), e.bits[1 - e.bc].clone()], fl=torch.zeros(N + G * PACKED_ALIGN, dtype=torch.uint8, device="cuda"))
+
+    for sweep in range(e.sweep, e.sweep + 3):
+        full = replica()
+        reps = [replica() for _ in range(G)]
+        want = ops.smc_swarm_packed(full["b"][0], full["b"][1], n, 0, n, full["s0"], full["s1"], full["lp"], full["dl"], full["fl"],
+                                    eps, g0, 1e-5, sweep)
+        for r, rep in enumerate(reps):
+            assert ops.smc_swarm_packed(rep["b"][0], rep["b"][1], n, cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"], rep["dl"],
+                                        rep["fl"], eps, g0, 1e-5, sweep, want_counts=False) is None
+        merged = torch.zeros_like(full["fl"])
+        for r, rep in enumerate(reps):
+            merged[cuts[r]:cuts[r + 1]] = rep["fl"][cuts[r]:cuts[r + 1]]
+        assert torch.equal(merged[:n], full["fl"][:n])
+        for r, rep in enumerate(reps):
+            got = ops.smc_replay_packed(rep["b"][0], rep["b"][1], n, cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"], merged,
+                                        g0, 1e-5, sweep)
+            assert got == want
+            for key in ("s0", "s1", "lp"):
+                assert same(rep[key], full[key]), (sweep, r, key)
+            assert same(rep["b"][1], full["b"][1])
+            own = slice(cuts[r], cuts[r + 1])
+            assert same(rep["dl"][own], full["dl"][own])
+        # carry the full sweep's result into the engine for the next sweep
+        e.buf[0][0].copy_(full["s0"]); e.buf[1][0].copy_(full["s1"]); cur[1].copy_(full["lp"]); cur[2].copy_(full["dl"])
+        e.bits[1 - e.bc].copy_(full["b"][1])
+        e.bc = 1 - e.bc
