@@ -19,7 +19,8 @@ int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
 int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
-int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*);
+int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
+int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
 int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int);
 int abz_launch_smc_replay_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, const uint8_t*, double, double, uint32_t);
 int abz_launch_resample_gather_packed(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, double*, double*, const double*, const double*, double*, double*, double*, uint8_t*);
@@ -254,7 +255,7 @@ int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, 
 }
 
 #define ABZ_MAX_N 0x7FFFFFFFll /* indices are 32-bit on the device */
-#define ABZ_PACKED_ALIGN 2048    /* = ABZ_REPLAY_CHUNK: sub-ranges of the packed prefix own whole blocks / bitmap words */
+#define ABZ_PACKED_ALIGN 64      /* sub-ranges of the packed prefix own whole wave-rounds of the replay and whole bitmap words */
 
 /* ---- blobs (second return value of dist!): stamps carried with the distances, data rebuilt on demand ---- */
 int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_nxt) {
@@ -397,8 +398,29 @@ int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_p
   ABZ_REQUIRE(ctx && alive && bits && bits_other && slot0 && slot1 && logpi && delta && wns, "smc_partition: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 0 <= n_new && n_new <= n_prev && n_prev <= N, "smc_partition: need 0 <= n_new <= n_prev <= N");
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_partition: the two bit arrays / slots must differ");
-  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_PART_ERR, 0, 8, ctx->stream));
-  return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns);
+  return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns, nullptr, 0.0);
+}
+
+int abcdez_smc_prologue_packed(abcdez_ctx* ctx, double* delta, double* wns, uint8_t* alive, int64_t N, int64_t n_prev,
+                               double alpha, double eps_prev, double eps_target, double eps_k_old, double ess_min,
+                               const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
+                               double* eps, double* q, double* wnorm, double* ess, int64_t* n_alive, int32_t* partitioned,
+                               double* dmin, double* dmax) {
+  ABZ_REQUIRE(ctx && delta && wns && alive && bits && bits_other && slot0 && slot1 && logpi && eps && wnorm && ess && n_alive &&
+              partitioned, "smc_prologue_packed: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 1 <= n_prev && n_prev <= N, "smc_prologue_packed: need 1 <= n_prev <= N");
+  ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0, "smc_prologue_packed: alpha must be in [0, 1]");
+  ABZ_REQUIRE(eps_k_old >= 0.0 && eps_target >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
+  ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_prologue_packed: the two bit arrays / slots must differ");
+  double out[6];
+  int rc = abz_prologue_packed_impl(ctx, delta, N, n_prev, wns, alive, alpha, eps_prev, eps_target, eps_k_old, ess_min, bits,
+                                    bits_other, slot0, slot1, logpi, delta, out, n_alive, partitioned);
+  if (rc) return rc;
+  *eps = out[0]; *wnorm = out[2]; *ess = out[3];
+  if (q) *q = out[1];
+  if (dmin) *dmin = out[4];
+  if (dmax) *dmax = out[5];
+  return 0;
 }
 
 int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive, int64_t r_lo,
@@ -410,7 +432,7 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_packed: position range out of bounds");
   ABZ_REQUIRE(r_lo % ABZ_PACKED_ALIGN == 0 && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
-              "smc_swarm_packed: a sub-range must start and end at multiples of 2048 positions (or at n_alive)");
+              "smc_swarm_packed: a sub-range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_swarm_packed: the two slots / bit arrays must differ");
   int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
                                        logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr);
@@ -430,7 +452,7 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
   ABZ_REQUIRE(skip_lo % ABZ_PACKED_ALIGN == 0 && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
-              "smc_replay_packed: the own range must start and end at multiples of 2048 positions (or at n_alive)");
+              "smc_replay_packed: the own range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_replay_packed: the two slots / bit arrays must differ");
   int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0,
                                         slot1, logpi, flags, gamma0, gamma_sigma, sweep);

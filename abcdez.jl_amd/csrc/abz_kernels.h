@@ -384,8 +384,8 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
 /* replay of a packed sweep on a replica (multi-GPU): every rank keeps the whole population, rank r sweeps a range of
  * positions and publishes one flag byte per position; the accepted proposal theta_i + gamma (theta_a - theta_b)
  * (smc:128) is a function of replicated rows and of the position's counter-based random numbers, so the other ranks
- * REBUILD it -- and its log-prior -- from their replica instead of receiving the row.  The ranges [skip_lo, skip_hi)
- * are multiples of ABZ_REPLAY_CHUNK, so a block is either all own (counted only) or all foreign.              */
+ * REBUILD it -- and its log-prior -- from their replica instead of receiving the row.  The own range [skip_lo, skip_hi)
+ * starts and ends at multiples of 64 (or at n_alive), so a wave's 64 positions are all own (counted only) or all foreign. */
 struct SmcReplayPackedArgs {
   HotModel hm;
   const uint32_t* bits;
@@ -415,7 +415,6 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
 
   const uint32_t base = blockIdx.x * (uint32_t)ABZ_REPLAY_CHUNK;
   const unsigned lane = threadIdx.x & 63u;
-  const bool foreign_blk = !(base >= a.skip_lo && base < a.skip_hi);
   unsigned int wacc = 0u, wsim = 0u;                      /* wave-uniform counters */
   unsigned fv[ABZ_REPLAY_PER];
 #pragma unroll
@@ -429,6 +428,9 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     const unsigned f = fv[k];
     wacc += (unsigned)__popcll(__ballot((f & 1u) != 0u));
     wsim += (unsigned)__popcll(__ballot((f & 2u) != 0u));
+    /* the wave's 64 positions are all own or all foreign: the own range starts and ends at multiples of 64 */
+    const uint32_t r0 = r - lane;
+    const bool foreign_blk = !(r0 >= a.skip_lo && r0 < a.skip_hi);
     const bool acc = foreign_blk && (f & 1u) != 0u;
     const unsigned long long m = __ballot(acc);
     if (foreign_blk && lane == 0u) {                      /* the wave's 64 positions = two words of the bitmap */

@@ -54,6 +54,7 @@ struct TileArgs {
   const double* wnorm;    /* NORMALISE: device scalar                                  */
   double* tile_alive;     /* NORMALISE: per-tile alive count (exact in f64)           */
   double eps_old, eps_new;
+  const double* eps_new_dev;   /* WPROD: non-null = read eps_new from the device (fused prologue) */
   int abck;
 };
 
@@ -70,7 +71,8 @@ __device__ inline double tile_elem(const TileArgs& a, int64_t k, int& n_pos) {
     double wp = 0.0;
     if (a.alive[k]) {
       const double d = a.delta[k];
-      const double w = abz_exp(abz_kernel_logpdf(a.abck, a.eps_new, d) - abz_kernel_logpdf(a.abck, a.eps_old, d));
+      const double en = a.eps_new_dev ? *a.eps_new_dev : a.eps_new;
+      const double w = abz_exp(abz_kernel_logpdf(a.abck, en, d) - abz_kernel_logpdf(a.abck, a.eps_old, d));
       wp = a.wns[k] * w;
     }
     a.wprod[k] = wp;
@@ -165,8 +167,8 @@ int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, d
   return 0;
 }
 
-int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
-                      double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
+static int reweight_enqueue(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
+                            double eps_new, const double* eps_new_dev) {
   double *p0, *p1;
   char* rest;
   const size_t ntile = (size_t)((N + ABZ_TILE - 1) / ABZ_TILE);
@@ -176,7 +178,7 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
   double* tile_alive = (double*)(rest + abz_align((size_t)N * 8));
   TileArgs a{};
   a.n = N; a.delta = delta; a.wns = wns; a.alive = alive; a.wprod = wprod;
-  a.eps_old = eps_old; a.eps_new = eps_new; a.abck = ctx->h_model.abck;
+  a.eps_old = eps_old; a.eps_new = eps_new; a.eps_new_dev = eps_new_dev; a.abck = ctx->h_model.abck;
   rc = tree_sum_device<LOAD_WPROD>(ctx, a, (double*)(ctx->d_scal + ABZ_S_WNORM), p0, p1);
   if (rc) return rc;
   TileArgs b{};
@@ -187,7 +189,11 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
   if (rc) return rc;
   TileArgs c{};
   c.x = tile_alive; c.n = (int64_t)ntile;      /* integers < 2^53: the f64 tree sum is exact */
-  rc = tree_sum_device<LOAD_PLAIN>(ctx, c, (double*)(ctx->d_scal + ABZ_S_NALIVE), p0, p1);
+  return tree_sum_device<LOAD_PLAIN>(ctx, c, (double*)(ctx->d_scal + ABZ_S_NALIVE), p0, p1);
+}
+int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
+                      double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
+  int rc = reweight_enqueue(ctx, delta, wns, alive, N, eps_old, eps_new, nullptr);
   if (rc) return rc;
   rc = read_scalars(ctx);
   if (rc) return rc;
@@ -318,9 +324,22 @@ int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t*
  *   part_scan    exclusive scans of both count arrays (two blocks), totals -> scalar area
  *   part_list    the two position lists in ascending order (ballot prefix inside the chunk) + bit-array sync
  *   part_swap    lane group k swaps rows / log-prior / distance / weight / flag / stamp of (hole_k, filler_k)     */
+/* dyn (fused prologue): n_new and the resampling decision are still on the device -- n_new = scal[NALIVE] (an f64), and
+ * when the ESS 1 / scal[SUMSQ] is below ess_min the driver will resample (smc:323-326), so nothing is partitioned */
+__device__ inline uint32_t part_n_new(const unsigned long long* __restrict__ dyn, uint32_t n_new, uint32_t n_prev, double ess_min) {
+  if (!dyn) return n_new;
+  const double na = abz_u2d(dyn[ABZ_S_NALIVE]);
+  const double ess = 1.0 / abz_u2d(dyn[ABZ_S_SUMSQ]);
+  if (na > 0.0 && ess < ess_min) return n_prev;       /* resampling ahead: no holes below n_prev, no fillers above */
+  return (uint32_t)na;
+}
 __global__ __launch_bounds__(ABZ_BLOCK) void part_count_kernel(const uint8_t* __restrict__ alive, uint32_t n_prev,
-                                                               uint32_t n_new, uint32_t* __restrict__ cnt, uint32_t nchunk) {
+                                                               uint32_t n_new_h, uint32_t* __restrict__ cnt, uint32_t nchunk,
+                                                               const unsigned long long* __restrict__ dyn, double ess_min,
+                                                               unsigned long long* __restrict__ err) {
   __shared__ uint32_t s_c[2];
+  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0ull;
   if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * ABZ_CHUNK;
@@ -361,12 +380,14 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(uint32_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __restrict__ alive, uint32_t n_prev,
-                                                              uint32_t n_new, const uint32_t* __restrict__ off,
+                                                              uint32_t n_new_h, const uint32_t* __restrict__ off,
                                                               uint32_t nchunk, uint32_t* __restrict__ holes,
                                                               uint32_t* __restrict__ fillers,
                                                               const uint32_t* __restrict__ bits,
-                                                              uint32_t* __restrict__ bits_other, uint32_t nwords) {
+                                                              uint32_t* __restrict__ bits_other, uint32_t nwords,
+                                                              const unsigned long long* __restrict__ dyn, double ess_min) {
   __shared__ uint32_t s_wave[2][4];
+  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min);
   /* both bit arrays must agree wherever no sweep writes: positions that just left the prefix keep the bit of the
    * CURRENT array (their last sweep may have flipped it) */
   for (uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x; w < nwords; w += gridDim.x * ABZ_BLOCK) bits_other[w] = bits[w];
@@ -403,51 +424,59 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_swap_kernel(const uint32_t* __
                                                               unsigned long long* __restrict__ err) {
   constexpr int LD = L * C;
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t k = gid / L;
   const int j = (int)(gid % L);
   const uint32_t m = (uint32_t)totals[0];
   if (gid == 0 && totals[0] != totals[1]) *err = 1ull;          /* the flags do not describe a prefix of length n_prev */
-  if (k >= m || totals[0] != totals[1]) return;
-  const uint32_t h = holes[k], f = fillers[k];
-  double* rh = ((bits[h >> 5] >> (h & 31u)) & 1u ? slot1 : slot0) + (size_t)h * LD;
-  double* rf = ((bits[f >> 5] >> (f & 31u)) & 1u ? slot1 : slot0) + (size_t)f * LD;
-  double a[C], b[C];
-  load_row<L, C>(rh, j, a);
-  load_row<L, C>(rf, j, b);
-  store_row<L, C>(rh, j, b);
-  store_row<L, C>(rf, j, a);
-  if (j == 0) {
-    double t;
-    t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
-    t = delta[h]; delta[h] = delta[f]; delta[f] = t;
-    t = wns[h]; wns[h] = wns[f]; wns[f] = t;
-    alive[h] = 1; alive[f] = 0;
-    if (stamp) { const uint64_t u = stamp[h]; stamp[h] = stamp[f]; stamp[f] = u; }
+  if (totals[0] != totals[1]) return;
+  for (uint32_t k = gid / L; k < m; k += gridDim.x * (ABZ_BLOCK / L)) {     /* the grid does not depend on m */
+    const uint32_t h = holes[k], f = fillers[k];
+    double* rh = ((bits[h >> 5] >> (h & 31u)) & 1u ? slot1 : slot0) + (size_t)h * LD;
+    double* rf = ((bits[f >> 5] >> (f & 31u)) & 1u ? slot1 : slot0) + (size_t)f * LD;
+    double a[C], b[C];
+    load_row<L, C>(rh, j, a);
+    load_row<L, C>(rf, j, b);
+    store_row<L, C>(rh, j, b);
+    store_row<L, C>(rf, j, a);
+    if (j == 0) {
+      double t;
+      t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
+      t = delta[h]; delta[h] = delta[f]; delta[f] = t;
+      t = wns[h]; wns[h] = wns[f]; wns[f] = t;
+      alive[h] = 1; alive[f] = 0;
+      if (stamp) { const uint64_t u = stamp[h]; stamp[h] = stamp[f]; stamp[f] = u; }
+    }
   }
 }
 
+/* dyn != null: n_new and the "no resampling ahead" predicate are read from the device (fused prologue; n_new is ignored) */
 int abz_partition_impl(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
-                       uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
+                       uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns,
+                       const unsigned long long* dyn, double ess_min) {
   const uint32_t np = (uint32_t)n_prev, nn = (uint32_t)n_new;
   const uint32_t nchunk = (np + ABZ_CHUNK - 1) / ABZ_CHUNK;
-  const uint32_t bound = nn < np - nn ? nn : np - nn;             /* #swaps <= min(#dead, #alive) */
+  const uint32_t bound = dyn ? np / 2 : (nn < np - nn ? nn : np - nn);             /* #swaps <= min(#dead, #alive) */
   const size_t cb = abz_align((size_t)2 * nchunk * 4), lb = abz_align((size_t)(bound + 1) * 4);
+  /* (every stage of the fused prologue is done with the workspace before the next stage's kernels start: one stream) */
   int rc = abz_ws_reserve(ctx, cb + 2 * lb);
   if (rc) return rc;
-  uint32_t* cnt = (uint32_t*)ctx->ws;
-  uint32_t* holes = (uint32_t*)((char*)ctx->ws + cb);
-  uint32_t* fillers = (uint32_t*)((char*)ctx->ws + cb + lb);
+  char* base = (char*)ctx->ws;
+  uint32_t* cnt = (uint32_t*)base;
+  uint32_t* holes = (uint32_t*)(base + cb);
+  uint32_t* fillers = (uint32_t*)(base + cb + lb);
   unsigned long long* totals = ctx->d_scal + ABZ_S_PART_H;
   const uint32_t nwords = (uint32_t)((N + 31) / 32);
-  hipLaunchKernelGGL(part_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk);
+  if (nchunk == 0) return 0;
+  hipLaunchKernelGGL(part_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk, dyn, ess_min,
+                     ctx->d_scal + ABZ_S_PART_ERR);
   hipLaunchKernelGGL(part_scan_kernel, dim3(2), dim3(1024), 0, ctx->stream, cnt, nchunk, totals);
   hipLaunchKernelGGL(part_list_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk, holes, fillers,
-                     bits, bits_other, nwords);
+                     bits, bits_other, nwords, dyn, ess_min);
   if (bound > 0) {
     bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
-      hipLaunchKernelGGL((part_swap_kernel<LL(), CC()>), dim3((unsigned)(((uint64_t)bound * LL() + ABZ_BLOCK - 1) / ABZ_BLOCK)),
-                         dim3(ABZ_BLOCK), 0, ctx->stream, holes, fillers, totals, bits, slot0, slot1, logpi, delta, wns, alive,
-                         ctx->stamp_cur, ctx->d_scal + ABZ_S_PART_ERR);
+      uint64_t blocks = ((uint64_t)bound * LL() + ABZ_BLOCK - 1) / ABZ_BLOCK;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((part_swap_kernel<LL(), CC()>), dim3((unsigned)blocks), dim3(ABZ_BLOCK), 0, ctx->stream, holes, fillers,
+                         totals, bits, slot0, slot1, logpi, delta, wns, alive, ctx->stamp_cur, ctx->d_scal + ABZ_S_PART_ERR);
     });
     if (!ok) { abz_set_error("smc_partition: unsupported layout"); return -3; }
   }
@@ -582,9 +611,9 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 }
 
 /* ================================================================ order statistics of alive distances (smc:301)
- * Exact selection of the rank-k alive distance and of the next larger one, on the IEEE bit
- * patterns (distances are >= 0, so the u64 pattern order is the value order; NaN never enters
- * the population; +Inf is just the largest key).
+ * Exact selection of the rank-k alive distance and of the next larger one, on the order-preserving
+ * u64 image of the IEEE bit patterns (f64_order_key: negative values and -0.0 sort below +0.0; NaN never
+ * enters the population; +Inf is just the largest key).
  *
  *   pass 1  qs_hist_kernel     2048-bin histogram of  (key - klo) >> shift  (clamped: any
  *                              monotone binning is correct, a good one is fast) + min/max key
@@ -636,7 +665,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __re
   unsigned long long lo = ~0ull, hi = 0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
-    const unsigned long long key = abz_d2u(delta[k]);
+    const unsigned long long key = f64_order_key(delta[k]);
     if (alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
   }
   block_minmax_u64(lo, hi);
@@ -674,7 +703,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
     for (int u = 0; u < 8; ++u) {
       const int64_t k = k0 + u * stride;
       const bool in = k < N;
-      key[u] = in ? abz_d2u(delta[k]) : 0ull;
+      key[u] = in ? f64_order_key(delta[k]) : 0ull;
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     for (int u = 0; u < 4; ++u) {
       const int64_t k = base + t + u * stride;
       const bool in = k < N;
-      key[u] = in ? abz_d2u(delta[k]) : 0ull;
+      key[u] = in ? f64_order_key(delta[k]) : 0ull;
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
@@ -991,8 +1020,31 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
 }
 #undef QS
 
-int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
-                    double* xk, double* xk1, int64_t* n_le) {
+static inline double f64_from_order_key(unsigned long long k) {
+  return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
+}
+__device__ inline double dev_from_order_key(unsigned long long k) {
+  return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
+}
+
+/* the driver's smc:301 on the device, right behind the select: q = x_(j) + g (x_(j+1) - x_(j)) (Julia quantile, type 7;
+ * j, g from the host, which knows n), eps = max(min(q, eps_prev), eps_target) -> scal[ABZ_S_EPS].  The host owns the
+ * schedule: it passes eps_prev / eps_target in and reads eps back with the other scalars.                        */
+__global__ void qs_eps_kernel(unsigned long long* __restrict__ scal, unsigned long long k0, double g, int single,
+                              double eps_prev, double eps_target) {
+  const unsigned long long key = scal[ABZ_S_SEL_PREFIX], less = scal[ABZ_S_SEL_LESS], eq = scal[ABZ_S_SEL_EQ];
+  const unsigned long long next = scal[ABZ_S_SEL_NEXT];
+  const double a = dev_from_order_key(key);
+  const double b = (single || k0 + 1ull < less + eq || next == ~0ull) ? a : dev_from_order_key(next);
+  const double q = a + g * (b - a);
+  double e = q < eps_prev ? q : eps_prev;             /* min(q, eps): Julia's min propagates NaN; distances are never NaN */
+  e = e > eps_target ? e : eps_target;
+  scal[ABZ_S_QVAL] = abz_d2u(q);
+  scal[ABZ_S_EPS] = abz_d2u(e);
+}
+
+/* enqueue the three passes of the select for rank k0 (0-based) among the alive distances; results stay on the device */
+static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0) {
   int rc = abz_ws_reserve(ctx, abz_align((size_t)N * 8));
   if (rc) return rc;
   unsigned long long* buf = (unsigned long long*)ctx->ws;
@@ -1004,7 +1056,8 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   uint32_t* hist2 = ctx->sel_hist + ABZ_QS_BINS;
   unsigned long long* bmin = (unsigned long long*)(ctx->sel_hist + 2 * ABZ_QS_BINS);
   unsigned long long* babove = bmin + ABZ_QS_GRID;
-  const bool reseed = !ctx->sel_clean || ctx->sel_delta != delta || ctx->sel_alive != alive || ctx->sel_N != N;
+  /* a SHORTER prefix of the same arrays keeps the window (packed population: the alive prefix shrinks every generation) */
+  const bool reseed = !ctx->sel_clean || ctx->sel_delta != delta || ctx->sel_alive != alive || ctx->sel_N < N;
   if (reseed) {
     /* device state of the select from scratch + window from a min / max pass */
     unsigned long long init[ABZ_S_SEL_END - ABZ_S_SEL_PREFIX] = {0};
@@ -1024,10 +1077,12 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
   hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist, bmin, babove, (int)grid,
                      hist2);
   ABZ_HIP_CHECK(hipGetLastError());
-  rc = read_scalars(ctx);
-  if (rc) return rc;
-  ctx->sel_clean = true;
   ctx->sel_delta = delta; ctx->sel_alive = alive; ctx->sel_N = N;
+  return 0;
+}
+/* after a read-back of the scalars: validate and convert */
+static int select_finish(abcdez_ctx* ctx, int64_t k0, double* xk, double* xk1, int64_t* n_le) {
+  ctx->sel_clean = true;
   const unsigned long long key = ctx->h_scal[ABZ_S_SEL_PREFIX];
   const unsigned long long less = ctx->h_scal[ABZ_S_SEL_LESS], eq = ctx->h_scal[ABZ_S_SEL_EQ];
   const unsigned long long next = ctx->h_scal[ABZ_S_SEL_NEXT];
@@ -1038,27 +1093,38 @@ int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, 
                       : "quantile_alive: internal selection error");
     return -1;
   }
-  *xk = abz_u2d(key);
-  *n_le = (int64_t)(less + eq);
+  if (xk) *xk = f64_from_order_key(key);
+  if (n_le) *n_le = (int64_t)(less + eq);
   /* rank k0+1 is the same value if it is still inside the run of equal keys */
-  *xk1 = ((unsigned long long)k0 + 1 < less + eq || next == ~0ull) ? abz_u2d(key) : abz_u2d(next);
+  if (xk1) *xk1 = ((unsigned long long)k0 + 1 < less + eq || next == ~0ull) ? f64_from_order_key(key) : f64_from_order_key(next);
   return 0;
+}
+int abz_select_impl(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
+                    double* xk, double* xk1, int64_t* n_le) {
+  int rc = select_enqueue(ctx, delta, alive, N, k0);
+  if (rc) return rc;
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  return select_finish(ctx, k0, xk, xk1, n_le);
 }
 
 /* ================================================================ extrema / counts (S10) */
-static inline double f64_from_order_key(unsigned long long k) {
-  return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
-}
 
 __global__ __launch_bounds__(ABZ_BLOCK) void extrema_kernel(const double* __restrict__ delta, int64_t N,
                                                             unsigned long long* __restrict__ mn,
                                                             unsigned long long* __restrict__ mx) {
   unsigned long long lo = ~0ull, hi = 0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
-  for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
-    const unsigned long long key = f64_order_key(delta[k]);
-    lo = key < lo ? key : lo;
-    hi = key > hi ? key : hi;
+  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k0 < N; k0 += 8 * stride) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = k0 + u * stride < N ? delta[k0 + u * stride] : delta[k0];   /* 8 loads in flight */
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned long long key = f64_order_key(v[u]);
+      lo = key < lo ? key : lo;
+      hi = key > hi ? key : hi;
+    }
   }
   block_minmax_u64(lo, hi);
   if (threadIdx.x == 0) { atomicMin(mn, lo); atomicMax(mx, hi); }
@@ -1095,15 +1161,20 @@ int abz_count_alive_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, int64
   return 0;
 }
 
-int abz_extrema_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi) {
+static int extrema_enqueue(abcdez_ctx* ctx, const double* delta, int64_t N) {
   unsigned long long init[2] = {~0ull, 0ull};
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->d_scal + ABZ_S_MIN, init, 16, hipMemcpyHostToDevice, ctx->stream));
-  unsigned grid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
-  if (grid > ABZ_REDUCE_GRID) grid = ABZ_REDUCE_GRID;
+  unsigned grid = (unsigned)((N + 8 * ABZ_BLOCK - 1) / (8 * ABZ_BLOCK));
+  if (grid > 2048u) grid = 2048u;
   hipLaunchKernelGGL(extrema_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, ctx->d_scal + ABZ_S_MIN,
                      ctx->d_scal + ABZ_S_MAX);
   ABZ_HIP_CHECK(hipGetLastError());
-  int rc = read_scalars(ctx);
+  return 0;
+}
+int abz_extrema_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi) {
+  int rc = extrema_enqueue(ctx, delta, N);
+  if (rc) return rc;
+  rc = read_scalars(ctx);
   if (rc) return rc;
   *lo = f64_from_order_key(ctx->h_scal[ABZ_S_MIN]);
   *hi = f64_from_order_key(ctx->h_scal[ABZ_S_MAX]);
@@ -1146,6 +1217,53 @@ void abz_fold_minmax(abcdez_ctx* ctx, int bank, double* lo, double* hi) {
   for (int k = 0; k < ABZ_MMSLOTS; ++k) { mn = m[2 * k] < mn ? m[2 * k] : mn; mx = m[2 * k + 1] > mx ? m[2 * k + 1] : mx; }
   *lo = f64_from_order_key(mn);
   *hi = f64_from_order_key(mx);
+}
+
+/* ================================================================ one generation's prologue in ONE enqueue + ONE read-back
+ * The statements of the driver between two groups of sweeps (smc:301-311,323 and the extrema of :364), in the order the
+ * reference runs them, without returning to the host in between:
+ *   extrema(Ds) of the generation that just ended            (history, smc:364)
+ *   x_(j), x_(j+1) of the alive distances -> q -> eps         (smc:301; eps_prev / eps_target / alpha come from the host)
+ *   incremental weights, normalisation, alive flags, ESS      (smc:305-311, :8)
+ *   partition of the packed population, unless ESS < ess_min  (then the host resamples: smc:323-326)
+ * The host still owns the schedule: it passes the previous eps and the target in and gets eps, wnorm (for logZ), ESS and
+ * n_alive back.  Four blocking read-backs become one.                                                            */
+int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N, int64_t n_prev, double* wns, uint8_t* alive,
+                             double alpha, double eps_prev, double eps_target, double eps_k_old, double ess_min,
+                             const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
+                             double* delta_rw, double* out /* eps, q, wnorm, ess, lo, hi */, int64_t* n_alive,
+                             int32_t* partitioned) {
+  int rc = extrema_enqueue(ctx, delta_all, N);
+  if (rc) return rc;
+  /* Julia Statistics.quantile, type 7, over the n_prev alive distances: h = (n-1) p + 1, j = clamp(floor(h), 1, n-1), g = h - j */
+  const int64_t n = n_prev;
+  const double h = (double)(n - 1) * alpha + 1.0;
+  int64_t j = (int64_t)__builtin_floor(h);
+  if (j < 1) j = 1;
+  if (j > n - 1) j = n - 1 > 1 ? n - 1 : 1;
+  const double g = h - (double)j;
+  rc = select_enqueue(ctx, delta_all, alive, n_prev, j - 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(qs_eps_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, (unsigned long long)(j - 1), g, n == 1 ? 1 : 0,
+                     eps_prev, eps_target);
+  rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS));
+  if (rc) return rc;
+  rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min);
+  if (rc) return rc;
+  rc = read_scalars(ctx);
+  if (rc) return rc;
+  rc = select_finish(ctx, j - 1, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  out[0] = scal_f64(ctx, ABZ_S_EPS);
+  out[1] = scal_f64(ctx, ABZ_S_QVAL);
+  out[2] = scal_f64(ctx, ABZ_S_WNORM);
+  out[3] = 1.0 / scal_f64(ctx, ABZ_S_SUMSQ);
+  out[4] = f64_from_order_key(ctx->h_scal[ABZ_S_MIN]);
+  out[5] = f64_from_order_key(ctx->h_scal[ABZ_S_MAX]);
+  *n_alive = (int64_t)scal_f64(ctx, ABZ_S_NALIVE);
+  *partitioned = !(*n_alive > 0 && out[3] < ess_min);
+  if (ctx->h_scal[ABZ_S_PART_ERR]) { abz_set_error("smc_prologue_packed: the alive flags did not describe a prefix of length n_prev"); return -1; }
+  return 0;
 }
 
 /* ================================================================ spec arithmetic on the device (test hook) */

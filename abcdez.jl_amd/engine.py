@@ -42,7 +42,7 @@ import torch
 from . import _lib
 from .model import ModelSpec
 
-PACKED_ALIGN = 2048      # sub-ranges of the packed prefix start / end at multiples of this (include/abcdez_hip.h)
+PACKED_ALIGN = 64        # sub-ranges of the packed prefix start / end at multiples of this (include/abcdez_hip.h)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -180,6 +180,18 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_smc_partition(self.ctx, _ptr(alive), alive.numel(), n_prev, n_new, _ptr(bits),
                                                            _ptr(bits_other), _ptr(slot0), _ptr(slot1), _ptr(logpi),
                                                            _ptr(delta), _ptr(wns)))
+
+    def smc_prologue_packed(self, delta, wns, alive, n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, bits, bits_other,
+                            slot0, slot1, logpi):
+        """extrema, eps (smc:301), reweight (smc:305-311), ESS and -- unless the driver is about to resample -- the
+        partition, in one call and one host synchronisation -> (eps, wnorm, ess, n_alive, partitioned, lo, hi)"""
+        eps, q, wnorm, ess, lo, hi = (C.c_double() for _ in range(6))
+        na, part = C.c_int64(), C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_smc_prologue_packed(
+            self.ctx, _ptr(delta), _ptr(wns), _ptr(alive), delta.numel(), n_prev, alpha, eps_prev, eps_target, eps_k, ess_min,
+            _ptr(bits), _ptr(bits_other), _ptr(slot0), _ptr(slot1), _ptr(logpi), C.byref(eps), C.byref(q), C.byref(wnorm),
+            C.byref(ess), C.byref(na), C.byref(part), C.byref(lo), C.byref(hi)))
+        return eps.value, wnorm.value, ess.value, na.value, bool(part.value), lo.value, hi.value
 
     def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
                          sweep, want_counts=True):
@@ -585,6 +597,28 @@ class PopulationEngine:
     def get_ess(self) -> float:
         return self.ops.get_ess(self.wns)
 
+    def smc_prologue(self, alpha: float, eps_prev: float, eps_target: float, eps_k: float, ess_min: float):
+        """Everything the driver does between two groups of sweeps except the resampling itself: extrema(Ds) of the
+        generation that just ended (smc:364), eps = max(min(quantile(Ds[alive], alpha), eps_prev), eps_target)
+        (smc:301), reweight + ESS (smc:305-311, :323) -> (eps, wnorm, ess, n_alive, (lo, hi)).  On the packed HIP
+        population this is ONE library call with ONE host synchronisation (which also partitions the population
+        unless ESS < ess_min announces a resampling); elsewhere the three separate calls."""
+        if self.packed and hasattr(self.ops, "smc_prologue_packed"):
+            self._sync_delta()
+            self._bind_stamps()
+            cur = self.buf[self.cur]
+            eps, wnorm, ess, n_alive, part, lo, hi = self.ops.smc_prologue_packed(
+                cur[2], self.wns, self.alive, self.n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, self.bits[self.bc],
+                self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0], cur[1])
+            self.n_alive = n_alive
+            if part:
+                self.n_prev = n_alive
+            return eps, wnorm, ess, n_alive, (lo, hi)
+        rng = self.extrema()
+        eps = max(min(self.quantile_alive(alpha), eps_prev), eps_target)
+        wnorm, ess, n_alive = self.smc_reweight(eps_k, eps)
+        return eps, wnorm, ess, n_alive, rng
+
     # ------------------------------------------------------------------ S7, S8
     def smc_resample(self):
         self.ops.wsample_stratified(self.wns, self.draw, self.inds)
@@ -857,7 +891,7 @@ class PopulationEngine:
 
 
 def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0,
-              storage: str = "rows", force_collectives: bool = False) -> PopulationEngine:
+              storage: str = "packed", force_collectives: bool = False) -> PopulationEngine:
     """The product engine: HIP kernels on the current CUDA(HIP) device.  Row-store sweeps (only accepted
     proposals are written); sharded runs keep one replica per GPU and exchange accept flags (module docstring)."""
     return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage,

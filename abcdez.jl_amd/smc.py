@@ -102,7 +102,7 @@ def _check(cond: bool, msg: str) -> None:
         raise ValueError(msg)  # the reference raises ErrorException via error(...)
 
 
-def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group, storage: str = "rows"):
+def _make_engine(spec: ModelSpec, nparticles: int, engine, process_group, storage: str = "packed"):
     if engine is not None:
         if not callable(engine):
             return engine
@@ -205,11 +205,14 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
 
     while iters < max_iters:           # smc:295
         iters += 1
-        # new ϵ target, smc:301 (S9: the order statistics come from the device)
-        ϵ = max(min(eng.quantile_alive(α), ϵ), ϵ_target)
+        # new ϵ target ϵ = max(min(quantile(Δs[alive], α), ϵ), ϵ_target) (smc:301; S9: the order statistics come from
+        # the device, the schedule stays here: ϵ and ϵ_target go in, the new ϵ comes back); target weights,
+        # normalisation, alive mask: smc:305-311 (S5) and ESS smc:323 (S6).  One engine call -- on the packed HIP
+        # population one host synchronisation; it also returns extrema(Δs) of the generation that just ended (smc:364)
+        ϵ, wnorm, ess, n_alive, range_prev = eng.smc_prologue(α, ϵ, ϵ_target, ϵ_k, ess_min)
+        if verboseout and iters > 1 and len(ranges_ϵ) < len(ϵs):
+            ranges_ϵ.append(range_prev)
         ABCk(ϵ)
-        # target weights, normalisation, alive mask: smc:305-311 (S5) and ESS smc:323 (S6)
-        wnorm, ess, n_alive = eng.smc_reweight(ϵ_k, ϵ)
         # evidence, smc:315
         logZ += math.log(wnorm) if wnorm > 0.0 else (-math.inf if wnorm == 0.0 else math.nan)
         naccs = 0                      # smc:318
@@ -232,9 +235,8 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
                     break
         facc = naccs / (n_alive * Ki) if n_alive > 0 else math.nan   # smc:357
         ϵ_k = ϵ                        # smc:360
-        if verboseout:                 # smc:362-370
+        if verboseout:                 # smc:362-370; ranges_ϵ gets this generation's extrema from the next prologue
             ϵs.append(ϵ)
-            ranges_ϵ.append(eng.extrema())
             logZs.append(logZ)
             esss.append(ess)
             faccs.append(facc)
@@ -247,6 +249,8 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             break
         if ϵ <= ϵ_target or nsims >= nsims_max or facc < facc_stop:   # smc:376
             break
+    if verboseout and len(ranges_ϵ) < len(ϵs):
+        ranges_ϵ.append(eng.extrema())     # smc:364 for the last generation
 
     if verbose:                        # smc:379
         log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)

@@ -55,7 +55,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-whole-run", action="store_true")
-    p.add_argument("--storage", default=None, choices=["rows", "packed"], help="abcdesmc storage (default: the config's)")
+    p.add_argument("--storage", default=None, choices=["rows", "packed", "classic"], help="abcdesmc storage (default: the config's)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -82,8 +82,9 @@ class Generation:
 
     def step(self):
         e = self.e
-        self.eps = max(min(e.quantile_alive(self.alpha), self.eps), self.eps_target)      # smc:301
-        wnorm, ess, n_alive = e.smc_reweight(self.eps_k, self.eps)                         # smc:305-311
+        # smc:301 (eps), smc:305-311 (reweight), ESS, and extrema(Ds) of the generation that just ended (smc:364)
+        self.eps, wnorm, ess, n_alive, self.range = e.smc_prologue(self.alpha, self.eps, self.eps_target, self.eps_k,
+                                                                   e.N * self.delta_ess)
         self.logZ += math.log(wnorm)                                                       # smc:315
         if ess < e.N * self.delta_ess:                                                     # smc:323-326
             e.smc_resample()
@@ -101,7 +102,6 @@ class Generation:
                 break
         self.naccs += naccs
         self.eps_k = self.eps
-        self.range = e.extrema()                                                           # smc:364 (verboseout default)
         self.generations += 1
 
     def done(self):
@@ -143,7 +143,7 @@ def cfg_smc32(A, args):
     prior = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(d)])
     sim = A.MVNormal(tuple([1.0] * d))
     return dict(kind="smc", prior=prior, sim=sim, d=d, eps_target=6.0 * math.sqrt(d / 32.0), ppg=1 << 22, steps=20, warmup=5,
-                cpu_particles=1 << 22, cpu_steps=10, storage="rows",
+                cpu_particles=1 << 22, cpu_steps=10, storage="packed",
                 workload=f"abcdesmc d={d} MVN simulator + Euclidean distance (BASELINE.json configs[2]); "
                          "alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
                 exact_logZ=-8.111642 if d == 32 else None)
@@ -162,7 +162,7 @@ def cfg_lv(A, args):
     sim = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=g["dt"], steps_per_obs=g["steps_per_obs"],
                              noise=g["noise"])
     return dict(kind="smc", prior=A.Factored(*[A.Uniform(0.0, 2.0)] * 4), sim=sim, d=4, eps_target=1.0, ppg=1 << 20, steps=12,
-                warmup=3, cpu_particles=1 << 15, cpu_steps=6, storage="rows",
+                warmup=3, cpu_particles=1 << 15, cpu_steps=6, storage="packed",
                 workload="abcdesmc Lotka-Volterra RK4 on device, dt 0.01 x 1500 steps per particle-update, 16 noisy (x, y) "
                          "observations, Euclidean distance (BASELINE.json configs[3]); alpha=0.95 Kmcmc=3",
                 exact_logZ=None)
@@ -170,7 +170,7 @@ def cfg_lv(A, args):
 
 def cfg_evidence1d(A, args):
     return dict(kind="smc", prior=A.Normal(0.0, math.sqrt(10.0)), sim=A.Normal1D(3.0), d=1, eps_target=0.3, ppg=1 << 23,
-                steps=12, warmup=3, cpu_particles=1 << 21, cpu_steps=6, storage="rows",
+                steps=12, warmup=3, cpu_particles=1 << 21, cpu_steps=6, storage="packed",
                 workload="abcdesmc two-model evidence of examples/minimal_example.jl (BASELINE.json configs[4]); timed: "
                          "generations of model 1 (prior N(0, sqrt 10)); both models then run to eps 0.3",
                 exact_logZ=-3.038051357)
@@ -440,8 +440,8 @@ def main():
                 "workload": f"{cfg['workload']}; {ppg} particles/GPU", "name": args.config,
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
                 "timed_window": window,
-                "step_includes": ("quantile, reweight, resample when ESS < N/2, alive compaction, <= Kmcmc sweeps with "
-                                  "their counter read-backs, extrema(Ds) (smc:301-364)") if cfg["kind"] == "smc" else
+                "step_includes": ("extrema(Ds), eps-quantile, reweight, ESS, partition (one call), resample when ESS < N/2, "
+                                  "<= Kmcmc sweeps with their counter read-backs (smc:301-364)") if cfg["kind"] == "smc" else
                                  "rank pass (while max Ds > eps_target), one sweep with nsim / completion / extrema folded in (mc:140-161)",
                 "parallelism": (f"particle-shard x{world}, replicated row store: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",

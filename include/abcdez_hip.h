@@ -165,7 +165,7 @@ ABCDEZ_API int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int6
  * smc_partition: alive[0 .. n_prev) holds the flags after the reweight, n_new = sum(alive) (the reweight's n_alive).
  *   Swaps rows / log-prior / distance / weight / flag / blob stamp; copies bits to bits_other.  Asynchronous.
  * smc_swarm_packed: S2+S3 for the positions [r_lo, r_hi) of the prefix [0, n_alive) (one GPU: 0, n_alive; sharded: a
- *   sub-range whose ends are multiples of 2048 or n_alive).  flags (may be NULL): per position, bit 0 accepted, bit 1
+ *   sub-range whose ends are multiples of 64 or n_alive).  flags (may be NULL): per position, bit 0 accepted, bit 1
  *   simulated.  nacc = nsim = NULL: no counters and no host synchronisation.
  * smc_replay_packed: what a replica does for the positions of the OTHER ranks after the flag exchange: rebuilds the
  *   accepted proposals theta_i + gamma (theta_a - theta_b) (smc:128) and their log-priors from its own rows and the
@@ -177,6 +177,19 @@ ABCDEZ_API int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int6
 ABCDEZ_API int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new,
                                     const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1,
                                     double* logpi, double* delta, double* wns);
+/* One generation's prologue of the driver loop in ONE call and ONE host synchronisation: extrema(Ds) of the generation
+ * that just ended (src/abcdez_smc.jl:364), eps = max(min(quantile(Ds[alive], alpha), eps_prev), eps_target) (:301),
+ * abcdesmc_update_ws! + normalisation + alive flags + ESS (:305-311, :323), and -- unless ESS < ess_min, in which case
+ * the driver resamples (:324-326) and *partitioned = 0 -- abcdez_smc_partition.  The host keeps the eps schedule and
+ * the evidence accumulator: it passes eps_prev, eps_target and the previous kernel width eps_k_old in and gets eps,
+ * wnorm (logZ += log(wnorm), :315), ESS and n_alive = sum(alive) back.  q = the raw quantile, (dmin, dmax) = the
+ * extrema: may be NULL.  delta / wns / alive are the FULL arrays of N; the first n_prev positions are the alive prefix. */
+ABCDEZ_API int abcdez_smc_prologue_packed(abcdez_ctx* ctx, double* delta, double* wns, uint8_t* alive, int64_t N,
+                                          int64_t n_prev, double alpha, double eps_prev, double eps_target,
+                                          double eps_k_old, double ess_min, const uint32_t* bits, uint32_t* bits_other,
+                                          double* slot0, double* slot1, double* logpi, double* eps, double* q,
+                                          double* wnorm, double* ess, int64_t* n_alive, int32_t* partitioned,
+                                          double* dmin, double* dmax);
 ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
                                        int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi,
                                        double* delta, uint8_t* flags, double eps, double gamma0, double gamma_sigma,

@@ -818,7 +818,7 @@ static void packed_proposal(const abz_model* M, const uint32_t* bits, int64_t n_
 }
 
 /* positions [r_lo, r_hi) of the alive prefix [0, n_alive); flags[p]: bit 0 accepted, bit 1 simulated (may be NULL).
- * bits_out gets the new bit of every position in [r_lo, r_hi); r_lo and r_hi must be multiples of 32 or the ends of
+ * bits_out gets the new bit of every position in [r_lo, r_hi); r_lo and r_hi must be multiples of 64 or the ends of
  * the prefix so that no word is shared with another caller.                                                    */
 ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
                                   int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta,

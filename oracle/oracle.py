@@ -226,6 +226,18 @@ class OracleOps:
                                           _p(slot1), _p(logpi), _p(delta), _p(wns))
         assert got == n_new, (got, n_new)
 
+    def smc_prologue_packed(self, delta, wns, alive, n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, bits, bits_other,
+                            slot0, slot1, logpi):
+        """the checker of abcdez_smc_prologue_packed: the same statements, one oracle call each"""
+        lo, hi = self.extrema(delta)
+        q = self.quantile_alive(delta[:n_prev], alive[:n_prev], alpha)[0]
+        eps = max(min(q, eps_prev), eps_target)
+        wnorm, ess, n_alive = self.smc_reweight(delta[:n_prev], wns[:n_prev], alive[:n_prev], eps_k, eps)
+        part = not (n_alive > 0 and ess < ess_min)
+        if part:
+            self.smc_partition(n_prev, n_alive, alive, bits, bits_other, slot0, slot1, logpi, delta, wns)
+        return eps, wnorm, ess, n_alive, part, lo, hi
+
     def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
                          sweep, want_counts=True):
         nacc, nsim = _i64(), _i64()
@@ -320,8 +332,10 @@ def oracle_engine(spec, nparticles, process_group=None, storage="classic"):
 
 
 def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0,
-                 facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000, packed=False):
-    """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c)."""
+                 facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000, packed=True):
+    """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c).  packed (default): the population is
+    partitioned after every reweight so that the alive particles form a prefix (orc_smc_partition) -- the spec of
+    the product's abcdesmc; packed=False: particles keep their index (the legacy double-buffer / row-store modes)."""
     L = lib()
     L.orc_set_stamps(None, None)      # the C drivers carry no blobs: unbind stamp arrays an earlier engine left behind
     m = OracleModel(spec)

@@ -19,13 +19,14 @@ from oracle import oracle as O
 
 def cases():
     return {
-        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 2000),     # blobs: stamps travel too
-        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8, blobs=True), 2.5, 1024),
+        # population sizes divisible by 1, 2, 3, 4 and 8 ranks
+        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 2016),     # blobs: stamps travel too
+        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8, blobs=True), 2.5, 1032),
         "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 600),
         # BASELINE.json configs[3] in miniature: Lotka-Volterra RK4, 4 x Uniform(0, 2) prior, 8 observations
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6),
-                                  dt=0.05, steps_per_obs=10, blobs=True), 1.2, 512),
+                                  dt=0.05, steps_per_obs=10, blobs=True), 1.2, 528),
     }
 
 
@@ -56,10 +57,10 @@ def main():
         return engine(spec, n, pg_, storage="classic")
 
     for name, (prior, sim, eps, N) in cases().items():
-        # default storage: row store; sharded = accept-flag exchange + replay on the replicas
+        # default storage: packed population; sharded = accept-flag exchange + replay on the replicas
         r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
-        assert r.engine.rows_mode and r.engine.sharded_rows == (world > 1 or mode == "rccl1")
+        assert r.engine.packed and r.engine.sharded_packed == (world > 1 or mode == "rccl1")
         c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=classic,
                        process_group=pg)
         assert not c.engine.rows_mode

@@ -1,9 +1,9 @@
-"""N > 1 path on CPU: world_size-2 (and 4) gloo jobs through the same PopulationEngine the
-GPU path uses (contiguous particle shards; row store: accept-flag all-gather + replay on the
-replicas, distances once per generation; classic storage: in-place all-gather of the new rows /
-logπ / Δ after every sweep; integer counter all-reduce), with the oracle as compute backend.  The RNG is
-keyed by the global particle index, so any world size must reproduce the single-process
-run bit for bit."""
+"""N > 1 path on CPU: gloo jobs of 2, 3, 4 and 8 ranks through the same PopulationEngine the GPU path uses
+(packed population: every rank sweeps a chunk of the alive prefix, accept-flag all-gather + replay on the
+replicas, distances once per generation; double-buffered storage (abcdemc, legacy abcdesmc): in-place all-gather
+of the new rows / logπ / Δ after every sweep; integer counter all-reduce), with the oracle as compute backend.
+The RNG is keyed by the global position, so any world size -- powers of two or not -- must reproduce the
+single-process run bit for bit."""
 import os
 import socket
 import subprocess
@@ -33,7 +33,7 @@ def run_world(world, outdir, mode="oracle", timeout=900):
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     out = {}
-    for world in (1, 2, 4):
+    for world in (1, 2, 3, 4, 8):
         d = tmp_path_factory.mktemp(f"world{world}")
         run_world(world, d)
         out[world] = d
@@ -41,7 +41,7 @@ def runs(tmp_path_factory):
 
 
 @pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "lv"])
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_run_equals_single_process(runs, name, world):
     ref = np.load(os.path.join(runs[1], f"result_{name}_rank0.npz"))
     for rank in range(world):
@@ -54,10 +54,7 @@ def test_sharded_run_equals_single_process(runs, name, world):
             assert ref["blobs"].shape[0] == ref["C"].shape[0]
             for k in ("blobs", "classic_blobs", "mc_blobs"):
                 assert np.array_equal(ref[k], got[k]), (name, world, rank, k)
-        # the two storages are the same algorithm
-        for k in ("theta", "C", "Wns", "logpi"):
-            assert np.array_equal(got[k], got["classic_" + k], equal_nan=True), (name, world, rank, k)
-        assert float(got["logZ"]) == float(got["classic_logZ"]) and int(got["nsims"]) == int(got["classic_nsims"])
+        assert float(ref["classic_logZ"]) == float(got["classic_logZ"]) and int(ref["classic_nsims"]) == int(got["classic_nsims"])
         assert float(ref["logZ"]) == float(got["logZ"])
         assert int(ref["nsims"]) == int(got["nsims"]) and int(ref["iters"]) == int(got["iters"])
         assert int(ref["mc_nsims"]) == int(got["mc_nsims"])

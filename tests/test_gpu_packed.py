@@ -40,6 +40,46 @@ def assert_equal(hip, orc, what):
     assert same(hip.buf[0][0], orc.buf[0][0]) and same(hip.buf[1][0], orc.buf[1][0]), f"{what}: a slot array differs"
 
 
+@pytest.mark.parametrize("name", ["normal1d", "mvn32", "mvn3", "quad2d_inf", "socks"])
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_packed_fused_prologue_parity(oracle, name, abck):
+    """abcdez_smc_prologue_packed (extrema, eps on the device, reweight, ESS, device-predicated partition: one call,
+    one read-back) against the same statements issued one by one through the oracle"""
+    prior, sim, eps_target = models()[name]
+    N = 9001
+    spec = A.ModelSpec(prior, sim, abck, seed=6)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    orc = PopulationEngine(spec, N, ops=oracle.OracleOps(spec), storage="packed")
+    for e in (hip, orc):
+        e.init_population()
+        e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps, eps_k, resampled, parts = math.inf, math.inf, 0, 0
+    for gen in range(16):
+        want = orc.smc_prologue(0.85, eps, eps_target, eps_k, 0.5 * N)
+        got = hip.smc_prologue(0.85, eps, eps_target, eps_k, 0.5 * N)
+        assert got == want, (gen, got, want)
+        assert hip.n_prev == orc.n_prev
+        eps, _, ess, n_alive, _ = want
+        assert_equal(hip, orc, f"gen {gen} prologue")
+        if n_alive > 0 and ess < 0.5 * N:
+            assert hip.n_prev > n_alive or n_alive == N               # not partitioned: the driver resamples
+            hip.smc_resample(); orc.smc_resample()
+            resampled += 1
+            n_alive = N
+        else:
+            parts += 1
+            assert bool(hip.alive[:n_alive].all()) and not bool(hip.alive[n_alive:].any())
+        if n_alive < 3:
+            break
+        hip.alive_compact(); orc.alive_compact()
+        for k in range(2):
+            assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5)
+        assert_equal(hip, orc, f"gen {gen} sweeps")
+        eps_k = eps
+    assert resampled >= 1 and parts >= 3
+
+
 @pytest.mark.parametrize("name", list(models()))
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
 def test_packed_generations_parity(oracle, name, abck):
@@ -138,7 +178,7 @@ def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
     all replicas must then equal the population one full sweep leaves -- rows of both slots, slot bits, log-priors
     -- and the replay's counters are the full sweep's"""
     prior, sim, eps_target = models()[name]
-    N, G = 3 * PACKED_ALIGN * 4 + 777, 3
+    N, G = 40000 + 777, 3
     spec = A.ModelSpec(prior, sim, seed=9)
     e = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
     e.init_population(); e.reset_weights()

@@ -211,7 +211,7 @@ CASES = {
 def test_shim_call_sequence_abcdesmc(oracle, name):
     prior, sim, eps, N = CASES[name]
     got = shim_abcdesmc(prior, sim, eps, N, seed=31)
-    ref = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=31), N, eps)
+    ref = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=31), N, eps, packed=False)
     assert got["iters"] == ref["iters"] and got["nsims"] == ref["nsims"] and got["logZ"] == ref["logZ"]
     assert np.array_equal(np.array(got["eps_hist"]), ref["eps_hist"])
     assert np.array_equal(got["C"], ref["C"]) and np.array_equal(got["Wns"], ref["Wns"])

@@ -25,7 +25,7 @@ def main():
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
-            if "smc_swarm_kernel" in r["Kernel_Name"]:
+            if "smc_swarm" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
                 grid = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
                 sweeps.append((grid, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
