@@ -21,6 +21,7 @@ PROTOTYPES = {
     "abcdez_ctx_create_user": [C.POINTER(Model), C.c_char_p, C.c_int, C.POINTER(_vp)],
     "abcdez_ctx_destroy": [_vp],
     "abcdez_ctx_set_stream": [_vp, _vp],
+    "abcdez_ctx_reserve": [_vp, _i64],
     "abcdez_ctx_set_lanes": [_vp, C.c_int],
     "abcdez_ctx_get_layout": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "abcdez_sync": [_vp],
@@ -60,15 +61,17 @@ PROTOTYPES = {
     "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _i64, _f64, _pf64, _pf64, _pf64],
     "abcdez_extrema": [_vp, _vp, _i64, _pf64, _pf64],
     "abcdez_count_gt": [_vp, _vp, _i64, _f64, _pi64],
-    "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _f64, _f64, _vp, _vp],
+    "abcdez_mc_rank_prepare": [_vp, _vp, _i64, _f64, _f64, _vp, _vp, _vp],
     "abcdez_mc_swarm": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64, _u32,
                         _pi64, _pi64, _pf64, _pf64],
+    "abcdez_mc_generation": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _f64, _u32,
+                             _pi64, _pi64, _pf64, _pf64],
     "abcdez_push_p": [_vp, _vp, _i64, _vp],
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
 # symbols with a non-status return type
-OTHER_SYMBOLS = ("abcdez_version", "abcdez_last_error")
+OTHER_SYMBOLS = ("abcdez_version", "abcdez_last_error", "abcdez_abi_layout")
 
 
 class AbcdezError(RuntimeError):
@@ -94,6 +97,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.abcdez_abi_layout.argtypes = [C.POINTER(_i32), C.c_int]
+    lib.abcdez_abi_layout.restype = C.c_int
     lib.abcdez_version.restype = C.c_int
     lib.abcdez_last_error.restype = C.c_char_p
     _LIB = lib

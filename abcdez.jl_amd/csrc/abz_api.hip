@@ -17,7 +17,7 @@ int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
 int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
-int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
@@ -63,7 +63,23 @@ static void default_shape(const abz_model& m, int* L, int* C) {
 
 extern "C" {
 
-int abcdez_version(void) { return 100; }
+int abcdez_version(void) { return 200; }
+
+/* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
+ * shim, the ctypes binding) can assert its layout instead of trusting it */
+int abcdez_abi_layout(int32_t* out, int n) {
+  const int32_t lay[] = {
+      (int32_t)sizeof(abz_prior_dim), (int32_t)offsetof(abz_prior_dim, family), (int32_t)offsetof(abz_prior_dim, discrete),
+      (int32_t)offsetof(abz_prior_dim, p0), (int32_t)offsetof(abz_prior_dim, p1), (int32_t)offsetof(abz_prior_dim, c0),
+      (int32_t)offsetof(abz_prior_dim, c1), (int32_t)offsetof(abz_prior_dim, reserved),
+      (int32_t)sizeof(abz_model), (int32_t)offsetof(abz_model, d), (int32_t)offsetof(abz_model, ld),
+      (int32_t)offsetof(abz_model, sim_id), (int32_t)offsetof(abz_model, abck), (int32_t)offsetof(abz_model, seed),
+      (int32_t)offsetof(abz_model, n_data), (int32_t)offsetof(abz_model, n_blob), (int32_t)offsetof(abz_model, sim_p),
+      (int32_t)offsetof(abz_model, data), (int32_t)offsetof(abz_model, prior)};
+  const int m = (int)(sizeof(lay) / sizeof(lay[0]));
+  for (int k = 0; k < m && k < n; ++k) out[k] = lay[k];
+  return m;
+}
 const char* abcdez_last_error(void) { return g_err.c_str(); }
 
 static int ctx_create_common(const abz_model* model, const char* user_source, int device, abcdez_ctx** out) {
@@ -166,6 +182,13 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   delete ctx;
   return 0;
+}
+
+int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
+  ABZ_REQUIRE(ctx, "ctx_reserve: null context");
+  ABZ_REQUIRE(N >= 1 && N <= 0x7FFFFFFFll, "ctx_reserve: N out of range");
+  /* the largest user: the resampling (8 N of cumulative weights + tile sums) / the rank pass of abcdemc (12 N + its table) */
+  return abz_ws_reserve(ctx, (size_t)N * 16 + ((size_t)8 << 20));
 }
 
 int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
@@ -431,7 +454,7 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_packed: position range out of bounds");
-  ABZ_REQUIRE(r_lo % ABZ_PACKED_ALIGN == 0 && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
+  ABZ_REQUIRE((r_lo % ABZ_PACKED_ALIGN == 0 || r_lo == n_alive) && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
               "smc_swarm_packed: a sub-range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_swarm_packed: the two slots / bit arrays must differ");
   int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
@@ -451,7 +474,7 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags && nacc && nsim, "smc_replay_packed: null argument");
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
-  ABZ_REQUIRE(skip_lo % ABZ_PACKED_ALIGN == 0 && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
+  ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
               "smc_replay_packed: the own range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_replay_packed: the two slots / bit arrays must differ");
   int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0,
@@ -592,23 +615,23 @@ int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr,
 }
 
 int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                           uint32_t* order, double* sorted_delta) {
-  ABZ_REQUIRE(ctx && delta && order && sorted_delta, "mc_rank_prepare: null argument");
+                           uint32_t* order, double* sorted_delta, uint32_t* cnt) {
+  ABZ_REQUIRE(ctx && delta && order && sorted_delta && cnt, "mc_rank_prepare: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
   ABZ_REQUIRE(eps_pop == eps_pop, "mc_rank_prepare: eps_pop is NaN");
-  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta);
+  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt);
 }
 
-int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N, const double* theta,
+int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, int64_t N, const double* theta,
                     const double* logpi, const double* delta, double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma, int64_t i0, int64_t n_local,
                     uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax) {
-  ABZ_REQUIRE(ctx && order && sorted_delta && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
+  ABZ_REQUIRE(ctx && order && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
               "mc_swarm: null argument");
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
-  int rc = abz_launch_mc_swarm(ctx, order, sorted_delta, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
+  int rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
                                eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep);
   if (rc) return rc;
   const int bank = ctx->mm_bank;
@@ -624,6 +647,20 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted
     if (dmax) *dmax = hi;
   }
   return 0;
+}
+
+/* one abcdemc generation in one call: the rank pass (when the population is not converged) and the sweep */
+int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                         double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta, uint32_t* cnt,
+                         double eps_pop, double eps_target, double dmax, double gamma0, double gamma_sigma, uint32_t sweep,
+                         int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out) {
+  ABZ_REQUIRE(ctx && order && sorted_delta && cnt, "mc_generation: null argument");
+  if (dmax > eps_target) {           /* mc:20-24 is only reached while some Ds[i] > eps */
+    const int rc = abcdez_mc_rank_prepare(ctx, delta, N, eps_pop, dmax, order, sorted_delta, cnt);
+    if (rc) return rc;
+  }
+  return abcdez_mc_swarm(ctx, order, cnt, N, theta, logpi, delta, ntheta, nlogpi, ndelta, eps_pop, eps_target, gamma0,
+                         gamma_sigma, 0, N, sweep, nsim, n_above_target, dmin, dmax_out);
 }
 
 int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) {

@@ -105,7 +105,7 @@ int abz_launch_resample_gather_rows(abcdez_ctx*, const uint32_t*, uint32_t, uint
                                     const double*, double*, double*, double*, uint8_t*);
 int abz_launch_rows_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
 int abz_rows_commit_impl(abcdez_ctx*, const uint32_t*, int64_t, uint32_t*);
-int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const double*, uint32_t, const double*, const double*,
+int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);
 int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,

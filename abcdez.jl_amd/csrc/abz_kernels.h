@@ -485,7 +485,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
 struct McSwarmArgs {
   HotModel hm;
   const uint32_t* order;
-  const double* sorted_delta;
+  const uint32_t* cnt;          /* by particle: #{j : Ds[j] <= Ds[i]} (valid where Ds[i] > eps_pop) */
   const double* theta;
   const double* logpi;
   const double* delta;
@@ -533,8 +533,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   const double eps = di <= a.eps_target ? a.eps_target : a.eps_pop;       /* mc:19 */
   uint32_t s = i;
   if (di > eps) {                                                         /* mc:20-24 */
-    const uint32_t cnt = upper_bound_f64(a.sorted_delta, a.N, di);
-    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, cnt)];
+    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, a.cnt[i])];
   }
   uint32_t ia, ib;                                                        /* mc:25-32 */
   abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.N, s, &ia, &ib);

@@ -15,13 +15,13 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
   mc_swarm_kernel_body<SIM, L, C>(a);
 }
 
-int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, uint32_t N,
+int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, uint32_t N,
                         const double* theta, const double* logpi, const double* delta, double* ntheta, double* nlogpi,
                         double* ndelta, double eps_pop, double eps_target, double gamma0, double gsig, uint32_t i0,
                         uint32_t n_local, uint32_t sweep) {
   if (n_local == 0) return 0;
   McSwarmArgs a;
-  a.hm = ctx->hot; a.order = order; a.sorted_delta = sorted_delta;
+  a.hm = ctx->hot; a.order = order; a.cnt = cnt;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
   const unsigned nblocks = abz_grid((uint64_t)n_local * (uint64_t)ctx->L);

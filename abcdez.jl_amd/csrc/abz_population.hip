@@ -326,11 +326,13 @@ int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t*
  *   part_swap    lane group k swaps rows / log-prior / distance / weight / flag / stamp of (hole_k, filler_k)     */
 /* dyn (fused prologue): n_new and the resampling decision are still on the device -- n_new = scal[NALIVE] (an f64), and
  * when the ESS 1 / scal[SUMSQ] is below ess_min the driver will resample (smc:323-326), so nothing is partitioned */
-__device__ inline uint32_t part_n_new(const unsigned long long* __restrict__ dyn, uint32_t n_new, uint32_t n_prev, double ess_min) {
+__device__ inline uint32_t part_n_new(const unsigned long long* __restrict__ dyn, uint32_t n_new, uint32_t n_prev, double ess_min,
+                                      bool* go) {
+  *go = true;
   if (!dyn) return n_new;
   const double na = abz_u2d(dyn[ABZ_S_NALIVE]);
   const double ess = 1.0 / abz_u2d(dyn[ABZ_S_SUMSQ]);
-  if (na > 0.0 && ess < ess_min) return n_prev;       /* resampling ahead: no holes below n_prev, no fillers above */
+  if (na > 0.0 && ess < ess_min) *go = false;          /* resampling ahead: neither holes nor fillers are listed */
   return (uint32_t)na;
 }
 __global__ __launch_bounds__(ABZ_BLOCK) void part_count_kernel(const uint8_t* __restrict__ alive, uint32_t n_prev,
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_count_kernel(const uint8_t* __
                                                                const unsigned long long* __restrict__ dyn, double ess_min,
                                                                unsigned long long* __restrict__ err) {
   __shared__ uint32_t s_c[2];
-  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min);
+  bool go;
+  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min, &go);
   if (blockIdx.x == 0 && threadIdx.x == 0) *err = 0ull;
   if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
   __syncthreads();
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_count_kernel(const uint8_t* __
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const uint32_t k = base + it * ABZ_BLOCK + threadIdx.x;
-    const bool in = k < n_prev;
+    const bool in = go && k < n_prev;
     const bool al = in && alive[k];
     h += (uint32_t)__popcll(__ballot(in && !al && k < n_new));
     f += (uint32_t)__popcll(__ballot(al && k >= n_new));
@@ -387,7 +390,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __r
                                                               uint32_t* __restrict__ bits_other, uint32_t nwords,
                                                               const unsigned long long* __restrict__ dyn, double ess_min) {
   __shared__ uint32_t s_wave[2][4];
-  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min);
+  bool go;
+  const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min, &go);
   /* both bit arrays must agree wherever no sweep writes: positions that just left the prefix keep the bit of the
    * CURRENT array (their last sweep may have flipped it) */
   for (uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x; w < nwords; w += gridDim.x * ABZ_BLOCK) bits_other[w] = bits[w];
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __r
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int it = 0; it < 4; ++it) {
     const uint32_t k = base + it * ABZ_BLOCK + threadIdx.x;
-    const bool in = k < n_prev;
+    const bool in = go && k < n_prev;
     const bool al = in && alive[k];
     const bool is_h = in && !al && k < n_new, is_f = al && k >= n_new;
     const unsigned long long bh = __ballot(is_h), bf = __ballot(is_f);
@@ -1164,8 +1168,9 @@ int abz_count_alive_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, int64
 static int extrema_enqueue(abcdez_ctx* ctx, const double* delta, int64_t N) {
   unsigned long long init[2] = {~0ull, 0ull};
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->d_scal + ABZ_S_MIN, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  /* few blocks: every block ends with two same-address atomics, which serialise (2048 blocks spent 45 us on them) */
   unsigned grid = (unsigned)((N + 8 * ABZ_BLOCK - 1) / (8 * ABZ_BLOCK));
-  if (grid > 2048u) grid = 2048u;
+  if (grid > 256u) grid = 256u;
   hipLaunchKernelGGL(extrema_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, N, ctx->d_scal + ABZ_S_MIN,
                      ctx->d_scal + ABZ_S_MAX);
   ABZ_HIP_CHECK(hipGetLastError());

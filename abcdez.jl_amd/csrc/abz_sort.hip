@@ -7,7 +7,9 @@
  *                   order is immaterial and a stable partition is enough);
  * order[nA .. N)  : the others sorted by (Ds, index);
  * sorted_delta[p] = max(Ds[order[p]], eps_pop): non-decreasing, so the candidate set of particle i is
- *                   order[0 .. upper_bound(sorted_delta, Ds[i])) exactly as in the reference's mask.
+ *                   order[0 .. upper_bound(sorted_delta, Ds[i])) exactly as in the reference's mask;
+ * cnt[i]          = that upper bound, #{j : Ds[j] <= Ds[i]}, for every particle outside the first block (the sweep
+ *                   reads it coalesced instead of searching sorted_delta: 20 dependent loads per particle).
  *
  * Hand-written for this path instead of a library sort of 64-bit keys:
  *   1. every particle gets a 24-bit BUCKET id: 0 for Ds <= eps_pop, else 1 + ((key - key(eps_pop) - 1) >> shift),
@@ -66,13 +68,18 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const double* __res
       }
 #pragma unroll
       for (int u = 0; u < MCR_BATCH; ++u) {
-        if (!in[u]) continue;
-        if constexpr (PASS == 0) {
-          const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
-          key[i] = k[u];
-          val[i] = (uint32_t)i;
+        if (in[u]) {
+          if constexpr (PASS == 0) {
+            const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
+            key[i] = k[u];
+            val[i] = (uint32_t)i;
+          }
         }
-        atomicAdd(&s_h[wave][(k[u] >> (8 * PASS)) & 255u], 1u);
+        /* bucket 0 (Ds <= eps_pop: most of the population late in a run) has digit 0 in every pass: counted with one
+         * ballot instead of up to 64 colliding LDS atomics */
+        const unsigned long long z = __ballot(in[u] && k[u] == 0u);
+        if (lane == 0 && z) atomicAdd(&s_h[wave][0], (uint32_t)__popcll(z));
+        if (in[u] && k[u] != 0u) atomicAdd(&s_h[wave][(k[u] >> (8 * PASS)) & 255u], 1u);
       }
     }
   }
@@ -119,7 +126,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
                                                                 uint32_t rounds, uint32_t* __restrict__ key_out,
                                                                 uint32_t* __restrict__ val_out,
                                                                 const double* __restrict__ delta, double eps_pop,
-                                                                double* __restrict__ sorted_delta) {
+                                                                double* __restrict__ sorted_delta,
+                                                                uint32_t* __restrict__ cnt_of) {
   __shared__ uint32_t s_run[MCR_WAVES][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
         if constexpr (LAST) {
           const double x = delta[v];
           sorted_delta[pos] = k == 0u ? eps_pop : x;
+          cnt_of[v] = pos + 1u;                       /* right for a bucket of one; shared buckets: mcr_fixup_kernel */
         }
         if (rank + 1u == cnt) run[d] = pos + 1u;
       }
@@ -184,13 +193,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
  * in index order) cost one pass over the run; bucket 0 (Ds <= eps_pop) keeps its index order by definition.   */
 __global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __restrict__ bucket, uint32_t n,
                                                               uint32_t* __restrict__ order,
-                                                              double* __restrict__ sorted_delta) {
+                                                              double* __restrict__ sorted_delta,
+                                                              uint32_t* __restrict__ cnt) {
   const uint32_t p = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   if (p >= n) return;
   const uint32_t b = bucket[p];
   if (b == 0u || (p > 0u && bucket[p - 1u] == b)) return;
   uint32_t e = p + 1u;
   while (e < n && bucket[e] == b) ++e;
+  if (e == p + 1u) return;                            /* a bucket of one: nothing to do */
   for (uint32_t q = p + 1u; q < e; ++q) {             /* insertion sort: linear on sorted input */
     const double x = sorted_delta[q];
     const uint32_t ix = order[q];
@@ -205,6 +216,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __
     }
     if (at != q) { sorted_delta[at] = x; order[at] = ix; }
   }
+  /* cnt of a particle = end of its run of EQUAL distances (upper bound), walking the sorted bucket from the back */
+  uint32_t end = e;
+  for (uint32_t q = e; q-- > p;) {
+    if (q + 1u < e && sorted_delta[q] != sorted_delta[q + 1u]) end = q + 1u;
+    cnt[order[q]] = end;
+  }
 }
 
 static inline unsigned long long host_order_key(double x) {
@@ -214,7 +231,7 @@ static inline unsigned long long host_order_key(double x) {
 }
 
 int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                          uint32_t* order, double* sorted_delta) {
+                          uint32_t* order, double* sorted_delta, uint32_t* cnt) {
   const uint32_t n = (uint32_t)N;
   /* window of the binning: (eps_pop, dmax_hint] in key space -> 2^24 - 2 buckets */
   const unsigned long long klo = host_order_key(eps_pop);
@@ -224,9 +241,10 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   int bits = 0;
   while (bits < 64 && (range >> bits) != 0ull) ++bits;   /* range < 2^bits */
   const int shift = bits > MCR_BITS ? bits - MCR_BITS : 0;
-  /* one wave per tile; at most 2048 tiles so that one block scans the table */
-  uint32_t rounds = 32;
-  while ((uint64_t)rounds * MCR_ROUND * 2048ull < (uint64_t)n) rounds *= 2;
+  /* one wave per tile of rounds x 64 elements; short tiles = many waves in flight (each walks its rounds one after the
+   * other), at most 4096 tiles so that the count table stays small */
+  uint32_t rounds = MCR_BATCH;
+  while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;
   const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
   const size_t pb = abz_align((size_t)n * 4), tb = abz_align((size_t)256 * ntiles * 4 + 256 * 4);
   int rc = abz_ws_reserve(ctx, 3 * pb + tb);
@@ -243,17 +261,17 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, valB, delta, eps_pop, sorted_delta);
+                     keyB, valB, delta, eps_pop, sorted_delta, cnt);
   hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyB, valB, table, ntiles, rounds);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyB, valB, n, table, totals, ntiles, rounds,
-                     keyA, valA, delta, eps_pop, sorted_delta);
+                     keyA, valA, delta, eps_pop, sorted_delta, cnt);
   hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, order, delta, eps_pop, sorted_delta);
+                     keyB, order, delta, eps_pop, sorted_delta, cnt);
   hipLaunchKernelGGL(mcr_fixup_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, st, keyB, n, order,
-                     sorted_delta);
+                     sorted_delta, cnt);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

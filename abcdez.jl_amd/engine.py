@@ -80,6 +80,10 @@ class HipOps:
         s = torch.cuda.current_stream(self.device)
         _lib.check(self.lib, self.lib.abcdez_ctx_set_stream(self.ctx, C.c_void_p(s.cuda_stream)))
 
+    def reserve(self, n: int):
+        """size the library's workspace for n particles up front (otherwise the first resampling grows it mid-run)"""
+        _lib.check(self.lib, self.lib.abcdez_ctx_reserve(self.ctx, n))
+
     def layout(self):
         ld, L, Cc = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
@@ -259,18 +263,27 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_count_gt(self.ctx, _ptr(delta), delta.numel(), thr, C.byref(c)))
         return c.value
 
-    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta):
+    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta, cnt):
         """asynchronous: no host synchronisation"""
         _lib.check(self.lib, self.lib.abcdez_mc_rank_prepare(self.ctx, _ptr(delta), delta.numel(), eps_pop, dmax_hint,
-                                                             _ptr(order), _ptr(sorted_delta)))
+                                                             _ptr(order), _ptr(sorted_delta), _ptr(cnt)))
 
-    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep):
+    def mc_swarm(self, order, cnt, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep):
         """-> (nsim, #(new Ds > eps_target), min, max of the new Ds) over particles [i0, i0+n_local): ONE host sync"""
         nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self.lib, self.lib.abcdez_mc_swarm(
-            self.ctx, _ptr(order), _ptr(sorted_delta), cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
+            self.ctx, _ptr(order), _ptr(cnt), cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
             _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep,
             C.byref(nsim), C.byref(ngt), C.byref(lo), C.byref(hi)))
+        return nsim.value, ngt.value, lo.value, hi.value
+
+    def mc_generation(self, cur, nxt, order, sorted_delta, cnt, eps_pop, eps_target, dmax, gamma0, gsig, sweep):
+        """rank pass (if dmax > eps_target) + sweep over all particles: one library call, one host sync"""
+        nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_mc_generation(
+            self.ctx, cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]),
+            _ptr(order), _ptr(sorted_delta), _ptr(cnt), eps_pop, eps_target, dmax, gamma0, gsig, sweep, C.byref(nsim),
+            C.byref(ngt), C.byref(lo), C.byref(hi)))
         return nsim.value, ngt.value, lo.value, hi.value
 
     def push_p(self, theta, out):
@@ -328,6 +341,8 @@ class PopulationEngine:
         self.lo = self.rank * self.n_local
         self.hi = self.lo + self.n_local
         self.ops = ops if ops is not None else HipOps(spec, lanes=lanes)
+        if hasattr(self.ops, "reserve"):
+            self.ops.reserve(self.N)
         dev = self.ops.device
         self.device = dev
         N, ld = self.N, spec.ld
@@ -769,29 +784,32 @@ class PopulationEngine:
         return self._allreduce_counts(nacc, nsim)
 
     # ------------------------------------------------------------------ S4
+    def _mc_arrays(self):
+        """the enumeration of mc:23: order (positions -> particles), sorted_delta, and every particle's candidate count"""
+        if self.order is None:
+            self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+            self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+            self.rank_cnt = torch.zeros(self.N, dtype=torch.int32, device=self.device)
+
     def mc_rank_prepare(self, eps_pop: float = None, dmax_hint: float = None):
         """the enumeration of mc:23 for the current distances: particles with Ds <= eps_pop in index order, then the
         others by (Ds, index).  eps_pop / dmax_hint default to the values of mc:146-147 with eps_target = 0 (one
         extrema pass); the driver passes what it already knows.  No host synchronisation on the HIP path."""
         if self.rows_mode or self.packed:
             raise RuntimeError("abcdemc needs storage='classic'")
-        if self.order is None:
-            self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
-            self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        self._mc_arrays()
         if eps_pop is None or dmax_hint is None:
             lo, hi = self.extrema()
             eps_pop = lo if eps_pop is None else eps_pop
             dmax_hint = hi if dmax_hint is None else dmax_hint
-        self.ops.mc_rank_prepare(self.state[2], eps_pop, dmax_hint, self.order, self.sorted_delta)
+        self.ops.mc_rank_prepare(self.state[2], eps_pop, dmax_hint, self.order, self.sorted_delta, self.rank_cnt)
 
     def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float):
         """one sweep of abcdemc_swarm! -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the generation it leaves
         (mc:149,156,146,163), global over all ranks"""
-        if self.order is None:   # converged population: the order is never consulted
-            self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
-            self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        self._mc_arrays()        # (a converged population never consults them)
         self._bind_stamps()
-        nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.sorted_delta, self.state, self.other, eps_pop, eps_target,
+        nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.rank_cnt, self.state, self.other, eps_pop, eps_target,
                                               gamma0, gsig, self.lo, self.n_local, self.sweep)
         self.sweep += 1
         self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
@@ -804,6 +822,21 @@ class PopulationEngine:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
             lo, hi = float(t[0]), -float(t[1])
         return nsim, ngt, lo, hi
+
+    def mc_generation(self, eps_pop: float, eps_target: float, dmax: float, gamma0: float, gsig: float):
+        """the body of abcdemc!'s loop (mc:140-156): rank pass while some Ds > eps_target, one sweep -> (nsim,
+        #(Ds > eps_target), min Ds, max Ds) of the new generation.  One library call on a single GPU."""
+        if not self._collectives and hasattr(self.ops, "mc_generation") and not self.rows_mode and not self.packed:
+            self._mc_arrays()
+            self._bind_stamps()
+            out = self.ops.mc_generation(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, eps_pop,
+                                         eps_target, dmax, gamma0, gsig, self.sweep)
+            self.sweep += 1
+            self._swap()
+            return out
+        if dmax > eps_target:
+            self.mc_rank_prepare(eps_pop, dmax)
+        return self.mc_swarm(eps_pop, eps_target, gamma0, gsig)
 
     # ------------------------------------------------------------------ checkpoint / resume
     def download_state(self) -> dict:

@@ -18,7 +18,7 @@ log = logging.getLogger("abcdez_amd")
 
 def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
             nparticles: int = 50, generations: int = 20, verbose: bool = True, rng: int = 1,
-            parallel: bool = True, engine=None, process_group=None, resume=None):
+            parallel: bool = False, engine=None, process_group=None, resume=None):
     """Run ABC with differential-evolution moves in an MCMC setup (src/abcdez_mc.jl:102).
 
     Same arguments and defaults as the reference (see :func:`abcdesmc` for the
@@ -53,11 +53,9 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     while iters < generations:                                # mc:134
         iters += 1
         ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))          # mc:147
-        if ϵ_h > ϵ_target:
-            # the "better particle" set of mc:23 is only consulted while some Δ_i > ϵ
-            eng.mc_rank_prepare(ϵ_pop, ϵ_h)
-        # mc:149 (S2, S4); the reductions of mc:156 and of the next generation's mc:146 ride along: one host sync
-        nsim, n_above, ϵ_l, ϵ_h = eng.mc_swarm(ϵ_pop, ϵ_target, γ0, γσ)
+        # the enumeration behind mc:23 (only while some Δ_i > ϵ_target) + abcdemc_swarm! mc:149 (S2, S4); the reductions of
+        # mc:156 and of the next generation's mc:146 ride along: one engine call, one host synchronisation
+        nsim, n_above, ϵ_l, ϵ_h = eng.mc_generation(ϵ_pop, ϵ_target, ϵ_h, γ0, γσ)
         nsims += nsim
         ncomplete = 1 - n_above / nparticles                  # mc:156
         if verbose and (ncomplete != complete or complete >= (nparticles - 1) / nparticles):

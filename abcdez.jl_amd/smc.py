@@ -120,7 +120,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
              nparticles: int = 100, α: float = 0.95, δess: float = 0.5,
              nsims_max: int = 10 ** 7, Kmcmc: int = 3, Kmcmc_min: float = 1.0,
              ABCk=IndicatorStrict0toϵ, facc_stop: float = 0.0, facc_min: float = 0.0, facc_tune: float = 0.975,
-             verbose: bool = True, verboseout: bool = True, rng: int = 1, parallel: bool = True,
+             verbose: bool = True, verboseout: bool = True, rng: int = 1, parallel: bool = False,
              engine=None, process_group=None, max_iters: int = 1_000_000, resume=None):
     """Run ABC with differential-evolution moves in an SMC setup (src/abcdez_smc.jl:215).
 

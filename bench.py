@@ -121,10 +121,8 @@ class McGeneration:
     def step(self):
         e = self.e
         eps_pop = max(self.eps_target, self.lo)                                            # mc:147 (alpha = 0)
-        if self.hi > self.eps_target:
-            e.mc_rank_prepare(eps_pop, self.hi)                                            # mc:23's candidate sets
-            self.ranked += 1
-        nsim, n_above, self.lo, self.hi = e.mc_swarm(eps_pop, self.eps_target, self.gamma0, 1e-5)   # mc:149,156,146
+        self.ranked += self.hi > self.eps_target                                           # mc:23's candidate sets are built
+        nsim, n_above, self.lo, self.hi = e.mc_generation(eps_pop, self.eps_target, self.hi, self.gamma0, 1e-5)   # mc:149,156,146
         self.nsims += nsim
         self.updates += e.N
         self.sweeps += 1

@@ -35,6 +35,10 @@ extern "C" {
 typedef struct abcdez_ctx abcdez_ctx;
 
 ABCDEZ_API int abcdez_version(void);
+/* Layout of the structs that cross the boundary: fills out[0 .. n) with { sizeof(abz_prior_dim), offsetof of its 7 fields
+ * in declaration order, sizeof(abz_model), offsetof of its 10 fields in declaration order } and returns how many
+ * values there are (19).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
+ABCDEZ_API int abcdez_abi_layout(int32_t* out, int n);
 ABCDEZ_API const char* abcdez_last_error(void);
 
 /* Context = (prior, dist!, varexternal, rng, ex) of the reference signatures
@@ -52,6 +56,9 @@ ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx*
  * (src/abcdez_smc.jl:137, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17).                               */
 ABCDEZ_API int abcdez_ctx_create_user(const abz_model* model, const char* user_source, int device, abcdez_ctx** out);
 ABCDEZ_API int abcdez_ctx_destroy(abcdez_ctx* ctx);
+/* Optional: size the context's internal workspace for populations of up to N particles now, so that no later call
+ * (the first resampling, the first quantile) has to grow it -- growing synchronises the stream and reallocates. */
+ABCDEZ_API int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N);
 ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */
 ABCDEZ_API int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
@@ -237,7 +244,9 @@ ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, 
  *     eps_pop, eps_target, gamma0, gamma_sigma, nparticles, nsims, rng, ex, nblobs)
  *     src/abcdez_mc.jl:5-61 plus the copies of :140-143.
  *     rank_prepare builds the enumeration the "better particle" draw of mc:23 indexes into -- the particles with
- *     Ds <= eps_pop in index order, then the others sorted by (Ds, index); sorted_delta[p] = max(Ds[order[p]], eps_pop)
+ *     Ds <= eps_pop in index order, then the others sorted by (Ds, index); sorted_delta[p] = max(Ds[order[p]], eps_pop);
+ *     cnt[i] = #{j : Ds[j] <= Ds[i]} = upper_bound(sorted_delta, Ds[i]) for every particle i with Ds[i] > eps_pop (the
+ *     size of its candidate set; undefined for the others, which never draw, mc:19-20)
  *     -- with hand-written kernels (bucket ids over the window (eps_pop, dmax_hint], stable LSD radix passes, fix-up
  *     of shared buckets).  dmax_hint: maximum(Ds) as the driver knows it from mc:146; it only shapes the binning,
  *     any value gives the same result.  Asynchronous (no host synchronisation).
@@ -245,13 +254,21 @@ ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, 
  *     particles [i0, i0+n_local): n_above_target = sum(nDs .> eps_target) (mc:156), (dmin, dmax) = extrema(nDs)
  *     (mc:146,163) -- any of the three pointers may be NULL.                                                    */
 ABCDEZ_API int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                           uint32_t* order, double* sorted_delta);
-ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const double* sorted_delta, int64_t N,
+                           uint32_t* order, double* sorted_delta, uint32_t* cnt);
+ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, int64_t N,
                     const double* theta, const double* logpi, const double* delta,
                     double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma,
                     int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim, int64_t* n_above_target,
                     double* dmin, double* dmax);
+
+/* One generation of abcdemc!'s loop body (src/abcdez_mc.jl:140-156) on one GPU in one call: rank_prepare when
+ * dmax > eps_target (the host passes the extrema it got from the previous generation, mc:146), then mc_swarm over
+ * all N particles.  One host synchronisation per generation.                                                  */
+ABCDEZ_API int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                         double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta, uint32_t* cnt,
+                         double eps_pop, double eps_target, double dmax, double gamma0, double gamma_sigma, uint32_t sweep,
+                         int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out);
 
 /* T2  push_p over the population (src/abcdez_types.jl:20-23; result P, smc:382, mc:166). */
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);

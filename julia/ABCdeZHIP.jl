@@ -2,7 +2,10 @@
 # entry points.  NOT EXECUTED IN THE BUILD CONTAINER (no Julia there); kept small and
 # literal so a maintainer can check it against src/abcdez_smc.jl / src/abcdez_mc.jl line by
 # line.  The Python package `abcdez_amd` is the tested host; this file is the same host
-# loop in the reference's language.
+# loop in the reference's language.  Its call sequence -- every entry point, argument order
+# and type it binds -- is pinned by tests/test_gpu_shim_sequence.py (a raw-ctypes
+# transliteration, no torch), its struct layout by abcdez_abi_layout() (asserted below and
+# in tests/test_host_api.py).
 #
 # Usage:
 #     using ABCdeZ, Distributions
@@ -11,12 +14,19 @@
 #
 # Dispatch: `abcdesmc!` / `abcdemc!` get a new method on a `DeviceSimulator` in the `dist!`
 # position; every other `dist!` (an ordinary closure) keeps hitting ABCdeZ.jl's CPU methods.
+#
+# Multi-GPU: the sharded entry points (abcdez_smc_swarm_packed on a sub-range with flags,
+# abcdez_smc_replay_packed) take plain device pointers; the collectives between them
+# (one all-gather of the flag bytes per sweep, one of the distances per generation) belong to the
+# host -- MPI.jl / NCCL.jl here, torch.distributed in abcdez_amd/engine.py, which is the
+# reference for the order of the calls.
 module ABCdeZHIP
 
 using ABCdeZ, Distributions
 import ABCdeZ: abcdesmc!, abcdemc!
 
-export DeviceSimulator, Normal1D, MVNormalSim, abcdesmc!, abcdemc!
+export DeviceSimulator, Normal1D, MVNormalSim, DiracSquare, Quad2D, Mixture01, NormalTimesDU, WienerRMS,
+       LotkaVolterraRK4, Socks, UserSimulator, abcdesmc!, abcdemc!
 
 const LIB = get(ENV, "ABCDEZ_HIP_LIB", joinpath(@__DIR__, "..", "abcdez.jl_amd", "lib", "libabcdez_hip.so"))
 
@@ -28,81 +38,164 @@ end
 struct AbzModel
     d::Int32; ld::Int32; sim_id::Int32; abck::Int32
     seed::UInt64
-    n_data::Int32; n_blob::Int32          # n_blob = 0: blobs off (abcdez_blob_eval not bound by this shim)
+    n_data::Int32; n_blob::Int32          # n_blob = 0: blobs off
     sim_p::NTuple{8,Float64}
     data::Ptr{Float64}
     prior::NTuple{64,AbzPriorDim}
 end
+# the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
+function check_abi()
+    lay = Vector{Int32}(undef, 32)
+    n = ccall((:abcdez_abi_layout, LIB), Cint, (Ptr{Int32}, Cint), lay, length(lay))
+    mine = Int32[sizeof(AbzPriorDim), fieldoffset.(AbzPriorDim, 1:7)...,
+                 sizeof(AbzModel), fieldoffset.(AbzModel, 1:10)...]
+    (n == length(mine) && lay[1:n] == mine) || error("ABCdeZHIP: struct layout differs from libabcdez_hip.so (abcdez_abi_layout)")
+end
 
+# ---- device simulators = dist!(θ, ve) on the GPU (include/abcdez_spec.h, ABZ_SIM_*) -------------------------------
 abstract type DeviceSimulator end
-struct Normal1D <: DeviceSimulator; data::Float64; sigma::Float64; end       # ABZ_SIM_NORMAL1D
-Normal1D(data) = Normal1D(data, 1.0)
-struct MVNormalSim <: DeviceSimulator; y::Vector{Float64}; sigma::Float64; end  # ABZ_SIM_MVN
-MVNormalSim(y) = MVNormalSim(collect(Float64, y), 1.0)
-simid(::Normal1D) = Int32(0);  simid(::MVNormalSim) = Int32(1)
-simparams(s::Normal1D) = (s.sigma,);  simparams(s::MVNormalSim) = (s.sigma,)
-simdata(s::Normal1D) = [s.data];  simdata(s::MVNormalSim) = s.y
+struct Normal1D <: DeviceSimulator; data::Float64; sigma::Float64; blobs::Bool; end                 # ABZ_SIM_NORMAL1D
+Normal1D(data; sigma=1.0, blobs=false) = Normal1D(data, sigma, blobs)
+struct MVNormalSim <: DeviceSimulator; y::Vector{Float64}; sigma::Float64; blobs::Bool; end          # ABZ_SIM_MVN
+MVNormalSim(y; sigma=1.0, blobs=false) = MVNormalSim(collect(Float64, y), sigma, blobs)
+struct DiracSquare <: DeviceSimulator; target::Float64; blobs::Bool; end                             # test/runtests.jl:495-497
+DiracSquare(target; blobs=false) = DiracSquare(target, blobs)
+struct Quad2D <: DeviceSimulator; p_inf::Float64; blobs::Bool; end                                   # test/runtests.jl:603,614
+Quad2D(p_inf; blobs=false) = Quad2D(p_inf, blobs)
+struct Mixture01 <: DeviceSimulator; data::Float64; blobs::Bool; end                                 # test/runtests.jl:582-583
+Mixture01(data; blobs=false) = Mixture01(data, blobs)
+struct NormalTimesDU <: DeviceSimulator; data::Float64; blobs::Bool; end                             # test/runtests.jl:524-525
+NormalTimesDU(data; blobs=false) = NormalTimesDU(data, blobs)
+struct WienerRMS <: DeviceSimulator; tdata::Vector{Float64}; blobs::Bool; end                        # test/runtests.jl:537-546
+WienerRMS(tdata; blobs=false) = WienerRMS(collect(Float64, tdata), blobs)
+struct LotkaVolterraRK4 <: DeviceSimulator                                                           # BASELINE.json configs[3]
+    obs::Vector{Float64}; x0::Float64; y0::Float64; dt::Float64; steps_per_obs::Int; noise::Float64; blobs::Bool
+end
+LotkaVolterraRK4(obs; x0=1.0, y0=0.5, dt=0.01, steps_per_obs=100, noise=0.1, blobs=false) =
+    LotkaVolterraRK4(collect(Float64, obs), x0, y0, dt, steps_per_obs, noise, blobs)
+struct Socks <: DeviceSimulator; pairs::Float64; odd::Float64; n_picked::Int; blobs::Bool; end       # test/runtests.jl:427-437
+Socks(pairs, odd; n_picked=11, blobs=false) = Socks(pairs, odd, n_picked, blobs)
+# a device function given as HIP source text (abcdez_ctx_create_user): must define abz_user_dist, and abz_user_blob
+# when n_blob > 0 (INTEGRATION.md section 1)
+struct UserSimulator <: DeviceSimulator; source::String; params::Vector{Float64}; data::Vector{Float64}; n_blob::Int; end
+UserSimulator(source; params=Float64[], data=Float64[], n_blob=0) = UserSimulator(source, collect(Float64, params), collect(Float64, data), n_blob)
+
+simid(::Normal1D) = Int32(0); simid(::MVNormalSim) = Int32(1); simid(::DiracSquare) = Int32(2); simid(::Quad2D) = Int32(3)
+simid(::Mixture01) = Int32(4); simid(::NormalTimesDU) = Int32(5); simid(::WienerRMS) = Int32(6); simid(::LotkaVolterraRK4) = Int32(7)
+simid(::Socks) = Int32(8); simid(::UserSimulator) = Int32(9)
+simparams(s::Normal1D) = (s.sigma,);              simdata(s::Normal1D) = [s.data]
+simparams(s::MVNormalSim) = (s.sigma,);           simdata(s::MVNormalSim) = s.y
+simparams(s::DiracSquare) = (s.target,);          simdata(s::DiracSquare) = Float64[]
+simparams(s::Quad2D) = (s.p_inf,);                simdata(s::Quad2D) = Float64[]
+simparams(s::Mixture01) = (s.data,);              simdata(s::Mixture01) = Float64[]
+simparams(s::NormalTimesDU) = (s.data,);          simdata(s::NormalTimesDU) = Float64[]
+simparams(s::WienerRMS) = ();                     simdata(s::WienerRMS) = s.tdata
+simparams(s::LotkaVolterraRK4) = (s.x0, s.y0, s.dt, Float64(s.steps_per_obs), s.noise); simdata(s::LotkaVolterraRK4) = s.obs
+simparams(s::Socks) = (s.pairs, s.odd, Float64(s.n_picked)); simdata(s::Socks) = Float64[]
+simparams(s::UserSimulator) = Tuple(s.params);    simdata(s::UserSimulator) = s.data
+# doubles per blob = the simulated data behind a distance (abz_sim_blob_size)
+blobsize(s::Union{Normal1D,DiracSquare,Mixture01,NormalTimesDU}, d) = 1
+blobsize(s::Union{Quad2D,Socks}, d) = 2
+blobsize(s::MVNormalSim, d) = d
+blobsize(s::WienerRMS, d) = length(s.tdata)
+blobsize(s::LotkaVolterraRK4, d) = length(s.obs)
+nblob(s::UserSimulator, d) = s.n_blob
+nblob(s::DeviceSimulator, d) = s.blobs ? blobsize(s, d) : 0
 
 factors(p::Factored) = collect(p.p)
 factors(p::UnivariateDistribution) = [p]
 const PAD = AbzPriorDim(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0)
+const lgam = Distributions.SpecialFunctions.loggamma
 descriptor(p::Normal) = AbzPriorDim(1, 0, p.μ, p.σ, -log(p.σ) - 0.5 * log(2π), 1 / p.σ, 0.0)
 descriptor(p::Uniform) = AbzPriorDim(2, 0, p.a, p.b, -log(p.b - p.a), 0.0, 0.0)
 descriptor(p::DiscreteUniform) = AbzPriorDim(3, 1, p.a, p.b, -log(p.b - p.a + 1), 0.0, 0.0)
+descriptor(p::Beta) = AbzPriorDim(4, 0, p.α, p.β, -(lgam(p.α) + lgam(p.β) - lgam(p.α + p.β)), 0.0, 0.0)
+descriptor(p::NegativeBinomial) = AbzPriorDim(5, 1, p.r, p.p, p.r * log(p.p) - lgam(p.r), p.p < 1 ? log1p(-p.p) : -Inf, 0.0)
 kernelid(::Type{ABCdeZ.Indicator0toϵ}) = Int32(0);  kernelid(::Type{ABCdeZ.IndicatorStrict0toϵ}) = Int32(1)
 kernelid(::Type{ABCdeZ.Epa0toϵ}) = Int32(2);        kernelid(::Type{ABCdeZ.EpaStrict0toϵ}) = Int32(3)
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:abcdez_last_error, LIB), Cstring, ())))
 
+# ---- the population the reference driver owns (smc:242-275), device-resident, PACKED layout (include/abcdez_hip.h):
+# two row slots per position + one bit per position naming the current one; (logπ, Δ, stamps) ping-pong at resamplings;
+# abcdemc uses slot[1] / slot[2] as the reference's (θs, nθs) double buffer
 mutable struct Engine
-    ctx::Ptr{Cvoid}; N::Int; ld::Int; d::Int
-    theta::Vector{Ptr{Cvoid}}; logpi::Vector{Ptr{Cvoid}}; delta::Vector{Ptr{Cvoid}}   # ping-pong, smc:337-350
-    wns::Ptr{Cvoid}; alive::Ptr{Cvoid}; alive_idx::Ptr{Cvoid}; arank::Ptr{Cvoid}; inds::Ptr{Cvoid}
-    order::Ptr{Cvoid}; sorted::Ptr{Cvoid}
-    cur::Int; sweep::UInt32; draw::UInt32; n_alive::Int; dead_synced::Bool
+    ctx::Ptr{Cvoid}; N::Int; ld::Int; d::Int; nb::Int
+    slot::Vector{Ptr{Cvoid}}; logpi::Vector{Ptr{Cvoid}}; delta::Vector{Ptr{Cvoid}}; bits::Vector{Ptr{Cvoid}}
+    stamp::Vector{Ptr{Cvoid}}
+    wns::Ptr{Cvoid}; alive::Ptr{Cvoid}; inds::Ptr{Cvoid}; order::Ptr{Cvoid}; sorted::Ptr{Cvoid}; cnt::Ptr{Cvoid}
+    cur::Int; bc::Int; sweep::UInt32; draw::UInt32; n_alive::Int; n_prev::Int
 end
 
 devalloc(bytes) = (p = Ref{Ptr{Cvoid}}(); check(ccall((:abcdez_dev_alloc, LIB), Cint, (Csize_t, Ptr{Ptr{Cvoid}}), bytes, p)); p[])
+devfree(p) = p == C_NULL || ccall((:abcdez_dev_free, LIB), Cint, (Ptr{Cvoid},), p)
+h2d(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
+d2h(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
 
 function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
+    check_abi()
     fs = factors(prior); d = length(fs); ld = nextpow(2, d)
-    data = simdata(sim); sp = simparams(sim)
-    m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), 0,
-                 ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), pointer(data),
+    data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d)
+    m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), nb,
+                 ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), isempty(data) ? C_NULL : pointer(data),
                  ntuple(k -> k <= d ? descriptor(fs[k]) : PAD, 64))
     ctx = Ref{Ptr{Cvoid}}()
-    GC.@preserve data check(ccall((:abcdez_ctx_create, LIB), Cint, (Ref{AbzModel}, Cint, Ptr{Ptr{Cvoid}}), m, 0, ctx))
-    Engine(ctx[], N, ld, d, [devalloc(8N * ld) for _ in 1:2], [devalloc(8N) for _ in 1:2], [devalloc(8N) for _ in 1:2],
-           devalloc(8N), devalloc(N), devalloc(4N), devalloc(4N), devalloc(4N), devalloc(4N), devalloc(8N),
-           1, 0, 0, N, true)
+    GC.@preserve data begin
+        if sim isa UserSimulator
+            check(ccall((:abcdez_ctx_create_user, LIB), Cint, (Ref{AbzModel}, Cstring, Cint, Ptr{Ptr{Cvoid}}), m, sim.source, 0, ctx))
+        else
+            check(ccall((:abcdez_ctx_create, LIB), Cint, (Ref{AbzModel}, Cint, Ptr{Ptr{Cvoid}}), m, 0, ctx))
+        end
+    end
+    check(ccall((:abcdez_ctx_reserve, LIB), Cint, (Ptr{Cvoid}, Int64), ctx[], N))
+    nw = cld(N, 32)
+    e = Engine(ctx[], N, ld, d, nb, [devalloc(8N * ld) for _ in 1:2], [devalloc(8N) for _ in 1:2], [devalloc(8N) for _ in 1:2],
+               [devalloc(4nw) for _ in 1:2], nb > 0 ? [devalloc(8N) for _ in 1:2] : Ptr{Cvoid}[],
+               devalloc(8N), devalloc(N), devalloc(4N), devalloc(4N), devalloc(8N), devalloc(4N), 1, 1, 0, 0, N, N)
+    z = zeros(UInt32, nw)                       # every position's current row is slot 1
+    h2d(e, e.bits[1], z, 4nw); h2d(e, e.bits[2], z, 4nw)
+    finalizer(free!, e)
+end
+# releases the population and the context; safe to call twice (ADVICE r1: every run used to leak its arrays)
+function free!(e::Engine)
+    e.ctx == C_NULL && return
+    foreach(devfree, vcat(e.slot, e.logpi, e.delta, e.bits, e.stamp, [e.wns, e.alive, e.inds, e.order, e.sorted, e.cnt]))
+    ccall((:abcdez_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
+    e.ctx = C_NULL
 end
 other(e) = 3 - e.cur
+bind_stamps!(e) = e.nb > 0 && check(ccall((:abcdez_ctx_set_stamps, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), e.ctx, e.stamp[e.cur], e.stamp[other(e)]))
 
 # ---- one ccall per reference function (include/abcdez_hip.h) --------------------------------
-init!(e) = check(ccall((:abcdez_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-                       e.ctx, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur], 0, e.N))                    # init.jl:2-22
+function init!(e)                                                                                         # init.jl:2-22
+    bind_stamps!(e)
+    check(ccall((:abcdez_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
+                e.ctx, e.slot[1], e.logpi[e.cur], e.delta[e.cur], 0, e.N))
+end
 function reset_weights!(e)                                                                                # smc:266-270: Wns = 1/N, alive = true
     w = fill(1.0 / e.N, e.N); a = ones(UInt8, e.N)
-    check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, e.wns, w, 8e.N))
-    check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, e.alive, a, e.N))
-    e.n_alive = e.N; e.dead_synced = true
+    h2d(e, e.wns, w, 8e.N); h2d(e, e.alive, a, e.N)
+    e.n_alive = e.n_prev = e.N
 end
 function extrema_dev(e)                                                                                   # smc:286,364
     lo = Ref(0.0); hi = Ref(0.0)
     check(ccall((:abcdez_extrema, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Float64}), e.ctx, e.delta[e.cur], e.N, lo, hi))
     (lo[], hi[])
 end
-function quantile_alive(e, α)                                                                             # smc:301
-    q = Ref(0.0)
-    check(ccall((:abcdez_quantile_alive, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64, Ref{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
-                e.ctx, e.delta[e.cur], e.alive, e.N, e.n_alive, α, q, C_NULL, C_NULL)); q[]
-end
-function reweight!(e, ϵ_old, ϵ_new)                                                                       # smc:59-83, :308-311, :323
-    wnorm = Ref(0.0); ess = Ref(0.0); na = Ref(Int64(0))
-    check(ccall((:abcdez_smc_reweight, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64, Ref{Float64}, Ref{Float64}, Ref{Int64}),
-                e.ctx, e.delta[e.cur], e.wns, e.alive, e.N, ϵ_old, ϵ_new, wnorm, ess, na))
-    e.n_alive = na[]; e.dead_synced = false
-    (wnorm[], ess[], Int(na[]))
+# smc:301 (ϵ), :305-311 (weights, alive), :323 (ESS), the extrema of :364 for the generation before, and the partition of
+# the packed population: ONE call, ONE host synchronisation.  The ϵ schedule stays here: ϵ and ϵ_target go in.
+function prologue!(e, α, ϵ, ϵ_target, ϵ_k, ess_min)
+    bind_stamps!(e)
+    ϵn = Ref(0.0); q = Ref(0.0); wnorm = Ref(0.0); ess = Ref(0.0); lo = Ref(0.0); hi = Ref(0.0); na = Ref(Int64(0)); part = Ref(Int32(0))
+    check(ccall((:abcdez_smc_prologue_packed, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Float64, Float64, Float64,
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Ref{Float64}, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}, Ref{Int32}, Ref{Float64}, Ref{Float64}),
+                e.ctx, e.delta[e.cur], e.wns, e.alive, e.N, e.n_prev, α, ϵ, ϵ_target, ϵ_k, ess_min,
+                e.bits[e.bc], e.bits[3 - e.bc], e.slot[1], e.slot[2], e.logpi[e.cur], ϵn, q, wnorm, ess, na, part, lo, hi))
+    e.n_alive = na[]
+    part[] != 0 && (e.n_prev = e.n_alive)
+    (ϵn[], wnorm[], ess[], Int(na[]), (lo[], hi[]))
 end
 function get_ess(e)                                                                                       # smc:8
     ess = Ref(0.0)
@@ -110,43 +203,64 @@ function get_ess(e)                                                             
 end
 function resample!(e)                                                                                     # smc:85-104
     check(ccall((:abcdez_wsample_stratified, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, UInt32, Ptr{Cvoid}), e.ctx, e.wns, e.N, e.draw, e.inds))
-    e.draw += 1; o = other(e)
-    check(ccall((:abcdez_smc_resample_gather, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                e.ctx, e.inds, e.N, 0, e.N, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur], e.theta[o], e.logpi[o], e.delta[o], e.wns, e.alive))
-    e.cur = o; e.n_alive = e.N; e.dead_synced = true
+    e.draw += 1; o = other(e); bind_stamps!(e)
+    check(ccall((:abcdez_smc_resample_gather_packed, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                e.ctx, e.inds, e.N, e.bits[e.bc], e.bits[3 - e.bc], e.slot[1], e.slot[2], e.logpi[e.cur], e.delta[e.cur],
+                e.logpi[o], e.delta[o], e.wns, e.alive))
+    e.cur = o; e.n_alive = e.n_prev = e.N
 end
-function compact!(e)                                                                                      # smc:121,125
-    na = Ref(Int64(0))
-    check(ccall((:abcdez_alive_compact, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}), e.ctx, e.alive, e.N, e.alive_idx, e.arank, na))
-    e.n_alive = na[]
-end
-function smc_swarm!(e, ϵ, γ0, γσ)                                                                         # smc:106-153 + :337-340
-    nacc = Ref(Int64(0)); nsim = Ref(Int64(0)); o = other(e)
-    check(ccall((:abcdez_smc_swarm, LIB), Cint,
-                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-                 Float64, Float64, Float64, Int64, Int64, Cint, Ptr{Cvoid}, UInt32, Ref{Int64}, Ref{Int64}),
-                e.ctx, e.alive_idx, e.arank, e.n_alive, 0, e.n_alive, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur],
-                e.theta[o], e.logpi[o], e.delta[o], ϵ, γ0, γσ, 0, e.N, (!e.dead_synced && e.n_alive < e.N) ? 1 : 0, C_NULL, e.sweep, nacc, nsim))
-    e.sweep += 1; e.dead_synced = true; e.cur = o
+function smc_swarm!(e, ϵ, γ0, γσ)                                                                         # smc:106-153 (+ the copies of :337-340, which the packed layout does not need)
+    nacc = Ref(Int64(0)); nsim = Ref(Int64(0)); bind_stamps!(e)
+    check(ccall((:abcdez_smc_swarm_packed, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Float64, Float64, Float64, UInt32, Ref{Int64}, Ref{Int64}),
+                e.ctx, e.bits[e.bc], e.bits[3 - e.bc], e.n_alive, 0, e.n_alive, e.slot[1], e.slot[2], e.logpi[e.cur], e.delta[e.cur],
+                C_NULL, ϵ, γ0, γσ, e.sweep, nacc, nsim))
+    e.sweep += 1; e.bc = 3 - e.bc
     (Int(nacc[]), Int(nsim[]))
 end
-function download(e)
-    th = Matrix{Float64}(undef, e.ld, e.N); pushed = devalloc(8 * e.N * e.ld)
-    check(ccall((:abcdez_push_p, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), e.ctx, e.theta[e.cur], e.N, pushed))   # types.jl:20-23
-    check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, th, pushed, sizeof(th)))
-    Δ = Vector{Float64}(undef, e.N); W = Vector{Float64}(undef, e.N)
-    check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, Δ, e.delta[e.cur], 8e.N))
-    check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, W, e.wns, 8e.N))
-    ccall((:abcdez_dev_free, LIB), Cint, (Ptr{Cvoid},), pushed)
-    P = e.d == 1 ? th[1, :] : [Tuple(th[1:e.d, i]) for i in 1:e.N]
-    (P, W, Δ)
+# P (push_p-cast, smc:382 / mc:166), Wns, C and -- with blobs on -- the simulated data behind every distance
+function download(e; packed::Bool)
+    rows = devalloc(8 * e.N * e.ld); pushed = devalloc(8 * e.N * e.ld)
+    try
+        if packed
+            check(ccall((:abcdez_packed_gather, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                        e.ctx, e.bits[e.bc], e.N, e.slot[1], e.slot[2], rows))
+        end
+        src = packed ? rows : e.slot[e.cur]
+        check(ccall((:abcdez_push_p, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), e.ctx, src, e.N, pushed))   # types.jl:20-23
+        th = Matrix{Float64}(undef, e.ld, e.N); d2h(e, th, pushed, sizeof(th))
+        Δ = Vector{Float64}(undef, e.N); W = Vector{Float64}(undef, e.N)
+        d2h(e, Δ, e.delta[e.cur], 8e.N); d2h(e, W, e.wns, 8e.N)
+        blobs = fill(nothing, e.N)
+        if e.nb > 0                                # rebuild the blobs from the stamps; the re-run distance must be the stored one
+            w = Ref(Int32(0)); check(ccall((:abcdez_blob_width, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), e.ctx, w))
+            bl = devalloc(8 * e.N * w[]); redo = devalloc(8e.N)
+            try
+                check(ccall((:abcdez_blob_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                            e.ctx, src, e.stamp[e.cur], e.N, bl, redo))
+                check(ccall((:abcdez_sync, LIB), Cint, (Ptr{Cvoid},), e.ctx))
+                B = Matrix{Float64}(undef, w[], e.N); R = Vector{Float64}(undef, e.N)
+                d2h(e, B, bl, sizeof(B)); d2h(e, R, redo, 8e.N)
+                reinterpret(UInt64, R) == reinterpret(UInt64, Δ) || error("blobs: a re-run simulation does not reproduce the stored distance")
+                blobs = e.nb == 1 ? B[1, :] : [B[1:e.nb, i] for i in 1:e.N]
+            finally
+                devfree(bl); devfree(redo)
+            end
+        end
+        P = e.d == 1 ? th[1, :] : [Tuple(th[1:e.d, i]) for i in 1:e.N]
+        return (P, W, Δ, blobs)
+    finally
+        devfree(rows); devfree(pushed)
+    end
 end
 
 # ---- abcdesmc!: the host loop of src/abcdez_smc.jl:215-394, each ★ call replaced by one ccall ----
 function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                    nparticles::Int=100, α=0.95, δess=0.5, nsims_max::Int=10^7, Kmcmc::Int=3, Kmcmc_min=1.0,
                    ABCk=ABCdeZ.IndicatorStrict0toϵ, facc_stop=0.0, facc_min=0.0, facc_tune=0.975,
-                   verbose::Bool=true, verboseout::Bool=true, rng::Integer=1, parallel::Bool=true)
+                   verbose::Bool=true, verboseout::Bool=true, rng::Integer=1, parallel::Bool=false)
     0.0 ≤ α < 1.0 || error("α must be in 0 <= α < 1")                                  # smc:223-235
     0.0 ≤ δess ≤ 1.0 || error("δess must be in 0 <= δess <= 1")
     0.0 ≤ facc_stop ≤ 1.0 || error("facc_stop must be in 0 <= facc_stop <= 1")
@@ -161,90 +275,95 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
     nparticles_min ≤ nparticles || error("nparticles must be at least $(nparticles_min)")
 
     e = Engine(prior, dist!, ABCk, rng, nparticles)
-    init!(e)                                                                            # smc:242-252
-    reset_weights!(e)                                                                   # smc:266-270
-    ϵ = Inf; ϵ_k = Inf; logZ = 0.0; ess = 0.0; nsims = 0; facc = 1.0; Ki = Kmcmc        # smc:255-276
-    ess_min = nparticles * δess
-    γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5                                      # smc:280-281
-    ϵs = [ϵ]; ranges_ϵ = [extrema_dev(e)]; logZs = [logZ]; esss = [get_ess(e)]; faccs = [facc]; γ0s = [γ0]; Kmcmcs = [Ki]
-    iters = 0
-    while true                                                                          # smc:295
-        iters += 1
-        ϵ = max(min(quantile_alive(e, α), ϵ), ϵ_target)                                 # smc:301
-        ABCk(ϵ)
-        wnorm, ess, n_alive = reweight!(e, ϵ_k, ϵ)                                      # smc:305-311
-        logZ += log(wnorm)                                                              # smc:315
-        naccs = 0; Ki = Kmcmc
-        facc < facc_min && (γ0 *= facc_tune)                                            # smc:320
-        if n_alive > 0 && ess < ess_min                                                 # smc:323-326
-            resample!(e); ess = get_ess(e); n_alive = nparticles
-        end
-        if n_alive ≥ 3
-            compact!(e)
-            for i in 1:Kmcmc                                                            # smc:336-353
-                nacc, nsim = smc_swarm!(e, ϵ, γ0, γσ)
-                naccs += nacc; nsims += nsim
-                (naccs / n_alive ≥ Kmcmc_min) && (Ki = i; break)                        # smc:352
+    try
+        init!(e)                                                                            # smc:242-252
+        reset_weights!(e)                                                                   # smc:266-270
+        ϵ = Inf; ϵ_k = Inf; logZ = 0.0; ess = 0.0; nsims = 0; facc = 1.0; Ki = Kmcmc        # smc:255-276
+        ess_min = nparticles * δess
+        γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5                                      # smc:280-281
+        ϵs = [ϵ]; ranges_ϵ = [extrema_dev(e)]; logZs = [logZ]; esss = [get_ess(e)]; faccs = [facc]; γ0s = [γ0]; Kmcmcs = [Ki]
+        iters = 0
+        while true                                                                          # smc:295
+            iters += 1
+            ϵ, wnorm, ess, n_alive, range_prev = prologue!(e, α, ϵ, ϵ_target, ϵ_k, ess_min) # smc:301-311, :323
+            iters > 1 && push!(ranges_ϵ, range_prev)                                        # smc:364 of the generation before
+            ABCk(ϵ)
+            logZ += log(wnorm)                                                              # smc:315
+            naccs = 0; Ki = Kmcmc
+            facc < facc_min && (γ0 *= facc_tune)                                            # smc:320
+            if n_alive > 0 && ess < ess_min                                                 # smc:323-326
+                resample!(e); ess = get_ess(e); n_alive = nparticles
             end
+            if n_alive ≥ 3
+                for i in 1:Kmcmc                                                            # smc:336-353
+                    nacc, nsim = smc_swarm!(e, ϵ, γ0, γσ)
+                    naccs += nacc; nsims += nsim
+                    (naccs / n_alive ≥ Kmcmc_min) && (Ki = i; break)                        # smc:352
+                end
+            end
+            facc = naccs / (n_alive * Ki); ϵ_k = ϵ                                          # smc:357-360
+            push!(ϵs, ϵ); push!(logZs, logZ); push!(esss, ess); push!(faccs, facc); push!(γ0s, γ0); push!(Kmcmcs, Ki)
+            verbose && (@info "Finished run:" iteration = iters nsim = nsims ϵ = ϵ ess = ess facc = facc logZ = logZ)
+            n_alive ≥ 3 || (@warn("No alive particles"); break)                             # smc:375
+            (ϵ ≤ ϵ_target || nsims ≥ nsims_max || facc < facc_stop) && break                # smc:376
         end
-        facc = naccs / (n_alive * Ki); ϵ_k = ϵ                                          # smc:357-360
-        push!(ϵs, ϵ); push!(ranges_ϵ, extrema_dev(e)); push!(logZs, logZ); push!(esss, ess)
-        push!(faccs, facc); push!(γ0s, γ0); push!(Kmcmcs, Ki)
-        verbose && (@info "Finished run:" iteration = iters nsim = nsims ϵ = ϵ ess = ess facc = facc logZ = logZ)
-        n_alive ≥ 3 || (@warn("No alive particles"); break)                             # smc:375
-        (ϵ ≤ ϵ_target || nsims ≥ nsims_max || facc < facc_stop) && break                # smc:376
+        push!(ranges_ϵ, extrema_dev(e))                                                     # smc:364 of the last generation
+        P, Wns, Δs, blobs = download(e; packed=true)                                        # smc:382
+        return verboseout ? (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs, ϵs = ϵs, ranges_ϵ = ranges_ϵ,
+                             logZs = logZs, esss = esss, faccs = faccs, γ0s = γ0s, Kmcmcs = Kmcmcs) :
+                            (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs)  # smc:388-393
+    finally
+        free!(e)
     end
-    P, Wns, Δs = download(e)                                                            # smc:382
-    ccall((:abcdez_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
-    blobs = fill(nothing, nparticles)
-    verboseout ? (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs, ϵs = ϵs, ranges_ϵ = ranges_ϵ,
-                  logZs = logZs, esss = esss, faccs = faccs, γ0s = γ0s, Kmcmcs = Kmcmcs) :
-                 (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs)         # smc:388-393
 end
 
 # ---- abcdemc!: the host loop of src/abcdez_mc.jl:102-172 --------------------------------------------
-function count_gt(e, thr)                                                                                 # mc:133,156
+function count_gt(e, thr)                                                                                 # mc:133
     c = Ref(Int64(0))
     check(ccall((:abcdez_count_gt, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Ref{Int64}), e.ctx, e.delta[e.cur], e.N, thr, c)); Int(c[])
 end
-rank_prepare!(e) = check(ccall((:abcdez_mc_rank_prepare, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
-                               e.ctx, e.delta[e.cur], e.N, e.order, e.sorted))                            # mc:23
-function mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                                            # mc:5-61 + :140-143
-    nsim = Ref(Int64(0)); o = other(e)
+rank_prepare!(e, ϵ_pop, ϵ_h) = check(ccall((:abcdez_mc_rank_prepare, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                                           e.ctx, e.delta[e.cur], e.N, ϵ_pop, ϵ_h, e.order, e.sorted, e.cnt))    # mc:23
+function mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                                            # mc:5-61 + :140-143; also mc:156, :146
+    nsim = Ref(Int64(0)); above = Ref(Int64(0)); lo = Ref(0.0); hi = Ref(0.0); o = other(e); bind_stamps!(e)
     check(ccall((:abcdez_mc_swarm, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-                 Float64, Float64, Float64, Float64, Int64, Int64, UInt32, Ref{Int64}),
-                e.ctx, e.order, e.sorted, e.N, e.theta[e.cur], e.logpi[e.cur], e.delta[e.cur], e.theta[o], e.logpi[o], e.delta[o],
-                ϵ_pop, ϵ_target, γ0, γσ, 0, e.N, e.sweep, nsim))
+                 Float64, Float64, Float64, Float64, Int64, Int64, UInt32, Ref{Int64}, Ref{Int64}, Ref{Float64}, Ref{Float64}),
+                e.ctx, e.order, e.cnt, e.N, e.slot[e.cur], e.logpi[e.cur], e.delta[e.cur], e.slot[o], e.logpi[o], e.delta[o],
+                ϵ_pop, ϵ_target, γ0, γσ, 0, e.N, e.sweep, nsim, above, lo, hi))
     e.sweep += 1; e.cur = o
-    Int(nsim[])
+    (Int(nsim[]), Int(above[]), lo[], hi[])
 end
 
 function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
-                  nparticles::Int=50, generations::Int=20, verbose=true, rng::Integer=1, parallel::Bool=true)
+                  nparticles::Int=50, generations::Int=20, verbose=true, rng::Integer=1, parallel::Bool=false)
     α = 0.0                                                                              # mc:107
     0.0 ≤ ϵ_target || error("ϵ_target must be non-negative")
     5 ≤ nparticles || error("nparticles must be at least 5")
     1 ≤ generations || error("generations must be at least 1")
     e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, rng, nparticles)
-    init!(e)                                                                             # mc:117-125
-    nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
-    complete = 1 - count_gt(e, ϵ_target) / nparticles                                    # mc:133
-    while iters < generations                                                            # mc:134
-        iters += 1
-        ϵ_l, ϵ_h = extrema_dev(e)                                                        # mc:146
-        ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))                                     # mc:147
-        ϵ_h > ϵ_target && rank_prepare!(e)
-        nsims += mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                   # mc:149
-        ncomplete = 1 - count_gt(e, ϵ_target) / nparticles                               # mc:156
-        verbose && (ncomplete != complete || complete >= (nparticles - 1) / nparticles) &&
-            (@info "Finished run:" completion = ncomplete nsim = nsims range_ϵ = extrema_dev(e))
-        complete = ncomplete
+    try
+        init!(e)                                                                             # mc:117-125
+        nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
+        complete = 1 - count_gt(e, ϵ_target) / nparticles                                    # mc:133
+        ϵ_l, ϵ_h = extrema_dev(e)                                                            # mc:146 (afterwards the sweep reports them)
+        while iters < generations                                                            # mc:134
+            iters += 1
+            ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))                                     # mc:147
+            ϵ_h > ϵ_target && rank_prepare!(e, ϵ_pop, ϵ_h)
+            nsim, above, ϵ_l, ϵ_h = mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                    # mc:149, :156, next :146 -- one host sync
+            nsims += nsim
+            ncomplete = 1 - above / nparticles                                               # mc:156
+            verbose && (ncomplete != complete || complete >= (nparticles - 1) / nparticles) &&
+                (@info "Finished run:" completion = ncomplete nsim = nsims range_ϵ = (ϵ_l, ϵ_h))
+            complete = ncomplete
+        end
+        conv = ϵ_h <= ϵ_target                                                               # mc:163
+        P, _, Δs, blobs = download(e; packed=false)                                          # mc:166
+        return (P = P, C = Δs, reached_ϵ = conv, blobs = blobs)                              # mc:171
+    finally
+        free!(e)
     end
-    conv = extrema_dev(e)[2] <= ϵ_target                                                 # mc:163
-    P, _, Δs = download(e)                                                               # mc:166
-    ccall((:abcdez_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
-    (P = P, C = Δs, reached_ϵ = conv, blobs = fill(nothing, nparticles))                # mc:171
 end
 
 end # module

@@ -976,7 +976,10 @@ static int cmp_key(const void* a, const void* b) {
  * sorted_delta[p] = max(Ds[order[p]], eps_pop) (non-decreasing).  A draw (mc:20-24) happens only for Ds[i] > eps_pop,
  * and every particle of the first block then belongs to the candidate set {j : Ds[j] <= Ds[i]}, so the first block
  * needs no sorting: the enumeration differs from "all sorted" only inside that block -- same set, same law.      */
-ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, double eps_pop, uint32_t* order, double* sorted_delta) {
+static int64_t upper_bound_d(const double* v, int64_t n, double x);
+/* cnt[i] = #{j : Ds[j] <= Ds[i]} = upper_bound(sorted_delta, Ds[i]) for Ds[i] > eps_pop, 0 for the first block */
+ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, double eps_pop, uint32_t* order, double* sorted_delta,
+                                 uint32_t* cnt) {
   orc_key* k = (orc_key*)malloc((size_t)N * sizeof(orc_key));
   int64_t nA = 0, nB = 0;
   for (int64_t i = 0; i < N; ++i)
@@ -985,13 +988,14 @@ ORC_API void orc_mc_rank_prepare(const double* delta, int64_t N, double eps_pop,
   qsort(k, (size_t)nB, sizeof(orc_key), cmp_key);
   for (int64_t i = 0; i < nB; ++i) { order[nA + i] = k[i].i; sorted_delta[nA + i] = k[i].d; }
   free(k);
+  for (int64_t i = 0; i < N; ++i) cnt[i] = delta[i] <= eps_pop ? 0u : (uint32_t)upper_bound_d(sorted_delta, N, delta[i]);
 }
 static int64_t upper_bound_d(const double* v, int64_t n, double x) { /* #elements <= x */
   int64_t lo = 0, hi = n;
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
   return lo;
 }
-ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const double* sorted_delta, int64_t N,
+ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint32_t* cnt_of, int64_t N,
                           const double* theta, const double* logpi, const double* delta,
                           double* ntheta, double* nlogpi, double* ndelta,
                           double eps_pop, double eps_target, double gamma0, double gsig,
@@ -1010,8 +1014,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const doubl
     double eps = di <= eps_target ? eps_target : eps_pop;               /* mc:19 */
     uint32_t s = (uint32_t)i;
     if (di > eps) {                                                     /* mc:20-24 */
-      int64_t cnt = upper_bound_d(sorted_delta, N, di);
-      s = order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, (uint32_t)cnt)];
+      s = order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_of[i])];   /* mc:23 */
     }
     uint32_t a, b;                                                      /* mc:25-32: uniform over all N */
     abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)N, s, &a, &b);

@@ -30,8 +30,8 @@ void orc_smc_resample_gather(const abz_model*, const uint32_t*, int64_t, int64_t
 double orc_quantile_alive(const double*, const uint8_t*, int64_t, double, double*, double*);
 void orc_extrema(const double*, int64_t, double*, double*);
 int64_t orc_count_gt(const double*, int64_t, double);
-void orc_mc_rank_prepare(const double*, int64_t, double, uint32_t*, double*);
-void orc_mc_swarm(const abz_model*, const uint32_t*, const double*, int64_t, const double*, const double*,
+void orc_mc_rank_prepare(const double*, int64_t, double, uint32_t*, double*, uint32_t*);
+void orc_mc_swarm(const abz_model*, const uint32_t*, const uint32_t*, int64_t, const double*, const double*,
                   const double*, double*, double*, double*, double, double, double, double, int64_t, int64_t,
                   uint32_t, int64_t*);
 
@@ -166,6 +166,7 @@ ORC_API int orc_abcdemc(const abz_model* M, orc_mc_run* R, double* theta_out, do
   pop_t cur = pop_alloc(N, ld), nxt = pop_alloc(N, ld);
   uint32_t* order = (uint32_t*)malloc((size_t)N * 4);
   double* sorted = (double*)malloc((size_t)N * sizeof(double));
+  uint32_t* cnt = (uint32_t*)calloc((size_t)N, 4);
   int rc = orc_init(M, cur.theta, cur.logpi, cur.delta, 0, N);      /* mc:117-125 */
   const double gamma0 = 2.38 / sqrt(2.0 * (double)M->d), gsig = 1e-5;   /* mc:129-130 */
   int64_t nsims = 0;
@@ -174,9 +175,9 @@ ORC_API int orc_abcdemc(const abz_model* M, orc_mc_run* R, double* theta_out, do
     double lo, hi;
     orc_extrema(cur.delta, N, &lo, &hi);                            /* mc:146 */
     double eps_pop = fmax(R->eps_target, lo + 0.0 * (hi - lo));     /* mc:147, alpha = 0 (mc:107) */
-    if (hi > R->eps_target) orc_mc_rank_prepare(cur.delta, N, eps_pop, order, sorted);   /* only consulted when D_i > eps */
+    if (hi > R->eps_target) orc_mc_rank_prepare(cur.delta, N, eps_pop, order, sorted, cnt);   /* only consulted when D_i > eps */
     int64_t nsim;
-    orc_mc_swarm(M, order, sorted, N, cur.theta, cur.logpi, cur.delta, nxt.theta, nxt.logpi, nxt.delta,
+    orc_mc_swarm(M, order, cnt, N, cur.theta, cur.logpi, cur.delta, nxt.theta, nxt.logpi, nxt.delta,
                  eps_pop, R->eps_target, gamma0, gsig, 0, N, (uint32_t)it, &nsim);           /* mc:149 */
     pop_swap(&cur, &nxt);                                           /* mc:152-155 */
     nsims += nsim;
@@ -189,7 +190,7 @@ ORC_API int orc_abcdemc(const abz_model* M, orc_mc_run* R, double* theta_out, do
   memcpy(theta_out, cur.theta, (size_t)N * ld * sizeof(double));
   memcpy(logpi_out, cur.logpi, (size_t)N * sizeof(double));
   memcpy(delta_out, cur.delta, (size_t)N * sizeof(double));
-  free(order); free(sorted);
+  free(order); free(sorted); free(cnt);
   pop_free(cur); pop_free(nxt);
   return rc;
 }

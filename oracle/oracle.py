@@ -125,7 +125,7 @@ def lib():
     L.orc_extrema.argtypes = [_vp, _i64, _pf64, _pf64]
     L.orc_count_gt.restype = _i64
     L.orc_count_gt.argtypes = [_vp, _i64, _f64]
-    L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _f64, _vp, _vp]
+    L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _f64, _vp, _vp, _vp]
     L.orc_mc_swarm.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64,
                                _u32, _pi64]
     L.orc_abcdesmc.argtypes = [_vp, C.POINTER(SmcRun)] + [_vp] * 13
@@ -290,12 +290,12 @@ class OracleOps:
     def count_gt(self, delta, thr) -> int:
         return self.L.orc_count_gt(_p(delta), delta.numel(), thr)
 
-    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta):
-        self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), eps_pop, _p(order), _p(sorted_delta))
+    def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta, cnt):
+        self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), eps_pop, _p(order), _p(sorted_delta), _p(cnt))
 
-    def mc_swarm(self, order, sorted_delta, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep) -> int:
+    def mc_swarm(self, order, cnt, cur, nxt, eps_pop, eps_target, gamma0, gsig, i0, n_local, sweep):
         nsim = _i64()
-        self.L.orc_mc_swarm(self.m.ptr, _p(order), _p(sorted_delta), cur[1].numel(), _p(cur[0]), _p(cur[1]),
+        self.L.orc_mc_swarm(self.m.ptr, _p(order), _p(cnt), cur[1].numel(), _p(cur[0]), _p(cur[1]),
                             _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps_pop, eps_target, gamma0, gsig, i0,
                             n_local, sweep, C.byref(nsim))
         nd = nxt[2][i0:i0 + n_local]            # the driver reductions of the new generation, over this call's particles

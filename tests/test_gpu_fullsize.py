@@ -351,12 +351,14 @@ def test_config2_abcdemc_one_million_particles(oracle):
             head = eng.order[:n_a].to(torch.int64)
             assert bool((head[1:] > head[:-1]).all()) and bool((eng.state[2][head] <= eps_pop).all())       # first block: index order
             if gen in (0, 5, 30):              # the whole enumeration against the oracle's (stable partition + qsort)
-                oo, os_ = torch.zeros(N, dtype=torch.int32), torch.zeros(N, dtype=torch.float64)
-                oracle.OracleOps(spec).mc_rank_prepare(eng.state[2].cpu(), eps_pop, hi, oo, os_)
+                oo, os_, oc = torch.zeros(N, dtype=torch.int32), torch.zeros(N, dtype=torch.float64), torch.zeros(N, dtype=torch.int32)
+                oracle.OracleOps(spec).mc_rank_prepare(eng.state[2].cpu(), eps_pop, hi, oo, os_, oc)
                 assert torch.equal(eng.order.cpu(), oo) and torch.equal(sd.cpu().view(torch.int64), os_.view(torch.int64))
+                draws = eng.state[2].cpu() > eps_pop
+                assert torch.equal(eng.rank_cnt.cpu()[draws], oc[draws])
         if gen == 5:
             th, lp, dl = (t.cpu().contiguous() for t in eng.state)
-            order, sd_h = eng.order.cpu().contiguous(), eng.sorted_delta.cpu().contiguous()
+            order, sd_h = eng.order.cpu().contiguous(), eng.rank_cnt.cpu().contiguous()
             sweep = eng.sweep
             eps_pop = max(0.3, lo)
             eng.mc_swarm(eps_pop, 0.3, g0, 1e-5)

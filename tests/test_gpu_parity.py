@@ -353,6 +353,8 @@ def test_mc_sweep_parity(oracle, name):
         # a hint that is too small, exact, or far too large only changes the binning, never the result
         hip.mc_rank_prepare(eps_pop, (0.5 * hi, hi, 1e6 * hi + 1.0)[gen % 3]); orc.mc_rank_prepare(eps_pop, hi)
         assert same(hip.order, orc.order) and same(hip.sorted_delta, orc.sorted_delta)
+        draws = orc.state[2] > eps_pop                              # candidate counts of the particles that draw (mc:19-20)
+        assert torch.equal(hip.rank_cnt.cpu()[draws], orc.rank_cnt[draws])
         sd = orc.sorted_delta
         assert bool((sd[1:] >= sd[:-1]).all())                      # upper_bound(sorted_delta, Ds[i]) is well defined
         got, want = hip.mc_swarm(eps_pop, eps_target, gamma0, 1e-5), orc.mc_swarm(eps_pop, eps_target, gamma0, 1e-5)

@@ -1,6 +1,7 @@
 """The call sequence of julia/ABCdeZHIP.jl, transliterated to raw ctypes: NO torch tensors, no engine.py -- device
 memory from abcdez_dev_alloc, transfers with abcdez_memcpy_*, one C call per reference function in the order the
-shim issues them (classic double buffer, abcdez_smc_swarm / abcdez_mc_swarm).  Julia is not available to run the
+shim issues them (packed population: abcdez_smc_prologue_packed / _swarm_packed / _resample_gather_packed /
+abcdez_packed_gather; abcdemc on the double buffer: abcdez_mc_rank_prepare / abcdez_mc_swarm; blobs; a user-supplied simulator).  Julia is not available to run the
 shim itself; this pins what it relies on -- argument order and types of every entry point it binds, library-side
 defaults, the need to initialise Wns / alive -- against the oracle's complete drivers, bit for bit."""
 import ctypes as C
@@ -16,23 +17,36 @@ pytestmark = pytest.mark.gpu
 
 
 class ShimEngine:
-    """mutable struct Engine of julia/ABCdeZHIP.jl"""
+    """mutable struct Engine of julia/ABCdeZHIP.jl (1-based Julia indices become 0-based here)"""
 
     def __init__(self, prior, sim, ABCk, seed, N):
         self.lib = _lib.load()
         self.spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
+        lay = (C.c_int32 * 32)()                                    # check_abi()
+        assert self.lib.abcdez_abi_layout(lay, 32) == 19
         self._data = np.ascontiguousarray(self.spec.data, dtype=np.float64)
         m = self.spec.cstruct(self._data.ctypes.data if self._data.size else None)
         ctx = C.c_void_p()
-        self.ck(self.lib.abcdez_ctx_create(C.byref(m), 0, C.byref(ctx)))
-        self.ctx, self.N, self.ld, self.d = ctx, N, self.spec.ld, self.spec.d
+        src = getattr(sim, "source", None)
+        if src is not None:
+            self.ck(self.lib.abcdez_ctx_create_user(C.byref(m), src.encode(), 0, C.byref(ctx)))
+        else:
+            self.ck(self.lib.abcdez_ctx_create(C.byref(m), 0, C.byref(ctx)))
+        self.ck(self.lib.abcdez_ctx_reserve(ctx, N))
+        self.ctx, self.N, self.ld, self.d, self.nb = ctx, N, self.spec.ld, self.spec.d, self.spec.n_blob
         al = self.devalloc
-        self.theta = [al(8 * N * self.ld) for _ in range(2)]
+        nw = (N + 31) // 32
+        self.slot = [al(8 * N * self.ld) for _ in range(2)]
         self.logpi = [al(8 * N) for _ in range(2)]
         self.delta = [al(8 * N) for _ in range(2)]
-        self.wns, self.alive, self.alive_idx, self.arank, self.inds = al(8 * N), al(N), al(4 * N), al(4 * N), al(4 * N)
-        self.order, self.sorted = al(4 * N), al(8 * N)
-        self.cur, self.sweep, self.draw, self.n_alive, self.dead_synced = 0, 0, 0, N, True
+        self.bits = [al(4 * nw) for _ in range(2)]
+        self.stamp = [al(8 * N) for _ in range(2)] if self.nb > 0 else []
+        self.wns, self.alive, self.inds = al(8 * N), al(N), al(4 * N)
+        self.order, self.sorted, self.cnt = al(4 * N), al(8 * N), al(4 * N)
+        self.cur, self.bc, self.sweep, self.draw, self.n_alive, self.n_prev = 0, 0, 0, 0, N, N
+        z = np.zeros(nw, dtype=np.uint32)
+        for b in self.bits:
+            self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, b, z.ctypes.data, 4 * nw))
 
     def ck(self, rc):
         assert rc == 0, self.lib.abcdez_last_error()
@@ -46,33 +60,38 @@ class ShimEngine:
     def other(self):
         return 1 - self.cur
 
+    def bind_stamps(self):
+        if self.nb > 0:
+            self.ck(self.lib.abcdez_ctx_set_stamps(self.ctx, self.stamp[self.cur], self.stamp[self.other]))
+
     def init(self):
-        self.ck(self.lib.abcdez_init(self.ctx, self.theta[self.cur], self.logpi[self.cur], self.delta[self.cur], 0, self.N))
+        self.bind_stamps()
+        self.ck(self.lib.abcdez_init(self.ctx, self.slot[0], self.logpi[self.cur], self.delta[self.cur], 0, self.N))
 
     def reset_weights(self):
         w = np.full(self.N, 1.0 / self.N)
         a = np.ones(self.N, dtype=np.uint8)
         self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.wns, w.ctypes.data, 8 * self.N))
         self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.alive, a.ctypes.data, self.N))
-        self.n_alive, self.dead_synced = self.N, True
+        self.n_alive = self.n_prev = self.N
 
     def extrema(self):
         lo, hi = C.c_double(), C.c_double()
         self.ck(self.lib.abcdez_extrema(self.ctx, self.delta[self.cur], self.N, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
-    def quantile_alive(self, alpha):
-        q = C.c_double()
-        self.ck(self.lib.abcdez_quantile_alive(self.ctx, self.delta[self.cur], self.alive, self.N, self.n_alive, alpha,
-                                               C.byref(q), None, None))
-        return q.value
-
-    def reweight(self, eps_old, eps_new):
-        wn, es, na = C.c_double(), C.c_double(), C.c_int64()
-        self.ck(self.lib.abcdez_smc_reweight(self.ctx, self.delta[self.cur], self.wns, self.alive, self.N, eps_old, eps_new,
-                                             C.byref(wn), C.byref(es), C.byref(na)))
-        self.n_alive, self.dead_synced = na.value, False
-        return wn.value, es.value, na.value
+    def prologue(self, alpha, eps, eps_target, eps_k, ess_min):
+        self.bind_stamps()
+        en, q, wn, es, lo, hi = (C.c_double() for _ in range(6))
+        na, part = C.c_int64(), C.c_int32()
+        self.ck(self.lib.abcdez_smc_prologue_packed(
+            self.ctx, self.delta[self.cur], self.wns, self.alive, self.N, self.n_prev, alpha, eps, eps_target, eps_k, ess_min,
+            self.bits[self.bc], self.bits[1 - self.bc], self.slot[0], self.slot[1], self.logpi[self.cur], C.byref(en),
+            C.byref(q), C.byref(wn), C.byref(es), C.byref(na), C.byref(part), C.byref(lo), C.byref(hi)))
+        self.n_alive = na.value
+        if part.value:
+            self.n_prev = self.n_alive
+        return en.value, wn.value, es.value, na.value, (lo.value, hi.value)
 
     def get_ess(self):
         e = C.c_double()
@@ -83,26 +102,20 @@ class ShimEngine:
         self.ck(self.lib.abcdez_wsample_stratified(self.ctx, self.wns, self.N, self.draw, self.inds))
         self.draw += 1
         o = self.other
-        self.ck(self.lib.abcdez_smc_resample_gather(self.ctx, self.inds, self.N, 0, self.N, self.theta[self.cur],
-                                                    self.logpi[self.cur], self.delta[self.cur], self.theta[o], self.logpi[o],
-                                                    self.delta[o], self.wns, self.alive))
-        self.cur, self.n_alive, self.dead_synced = o, self.N, True
-
-    def compact(self):
-        na = C.c_int64()
-        self.ck(self.lib.abcdez_alive_compact(self.ctx, self.alive, self.N, self.alive_idx, self.arank, C.byref(na)))
-        self.n_alive = na.value
+        self.bind_stamps()
+        self.ck(self.lib.abcdez_smc_resample_gather_packed(
+            self.ctx, self.inds, self.N, self.bits[self.bc], self.bits[1 - self.bc], self.slot[0], self.slot[1],
+            self.logpi[self.cur], self.delta[self.cur], self.logpi[o], self.delta[o], self.wns, self.alive))
+        self.cur, self.n_alive, self.n_prev = o, self.N, self.N
 
     def smc_swarm(self, eps, g0, gs):
         nacc, nsim = C.c_int64(), C.c_int64()
-        o = self.other
-        self.ck(self.lib.abcdez_smc_swarm(self.ctx, self.alive_idx, self.arank, self.n_alive, 0, self.n_alive,
-                                          self.theta[self.cur], self.logpi[self.cur], self.delta[self.cur], self.theta[o],
-                                          self.logpi[o], self.delta[o], eps, g0, gs, 0, self.N,
-                                          1 if (not self.dead_synced and self.n_alive < self.N) else 0, None, self.sweep,
-                                          C.byref(nacc), C.byref(nsim)))
+        self.bind_stamps()
+        self.ck(self.lib.abcdez_smc_swarm_packed(
+            self.ctx, self.bits[self.bc], self.bits[1 - self.bc], self.n_alive, 0, self.n_alive, self.slot[0], self.slot[1],
+            self.logpi[self.cur], self.delta[self.cur], None, eps, g0, gs, self.sweep, C.byref(nacc), C.byref(nsim)))
         self.sweep += 1
-        self.dead_synced, self.cur = True, o
+        self.bc = 1 - self.bc
         return nacc.value, nsim.value
 
     def count_gt(self, thr):
@@ -112,34 +125,51 @@ class ShimEngine:
 
     def rank_prepare(self, eps_pop, dmax):
         self.ck(self.lib.abcdez_mc_rank_prepare(self.ctx, self.delta[self.cur], self.N, eps_pop, dmax, self.order,
-                                                self.sorted))
+                                                self.sorted, self.cnt))
 
     def mc_swarm(self, eps_pop, eps_target, g0, gs):
         nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         o = self.other
-        self.ck(self.lib.abcdez_mc_swarm(self.ctx, self.order, self.sorted, self.N, self.theta[self.cur], self.logpi[self.cur],
-                                         self.delta[self.cur], self.theta[o], self.logpi[o], self.delta[o], eps_pop,
+        self.bind_stamps()
+        self.ck(self.lib.abcdez_mc_swarm(self.ctx, self.order, self.cnt, self.N, self.slot[self.cur], self.logpi[self.cur],
+                                         self.delta[self.cur], self.slot[o], self.logpi[o], self.delta[o], eps_pop,
                                          eps_target, g0, gs, 0, self.N, self.sweep, C.byref(nsim), C.byref(ngt),
                                          C.byref(lo), C.byref(hi)))
         self.sweep += 1
         self.cur = o
         return nsim.value, ngt.value, lo.value, hi.value
 
-    def download(self):
+    def download(self, packed):
         th = np.empty((self.N, self.ld))
-        pushed = self.devalloc(8 * self.N * self.ld)
-        self.ck(self.lib.abcdez_push_p(self.ctx, self.theta[self.cur], self.N, pushed))
+        rows, pushed = self.devalloc(8 * self.N * self.ld), self.devalloc(8 * self.N * self.ld)
+        if packed:
+            self.ck(self.lib.abcdez_packed_gather(self.ctx, self.bits[self.bc], self.N, self.slot[0], self.slot[1], rows))
+        src = rows if packed else self.slot[self.cur]
+        self.ck(self.lib.abcdez_push_p(self.ctx, src, self.N, pushed))
         self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, th.ctypes.data, pushed, th.nbytes))
         dl, w = np.empty(self.N), np.empty(self.N)
         self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, dl.ctypes.data, self.delta[self.cur], 8 * self.N))
         self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, w.ctypes.data, self.wns, 8 * self.N))
-        self.lib.abcdez_dev_free(pushed)
-        return th[:, :self.d], w, dl
+        blobs = None
+        if self.nb > 0:
+            wd = C.c_int32()
+            self.ck(self.lib.abcdez_blob_width(self.ctx, C.byref(wd)))
+            bl, redo = self.devalloc(8 * self.N * wd.value), self.devalloc(8 * self.N)
+            self.ck(self.lib.abcdez_blob_eval(self.ctx, src, self.stamp[self.cur], self.N, bl, redo))
+            self.ck(self.lib.abcdez_sync(self.ctx))
+            B, R = np.empty((self.N, wd.value)), np.empty(self.N)
+            self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, B.ctypes.data, bl, B.nbytes))
+            self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, R.ctypes.data, redo, 8 * self.N))
+            assert np.array_equal(R.view(np.int64), dl.view(np.int64))     # the re-run distance is the stored one
+            blobs = B[:, :self.nb]
+            self.lib.abcdez_dev_free(bl); self.lib.abcdez_dev_free(redo)
+        self.lib.abcdez_dev_free(rows); self.lib.abcdez_dev_free(pushed)
+        return th[:, :self.d], w, dl, blobs
 
-    def close(self):
-        for p in self.theta + self.logpi + self.delta + [self.wns, self.alive, self.alive_idx, self.arank, self.inds, self.order,
-                                                         self.sorted]:
-            self.lib.abcdez_dev_free(p)
+    def close(self):                                                # free!(e)
+        for p in self.slot + self.logpi + self.delta + self.bits + self.stamp + [self.wns, self.alive, self.inds, self.order,
+                                                                                 self.sorted, self.cnt]:
+            self.ck(self.lib.abcdez_dev_free(p))
         self.lib.abcdez_ctx_destroy(self.ctx)
 
 
@@ -152,11 +182,12 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
     eps = eps_k = math.inf
     logZ, nsims, facc, Ki, iters = 0.0, 0, 1.0, Kmcmc, 0
     g0, gs = 2.38 / math.sqrt(2 * e.d), 1e-5
-    eps_hist = [eps]
+    eps_hist, ranges = [eps], [e.extrema()]
     while True:
         iters += 1
-        eps = max(min(e.quantile_alive(alpha), eps), eps_target)
-        wnorm, ess, n_alive = e.reweight(eps_k, eps)
+        eps, wnorm, ess, n_alive, range_prev = e.prologue(alpha, eps, eps_target, eps_k, N * dess)
+        if iters > 1:
+            ranges.append(range_prev)
         logZ += math.log(wnorm)
         naccs, Ki = 0, Kmcmc
         if n_alive > 0 and ess < N * dess:
@@ -164,7 +195,6 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
             ess = e.get_ess()
             n_alive = N
         if n_alive >= 3:
-            e.compact()
             for i in range(1, Kmcmc + 1):
                 nacc, nsim = e.smc_swarm(eps, g0, gs)
                 naccs += nacc
@@ -177,9 +207,10 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
         eps_hist.append(eps)
         if n_alive < 3 or eps <= eps_target or nsims >= nsims_max:
             break
-    P, W, D = e.download()
+    ranges.append(e.extrema())
+    P, W, D, blobs = e.download(packed=True)
     e.close()
-    return dict(P=P, Wns=W, C=D, logZ=logZ, iters=iters, nsims=nsims, eps_hist=eps_hist)
+    return dict(P=P, Wns=W, C=D, logZ=logZ, iters=iters, nsims=nsims, eps_hist=eps_hist, ranges=ranges, blobs=blobs)
 
 
 def shim_abcdemc(prior, sim, eps_target, N, seed, generations):
@@ -195,7 +226,7 @@ def shim_abcdemc(prior, sim, eps_target, N, seed, generations):
         nsims += nsim
         assert n_above == e.count_gt(eps_target) and (lo, hi) == e.extrema()
     conv = hi <= eps_target
-    P, _, D = e.download()
+    P, _, D, _ = e.download(packed=False)
     e.close()
     return dict(P=P, C=D, nsims=nsims, reached=conv)
 
@@ -204,6 +235,8 @@ CASES = {
     "normal1d": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.3, 3000),
     "mvn8": (A.Factored(*[A.Normal(0.0, 1.0)] * 8), A.MVNormal((1.0,) * 8), 2.5, 2048),
     "mixed": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.05, 400),
+    "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)), A.Socks(0, 11), 0.01, 1500),
+    "blobs": (A.Factored(*[A.Normal(0.0, 1.0)] * 3), A.MVNormal((1.0, 0.5, 0.2), blobs=True), 1.0, 1000),
 }
 
 
@@ -211,9 +244,13 @@ CASES = {
 def test_shim_call_sequence_abcdesmc(oracle, name):
     prior, sim, eps, N = CASES[name]
     got = shim_abcdesmc(prior, sim, eps, N, seed=31)
-    ref = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=31), N, eps, packed=False)
+    ref = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=31), N, eps)
     assert got["iters"] == ref["iters"] and got["nsims"] == ref["nsims"] and got["logZ"] == ref["logZ"]
     assert np.array_equal(np.array(got["eps_hist"]), ref["eps_hist"])
+    assert [r[0] for r in got["ranges"]] == list(ref["lo_hist"]) and [r[1] for r in got["ranges"]] == list(ref["hi_hist"])
+    if name == "blobs":            # the product host returns the same blobs (and checks them against the distances)
+        r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=31)
+        assert np.array_equal(r.blobs, got["blobs"]) and np.array_equal(r.C, got["C"])
     assert np.array_equal(got["C"], ref["C"]) and np.array_equal(got["Wns"], ref["Wns"])
     m = oracle.OracleModel(A.ModelSpec(prior, sim, seed=31))
     th = np.ascontiguousarray(np.pad(ref["theta"], ((0, 0), (0, A.ModelSpec(prior, sim).ld - ref["theta"].shape[1]))))

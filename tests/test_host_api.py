@@ -23,12 +23,12 @@ def test_defaults_match_reference():
     """src/abcdez_smc.jl:215-220, src/abcdez_mc.jl:102-104"""
     p = inspect.signature(A.abcdesmc).parameters
     want = dict(nparticles=100, α=0.95, δess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0, facc_stop=0.0,
-                facc_min=0.0, facc_tune=0.975, verbose=True, verboseout=True)
+                facc_min=0.0, facc_tune=0.975, verbose=True, verboseout=True, parallel=False)
     for k, v in want.items():
         assert p[k].default == v, k
     assert p["ABCk"].default is A.IndicatorStrict0toϵ
     q = inspect.signature(A.abcdemc).parameters
-    assert q["nparticles"].default == 50 and q["generations"].default == 20
+    assert q["nparticles"].default == 50 and q["generations"].default == 20 and q["parallel"].default is False
 
 
 @pytest.mark.parametrize("kw,msg", [
@@ -120,6 +120,43 @@ def test_library_exports_every_declared_symbol():
     bound = set(_lib.PROTOTYPES) | set(_lib.OTHER_SYMBOLS)
     assert set(names) - bound <= {"abcdez_tree_sum"} or set(names) <= bound | {"abcdez_tree_sum"}
     assert _lib.load().abcdez_version() >= 100
+
+
+def test_abi_layout_of_the_hand_mirrored_structs():
+    """abcdez_abi_layout() (sizeof / offsetof as the library was compiled) == the ctypes mirror in abcdez_amd/model.py;
+    the Julia shim declares the same fields in the same order and asserts the same call at load time"""
+    from abcdez_amd.model import Model, PriorDim
+
+    lib = _lib.load()
+    out = (ctypes.c_int32 * 32)()
+    n = lib.abcdez_abi_layout(out, 32)
+    mine = [ctypes.sizeof(PriorDim)] + [getattr(PriorDim, f).offset for f, _ in PriorDim._fields_] + \
+           [ctypes.sizeof(Model)] + [getattr(Model, f).offset for f, _ in Model._fields_]
+    assert n == len(mine) == 19 and list(out[:n]) == mine
+    jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    body = lambda name: re.search(r"struct %s\n(.*?)\nend" % name, jl, re.S).group(1)
+    fields = lambda name: re.findall(r"(\w+)::", re.sub(r"#.*", "", body(name)))
+    assert fields("AbzPriorDim") == [f for f, _ in PriorDim._fields_]
+    assert fields("AbzModel") == [f for f, _ in Model._fields_]
+    assert "abcdez_abi_layout" in jl and "check_abi()" in jl
+
+
+def test_julia_shim_binds_only_exported_symbols_with_the_declared_arity():
+    """every `ccall((:abcdez_x, LIB), Cint, (types...), args...)` of julia/ABCdeZHIP.jl names an exported function and
+    passes as many argument types as include/abcdez_hip.h declares parameters"""
+    jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    hdr = open(os.path.join(ROOT, "include", "abcdez_hip.h")).read()
+    calls = re.findall(r"ccall\(\(:(abcdez_\w+), LIB\), \w+,\s*\((.*?)\)\s*,", jl, re.S)
+    assert len(calls) >= 20
+    for name, types in calls:
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, hdr, re.S)
+        assert m, f"{name} is not declared in include/abcdez_hip.h"
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        ntypes = len([t for t in re.sub(r"\{[^}]*\}", "", types).split(",") if t.strip()])
+        assert ntypes == len(params), (name, ntypes, len(params))
+    for need in ("abcdez_smc_prologue_packed", "abcdez_smc_swarm_packed", "abcdez_smc_resample_gather_packed",
+                 "abcdez_packed_gather", "abcdez_ctx_create_user", "abcdez_blob_eval", "abcdez_dev_free"):
+        assert any(c[0] == need for c in calls), need
 
 
 def test_header_cites_the_reference_for_every_entry_point():

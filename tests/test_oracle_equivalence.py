@@ -232,7 +232,8 @@ def test_mc_better_particle_enumeration_is_the_reference_mask(oracle, kind):
     eps_pop = max(eps_target, float(d.min()))
     order = np.zeros(N, dtype=np.uint32)
     sd = np.zeros(N)
-    oracle.lib().orc_mc_rank_prepare(d.ctypes.data, N, eps_pop, order.ctypes.data, sd.ctypes.data)
+    cnt_of = np.zeros(N, dtype=np.uint32)
+    oracle.lib().orc_mc_rank_prepare(d.ctypes.data, N, eps_pop, order.ctypes.data, sd.ctypes.data, cnt_of.ctypes.data)
     assert np.array_equal(np.sort(order), np.arange(N))                       # a permutation
     assert np.all(sd[1:] >= sd[:-1])                                          # upper_bound is well defined
     assert np.array_equal(sd, np.maximum(d[order], eps_pop))
@@ -242,4 +243,5 @@ def test_mc_better_particle_enumeration_is_the_reference_mask(oracle, kind):
     assert np.all((d[tail][1:] > d[tail][:-1]) | ((d[tail][1:] == d[tail][:-1]) & (tail[1:] > tail[:-1])))
     for i in np.flatnonzero(d > eps_pop)[:400]:
         cnt = int(np.searchsorted(sd, d[i], side="right"))
+        assert cnt == int(cnt_of[i])
         assert set(order[:cnt].tolist()) == set(np.flatnonzero(d <= d[i]).tolist())

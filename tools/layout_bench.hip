@@ -14,7 +14,7 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int D = 32;
 
-__device__ inline uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__host__ __device__ inline uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
 // (A) 4 lanes per particle, lane j loads doubles [2j,2j+1] and [8+2j, 8+2j+1] ... (2 x 16 B per row)
 __global__ __launch_bounds__(256) void k_rows(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
@@ -125,6 +125,44 @@ __global__ __launch_bounds__(256) void k_rows_store_il(const double* __restrict_
     aout[r] = wr ? (i | 0x80000000u) : i;
   }
 }
+// (P) the PACKED population's pattern (abz_kernels.h, smc_swarm_packed_body): alive rank = position, so the own row
+//     streams and the donors are addressed directly; the only indirection is one bit per position (current slot) in an
+//     L2-resident bitmap; the accepted fraction is written to the position's other slot, 16 B of state read always and
+//     rewritten in place on accept, one bitmap word per 32 positions written
+__global__ __launch_bounds__(256) void k_packed(const double* __restrict__ s0, const double* __restrict__ s1,
+                                                const uint32_t* __restrict__ bits, uint32_t* __restrict__ bits_out, uint32_t N,
+                                                double* __restrict__ w0, double* __restrict__ w1, double* __restrict__ st, int wfrac) {
+  __shared__ uint32_t s_acc[2];
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, r = gid >> 2; const int j = gid & 3;
+  if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+  __syncthreads();
+  if (r < N) {
+    const uint32_t a = hash32(r * 2 + 1) % N, b = hash32(r * 2 + 2) % N;
+    const uint32_t bi = (bits[r >> 5] >> (r & 31)) & 1u, ba = (bits[a >> 5] >> (a & 31)) & 1u, bb = (bits[b >> 5] >> (b & 31)) & 1u;
+    const bool wr = (hash32(r * 7 + 3) % 100) < (uint32_t)wfrac;
+    double acc = st[r] + st[N + r];
+    const double* ri = (bi ? s1 : s0) + (size_t)r * D;
+    const double* ra = (ba ? s1 : s0) + (size_t)a * D;
+    const double* rb = (bb ? s1 : s0) + (size_t)b * D;
+    double* ro = (bi ? w0 : w1) + (size_t)r * D;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double2 o = *(const double2*)(ri + m * 8 + 2 * j);
+      const double2 x = *(const double2*)(ra + m * 8 + 2 * j);
+      const double2 y = *(const double2*)(rb + m * 8 + 2 * j);
+      double2 v; v.x = o.x + (x.x - y.x); v.y = o.y + (x.y - y.y);
+      acc += v.x + v.y;
+      if (wr) *(double2*)(ro + m * 8 + 2 * j) = v;
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    if (j == 0 && wr) {
+      st[r] = acc * 1e-300; st[N + r] = 2.0;
+      atomicOr(&s_acc[(threadIdx.x >> 2) >> 5], 1u << ((threadIdx.x >> 2) & 31));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) { const uint32_t w = blockIdx.x * 2 + threadIdx.x; if (w * 32 < N) bits_out[w] = bits[w] ^ s_acc[threadIdx.x]; }
+}
 // (B) component-major: thread per particle, component k at th[k*N + i]
 __global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -198,6 +236,27 @@ int main() {
     run("A14 as A6 (25% accepted) with the two slots of a particle adjacent in memory (store[N][2][32])", [&] { hipLaunchKernelGGL(k_rows_store_il, dim3(N * 4 / 256), dim3(256), 0, 0, st2, idx, N, st2, nlp, aout, 25); });
     run("A15 as A14 with 0% accepted", [&] { hipLaunchKernelGGL(k_rows_store_il, dim3(N * 4 / 256), dim3(256), 0, 0, st2, idx, N, st2, nlp, aout, 0); });
     CHECK(hipFree(st2));
+  }
+  {
+    double *q0, *q1; uint32_t *bits, *bo;
+    CHECK(hipMalloc(&q0, bytes)); CHECK(hipMalloc(&q1, bytes)); CHECK(hipMemset(q0, 0, bytes)); CHECK(hipMemset(q1, 0, bytes));
+    CHECK(hipMalloc(&bits, N / 8)); CHECK(hipMalloc(&bo, N / 8));
+    { std::vector<uint32_t> h(N / 32); for (uint32_t k = 0; k < N / 32; ++k) h[k] = hash32(k * 977 + 5); CHECK(hipMemcpy(bits, h.data(), N / 8, hipMemcpyHostToDevice)); }
+    for (uint32_t M : {N, 3u * (N / 4), N / 2}) {          // the alive prefix shrinks from N to N/2 between two resamplings
+      for (int wf : {15, 25, 0}) {
+        char name[160];
+        snprintf(name, sizeof name, "P packed population: prefix %u of %u positions, %d%% accepted (bitmap look-ups, rows to the other slot)", M, N, wf);
+        const uint32_t saveN = N; (void)saveN;
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_packed, dim3(M * 4 / 256), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        for (int rr = 0; rr < 20; ++rr) hipLaunchKernelGGL(k_packed, dim3(M * 4 / 256), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+        printf("{\"variant\": \"%s\", \"ms\": %.4f, \"useful_GBps\": %.1f, \"particles_per_s\": %.4e}\n", name, ms, (double)M * 768 / ms / 1e6, M / (ms * 1e-3));
+      }
+    }
+    CHECK(hipFree(q0)); CHECK(hipFree(q1)); CHECK(hipFree(bits)); CHECK(hipFree(bo));
   }
   run("B component-major f64[32][N], thread per particle", [&] { hipLaunchKernelGGL(k_soa, dim3(N / 256), dim3(256), 0, 0, th, N, out); });
   run("C rows f64[N][32] staged through LDS per workgroup", [&] { hipLaunchKernelGGL(k_rows_lds, dim3(N / 64), dim3(256), 0, 0, th, N, out); });

@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""HBM traffic of the sweep kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
-MI355X_MICROARCH.md prescribes) -> profiles/<round>_hbm_traffic.json, the file bench.py's roofline.traffic reads.
+"""HBM traffic of a sweep kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
+MI355X_MICROARCH.md prescribes) -> profiles/<round>_hbm_traffic_<config>.json, the file bench.py's roofline.traffic reads.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [lanes]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel substring> <lanes> <ld> [accept rate]
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half
 the bytes of 16-byte-per-lane coalesced reads, so it is doubled.  Particle-updates per dispatch = grid size / lanes
 per particle (the kernel maps one alive particle to `lanes` consecutive threads; the last block is padded, < 64
-particles of error)."""
+particles of error).  Infinity-Cache hits are counted by FETCH_SIZE (it counts the L2's fabric requests)."""
 import csv
 import json
 import sys
 
 
-def collect(path, counter, kernel="smc_swarm_kernel"):
+def collect(path, counter, kernel):
     tot, updates, n = 0.0, 0, 0
     with open(path) as f:
         for row in csv.DictReader(f):
@@ -25,23 +25,27 @@ def collect(path, counter, kernel="smc_swarm_kernel"):
 
 
 def main():
-    fetch_csv, write_csv, out = sys.argv[1:4]
-    lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-    f, gu, nf = collect(fetch_csv, "FETCH_SIZE")
-    w, gw, nw = collect(write_csv, "WRITE_SIZE")
+    fetch_csv, write_csv, out, kernel = sys.argv[1:5]
+    lanes, ld = int(sys.argv[5]), int(sys.argv[6])
+    acc = float(sys.argv[7]) if len(sys.argv) > 7 else None
+    f, gu, nf = collect(fetch_csv, "FETCH_SIZE", kernel)
+    w, gw, nw = collect(write_csv, "WRITE_SIZE", kernel)
     rd = 2.0 * f * 1024.0 / (gu / lanes)
     wr = w * 1024.0 / (gw / lanes)
-    ld = 32
+    b_read, b_write = 24 * ld + 17, 8 * ld + 16
     res = {
-        "kernel": f"smc_swarm_kernel<MVN, L={lanes}, C={ld // lanes}>, row-store mode",
-        "workload": "bench.py (d=32 MVN, N=2^22), one rocprofv3 --pmc pass per counter",
+        "kernel": kernel, "lanes": lanes, "ld": ld,
+        "workload": "bench.py of this configuration, one rocprofv3 --pmc pass per counter",
         "method": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports "
-                  "half the bytes of 16-B-per-lane coalesced reads). Infinity-Cache hits (the 16 MB alive list) are counted.",
+                  "half the bytes of 16-B-per-lane coalesced reads). Infinity-Cache hits are counted.",
         "dispatches": nf, "dispatches_write_pass": nw,
         "read_bytes_per_update": rd, "write_bytes_per_update": wr,
-        "algorithmic_read_bytes_per_update": 24 * ld + 17, "algorithmic_write_bytes_per_update": 8 * ld + 16,
-        "total_bytes_per_update": rd + wr, "ratio_to_algorithmic": (rd + wr) / (32 * ld + 33),
+        "algorithmic_read_bytes_per_update": b_read, "algorithmic_write_bytes_per_update": b_write,
+        "total_bytes_per_update": rd + wr, "ratio_to_algorithmic_total": (rd + wr) / (b_read + b_write),
     }
+    if acc is not None:
+        moved = b_read + acc * b_write
+        res.update(acceptance_rate=acc, moved_bytes_per_update=moved, ratio_to_moved_bytes=(rd + wr) / moved)
     with open(out, "w") as fo:
         json.dump(res, fo, indent=1)
     print(json.dumps(res))

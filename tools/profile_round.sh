@@ -1,20 +1,30 @@
-# Regenerates the measurement evidence of a round on the GPU box (run through gpurun):
-#   bench line (with the CPU baseline), rocprofv3 kernel-trace stats of the same command, per-generation timeline.
-# PMC passes (FETCH_SIZE / WRITE_SIZE, one counter per pass) are taken when PMC=1 -- the sweep kernel has to have
-# changed for them to move.
+# Regenerates the measurement evidence of a round on the GPU box (run through gpurun, one call per CFG to stay inside
+# the time limit):   TAG=r02 CFG=smc32 PMC=1 bash tools/profile_round.sh
+#   bench line with the CPU baseline, rocprofv3 kernel-trace stats + per-generation timeline of the same command,
+#   PMC passes (FETCH_SIZE / WRITE_SIZE, one counter per pass) when PMC=1, the access-pattern ceiling when CEIL=1.
 set -x
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r01}
+TAG=${TAG:-r02}; CFG=${CFG:-smc32}
+case $CFG in
+  smc32) MARK=extrema_kernel; LANES=4; LD=32; KERN=smc_swarm_packed_kernel;;
+  lv) MARK=extrema_kernel; LANES=1; LD=4; KERN=smc_swarm_packed_kernel;;
+  evidence1d) MARK=extrema_kernel; LANES=1; LD=1; KERN=smc_swarm_packed_kernel;;
+  mc1d) MARK=mc_swarm_kernel; LANES=1; LD=1; KERN=mc_swarm_kernel;;
+esac
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o kt -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_prof_bench.log 2>&1
-F=$(find $R/gpurun_out/prof_final -name 'kt_kernel_trace.csv' | head -1)
-python3 $R/tools/timeline_gaps.py $F qs_hist_kernel 3 4 > $R/gpurun_out/${TAG}_generation_timeline.txt 2>&1
-cp $(find $R/gpurun_out/prof_final -name 'kt_kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_bench_kernel_stats.csv
-rm -rf $R/gpurun_out/prof_final
+timeout 600 python3 $R/bench.py --config $CFG > $R/gpurun_out/${TAG}_${CFG}_bench.log 2>&1
+MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG bash $R/tools/profile_config.sh
 if [ "${PMC:-0}" = "1" ]; then
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
-  ls -R $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write | head -30
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --steps 6 --warmup 2 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --steps 6 --warmup 2 > /dev/null 2>&1
+  FC=$(find $R/gpurun_out/pmc_fetch_$CFG -name '*counter_collection.csv' | head -1)
+  WC=$(find $R/gpurun_out/pmc_write_$CFG -name '*counter_collection.csv' | head -1)
+  ACC=$(python3 -c "import json,sys;[print(json.loads(l)['roofline'].get('acceptance_rate',0)) for l in open('$R/gpurun_out/${TAG}_${CFG}_bench.log') if l.startswith('{')]" | tail -1)
+  python3 $R/tools/pmc_traffic.py $FC $WC $R/gpurun_out/${TAG}_hbm_traffic_${CFG}.json $KERN $LANES $LD $ACC
+  cp $FC $R/gpurun_out/${TAG}_${CFG}_pmc_fetch_size.csv; cp $WC $R/gpurun_out/${TAG}_${CFG}_pmc_write_size.csv
+  rm -rf $R/gpurun_out/pmc_fetch_$CFG $R/gpurun_out/pmc_write_$CFG
 fi
-grep metric $R/gpurun_out/${TAG}_bench.log | cut -c1-300
+if [ "${CEIL:-0}" = "1" ]; then
+  $R/tools/layout_bench > $R/gpurun_out/${TAG}_layout_bench.jsonl 2>&1
+fi
+grep '^{' $R/gpurun_out/${TAG}_${CFG}_bench.log | cut -c1-400
