@@ -188,7 +188,28 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
   ABZ_REQUIRE(ctx, "ctx_reserve: null context");
   ABZ_REQUIRE(N >= 1 && N <= 0x7FFFFFFFll, "ctx_reserve: N out of range");
   /* the largest user: the resampling (8 N of cumulative weights + tile sums) / the rank pass of abcdemc (12 N + its table) */
-  return abz_ws_reserve(ctx, (size_t)N * 16 + ((size_t)8 << 20));
+  int rc = abz_ws_reserve(ctx, (size_t)N * 16 + ((size_t)8 << 20));
+  if (rc) return rc;
+  /* The resampling's kernels run for the first time ~14 generations into a run; HIP loads a kernel's code on its first
+   * launch (about 0.2 ms each), which would land in the middle of the loop: run them once here on a 64-particle dummy. */
+  const int64_t n = 64;
+  const size_t ld = (size_t)ctx->h_model.ld;
+  char* scratch = nullptr;
+  const size_t rows = n * ld * 8;
+  ABZ_HIP_CHECK(hipMalloc((void**)&scratch, 2 * rows + 6 * n * 8 + 4 * 64));
+  ABZ_HIP_CHECK(hipMemsetAsync(scratch, 0, 2 * rows + 6 * n * 8 + 4 * 64, ctx->stream));
+  double* s0 = (double*)scratch; double* s1 = (double*)(scratch + rows);
+  double* f = (double*)(scratch + 2 * rows);             /* wns | logpi | delta | nlogpi | ndelta | (inds, alive) */
+  uint32_t* inds = (uint32_t*)(f + 5 * n); uint8_t* alive = (uint8_t*)(inds + n);
+  uint32_t* bits = (uint32_t*)(scratch + 2 * rows + 6 * n * 8);
+  uint64_t* st_cur = ctx->stamp_cur; uint64_t* st_nxt = ctx->stamp_nxt;
+  ctx->stamp_cur = ctx->stamp_nxt = nullptr;
+  rc = abz_stratified_impl(ctx, f, n, 0u, inds);         /* all-zero weights: every stratum picks index 0 */
+  if (!rc) rc = abz_launch_resample_gather_packed(ctx, inds, (uint32_t)n, bits, bits + 8, s0, s1, f + n, f + 2 * n, f + 3 * n, f + 4 * n, f, alive);
+  ctx->stamp_cur = st_cur; ctx->stamp_nxt = st_nxt;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(scratch);
+  return rc;
 }
 
 int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {

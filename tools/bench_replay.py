@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Cost of the sharded row store's replay step, measured on ONE GPU.
+"""Cost of the sharded packed population's per-sweep and per-generation steps, measured on ONE GPU.
 
-Emulates rank 0 of a G-rank job at 2^22 particles per rank (the bench.py workload, d = 32 MVN):
-a full population of G * 2^22 particles lives on the GPU (as it would on every rank), the accept
-flags of one sweep are produced by sweeping everything on a scratch copy, then the timed part is what
-rank 0 does per sweep: abcdez_smc_swarm_rows_shard over its own alive ranks + abcdez_smc_replay_rows over
-the others'.  Prints one JSON line per G (times from HIP events on the library's stream).
+Emulates rank 0 of a G-rank job at 2^22 particles per rank (the bench.py workload, d = 32 MVN): a full population of
+G * 2^22 particles lives on the GPU (as it would on every rank).  The accept flags of one sweep are produced by sweeping
+everything on a scratch copy; the timed parts are what rank 0 does
+  per sweep:       abcdez_smc_swarm_packed over its own chunk of the prefix + abcdez_smc_replay_packed over the others'
+  per generation:  abcdez_smc_prologue_packed over the whole replicated population (extrema, quantile, reweight, partition)
+Prints one JSON line per G (device times from HIP events on the library's stream).
 
     python tools/bench_replay.py [--gpus-emulated 2 4 8]
 """
@@ -20,12 +21,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import abcdez_amd as A
-from abcdez_amd.engine import HipEngine
+from abcdez_amd.engine import PACKED_ALIGN, HipEngine
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus-emulated", type=int, nargs="+", default=[2, 4, 8])
+    ap.add_argument("--gpus-emulated", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--particles-per-gpu", type=int, default=1 << 22)
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--reps", type=int, default=5)
@@ -40,48 +41,55 @@ def main():
         ld = e.ops.layout()[0]
         e.init_population()
         e.reset_weights()
-        eps = math.inf
-        for _ in range(3):                                   # a few generations so acceptance is at its typical level
-            eps = min(e.quantile_alive(0.95), eps)
-            e.smc_reweight(math.inf, eps)
+        eps, eps_k = math.inf, math.inf
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_pro = []
+        for g in range(4):                                   # a few generations so acceptance is at its typical level
+            ev[0].record()
+            eps, wnorm, ess, n, _ = e.smc_prologue(0.95, eps, 0.0, eps_k, 0.5 * N)
+            ev[1].record()
+            torch.cuda.synchronize()
+            t_pro.append(ev[0].elapsed_time(ev[1]))
             e.alive_compact()
-            for _ in range(3):
-                e.smc_swarm(eps, gamma0, 1e-5)
-        eps = min(e.quantile_alive(0.95), eps)
-        e.smc_reweight(math.inf, eps)
-        n = e.alive_compact()
-        a_in, a_out = e.alive_row[e.ar], e.alive_row[1 - e.ar]
+            if g < 3:
+                for _ in range(3):
+                    e.smc_swarm(eps, gamma0, 1e-5)
+            eps_k = eps
+        b_in, b_out = e.bits[e.bc], e.bits[1 - e.bc]
         s0, s1 = e.buf[0][0], e.buf[1][0]
         lp, dl = e.buf[e.cur][1], e.buf[e.cur][2]
-        flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
+        flags = torch.zeros(N + G * PACKED_ALIGN, dtype=torch.uint8, device="cuda")
         # accept flags of the whole sweep, on scratch copies of the mutable state
-        c0, c1, clp, cdl, cout = s0.clone(), s1.clone(), lp.clone(), dl.clone(), torch.empty_like(a_out)
-        nacc, _ = e.ops.smc_swarm_rows_shard(a_in, cout, n, 0, n, c0, c1, clp, cdl, flags, eps, gamma0, 1e-5, e.sweep)
+        c0, c1, clp, cdl, cout = s0.clone(), s1.clone(), lp.clone(), dl.clone(), b_out.clone()
+        nacc, _ = e.ops.smc_swarm_packed(b_in, cout, n, 0, n, c0, c1, clp, cdl, flags, eps, gamma0, 1e-5, e.sweep)
         del c0, c1, clp, cdl
-        r_hi = n // G
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        chunk = -(-(-(-n // G)) // PACKED_ALIGN) * PACKED_ALIGN
+        r_hi = min(chunk, n)
         t_sw, t_rp = [], []
         for _ in range(args.reps):                           # the same sweep again and again: writes go to the other slots
             ev[0].record()
-            e.ops.smc_swarm_rows_shard(a_in, a_out, n, 0, r_hi, s0, s1, lp.clone(), dl.clone(), flags.clone(), eps, gamma0,
-                                       1e-5, e.sweep)
+            e.ops.smc_swarm_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp.clone(), dl.clone(), flags.clone(), eps, gamma0, 1e-5,
+                                   e.sweep, want_counts=False)
             ev[1].record()
-            e.ops.smc_replay_rows(a_in, a_out, n, 0, r_hi, s0, s1, flags, gamma0, 1e-5, e.sweep)
+            e.ops.smc_replay_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp.clone(), flags, gamma0, 1e-5, e.sweep)
             ev[2].record()
             torch.cuda.synchronize()
             t_sw.append(ev[0].elapsed_time(ev[1]))
             t_rp.append(ev[1].elapsed_time(ev[2]))
-        assert torch.equal(a_out[:n], cout[:n])                    # shard + replay == the full sweep
-        acc_remote = int((flags & 1).sum().item()) - int((a_out[:r_hi] != a_in[:r_hi]).sum().item())
+        assert torch.equal(b_out, cout)                      # shard + replay == the full sweep
+        acc_all = int((flags[:n] & 1).sum().item())
+        acc_remote = acc_all - int((flags[:r_hi] & 1).sum().item())
         rp = min(t_rp)
         print(json.dumps({
-            "gpus_emulated": G, "particles_total": N, "n_alive": n, "acceptance": nacc / n,
-            "own_sweep_ms_incl_host": min(t_sw), "replay_ms": rp, "replayed_ranks": n - r_hi,
+            "gpus_emulated": G, "particles_total": N, "n_alive": n, "acceptance": nacc / n, "own_positions": r_hi,
+            "own_sweep_ms_incl_clones": min(t_sw), "replay_ms": rp, "replayed_positions": n - r_hi,
             "replayed_accepted": acc_remote,
-            "replay_GBps": (acc_remote * 32 * ld + (n - r_hi) * 9) / (rp * 1e-3) / 1e9,
-            "xgmi_bytes_per_sweep_flags": N - N // G, "xgmi_bytes_per_sweep_rows_allgather": (N - N // G) * (8 * ld + 16),
+            "replay_GBps": (acc_remote * 32 * ld + (n - r_hi) * 1.125) / (rp * 1e-3) / 1e9 if rp > 0 else 0.0,
+            "prologue_ms_replicated": min(t_pro[1:]),
+            "xgmi_bytes_per_sweep_flags": n - r_hi, "xgmi_bytes_per_generation_distances": 8 * (n - r_hi),
+            "xgmi_bytes_per_sweep_rows_allgather_it_replaces": (n - r_hi) * (8 * ld + 16),
         }), flush=True)
-        del e, s0, s1, lp, dl, a_in, a_out, flags, cout
+        del e, s0, s1, lp, dl, b_in, b_out, flags, cout
         torch.cuda.empty_cache()
 
 
