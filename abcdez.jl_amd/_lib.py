@@ -32,20 +32,9 @@ PROTOTYPES = {
     "abcdez_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
     "abcdez_memcpy_d2h": [_vp, _vp, _vp, C.c_size_t],
     "abcdez_init": [_vp, _vp, _vp, _vp, _i64, _i64],
-    "abcdez_alive_compact": [_vp, _vp, _i64, _vp, _vp, _pi64],
-    "abcdez_smc_swarm": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64,
-                         _i64, _i64, C.c_int, _vp, _u32, _pi64, _pi64],
-    "abcdez_alive_compact_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _pi64],
-    "abcdez_smc_swarm_rows": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _pi64, _pi64],
-    "abcdez_rows_commit": [_vp, _vp, _i64, _vp],
     "abcdez_ctx_set_stamps": [_vp, _vp, _vp],
     "abcdez_blob_width": [_vp, _vp],
     "abcdez_blob_eval": [_vp, _vp, _vp, _i64, _vp, _vp],
-    "abcdez_smc_swarm_rows_shard": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
-                                    _pi64, _pi64],
-    "abcdez_smc_replay_rows": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
-    "abcdez_smc_resample_gather_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "abcdez_rows_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
     "abcdez_smc_partition": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_smc_prologue_packed": [_vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp,
                                    _pf64, _pf64, _pf64, _pf64, _pi64, C.POINTER(_i32), _pf64, _pf64],
@@ -57,7 +46,6 @@ PROTOTYPES = {
     "abcdez_get_ess": [_vp, _vp, _i64, _pf64],
     "abcdez_tree_sum": [_vp, _vp, _i64, _pf64],
     "abcdez_wsample_stratified": [_vp, _vp, _i64, _u32, _vp],
-    "abcdez_smc_resample_gather": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_quantile_alive": [_vp, _vp, _vp, _i64, _i64, _f64, _pf64, _pf64, _pf64],
     "abcdez_extrema": [_vp, _vp, _i64, _pf64, _pf64],
     "abcdez_count_gt": [_vp, _vp, _i64, _f64, _pi64],

@@ -11,7 +11,6 @@
 
 int abz_tree_sum_impl(abcdez_ctx*, const double*, int64_t, int, double*);
 int abz_reweight_impl(abcdez_ctx*, const double*, double*, uint8_t*, int64_t, double, double, double*, double*, int64_t*);
-int abz_compact_impl(abcdez_ctx*, const uint8_t*, int64_t, uint32_t*, uint32_t*, int64_t*, const uint32_t*);
 int abz_stratified_impl(abcdez_ctx*, const double*, int64_t, uint32_t, uint32_t*);
 int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t, double*, double*, int64_t*);
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
@@ -338,104 +337,6 @@ int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, in
   return 0;
 }
 
-int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
-                         int64_t* n_alive) {
-  ABZ_REQUIRE(ctx && alive && alive_idx && arank, "alive_compact: null argument");
-  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact: N out of range");
-  return abz_compact_impl(ctx, alive, N, alive_idx, arank, n_alive, nullptr);
-}
-
-/* ---- row-store mode: see the comment at SmcSwarmArgs::rows in abz_kernels.h ---- */
-int abcdez_alive_compact_rows(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, const uint32_t* cur_row,
-                              uint32_t* alive_row, uint32_t* arank, int64_t* n_alive) {
-  ABZ_REQUIRE(ctx && alive && cur_row && alive_row && arank, "alive_compact_rows: null argument");
-  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "alive_compact_rows: N out of range");
-  return abz_compact_impl(ctx, alive, N, alive_row, arank, n_alive, cur_row);
-}
-
-int abcdez_smc_swarm_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
-                          double* slot0, double* slot1, double* logpi, double* delta, double eps, double gamma0,
-                          double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
-  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && logpi && delta && nacc && nsim,
-              "smc_swarm_rows: null argument");
-  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
-  ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows: the two slots / alive lists must differ");
-  int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, logpi, delta,
-                                slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
-                                alive_row_out, nullptr, 1);
-  if (rc) return rc;
-  rc = read_counters(ctx);
-  if (rc) return rc;
-  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
-  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
-  return 0;
-}
-
-/* ---- sharded row store: one replica per GPU, rank r sweeps the alive ranks [r_lo, r_hi) of its own particles and
- * records per-particle accept flags; the other ranks replay the accepted proposals (abz_kernels.h) ---- */
-int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
-                                int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta,
-                                uint8_t* accepted, double eps, double gamma0, double gamma_sigma, uint32_t sweep,
-                                int64_t* nacc, int64_t* nsim) {
-  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && logpi && delta && accepted,
-              "smc_swarm_rows_shard: null argument");
-  ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_rows_shard: pass both counters or neither");
-  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
-  ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_rows_shard: alive-rank range out of bounds");
-  ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_swarm_rows_shard: the two slots / alive lists must differ");
-  int rc = abz_launch_smc_swarm(ctx, alive_row, nullptr, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, logpi,
-                                delta, slot1, logpi, delta, eps, gamma0, gamma_sigma, 0u, 0u, 0, nullptr, sweep, 0u,
-                                alive_row_out, accepted, nacc != nullptr);
-  if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_rows reports totals) */
-  rc = read_counters(ctx);
-  if (rc) return rc;
-  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
-  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
-  return 0;
-}
-
-int abcdez_smc_replay_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
-                           int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                           double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
-  ABZ_REQUIRE(ctx && alive_row && alive_row_out && slot0 && slot1 && accepted && nacc && nsim,
-              "smc_replay_rows: null argument");
-  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_rows: needs at least 3 alive particles");
-  ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_rows: alive-rank range out of bounds");
-  ABZ_REQUIRE(slot0 != slot1 && alive_row != alive_row_out, "smc_replay_rows: the two slots / alive lists must differ");
-  int rc = abz_launch_smc_replay(ctx, alive_row, alive_row_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi,
-                                 slot0, slot1, accepted, gamma0, gamma_sigma, sweep);
-  if (rc) return rc;
-  rc = read_counters(ctx);
-  if (rc) return rc;
-  *nacc = (int64_t)ctx->h_scal[ABZ_S_RACC];
-  *nsim = (int64_t)ctx->h_scal[ABZ_S_RSIM];
-  return 0;
-}
-
-int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row) {
-  ABZ_REQUIRE(ctx && alive_row && cur_row, "rows_commit: null argument");
-  ABZ_REQUIRE(n_alive >= 0 && n_alive <= ABZ_MAX_N, "rows_commit: n_alive out of range");
-  return abz_rows_commit_impl(ctx, alive_row, n_alive, cur_row);
-}
-
-int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* cur_row, double* slot0,
-                                    double* slot1, const double* logpi, const double* delta, double* nlogpi,
-                                    double* ndelta, double* wns, uint8_t* alive) {
-  ABZ_REQUIRE(ctx && inds && cur_row && slot0 && slot1 && logpi && delta && nlogpi && ndelta && wns && alive,
-              "smc_resample_gather_rows: null argument");
-  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_rows: N out of range");
-  ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1, "smc_resample_gather_rows: in/out arrays must differ");
-  return abz_launch_resample_gather_rows(ctx, inds, (uint32_t)N, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns,
-                                         alive);
-}
-
-int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, const double* slot0, const double* slot1,
-                       double* out) {
-  ABZ_REQUIRE(ctx && cur_row && slot0 && slot1 && out, "rows_gather: null argument");
-  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "rows_gather: N out of range");
-  return abz_launch_rows_gather(ctx, cur_row, (uint32_t)N, slot0, slot1, out);
-}
-
 /* ---- packed population: see the comment at SmcPackedArgs in abz_kernels.h ---- */
 int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
                          uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
@@ -527,33 +428,6 @@ int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const
   return abz_launch_packed_gather(ctx, bits, (uint32_t)N, slot0, slot1, out);
 }
 
-int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive, int64_t r_lo,
-                     int64_t r_hi, const double* theta, const double* logpi, const double* delta, double* ntheta,
-                     double* nlogpi, double* ndelta, double eps, double gamma0, double gamma_sigma, int64_t i0,
-                     int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep, int64_t* nacc,
-                     int64_t* nsim) {
-  ABZ_REQUIRE(ctx && alive_idx && arank && theta && logpi && delta && ntheta && nlogpi && ndelta && nacc && nsim,
-              "smc_swarm: null argument");
-  /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
-  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
-  ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm: alive-rank range out of bounds");
-  ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= ABZ_MAX_N, "smc_swarm: particle range out of bounds");
-  ABZ_REQUIRE(r_hi - r_lo <= n_local, "smc_swarm: more alive ranks than particles in the range");
-  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "smc_swarm: in/out arrays must differ (synchronous update)");
-  int rc = abz_launch_smc_swarm(ctx, alive_idx, arank, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, theta, logpi,
-                                delta, ntheta, nlogpi, ndelta, eps, gamma0, gamma_sigma, (uint32_t)i0,
-                                (uint32_t)n_local, copy_dead, dead_synced, sweep,
-                                /* alive list is the identity iff every particle of a range starting at 0 is alive */
-                                (i0 == 0 && r_lo == 0 && r_hi == n_alive && n_alive == n_local) ? (uint32_t)n_alive : 0u,
-                                nullptr, nullptr, 1);
-  if (rc) return rc;
-  rc = read_counters(ctx);
-  if (rc) return rc;
-  *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
-  *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
-  return 0;
-}
-
 int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
                         double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
   ABZ_REQUIRE(ctx && delta && wns && alive && wnorm && ess && n_alive, "smc_reweight: null argument");
@@ -582,18 +456,6 @@ int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uin
   ABZ_REQUIRE(ctx && wns && inds, "wsample_stratified: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "wsample_stratified: N out of range");
   return abz_stratified_impl(ctx, wns, N, draw, inds);
-}
-
-int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
-                               const double* theta, const double* logpi, const double* delta, double* ntheta,
-                               double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
-  ABZ_REQUIRE(ctx && inds && theta && logpi && delta && ntheta && nlogpi && ndelta && wns && alive,
-              "smc_resample_gather: null argument");
-  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && i0 >= 0 && n_local >= 0 && i0 + n_local <= N,
-              "smc_resample_gather: range out of bounds");
-  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "smc_resample_gather: in/out arrays must differ");
-  return abz_launch_resample_gather(ctx, inds, (uint32_t)N, (uint32_t)i0, (uint32_t)n_local, theta, logpi, delta,
-                                    ntheta, nlogpi, ndelta, wns, alive);
 }
 
 int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t n_alive_hint,

@@ -94,22 +94,9 @@ enum {
 
 /* kernel launchers implemented across the .hip files */
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
-int abz_launch_smc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t,
-                         const double*, const double*, const double*, double*, double*, double*,
-                         double, double, double, uint32_t, uint32_t, int, uint8_t*, uint32_t, uint32_t, uint32_t*,
-                         uint8_t* acc_flag, int want_counts);
-int abz_launch_smc_replay(abcdez_ctx*, const uint32_t* alive_row, uint32_t* alive_out, uint32_t n_alive, uint32_t skip_lo,
-                          uint32_t skip_hi, double* slot0, double* slot1, const uint8_t* acc_flag, double gamma0,
-                          double gsig, uint32_t sweep);
-int abz_launch_resample_gather_rows(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, double*, double*, const double*,
-                                    const double*, double*, double*, double*, uint8_t*);
-int abz_launch_rows_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
-int abz_rows_commit_impl(abcdez_ctx*, const uint32_t*, int64_t, uint32_t*);
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);
-int abz_launch_resample_gather(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t, uint32_t, const double*,
-                               const double*, const double*, double*, double*, double*, double*, uint8_t*);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
 void abz_fold_minmax(abcdez_ctx*, int bank, double* lo, double* hi);
@@ -120,7 +107,6 @@ int abz_jit_launch_blob(abcdez_ctx*, const double* theta, const uint64_t* stamp,
                         double* delta_out, uint32_t nbw);
 int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp, int64_t n, double* blob,
                          double* delta_out, uint32_t nbw);
-int abz_jit_launch_smc(abcdez_ctx*, const void* args, unsigned nblocks);
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned nblocks);
 int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
 

@@ -21,7 +21,7 @@
 
 struct AbzUserModule {
   hipModule_t mod = nullptr;
-  hipFunction_t f_init = nullptr, f_smc = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
+  hipFunction_t f_init = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
 };
 
 #define ABZ_RTC_CHECK(expr)                                                                \
@@ -41,8 +41,6 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_init(const HotModel M, double* theta, "
         "double* logpi, double* delta, uint32_t i0, uint32_t n, unsigned long long* bad, uint64_t* stamp) {\n"
         "  init_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad, stamp);\n}\n"
-        "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc(const SmcSwarmArgs a) {\n"
-        "  smc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_packed(const SmcPackedArgs a) {\n"
         "  smc_swarm_packed_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_mc(const McSwarmArgs a) {\n"
@@ -81,7 +79,6 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   AbzUserModule* um = new AbzUserModule();
   ABZ_HIP_CHECK(hipModuleLoadData(&um->mod, code.data()));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_init, um->mod, "abz_user_init"));
-  ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smc, um->mod, "abz_user_smc"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_mc, um->mod, "abz_user_mc"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smcp, um->mod, "abz_user_smc_packed"));
   if (has_blob) ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_blob, um->mod, "abz_user_blob_eval"));
@@ -114,12 +111,6 @@ int abz_jit_launch_blob(abcdez_ctx* ctx, const double* theta, const uint64_t* st
   void* params[] = {&M, &theta, &stamp, &n, &blob, &delta_out, &nbw};
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_blob, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
                                       params, nullptr));
-  return 0;
-}
-int abz_jit_launch_smc(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
-  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
-  void* params[] = {const_cast<void*>(args)};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smc, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }
 int abz_jit_launch_mc(abcdez_ctx* ctx, const void* args, unsigned nblocks) {

@@ -1,5 +1,5 @@
 /*
- * abz_kernels.h -- bodies of the simulator-dependent kernels (initial population, SMC sweep, MC sweep)
+ * abz_kernels.h -- bodies of the simulator-dependent kernels (initial population, SMC sweep + replay, MC sweep)
  * as __device__ function templates.  The library instantiates them for the built-in simulators
  * (abz_init.hip, abz_smc_swarm.hip, abz_mc_swarm.hip); abz_jit.hip compiles the same text with
  * hiprtc around a user-supplied abz_user_dist.
@@ -76,222 +76,7 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
   }
 }
 
-/* ================================================================ S2+S3: abcdesmc_swarm! (src/abcdez_smc.jl:106-153) */
-struct SmcSwarmArgs {
-  HotModel hm;
-  const uint32_t* alive_idx;
-  const uint32_t* arank;
-  const double* theta;
-  const double* logpi;
-  const double* delta;
-  double* ntheta;
-  double* nlogpi;
-  double* ndelta;
-  unsigned long long* cslots;   /* cumulative counter slots; (nacc, nsim) go to classes c_cls, c_cls + 1 */
-  uint32_t c_cls;
-  uint8_t* row_synced;          /* per particle: both generations' theta rows are equal (may be NULL) */
-  double eps, gamma0, gsig;
-  uint32_t n_alive, r_lo, n_work, sweep;
-  uint32_t all_alive;           /* alive_idx is the identity: skip the indirections */
-  /* "row store" mode (one replica per GPU): theta / ntheta are the two slots of a 2N-row store, alive_idx[r] holds
-   * the CURRENT row id (particle | slot << 31) of the r-th alive particle; an accepted proposal is written to
-   * the particle's other slot and its row id flips in alive_out, a rejected one writes nothing; log-prior and
-   * distance are updated in place (only their owner reads them).  No dead rows to carry, no copies.        */
-  uint32_t rows;
-  uint32_t* alive_out;
-  /* sharded row store (one replica per GPU): per-PARTICLE flags of this sweep (bit 0 accepted, bit 1 simulated),
-   * the only thing the other ranks need to replay the accepted proposals on their replicas and to know the
-   * sweep's global counters (smc_replay_kernel_body); NULL = not recorded */
-  uint8_t* acc_flag;
-  /* blob stamps (abcdez_spec.h, abz_stamp): carried like the distances; both NULL when blobs are off */
-  const uint64_t* stamp;
-  uint64_t* nstamp;
-};
-
-template <int SIM, int L, int C>
-__device__ inline void smc_swarm_kernel_body(const SmcSwarmArgs& a) {
-  constexpr int LD = L * C;
-  const HotModel& M = a.hm;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_work;
-  const uint32_t ri = a.r_lo + (active ? grp : 0u);
-  const uint32_t rowi = a.all_alive ? ri : a.alive_idx[ri];
-  const uint32_t i = rowi & 0x7FFFFFFFu;
-
-  __shared__ ModelLds<LD> s_model;
-
-  /* own row + state */
-  double ti[C];
-  load_row<L, C>(((rowi >> 31) ? a.ntheta : a.theta) + (size_t)i * LD, j, ti);
-  const double lpi = a.logpi[i];
-  const double dli = a.delta[i];
-  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
-  stage.load(M);
-
-  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
-  stage.store(s_model);
-  __syncthreads();                                                /* sampler + model tables staged */
-  uint32_t ra, rb;
-  double g, log_u;
-  particle_draws<L>(&s_model.tab, M.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
-  const uint32_t rowa = a.all_alive ? ra : a.alive_idx[ra];
-  const uint32_t rowb = a.all_alive ? rb : a.alive_idx[rb];
-  double ta[C], tb[C];
-  load_row<L, C>(((rowa >> 31) ? a.ntheta : a.theta) + (size_t)(rowa & 0x7FFFFFFFu) * LD, j, ta);
-  load_row<L, C>(((rowb >> 31) ? a.ntheta : a.theta) + (size_t)(rowb & 0x7FFFFFFFu) * LD, j, tb);
-
-  double tp[C], pp[C];
-#pragma unroll
-  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
-
-  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
-  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
-  bool acc = false;
-  double dp = dli;
-  if (insupport) {
-    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
-    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
-    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
-  }
-  if (active && a.rows) {                                         /* smc:146-150, row-store mode */
-    if (acc) {
-      store_row<L, C>(((rowi >> 31) ? const_cast<double*>(a.theta) : a.ntheta) + (size_t)i * LD, j, tp);
-      if (j == 0) {
-        a.nlogpi[i] = lp; a.ndelta[i] = dp;
-        if (a.nstamp) a.nstamp[i] = abz_stamp(i, a.sweep, 0);
-      }
-    }
-    if (j == 0) {
-      a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
-      if (a.acc_flag) a.acc_flag[i] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
-    }
-  } else if (active) {                                            /* smc:146-150 + copies :337-340 */
-    /* lazy copy: a rejected particle whose row is already identical in both generations'
-     * arrays writes nothing (about half of all row writes at a 30 % acceptance rate) */
-    const bool synced = a.row_synced ? a.row_synced[i] != 0 : false;
-    if (acc || !synced) {
-      double to[C];
-#pragma unroll
-      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-      store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
-    }
-    if (j == 0) {
-      a.nlogpi[i] = acc ? lp : lpi;
-      a.ndelta[i] = acc ? dp : dli;
-      if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
-      if (a.row_synced && (acc == synced)) a.row_synced[i] = acc ? 0 : 1;
-    }
-  }
-  block_count2(active && j == 0 && acc, active && j == 0 && insupport, a.cslots, a.c_cls);
-}
-
-/* ================================================================ replay of a sweep on a replica
- * Multi-GPU row store: every rank keeps the whole population; rank r runs smc_swarm_kernel on the alive ranks of
- * its own particles and publishes one accept flag per particle.  The accepted proposal theta_i + gamma (theta_a -
- * theta_b) (smc:128) is a function of replicated state and of the particle's counter-based random numbers only,
- * so the other ranks REBUILD it from their replica instead of receiving the row: 1 byte per particle crosses
- * xGMI instead of 8 ld + 16, paid for with 3 row reads + 1 row write of local HBM per accepted particle.      */
-struct SmcReplayArgs {
-  HotModel hm;
-  const uint32_t* alive_idx;    /* current row id (particle | slot << 31) by alive rank */
-  uint32_t* alive_out;
-  const uint8_t* acc_flag;      /* by particle: bit 0 accepted, bit 1 simulated (proposal inside the prior support) */
-  double* slot0;
-  double* slot1;
-  unsigned long long* cslots;   /* cumulative counter slots: (nacc, nsim) over the block's alive ranks (own ones included)
-                                   go to classes ABZ_C_RACC, ABZ_C_RSIM */
-  double gamma0, gsig;
-  uint32_t n_alive, skip_lo, skip_hi, sweep;          /* ranks [skip_lo, skip_hi) are this rank's own: counted only */
-};
-
-
-/* Two phases per block.  Scan: the block reads the flags of ABZ_REPLAY_CHUNK consecutive alive ranks (coalesced),
- * completes alive_out for all of them, counts, and compacts the ACCEPTED ones into an LDS list (wave ballot +
- * one LDS atomic per wave).  Rebuild: the lane groups walk that list densely, so every wave of the expensive
- * part (3 row reads, 1 row write) is full although only ~1 in 4-5 particles was accepted.                     */
-template <int L, int C>
-__device__ inline void smc_replay_kernel_body(const SmcReplayArgs& a) {
-  constexpr int LD = L * C;
-  __shared__ abz_tables s_tab;
-  __shared__ uint2 s_list[ABZ_REPLAY_CHUNK];              /* (alive rank, current row id) of the accepted */
-  __shared__ unsigned int s_n;
-  __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
-
-  TabStage stage;
-  stage.load(a.hm);
-  if (threadIdx.x == 0) s_n = 0u;
-  __syncthreads();
-
-  const uint32_t base = blockIdx.x * (uint32_t)ABZ_REPLAY_CHUNK;
-  const unsigned lane = threadIdx.x & 63u;
-  unsigned int wacc = 0u, wsim = 0u;                      /* wave-uniform counters */
-  /* all row ids first, then all flag bytes: two batches of independent loads instead of eight dependent pairs */
-  uint32_t rowv[ABZ_REPLAY_PER];
-  unsigned fv[ABZ_REPLAY_PER];
-#pragma unroll
-  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
-    const uint32_t w = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
-    rowv[k] = a.alive_idx[w < a.n_alive ? w : 0u];
-  }
-#pragma unroll
-  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
-    const uint32_t w = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
-    fv[k] = w < a.n_alive ? (unsigned)a.acc_flag[rowv[k] & 0x7FFFFFFFu] : 0u;
-  }
-#pragma unroll
-  for (int k = 0; k < ABZ_REPLAY_PER; ++k) {
-    const uint32_t ri = base + (uint32_t)k * ABZ_BLOCK + threadIdx.x;
-    const bool foreign = ri < a.n_alive && !(ri >= a.skip_lo && ri < a.skip_hi);
-    const uint32_t rowi = rowv[k];
-    const unsigned f = fv[k];
-    wacc += (unsigned)__popcll(__ballot((f & 1u) != 0u));
-    wsim += (unsigned)__popcll(__ballot((f & 2u) != 0u));
-    const bool acc = foreign && (f & 1u) != 0u;
-    if (foreign) a.alive_out[ri] = acc ? (rowi ^ 0x80000000u) : rowi;
-    const unsigned long long m = __ballot(acc);
-    const unsigned cnt = (unsigned)__popcll(m);
-    unsigned int at = 0u;
-    if (lane == 0u && cnt) at = atomicAdd(&s_n, cnt);
-    at = __shfl(at, 0, 64);
-    if (acc) {
-      uint2 e; e.x = ri; e.y = rowi;
-      s_list[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = e;
-    }
-  }
-  if (lane == 0u) { s_cnt[0][threadIdx.x >> 6] = wacc; s_cnt[1][threadIdx.x >> 6] = wsim; }
-  stage.store(s_tab);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-    const unsigned long long y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
-    unsigned long long* s = a.cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE;
-    if (x) (void)__hip_atomic_fetch_add(s + ABZ_C_RACC, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (y) (void)__hip_atomic_fetch_add(s + ABZ_C_RSIM, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-
-  const unsigned n = s_n;
-  const int j = (int)(threadIdx.x % L);
-  for (unsigned t = threadIdx.x / L; t < n; t += ABZ_BLOCK / L) {   /* uniform over the lanes of a group */
-    const uint2 e = s_list[t];
-    const uint32_t ri = e.x, rowi = e.y, i = rowi & 0x7FFFFFFFu;
-    uint32_t ra, rb;
-    double g, log_u;
-    particle_draws<L>(&s_tab, a.hm.seed, i, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
-    const uint32_t rowa = a.alive_idx[ra];
-    const uint32_t rowb = a.alive_idx[rb];
-    double ti[C], ta[C], tb[C], tp[C];
-    load_row<L, C>(((rowi >> 31) ? a.slot1 : a.slot0) + (size_t)i * LD, j, ti);
-    load_row<L, C>(((rowa >> 31) ? a.slot1 : a.slot0) + (size_t)(rowa & 0x7FFFFFFFu) * LD, j, ta);
-    load_row<L, C>(((rowb >> 31) ? a.slot1 : a.slot0) + (size_t)(rowb & 0x7FFFFFFFu) * LD, j, tb);
-#pragma unroll
-    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
-    store_row<L, C>(((rowi >> 31) ? a.slot0 : a.slot1) + (size_t)i * LD, j, tp);
-  }
-}
-
-/* ================================================================ S2+S3 on the PACKED population
+/* ================================================================ S2+S3: abcdesmc_swarm! (src/abcdez_smc.jl:106-153) on the PACKED population
  * The alive particles are the positions [0, n_alive) (abcdez_smc_partition keeps them a prefix), so "alive rank r" is
  * "position r": the own row streams in, the two donors are addressed directly, and the only indirection left is ONE
  * BIT per position -- which of its two row slots is current -- in a bitmap of N / 8 bytes (512 KB at N = 2^22: resident

@@ -1,6 +1,6 @@
 /*
  * abz_mc_swarm.hip -- one greedy ABC-DE-MCMC sweep over all N particles, plus the
- * resampling gather and push_p.
+ * resampling gathers of the packed population and push_p.
  *
  * abcdemc_swarm! (src/abcdez_mc.jl:5-61) with the copies of mc:140-143 fused in.
  * The "better particle" draw s = rand((1:N)[Ds .<= Ds[i]]) (mc:23) indexes the
@@ -50,118 +50,9 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   return 0;
 }
 
-/* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) ---- */
-template <int L, int C>
-__global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_kernel(
-    const uint32_t* __restrict__ inds, uint32_t N, uint32_t i0, uint32_t n, const double* __restrict__ theta,
-    const double* __restrict__ logpi, const double* __restrict__ delta, double* __restrict__ ntheta,
-    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive,
-    const uint64_t* __restrict__ stamp, uint64_t* __restrict__ nstamp) {
-  constexpr int LD = L * C;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  if (grp >= n) return;
-  const uint32_t s = i0 + grp;
-  const uint32_t src = inds[s];
-  double t[C];
-  load_row<L, C>(theta + (size_t)src * LD, j, t);
-  store_row<L, C>(ntheta + (size_t)s * LD, j, t);
-  if (j == 0) {
-    nlogpi[s] = logpi[src];
-    ndelta[s] = delta[src];
-    if (nstamp) nstamp[s] = stamp[src];                          /* blobs .= blobs[inds], smc:99 */
-    wns[s] = 1.0 / (double)N;
-    alive[s] = 1;
-  }
-}
-
-int abz_launch_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N, uint32_t i0, uint32_t n_local,
-                               const double* theta, const double* logpi, const double* delta, double* ntheta,
-                               double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
-  if (n_local == 0) return 0;
-  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
-    hipLaunchKernelGGL((resample_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)n_local * LL())),
-                       dim3(ABZ_BLOCK), 0, ctx->stream, inds, N, i0, n_local, theta, logpi, delta, ntheta, nlogpi,
-                       ndelta, wns, alive, (const uint64_t*)ctx->stamp_cur, ctx->stamp_cur ? ctx->stamp_nxt : nullptr);
-  });
-  if (!ok) { abz_set_error("resample_gather: unsupported layout"); return -3; }
-  ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-/* ---- row-store mode: the same gathers; source = current row of inds[s], destination = the OTHER slot of s
- * (never a current row, so no source is overwritten); rows_flip_kernel then flips every cur_row.      */
-template <int L, int C>
-__global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_rows_kernel(
-    const uint32_t* __restrict__ inds, uint32_t N, const uint32_t* __restrict__ cur_row, double* __restrict__ slot0,
-    double* __restrict__ slot1, const double* __restrict__ logpi, const double* __restrict__ delta,
-    double* __restrict__ nlogpi, double* __restrict__ ndelta, double* __restrict__ wns, uint8_t* __restrict__ alive,
-    const uint64_t* __restrict__ stamp, uint64_t* __restrict__ nstamp) {
-  constexpr int LD = L * C;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t s = gid / L;
-  const int j = (int)(gid % L);
-  if (s >= N) return;
-  const uint32_t src = inds[s];
-  const uint32_t srow = cur_row[src], drow = cur_row[s] ^ 0x80000000u;
-  double t[C];
-  load_row<L, C>(((srow >> 31) ? slot1 : slot0) + (size_t)src * LD, j, t);
-  store_row<L, C>(((drow >> 31) ? slot1 : slot0) + (size_t)s * LD, j, t);
-  if (j == 0) {
-    nlogpi[s] = logpi[src];
-    ndelta[s] = delta[src];
-    if (nstamp) nstamp[s] = stamp[src];                          /* blobs .= blobs[inds], smc:99 */
-    wns[s] = 1.0 / (double)N;
-    alive[s] = 1;
-  }
-}
-__global__ __launch_bounds__(ABZ_BLOCK) void rows_flip_kernel(uint32_t* __restrict__ cur_row, uint32_t N) {
-  const uint32_t s = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  if (s < N) cur_row[s] ^= 0x80000000u;
-}
-template <int L, int C>
-__global__ __launch_bounds__(ABZ_BLOCK) void rows_gather_kernel(const uint32_t* __restrict__ cur_row, uint32_t N,
-                                                                const double* __restrict__ slot0,
-                                                                const double* __restrict__ slot1,
-                                                                double* __restrict__ out) {
-  constexpr int LD = L * C;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t s = gid / L;
-  const int j = (int)(gid % L);
-  if (s >= N) return;
-  const uint32_t row = cur_row[s];
-  double t[C];
-  load_row<L, C>(((row >> 31) ? slot1 : slot0) + (size_t)s * LD, j, t);
-  store_row<L, C>(out + (size_t)s * LD, j, t);
-}
-
-int abz_launch_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, uint32_t N, uint32_t* cur_row, double* slot0,
-                                    double* slot1, const double* logpi, const double* delta, double* nlogpi,
-                                    double* ndelta, double* wns, uint8_t* alive) {
-  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
-    hipLaunchKernelGGL((resample_gather_rows_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)N * LL())), dim3(ABZ_BLOCK), 0,
-                       ctx->stream, inds, N, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive,
-                       (const uint64_t*)ctx->stamp_cur, ctx->stamp_cur ? ctx->stamp_nxt : nullptr);
-  });
-  if (!ok) { abz_set_error("resample_gather_rows: unsupported layout"); return -3; }
-  hipLaunchKernelGGL(rows_flip_kernel, dim3(abz_grid(N)), dim3(ABZ_BLOCK), 0, ctx->stream, cur_row, N);
-  ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-int abz_launch_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, uint32_t N, const double* slot0, const double* slot1,
-                           double* out) {
-  bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
-    hipLaunchKernelGGL((rows_gather_kernel<LL(), CC()>), dim3(abz_grid((uint64_t)N * LL())), dim3(ABZ_BLOCK), 0, ctx->stream,
-                       cur_row, N, slot0, slot1, out);
-  });
-  if (!ok) { abz_set_error("rows_gather: unsupported layout"); return -3; }
-  ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-/* ---- packed store: the same gathers; source = current row of inds[s], destination = the OTHER slot of s (never a
- * current row, so no source is overwritten); bits_flip_kernel then flips every bit, in both bit arrays.          */
+/* ---- S8 gathers: thetas .= thetas[inds] etc. (src/abcdez_smc.jl:96-103) on the packed store: source = current row of
+ * inds[s], destination = the OTHER slot of s (never a current row, so no source is overwritten); bits_flip_kernel then
+ * flips every bit, in both bit arrays.                                                                          */
 template <int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_packed_kernel(
     const uint32_t* __restrict__ inds, uint32_t N, const uint32_t* __restrict__ bits, double* __restrict__ slot0,

@@ -1,7 +1,7 @@
 /*
  * abz_population.hip -- population-wide streaming passes around the sweeps:
  *   tile-tree sums + ABC-kernel reweighting  (src/abcdez_smc.jl:59-83, :308-311, :8)
- *   alive compaction (wave ballot / popcount prefix)   (implicit in smc:121,125)
+ *   partition of the packed population (wave ballot / popcount prefix)   (replaces the scans of smc:121,125)
  *   integer cumulative weights + stratified search     (src/abcdez_smc.jl:15-56)
  *   radix select for the eps-quantile                  (src/abcdez_smc.jl:301)
  *   extrema / counts                                   (smc:286,364; mc:133,146,156,163)
@@ -203,117 +203,7 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
   return 0;
 }
 
-/* ================================================================ alive compaction
- * chunk = 1024 flags per block.  Pass 1 counts, pass 2 scans the chunk counts,
- * pass 3 ranks each flag with wave ballot + popcount prefix and scatters.        */
 #define ABZ_CHUNK 1024
-
-__global__ __launch_bounds__(ABZ_BLOCK) void compact_count_kernel(const uint8_t* __restrict__ alive, int64_t N,
-                                                                  uint32_t* __restrict__ chunk_cnt) {
-  __shared__ uint32_t s_c;
-  if (threadIdx.x == 0) s_c = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * ABZ_CHUNK;
-  uint32_t c = 0;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int64_t k = base + it * ABZ_BLOCK + threadIdx.x;
-    const bool f = k < N && alive[k];
-    c += (uint32_t)__popcll(__ballot(f));
-  }
-  if ((threadIdx.x & 63) == 0) atomicAdd(&s_c, c);
-  __syncthreads();
-  if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s_c;
-}
-
-/* exclusive scan of up to 2^20 chunk counts by one block; total -> *total_out */
-__global__ __launch_bounds__(1024) void scan_u32_kernel(uint32_t* __restrict__ v, uint32_t n,
-                                                        unsigned long long* __restrict__ total_out) {
-  __shared__ uint32_t s_part[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
-  uint32_t s = 0;
-  for (uint32_t k = lo; k < hi; ++k) s += v[k];
-  s_part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t add = t >= off ? s_part[t - off] : 0;
-    __syncthreads();
-    s_part[t] += add;
-    __syncthreads();
-  }
-  uint32_t run = t ? s_part[t - 1] : 0;
-  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = v[k]; v[k] = run; run += c; }
-  if (t == 1023) *total_out = s_part[1023];
-}
-
-__global__ __launch_bounds__(ABZ_BLOCK) void compact_scatter_kernel(const uint8_t* __restrict__ alive, int64_t N,
-                                                                    const uint32_t* __restrict__ chunk_off,
-                                                                    uint32_t* __restrict__ alive_idx,
-                                                                    uint32_t* __restrict__ arank,
-                                                                    const uint32_t* __restrict__ cur_row) {
-  __shared__ uint32_t s_wave[4];
-  const int64_t base = (int64_t)blockIdx.x * ABZ_CHUNK;
-  uint32_t run = chunk_off[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int it = 0; it < 4; ++it) {
-    const int64_t k = base + it * ABZ_BLOCK + threadIdx.x;
-    const bool f = k < N && alive[k];
-    const unsigned long long bal = __ballot(f);
-    const uint32_t below = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w];
-    const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (k < N) {
-      if (f) {
-        const uint32_t r = run + woff + below;
-        alive_idx[r] = cur_row ? cur_row[k] : (uint32_t)k;      /* row-store mode: particle | slot << 31 */
-        arank[k] = r;
-      } else {
-        arank[k] = ABZ_DEAD;
-      }
-    }
-    run += tot;
-    __syncthreads();
-  }
-}
-
-/* row-store mode: cur_row[particle] = its current row id, from the alive list the sweeps ping-pong */
-__global__ __launch_bounds__(ABZ_BLOCK) void rows_commit_kernel(const uint32_t* __restrict__ alive_row, uint32_t n,
-                                                                uint32_t* __restrict__ cur_row) {
-  const uint32_t r = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  if (r >= n) return;
-  const uint32_t row = alive_row[r];
-  cur_row[row & 0x7FFFFFFFu] = row;
-}
-int abz_rows_commit_impl(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row) {
-  if (n_alive <= 0) return 0;
-  hipLaunchKernelGGL(rows_commit_kernel, dim3((unsigned)((n_alive + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
-                     ctx->stream, alive_row, (uint32_t)n_alive, cur_row);
-  ABZ_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-int abz_compact_impl(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, uint32_t* alive_idx, uint32_t* arank,
-                     int64_t* n_alive, const uint32_t* cur_row) {
-  const uint32_t nchunk = (uint32_t)((N + ABZ_CHUNK - 1) / ABZ_CHUNK);
-  int rc = abz_ws_reserve(ctx, abz_align((size_t)nchunk * 4));
-  if (rc) return rc;
-  uint32_t* cnt = (uint32_t*)ctx->ws;
-  hipLaunchKernelGGL(compact_count_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt);
-  hipLaunchKernelGGL(scan_u32_kernel, dim3(1), dim3(1024), 0, ctx->stream, cnt, nchunk, ctx->d_scal + ABZ_S_NALIVE);
-  hipLaunchKernelGGL(compact_scatter_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, N, cnt, alive_idx,
-                     arank, cur_row);
-  ABZ_HIP_CHECK(hipGetLastError());
-  if (!n_alive) return 0;            /* caller already knows sum(alive): stay asynchronous */
-  rc = read_scalars(ctx);
-  if (rc) return rc;
-  *n_alive = (int64_t)ctx->h_scal[ABZ_S_NALIVE];
-  return 0;
-}
 
 /* ================================================================ partition of the packed population
  * After a reweight the alive flags of the prefix [0, n_prev) have holes; n_new = sum(alive) is known to the host.

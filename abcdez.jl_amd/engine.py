@@ -2,7 +2,7 @@
 
 ``PopulationEngine`` owns the arrays the reference driver owns
 (``θs, logπ, Δs, Wns, alive`` and their ``n*`` doubles, src/abcdez_smc.jl:242-275)
-as torch tensors, shards the particles over the ranks of a ``torch.distributed``
+as torch tensors, shards the work over the ranks of a ``torch.distributed``
 process group, and forwards every population-sized step to an *ops* backend:
 
 * :class:`HipOps` -- the product: ctypes calls into ``libabcdez_hip.so`` with raw
@@ -10,26 +10,22 @@ process group, and forwards every population-sized step to an *ops* backend:
 * the test suite injects an oracle-backed ops object to exercise this file's host
   logic (sharding, collectives, buffer swapping) on CPU over ``gloo``.
 
-Layout in HBM (per rank, every array FULL length N so donors can be any particle):
-``theta[2][N][ld]`` f64 row-major ping-pong, ``logpi[2][N]``, ``delta[2][N]`` f64,
-``wns[N]`` f64, ``alive[N]`` u8, ``alive_idx[N]``, ``arank[N]``, ``inds[N]`` u32,
-and for abcdemc ``order[N]`` u32 + ``sorted_delta[N]`` f64.
+Two storages, one per driver (every array has FULL length N on every rank: a donor can be any particle):
 
-Multi-GPU: rank r updates the contiguous index range
-[r N/G, (r+1) N/G) and every rank keeps the whole population, so the next sweep's
-donors come from the global population.  RNG counters are keyed by the global
-particle index, so results do not depend on G.  The cheap per-generation passes
-(quantile, reweight, compaction, resampling indices) run replicated on the full arrays.
-
-* ``storage="classic"`` (abcdemc; abcdesmc on request): after every sweep the new
-  rows / logπ / Δ of all ranks are exchanged with one in-place all-gather each.
-* ``storage="rows"`` (abcdesmc default): the replicas exchange ONE BYTE per particle
-  and sweep -- the accept flag -- and rebuild the accepted proposals themselves
-  (``smc_replay_rows``: the proposal is a function of replicated rows and of
-  counter-based random numbers).  Distances are all-gathered once per generation
-  (quantile / reweight need them), log-priors only before a resampling, and the
-  resampling gathers run replicated.  xGMI carries 1 + 8/K bytes per particle and
-  sweep instead of 8 ld + 16.
+* ``storage="packed"`` -- ``abcdesmc``.  Two row slots per position (``buf[0][0]``, ``buf[1][0]``, each
+  ``f64[N][ld]`` row-major), one bit per position naming the current slot (``bits``, ping-pong), ``logpi`` /
+  ``delta`` updated in place (they ping-pong only at resamplings), ``wns``, ``alive``.  After every reweight the
+  population is PARTITIONED so that the alive particles are the positions ``[0, n_alive)`` (include/abcdez_hip.h):
+  no alive list, donors addressed directly, reweight / quantile touch the prefix only.
+  Multi-GPU: every rank keeps the whole population; rank r sweeps the chunk
+  ``[r c, (r+1) c)`` of the prefix (c = a multiple of 64 covering n_alive / G), the ranks exchange ONE BYTE per
+  position and sweep -- the accept flag -- and rebuild the other ranks' accepted proposals and their log-priors
+  themselves (``smc_replay_packed``: a proposal is a function of replicated rows and of counter-based random
+  numbers).  Distances are all-gathered once per generation, overlapped with the last replay.  Random numbers
+  are keyed by position, so results do not depend on G.
+* ``storage="classic"`` -- ``abcdemc``.  ``buf[t]`` / ``buf[1-t]`` are generations t and t+1 (the reference's
+  ``θs`` / ``nθs``, src/abcdez_mc.jl:140-155); rank r updates the particles ``[r N/G, (r+1) N/G)`` and the new rows /
+  logπ / Δ are exchanged with one in-place all-gather each after every sweep.
 """
 from __future__ import annotations
 
@@ -113,70 +109,6 @@ class HipOps:
     def init(self, theta, logpi, delta, i0, n):
         _lib.check(self.lib, self.lib.abcdez_init(self.ctx, _ptr(theta), _ptr(logpi), _ptr(delta), i0, n))
 
-    def alive_compact(self, alive, alive_idx, arank, n_known=None) -> int:
-        if n_known is not None:     # sum(alive) known from the reweight: no host sync
-            _lib.check(self.lib, self.lib.abcdez_alive_compact(self.ctx, _ptr(alive), alive.numel(), _ptr(alive_idx),
-                                                               _ptr(arank), None))
-            return n_known
-        n = C.c_int64()
-        _lib.check(self.lib, self.lib.abcdez_alive_compact(self.ctx, _ptr(alive), alive.numel(), _ptr(alive_idx),
-                                                           _ptr(arank), C.byref(n)))
-        return n.value
-
-    def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
-                  sweep, dead_synced=None):
-        nacc, nsim = C.c_int64(), C.c_int64()
-        _lib.check(self.lib, self.lib.abcdez_smc_swarm(
-            self.ctx, _ptr(alive_idx), _ptr(arank), n_alive, r_lo, r_hi, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
-            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), eps, gamma0, gsig, i0, n_local, int(copy_dead),
-            _ptr(dead_synced), sweep, C.byref(nacc), C.byref(nsim)))
-        return nacc.value, nsim.value
-
-    # ---- row-store mode: include/abcdez_hip.h, abcdez_smc_swarm_rows (+ _shard / replay for sharded runs) ----
-    supports_rows = True
-
-    def alive_compact_rows(self, alive, cur_row, alive_row, arank):
-        _lib.check(self.lib, self.lib.abcdez_alive_compact_rows(self.ctx, _ptr(alive), alive.numel(), _ptr(cur_row),
-                                                                _ptr(alive_row), _ptr(arank), None))
-
-    def smc_swarm_rows(self, alive_row, alive_row_out, n_alive, slot0, slot1, logpi, delta, eps, gamma0, gsig, sweep):
-        nacc, nsim = C.c_int64(), C.c_int64()
-        _lib.check(self.lib, self.lib.abcdez_smc_swarm_rows(
-            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta),
-            eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
-        return nacc.value, nsim.value
-
-    def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
-                             eps, gamma0, gsig, sweep, want_counts=True):
-        """want_counts=False: no host synchronisation (the replay reports the other ranks' counters, the flags
-        carry this rank's)"""
-        nacc, nsim = C.c_int64(), C.c_int64()
-        _lib.check(self.lib, self.lib.abcdez_smc_swarm_rows_shard(
-            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, r_lo, r_hi, _ptr(slot0), _ptr(slot1), _ptr(logpi),
-            _ptr(delta), _ptr(accepted), eps, gamma0, gsig, sweep, C.byref(nacc) if want_counts else None,
-            C.byref(nsim) if want_counts else None))
-        return (nacc.value, nsim.value) if want_counts else None
-
-    def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
-                        sweep):
-        nacc, nsim = C.c_int64(), C.c_int64()
-        _lib.check(self.lib, self.lib.abcdez_smc_replay_rows(
-            self.ctx, _ptr(alive_row), _ptr(alive_row_out), n_alive, skip_lo, skip_hi, _ptr(slot0), _ptr(slot1),
-            _ptr(accepted), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim)))
-        return nacc.value, nsim.value
-
-    def rows_commit(self, alive_row, n_alive, cur_row):
-        _lib.check(self.lib, self.lib.abcdez_rows_commit(self.ctx, _ptr(alive_row), n_alive, _ptr(cur_row)))
-
-    def smc_resample_gather_rows(self, inds, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
-        _lib.check(self.lib, self.lib.abcdez_smc_resample_gather_rows(
-            self.ctx, _ptr(inds), inds.numel(), _ptr(cur_row), _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta),
-            _ptr(nlogpi), _ptr(ndelta), _ptr(wns), _ptr(alive)))
-
-    def rows_gather(self, cur_row, slot0, slot1, out):
-        _lib.check(self.lib, self.lib.abcdez_rows_gather(self.ctx, _ptr(cur_row), cur_row.numel(), _ptr(slot0),
-                                                         _ptr(slot1), _ptr(out)))
-
     # ---- packed population: include/abcdez_hip.h, abcdez_smc_partition / abcdez_smc_swarm_packed / ... ----
     supports_packed = True
 
@@ -241,11 +173,6 @@ class HipOps:
 
     def wsample_stratified(self, wns, draw, inds):
         _lib.check(self.lib, self.lib.abcdez_wsample_stratified(self.ctx, _ptr(wns), wns.numel(), draw, _ptr(inds)))
-
-    def smc_resample_gather(self, inds, i0, n_local, cur, nxt, wns, alive):
-        _lib.check(self.lib, self.lib.abcdez_smc_resample_gather(
-            self.ctx, _ptr(inds), inds.numel(), i0, n_local, _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]),
-            _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]), _ptr(wns), _ptr(alive)))
 
     def quantile_alive(self, delta, alive, p, n_alive=-1):
         q, a, b = C.c_double(), C.c_double(), C.c_double()
@@ -317,12 +244,12 @@ class PopulationEngine:
     """Device-resident population + the reference's per-generation functions."""
 
     def __init__(self, spec: ModelSpec, nparticles: int, process_group=None, ops=None, lanes: int = 0,
-                 storage: str = "classic", force_collectives: bool = False):
-        """storage = "classic": two full generations' arrays, every sweep writes the next one (the reference's
-        thetas / nthetas).  storage = "rows": row store -- two slots per particle, only accepted proposals are
-        written (abcdez_smc_swarm_rows); sharded: accept-flag exchange + replay (module docstring); abcdesmc only.
-        force_collectives: take the sharded code path (collectives, shard sweep + replay) even in a group of ONE
+                 storage: str = "packed", force_collectives: bool = False):
+        """storage = "packed": abcdesmc (module docstring); storage = "classic": the double buffer of abcdemc.
+        force_collectives: take the sharded code path (collectives, chunk sweep + replay) even in a group of ONE
         rank -- lets a single-GPU box exercise the RCCL calls (tests)."""
+        if storage not in ("packed", "classic"):
+            raise ValueError("storage must be 'packed' (abcdesmc) or 'classic' (abcdemc)")
         self.spec = spec
         self.N = int(nparticles)
         self.pg = process_group
@@ -347,16 +274,12 @@ class PopulationEngine:
         self.device = dev
         N, ld = self.N, spec.ld
         f64 = dict(dtype=torch.float64, device=dev)
-        self.rows_mode = storage == "rows" and getattr(self.ops, "supports_rows", False)
-        self.packed = storage == "packed" and getattr(self.ops, "supports_packed", False)
-        if storage == "packed" and not self.packed:
-            raise ValueError("this ops backend has no packed storage")
+        self.packed = storage == "packed"
         self._collectives = self.world > 1 or (force_collectives and self.pg is not None)
-        self.sharded_rows = self.rows_mode and self._collectives
         self.sharded_packed = self.packed and self._collectives
-        # (theta, logpi, delta) x 2: generation t and t+1 (smc:337-350); in row-store / packed mode the two theta
-        # arrays are the two slots of the store and only (logpi, delta) ping-pong -- at resamplings.
-        # Sharded packed runs exchange [r_lo, r_lo + chunk) pieces of the per-position arrays: room for G chunks.
+        # (theta, logpi, delta) x 2.  classic: generations t and t+1.  packed: the theta arrays are the two slots of the
+        # store, (logpi, delta) ping-pong at resamplings only.  Sharded packed runs exchange [r c, (r+1) c) pieces of
+        # the per-position arrays: room for G chunks.
         self._npad = N + (self.world * PACKED_ALIGN if self.sharded_packed else 0)
         self._full = [(torch.zeros(self._npad, **f64), torch.zeros(self._npad, **f64)) for _ in range(2)]
         self.buf = [(torch.zeros((N, ld), **f64), self._full[k][0][:N], self._full[k][1][:N]) for k in range(2)]
@@ -368,59 +291,41 @@ class PopulationEngine:
             self.n_prev = N                 # length of the alive prefix
             self.flags = torch.zeros(self._npad, dtype=torch.uint8, device=dev) if self.sharded_packed else None
             self.chunk = 0
-        if self.rows_mode:
-            self.cur_row = torch.arange(N, dtype=torch.int32, device=dev)      # particle | slot << 31
-            self.alive_row = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(2)]
-            self.ar = 0
-            self._rows_dirty = False
-            self._rows_n = 0
-        if self.sharded_rows:
-            self.accepted = torch.zeros(N, dtype=torch.uint8, device=dev)   # accept flags of the last sweep, by particle
-        # blobs (spec.n_blob > 0): one stamp per particle, ping-ponging with (logpi, delta)
+        # blobs (spec.n_blob > 0): one stamp per particle, travelling with (logpi, delta)
         self.blob_on = getattr(spec, "n_blob", 0) > 0
         self.stamp = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)] if self.blob_on else None
-        self._delta_work = None      # sharded row store: distance all-gather in flight (overlapped with the last replay)
+        self._delta_work = None      # sharded packed: distance all-gather in flight (overlapped with the last replay)
         self._prof = None            # optional event timing of the sharded sweep's phases (enable_phase_timing)
-        self._delta_stale = False    # sharded row store: other ranks' distances / log-priors not yet fetched
-        self._logpi_stale = False
+        self._delta_stale = False    # sharded packed: the other ranks' distances not yet fetched
         self.wns = torch.full((N,), 1.0 / N, **f64)
         self.alive = torch.ones(N, dtype=torch.uint8, device=dev)
-        self.alive_idx = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.arank = torch.zeros(N, dtype=torch.int32, device=dev)
         self.inds = torch.zeros(N, dtype=torch.int32, device=dev)
         self.order = None
         self.sorted_delta = None
+        self.rank_cnt = None
         self.n_alive = N
-        self.r_lo, self.r_hi = self.lo, self.hi
-        self.row_synced = torch.zeros(N, dtype=torch.uint8, device=dev)   # dead rows already carried to both buffers
+        self.r_lo, self.r_hi = 0, N
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
-        self._dead_carried = True
+
+    def _stream(self):
+        """the library launches on the stream that is current NOW: torch ops and collectives issued by this engine
+        between library calls go to torch's current stream, so the two must be the same one at every call"""
+        if hasattr(self.ops, "use_current_stream"):
+            self.ops.use_current_stream()
 
     # ------------------------------------------------------------------ helpers
     @property
     def state(self):
-        """(theta, logpi, delta) of the current generation.  Row-store mode gathers the current rows into a
-        fresh array (tests / results only; the hot path never calls this)."""
-        if self.packed:
-            self._sync_delta()
-            th = torch.empty_like(self.buf[0][0])
-            self.ops.packed_gather(self.bits[self.bc], self.buf[0][0], self.buf[1][0], th)
-            return (th, self.buf[self.cur][1], self.buf[self.cur][2])
-        if not self.rows_mode:
+        """(theta, logpi, delta) of the current generation.  Packed storage gathers the current rows into a fresh
+        dense array (tests / results only; the hot path never calls this)."""
+        if not self.packed:
             return self.buf[self.cur]
-        self._rows_commit()
+        self._stream()
         self._sync_delta()
-        self._sync_logpi()
         th = torch.empty_like(self.buf[0][0])
-        self.ops.rows_gather(self.cur_row, self.buf[0][0], self.buf[1][0], th)
+        self.ops.packed_gather(self.bits[self.bc], self.buf[0][0], self.buf[1][0], th)
         return (th, self.buf[self.cur][1], self.buf[self.cur][2])
-
-    def _rows_commit(self):
-        if self.rows_mode and self._rows_dirty:
-            # the list was built for the alive set of the LAST compaction (a reweight may have shrunk n_alive since)
-            self.ops.rows_commit(self.alive_row[self.ar], self._rows_n, self.cur_row)
-            self._rows_dirty = False
 
     @property
     def delta(self):
@@ -428,7 +333,7 @@ class PopulationEngine:
         return self.buf[self.cur][2]
 
     def _sync_delta(self):
-        """sharded row store: fetch the other ranks' distances (once per generation, before the first consumer)"""
+        """sharded packed: fetch the other ranks' distances (once per generation, before the first consumer)"""
         if self._delta_work is not None:          # started behind the generation's last replay: just join it
             self._mark("delta_allgather_wait", 0)
             self._delta_work.wait()
@@ -437,31 +342,24 @@ class PopulationEngine:
             self._delta_stale = False
         if self._delta_stale:
             self._mark("delta_allgather", 0)
-            if self.sharded_packed:
-                self._allgather_chunks(self._full[self.cur][1])
-            else:
-                self._allgather_state((self.buf[self.cur][2],))
+            self._allgather_chunks(self._full[self.cur][1])
             self._mark("delta_allgather", 1)
             self._delta_stale = False
 
     def _start_delta_allgather(self):
-        """sharded row store, last sweep of a generation: the owners' distances are final once the shard sweep has
-        run, so their all-gather goes out on the collective stream while this rank replays the other shards."""
+        """sharded packed, last sweep of a generation: the owners' distances are final once the chunk sweep has run,
+        so their all-gather goes out on the collective stream while this rank replays the other chunks."""
         import torch.distributed as dist
 
         if self._backend == "nccl" or self.device.type == "cpu":
-            if self.sharded_packed:
-                t = self._full[self.cur][1]
-                self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
-                                                               t[self.rank * self.chunk:(self.rank + 1) * self.chunk],
-                                                               group=self.pg, async_op=True)
-                return
-            t = self.buf[self.cur][2]
-            self._delta_work = dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg, async_op=True)
+            t = self._full[self.cur][1]
+            self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
+                                                           t[self.rank * self.chunk:(self.rank + 1) * self.chunk],
+                                                           group=self.pg, async_op=True)
 
-    # ---- optional phase timing of the sharded row-store sweep (bench.py's multi-GPU breakdown) ----
+    # ---- optional phase timing of the sharded packed sweep (bench.py's multi-GPU breakdown) ----
     def enable_phase_timing(self):
-        """record device events around the phases of every sharded sweep: own shard sweep, flag all-gather, replay,
+        """record device events around the phases of every sharded sweep: own chunk sweep, flag all-gather, replay,
         and the per-generation distance all-gather (device tensors only)"""
         self._prof = {} if self.device.type == "cuda" else None
 
@@ -483,13 +381,6 @@ class PopulationEngine:
             out[phase] = (len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
         return out
 
-    def _sync_logpi(self):
-        """sharded row store: fetch the other ranks' log-priors and blob stamps (read by other ranks only when
-        resampling, smc:97,99)"""
-        if self._logpi_stale:
-            self._allgather_state((self.buf[self.cur][1],) + ((self.stamp[self.cur],) if self.blob_on else ()))
-            self._logpi_stale = False
-
     def _bind_stamps(self):
         """blobs: tell the ops which stamp arrays belong to the current / next generation"""
         if self.blob_on:
@@ -498,12 +389,8 @@ class PopulationEngine:
             self.ops.set_stamps(None, None)
 
     def alive_indices(self) -> torch.Tensor:
-        """particle indices of the alive list of the last compaction (int64)"""
-        if self.packed:
-            return torch.arange(self.n_prev, dtype=torch.int64, device=self.device)
-        if self.rows_mode:
-            return self.alive_row[self.ar][:self._rows_n].to(torch.int64) & 0x7FFFFFFF
-        return self.alive_idx[:self.n_alive].to(torch.int64)
+        """positions of the alive particles (int64): the prefix of the packed population"""
+        return torch.arange(self.n_prev, dtype=torch.int64, device=self.device)
 
     @property
     def other(self):
@@ -513,7 +400,8 @@ class PopulationEngine:
         self.cur = 1 - self.cur
 
     def _allgather_state(self, bufs):
-        """exchange entries [lo, hi) of per-particle arrays (theta, logpi, delta, ...) -- one all-gather per array.
+        """classic storage: exchange entries [lo, hi) of per-particle arrays (theta, logpi, delta, ...) -- one
+        all-gather per array.
 
         RCCL ("nccl" backend): in place, straight between the device buffers over xGMI.
         Any other backend (gloo in the CPU tests): CPU tensors in place; device tensors are
@@ -553,22 +441,21 @@ class PopulationEngine:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return tuple(int(v) for v in t.tolist())
 
+    def _need_packed(self, what):
+        if not self.packed:
+            raise RuntimeError(f"{what} needs storage='packed' (abcdesmc); this engine holds abcdemc's double buffer")
+
     # ------------------------------------------------------------------ S1
     def init_population(self):
+        self._stream()
         if self._delta_work is not None:
             self._delta_work.wait()
             self._delta_work = None
-        if self.rows_mode:       # a fresh population lives in slot `cur` of every particle (also when an engine is re-used)
-            self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
-            if self.cur:
-                self.cur_row.bitwise_or_(-(1 << 31))
-            self._rows_dirty = False
-            self._rows_n = 0
-        if self.packed:          # a fresh population lives in slot `cur` of every position
+        if self.packed:          # a fresh population lives in slot `cur` of every position (also when an engine is re-used)
             for b in self.bits:
                 b.fill_(-1 if self.cur else 0)
             self.n_prev = self.N
-        self._delta_stale = self._logpi_stale = False
+        self._delta_stale = False
         th, lp, dl = self.buf[self.cur]
         self._bind_stamps()
         self.ops.init(th, lp, dl, self.lo, self.n_local)
@@ -580,212 +467,130 @@ class PopulationEngine:
         self.n_alive = self.N
         if self.packed:
             self.n_prev = self.N
-        self._dead_carried = True
-        self.row_synced.zero_()
 
     # ------------------------------------------------------------------ S9, S10
     def quantile_alive(self, alpha: float) -> float:
-        if self.packed:      # the alive particles are the prefix [0, n_prev): the dead tail is not even read
-            n = self.n_prev
-            return self.ops.quantile_alive(self.delta[:n], self.alive[:n], alpha, self.n_alive)[0]
-        return self.ops.quantile_alive(self.delta, self.alive, alpha, self.n_alive)[0]
+        self._stream()
+        n = self.n_prev if self.packed else self.N      # packed: the alive particles are the prefix, the tail is not read
+        return self.ops.quantile_alive(self.delta[:n], self.alive[:n], alpha, self.n_alive)[0]
 
     def extrema(self):
+        self._stream()
         return self.ops.extrema(self.delta)
 
     def count_gt(self, thr: float) -> int:
+        self._stream()
         return self.ops.count_gt(self.delta, thr)
 
     # ------------------------------------------------------------------ S5, S6
     def smc_reweight(self, eps_old: float, eps_new: float):
-        if self.packed:
-            # prefix only: the dead tail has weight +0.0 and contributes exact zeros to the fixed summation trees
-            n = self.n_prev
-            wnorm, ess, n_alive = self.ops.smc_reweight(self.delta[:n], self.wns[:n], self.alive[:n], eps_old, eps_new)
-            self.n_alive = n_alive
-            return wnorm, ess, n_alive
-        wnorm, ess, n_alive = self.ops.smc_reweight(self.delta, self.wns, self.alive, eps_old, eps_new)
+        self._need_packed("smc_reweight")
+        self._stream()
+        # prefix only: the dead tail has weight +0.0 and contributes exact zeros to the fixed summation trees
+        n = self.n_prev
+        wnorm, ess, n_alive = self.ops.smc_reweight(self.delta[:n], self.wns[:n], self.alive[:n], eps_old, eps_new)
         self.n_alive = n_alive
-        self._dead_carried = False
         return wnorm, ess, n_alive
 
     def get_ess(self) -> float:
+        self._stream()
         return self.ops.get_ess(self.wns)
 
     def smc_prologue(self, alpha: float, eps_prev: float, eps_target: float, eps_k: float, ess_min: float):
         """Everything the driver does between two groups of sweeps except the resampling itself: extrema(Ds) of the
         generation that just ended (smc:364), eps = max(min(quantile(Ds[alive], alpha), eps_prev), eps_target)
-        (smc:301), reweight + ESS (smc:305-311, :323) -> (eps, wnorm, ess, n_alive, (lo, hi)).  On the packed HIP
-        population this is ONE library call with ONE host synchronisation (which also partitions the population
-        unless ESS < ess_min announces a resampling); elsewhere the three separate calls."""
-        if self.packed and hasattr(self.ops, "smc_prologue_packed"):
-            self._sync_delta()
-            self._bind_stamps()
-            cur = self.buf[self.cur]
-            eps, wnorm, ess, n_alive, part, lo, hi = self.ops.smc_prologue_packed(
-                cur[2], self.wns, self.alive, self.n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, self.bits[self.bc],
-                self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0], cur[1])
-            self.n_alive = n_alive
-            if part:
-                self.n_prev = n_alive
-            return eps, wnorm, ess, n_alive, (lo, hi)
-        rng = self.extrema()
-        eps = max(min(self.quantile_alive(alpha), eps_prev), eps_target)
-        wnorm, ess, n_alive = self.smc_reweight(eps_k, eps)
-        return eps, wnorm, ess, n_alive, rng
+        (smc:301), reweight + ESS (smc:305-311, :323) -> (eps, wnorm, ess, n_alive, (lo, hi)).  ONE library call
+        with ONE host synchronisation, which also partitions the population unless ESS < ess_min announces a
+        resampling."""
+        self._need_packed("smc_prologue")
+        self._stream()
+        self._sync_delta()
+        self._bind_stamps()
+        cur = self.buf[self.cur]
+        eps, wnorm, ess, n_alive, part, lo, hi = self.ops.smc_prologue_packed(
+            cur[2], self.wns, self.alive, self.n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, self.bits[self.bc],
+            self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0], cur[1])
+        self.n_alive = n_alive
+        if part:
+            self.n_prev = n_alive
+        return eps, wnorm, ess, n_alive, (lo, hi)
 
     # ------------------------------------------------------------------ S7, S8
     def smc_resample(self):
+        self._need_packed("smc_resample")
+        self._stream()
         self.ops.wsample_stratified(self.wns, self.draw, self.inds)
         self.draw += 1
         self._bind_stamps()
-        if self.packed:
-            self._sync_delta()
-            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
-            self.ops.smc_resample_gather_packed(self.inds, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0],
-                                                self.buf[1][0], cur[1], cur[2], oth[1], oth[2], self.wns, self.alive)
-            self._swap()
-            self.n_alive = self.n_prev = self.N
-            return
-        if self.rows_mode:
-            self._rows_commit()
-            self._sync_delta()
-            self._sync_logpi()
-            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
-            self.ops.smc_resample_gather_rows(self.inds, self.cur_row, self.buf[0][0], self.buf[1][0], cur[1], cur[2],
-                                              oth[1], oth[2], self.wns, self.alive)
-            self._swap()
-            self.n_alive = self.N
-            return
-        self.ops.smc_resample_gather(self.inds, self.lo, self.n_local, self.state, self.other, self.wns, self.alive)
-        if self._collectives:
-            self.wns.fill_(1.0 / self.N)   # the other ranks' ranges (smc:102-103)
-            self.alive.fill_(1)
-        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
+        self._sync_delta()
+        cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
+        self.ops.smc_resample_gather_packed(self.inds, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0],
+                                            self.buf[1][0], cur[1], cur[2], oth[1], oth[2], self.wns, self.alive)
         self._swap()
-        self.n_alive = self.N
-        self._dead_carried = True
-        self.row_synced.zero_()
+        self.n_alive = self.n_prev = self.N
 
-    # ------------------------------------------------------------------ alive list + S2, S3
+    # ------------------------------------------------------------------ partition + S2, S3
     def alive_compact(self) -> int:
-        if self.packed:
-            # no alive list: the population is partitioned so that the alive particles are the positions [0, n_alive)
-            if self.n_alive < self.n_prev:
-                self._sync_delta()
-                cur = self.buf[self.cur]
-                self._bind_stamps()
-                self.ops.smc_partition(self.n_prev, self.n_alive, self.alive, self.bits[self.bc], self.bits[1 - self.bc],
-                                       self.buf[0][0], self.buf[1][0], cur[1], cur[2], self.wns)
-                self.n_prev = self.n_alive
-            if self.sharded_packed:     # positions [r_lo, r_hi) of the prefix are this rank's for the coming sweeps
-                per = -(-self.n_alive // self.world)
-                self.chunk = -(-per // PACKED_ALIGN) * PACKED_ALIGN
-                self.r_lo = min(self.rank * self.chunk, self.n_alive)
-                self.r_hi = min(self.r_lo + self.chunk, self.n_alive)
-            else:
-                self.r_lo, self.r_hi = 0, self.n_alive
-            return self.n_alive
-        if self.rows_mode:
-            self._rows_commit()
-            self.ops.alive_compact_rows(self.alive, self.cur_row, self.alive_row[self.ar], self.arank)
-            self._rows_n = self.n_alive
-            if self.sharded_rows:   # alive ranks of this rank's particles: #alive below lo, #alive in [lo, hi)
-                below = self.alive[:self.lo].sum(dtype=torch.int64)
-                mine = self.alive[self.lo:self.hi].sum(dtype=torch.int64)
-                b, m = (int(v) for v in torch.stack((below, mine)).tolist())
-                self.r_lo, self.r_hi = b, b + m
-            return self.n_alive
-        n = self.ops.alive_compact(self.alive, self.alive_idx, self.arank, self.n_alive)
-        self.n_alive = n
-        if self.world == 1:
-            self.r_lo, self.r_hi = 0, n
+        """the reference finds its donors by scanning `alive` (smc:121,125); here the population is partitioned so that
+        the alive particles are the positions [0, n_alive) (a no-op when smc_prologue has done it already)"""
+        self._need_packed("alive_compact")
+        self._stream()
+        if self.n_alive < self.n_prev:
+            self._sync_delta()
+            cur = self.buf[self.cur]
+            self._bind_stamps()
+            self.ops.smc_partition(self.n_prev, self.n_alive, self.alive, self.bits[self.bc], self.bits[1 - self.bc],
+                                   self.buf[0][0], self.buf[1][0], cur[1], cur[2], self.wns)
+            self.n_prev = self.n_alive
+        if self.sharded_packed:     # positions [r_lo, r_hi) of the prefix are this rank's for the coming sweeps
+            per = -(-self.n_alive // self.world)
+            self.chunk = -(-per // PACKED_ALIGN) * PACKED_ALIGN
+            self.r_lo = min(self.rank * self.chunk, self.n_alive)
+            self.r_hi = min(self.r_lo + self.chunk, self.n_alive)
         else:
-            # alive ranks owned by this rank's index range: first alive index >= lo / >= hi
-            idx = self.alive_idx[:n]
-            bounds = torch.searchsorted(idx, torch.tensor([self.lo, self.hi], dtype=torch.int32, device=self.device))
-            self.r_lo, self.r_hi = (int(v) for v in bounds.tolist())
-        return n
+            self.r_lo, self.r_hi = 0, self.n_alive
+        return self.n_alive
 
     def smc_swarm(self, eps: float, gamma0: float, gsig: float, last: bool = False):
         """last: no further sweep follows in this generation (the driver's i == Kmcmc) -- lets a sharded run start
         the per-generation distance exchange early; has no effect on results"""
+        self._need_packed("smc_swarm")
+        self._stream()
         self._bind_stamps()
-        if self.packed:
-            cur = self.buf[self.cur]
-            b_in, b_out = self.bits[self.bc], self.bits[1 - self.bc]
-            if not self.sharded_packed:
-                counts = self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, 0, self.n_alive, self.buf[0][0],
-                                                   self.buf[1][0], cur[1], cur[2], None, eps, gamma0, gsig, self.sweep)
-                self.sweep += 1
-                self.bc = 1 - self.bc
-                return counts
-            if self._delta_work is not None:      # a caller swept again after announcing the last sweep
-                self._delta_work.wait()
-                self._delta_work = None
-            self._mark("own_sweep", 0)
-            self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
-                                      cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep, want_counts=False)
-            self._mark("own_sweep", 1)
-            self._mark("flag_allgather", 0)
-            self._allgather_chunks(self.flags)               # 1 byte per position: accepted | simulated << 1
-            self._mark("flag_allgather", 1)
-            if last:
-                self._start_delta_allgather()
-            self._mark("replay", 0)
-            counts = self.ops.smc_replay_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
-                                                self.buf[1][0], cur[1], self.flags, gamma0, gsig, self.sweep)
-            self._mark("replay", 1)
+        cur = self.buf[self.cur]
+        b_in, b_out = self.bits[self.bc], self.bits[1 - self.bc]
+        if not self.sharded_packed:
+            counts = self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, 0, self.n_alive, self.buf[0][0],
+                                               self.buf[1][0], cur[1], cur[2], None, eps, gamma0, gsig, self.sweep)
             self.sweep += 1
             self.bc = 1 - self.bc
-            self._delta_stale = True
-            return counts                                    # global (nacc, nsim), counted from the flags
-        if self.sharded_rows:
-            if self._delta_work is not None:      # a caller swept again after announcing the last sweep: that
-                self._delta_work.wait()           # exchange is obsolete (the stale flag stays set)
-                self._delta_work = None
-            cur = self.buf[self.cur]
-            a_in, a_out = self.alive_row[self.ar], self.alive_row[1 - self.ar]
-            self._mark("own_sweep", 0)
-            self.ops.smc_swarm_rows_shard(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
-                                          cur[1], cur[2], self.accepted, eps, gamma0, gsig, self.sweep, want_counts=False)
-            self._mark("own_sweep", 1)
-            self._mark("flag_allgather", 0)
-            self._allgather_state((self.accepted,))          # 1 byte per particle: accepted | simulated << 1
-            self._mark("flag_allgather", 1)
-            if last:
-                self._start_delta_allgather()
-            self._mark("replay", 0)
-            counts = self.ops.smc_replay_rows(a_in, a_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
-                                              self.buf[1][0], self.accepted, gamma0, gsig, self.sweep)
-            self._mark("replay", 1)
-            self.sweep += 1
-            self.ar = 1 - self.ar
-            self._rows_dirty = True
-            self._delta_stale = self._logpi_stale = True
-            return counts                                    # global (nacc, nsim), counted from the flags
-        if self.rows_mode:
-            cur = self.buf[self.cur]
-            nacc, nsim = self.ops.smc_swarm_rows(self.alive_row[self.ar], self.alive_row[1 - self.ar], self.n_alive,
-                                                 self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
-                                                 self.sweep)
-            self.sweep += 1
-            self.ar = 1 - self.ar
-            self._rows_dirty = True
-            return nacc, nsim
-        copy_dead = (not self._dead_carried) and self.n_alive < self.N
-        nacc, nsim = self.ops.smc_swarm(self.alive_idx, self.arank, self.n_alive, self.r_lo, self.r_hi, self.state,
-                                        self.other, eps, gamma0, gsig, self.lo, self.n_local, copy_dead, self.sweep,
-                                        self.row_synced)
+            return counts
+        if self._delta_work is not None:      # a caller swept again after announcing the last sweep: that exchange
+            self._delta_work.wait()           # is obsolete (the stale flag stays set)
+            self._delta_work = None
+        self._mark("own_sweep", 0)
+        self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                  cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep, want_counts=False)
+        self._mark("own_sweep", 1)
+        self._mark("flag_allgather", 0)
+        self._allgather_chunks(self.flags)               # 1 byte per position: accepted | simulated << 1
+        self._mark("flag_allgather", 1)
+        if last:
+            self._start_delta_allgather()
+        self._mark("replay", 0)
+        counts = self.ops.smc_replay_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
+                                            self.buf[1][0], cur[1], self.flags, gamma0, gsig, self.sweep)
+        self._mark("replay", 1)
         self.sweep += 1
-        self._dead_carried = True
-        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
-        self._swap()
-        return self._allreduce_counts(nacc, nsim)
+        self.bc = 1 - self.bc
+        self._delta_stale = True
+        return counts                                    # global (nacc, nsim), counted from the flags
 
     # ------------------------------------------------------------------ S4
     def _mc_arrays(self):
         """the enumeration of mc:23: order (positions -> particles), sorted_delta, and every particle's candidate count"""
+        if self.packed:
+            raise RuntimeError("abcdemc needs storage='classic'")
         if self.order is None:
             self.order = torch.zeros(self.N, dtype=torch.int32, device=self.device)
             self.sorted_delta = torch.zeros(self.N, dtype=torch.float64, device=self.device)
@@ -795,9 +600,8 @@ class PopulationEngine:
         """the enumeration of mc:23 for the current distances: particles with Ds <= eps_pop in index order, then the
         others by (Ds, index).  eps_pop / dmax_hint default to the values of mc:146-147 with eps_target = 0 (one
         extrema pass); the driver passes what it already knows.  No host synchronisation on the HIP path."""
-        if self.rows_mode or self.packed:
-            raise RuntimeError("abcdemc needs storage='classic'")
         self._mc_arrays()
+        self._stream()
         if eps_pop is None or dmax_hint is None:
             lo, hi = self.extrema()
             eps_pop = lo if eps_pop is None else eps_pop
@@ -808,6 +612,7 @@ class PopulationEngine:
         """one sweep of abcdemc_swarm! -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the generation it leaves
         (mc:149,156,146,163), global over all ranks"""
         self._mc_arrays()        # (a converged population never consults them)
+        self._stream()
         self._bind_stamps()
         nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.rank_cnt, self.state, self.other, eps_pop, eps_target,
                                               gamma0, gsig, self.lo, self.n_local, self.sweep)
@@ -826,8 +631,9 @@ class PopulationEngine:
     def mc_generation(self, eps_pop: float, eps_target: float, dmax: float, gamma0: float, gsig: float):
         """the body of abcdemc!'s loop (mc:140-156): rank pass while some Ds > eps_target, one sweep -> (nsim,
         #(Ds > eps_target), min Ds, max Ds) of the new generation.  One library call on a single GPU."""
-        if not self._collectives and hasattr(self.ops, "mc_generation") and not self.rows_mode and not self.packed:
+        if not self._collectives and hasattr(self.ops, "mc_generation"):
             self._mc_arrays()
+            self._stream()
             self._bind_stamps()
             out = self.ops.mc_generation(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, eps_pop,
                                          eps_target, dmax, gamma0, gsig, self.sweep)
@@ -882,16 +688,11 @@ class PopulationEngine:
             self.n_prev = self.n_alive
             if not bool(self.alive[:self.n_alive].all()):
                 raise ValueError("checkpoint of a packed population must have its alive particles in front")
-        if self.rows_mode:                       # every particle's current row is slot 0 again
-            self.cur_row.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
-            self._rows_dirty = False
-            self._rows_n = 0
-        self._delta_stale = self._logpi_stale = False
-        self._dead_carried = False
-        self.row_synced.zero_()
+        self._delta_stale = False
 
     # ------------------------------------------------------------------ results (smc:382-393, mc:166-171)
     def result(self):
+        self._stream()
         th, lp, dl = self.state
         pushed = torch.empty_like(th)
         self.ops.push_p(th, pushed)
@@ -925,7 +726,7 @@ class PopulationEngine:
 
 def HipEngine(spec: ModelSpec, nparticles: int, process_group=None, lanes: int = 0,
               storage: str = "packed", force_collectives: bool = False) -> PopulationEngine:
-    """The product engine: HIP kernels on the current CUDA(HIP) device.  Row-store sweeps (only accepted
-    proposals are written); sharded runs keep one replica per GPU and exchange accept flags (module docstring)."""
+    """The product engine: HIP kernels on the current CUDA(HIP) device.  storage="packed" for abcdesmc (only accepted
+    proposals are written; sharded runs keep one replica per GPU and exchange accept flags), "classic" for abcdemc."""
     return PopulationEngine(spec, nparticles, process_group, ops=None, lanes=lanes, storage=storage,
                             force_collectives=force_collectives)

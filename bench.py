@@ -55,7 +55,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-whole-run", action="store_true")
-    p.add_argument("--storage", default=None, choices=["rows", "packed", "classic"], help="abcdesmc storage (default: the config's)")
+    p.add_argument("--storage", default=None, choices=["packed"], help="abcdesmc storage (one choice left: the packed population)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -383,7 +383,7 @@ def main():
                   eps=getattr(gen, "eps", None), logZ=getattr(gen, "logZ", None))
     acc_rate = (gen.naccs - a0) / max(updates, 1) if cfg["kind"] == "smc" else 0.0
     phases = {}
-    if eng.sharded_rows:
+    if eng.sharded_packed:
         # device-event breakdown of the sharded sweep, taken on three EXTRA generations after the timed region
         # (recording eight events per sweep would cost the timed loop several percent)
         eng.enable_phase_timing()
@@ -393,7 +393,7 @@ def main():
 
     # ---- the whole run next to the window: from a fresh population to eps_target (device-resident, no result download)
     whole = None
-    if cfg["kind"] == "smc" and not args.no_whole_run and not eng.sharded_rows:
+    if cfg["kind"] == "smc" and not args.no_whole_run and not eng.sharded_packed:
         whole = {}
         models = [("model", cfg["prior"])] if args.config != "evidence1d" else \
             [("model1_prior_N(0,sqrt10)", cfg["prior"]), ("model2_prior_N(0,sqrt100)", A.Normal(0.0, math.sqrt(100.0)))]
@@ -450,7 +450,7 @@ def main():
             out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
         if whole is not None:
             out["whole_run"] = whole
-        if eng.sharded_rows:    # rank 0's device-event breakdown of the sharded sweep
+        if eng.sharded_packed:    # rank 0's device-event breakdown of the sharded sweep
             out["sharded_phases_ms"] = {k: {"calls": c, "avg_ms": (t / c if c else 0.0)} for k, (c, t) in phases.items()}
         if world == 1 and not args.no_cpu_baseline:
             faithful, out["cpu_baseline"] = cpu_baseline(A, args, cfg)

@@ -7,8 +7,8 @@
  * replaces one of them and keeps its argument meaning.  Conventions:
  *   - every array argument is a DEVICE pointer to a caller-owned buffer (allocate
  *     with the host's own GPU array package, with torch, or with abcdez_dev_alloc);
- *   - arrays are FULL population arrays of N elements (theta: N rows of `ld`
- *     doubles, row-major); functions that shard take a global range [i0, i0+n_local);
+ *   - arrays are FULL population arrays of N elements (theta / row slots: N rows of `ld`
+ *     doubles, row-major); functions that shard take a global range of particles / positions;
  *   - scalar results come back through HOST pointers; such functions synchronise
  *     the context's stream before returning, the others only enqueue;
  *   - return value: 0 = ok, negative = error (text via abcdez_last_error());
@@ -95,70 +95,10 @@ ABCDEZ_API int abcdez_blob_width(abcdez_ctx* ctx, int32_t* width);
 ABCDEZ_API int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
                      double* delta_out);
 
-/* Alive list: the index set wsample(rng, 1:N, alive) draws from (src/abcdez_smc.jl:121,125).
- * alive_idx[r] = index of the r-th alive particle; arank[i] = rank of i or 0xFFFFFFFF.
- * n_alive may be NULL (the caller knows sum(alive) from the reweight): then the call only enqueues. */
-ABCDEZ_API int abcdez_alive_compact(abcdez_ctx* ctx, const uint8_t* alive, int64_t N,
-                         uint32_t* alive_idx, uint32_t* arank, int64_t* n_alive);
-
-/* S2+S3  abcdesmc_swarm!(prior, dist!, varexternal, alive, thetas, logpi, Ds, nthetas, nlogpi, nDs,
- *        eps_k_new, gamma0, gamma_sigma, nparticles, nsims, naccs, rng, ex, nblobs)
- *        src/abcdez_smc.jl:106-153 plus the identity. copies of :337-340.
- * Processes the alive particles of [i0, i0+n_local) = alive ranks [r_lo, r_hi).
- * copy_dead != 0 also carries the dead rows of the range into the n* arrays.
- * dead_synced (may be NULL) = N flags "theta[i] == ntheta[i]" maintained by the library and
- * zeroed by the caller at start and after each resampling: with it a dead row is carried only
- * once and a rejected particle whose row is already equal in both arrays is not rewritten.
- * sweep = global sweep number (RNG epoch).  *nacc / *nsim = sums of the reference's
- * naccs[i] += 1 / nsims[i] += 1 over the range.                                      */
-ABCDEZ_API int abcdez_smc_swarm(abcdez_ctx* ctx, const uint32_t* alive_idx, const uint32_t* arank, int64_t n_alive,
-                     int64_t r_lo, int64_t r_hi,
-                     const double* theta, const double* logpi, const double* delta,
-                     double* ntheta, double* nlogpi, double* ndelta,
-                     double eps, double gamma0, double gamma_sigma,
-                     int64_t i0, int64_t n_local, int copy_dead, uint8_t* dead_synced, uint32_t sweep,
-                     int64_t* nacc, int64_t* nsim);
-
-/* Row-store variant of the same sweep (what bench.py measures; sharded runs: the _shard / replay pair below).  theta lives in a store of
- * two slots per particle (slot0[N][ld], slot1[N][ld]); cur_row[i] = i | slot << 31 names particle i's current
- * row, alive_row[r] the current row of the r-th alive particle.  An accepted proposal is written to the
- * particle's other slot and its entry flips in alive_row_out; a rejected or dead particle writes nothing, and
- * log-prior / distance are updated in place -- the identity. copies of src/abcdez_smc.jl:337-340 cost nothing.
- * Call order per generation: alive_compact_rows -> smc_swarm_rows (ping-pong alive_row / alive_row_out)
- * -> rows_commit (alive list -> cur_row) before the next compaction, resampling or rows_gather.          */
-ABCDEZ_API int abcdez_alive_compact_rows(abcdez_ctx* ctx, const uint8_t* alive, int64_t N, const uint32_t* cur_row,
-                              uint32_t* alive_row, uint32_t* arank, int64_t* n_alive);
-ABCDEZ_API int abcdez_smc_swarm_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
-                          double* slot0, double* slot1, double* logpi, double* delta,
-                          double eps, double gamma0, double gamma_sigma, uint32_t sweep,
-                          int64_t* nacc, int64_t* nsim);
-ABCDEZ_API int abcdez_rows_commit(abcdez_ctx* ctx, const uint32_t* alive_row, int64_t n_alive, uint32_t* cur_row);
-
-/* Sharded row store (one process per GPU).  Every rank keeps a full replica of the store.
- * Rank r runs the sweep on the alive ranks [r_lo, r_hi) of its own particles (src/abcdez_smc.jl:106-153 restricted
- * to that range) and records accepted[i] = (accepted ? 1 : 0) | (simulated ? 2 : 0) for each of them (nacc / nsim
- * may both be NULL: no host synchronisation); after an all-gather of the flags (1 byte per particle -- the only
- * per-sweep traffic) every rank calls smc_replay_rows, which rebuilds the accepted proposals theta_i + gamma
- * (theta_a - theta_b) (smc:128) of all alive ranks OUTSIDE [skip_lo, skip_hi) from its replica and the particles'
- * counter-based random numbers, completes alive_row_out, and returns in nacc / nsim the sweep's GLOBAL counters
- * (sum(naccs), sum(nsims) of smc:138,149,352, counted from the flags of all alive ranks -- no all-reduce).
- * Log-priors and distances stay with their owner between the sweeps (the host all-gathers distances once per
- * generation for the quantile / reweight, log-priors before a resampling).                                   */
-ABCDEZ_API int abcdez_smc_swarm_rows_shard(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out,
-                          int64_t n_alive, int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi,
-                          double* delta, uint8_t* accepted, double eps, double gamma0, double gamma_sigma,
-                          uint32_t sweep, int64_t* nacc, int64_t* nsim);
-ABCDEZ_API int abcdez_smc_replay_rows(abcdez_ctx* ctx, const uint32_t* alive_row, uint32_t* alive_row_out, int64_t n_alive,
-                          int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                          double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim);
-ABCDEZ_API int abcdez_smc_resample_gather_rows(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* cur_row,
-                                    double* slot0, double* slot1, const double* logpi, const double* delta,
-                                    double* nlogpi, double* ndelta, double* wns, uint8_t* alive);
-ABCDEZ_API int abcdez_rows_gather(abcdez_ctx* ctx, const uint32_t* cur_row, int64_t N, const double* slot0,
-                       const double* slot1, double* out);
-
-/* ---- Packed population (abcdesmc's default storage).
- * After every reweight that kills particles the population is PARTITIONED so that the alive particles are the
+/* ---- S2+S3  abcdesmc_swarm!(prior, dist!, varexternal, alive, thetas, logpi, Ds, nthetas, nlogpi, nDs, eps_k_new, gamma0,
+ *        gamma_sigma, nparticles, nsims, naccs, rng, ex, nblobs)  src/abcdez_smc.jl:106-153, the identity. copies of
+ *        :337-340, and S8 abcdesmc_resample! src/abcdez_smc.jl:85-104 -- on the PACKED population.
+ * The alive list wsample(rng, 1:N, alive) scans for (smc:121,125) is replaced by an invariant: after every reweight that kills particles the population is PARTITIONED so that the alive particles are the
  * positions [0, n_alive): the k-th dead position below n_new swaps its whole state with the k-th alive position at or
  * above it (the reference's algorithm is symmetric under relabelling of the particles, src/abcdez_smc.jl:106-153, so
  * the law of every output is unchanged; everything -- random numbers, donor ranks, summation trees -- is keyed by
@@ -221,13 +161,6 @@ ABCDEZ_API int abcdez_get_ess(abcdez_ctx* ctx, const double* wns, int64_t N, dou
 /* S7  wsample_stratified!(rng, weights, inds)  src/abcdez_smc.jl:15-56 (0-based indices).
  *     draw = resampling number (RNG epoch).                                           */
 ABCDEZ_API int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t draw, uint32_t* inds);
-
-/* S8  abcdesmc_resample!(ess_inds, thetas, logpi, Ds, Wns, alive, nparticles, rng, blobs)
- *     src/abcdez_smc.jl:85-104, gathers for rows [i0, i0+n_local) into the n* arrays,
- *     Wns = 1/N and alive = true on that range.                                       */
-ABCDEZ_API int abcdez_smc_resample_gather(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, int64_t i0, int64_t n_local,
-                               const double* theta, const double* logpi, const double* delta,
-                               double* ntheta, double* nlogpi, double* ndelta, double* wns, uint8_t* alive);
 
 /* S9  quantile(Ds[alive], alpha)  src/abcdez_smc.jl:301 (Julia default, type 7).
  *     Also returns the two order statistics it interpolates.                         */

@@ -26,9 +26,13 @@
  *          the Philox stream standing in for Julia's rng;
  *   orc_*  the "spec" restatement the HIP kernels must match bit for bit: same
  *          algorithm, but with the order-free formulations a GPU needs (rank-skip
- *          donors, integer cumulative weights, fixed summation trees).  Tests show
- *          ref_* and orc_* agree (exactly where the formulation is exact, in law
- *          where only the consumption of random numbers differs).
+ *          donors, integer cumulative weights, fixed summation trees, alive particles
+ *          kept as a prefix by orc_smc_partition).  Tests show ref_* and orc_* agree
+ *          (exactly where the formulation is exact, in law where only the consumption
+ *          of random numbers or the labelling of the particles differs).  The dense
+ *          functions (orc_smc_swarm on plain arrays, used by the C driver) and the
+ *          *_packed functions (the device's two-slot storage) are two restatements of
+ *          the same spec and are tested against each other.
  *
  * All citations are into /root/reference (ABCdeZ.jl v0.6.0).
  * Layout: theta is row-major double[N][ld]; logpi, delta, wns are double[N];
@@ -606,127 +610,6 @@ ORC_API void orc_smc_resample_gather(const abz_model* M, const uint32_t* inds, i
     wns[s] = 1.0 / (double)N;                                              /* smc:102 */
     alive[s] = 1;                                                          /* smc:103 */
   }
-}
-
-/* ---------------------------------------------------------------- row-store restatement of S2/S3/S8
- * The same sweep / resampling over a store of two slots per particle (slot0[N][ld], slot1[N][ld]); cur_row[i] =
- * i | slot << 31 names particle i's current row and alive_row[r] the current row of the r-th alive particle.
- * An accepted proposal goes to the particle's OTHER slot and its entry flips in alive_out; log-prior and
- * distance are updated in place.  Checker for abcdez_*_rows / abcdez_smc_swarm_rows_shard / abcdez_smc_replay_rows
- * (include/abcdez_hip.h); values identical to orc_smc_swarm / orc_smc_resample_gather on the dense arrays.   */
-#define ORC_ROW(slot0, slot1, rid, ld) (((rid) >> 31) ? (slot1) : (slot0)) + (int64_t)((rid) & 0x7FFFFFFFu) * (ld)
-
-ORC_API int64_t orc_alive_compact_rows(const uint8_t* alive, int64_t N, const uint32_t* cur_row, uint32_t* alive_row,
-                                       uint32_t* arank) {
-  uint32_t r = 0;
-  for (int64_t i = 0; i < N; ++i) {
-    if (alive[i]) { alive_row[r] = cur_row[i]; arank[i] = r; ++r; }
-    else arank[i] = ABZ_DEAD;
-  }
-  return (int64_t)r;
-}
-
-ORC_API void orc_rows_commit(const uint32_t* alive_row, int64_t n, uint32_t* cur_row) {
-  for (int64_t r = 0; r < n; ++r) cur_row[alive_row[r] & 0x7FFFFFFFu] = alive_row[r];
-}
-
-ORC_API void orc_rows_gather(const uint32_t* cur_row, int64_t N, int ld, const double* slot0, const double* slot1,
-                             double* out) {
-  for (int64_t i = 0; i < N; ++i) memcpy(out + i * ld, ORC_ROW(slot0, slot1, cur_row[i], ld), (size_t)ld * sizeof(double));
-}
-
-/* the proposal of alive rank ri (particle i): smc:119-128 */
-static void rows_proposal(const abz_model* M, const uint32_t* alive_row, int64_t n_alive, const double* slot0,
-                          const double* slot1, uint32_t ri, double gamma0, double gsig, uint32_t sweep, double* tp) {
-  const int ld = M->ld;
-  const uint32_t rowi = alive_row[ri], i = rowi & 0x7FFFFFFFu;
-  uint32_t ra, rb;
-  abz_donor_ranks(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)n_alive, ri, &ra, &rb);
-  const double* ti = ORC_ROW(slot0, slot1, rowi, ld);
-  const double* ta = ORC_ROW(slot0, slot1, alive_row[ra], ld);
-  const double* tb = ORC_ROW(slot0, slot1, alive_row[rb], ld);
-  double z0, z1;
-  abz_normal_pair(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
-  const double g = gamma0 * (1.0 + z0 * gsig);
-  for (int k = 0; k < ld; ++k) tp[k] = ti[k] + (ta[k] - tb[k]) * g;
-}
-
-ORC_API void orc_smc_swarm_rows(const abz_model* M, const uint32_t* alive_row, uint32_t* alive_out, int64_t n_alive,
-                                int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta,
-                                uint8_t* accepted /* by particle, may be NULL */, double eps, double gamma0, double gsig,
-                                uint32_t sweep, int64_t* nacc_out, int64_t* nsim_out) {
-  const int ld = M->ld;
-  int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
-  for (int64_t r = r_lo; r < r_hi; ++r) {
-    const uint32_t rowi = alive_row[r], i = rowi & 0x7FFFFFFFu;
-    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
-    rows_proposal(M, alive_row, n_alive, slot0, slot1, (uint32_t)r, gamma0, gsig, sweep, tp);
-    push_row(M, tp, pp);
-    const double lp = logprior_tree(M, pp);                                          /* smc:134 */
-    int acc = 0, simulated = 0;
-    if (!(lp < 0.0 && !abz_isfinite(lp) && !abz_isnan(lp))) {                        /* smc:135 */
-      const double dp = sim_dist(M, pp, i, sweep, ABZ_RNG_SIM);                      /* smc:137 */
-      nsim += 1;
-      simulated = 1;
-      const double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i]));
-      acc = (0.0 <= w);
-      if (!acc) acc = abz_log_tab(abz_u01_open(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T) < w;  /* smc:145 */
-      if (acc) {                                                                     /* smc:146-150 */
-        double* to = (double*)(ORC_ROW(slot0, slot1, rowi ^ 0x80000000u, ld));
-        for (int k = 0; k < ld; ++k) to[k] = tp[k];
-        logpi[i] = lp; delta[i] = dp;
-        if (g_stamp_cur) g_stamp_cur[i] = abz_stamp(i, sweep, 0);
-        nacc += 1;
-      }
-    }
-    alive_out[r] = acc ? (rowi ^ 0x80000000u) : rowi;
-    if (accepted) accepted[i] = (uint8_t)(acc | (simulated << 1));
-  }
-  *nacc_out = nacc; *nsim_out = nsim;
-}
-
-/* what a replica does for the alive ranks it does not own: rebuild the accepted proposals from the flags */
-ORC_API void orc_smc_replay_rows(const abz_model* M, const uint32_t* alive_row, uint32_t* alive_out, int64_t n_alive,
-                                 int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, const uint8_t* accepted,
-                                 double gamma0, double gsig, uint32_t sweep, int64_t* nacc_out, int64_t* nsim_out) {
-  const int ld = M->ld;
-  int64_t nacc = 0, nsim = 0;                /* the sweep's global counters (flags: bit 0 accepted, bit 1 simulated) */
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
-  for (int64_t r = 0; r < n_alive; ++r) {
-    const uint32_t rowi = alive_row[r], i = rowi & 0x7FFFFFFFu;
-    nacc += accepted[i] & 1;
-    nsim += (accepted[i] >> 1) & 1;
-    if (r >= skip_lo && r < skip_hi) continue;
-    if (accepted[i] & 1) {
-      double tp[ABZ_MAX_D];
-      rows_proposal(M, alive_row, n_alive, slot0, slot1, (uint32_t)r, gamma0, gsig, sweep, tp);
-      double* to = (double*)(ORC_ROW(slot0, slot1, rowi ^ 0x80000000u, ld));
-      for (int k = 0; k < ld; ++k) to[k] = tp[k];
-      alive_out[r] = rowi ^ 0x80000000u;
-    } else {
-      alive_out[r] = rowi;
-    }
-  }
-  *nacc_out = nacc; *nsim_out = nsim;
-}
-
-ORC_API void orc_smc_resample_gather_rows(const abz_model* M, const uint32_t* inds, int64_t N, uint32_t* cur_row,
-                                          double* slot0, double* slot1, const double* logpi, const double* delta,
-                                          double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
-  const int ld = M->ld;
-#pragma omp parallel for schedule(static)
-  for (int64_t s = 0; s < N; ++s) {
-    const int64_t j = inds[s];
-    memcpy((double*)(ORC_ROW(slot0, slot1, cur_row[s] ^ 0x80000000u, ld)), ORC_ROW(slot0, slot1, cur_row[j], ld),
-           (size_t)ld * sizeof(double));                                   /* smc:96 */
-    nlogpi[s] = logpi[j];                                                  /* smc:97 */
-    ndelta[s] = delta[j];                                                  /* smc:98 */
-    if (g_stamp_nxt) g_stamp_nxt[s] = g_stamp_cur[j];                      /* smc:99 */
-    wns[s] = 1.0 / (double)N;                                              /* smc:102 */
-    alive[s] = 1;                                                          /* smc:103 */
-  }
-  for (int64_t s = 0; s < N; ++s) cur_row[s] ^= 0x80000000u;
 }
 
 /* ---------------------------------------------------------------- packed population: alive particles form a prefix

@@ -101,14 +101,6 @@ def lib():
     L.orc_wsample_stratified.argtypes = [_u64, _vp, _i64, _u32, _vp]
     L.orc_stratum_uniforms.argtypes = [_u64, _i64, _u32, _vp]
     L.orc_smc_resample_gather.argtypes = [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
-    L.orc_alive_compact_rows.restype = _i64
-    L.orc_alive_compact_rows.argtypes = [_vp, _i64, _vp, _vp, _vp]
-    L.orc_rows_commit.argtypes = [_vp, _i64, _vp]
-    L.orc_rows_gather.argtypes = [_vp, _i64, C.c_int, _vp, _vp, _vp]
-    L.orc_smc_swarm_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32,
-                                     _pi64, _pi64]
-    L.orc_smc_replay_rows.argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64]
-    L.orc_smc_resample_gather_rows.argtypes = [_vp] * 2 + [_i64] + [_vp] * 9
     L.orc_smc_partition.restype = _i64
     L.orc_smc_partition.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp]
     L.orc_packed_partition.restype = _i64
@@ -172,52 +164,6 @@ class OracleOps:
         if rc:
             raise RuntimeError("oracle init: no finite (log-prior, distance) within the retry limit")
 
-    def alive_compact(self, alive, alive_idx, arank, n_known=None) -> int:
-        return self.L.orc_alive_compact(_p(alive), alive.numel(), _p(alive_idx), _p(arank))
-
-    def smc_swarm(self, alive_idx, arank, n_alive, r_lo, r_hi, cur, nxt, eps, gamma0, gsig, i0, n_local, copy_dead,
-                  sweep, dead_synced=None):
-        nacc, nsim = _i64(), _i64()
-        self.L.orc_smc_swarm(self.m.ptr, _p(alive_idx), _p(arank), n_alive, _p(cur[0]), _p(cur[1]), _p(cur[2]),
-                             _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), eps, gamma0, gsig, i0, n_local, sweep,
-                             C.byref(nacc), C.byref(nsim))
-        return nacc.value, nsim.value
-
-    # ---- row-store restatement (checker for the abcdez_*_rows entry points) ----
-    supports_rows = True
-
-    def alive_compact_rows(self, alive, cur_row, alive_row, arank):
-        self.L.orc_alive_compact_rows(_p(alive), alive.numel(), _p(cur_row), _p(alive_row), _p(arank))
-
-    def smc_swarm_rows(self, alive_row, alive_row_out, n_alive, slot0, slot1, logpi, delta, eps, gamma0, gsig, sweep):
-        return self.smc_swarm_rows_shard(alive_row, alive_row_out, n_alive, 0, n_alive, slot0, slot1, logpi, delta, None,
-                                         eps, gamma0, gsig, sweep)
-
-    def smc_swarm_rows_shard(self, alive_row, alive_row_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, accepted,
-                             eps, gamma0, gsig, sweep, want_counts=True):
-        nacc, nsim = _i64(), _i64()
-        self.L.orc_smc_swarm_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, r_lo, r_hi, _p(slot0), _p(slot1),
-                                  _p(logpi), _p(delta), _p(accepted), eps, gamma0, gsig, sweep, C.byref(nacc),
-                                  C.byref(nsim))
-        return nacc.value, nsim.value
-
-    def smc_replay_rows(self, alive_row, alive_row_out, n_alive, skip_lo, skip_hi, slot0, slot1, accepted, gamma0, gsig,
-                        sweep):
-        nacc, nsim = _i64(), _i64()
-        self.L.orc_smc_replay_rows(self.m.ptr, _p(alive_row), _p(alive_row_out), n_alive, skip_lo, skip_hi, _p(slot0),
-                                   _p(slot1), _p(accepted), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
-        return nacc.value, nsim.value
-
-    def rows_commit(self, alive_row, n_alive, cur_row):
-        self.L.orc_rows_commit(_p(alive_row), n_alive, _p(cur_row))
-
-    def smc_resample_gather_rows(self, inds, cur_row, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
-        self.L.orc_smc_resample_gather_rows(self.m.ptr, _p(inds), inds.numel(), _p(cur_row), _p(slot0), _p(slot1),
-                                            _p(logpi), _p(delta), _p(nlogpi), _p(ndelta), _p(wns), _p(alive))
-
-    def rows_gather(self, cur_row, slot0, slot1, out):
-        self.L.orc_rows_gather(_p(cur_row), cur_row.numel(), self.spec.ld, _p(slot0), _p(slot1), _p(out))
-
     # ---- packed store (checker for the abcdez_*_packed entry points) ----
     supports_packed = True
 
@@ -273,10 +219,6 @@ class OracleOps:
     def wsample_stratified(self, wns, draw, inds):
         self.L.orc_wsample_stratified(self.spec.seed, _p(wns), wns.numel(), draw, _p(inds))
 
-    def smc_resample_gather(self, inds, i0, n_local, cur, nxt, wns, alive):
-        self.L.orc_smc_resample_gather(self.m.ptr, _p(inds), inds.numel(), i0, n_local, _p(cur[0]), _p(cur[1]),
-                                       _p(cur[2]), _p(nxt[0]), _p(nxt[1]), _p(nxt[2]), _p(wns), _p(alive))
-
     def quantile_alive(self, delta, alive, p, n_alive=-1):
         a, b = _f64(), _f64()
         q = self.L.orc_quantile_alive(_p(delta), _p(alive), delta.numel(), p, C.byref(a), C.byref(b))
@@ -324,7 +266,7 @@ class OracleOps:
                                   _p(log_u))
 
 
-def oracle_engine(spec, nparticles, process_group=None, storage="classic"):
+def oracle_engine(spec, nparticles, process_group=None, storage="packed"):
     """PopulationEngine (the product's host logic) driven by the oracle instead of the GPU."""
     import abcdez_amd.engine as E
 
@@ -333,9 +275,10 @@ def oracle_engine(spec, nparticles, process_group=None, storage="classic"):
 
 def run_abcdesmc(spec, nparticles, eps_target, alpha=0.95, delta_ess=0.5, nsims_max=10 ** 7, Kmcmc=3, Kmcmc_min=1.0,
                  facc_stop=0.0, facc_min=0.0, facc_tune=0.975, max_iters=100000, packed=True):
-    """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c).  packed (default): the population is
-    partitioned after every reweight so that the alive particles form a prefix (orc_smc_partition) -- the spec of
-    the product's abcdesmc; packed=False: particles keep their index (the legacy double-buffer / row-store modes)."""
+    """The C restatement of the whole driver (oracle/abcdez_oracle_driver.c) on dense arrays.  packed (default, the
+    spec): the population is partitioned after every reweight so that the alive particles form a prefix
+    (orc_smc_partition); packed=False: particles keep their index for life as in the reference -- the same algorithm
+    under another labelling of the particles, used by the tests that show the two agree in law."""
     L = lib()
     L.orc_set_stamps(None, None)      # the C drivers carry no blobs: unbind stamp arrays an earlier engine left behind
     m = OracleModel(spec)

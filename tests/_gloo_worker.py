@@ -53,28 +53,19 @@ def main():
 
         torch.cuda.set_device(0)          # every rank shares the one GPU of the test box; collectives go through gloo
         engine = HipEngine
-    def classic(spec, n, pg_):           # abcdesmc on the double-buffered storage (per-sweep all-gather of the rows)
-        return engine(spec, n, pg_, storage="classic")
-
     for name, (prior, sim, eps, N) in cases().items():
         # default storage: packed population; sharded = accept-flag exchange + replay on the replicas
         r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
         assert r.engine.packed and r.engine.sharded_packed == (world > 1 or mode == "rccl1")
-        c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=classic,
-                       process_group=pg)
-        assert not c.engine.rows_mode
-        cres = c.engine.result()
         m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=25, verbose=False, rng=22,
                       engine=engine, process_group=pg)
         res, mres = r.engine.result(), m.engine.result()
         # every rank must hold the same full population after the all-gathers
         np.savez(os.path.join(outdir, f"result_{name}_rank{rank}.npz"), theta=res["theta"], C=res["C"], Wns=res["Wns"],
                  logZ=r.logZ, eps_hist=np.array(r.ϵs), nsims=r.nsims, iters=r.iters, mc_theta=mres["theta"],
-                 mc_C=mres["C"], mc_nsims=m.nsims, world=world, logpi=res["logpi"], classic_theta=cres["theta"],
-                 classic_C=cres["C"], classic_logpi=cres["logpi"], classic_Wns=cres["Wns"], classic_logZ=c.logZ,
-                 classic_nsims=c.nsims, **({"blobs": res["blobs"], "classic_blobs": cres["blobs"], "mc_blobs": mres["blobs"]}
-                                           if res["blobs"] is not None else {}))
+                 mc_C=mres["C"], mc_nsims=m.nsims, world=world, logpi=res["logpi"],
+                 **({"blobs": res["blobs"], "mc_blobs": mres["blobs"]} if res["blobs"] is not None else {}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -47,14 +47,12 @@ def test_sharded_run_equals_single_process(runs, name, world):
     for rank in range(world):
         got = np.load(os.path.join(runs[world], f"result_{name}_rank{rank}.npz"))
         assert int(got["world"]) == world
-        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C",
-                  "classic_logpi", "classic_Wns"):
+        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C"):
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, world, rank, k)
-        if "blobs" in ref.files:        # blob stamps: all-gathered with the rows (classic) / before resampling (row store)
+        if "blobs" in ref.files:        # blob stamps: rebuilt by the replay (abcdesmc) / all-gathered with the rows (abcdemc)
             assert ref["blobs"].shape[0] == ref["C"].shape[0]
-            for k in ("blobs", "classic_blobs", "mc_blobs"):
+            for k in ("blobs", "mc_blobs"):
                 assert np.array_equal(ref[k], got[k]), (name, world, rank, k)
-        assert float(ref["classic_logZ"]) == float(got["classic_logZ"]) and int(ref["classic_nsims"]) == int(got["classic_nsims"])
         assert float(ref["logZ"]) == float(got["logZ"])
         assert int(ref["nsims"]) == int(got["nsims"]) and int(ref["iters"]) == int(got["iters"])
         assert int(ref["mc_nsims"]) == int(got["mc_nsims"])
@@ -76,7 +74,7 @@ def test_uneven_shard_is_rejected(oracle):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
     """The product engine (HIP kernels) sharded over 2 / 4 ranks that share the single GPU of the test box,
-    collectives over gloo: exercises i0 > 0, alive-rank sub-ranges, shard sweep + flag exchange + replay, the in-place
+    collectives over gloo: exercises i0 > 0, chunks of the alive prefix, chunk sweep + flag exchange + replay, the in-place
     all-gathers on device tensors and the counters -- everything of the N > 1 path except RCCL itself -- and must
     reproduce the single-process CPU-oracle result bit for bit."""
     ref_dir = tmp_path_factory.mktemp("ref_oracle")
@@ -87,15 +85,15 @@ def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(world):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
-            for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C") + \
-                    (("blobs", "classic_blobs", "mc_blobs") if "blobs" in ref.files else ()):
+            for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C") + \
+                    (("blobs", "mc_blobs") if "blobs" in ref.files else ()):
                 assert np.array_equal(ref[k], got[k], equal_nan=True), (name, rank, k)
             assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
 
 
 @pytest.mark.gpu
 def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
-    """The sharded code path (flag all-gather + replay, per-generation distance all-gather, classic row
+    """The sharded code path (flag all-gather + replay, per-generation distance all-gather, abcdemc's row
     all-gathers, counter all-reduce) over the real RCCL backend in a group of one rank -- all a single-GPU box
     can run of `nccl` -- must reproduce the single-process CPU-oracle result bit for bit."""
     ref_dir = tmp_path_factory.mktemp("ref_oracle_rccl")
@@ -105,7 +103,7 @@ def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
     for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
-        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C", "classic_theta", "classic_C") + \
-                (("blobs", "classic_blobs", "mc_blobs") if "blobs" in ref.files else ()):
+        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C") + \
+                (("blobs", "mc_blobs") if "blobs" in ref.files else ()):
             assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
         assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])

@@ -67,7 +67,10 @@ def test_remaining_simulators_parity(oracle, which):
             for k in range(3):
                 assert torch.equal(hip.state[k].cpu().view(torch.int64), orc.state[k].view(torch.int64))
         eps_old = eps
-    # abcdemc path on the same model
+    # abcdemc path on the same model (double-buffered storage)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="classic")
+    orc = oracle.oracle_engine(spec, N, storage="classic")
+    hip.init_population(); orc.init_population()
     lo, hi = orc.extrema()
     hip.mc_rank_prepare(lo, hi); orc.mc_rank_prepare(lo, hi)
     assert torch.equal(hip.order.cpu(), orc.order)
@@ -91,13 +94,13 @@ def test_lotka_volterra_end_to_end(oracle):
 def test_config4_lotka_volterra_full_size_properties_and_oracle_spot_checks(oracle):
     """BASELINE.json configs[3] at its stated workload on one GPU: Lotka-Volterra RK4, dt = 0.01, 1500 steps per
     particle-update, N = 2^20.  Whole-population properties every generation; one more sweep replayed bit for bit
-    by the oracle for three 4096-particle ranges from the same full input state; the initial population's first
+    by the oracle for three 8192-position ranges from the same full input state; the initial population's first
     and last 2048 particles (prior draws, redraws of blown-up trajectories, first distances) against the oracle."""
     prior, sim = lv_model()
     assert sim.dt == 0.01 and sim.steps_per_obs == 100 and len(sim.obs) == 32
     N, d = 1 << 20, 4
     spec = A.ModelSpec(prior, sim, seed=11)
-    eng = PopulationEngine(spec, N, ops=HipOps(spec), storage="classic")
+    eng = PopulationEngine(spec, N, ops=HipOps(spec))
     eng.init_population()
     th0, lp0, dl0 = (t.cpu() for t in eng.state)
     assert torch.isfinite(dl0).all() and torch.isfinite(lp0).all()                       # init.jl:14
@@ -116,35 +119,10 @@ def test_config4_lotka_volterra_full_size_properties_and_oracle_spot_checks(orac
     for gen in range(3):
         loop.generation(chk)
     assert loop.eps < float(dl0.max())
-    eps = loop.eps
-    th, lp, dl = (t.cpu().contiguous() for t in eng.state)
-    aidx, arank = eng.alive_idx.cpu().contiguous(), eng.arank.cpu().contiguous()
-    n_alive, sweep = eng.n_alive, eng.sweep
-    nacc_all, nsim_all = eng.smc_swarm(eps, loop.g0, 1e-5)
-    assert 0 < nacc_all <= nsim_all <= n_alive and nsim_all < n_alive                   # bounded prior: some proposals fall outside
-    nth, nlp, ndl = torch.zeros_like(th), torch.zeros_like(lp), torch.zeros_like(dl)
-    for i0 in (0, N // 2 - 2048, N - 4096):
-        nacc, nsim = C.c_int64(), C.c_int64()
-        oracle.lib().orc_smc_swarm(m.ptr, aidx.data_ptr(), arank.data_ptr(), n_alive, th.data_ptr(), lp.data_ptr(),
-                                   dl.data_ptr(), nth.data_ptr(), nlp.data_ptr(), ndl.data_ptr(), eps, loop.g0, 1e-5,
-                                   i0, 4096, sweep, C.byref(nacc), C.byref(nsim))
-        sl = slice(i0, i0 + 4096)
-        got = [t[sl].cpu() for t in eng.state]
-        assert torch.equal(got[0].view(torch.int64), nth[sl].view(torch.int64))
-        assert torch.equal(got[1].view(torch.int64), nlp[sl].view(torch.int64))
-        assert torch.equal(got[2].view(torch.int64), ndl[sl].view(torch.int64))
-        assert nacc.value == int((got[2] != dl[sl]).sum()) or abs(nacc.value - int((got[2] != dl[sl]).sum())) <= 1
-    # the row store (the default storage of abcdesmc) gives the same population as the double buffer
-    e2 = PopulationEngine(spec, N, ops=HipOps(spec), storage="rows")
-    e2.init_population()
-    e2.reset_weights()
-    l2 = Loop(e2, d, 1.0)
-    for gen in range(3):
-        l2.generation(Checks(oracle, spec, deep=False))
-    e2.smc_swarm(l2.eps, l2.g0, 1e-5)
-    assert l2.eps == loop.eps and l2.logZ == loop.logZ
-    for k in range(3):
-        assert checksum(e2.state[k]) == checksum(eng.state[k])
+    n = eng.n_alive
+    nacc_all, nsim_all = oracle_spot_check_of_a_packed_sweep(oracle, spec, eng, loop.eps, loop.g0,
+                                                             (0, (n // 2) // 64 * 64, (n - 8192) // 64 * 64))
+    assert nsim_all < n                                                                 # bounded prior: some proposals fall outside
 
 
 def test_spec_vectors_on_gpu():
@@ -167,6 +145,30 @@ def test_spec_vectors_on_gpu():
         assert int(res["alive"].sum()) == g["n_alive"]
         assert float(np.sum(res["theta"][res["alive"]])) == float.fromhex(g["theta_sum"])
         assert float(np.sum(res["C"])) == float.fromhex(g["delta_sum"])
+
+
+def oracle_spot_check_of_a_packed_sweep(oracle, spec, eng, eps, g0, ranges):
+    """one more sweep on the device; the oracle replays the given position ranges of it from the same full input
+    (both row slots, slot bits, log-priors, distances) and every touched byte of those ranges must agree"""
+    b_in = eng.bits[eng.bc].cpu().contiguous()
+    s0, s1 = eng.buf[0][0].cpu().contiguous(), eng.buf[1][0].cpu().contiguous()
+    lp, dl = eng.buf[eng.cur][1].cpu().contiguous(), eng.buf[eng.cur][2].cpu().contiguous()
+    n_alive, sweep = eng.n_alive, eng.sweep
+    nacc_all, nsim_all = eng.smc_swarm(eps, g0, 1e-5)
+    assert 0 < nacc_all <= nsim_all <= n_alive
+    ops = oracle.OracleOps(spec)
+    b_out = b_in.clone()
+    flags = torch.zeros(eng.N, dtype=torch.uint8)
+    for lo in ranges:
+        hi = min(lo + 8192, n_alive)
+        assert lo % 64 == 0 and lo < hi
+        ops.smc_swarm_packed(b_in, b_out, n_alive, lo, hi, s0, s1, lp, dl, flags, eps, g0, 1e-5, sweep)
+        sl = slice(lo, hi)
+        for a, b in ((eng.buf[0][0], s0), (eng.buf[1][0], s1), (eng.buf[eng.cur][1], lp), (eng.buf[eng.cur][2], dl)):
+            assert torch.equal(a[sl].cpu().view(torch.int64), b[sl].view(torch.int64))
+        w = slice(lo // 32, (hi + 31) // 32 if hi % 32 == 0 else hi // 32)      # whole words of the range
+        assert torch.equal(eng.bits[eng.bc][w].cpu(), b_out[w])
+    return nacc_all, nsim_all
 
 
 class Loop:
@@ -204,12 +206,12 @@ class Checks:
         self.oracle, self.spec, self.deep = oracle, spec, deep
 
     def compaction(self, e, n_alive):
-        idx = e.alive_indices()
-        assert idx.numel() == n_alive
+        """after the partition the alive particles are exactly the positions [0, n_alive)"""
+        assert e.alive_indices().numel() == n_alive == e.n_prev
         assert int(e.alive.sum().item()) == n_alive
-        assert bool((idx[1:] > idx[:-1]).all())                          # sorted, unique
-        assert bool(e.alive[idx].all())
-        assert bool((e.arank[idx].to(torch.int64) == torch.arange(n_alive, device=idx.device)).all())
+        assert bool(e.alive[:n_alive].all()) and not bool(e.alive[n_alive:].any())
+        assert bool((e.wns[:n_alive] > 0).all()) and not bool((e.wns[n_alive:] != 0).any())
+        assert torch.equal(e.bits[0], e.bits[1])                         # the two bit arrays agree between sweeps
 
     def resample(self, e, w_before):
         inds = e.inds.to(torch.int64)
@@ -232,15 +234,15 @@ class Checks:
 
 def test_config3_full_size_properties_and_oracle_spot_checks(oracle):
     """BASELINE.json configs[2]: d = 32 MVN, N = 2^22.  Properties on the whole population every generation;
-    bit-exact comparison of three 8192-particle ranges of one sweep against the oracle; identical checksums
-    for two lane-group shapes and for a repeated run."""
+    bit-exact comparison of three 8192-position ranges of one sweep against the oracle; identical checksums
+    for two lane-group shapes."""
     d, N = 32, 1 << 22
     prior = A.Factored(*[A.Normal(0, 1)] * d)
     sim = A.MVNormal((1.0,) * d)
     spec = A.ModelSpec(prior, sim, seed=1)
     sums = []
-    for lanes, deep, storage in ((0, True, "classic"), (8, False, "classic"), (0, False, "rows")):
-        eng = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes), storage=storage)
+    for lanes, deep in ((0, True), (8, False), (0, False)):
+        eng = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes))
         eng.init_population()
         eng.reset_weights()
         loop = Loop(eng, d, 6.0)
@@ -248,42 +250,27 @@ def test_config3_full_size_properties_and_oracle_spot_checks(oracle):
         for gen in range(4 if deep else 16):
             loop.generation(chk)
         if deep:
-            # one more sweep, replayed for three ranges by the oracle from the same full input state
-            eps = loop.eps
-            th, lp, dl = (t.cpu().contiguous() for t in eng.state)
-            aidx, arank = eng.alive_idx.cpu().contiguous(), eng.arank.cpu().contiguous()
-            n_alive, sweep = eng.n_alive, eng.sweep
-            eng.smc_swarm(eps, loop.g0, 1e-5)
-            nth, nlp, ndl = torch.zeros_like(th), torch.zeros_like(lp), torch.zeros_like(dl)
-            m = oracle.OracleModel(spec)
-            for i0 in (0, N // 2 - 4096, N - 8192):
-                nacc, nsim = C.c_int64(), C.c_int64()
-                oracle.lib().orc_smc_swarm(m.ptr, aidx.data_ptr(), arank.data_ptr(), n_alive, th.data_ptr(),
-                                           lp.data_ptr(), dl.data_ptr(), nth.data_ptr(), nlp.data_ptr(),
-                                           ndl.data_ptr(), eps, loop.g0, 1e-5, i0, 8192, sweep, C.byref(nacc),
-                                           C.byref(nsim))
-                sl = slice(i0, i0 + 8192)
-                got = [t[sl].cpu() for t in eng.state]
-                assert torch.equal(got[0].view(torch.int64), nth[sl].view(torch.int64))
-                assert torch.equal(got[1].view(torch.int64), nlp[sl].view(torch.int64))
-                assert torch.equal(got[2].view(torch.int64), ndl[sl].view(torch.int64))
+            n = eng.n_alive
+            oracle_spot_check_of_a_packed_sweep(oracle, spec, eng, loop.eps, loop.g0, (0, (n // 2) // 64 * 64, (n - 8192) // 64 * 64))
         else:
             assert loop.eps < 9.9 and -2.5 < loop.logZ < 0.0
             sums.append((checksum(eng.state[0]), checksum(eng.state[2]), checksum(eng.wns), loop.logZ, loop.eps))
         del eng
         torch.cuda.empty_cache()
-    assert sums[0] == sums[1]            # 8 x 4 lanes, classic double buffer == 4 x 8 lanes, row store
+    assert sums[0] == sums[1]            # 8 lanes x 4 components == 4 lanes x 8 components
 
 
 def test_config3_full_size_shard_sweep_plus_replay_equals_full_sweep():
-    """The multi-GPU row-store path at BASELINE.json configs[2] size (d = 32, N = 2^22), as rank 1 of 4 sees it:
-    sweeping only its own alive ranks and replaying the others' accepted proposals from the flag bytes must
-    leave the replica exactly as the full sweep does (new alive list, every current row, the sweep counters),
-    for three consecutive sweeps of a generation."""
+    """The multi-GPU path at BASELINE.json configs[2] size (d = 32, N = 2^22), as rank 1 of 4 sees it: sweeping only
+    its own chunk of the prefix and replaying the others' accepted proposals from the flag bytes must leave the
+    replica exactly as the full sweep does (slot bits, both row slots, log-priors, the sweep counters), for three
+    consecutive sweeps of a generation."""
+    from abcdez_amd.engine import PACKED_ALIGN
+
     d, N, G, rank = 32, 1 << 22, 4, 1
     prior = A.Factored(*[A.Normal(0, 1)] * d)
     spec = A.ModelSpec(prior, A.MVNormal((1.0,) * d), seed=1)
-    e = PopulationEngine(spec, N, ops=HipOps(spec), storage="rows")
+    e = PopulationEngine(spec, N, ops=HipOps(spec))
     e.init_population()
     e.reset_weights()
     g0 = 2.38 / math.sqrt(2 * d)
@@ -299,31 +286,32 @@ def test_config3_full_size_shard_sweep_plus_replay_equals_full_sweep():
     n = e.alive_compact()
     assert n < N
     ops = e.ops
-    r_lo, r_hi = rank * n // G, (rank + 1) * n // G
-    full = dict(s0=e.buf[0][0].clone(), s1=e.buf[1][0].clone(), lp=e.buf[e.cur][1].clone(), dl=e.buf[e.cur][2].clone())
-    mine = dict(s0=e.buf[0][0], s1=e.buf[1][0], lp=e.buf[e.cur][1], dl=e.buf[e.cur][2])
-    a_full = [e.alive_row[e.ar].clone(), torch.zeros_like(e.alive_row[0])]
-    a_mine = [e.alive_row[e.ar].clone(), torch.zeros_like(e.alive_row[0])]
+    chunk = -(-(-(-n // G)) // PACKED_ALIGN) * PACKED_ALIGN
+    r_lo, r_hi = rank * chunk, min((rank + 1) * chunk, n)
+    cur = e.buf[e.cur]
+    full = dict(s0=e.buf[0][0].clone(), s1=e.buf[1][0].clone(), lp=cur[1].clone(), dl=cur[2].clone())
+    mine = dict(s0=e.buf[0][0], s1=e.buf[1][0], lp=cur[1], dl=cur[2])
+    b_full = [e.bits[e.bc].clone(), e.bits[1 - e.bc].clone()]
+    b_mine = [e.bits[e.bc].clone(), e.bits[1 - e.bc].clone()]
     flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
     scratch = torch.zeros(N, dtype=torch.uint8, device="cuda")
     for k in range(3):
         sweep = e.sweep + k
-        cnt = ops.smc_swarm_rows_shard(a_full[0], a_full[1], n, 0, n, full["s0"], full["s1"], full["lp"], full["dl"], flags,
-                                       eps, g0, 1e-5, sweep)
-        assert ops.smc_swarm_rows_shard(a_mine[0], a_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], mine["lp"], mine["dl"],
-                                        scratch, eps, g0, 1e-5, sweep, want_counts=False) is None
-        own = a_mine[0][r_lo:r_hi].to(torch.int64) & 0x7FFFFFFF
-        assert torch.equal(scratch[own], flags[own])                          # the owner's flags
-        assert ops.smc_replay_rows(a_mine[0], a_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], flags, g0, 1e-5,
-                                   sweep) == cnt                              # global counters from the flags
+        cnt = ops.smc_swarm_packed(b_full[0], b_full[1], n, 0, n, full["s0"], full["s1"], full["lp"], full["dl"], flags,
+                                   eps, g0, 1e-5, sweep)
+        assert ops.smc_swarm_packed(b_mine[0], b_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], mine["lp"], mine["dl"],
+                                    scratch, eps, g0, 1e-5, sweep, want_counts=False) is None
+        assert torch.equal(scratch[r_lo:r_hi], flags[r_lo:r_hi])              # the owner's flags
+        assert ops.smc_replay_packed(b_mine[0], b_mine[1], n, r_lo, r_hi, mine["s0"], mine["s1"], mine["lp"], flags, g0,
+                                     1e-5, sweep) == cnt                      # global counters from the flags
         assert 0.05 * n < cnt[0] < 0.6 * n and cnt[1] == n                    # Normal prior: every proposal simulated
-        assert torch.equal(a_mine[1][:n], a_full[1][:n])
-        for key in ("s0", "s1"):                                              # both slots: current AND previous rows
+        assert torch.equal(b_mine[1], b_full[1])
+        for key in ("s0", "s1", "lp"):                                        # both slots: current AND previous rows
             assert checksum(mine[key]) == checksum(full[key])
-        assert torch.equal(mine["dl"][own], full["dl"][own]) and torch.equal(mine["lp"][own], full["lp"][own])
-        # next sweep: the other owners' distances / log-priors arrive by all-gather in the real job
-        mine["dl"].copy_(full["dl"]); mine["lp"].copy_(full["lp"])
-        a_full.reverse(); a_mine.reverse()
+        assert torch.equal(mine["dl"][r_lo:r_hi], full["dl"][r_lo:r_hi])
+        # next sweep: the other owners' distances arrive by all-gather in the real job
+        mine["dl"].copy_(full["dl"])
+        b_full.reverse(); b_mine.reverse()
 
 
 def test_config2_abcdemc_one_million_particles(oracle):
@@ -332,7 +320,7 @@ def test_config2_abcdemc_one_million_particles(oracle):
     N = 1 << 20
     prior, sim = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0)
     spec = A.ModelSpec(prior, sim, seed=3)
-    eng = PopulationEngine(spec, N, ops=HipOps(spec))
+    eng = PopulationEngine(spec, N, ops=HipOps(spec), storage="classic")
     eng.init_population()
     g0 = 2.38 / math.sqrt(2)
     prev_max = math.inf

@@ -143,8 +143,11 @@ def test_packed_abcdesmc_end_to_end(oracle, name, N, abck):
         assert np.array_equal(res[k], c[k]), k
 
 
-@pytest.mark.parametrize("d,shapes", [(32, (2, 4, 8)), (16, (1, 2, 4, 8)), (8, (1, 2, 4))])
+@pytest.mark.parametrize("d,shapes", [(32, (2, 4, 8)), (16, (1, 2, 4, 8)), (8, (1, 2, 4)), (3, (1, 2))])
 def test_packed_lane_shapes(oracle, d, shapes):
+    """several generations (reweight, resampling, partition, two sweeps each) for EVERY lane shape the dispatch table
+    holds for this row width (up to 8 lanes: a block must own whole bitmap words): sweep counters, final population
+    and weights equal the oracle's -- hence each other's"""
     prior = A.Factored(*[A.Normal(0.0, 1.0) for _ in range(d)])
     spec = A.ModelSpec(prior, A.MVNormal(tuple([1.0] * d)), seed=5)
     N = 1 << 14

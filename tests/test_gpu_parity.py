@@ -29,11 +29,13 @@ def models():
     }
 
 
-def engines(name, N, seed=3, ABCk=A.IndicatorStrict0toϵ, lanes=0, oracle=None, storage="classic"):
+def engines(name, N, seed=3, ABCk=A.IndicatorStrict0toϵ, lanes=0, oracle=None, storage="packed"):
+    """(spec, product engine on the GPU, the same host logic on the oracle, eps); storage "packed" = abcdesmc's
+    population, "classic" = abcdemc's double buffer"""
     prior, sim, eps = models()[name]
     spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
     hip = PopulationEngine(spec, N, ops=HipOps(spec, lanes=lanes), storage=storage)
-    orc = oracle.oracle_engine(spec, N)
+    orc = oracle.oracle_engine(spec, N, storage=storage)
     return spec, hip, orc, eps
 
 
@@ -141,9 +143,10 @@ def test_reweight_quantile_compact_parity(oracle, N, abck):
         assert rh == ro, (rh, ro)
         assert hip.get_ess() == orc.get_ess()
         assert same(hip.wns, orc.wns) and same(hip.alive, orc.alive)
-        nh, no = hip.alive_compact(), orc.alive_compact()
+        nh, no = hip.alive_compact(), orc.alive_compact()          # partition: the alive particles become a prefix
         assert nh == no == ro[2]
-        assert same(hip.alive_idx[:nh], orc.alive_idx[:no]) and same(hip.arank, orc.arank)
+        assert bool(hip.alive[:nh].all()) and not bool(hip.alive[nh:].any())
+        assert_state_equal(hip, orc, "partition")
         eps_old = qh
 
 
@@ -240,110 +243,14 @@ def test_stratified_resample_parity(oracle, N):
     assert (counts >= np.floor(expect) - 1).all() and (counts <= np.ceil(expect) + 1).all()
 
 
-# ---------------------------------------------------------------- S2/S3 sweeps incl. dead particles
-@pytest.mark.parametrize("name,lanes", [
-    ("normal1d", 0), ("uniform1d", 0), ("mvn32", 0), ("mvn32", 4), ("mvn32", 16), ("mvn32", 8), ("mvn8", 0),
-    ("mvn8", 1), ("mvn3", 0), ("quad2d_inf", 0), ("normdu", 0), ("dirac", 0), ("mixture", 0), ("socks", 0),
-])
-@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
-@pytest.mark.parametrize("storage", ["classic", "rows"])
-def test_smc_sweep_parity(oracle, name, lanes, abck, storage):
-    """storage: the classic double buffer (abcdemc, abcdesmc on request) and the row store (abcdesmc default)"""
-    N = 6000
-    spec, hip, orc, _ = engines(name, N, ABCk=abck, lanes=lanes, oracle=oracle, storage=storage)
-    assert hip.rows_mode == (storage == "rows")
-    hip.init_population(); orc.init_population()
-    d = spec.d
-    gamma0 = 2.38 / math.sqrt(2 * d)
-    eps_old = math.inf
-    for gen in range(4):
-        q = orc.quantile_alive(0.8)
-        assert hip.quantile_alive(0.8) == q
-        eps = min(q, eps_old)
-        rh, ro = hip.smc_reweight(eps_old, eps), orc.smc_reweight(eps_old, eps)
-        assert rh[2] == ro[2]
-        if ro[2] < 3:        # integer distances + strict kernel can wipe the population out (wnorm = 0 -> NaN weights)
-            break
-        assert rh == ro
-        if gen == 2:
-            hip.smc_resample(); orc.smc_resample()
-            assert same(hip.inds, orc.inds)
-        assert hip.alive_compact() == orc.alive_compact()
-        for _ in range(3):
-            ch, co = hip.smc_swarm(eps, gamma0, 1e-5), orc.smc_swarm(eps, gamma0, 1e-5)
-            assert ch == co, (ch, co)                      # bit-exact accept mask => equal counters
-            assert_state_equal(hip, orc, f"{name} gen {gen}")
-        eps_old = eps
-
-
-# ---------------------------------------------------------------- sharded row store: shard sweep + replay on replicas
-@pytest.mark.parametrize("name,lanes", [("normal1d", 0), ("mvn32", 0), ("mvn32", 8), ("mvn8", 0), ("mvn3", 0),
-                                        ("quad2d_inf", 0), ("normdu", 0), ("socks", 0)])
-def test_shard_sweep_and_replay_parity(oracle, name, lanes):
-    """Three replicas of one population on the one GPU, each sweeping its own third of the alive ranks
-    (abcdez_smc_swarm_rows_shard) and replaying the other two thirds from the merged accept flags
-    (abcdez_smc_replay_rows): every replica must end bit-identical to the oracle's full sweep."""
-    N, G = 6000, 3
-    spec, hip, orc, _ = engines(name, N, lanes=lanes, oracle=oracle, storage="rows")
-    hip.init_population(); orc.init_population()
-    gamma0 = 2.38 / math.sqrt(2 * spec.d)
-    eps = orc.quantile_alive(0.7)
-    assert hip.quantile_alive(0.7) == eps
-    assert hip.smc_reweight(math.inf, eps) == orc.smc_reweight(math.inf, eps)
-    n = orc.alive_compact()
-    assert hip.alive_compact() == n and n >= 3
-    ops = hip.ops
-    a_in = hip.alive_row[hip.ar]
-    cuts = [0, n // 5, n // 5 + n // 2, n]                        # uneven alive-rank ranges
-    pcut = [0] + [int(a_in[c].item() & 0x7FFFFFFF) for c in cuts[1:-1]] + [N]    # the particles they start at
-    for sweep in range(3):
-        reps = []
-        for r in range(G):
-            rep = dict(s0=hip.buf[0][0].clone(), s1=hip.buf[1][0].clone(), lp=hip.buf[hip.cur][1].clone(),
-                       dl=hip.buf[hip.cur][2].clone(), out=torch.zeros_like(a_in),
-                       acc=torch.full((N,), 7, dtype=torch.uint8, device=a_in.device))
-            rep["cnt"] = ops.smc_swarm_rows_shard(a_in, rep["out"], n, cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"],
-                                                  rep["dl"], rep["acc"], eps, gamma0, 1e-5, hip.sweep)
-            reps.append(rep)
-        flags = torch.zeros(N, dtype=torch.uint8, device=a_in.device)           # the all-gather of the accept flags
-        for r in range(G):
-            flags[pcut[r]:pcut[r + 1]] = reps[r]["acc"][pcut[r]:pcut[r + 1]]
-        co = orc.smc_swarm(eps, gamma0, 1e-5)
-        for r in range(G):          # every replica learns the sweep's global counters from the flags
-            assert ops.smc_replay_rows(a_in, reps[r]["out"], n, cuts[r], cuts[r + 1], reps[r]["s0"], reps[r]["s1"], flags,
-                                       gamma0, 1e-5, hip.sweep) == co
-        assert (sum(rep["cnt"][0] for rep in reps), sum(rep["cnt"][1] for rep in reps)) == co
-        th_o, lp_o, dl_o = orc.state
-        alive = orc.alive.bool().to(flags.device)
-        assert int((flags[alive] & 1).sum()) == co[0] and int((flags[alive] >> 1).sum()) == co[1]
-        for r in range(G):
-            rep = reps[r]
-            assert same(rep["out"], reps[0]["out"])                           # identical alive lists everywhere
-            cur_row = hip.cur_row.clone()
-            ops.rows_commit(rep["out"], n, cur_row)
-            th = torch.empty_like(rep["s0"])
-            ops.rows_gather(cur_row, rep["s0"], rep["s1"], th)
-            assert same(th, th_o), f"{name} sweep {sweep} replica {r}: theta differs"
-            assert same(rep["lp"][pcut[r]:pcut[r + 1]], lp_o[pcut[r]:pcut[r + 1]])   # owners hold logpi / delta
-            assert same(rep["dl"][pcut[r]:pcut[r + 1]], dl_o[pcut[r]:pcut[r + 1]])
-        # carry replica 0 (completed with the owners' log-priors / distances) into the engine for the next sweep
-        hip.buf[0][0].copy_(reps[0]["s0"]); hip.buf[1][0].copy_(reps[0]["s1"])
-        for r in range(G):
-            hip.buf[hip.cur][1][pcut[r]:pcut[r + 1]] = reps[r]["lp"][pcut[r]:pcut[r + 1]]
-            hip.buf[hip.cur][2][pcut[r]:pcut[r + 1]] = reps[r]["dl"][pcut[r]:pcut[r + 1]]
-        hip.alive_row[1 - hip.ar].copy_(reps[0]["out"])
-        hip.ar = 1 - hip.ar
-        hip._rows_dirty = True
-        hip.sweep += 1
-        a_in = hip.alive_row[hip.ar]
-    assert_state_equal(hip, orc, name)
+# (S2/S3 sweeps, partition, replay: tests/test_gpu_packed.py)
 
 
 # ---------------------------------------------------------------- S4
 @pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac", "socks"])
 def test_mc_sweep_parity(oracle, name):
     N = 5000
-    spec, hip, orc, eps_target = engines(name, N, oracle=oracle)
+    spec, hip, orc, eps_target = engines(name, N, oracle=oracle, storage="classic")
     hip.init_population(); orc.init_population()
     gamma0 = 2.38 / math.sqrt(2 * spec.d)
     for gen in range(6):
@@ -466,25 +373,45 @@ def test_c_abi_error_paths():
     spec = A.ModelSpec(prior, sim, seed=1)
     eng = PopulationEngine(spec, 1000, ops=HipOps(spec))
     eng.init_population()
+    eng.reset_weights()
     ops, lib = eng.ops, eng.ops.lib
-    th, lp, dl = eng.state
-    oth, olp, odl = eng.other
+    s0, s1, lp, dl = eng.buf[0][0], eng.buf[1][0], eng.buf[eng.cur][1], eng.buf[eng.cur][2]
+    b_in, b_out = eng.bits[eng.bc], eng.bits[1 - eng.bc]
+    flags = torch.zeros(1064, dtype=torch.uint8, device="cuda")
     nacc, nsim = C.c_int64(), C.c_int64()
 
-    def swarm(n_alive=1000, r_lo=0, r_hi=1000, i0=0, n_local=1000, src=th, dst=oth):
-        return lib.abcdez_smc_swarm(ops.ctx, eng.alive_idx.data_ptr(), eng.arank.data_ptr(), n_alive, r_lo, r_hi,
-                                    src.data_ptr(), lp.data_ptr(), dl.data_ptr(), dst.data_ptr(), olp.data_ptr(),
-                                    odl.data_ptr(), 5.0, 0.5, 1e-5, i0, n_local, 0, None, 0, C.byref(nacc), C.byref(nsim))
+    def swarm(n_alive=1000, r_lo=0, r_hi=1000, out=b_out, slot1=s1, fl=flags, counters=True):
+        return lib.abcdez_smc_swarm_packed(ops.ctx, b_in.data_ptr(), out.data_ptr(), n_alive, r_lo, r_hi, s0.data_ptr(),
+                                           slot1.data_ptr(), lp.data_ptr(), dl.data_ptr(), fl.data_ptr() if fl is not None else None,
+                                           5.0, 0.5, 1e-5, 0, C.byref(nacc) if counters else None, C.byref(nsim) if counters else None)
 
-    eng.alive_compact()
     assert swarm() == 0
+    assert swarm(fl=None) == 0                                                          # flags are optional
     assert swarm(n_alive=2, r_hi=2) != 0 and b"3 alive" in lib.abcdez_last_error()       # donor loops need 3 (smc:119-126)
-    assert swarm(r_lo=5, r_hi=2) != 0 and b"rank range" in lib.abcdez_last_error()
+    assert swarm(r_lo=5, r_hi=2) != 0 and b"range" in lib.abcdez_last_error()
     assert swarm(r_hi=1001) != 0
-    assert swarm(dst=th) != 0 and b"must differ" in lib.abcdez_last_error()              # synchronous update needs two buffers
-    assert lib.abcdez_smc_swarm(ops.ctx, None, None, 1000, 0, 1000, None, None, None, None, None, None, 5.0, 0.5, 1e-5,
-                                0, 1000, 0, None, 0, C.byref(nacc), C.byref(nsim)) != 0
+    assert swarm(r_lo=32, r_hi=640) != 0 and b"multiples of 64" in lib.abcdez_last_error()   # sub-ranges own whole bitmap words
+    assert swarm(r_lo=64, r_hi=640) == 0 and swarm(r_lo=64, r_hi=1000) == 0
+    assert swarm(out=b_in) != 0 and b"must differ" in lib.abcdez_last_error()            # synchronous update: two bit arrays
+    assert swarm(slot1=s0) != 0 and b"must differ" in lib.abcdez_last_error()
+    assert swarm(counters=False) == 0                                                    # asynchronous form
+    assert lib.abcdez_smc_swarm_packed(ops.ctx, None, None, 1000, 0, 1000, None, None, None, None, None, 5.0, 0.5, 1e-5, 0,
+                                       C.byref(nacc), C.byref(nsim)) != 0
     assert b"null" in lib.abcdez_last_error()
+    assert swarm() == 0
+    assert lib.abcdez_smc_replay_packed(ops.ctx, b_in.data_ptr(), b_out.data_ptr(), 1000, 0, 1001, s0.data_ptr(), s1.data_ptr(),
+                                        lp.data_ptr(), flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) != 0
+    assert lib.abcdez_smc_replay_packed(ops.ctx, b_in.data_ptr(), b_out.data_ptr(), 1000, 0, 1000, s0.data_ptr(), s1.data_ptr(),
+                                        lp.data_ptr(), flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) == 0
+    assert nacc.value == int((flags[:1000] & 1).sum()) and nsim.value == 1000     # everything is this rank's: counted only
+    # partition: the flags must describe a prefix
+    assert lib.abcdez_smc_partition(ops.ctx, eng.alive.data_ptr(), 1000, 1000, 1001, b_in.data_ptr(), b_out.data_ptr(), s0.data_ptr(),
+                                    s1.data_ptr(), lp.data_ptr(), dl.data_ptr(), eng.wns.data_ptr()) != 0
+    eng.alive[::2] = 0                                  # 500 alive; a caller claiming n_new = 400 is caught at the next read-back
+    assert lib.abcdez_smc_partition(ops.ctx, eng.alive.data_ptr(), 1000, 1000, 400, b_in.data_ptr(), b_out.data_ptr(), s0.data_ptr(),
+                                    s1.data_ptr(), lp.data_ptr(), dl.data_ptr(), eng.wns.data_ptr()) == 0
+    assert swarm(n_alive=400, r_hi=400) != 0 and b"prefix" in lib.abcdez_last_error()
+    eng.alive.fill_(1)
     wn, es, na = C.c_double(), C.c_double(), C.c_int64()
     assert lib.abcdez_smc_reweight(ops.ctx, dl.data_ptr(), eng.wns.data_ptr(), eng.alive.data_ptr(), 1000, 1.0, -0.5,
                                    C.byref(wn), C.byref(es), C.byref(na)) != 0
@@ -507,70 +434,45 @@ def test_c_abi_error_paths():
         _lib.check(lib, -1)
     # the context still works after the errors
     assert swarm() == 0
-    # row store / sharded / blob entry points
-    rows = PopulationEngine(spec, 1000, ops=ops, storage="rows")
-    rows.init_population()
-    rows.alive_compact()
-    a_in, a_out = rows.alive_row[rows.ar], rows.alive_row[1 - rows.ar]
-    s0, s1, rlp, rdl = rows.buf[0][0], rows.buf[1][0], rows.buf[0][1], rows.buf[0][2]
-    flags = torch.zeros(1000, dtype=torch.uint8, device="cuda")
-
-    def shard(r_lo=0, r_hi=1000, out=a_out, acc=flags):
-        return lib.abcdez_smc_swarm_rows_shard(ops.ctx, a_in.data_ptr(), out.data_ptr(), 1000, r_lo, r_hi, s0.data_ptr(),
-                                               s1.data_ptr(), rlp.data_ptr(), rdl.data_ptr(),
-                                               acc.data_ptr() if acc is not None else None, 5.0, 0.5, 1e-5, 0,
-                                               C.byref(nacc), C.byref(nsim))
-
-    assert shard() == 0
-    assert shard(r_lo=7, r_hi=3) != 0 and b"rank range" in lib.abcdez_last_error()
-    assert shard(out=a_in) != 0 and b"must differ" in lib.abcdez_last_error()
-    assert shard(acc=None) != 0 and b"null" in lib.abcdez_last_error()
-    assert lib.abcdez_smc_replay_rows(ops.ctx, a_in.data_ptr(), a_out.data_ptr(), 1000, 0, 1001, s0.data_ptr(), s1.data_ptr(),
-                                      flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) != 0
-    assert lib.abcdez_smc_replay_rows(ops.ctx, a_in.data_ptr(), a_out.data_ptr(), 1000, 0, 1000, s0.data_ptr(), s1.data_ptr(),
-                                      flags.data_ptr(), 0.5, 1e-5, 0, C.byref(nacc), C.byref(nsim)) == 0
-    assert nacc.value == int((flags & 1).sum()) and nsim.value == 1000        # everything is this rank's: counted only
+    # blob entry points on a model created without blobs
     st = torch.zeros(1000, dtype=torch.int64, device="cuda")
     assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), st.data_ptr()) != 0
     assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), None) != 0
     st2 = torch.zeros_like(st)
     assert lib.abcdez_ctx_set_stamps(ops.ctx, st.data_ptr(), st2.data_ptr()) != 0 and b"n_blob = 0" in lib.abcdez_last_error()
-    assert lib.abcdez_blob_eval(ops.ctx, s0.data_ptr(), st.data_ptr(), 1000, s1.data_ptr(), rdl.data_ptr()) != 0
+    assert lib.abcdez_blob_eval(ops.ctx, s0.data_ptr(), st.data_ptr(), 1000, s1.data_ptr(), dl.data_ptr()) != 0
     assert lib.abcdez_ctx_set_stamps(ops.ctx, None, None) == 0
     host_data = np.ascontiguousarray(spec.data, dtype=np.float64)
     badblob = A.ModelSpec(prior, sim, seed=1).cstruct(host_data.ctypes.data)
     badblob.n_blob = 5                                                          # the MVN simulator's blob is d = 8 doubles
     assert lib.abcdez_ctx_create(C.byref(badblob), 0, C.byref(ctx)) != 0 and b"n_blob" in lib.abcdez_last_error()
+    # lane groups wider than 8 cannot own whole bitmap words
+    spec32 = A.ModelSpec(*models()["mvn32"][:2], seed=1)
+    e16 = PopulationEngine(spec32, 1000, ops=HipOps(spec32, lanes=16))
+    e16.init_population(); e16.reset_weights()
+    with pytest.raises(_lib.AbcdezError, match="at most 8 lanes"):
+        e16.smc_swarm(9.0, 0.3, 1e-5)
 
 
 # ---------------------------------------------------------------- blobs: stamps + rebuild, product vs C restatement
 @pytest.mark.parametrize("name,N", [("normal1d", 4000), ("mvn8", 3000), ("mvn32", 4096), ("mvn3", 1500), ("quad2d_inf", 500),
                                     ("normdu", 300), ("dirac", 200), ("mixture", 1500), ("socks", 3000)])
-@pytest.mark.parametrize("storage", ["rows", "classic"])
-def test_blobs_parity(oracle, name, N, storage):
-    """blobs=True: the stamps the HIP kernels carry and the data abcdez_blob_eval rebuilds from them equal the
-    oracle's bit for bit, for both storages and for abcdemc; the rebuilt distances equal the stored ones (checked
-    inside engine.result())."""
+def test_blobs_parity(oracle, name, N):
+    """blobs=True: the stamps the HIP kernels carry (through sweeps, partitions and resamplings) and the data
+    abcdez_blob_eval rebuilds from them equal the oracle's bit for bit, for abcdesmc and for abcdemc; the rebuilt
+    distances equal the stored ones (checked inside engine.result())."""
     import dataclasses
     prior, sim, eps = models()[name]
     sim = dataclasses.replace(sim, blobs=True)
-
-    def hip_engine(spec, n, pg):
-        return PopulationEngine(spec, n, pg, ops=HipOps(spec), storage=storage)
-
-    def orc_engine(spec, n, pg):
-        return oracle.oracle_engine(spec, n, pg, storage="classic")
-
-    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8, engine=hip_engine)
-    c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8, engine=orc_engine)
-    assert r.engine.rows_mode == (storage == "rows") and r.blobs is not None
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8)
+    c = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=11, nsims_max=10 ** 8, engine=oracle.oracle_engine)
+    assert r.engine.packed and type(r.engine.ops).__name__ == "HipOps" and r.blobs is not None
     assert r.iters == c.iters and np.array_equal(r.C, c.C, equal_nan=True)
     assert np.array_equal(r.blobs, c.blobs, equal_nan=True)
     assert same(r.engine.stamp[r.engine.cur], c.engine.stamp[c.engine.cur])
-    if storage == "classic":
-        m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=hip_engine)
-        mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=orc_engine)
-        assert np.array_equal(m.C, mo.C) and np.array_equal(m.blobs, mo.blobs)
+    m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13)
+    mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=13, engine=oracle.oracle_engine)
+    assert np.array_equal(m.C, mo.C) and np.array_equal(m.blobs, mo.blobs)
 
 
 # ---------------------------------------------------------------- randomized models: every d, mixed prior families
@@ -614,7 +516,7 @@ def test_random_models_end_to_end_parity(oracle, seed):
               Kmcmc=int(rng.integers(1, 5)), α=float(rng.uniform(0.5, 0.95)), δess=float(rng.uniform(0.2, 0.8)))
     r = A.abcdesmc(prior, sim, eps, None, **kw)
     c = A.abcdesmc(prior, sim, eps, None, engine=oracle.oracle_engine, **kw)
-    assert type(r.engine.ops).__name__ == "HipOps" and r.engine.rows_mode
+    assert type(r.engine.ops).__name__ == "HipOps" and r.engine.packed
     assert r.iters == c.iters and r.nsims == c.nsims
     assert r.logZ == c.logZ or (math.isnan(r.logZ) and math.isnan(c.logZ))
     assert list(r.ϵs) == list(c.ϵs) and np.array_equal(np.array(r.esss), np.array(c.esss), equal_nan=True)

@@ -154,13 +154,16 @@ def test_sweep_spec_equals_literal_in_law(oracle):
     alive = eng.alive.numpy().copy()
     g0 = 2.38 / math.sqrt(8)
     L, m = oracle.lib(), oracle.OracleModel(spec)
+    aidx, arank = np.zeros(N, dtype=np.uint32), np.zeros(N, dtype=np.uint32)      # the alive list of the dense restatement
+    assert L.orc_alive_compact(alive.ctypes.data, N, aidx.ctypes.data, arank.ctypes.data) == eng.n_alive
+    assert np.array_equal(aidx[:eng.n_alive], np.arange(eng.n_alive))             # partitioned: alive rank r IS position r
     acc = []
     means = []
     for tier in ("spec", "literal"):
         nth, nlp, ndl = np.zeros_like(th), np.zeros_like(lp), np.zeros_like(dl)
         nacc, nsim = C.c_int64(), C.c_int64()
         if tier == "spec":
-            L.orc_smc_swarm(m.ptr, eng.alive_idx.data_ptr(), eng.arank.data_ptr(), eng.n_alive, th.ctypes.data,
+            L.orc_smc_swarm(m.ptr, aidx.ctypes.data, arank.ctypes.data, eng.n_alive, th.ctypes.data,
                             lp.ctypes.data, dl.ctypes.data, nth.ctypes.data, nlp.ctypes.data, ndl.ctypes.data, eps, g0,
                             1e-5, 0, N, 0, C.byref(nacc), C.byref(nsim))
         else:
@@ -245,3 +248,49 @@ def test_mc_better_particle_enumeration_is_the_reference_mask(oracle, kind):
         cnt = int(np.searchsorted(sd, d[i], side="right"))
         assert cnt == int(cnt_of[i])
         assert set(order[:cnt].tolist()) == set(np.flatnonzero(d <= d[i]).tolist())
+
+
+@pytest.mark.parametrize("name", ["mvn8", "normal1d", "uniform1d", "quad2d"])
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_packed_restatement_equals_dense_driver(oracle, name, abck):
+    """two restatements of the spec against each other: the product's host driver on the oracle's PACKED population
+    (two row slots + slot bits per position, partition by swaps: orc_packed_partition / orc_smc_swarm_packed / ...)
+    and the dense C driver (plain arrays, orc_smc_partition + orc_smc_swarm) give the same run, bit for bit"""
+    cases = {
+        "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8), 2.5, 4096),
+        "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, 3000),
+        "uniform1d": (A.Uniform(-10, 10), A.Normal1D(3.0), 0.3, 2500),
+        "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 700),
+    }
+    prior, sim, eps, N = cases[name]
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, ABCk=abck, verbose=False, rng=11, nsims_max=10 ** 8,
+                   engine=oracle.oracle_engine)
+    assert r.engine.packed
+    c = oracle.run_abcdesmc(ModelSpec(prior, sim, abck, seed=11), N, eps, nsims_max=10 ** 8)
+    res = r.engine.result()
+    assert r.iters == c["iters"] and r.nsims == c["nsims"] and r.logZ == c["logZ"]
+    assert np.array_equal(np.array(r.ϵs), c["eps_hist"])
+    assert [x[0] for x in r.ranges_ϵ] == list(c["lo_hist"]) and [x[1] for x in r.ranges_ϵ] == list(c["hi_hist"])
+    for k in ("theta", "C", "Wns", "alive"):
+        assert np.array_equal(res[k], c[k]), k
+    n_alive = int(res["alive"].sum())
+    assert res["alive"][:n_alive].all() and not res["alive"][n_alive:].any()      # the alive particles are a prefix
+
+
+def test_partitioned_and_index_keeping_populations_agree_in_law(oracle):
+    """the spec relabels the particles at every reweight (orc_smc_partition); the reference keeps a particle's index
+    for life.  Same algorithm under another labelling: over seeds, log-evidence and posterior mean agree within
+    their Monte-Carlo error (and with the exact finite-eps evidence of examples/minimal_example.jl's model 1)"""
+    prior, sim = A.Normal(0, math.sqrt(10)), A.Normal1D(3.0)
+    z = {True: [], False: []}
+    mu = {True: [], False: []}
+    for seed in range(1, 13):
+        for packed in (True, False):
+            c = oracle.run_abcdesmc(ModelSpec(prior, sim, seed=seed), 4000, 0.3, packed=packed)
+            z[packed].append(c["logZ"])
+            mu[packed].append(float(c["theta"][c["alive"], 0].mean()))
+    for arr in (z, mu):
+        a, b = np.array(arr[True]), np.array(arr[False])
+        se = math.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size)
+        assert abs(a.mean() - b.mean()) < 3.5 * se
+    assert abs(np.mean(z[True]) - (-3.038051357)) < 0.03 and abs(np.mean(mu[True]) - 30 / 11) < 0.05
