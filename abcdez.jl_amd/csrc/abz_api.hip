@@ -122,37 +122,48 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ABZ_REQUIRE(ndev > 0, "ctx_create: no HIP device visible");
   ABZ_REQUIRE(device >= 0 && device < ndev, "ctx_create: device index out of range");
   ABZ_HIP_CHECK(hipSetDevice(device));
+  /* from here on every failure releases what has been allocated so far (abcdez_ctx_destroy copes with a half-built context) */
+#define ABZ_CTX_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      abz_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+      abcdez_ctx_destroy(ctx);                                                           \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
   abcdez_ctx* ctx = new abcdez_ctx();
   ctx->device = device;
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
   if (model->n_data > 0) {
-    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_data, (size_t)model->n_data * 8));
-    ABZ_HIP_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));
+    ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_data, (size_t)model->n_data * 8));
+    ABZ_CTX_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));
   }
   ctx->h_model.data = ctx->d_data;
-  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
-  ABZ_HIP_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
-  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_tables, sizeof(abz_tables)));
-  ABZ_HIP_CHECK(hipMemcpy(ctx->d_tables, &abz_tables_host, sizeof(abz_tables), hipMemcpyHostToDevice));
+  ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
+  ABZ_CTX_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
+  ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_tables, sizeof(abz_tables)));
+  ABZ_CTX_CHECK(hipMemcpy(ctx->d_tables, &abz_tables_host, sizeof(abz_tables), hipMemcpyHostToDevice));
   ctx->hot.tables = ctx->d_tables;
   ctx->hot.seed = model->seed;
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
   for (int q = 0; q < 8; ++q) ctx->hot.sim_p[q] = model->sim_p[q];
   ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.n_blob = model->n_blob;
-  ABZ_HIP_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
-  ABZ_HIP_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
+  ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
+  ABZ_CTX_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
   {   /* both min / max banks start empty: (min key, max key) = (~0, 0) */
     unsigned long long mm[2 * ABZ_MMSLOTS * 2];
     for (int k = 0; k < 2 * ABZ_MMSLOTS * 2; ++k) mm[k] = (k & 1) ? 0ull : ~0ull;
-    ABZ_HIP_CHECK(hipMemcpy(ctx->d_scal + ABZ_S_MM0, mm, sizeof(mm), hipMemcpyHostToDevice));
+    ABZ_CTX_CHECK(hipMemcpy(ctx->d_scal + ABZ_S_MM0, mm, sizeof(mm), hipMemcpyHostToDevice));
   }
-  ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
+  ABZ_CTX_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
   if (user_source) {
     const int rc = abz_jit_build(ctx, user_source);
     if (rc) { abcdez_ctx_destroy(ctx); return rc; }
   }
+#undef ABZ_CTX_CHECK
   *out = ctx;
   return 0;
 }
@@ -386,7 +397,11 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   if (rc) return rc;
   *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
   *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
-  ABZ_REQUIRE(ctx->h_scal[ABZ_S_PART_ERR] == 0, "smc_partition: the alive flags did not describe a prefix of length n_prev");
+  if (ctx->h_scal[ABZ_S_PART_ERR] != 0) {       /* reported once: the flag is cleared so that the context stays usable */
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_PART_ERR, 0, 8, ctx->stream));
+    abz_set_error("smc_partition: the alive flags did not describe a prefix of length n_prev");
+    return -1;
+  }
   return 0;
 }
 

@@ -77,12 +77,12 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   ABZ_RTC_CHECK(hiprtcGetCode(prog, code.data()));
   hiprtcDestroyProgram(&prog);
   AbzUserModule* um = new AbzUserModule();
+  ctx->user_module = um;            /* owned by the context from here on: abz_jit_destroy releases it on any failure below */
   ABZ_HIP_CHECK(hipModuleLoadData(&um->mod, code.data()));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_init, um->mod, "abz_user_init"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_mc, um->mod, "abz_user_mc"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smcp, um->mod, "abz_user_smc_packed"));
   if (has_blob) ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_blob, um->mod, "abz_user_blob_eval"));
-  ctx->user_module = um;
   return 0;
 }
 
