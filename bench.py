@@ -221,7 +221,7 @@ def cpu_baseline(A, args, cfg):
     n = args.cpu_particles or cfg["cpu_particles"]
     steps = args.cpu_steps or cfg["cpu_steps"]
     spec = A.ModelSpec(cfg["prior"], cfg["sim"], seed=1)
-    eng = O.oracle_engine(spec, n)
+    eng = O.oracle_engine(spec, n, storage=cfg["storage"])
     eng.init_population()
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     if cfg["kind"] == "mc":
@@ -264,7 +264,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
     if args_config == "lv":
         fl = lv_flops_per_update(cfg["sim"])
         ach = fl * rate / 1e12
-        return {"kernel": "smc_swarm_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+        return {"kernel": "smc_swarm_packed_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None,
                 "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per update; the row traffic "
                         "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl,
@@ -277,10 +277,10 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
         b_read, b_write, kernel = 24 * ld + 17, 8 * ld + 16, "mc_swarm_kernel"
         b_moved = 32 * ld + 16 + 12 + b_write
     else:
-        b_read, b_write, kernel = 24 * ld + 17, 8 * ld + 16, "smc_swarm_kernel"
-        # what the row store has to move per update: the reads, an accepted row + its log-prior / distance, the
-        # 4-byte entry of the next alive list
-        b_moved = b_read + acc_rate * b_write + 4
+        b_read, b_write, kernel = 24 * ld + 17, 8 * ld + 16, "smc_swarm_packed_kernel"
+        # what the packed population has to move per update: the reads, an accepted row + its log-prior / distance
+        # (the slot bits are 1/8 B per update)
+        b_moved = b_read + acc_rate * b_write
     to_gbs = lambda b: b * rate / 1e9
     ach = to_gbs(b_read)
     out = {

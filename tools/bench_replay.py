@@ -67,11 +67,11 @@ def main():
         r_hi = min(chunk, n)
         t_sw, t_rp = [], []
         for _ in range(args.reps):                           # the same sweep again and again: writes go to the other slots
+            lp1, dl1, fl1, lp2 = lp.clone(), dl.clone(), flags.clone(), lp.clone()   # scratch state, outside the timed region
             ev[0].record()
-            e.ops.smc_swarm_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp.clone(), dl.clone(), flags.clone(), eps, gamma0, 1e-5,
-                                   e.sweep, want_counts=False)
+            e.ops.smc_swarm_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp1, dl1, fl1, eps, gamma0, 1e-5, e.sweep, want_counts=False)
             ev[1].record()
-            e.ops.smc_replay_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp.clone(), flags, gamma0, 1e-5, e.sweep)
+            e.ops.smc_replay_packed(b_in, b_out, n, 0, r_hi, s0, s1, lp2, flags, gamma0, 1e-5, e.sweep)
             ev[2].record()
             torch.cuda.synchronize()
             t_sw.append(ev[0].elapsed_time(ev[1]))
@@ -82,7 +82,7 @@ def main():
         rp = min(t_rp)
         print(json.dumps({
             "gpus_emulated": G, "particles_total": N, "n_alive": n, "acceptance": nacc / n, "own_positions": r_hi,
-            "own_sweep_ms_incl_clones": min(t_sw), "replay_ms": rp, "replayed_positions": n - r_hi,
+            "own_sweep_ms": min(t_sw), "replay_ms": rp, "replayed_positions": n - r_hi,
             "replayed_accepted": acc_remote,
             "replay_GBps": (acc_remote * 32 * ld + (n - r_hi) * 1.125) / (rp * 1e-3) / 1e9 if rp > 0 else 0.0,
             "prologue_ms_replicated": min(t_pro[1:]),
