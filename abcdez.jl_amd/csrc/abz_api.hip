@@ -20,7 +20,8 @@ int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, u
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
-int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int);
+int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int, const unsigned long long*);
+int abz_launch_group_check(abcdez_ctx*, int, unsigned long long, uint32_t, double);
 int abz_launch_smc_replay_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, const uint8_t*, double, double, uint32_t);
 int abz_launch_resample_gather_packed(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, double*, double*, const double*, const double*, double*, double*, double*, uint8_t*);
 int abz_launch_packed_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
@@ -182,7 +183,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   abz_jit_destroy(ctx);
-  if (ctx->ev0) { (void)hipEventDestroy(ctx->ev0); (void)hipEventDestroy(ctx->ev1); }
+  for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
@@ -276,29 +277,31 @@ int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes)
   return 0;
 }
 
-static int read_counters(abcdez_ctx* ctx) {
+/* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
+ * end early: the later launches return at once and are not launches of the roofline figure); < 0 = all of them */
+static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   abz_fold_counters(ctx);
-  if (ctx->ev_pending) {
+  if (ran_limit == -2) ran_limit = (int)ctx->h_scal[ABZ_S_GRP_DONE];
+  const int n_ev = ctx->ev_n;
+  ctx->ev_n = 0;
+  for (int k = 0; k < n_ev && (ran_limit < 0 || k < ran_limit); ++k) {
     float ms = 0.f;
-    ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]));
     ctx->swarm_ms += (double)ms;
     ctx->swarm_launches += 1;
-    ctx->swarm_units += ctx->ev_units;
-    ctx->ev_pending = false;
+    ctx->swarm_units += ctx->ev_units[k];
   }
   return 0;
 }
 
 int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
   ABZ_REQUIRE(ctx, "set_timing: null context");
-  if (on && !ctx->ev0) {
-    ABZ_HIP_CHECK(hipEventCreate(&ctx->ev0));
-    ABZ_HIP_CHECK(hipEventCreate(&ctx->ev1));
-  }
+  if (on && !ctx->ev[0])
+    for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreate(&e));
   ctx->timing = on != 0;
-  ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_pending = false;
+  ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_n = 0;
   return 0;
 }
 
@@ -391,13 +394,58 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
               "smc_swarm_packed: a sub-range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_swarm_packed: the two slots / bit arrays must differ");
   int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
-                                       logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr);
+                                       logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr, nullptr);
   if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_packed reports totals) */
   rc = read_counters(ctx);
   if (rc) return rc;
   *nacc = (int64_t)ctx->h_scal[ABZ_S_NACC];
   *nsim = (int64_t)ctx->h_scal[ABZ_S_NSIM];
   if (ctx->h_scal[ABZ_S_PART_ERR] != 0) {       /* reported once: the flag is cleared so that the context stays usable */
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_PART_ERR, 0, 8, ctx->stream));
+    abz_set_error("smc_partition: the alive flags did not describe a prefix of length n_prev");
+    return -1;
+  }
+  return 0;
+}
+
+/* The sweeps of one generation (smc:336-353) in ONE enqueue and ONE read-back: sweep k+1 is launched behind a device-side
+ * evaluation of the early-exit test `sum(naccs) / n_alive >= Kmcmc_min` (smc:352) on the counters of sweeps 1..k, and
+ * returns at once when it holds.  Same arithmetic as the host's test (one IEEE division of exactly represented integers). */
+int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive, double* slot0, double* slot1,
+                             double* logpi, double* delta, double eps, double gamma0, double gamma_sigma, uint32_t sweep0,
+                             int32_t k_max, double kmcmc_min, int64_t* nacc, int64_t* nsim, int32_t* k_done) {
+  ABZ_REQUIRE(ctx && bits_a && bits_b && slot0 && slot1 && logpi && delta && nacc && nsim && k_done, "smc_sweeps_packed: null argument");
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE(1 <= k_max && k_max <= ABZ_GROUP_MAX, "smc_sweeps_packed: 1 <= k_max <= 16 sweeps per call");
+  ABZ_REQUIRE(slot0 != slot1 && bits_a != bits_b, "smc_sweeps_packed: the two slots / bit arrays must differ");
+  ABZ_REQUIRE(kmcmc_min >= 0.0, "smc_sweeps_packed: Kmcmc_min must not be negative");
+  const unsigned long long base_acc = ctx->cnt_prev[ABZ_C_NACC], base_sim = ctx->cnt_prev[ABZ_C_NSIM];
+  for (int k = 0; k < k_max; ++k) {
+    uint32_t* in = (k & 1) ? bits_b : bits_a;
+    uint32_t* out = (k & 1) ? bits_a : bits_b;
+    int rc = abz_launch_smc_swarm_packed(ctx, in, out, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, slot1, logpi, delta,
+                                         nullptr, eps, gamma0, gamma_sigma, sweep0 + (uint32_t)k, 1,
+                                         k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
+    if (rc) return rc;
+    rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min);
+    if (rc) return rc;
+  }
+  int rc = read_counters(ctx, -2);
+  if (rc) return rc;
+  const int done = (int)ctx->h_scal[ABZ_S_GRP_DONE];
+  ABZ_REQUIRE(1 <= done && done <= k_max, "smc_sweeps_packed: inconsistent sweep count read back");
+  unsigned long long pa = base_acc, ps = base_sim;
+  for (int k = 0; k < k_max; ++k) {
+    if (k < done) {
+      const unsigned long long ca = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k], cs = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k + 1];
+      nacc[k] = (int64_t)(ca - pa); nsim[k] = (int64_t)(cs - ps);
+      pa = ca; ps = cs;
+    } else {
+      nacc[k] = 0; nsim[k] = 0;
+    }
+  }
+  *k_done = done;
+  if (ctx->h_scal[ABZ_S_PART_ERR] != 0) {
     ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_PART_ERR, 0, 8, ctx->stream));
     abz_set_error("smc_partition: the alive flags did not describe a prefix of length n_prev");
     return -1;

@@ -11,6 +11,8 @@
 #include "abcdez_spec.h"
 #include "abz_hotmodel.h"
 
+#define ABZ_GROUP_MAX 16    /* sweeps per abcdez_smc_sweeps_packed call */
+
 struct abcdez_ctx {
   int device = 0;
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
@@ -43,10 +45,12 @@ struct abcdez_ctx {
   uint64_t* stamp_cur = nullptr;
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
-  bool timing = false, ev_pending = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  int ev_n = 0;                                   /* sweeps enqueued since the last read-back, one event pair each */
+  hipEvent_t ev[2 * ABZ_GROUP_MAX] = {nullptr};
+  long long ev_units[ABZ_GROUP_MAX] = {0};
   double swarm_ms = 0.0;
-  long long swarm_launches = 0, swarm_units = 0, ev_units = 0;
+  long long swarm_launches = 0, swarm_units = 0;
 };
 
 void abz_set_error(const std::string& msg);
@@ -89,11 +93,28 @@ enum {
   /* min / max of the distances an abcdemc sweep leaves (mc:146,163): two banks of ABZ_MMSLOTS (min key, max key)
    * pairs; a sweep reduces into one bank and resets the other for its successor                                */
   ABZ_S_MM0 = ABZ_S_CSLOT0 + ABZ_CSLOTS * ABZ_CSTRIDE,
-  ABZ_S_N = ABZ_S_MM0 + 2 * ABZ_MMSLOTS * 2
+  /* a group of sweeps enqueued behind the device-side test of smc:352 (abcdez_smc_sweeps_packed): stop flag, number of
+   * sweeps that ran, and the totals of the (nacc, nsim) counter slots after each of them                             */
+  ABZ_S_GRP_STOP = ABZ_S_MM0 + 2 * ABZ_MMSLOTS * 2,
+  ABZ_S_GRP_DONE = ABZ_S_GRP_STOP + 1,
+  ABZ_S_GRP_SNAP = ABZ_S_GRP_STOP + 2,
+  ABZ_S_N = ABZ_S_GRP_SNAP + 2 * ABZ_GROUP_MAX + 6
 };
 
 /* kernel launchers implemented across the .hip files */
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
+/* HIP-event timing of the sweep kernels: bracket a launch; the pairs are read at the next counter read-back */
+static inline int abz_time_begin(abcdez_ctx* ctx) {
+  if (!ctx->timing || ctx->ev_n >= ABZ_GROUP_MAX) return -1;
+  (void)hipEventRecord(ctx->ev[2 * ctx->ev_n], ctx->stream);
+  return ctx->ev_n;
+}
+static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
+  if (k < 0) return;
+  (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
+  ctx->ev_units[k] = units;
+  ctx->ev_n = k + 1;
+}
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t);

@@ -94,6 +94,7 @@ struct SmcPackedArgs {
   unsigned long long* cslots;   /* cumulative counter slots; (nacc, nsim) go to classes c_cls, c_cls + 1 */
   uint8_t* flags;               /* per position: bit 0 accepted, bit 1 simulated (sharded runs; may be NULL) */
   uint64_t* stamp;              /* blob stamps, in place; NULL when blobs are off */
+  const unsigned long long* stop;   /* group of sweeps: non-zero = the early exit of smc:352 held before this sweep; NULL = always run */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep, c_cls;
 };
@@ -106,6 +107,7 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
   static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
   const HotModel& M = a.hm;
+  if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
   const int j = (int)(gid % L);

@@ -32,7 +32,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
   a.stamp = ctx->stamp_cur; a.nstamp = ctx->stamp_cur ? ctx->stamp_nxt : nullptr;      /* blob stamps */
   bool ok = true;
-  if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  const int tk = abz_time_begin(ctx);
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
   } else {
@@ -40,11 +40,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
       hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
     });
   }
-  if (ctx->timing) {
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    ctx->ev_pending = true;
-    ctx->ev_units = n_local;
-  }
+  abz_time_end(ctx, tk, n_local);
   if (!ok) { abz_set_error("mc_swarm: no kernel for this (simulator, ld, lanes) combination"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;

@@ -28,8 +28,10 @@ __global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcR
 
 int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, uint32_t n_alive, uint32_t r_lo,
                                 uint32_t r_hi, double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags,
-                                double eps, double gamma0, double gsig, uint32_t sweep, int want_counts) {
+                                double eps, double gamma0, double gsig, uint32_t sweep, int want_counts,
+                                const unsigned long long* stop) {
   SmcPackedArgs a;
+  a.stop = stop;
   a.hm = ctx->hot; a.bits = bits; a.bits_out = bits_out; a.slot0 = slot0; a.slot1 = slot1; a.logpi = logpi; a.delta = delta;
   a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
   a.c_cls = want_counts ? ABZ_C_NACC : ABZ_C_DISCARD;
@@ -40,7 +42,7 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
   const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
-  if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
@@ -50,12 +52,36 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
         hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
     });
   }
-  if (ctx->timing) {
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    ctx->ev_pending = true;
-    ctx->ev_units = a.n_work;
-  }
+  abz_time_end(ctx, tk, a.n_work);
   if (!ok) { abz_set_error("smc_swarm_packed: no kernel for this (simulator, ld, lanes) combination"); return -3; }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* After sweep k of a group: totals of the (nacc, nsim) slots -> snapshot k; the test of smc:352 on the group's
+ * acceptances so far -> stop flag for the sweeps enqueued behind it.  One block. */
+__global__ __launch_bounds__(ABZ_CSLOTS) void group_check_kernel(unsigned long long* __restrict__ scal, int k,
+                                                                 unsigned long long base_acc, uint32_t n_alive, double kmin) {
+  __shared__ unsigned long long s_a[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
+  const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
+  unsigned long long va = cs[ABZ_C_NACC], vs = cs[ABZ_C_NSIM];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { va += __shfl_xor(va, o); vs += __shfl_xor(vs, o); }
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = va; s_s[threadIdx.x >> 6] = vs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (k == 0 || scal[ABZ_S_GRP_STOP] == 0ull) {
+      unsigned long long ta = 0, ts = 0;
+      for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { ta += s_a[w]; ts += s_s[w]; }
+      scal[ABZ_S_GRP_SNAP + 2 * k] = ta;
+      scal[ABZ_S_GRP_SNAP + 2 * k + 1] = ts;
+      scal[ABZ_S_GRP_DONE] = (unsigned long long)(k + 1);
+      scal[ABZ_S_GRP_STOP] = ((double)(ta - base_acc) / (double)n_alive >= kmin) ? 1ull : 0ull;   /* smc:352 */
+    }
+  }
+}
+int abz_launch_group_check(abcdez_ctx* ctx, int k, unsigned long long base_acc, uint32_t n_alive, double kmin) {
+  hipLaunchKernelGGL(group_check_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, k, base_acc, n_alive, kmin);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

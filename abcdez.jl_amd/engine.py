@@ -139,6 +139,16 @@ class HipOps:
             C.byref(nsim) if want_counts else None))
         return (nacc.value, nsim.value) if want_counts else None
 
+    SWEEPS_MAX = 16
+
+    def smc_sweeps_packed(self, bits_a, bits_b, n_alive, slot0, slot1, logpi, delta, eps, gamma0, gsig, sweep0, k_max, kmcmc_min):
+        """up to k_max sweeps behind the device-side test of smc:352 -> (naccs per sweep, nsims per sweep, Ki): ONE host sync"""
+        nacc, nsim, done = (C.c_int64 * k_max)(), (C.c_int64 * k_max)(), C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_smc_sweeps_packed(
+            self.ctx, _ptr(bits_a), _ptr(bits_b), n_alive, _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta), eps, gamma0,
+            gsig, sweep0, k_max, kmcmc_min, nacc, nsim, C.byref(done)))
+        return list(nacc[:done.value]), list(nsim[:done.value]), done.value
+
     def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_replay_packed(
@@ -585,6 +595,33 @@ class PopulationEngine:
         self.bc = 1 - self.bc
         self._delta_stale = True
         return counts                                    # global (nacc, nsim), counted from the flags
+
+    def smc_sweeps(self, eps: float, gamma0: float, gsig: float, Kmcmc: int, Kmcmc_min: float):
+        """The sweeps of one generation, `for i in 1:Kmcmc ... (sum(naccs) / n_alive >= Kmcmc_min) && break`
+        (smc:336-353) -> (naccs per sweep, nsims per sweep, Ki).  On an unsharded HIP population the whole group is one
+        library call with the test of smc:352 evaluated on the device between the sweeps (one host synchronisation);
+        otherwise one call per sweep with the test here."""
+        self._need_packed("smc_sweeps")
+        if (not self.sharded_packed and hasattr(self.ops, "smc_sweeps_packed") and Kmcmc <= self.ops.SWEEPS_MAX
+                and Kmcmc_min >= 0.0):
+            self._stream()
+            self._bind_stamps()
+            cur = self.buf[self.cur]
+            naccs, nsims, Ki = self.ops.smc_sweeps_packed(self.bits[self.bc], self.bits[1 - self.bc], self.n_alive,
+                                                          self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
+                                                          self.sweep, Kmcmc, Kmcmc_min)
+            self.sweep += Ki
+            if Ki & 1:
+                self.bc = 1 - self.bc
+            return naccs, nsims, Ki
+        naccs, nsims = [], []
+        for i in range(1, Kmcmc + 1):
+            nacc, nsim = self.smc_swarm(eps, gamma0, gsig, last=(i == Kmcmc))
+            naccs.append(nacc)
+            nsims.append(nsim)
+            if sum(naccs) / self.n_alive >= Kmcmc_min:   # smc:352
+                break
+        return naccs, nsims, len(naccs)
 
     # ------------------------------------------------------------------ S4
     def _mc_arrays(self):

@@ -225,14 +225,12 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             n_alive = nparticles
         if n_alive >= 3:               # donor draws need three alive particles (smc:119-126)
             eng.alive_compact()
-            for i in range(1, Kmcmc + 1):   # smc:336-353 (S2, S3)
-                nacc, nsim = eng.smc_swarm(ϵ, γ0, γσ, last=(i == Kmcmc))
-                naccs += nacc
-                nsims += nsim
-                updates += n_alive
-                if naccs / n_alive >= Kmcmc_min:   # smc:352
-                    Ki = i
-                    break
+            # for i in 1:Kmcmc: sweep; naccs, nsims; (naccs / n_alive >= Kmcmc_min) && (Ki = i; break)   smc:336-353 (S2, S3)
+            # -- one engine call; on the HIP population the test of :352 runs on the device between the sweeps
+            naccs_i, nsims_i, Ki = eng.smc_sweeps(ϵ, γ0, γσ, Kmcmc, Kmcmc_min)
+            naccs += sum(naccs_i)
+            nsims += sum(nsims_i)
+            updates += n_alive * Ki
         facc = naccs / (n_alive * Ki) if n_alive > 0 else math.nan   # smc:357
         ϵ_k = ϵ                        # smc:360
         if verboseout:                 # smc:362-370; ranges_ϵ gets this generation's extrema from the next prologue

@@ -91,16 +91,11 @@ class Generation:
             n_alive = e.N
             self.resamples += 1
         e.alive_compact()
-        naccs = 0
-        for i in range(1, self.Kmcmc + 1):                                                 # smc:336-353
-            nacc, nsim = e.smc_swarm(self.eps, self.gamma0, 1e-5, last=(i == self.Kmcmc))
-            naccs += nacc
-            self.nsims += nsim
-            self.updates += n_alive
-            self.sweeps += 1
-            if naccs / n_alive >= self.Kmcmc_min:
-                break
-        self.naccs += naccs
+        naccs_i, nsims_i, Ki = e.smc_sweeps(self.eps, self.gamma0, 1e-5, self.Kmcmc, self.Kmcmc_min)   # smc:336-353
+        self.naccs += sum(naccs_i)
+        self.nsims += sum(nsims_i)
+        self.updates += n_alive * Ki
+        self.sweeps += Ki
         self.eps_k = self.eps
         self.generations += 1
 

@@ -141,6 +141,17 @@ ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, ui
                                        int64_t r_lo, int64_t r_hi, double* slot0, double* slot1, double* logpi,
                                        double* delta, uint8_t* flags, double eps, double gamma0, double gamma_sigma,
                                        uint32_t sweep, int64_t* nacc, int64_t* nsim);
+/* The sweeps of ONE generation -- `for i in 1:Kmcmc ... (sum(naccs) / n_alive >= Kmcmc_min) && break`
+ * (src/abcdez_smc.jl:336-353) -- in one call and one host synchronisation: up to k_max (<= 16) sweeps over the whole
+ * prefix, numbered sweep0, sweep0 + 1, ...; sweep i reads bits_a and writes bits_b for odd i (1-based), the other way
+ * round for even i.  The early-exit test of :352 is evaluated on the device after every sweep (same IEEE division as
+ * the host's) and the sweeps enqueued behind a test that held do nothing.  Returns the per-sweep counters
+ * nacc[0 .. k_max), nsim[0 .. k_max) (zero for sweeps that did not run) and *k_done = Ki of :352; the current bit array
+ * afterwards is bits_b when *k_done is odd, bits_a when it is even.                                                */
+ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
+                                        double* slot0, double* slot1, double* logpi, double* delta, double eps,
+                                        double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,
+                                        double kmcmc_min, int64_t* nacc, int64_t* nsim, int32_t* k_done);
 ABCDEZ_API int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
                                         int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, double* logpi,
                                         const uint8_t* flags, double gamma0, double gamma_sigma, uint32_t sweep,

@@ -220,6 +220,18 @@ function smc_swarm!(e, ϵ, γ0, γσ)                                           
     e.sweep += 1; e.bc = 3 - e.bc
     (Int(nacc[]), Int(nsim[]))
 end
+# the sweeps of one generation, `for i in 1:Kmcmc ... (sum(naccs) / n_alive ≥ Kmcmc_min) && break` (smc:336-353), in one
+# call: the test of :352 runs on the device between the sweeps -> (Σnaccs, Σnsims, Ki); Kmcmc ≤ 16 per call
+function smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min)
+    nacc = zeros(Int64, Kmcmc); nsim = zeros(Int64, Kmcmc); done = Ref(Int32(0)); bind_stamps!(e)
+    check(ccall((:abcdez_smc_sweeps_packed, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Float64, Float64, Float64, UInt32, Int32, Float64, Ptr{Int64}, Ptr{Int64}, Ref{Int32}),
+                e.ctx, e.bits[e.bc], e.bits[3 - e.bc], e.n_alive, e.slot[1], e.slot[2], e.logpi[e.cur], e.delta[e.cur],
+                ϵ, γ0, γσ, e.sweep, Kmcmc, Kmcmc_min, nacc, nsim, done))
+    e.sweep += done[]; isodd(done[]) && (e.bc = 3 - e.bc)
+    (sum(nacc), sum(nsim), Int(done[]))
+end
 # P (push_p-cast, smc:382 / mc:166), Wns, C and -- with blobs on -- the simulated data behind every distance
 function download(e; packed::Bool)
     rows = devalloc(8 * e.N * e.ld); pushed = devalloc(8 * e.N * e.ld)
@@ -294,7 +306,10 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
             if n_alive > 0 && ess < ess_min                                                 # smc:323-326
                 resample!(e); ess = get_ess(e); n_alive = nparticles
             end
-            if n_alive ≥ 3
+            if n_alive ≥ 3 && Kmcmc ≤ 16
+                naccs, nsim, Ki = smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min)                # smc:336-353, one call
+                nsims += nsim
+            elseif n_alive ≥ 3
                 for i in 1:Kmcmc                                                            # smc:336-353
                     nacc, nsim = smc_swarm!(e, ϵ, γ0, γσ)
                     naccs += nacc; nsims += nsim

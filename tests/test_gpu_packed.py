@@ -223,3 +223,40 @@ def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
         e.buf[0][0].copy_(full["s0"]); e.buf[1][0].copy_(full["s1"]); cur[1].copy_(full["lp"]); cur[2].copy_(full["dl"])
         e.bits[1 - e.bc].copy_(full["b"][1])
         e.bc = 1 - e.bc
+
+
+@pytest.mark.parametrize("name", ["normal1d", "mvn32", "mvn3"])
+def test_grouped_sweeps_equal_sweep_by_sweep(oracle, name):
+    """abcdez_smc_sweeps_packed (the Kmcmc sweeps of a generation behind the device-side test of smc:352, one read-back)
+    against the oracle swept one call at a time with the test on the host: same Ki, same per-sweep counters, same
+    population -- for thresholds that stop after the first sweep, somewhere in the middle, and never"""
+    prior, sim, eps_target = models()[name]
+    N = 6000
+    spec = A.ModelSpec(prior, sim, seed=11)
+    hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    orc = PopulationEngine(spec, N, ops=oracle.OracleOps(spec), storage="packed")
+    for e in (hip, orc):
+        e.init_population()
+        e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps, eps_k, seen = math.inf, math.inf, set()
+    plan = [(3, 1.0), (1, 0.0), (4, 0.0), (5, 0.25), (16, 0.6), (2, 5.0), (3, 0.05), (7, 0.9), (3, 1.0), (6, 0.4)]
+    for gen, (K, kmin) in enumerate(plan):
+        want = orc.smc_prologue(0.9, eps, eps_target, eps_k, 0.5 * N)
+        assert hip.smc_prologue(0.9, eps, eps_target, eps_k, 0.5 * N) == want
+        eps, _, ess, n_alive, _ = want
+        if n_alive > 0 and ess < 0.5 * N:
+            hip.smc_resample(); orc.smc_resample()
+        hip.alive_compact(); orc.alive_compact()
+        got = hip.smc_sweeps(eps, g0, 1e-5, K, kmin)
+        ref = orc.smc_sweeps(eps, g0, 1e-5, K, kmin)           # OracleOps has no grouped call: the engine's host loop
+        assert got == ref, (gen, got, ref)
+        assert hip.sweep == orc.sweep and hip.bc == orc.bc
+        assert_equal(hip, orc, f"gen {gen} sweeps")
+        seen.add("first" if got[2] == 1 and K > 1 else "all" if got[2] == K else "middle")
+        eps_k = eps
+    assert seen == {"first", "all", "middle"}
+    # the single-sweep entry point still interleaves with groups (cumulative counters have one baseline)
+    assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5)
+    assert hip.smc_sweeps(eps, g0, 1e-5, 2, 9.0) == orc.smc_sweeps(eps, g0, 1e-5, 2, 9.0)
+    assert_equal(hip, orc, "mixed calls")

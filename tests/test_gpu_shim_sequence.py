@@ -118,6 +118,17 @@ class ShimEngine:
         self.bc = 1 - self.bc
         return nacc.value, nsim.value
 
+    def smc_sweeps(self, eps, g0, gs, Kmcmc, Kmcmc_min):
+        nacc, nsim, done = (C.c_int64 * Kmcmc)(), (C.c_int64 * Kmcmc)(), C.c_int32()
+        self.bind_stamps()
+        self.ck(self.lib.abcdez_smc_sweeps_packed(
+            self.ctx, self.bits[self.bc], self.bits[1 - self.bc], self.n_alive, self.slot[0], self.slot[1],
+            self.logpi[self.cur], self.delta[self.cur], eps, g0, gs, self.sweep, Kmcmc, Kmcmc_min, nacc, nsim, C.byref(done)))
+        self.sweep += done.value
+        if done.value & 1:
+            self.bc = 1 - self.bc
+        return sum(nacc), sum(nsim), done.value
+
     def count_gt(self, thr):
         c = C.c_int64()
         self.ck(self.lib.abcdez_count_gt(self.ctx, self.delta[self.cur], self.N, thr, C.byref(c)))
@@ -194,7 +205,10 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
             e.resample()
             ess = e.get_ess()
             n_alive = N
-        if n_alive >= 3:
+        if n_alive >= 3 and Kmcmc <= 16:
+            naccs, nsim, Ki = e.smc_sweeps(eps, g0, gs, Kmcmc, Kmcmc_min)
+            nsims += nsim
+        elif n_alive >= 3:
             for i in range(1, Kmcmc + 1):
                 nacc, nsim = e.smc_swarm(eps, g0, gs)
                 naccs += nacc
