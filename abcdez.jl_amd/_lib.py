@@ -56,6 +56,9 @@ PROTOTYPES = {
                         _pi64, _pi64, _pf64, _pf64],
     "abcdez_mc_generation": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _f64, _u32,
                              _pi64, _pi64, _pf64, _pf64],
+    "abcdez_mc_generation_async": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _pf64, _i32, _f64, _f64,
+                                   _u32, _pi64],
+    "abcdez_mc_generation_wait": [_vp, _i64, _pi64, _pi64, _pf64, _pf64, _pf64],
     "abcdez_push_p": [_vp, _vp, _i64, _vp],
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],

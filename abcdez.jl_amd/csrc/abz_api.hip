@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../include/abcdez_hip.h"
+#include <chrono>
 #include "abz_ctx.h"
 
 int abz_tree_sum_impl(abcdez_ctx*, const double*, int64_t, int, double*);
@@ -16,7 +17,7 @@ int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
 int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
-int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
@@ -184,6 +185,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   abz_jit_destroy(ctx);
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
@@ -277,23 +279,48 @@ int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes)
   return 0;
 }
 
+static inline double f64_from_order_key_host(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  double x; memcpy(&x, &u, 8); return x;
+}
+/* consumes up to `n` completed event pairs of the timing FIFO; only the first `count` of them are launches that did work */
+static int timing_consume(abcdez_ctx* ctx, long long n, long long count) {
+  for (long long k = 0; k < n && ctx->ev_head < ctx->ev_tail; ++k, ++ctx->ev_head) {
+    if (k >= count) continue;
+    const int slot = (int)(ctx->ev_head % ABZ_GROUP_MAX);
+    float ms = 0.f;
+    ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
+    ctx->swarm_ms += (double)ms;
+    ctx->swarm_launches += 1;
+    ctx->swarm_units += ctx->ev_units[slot];
+  }
+  return 0;
+}
+/* takes generation `t` of the asynchronous abcdemc ring (its snapshot must be complete) into the counter baseline */
+static void ring_fold(abcdez_ctx* ctx, long long t) {
+  const int slot = (int)(t % ABZ_MC_RING);
+  if (ctx->ring_folded[slot]) return;
+  const volatile unsigned long long* snap = ctx->h_ring + (size_t)slot * ABZ_RING_WORDS;
+  const unsigned long long tg = snap[0], ts = snap[1];
+  ctx->ring_res[slot][0] = (long long)(ts - ctx->cnt_prev[ABZ_C_MCSIM]);
+  ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
+  ctx->cnt_prev[ABZ_C_MCSIM] = ts;
+  ctx->cnt_prev[ABZ_C_MCGT] = tg;
+  ctx->ring_folded[slot] = true;
+}
 /* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
- * end early: the later launches return at once and are not launches of the roofline figure); < 0 = all of them */
+ * end early: the later launches return at once and are not launches of the roofline figure); -1 = all of them,
+ * -2 = the number the group reports */
 static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
   ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  /* generations still in the ring (complete: the stream was synchronised): their counters come first, their results
+   * stay redeemable */
+  for (long long t = ctx->mc_waited; t < ctx->mc_issued; ++t) ring_fold(ctx, t);
   abz_fold_counters(ctx);
   if (ran_limit == -2) ran_limit = (int)ctx->h_scal[ABZ_S_GRP_DONE];
-  const int n_ev = ctx->ev_n;
-  ctx->ev_n = 0;
-  for (int k = 0; k < n_ev && (ran_limit < 0 || k < ran_limit); ++k) {
-    float ms = 0.f;
-    ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2 * k], ctx->ev[2 * k + 1]));
-    ctx->swarm_ms += (double)ms;
-    ctx->swarm_launches += 1;
-    ctx->swarm_units += ctx->ev_units[k];
-  }
-  return 0;
+  const long long n_ev = ctx->ev_tail - ctx->ev_head;
+  return timing_consume(ctx, n_ev, ran_limit < 0 ? n_ev : ran_limit);
 }
 
 int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
@@ -301,7 +328,7 @@ int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
   if (on && !ctx->ev[0])
     for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreate(&e));
   ctx->timing = on != 0;
-  ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_n = 0;
+  ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_head = ctx->ev_tail;
   return 0;
 }
 
@@ -565,7 +592,7 @@ int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, doub
   ABZ_REQUIRE(ctx && delta && order && sorted_delta && cnt, "mc_rank_prepare: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
   ABZ_REQUIRE(eps_pop == eps_pop, "mc_rank_prepare: eps_pop is NaN");
-  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt);
+  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt, nullptr);
 }
 
 int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, int64_t N, const double* theta,
@@ -578,10 +605,11 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
   int rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
-                               eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep);
+                               eps_pop, eps_target, gamma0, gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep, nullptr);
   if (rc) return rc;
   const int bank = ctx->mm_bank;
   if (n_local > 0) ctx->mm_bank = 1 - bank;          /* the kernel reset the other bank for the next sweep */
+  ctx->mc_have_bank = (i0 == 0 && n_local == N);     /* the bank holds the extrema of the whole population */
   rc = read_counters(ctx);
   if (rc) return rc;
   *nsim = (int64_t)ctx->h_scal[ABZ_S_COUNT];
@@ -607,6 +635,83 @@ int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const 
   }
   return abcdez_mc_swarm(ctx, order, cnt, N, theta, logpi, delta, ntheta, nlogpi, ndelta, eps_pop, eps_target, gamma0,
                          gamma_sigma, 0, N, sweep, nsim, n_above_target, dmin, dmax_out);
+}
+
+/* abcdemc!'s loop body (mc:146-149) WITHOUT a host synchronisation.  The population extrema of mc:146 come from the
+ * sweep before (still on the device) unless lo_hi is given; eps_pop = max(eps_target, lo + alpha (hi - lo)) (mc:147) is
+ * evaluated on the device with the host driver's operations; then the rank pass (do_rank) and the sweep.  A snapshot of
+ * the counters and extrema is copied to pinned memory behind an event: abcdez_mc_generation_wait redeems the tickets in
+ * the order they were issued (at most ABZ_MC_RING of them in flight). */
+int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                               double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta,
+                               uint32_t* cnt, double alpha, double eps_target, const double* lo_hi, int32_t do_rank,
+                               double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket) {
+  ABZ_REQUIRE(ctx && order && sorted_delta && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && ticket,
+              "mc_generation_async: null argument");
+  ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
+  ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0 && eps_target >= 0.0, "mc_generation_async: need 0 <= alpha <= 1 and eps_target >= 0");
+  ABZ_REQUIRE(ctx->mc_issued - ctx->mc_waited < ABZ_MC_RING, "mc_generation_async: too many generations in flight (redeem a ticket first)");
+  ABZ_REQUIRE(lo_hi || ctx->mc_have_bank, "mc_generation_async: the first generation needs the population's extrema (lo_hi)");
+  if (!ctx->h_ring) {
+    ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_ring, (size_t)ABZ_MC_RING * ABZ_RING_WORDS * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_ring, 0, (size_t)ABZ_MC_RING * ABZ_RING_WORDS * 8);
+    ABZ_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
+  }
+  int rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
+  if (rc) return rc;
+  const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
+  if (do_rank) {                     /* mc:20-24 is only reached while some Ds[i] > eps */
+    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win);
+    if (rc) return rc;
+  }
+  rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
+                           gamma_sigma, 0u, (uint32_t)N, sweep, win);
+  if (rc) return rc;
+  const int slot = (int)(ctx->mc_issued % ABZ_MC_RING);
+  ctx->ring_folded[slot] = false;
+  rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull);
+  if (rc) return rc;
+  ctx->mm_bank = 1 - ctx->mm_bank;   /* the kernel reset the other bank for the next sweep */
+  ctx->mc_have_bank = true;
+  *ticket = (int64_t)ctx->mc_issued;
+  ctx->mc_issued += 1;
+  return 0;
+}
+
+/* Results of the generation `ticket` (the oldest one not yet redeemed): nsim, #(new Ds > eps_target) (mc:156), extrema of the
+ * new distances (mc:146 of the next generation, mc:163), and the eps_pop it ran with.  Waits for THAT generation only. */
+int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, int64_t* n_above_target, double* dmin,
+                              double* dmax, double* eps_pop) {
+  ABZ_REQUIRE(ctx && nsim, "mc_generation_wait: null argument");
+  ABZ_REQUIRE(ticket == (int64_t)ctx->mc_waited && ticket < (int64_t)ctx->mc_issued,
+              "mc_generation_wait: tickets are redeemed in the order they were issued");
+  const int slot = (int)(ticket % ABZ_MC_RING);
+  const volatile unsigned long long* snap = ctx->h_ring + (size_t)slot * ABZ_RING_WORDS;
+  if (!ctx->ring_folded[slot]) {
+    /* the snapshot kernel stores the ticket word last (system-scope release): poll it; a failed launch cannot hang us */
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(ctx->h_ring + (size_t)slot * ABZ_RING_WORDS + ABZ_RING_WORDS - 1, __ATOMIC_ACQUIRE) != (unsigned long long)ticket + 1ull) {
+      if ((++spins & 1023u) == 0) {
+        if (hipStreamQuery(ctx->stream) == hipSuccess &&
+            __atomic_load_n(ctx->h_ring + (size_t)slot * ABZ_RING_WORDS + ABZ_RING_WORDS - 1, __ATOMIC_ACQUIRE) != (unsigned long long)ticket + 1ull) {
+          abz_set_error("mc_generation_wait: the stream drained without the generation's snapshot"); return -2;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { abz_set_error("mc_generation_wait: timed out"); return -2; }
+      }
+    }
+  }
+  ring_fold(ctx, ticket);
+  ctx->mc_waited += 1;
+  *nsim = (int64_t)ctx->ring_res[slot][0];
+  if (n_above_target) *n_above_target = (int64_t)ctx->ring_res[slot][1];
+  if (dmin) *dmin = f64_from_order_key_host(snap[2]);
+  if (dmax) *dmax = f64_from_order_key_host(snap[3]);
+  if (eps_pop) { const unsigned long long e = snap[4]; memcpy(eps_pop, &e, 8); }
+  if (!ctx->timing) return 0;
+  ABZ_HIP_CHECK(hipEventSynchronize(ctx->ev[2 * (int)(ctx->ev_head % ABZ_GROUP_MAX) + 1]));   /* the sweep's own end event */
+  return timing_consume(ctx, 1, 1);
 }
 
 int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) {

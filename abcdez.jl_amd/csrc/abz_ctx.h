@@ -12,6 +12,8 @@
 #include "abz_hotmodel.h"
 
 #define ABZ_GROUP_MAX 16    /* sweeps per abcdez_smc_sweeps_packed call */
+#define ABZ_MC_RING 8       /* abcdemc generations in flight (abcdez_mc_generation_async) */
+#define ABZ_RING_WORDS 8    /* per generation: total #(Ds > eps_target), total nsim (cumulative), min key, max key, eps_pop, -, -, ticket + 1 */
 
 struct abcdez_ctx {
   int device = 0;
@@ -46,9 +48,17 @@ struct abcdez_ctx {
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
   bool timing = false;
-  int ev_n = 0;                                   /* sweeps enqueued since the last read-back, one event pair each */
+  long long ev_head = 0, ev_tail = 0;             /* FIFO of sweeps timed but not yet read: pair k lives in slot k % ABZ_GROUP_MAX */
   hipEvent_t ev[2 * ABZ_GROUP_MAX] = {nullptr};
   long long ev_units[ABZ_GROUP_MAX] = {0};
+  /* abcdemc generations enqueued without a host synchronisation (abcdez_mc_generation_async): a ring of pinned snapshots of
+   * the scalar area, one per generation in flight, each behind its own event; tickets are issued and redeemed in order */
+  unsigned long long* h_ring = nullptr;           /* ABZ_MC_RING x ABZ_RING_WORDS u64, pinned + mapped: written BY a kernel */
+  unsigned long long* d_ring = nullptr;           /* the same memory as the device sees it */
+  bool ring_folded[ABZ_MC_RING] = {false};
+  long long ring_res[ABZ_MC_RING][2] = {{0, 0}};  /* (nsim, #above target) once folded */
+  long long mc_issued = 0, mc_waited = 0;
+  bool mc_have_bank = false;                      /* a sweep of this context has left extrema in a bank */
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
 };
@@ -98,26 +108,34 @@ enum {
   ABZ_S_GRP_STOP = ABZ_S_MM0 + 2 * ABZ_MMSLOTS * 2,
   ABZ_S_GRP_DONE = ABZ_S_GRP_STOP + 1,
   ABZ_S_GRP_SNAP = ABZ_S_GRP_STOP + 2,
-  ABZ_S_N = ABZ_S_GRP_SNAP + 2 * ABZ_GROUP_MAX + 6
+  /* abcdemc generation enqueued without host values (abcdez_mc_generation_async): eps_pop of mc:147 (f64), the binning
+   * window of the rank pass (key of eps_pop, shift) and the extrema it was made from (f64 lo, hi)                     */
+  ABZ_S_MCW_EPS = ABZ_S_GRP_SNAP + 2 * ABZ_GROUP_MAX,
+  ABZ_S_MCW_KLO = ABZ_S_MCW_EPS + 1, ABZ_S_MCW_SHIFT = ABZ_S_MCW_EPS + 2, ABZ_S_MCW_LO = ABZ_S_MCW_EPS + 3,
+  ABZ_S_MCW_HI = ABZ_S_MCW_EPS + 4,
+  ABZ_S_N = ABZ_S_MCW_EPS + 6
 };
 
 /* kernel launchers implemented across the .hip files */
 int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 /* HIP-event timing of the sweep kernels: bracket a launch; the pairs are read at the next counter read-back */
 static inline int abz_time_begin(abcdez_ctx* ctx) {
-  if (!ctx->timing || ctx->ev_n >= ABZ_GROUP_MAX) return -1;
-  (void)hipEventRecord(ctx->ev[2 * ctx->ev_n], ctx->stream);
-  return ctx->ev_n;
+  if (!ctx->timing || ctx->ev_tail - ctx->ev_head >= ABZ_GROUP_MAX) return -1;
+  const int k = (int)(ctx->ev_tail % ABZ_GROUP_MAX);
+  (void)hipEventRecord(ctx->ev[2 * k], ctx->stream);
+  return k;
 }
 static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
   if (k < 0) return;
   (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
   ctx->ev_units[k] = units;
-  ctx->ev_n = k + 1;
+  ctx->ev_tail += 1;
 }
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
-                        uint32_t, uint32_t, uint32_t);
+                        uint32_t, uint32_t, uint32_t, const unsigned long long*);
+int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
+int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
 void abz_fold_minmax(abcdez_ctx*, int bank, double* lo, double* hi);

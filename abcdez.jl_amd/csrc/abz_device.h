@@ -398,4 +398,8 @@ __device__ inline unsigned long long f64_order_key(double x) {
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+__device__ inline double f64_from_order_key_dev(unsigned long long k) {
+  return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
+}
+
 #endif /* ABZ_DEVICE_H */

@@ -283,6 +283,7 @@ struct McSwarmArgs {
   unsigned long long* mm_cur;   /* [ABZ_MMSLOTS][2] (min key, max key) of the new distances: this sweep's bank ... */
   unsigned long long* mm_nxt;   /* ... and the bank it resets for its successor */
   double eps_pop, eps_target, gamma0, gsig;
+  const unsigned long long* eps_pop_dev;   /* non-NULL: eps_pop (f64 bits) was made on the device (mc_window_kernel) */
   uint32_t N, i0, n_local, sweep;
   const uint64_t* stamp;        /* blob stamps, both NULL when blobs are off */
   uint64_t* nstamp;
@@ -317,7 +318,8 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
 
   const double lpi = a.logpi[i];
   const double di = a.delta[i];
-  const double eps = di <= a.eps_target ? a.eps_target : a.eps_pop;       /* mc:19 */
+  const double eps_pop = a.eps_pop_dev ? abz_u2d(*a.eps_pop_dev) : a.eps_pop;
+  const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
   uint32_t s = i;
   if (di > eps) {                                                         /* mc:20-24 */
     s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, a.cnt[i])];

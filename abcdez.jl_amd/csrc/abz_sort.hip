@@ -45,8 +45,9 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const double* __res
                                                              unsigned long long klo, int shift,
                                                              uint32_t* __restrict__ key, uint32_t* __restrict__ val,
                                                              uint32_t* __restrict__ table, uint32_t ntiles,
-                                                             uint32_t rounds) {
+                                                             uint32_t rounds, const unsigned long long* __restrict__ win) {
   __shared__ uint32_t s_h[MCR_WAVES][256];
+  if (PASS == 0 && win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; shift = (int)win[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS]; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
   for (int b = lane; b < 256; b += 64) s_h[wave][b] = 0u;
@@ -127,8 +128,10 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
                                                                 uint32_t* __restrict__ val_out,
                                                                 const double* __restrict__ delta, double eps_pop,
                                                                 double* __restrict__ sorted_delta,
-                                                                uint32_t* __restrict__ cnt_of) {
+                                                                uint32_t* __restrict__ cnt_of,
+                                                                const unsigned long long* __restrict__ win) {
   __shared__ uint32_t s_run[MCR_WAVES][256];
+  if (LAST && win) eps_pop = abz_u2d(win[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
   if (tile >= ntiles) return;                         /* whole waves leave; no block-level barrier below */
@@ -230,8 +233,88 @@ static inline unsigned long long host_order_key(double x) {
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+/* The generation's eps_pop (mc:147) and the binning window of the rank pass, made ON THE DEVICE from the extrema the
+ * previous sweep left in its min / max bank (bank >= 0) or from host values (bank < 0): abcdez_mc_generation_async.
+ * eps_pop = max(eps_target, lo + alpha (hi - lo)) with the host driver's operations (two roundings, `b > a ? b : a`). */
+__global__ __launch_bounds__(64) void mc_window_kernel(unsigned long long* __restrict__ scal, int bank, double lo_h, double hi_h,
+                                                       double alpha, double eps_target) {
+  double lo = lo_h, hi = hi_h;
+  if (bank >= 0) {
+    const unsigned long long* m = scal + ABZ_S_MM0 + (size_t)bank * 2 * ABZ_MMSLOTS;
+    unsigned long long mn = m[2 * threadIdx.x], mx = m[2 * threadIdx.x + 1];      /* ABZ_MMSLOTS == 64 */
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    lo = f64_from_order_key_dev(mn);
+    hi = f64_from_order_key_dev(mx);
+  }
+  if (threadIdx.x != 0) return;
+  const double v = lo + alpha * (hi - lo);
+  const double eps_pop = v > eps_target ? v : eps_target;
+  const unsigned long long klo = f64_order_key(eps_pop);
+  unsigned long long khi = f64_order_key(hi);
+  if (!(hi > eps_pop)) khi = klo + 1ull;
+  const unsigned long long range = khi - klo;
+  int bits = 0;
+  while (bits < 64 && (range >> bits) != 0ull) ++bits;
+  unsigned long long* w = scal + ABZ_S_MCW_EPS;
+  w[0] = abz_d2u(eps_pop);
+  w[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS] = klo;
+  w[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS] = (unsigned long long)(bits > MCR_BITS ? bits - MCR_BITS : 0);
+  w[ABZ_S_MCW_LO - ABZ_S_MCW_EPS] = abz_d2u(lo);
+  w[ABZ_S_MCW_HI - ABZ_S_MCW_EPS] = abz_d2u(hi);
+}
+int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double alpha, double eps_target) {
+  static_assert(ABZ_MMSLOTS == 64, "mc_window_kernel folds one slot per lane");
+  hipLaunchKernelGGL(mc_window_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_scal, bank, lo, hi, alpha, eps_target);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* What the driver reads of a generation (mc:156, mc:146, nsims), folded on the device and written STRAIGHT into pinned
+ * host memory: totals of the two cumulative counter classes, extrema of the bank the sweep reduced into, eps_pop; the
+ * ticket word last, behind a system-scope fence -- the host polls it (no copy engine, no event, no stream synchronisation) */
+__global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(const unsigned long long* __restrict__ scal, int bank,
+                                                                 unsigned long long* __restrict__ out, unsigned long long seq) {
+  __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
+  const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
+  unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
+  unsigned long long mn = ~0ull, mx = 0ull;
+  if (threadIdx.x < ABZ_MMSLOTS) {
+    const unsigned long long* m = scal + ABZ_S_MM0 + (size_t)bank * 2 * ABZ_MMSLOTS;
+    mn = m[2 * threadIdx.x]; mx = m[2 * threadIdx.x + 1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    vg += __shfl_xor(vg, o); vs += __shfl_xor(vs, o);
+    const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { s_g[threadIdx.x >> 6] = vg; s_s[threadIdx.x >> 6] = vs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tg = 0, ts = 0;
+    for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { tg += s_g[w]; ts += s_s[w]; }
+    out[0] = tg; out[1] = ts; out[2] = mn; out[3] = mx;        /* wave 0 holds the bank's extrema */
+    out[4] = scal[ABZ_S_MCW_EPS];
+    __threadfence_system();
+    __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq) {
+  static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
+  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* win: NULL = (eps_pop, dmax_hint) are host values; else the device window mc_window_kernel wrote (the two host values are ignored) */
 int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                          uint32_t* order, double* sorted_delta, uint32_t* cnt) {
+                          uint32_t* order, double* sorted_delta, uint32_t* cnt, const unsigned long long* win) {
   const uint32_t n = (uint32_t)N;
   /* window of the binning: (eps_pop, dmax_hint] in key space -> 2^24 - 2 buckets */
   const unsigned long long klo = host_order_key(eps_pop);
@@ -258,18 +341,18 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   uint32_t* valB = order;                                /* pass 0 -> (keyB, order), pass 1 -> (keyA, valA), pass 2 -> (keyB, order) */
   const unsigned grid = (ntiles + MCR_WAVES - 1) / MCR_WAVES;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
+  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds, win);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, valB, delta, eps_pop, sorted_delta, cnt);
-  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyB, valB, table, ntiles, rounds);
+                     keyB, valB, delta, eps_pop, sorted_delta, cnt, win);
+  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyB, valB, table, ntiles, rounds, win);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyB, valB, n, table, totals, ntiles, rounds,
-                     keyA, valA, delta, eps_pop, sorted_delta, cnt);
-  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds);
+                     keyA, valA, delta, eps_pop, sorted_delta, cnt, win);
+  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds, win);
   hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
   hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, order, delta, eps_pop, sorted_delta, cnt);
+                     keyB, order, delta, eps_pop, sorted_delta, cnt, win);
   hipLaunchKernelGGL(mcr_fixup_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, st, keyB, n, order,
                      sorted_delta, cnt);
   ABZ_HIP_CHECK(hipGetLastError());

@@ -30,6 +30,7 @@ Two storages, one per driver (every array has FULL length N on every rank: a don
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional
 
 import numpy as np
@@ -222,6 +223,25 @@ class HipOps:
             _ptr(order), _ptr(sorted_delta), _ptr(cnt), eps_pop, eps_target, dmax, gamma0, gsig, sweep, C.byref(nsim),
             C.byref(ngt), C.byref(lo), C.byref(hi)))
         return nsim.value, ngt.value, lo.value, hi.value
+
+    MC_IN_FLIGHT = 8
+
+    def mc_generation_async(self, cur, nxt, order, sorted_delta, cnt, alpha, eps_target, lo_hi, do_rank, gamma0, gsig, sweep):
+        """the same without a host synchronisation (extrema / eps_pop of mc:146-147 stay on the device) -> ticket"""
+        t = C.c_int64()
+        lh = (C.c_double * 2)(*lo_hi) if lo_hi is not None else None
+        _lib.check(self.lib, self.lib.abcdez_mc_generation_async(
+            self.ctx, cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]),
+            _ptr(order), _ptr(sorted_delta), _ptr(cnt), alpha, eps_target, lh, 1 if do_rank else 0, gamma0, gsig, sweep,
+            C.byref(t)))
+        return t.value
+
+    def mc_generation_wait(self, ticket):
+        """-> (nsim, #(Ds > eps_target), min Ds, max Ds, eps_pop) of generation `ticket`; waits for that generation only"""
+        nsim, ngt, lo, hi, ep = C.c_int64(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        _lib.check(self.lib, self.lib.abcdez_mc_generation_wait(self.ctx, ticket, C.byref(nsim), C.byref(ngt), C.byref(lo),
+                                                                C.byref(hi), C.byref(ep)))
+        return nsim.value, ngt.value, lo.value, hi.value, ep.value
 
     def push_p(self, theta, out):
         _lib.check(self.lib, self.lib.abcdez_push_p(self.ctx, _ptr(theta), theta.shape[0], _ptr(out)))
@@ -680,6 +700,43 @@ class PopulationEngine:
         if dmax > eps_target:
             self.mc_rank_prepare(eps_pop, dmax)
         return self.mc_swarm(eps_pop, eps_target, gamma0, gsig)
+
+    # abcdemc!'s loop has no data-dependent exit (mc:134): generations can be ENQUEUED ahead of their results
+    def mc_generation_issue(self, alpha: float, eps_target: float, gamma0: float, gsig: float, lo_hi=None, do_rank: bool = True):
+        """Enqueue one generation (mc:146-149): eps_pop = max(eps_target, lo + alpha (hi - lo)) from the extrema of the
+        generation before -- on an unsharded HIP population they never leave the device and this call does not wait;
+        `lo_hi` = the extrema when the host has them (first generation).  Results: :meth:`mc_generation_collect`, in
+        issue order.  do_rank=False skips the rank pass (only once a collected generation reported max Ds <= eps_target)."""
+        if not hasattr(self, "_mc_pending"):
+            self._mc_pending, self._mc_last = [], None
+        if not self._collectives and hasattr(self.ops, "mc_generation_async"):
+            self._mc_arrays()
+            self._stream()
+            self._bind_stamps()
+            t = self.ops.mc_generation_async(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, alpha,
+                                             eps_target, lo_hi, do_rank, gamma0, gsig, self.sweep)
+            self.sweep += 1
+            self._swap()
+            self._mc_pending.append(("ticket", t))
+            return
+        lo, hi = lo_hi if lo_hi is not None else self._mc_last
+        v = lo + alpha * (hi - lo)
+        eps_pop = max(eps_target, v)                                                       # mc:147
+        nsim, ngt, nlo, nhi = self.mc_generation(eps_pop, eps_target, hi if do_rank else -math.inf, gamma0, gsig)
+        self._mc_last = (nlo, nhi)
+        self._mc_pending.append(("done", (nsim, ngt, nlo, nhi, eps_pop)))
+
+    def mc_generations_in_flight(self) -> int:
+        return len(getattr(self, "_mc_pending", []))
+
+    def mc_generation_collect(self):
+        """-> (nsim, #(Ds > eps_target), min Ds, max Ds, eps_pop) of the oldest generation issued and not yet collected"""
+        kind, v = self._mc_pending.pop(0)
+        if kind == "done":
+            return v
+        out = self.ops.mc_generation_wait(v)
+        self._mc_last = (out[2], out[3])
+        return out
 
     # ------------------------------------------------------------------ checkpoint / resume
     def download_state(self) -> dict:

@@ -50,17 +50,33 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     γσ = 1e-5                                                 # mc:130
     complete = 1 - eng.count_gt(ϵ_target) / nparticles        # mc:133
     ϵ_l, ϵ_h = eng.extrema()                                  # mc:146, first generation; afterwards the sweep reports them
-    while iters < generations:                                # mc:134
-        iters += 1
-        ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))          # mc:147
-        # the enumeration behind mc:23 (only while some Δ_i > ϵ_target) + abcdemc_swarm! mc:149 (S2, S4); the reductions of
-        # mc:156 and of the next generation's mc:146 ride along: one engine call, one host synchronisation
-        nsim, n_above, ϵ_l, ϵ_h = eng.mc_generation(ϵ_pop, ϵ_target, ϵ_h, γ0, γσ)
+    # abcdemc!'s loop has no data-dependent exit, so the host runs up to `ahead` generations ahead of the device: a
+    # generation is ISSUED (eps_pop of mc:147 is evaluated on the device from the extrema the sweep before left there) and its
+    # reductions (mc:156, mc:146) are COLLECTED later, in order -- the loop below is the reference's, with the log lines lagging
+    ahead = 4
+    converged = False                                         # a collected generation had ϵ_h <= ϵ_target (stays true: mc:19)
+
+    def collect():
+        nonlocal nsims, complete, ϵ_l, ϵ_h, converged
+        nsim, n_above, ϵ_l, ϵ_h, _ = eng.mc_generation_collect()
         nsims += nsim
         ncomplete = 1 - n_above / nparticles                  # mc:156
         if verbose and (ncomplete != complete or complete >= (nparticles - 1) / nparticles):
             log.info("Finished run: completion=%s nsim=%d range_ϵ=%s", ncomplete, nsims, (ϵ_l, ϵ_h))
         complete = ncomplete
+        converged = converged or ϵ_h <= ϵ_target
+
+    first = True
+    while iters < generations:                                # mc:134
+        iters += 1
+        # ϵ_pop = max(ϵ_target, ϵ_l + α (ϵ_h - ϵ_l)) mc:147; the enumeration behind mc:23 (only while some Δ_i > ϵ_target) +
+        # abcdemc_swarm! mc:149 (S2, S4); the reductions of mc:156 and of the next generation's mc:146 ride along
+        eng.mc_generation_issue(α, ϵ_target, γ0, γσ, lo_hi=(ϵ_l, ϵ_h) if first else None, do_rank=not converged)
+        first = False
+        while eng.mc_generations_in_flight() > ahead:
+            collect()
+    while eng.mc_generations_in_flight() > 0:
+        collect()
 
     conv = ϵ_h <= ϵ_target                                    # mc:163
     if verbose:

@@ -112,17 +112,32 @@ class McGeneration:
         self.lo, self.hi = eng.extrema()                                                   # mc:146 (first generation)
         self.updates = self.sweeps = self.nsims = self.generations = self.ranked = 0
         self.complete = 0.0
+        self.first, self.converged = True, False
+
+    AHEAD = 4      # abcdemc!'s loop has no data-dependent exit: the host may issue generations ahead of their results
 
     def step(self):
         e = self.e
-        eps_pop = max(self.eps_target, self.lo)                                            # mc:147 (alpha = 0)
-        self.ranked += self.hi > self.eps_target                                           # mc:23's candidate sets are built
-        nsim, n_above, self.lo, self.hi = e.mc_generation(eps_pop, self.eps_target, self.hi, self.gamma0, 1e-5)   # mc:149,156,146
-        self.nsims += nsim
+        # mc:147 (alpha = 0: eps_pop = max(eps_target, min Ds), evaluated on the device), rank pass, sweep mc:149
+        e.mc_generation_issue(0.0, self.eps_target, self.gamma0, 1e-5, lo_hi=(self.lo, self.hi) if self.first else None,
+                              do_rank=not self.converged)
+        self.first = False
+        self.ranked += not self.converged                                                  # mc:23's candidate sets are built
         self.updates += e.N
         self.sweeps += 1
         self.generations += 1
-        self.complete = 1 - n_above / e.N
+        while e.mc_generations_in_flight() > self.AHEAD:
+            self.collect()
+
+    def collect(self):
+        nsim, n_above, self.lo, self.hi, _ = self.e.mc_generation_collect()                # mc:156, mc:146
+        self.nsims += nsim
+        self.complete = 1 - n_above / self.e.N
+        self.converged = self.converged or self.hi <= self.eps_target
+
+    def flush(self):
+        while self.e.mc_generations_in_flight() > 0:
+            self.collect()
 
 
 # ---------------------------------------------------------------------------------------------- workloads
@@ -359,12 +374,16 @@ def main():
 
     for _ in range(warmup):
         gen.step()
+    if hasattr(gen, "flush"):
+        gen.flush()
     eng.ops.set_timing(True)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         gen.step()
+    if hasattr(gen, "flush"):
+        gen.flush()                     # results of the generations still in flight (abcdemc runs ahead of its read-backs)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

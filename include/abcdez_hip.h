@@ -213,6 +213,21 @@ ABCDEZ_API int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* th
                          double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta, uint32_t* cnt,
                          double eps_pop, double eps_target, double dmax, double gamma0, double gamma_sigma, uint32_t sweep,
                          int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out);
+/* The same loop body WITHOUT a host synchronisation -- abcdemc!'s loop (mc:134-161) has no data-dependent exit, so the
+ * host may run ahead of the device.  The extrema of mc:146 are taken from the sweep before, on the device (lo_hi = NULL),
+ * or from lo_hi[0..1] (first generation of a run / after anything else changed the population); eps_pop =
+ * max(eps_target, lo + alpha (hi - lo)) (mc:147) is evaluated on the device with the host driver's operations; do_rank = 0
+ * skips the rank pass (legal once a redeemed generation reported max Ds <= eps_target: converged populations stay
+ * converged and nobody draws from mc:23's sets).  *ticket numbers the generation; at most 8 may be in flight.
+ * abcdez_mc_generation_wait redeems the tickets in issue order and waits for THAT generation only: nsim, #(new Ds >
+ * eps_target) (mc:156), extrema of the new distances (mc:146, :163) and the eps_pop the generation ran with.          */
+ABCDEZ_API int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi,
+                                          const double* delta, double* ntheta, double* nlogpi, double* ndelta,
+                                          uint32_t* order, double* sorted_delta, uint32_t* cnt, double alpha,
+                                          double eps_target, const double* lo_hi, int32_t do_rank, double gamma0,
+                                          double gamma_sigma, uint32_t sweep, int64_t* ticket);
+ABCDEZ_API int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, int64_t* n_above_target,
+                                         double* dmin, double* dmax, double* eps_pop);
 
 /* T2  push_p over the population (src/abcdez_types.jl:20-23; result P, smc:382, mc:166). */
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);

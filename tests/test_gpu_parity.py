@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import abcdez_amd as A
+from abcdez_amd import _lib
 from abcdez_amd.engine import HipOps, PopulationEngine
 
 pytestmark = pytest.mark.gpu
@@ -268,6 +269,62 @@ def test_mc_sweep_parity(oracle, name):
         assert got == want                                          # (nsim, #(Ds > eps_target), min Ds, max Ds)
         assert got[1:] == (orc.count_gt(eps_target),) + orc.extrema()   # the folded-in reductions: mc:156, mc:146
         assert_state_equal(hip, orc, f"mc gen {gen}")
+
+
+@pytest.mark.parametrize("name,alpha", [("normal1d", 0.0), ("mvn8", 0.0), ("mvn8", 0.3), ("normdu", 0.0), ("dirac", 0.0)])
+def test_mc_generations_issued_ahead_equal_the_step_by_step_oracle(oracle, name, alpha):
+    """abcdez_mc_generation_async / _wait: generations enqueued AHEAD of their results (eps_pop of mc:147 and the rank
+    pass's binning window made on the device from the extrema the sweep before left there) against the oracle driven one
+    synchronous generation at a time with eps_pop computed on the host -- every generation's reductions and eps_pop, and
+    the final population, bit for bit; converged populations (do_rank = False) included"""
+    N = 3000
+    spec, hip, orc, eps_target = engines(name, N, oracle=oracle, storage="classic")
+    hip.init_population(); orc.init_population()
+    gamma0 = 2.38 / math.sqrt(2 * spec.d)
+    lo, hi = orc.extrema()
+    want, got, converged = [], [], False
+    gens = 40
+    for gen in range(gens):
+        eps_pop = max(eps_target, lo + alpha * (hi - lo))                                  # mc:147 on the host
+        nsim, ngt, lo, hi = orc.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5)
+        want.append((nsim, ngt, lo, hi, eps_pop))
+    first = hip.extrema()
+    for gen in range(gens):
+        hip.mc_generation_issue(alpha, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=not converged)
+        while hip.mc_generations_in_flight() > (gen % 7):                                  # 0 .. 6 generations ahead
+            got.append(hip.mc_generation_collect())
+            converged = converged or got[-1][3] <= eps_target
+    while hip.mc_generations_in_flight():
+        got.append(hip.mc_generation_collect())
+    assert got == want
+    assert_state_equal(hip, orc, "after the pipelined generations")
+    assert hip.sweep == orc.sweep
+    # the synchronous entry points still work afterwards (one baseline for the cumulative counters)
+    eps_pop = max(eps_target, lo)
+    assert hip.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5) == orc.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5)
+
+
+def test_mc_generation_tickets_are_bounded_and_ordered(oracle):
+    spec, hip, _, eps_target = engines("normal1d", 2000, oracle=oracle, storage="classic")
+    hip.init_population()
+    hip._mc_arrays()
+    lo_hi = hip.extrema()
+    tickets = []
+    for k in range(8):
+        tickets.append(hip.ops.mc_generation_async(hip.state, hip.other, hip.order, hip.sorted_delta, hip.rank_cnt, 0.0,
+                                                   eps_target, lo_hi if k == 0 else None, True, 0.5, 1e-5, hip.sweep))
+        hip.sweep += 1
+        hip._swap()
+    with pytest.raises(_lib.AbcdezError, match="too many generations in flight"):
+        hip.ops.mc_generation_async(hip.state, hip.other, hip.order, hip.sorted_delta, hip.rank_cnt, 0.0, eps_target, None,
+                                    True, 0.5, 1e-5, hip.sweep)
+    with pytest.raises(_lib.AbcdezError, match="in the order they were issued"):
+        hip.ops.mc_generation_wait(tickets[3])
+    n_above_sync = hip.count_gt(eps_target)            # a synchronising call in between keeps the tickets redeemable
+    res = [hip.ops.mc_generation_wait(t) for t in tickets]
+    assert res[-1][1] == n_above_sync and all(r[0] > 0 for r in res)
+    with pytest.raises(_lib.AbcdezError, match="in the order they were issued"):
+        hip.ops.mc_generation_wait(tickets[-1] + 1)
 
 
 # ---------------------------------------------------------------- whole drivers, product vs C restatement
