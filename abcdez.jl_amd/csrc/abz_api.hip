@@ -160,7 +160,9 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     for (int k = 0; k < 2 * ABZ_MMSLOTS * 2; ++k) mm[k] = (k & 1) ? 0ull : ~0ull;
     ABZ_CTX_CHECK(hipMemcpy(ctx->d_scal + ABZ_S_MM0, mm, sizeof(mm), hipMemcpyHostToDevice));
   }
-  ABZ_CTX_CHECK(hipHostMalloc((void**)&ctx->h_scal, ABZ_S_N * 8, hipHostMallocDefault));
+  ABZ_CTX_CHECK(hipHostMalloc((void**)&ctx->h_scal, (ABZ_S_N + 8) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->h_scal, 0, (ABZ_S_N + 8) * 8);
+  ABZ_CTX_CHECK(hipHostGetDevicePointer((void**)&ctx->h_scal_dev, ctx->h_scal, 0));
   if (user_source) {
     const int rc = abz_jit_build(ctx, user_source);
     if (rc) { abcdez_ctx_destroy(ctx); return rc; }
@@ -312,8 +314,7 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
  * end early: the later launches return at once and are not launches of the roofline figure); -1 = all of them,
  * -2 = the number the group reports */
 static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
-  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_N * 8, hipMemcpyDeviceToHost, ctx->stream));
-  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
   /* generations still in the ring (complete: the stream was synchronised): their counters come first, their results
    * stay redeemable */
   for (long long t = ctx->mc_waited; t < ctx->mc_issued; ++t) ring_fold(ctx, t);

@@ -26,7 +26,9 @@ struct abcdez_ctx {
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
   /* device scalars + pinned host mirror */
   unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
-  unsigned long long* h_scal = nullptr;
+  unsigned long long* h_scal = nullptr;   /* pinned + mapped: ABZ_S_N words + the sequence word of abz_publish */
+  unsigned long long* h_scal_dev = nullptr;   /* the same memory as the device sees it */
+  unsigned long long pub_seq = 0;
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -138,6 +140,10 @@ int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
 int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
+/* Read-back of the first `nwords` device scalars WITHOUT the copy engine and without a stream synchronisation: a one-block
+ * kernel writes them straight into the pinned host mirror and stores a sequence word last (system-scope release); the
+ * host polls that word.  Returns when everything enqueued before it has completed.                                  */
+int abz_publish(abcdez_ctx* ctx, int nwords);
 void abz_fold_minmax(abcdez_ctx*, int bank, double* lo, double* hi);
 int abz_jit_build(abcdez_ctx*, const char* user_source);
 void abz_jit_destroy(abcdez_ctx*);

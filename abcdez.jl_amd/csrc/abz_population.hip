@@ -7,6 +7,7 @@
  *   extrema / counts                                   (smc:286,364; mc:133,146,156,163)
  * All HBM-streaming, a few bytes per particle per generation.
  */
+#include <chrono>
 #include <string.h>
 
 #include "abz_ctx.h"
@@ -134,10 +135,35 @@ static int tree_sum_device(abcdez_ctx* ctx, TileArgs a, double* d_out, double* p
   return 0;
 }
 
-static int read_scalars(abcdez_ctx* ctx) {        /* the plain scalars only; the counter slots are read by abz_api.hip */
-  ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, ABZ_S_SCALARS * 8, hipMemcpyDeviceToHost, ctx->stream));
-  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+__global__ __launch_bounds__(ABZ_BLOCK) void publish_kernel(const unsigned long long* __restrict__ scal,
+                                                           unsigned long long* __restrict__ host, int nwords,
+                                                           unsigned long long seq) {
+  for (int k = threadIdx.x; k < nwords; k += ABZ_BLOCK) host[k] = scal[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host + ABZ_S_N, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int abz_publish(abcdez_ctx* ctx, int nwords) {
+  const unsigned long long seq = ++ctx->pub_seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(ABZ_BLOCK), 0, ctx->stream, ctx->d_scal, ctx->h_scal_dev, nwords, seq);
+  ABZ_HIP_CHECK(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(ctx->h_scal + ABZ_S_N, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 4095u) == 0) {
+      if (hipStreamQuery(ctx->stream) == hipSuccess && __atomic_load_n(ctx->h_scal + ABZ_S_N, __ATOMIC_ACQUIRE) != seq) {
+        /* the stream drained without the word (a failed launch): fall back to the copy engine so that the error surfaces */
+        ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, (size_t)nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return 0;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) { abz_set_error("read-back timed out"); return -2; }
+    }
+  }
   return 0;
+}
+static int read_scalars(abcdez_ctx* ctx) {        /* the plain scalars only; the counter slots are read by abz_api.hip */
+  return abz_publish(ctx, ABZ_S_SCALARS);
 }
 static double scal_f64(abcdez_ctx* ctx, int slot) { double v; memcpy(&v, &ctx->h_scal[slot], 8); return v; }
 

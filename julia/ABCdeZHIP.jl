@@ -350,6 +350,27 @@ function mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                             
     (Int(nsim[]), Int(above[]), lo[], hi[])
 end
 
+# abcdemc!'s loop has no data-dependent exit (mc:134): a generation is ISSUED without waiting (ϵ_pop of mc:147 and the rank pass's
+# window are made on the device from the extrema the sweep before left there; lo_hi only for the first one) and its reductions
+# are COLLECTED later, in issue order; at most 8 tickets may be outstanding
+function mc_generation_issue!(e, α, ϵ_target, γ0, γσ, lo_hi, do_rank::Bool)
+    t = Ref(Int64(0)); o = other(e); bind_stamps!(e)
+    lh = lo_hi === nothing ? C_NULL : pointer(lo_hi)
+    GC.@preserve lo_hi check(ccall((:abcdez_mc_generation_async, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Float64, Float64, Ptr{Float64}, Int32, Float64, Float64, UInt32, Ref{Int64}),
+                e.ctx, e.N, e.slot[e.cur], e.logpi[e.cur], e.delta[e.cur], e.slot[o], e.logpi[o], e.delta[o], e.order, e.sorted, e.cnt,
+                α, ϵ_target, lh, do_rank ? 1 : 0, γ0, γσ, e.sweep, t))
+    e.sweep += 1; e.cur = o
+    t[]
+end
+function mc_generation_collect!(e, ticket)
+    nsim = Ref(Int64(0)); above = Ref(Int64(0)); lo = Ref(0.0); hi = Ref(0.0); ϵ_pop = Ref(0.0)
+    check(ccall((:abcdez_mc_generation_wait, LIB), Cint, (Ptr{Cvoid}, Int64, Ref{Int64}, Ref{Int64}, Ref{Float64}, Ref{Float64}, Ref{Float64}),
+                e.ctx, ticket, nsim, above, lo, hi, ϵ_pop))
+    (Int(nsim[]), Int(above[]), lo[], hi[])
+end
+
 function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                   nparticles::Int=50, generations::Int=20, verbose=true, rng::Integer=1, parallel::Bool=false)
     α = 0.0                                                                              # mc:107
@@ -361,18 +382,24 @@ function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
         init!(e)                                                                             # mc:117-125
         nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
         complete = 1 - count_gt(e, ϵ_target) / nparticles                                    # mc:133
-        ϵ_l, ϵ_h = extrema_dev(e)                                                            # mc:146 (afterwards the sweep reports them)
-        while iters < generations                                                            # mc:134
-            iters += 1
-            ϵ_pop = max(ϵ_target, ϵ_l + α * (ϵ_h - ϵ_l))                                     # mc:147
-            ϵ_h > ϵ_target && rank_prepare!(e, ϵ_pop, ϵ_h)
-            nsim, above, ϵ_l, ϵ_h = mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                    # mc:149, :156, next :146 -- one host sync
+        ϵ_l, ϵ_h = extrema_dev(e)                                                            # mc:146 (afterwards the sweeps keep them on the device)
+        tickets = Int64[]; converged = false; ahead = 4
+        function collect!()
+            nsim, above, ϵ_l, ϵ_h = mc_generation_collect!(e, popfirst!(tickets))            # mc:156, next :146
             nsims += nsim
             ncomplete = 1 - above / nparticles                                               # mc:156
             verbose && (ncomplete != complete || complete >= (nparticles - 1) / nparticles) &&
                 (@info "Finished run:" completion = ncomplete nsim = nsims range_ϵ = (ϵ_l, ϵ_h))
             complete = ncomplete
+            converged = converged || ϵ_h <= ϵ_target                                         # stays true (mc:19): no more rank passes
         end
+        while iters < generations                                                            # mc:134
+            iters += 1
+            # ϵ_pop = max(ϵ_target, ϵ_l + α (ϵ_h - ϵ_l)) mc:147 on the device; rank pass; abcdemc_swarm! mc:149
+            push!(tickets, mc_generation_issue!(e, α, ϵ_target, γ0, γσ, iters == 1 ? [ϵ_l, ϵ_h] : nothing, !converged))
+            while length(tickets) > ahead; collect!(); end
+        end
+        while !isempty(tickets); collect!(); end
         conv = ϵ_h <= ϵ_target                                                               # mc:163
         P, _, Δs, blobs = download(e; packed=false)                                          # mc:166
         return (P = P, C = Δs, reached_ϵ = conv, blobs = blobs)                              # mc:171

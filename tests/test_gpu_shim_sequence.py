@@ -129,6 +129,25 @@ class ShimEngine:
             self.bc = 1 - self.bc
         return sum(nacc), sum(nsim), done.value
 
+    def mc_generation_issue(self, alpha, eps_target, g0, gs, lo_hi, do_rank):
+        t = C.c_int64()
+        o = self.other
+        self.bind_stamps()
+        lh = (C.c_double * 2)(*lo_hi) if lo_hi is not None else None
+        self.ck(self.lib.abcdez_mc_generation_async(
+            self.ctx, self.N, self.slot[self.cur], self.logpi[self.cur], self.delta[self.cur], self.slot[o], self.logpi[o],
+            self.delta[o], self.order, self.sorted, self.cnt, alpha, eps_target, lh, 1 if do_rank else 0, g0, gs, self.sweep,
+            C.byref(t)))
+        self.sweep += 1
+        self.cur = o
+        return t.value
+
+    def mc_generation_collect(self, ticket):
+        nsim, ngt, lo, hi, ep = C.c_int64(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        self.ck(self.lib.abcdez_mc_generation_wait(self.ctx, ticket, C.byref(nsim), C.byref(ngt), C.byref(lo), C.byref(hi),
+                                                   C.byref(ep)))
+        return nsim.value, ngt.value, lo.value, hi.value
+
     def count_gt(self, thr):
         c = C.c_int64()
         self.ck(self.lib.abcdez_count_gt(self.ctx, self.delta[self.cur], self.N, thr, C.byref(c)))
@@ -227,18 +246,20 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
     return dict(P=P, Wns=W, C=D, logZ=logZ, iters=iters, nsims=nsims, eps_hist=eps_hist, ranges=ranges, blobs=blobs)
 
 
-def shim_abcdemc(prior, sim, eps_target, N, seed, generations):
+def shim_abcdemc(prior, sim, eps_target, N, seed, generations, ahead=4):
     e = ShimEngine(prior, sim, A.IndicatorStrict0toϵ, seed, N)
     e.init()
     nsims, g0, gs = 0, 2.38 / math.sqrt(2 * e.d), 1e-5
     lo, hi = e.extrema()
-    for _ in range(generations):
-        eps_pop = max(eps_target, lo)
-        if hi > eps_target:
-            e.rank_prepare(eps_pop, hi)
-        nsim, n_above, lo, hi = e.mc_swarm(eps_pop, eps_target, g0, gs)
-        nsims += nsim
-        assert n_above == e.count_gt(eps_target) and (lo, hi) == e.extrema()
+    tickets, converged = [], False
+    for it in range(generations):
+        tickets.append(e.mc_generation_issue(0.0, eps_target, g0, gs, (lo, hi) if it == 0 else None, not converged))
+        while len(tickets) > (ahead if it < generations - 1 else 0):
+            nsim, n_above, lo, hi = e.mc_generation_collect(tickets.pop(0))
+            nsims += nsim
+            converged = converged or hi <= eps_target
+            if not tickets:                              # nothing in flight: the arrays are this generation's
+                assert n_above == e.count_gt(eps_target) and (lo, hi) == e.extrema()
     conv = hi <= eps_target
     P, _, D, _ = e.download(packed=False)
     e.close()

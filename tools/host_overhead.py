@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the wall time of a generation goes on the host side: per-call wall time of the prologue and of each sweep
 (call -> return, i.e. enqueue + device time + read-back) against the device time of the same kernels.
-    python tools/host_overhead.py [storage]"""
+    python tools/host_overhead.py [--per-sweep]"""
 import math, sys, time
 sys.path.insert(0, ".")
 import torch
@@ -10,7 +10,8 @@ from abcdez_amd.engine import HipEngine
 
 d, N = 32, 1 << 22
 spec = A.ModelSpec(A.Factored(*[A.Normal(0.0, 1.0)] * d), A.MVNormal((1.0,) * d), seed=1)
-e = HipEngine(spec, N, storage=sys.argv[1] if len(sys.argv) > 1 else "packed")
+GROUP = "--per-sweep" not in sys.argv          # default: the generation's sweeps as one call (abcdez_smc_sweeps_packed)
+e = HipEngine(spec, N, storage="packed")
 e.init_population(); e.reset_weights()
 eps, eps_k, g0 = math.inf, math.inf, 2.38 / math.sqrt(2 * d)
 T = {"prologue": 0.0, "sweep": 0.0, "compact": 0.0, "resample": 0.0}
@@ -21,19 +22,23 @@ for gen in range(40):
     if gen == 10:
         for k in T: T[k] = 0.0
         for k in n: n[k] = 0
-        e.ops.set_timing(True)
+        e.ops.set_timing("--no-timing" not in sys.argv)
         torch.cuda.synchronize(); t0 = time.perf_counter()
     eps, wnorm, ess, n_alive, _ = timed("prologue", e.smc_prologue, 0.95, eps, 6.0, eps_k, 0.5 * N)
     if ess < 0.5 * N:
         timed("resample", e.smc_resample); n_alive = N
     timed("compact", e.alive_compact)
-    for k in range(3):
-        timed("sweep", e.smc_swarm, eps, g0, 1e-5)
+    if GROUP:
+        timed("sweep", e.smc_sweeps, eps, g0, 1e-5, 3, 1.0)
+    else:
+        for k in range(3):
+            timed("sweep", e.smc_swarm, eps, g0, 1e-5)
     eps_k = eps
 torch.cuda.synchronize(); wall = time.perf_counter() - t0
 ms, launches, units = e.ops.get_timing()
+launches = max(launches, 1)
 print(f"30 generations: wall {wall*1e3/30:.3f} ms/gen; prologue {T['prologue']*1e3/n['prologue']:.3f} ms/call; "
-      f"sweep call {T['sweep']*1e3/n['sweep']:.3f} ms vs kernel {ms/launches:.3f} ms; compact {T['compact']*1e3/30:.4f} ms/gen; "
+      f"{'group of 3 sweeps' if GROUP else 'sweep'} call {T['sweep']*1e3/n['sweep']:.3f} ms vs kernel {ms/launches:.3f} ms per sweep; compact {T['compact']*1e3/30:.4f} ms/gen; "
       f"resample total {T['resample']*1e3:.3f} ms over {n.get('resample', 0)} calls")
 # cost of an empty host round trip through the library
 t = time.perf_counter()
