@@ -45,6 +45,8 @@ def profile_json(name):
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--no-pattern", action="store_true",
+                   help="do not run tools/layout_bench for roofline.pattern_ceiling (profiling runs: keeps its kernels out of the trace)")
     p.add_argument("--steps", type=int, default=None)
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--config", default="smc32", choices=sorted(CONFIGS))
@@ -314,22 +316,48 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
         out["traffic_over_moved_bytes"] = tr["total_bytes_per_update"] / b_moved
     else:
         out["traffic"] = None
-    pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json") if args_config == "smc32" and ld == 32 else None
-    if pc:
-        out["pattern_ceiling"] = {"updates_per_s": pc["updates_per_s"], "read_frac": pc["updates_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
-                                  "source": pc.get("source", f"profiles/{PROFILE_TAG}_pattern_ceiling.json"),
-                                  "what": "the sweep's memory-access pattern with all arithmetic removed (tools/layout_bench.hip), "
-                                          "same population; the exact algorithm cannot run faster on this part"}
+    if args_config == "smc32" and ld == 32:
+        what = ("the sweep's memory-access pattern with all arithmetic removed (tools/layout_bench.hip, variant P), same "
+                "population layout; the exact algorithm cannot run faster on this part")
+        live = pattern_ceiling_live(int(round(upl)), int(round(100 * acc_rate))) if PATTERN_LIVE else None
+        pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json")
+        if live:
+            out["pattern_ceiling"] = {"updates_per_s": live["particles_per_s"], "read_frac": live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
+                                      "kernel_over_ceiling": rate / live["particles_per_s"],
+                                      "source": f"measured in this run on this GPU right after the timed window: tools/layout_bench --packed "
+                                                f"{live['prefix']} {live['accepted_percent']} (prefix = mean alive count of the timed "
+                                                f"sweeps, accepted = their acceptance rate; mean of 5 x 20 launches)", "what": what}
+        elif pc:
+            out["pattern_ceiling"] = {"updates_per_s": pc["updates_per_s"], "read_frac": pc["updates_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
+                                      "source": "NOT measured in this run: " + pc.get("source", f"profiles/{PROFILE_TAG}_pattern_ceiling.json"),
+                                      "what": what}
     return out
+
+
+PATTERN_LIVE = True
+
+
+def pattern_ceiling_live(prefix, accepted_percent):
+    """runs the arithmetic-free access pattern on the same GPU (a child process; ~1 s); None if the tool is not built"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "layout_bench")
+    if not os.path.exists(exe) or prefix < 64:
+        return None
+    try:
+        r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent)], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        return None
 
 
 args_config = "smc32"
 
 
 def main():
-    global args_config
+    global args_config, PATTERN_LIVE
     args = parse()
     args_config = args.config
+    PATTERN_LIVE = not args.no_pattern and args.gpus == 1
     import torch
     import torch.distributed as dist
 

@@ -10,6 +10,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <string>
+#include <cstdlib>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int D = 32;
@@ -163,6 +165,44 @@ __global__ __launch_bounds__(256) void k_packed(const double* __restrict__ s0, c
   __syncthreads();
   if (threadIdx.x < 2) { const uint32_t w = blockIdx.x * 2 + threadIdx.x; if (w * 32 < N) bits_out[w] = bits[w] ^ s_acc[threadIdx.x]; }
 }
+// (Q) as (P), with non-temporal hints: mode bit 0 = the accepted row is stored non-temporally, bit 1 = the own row (a pure
+//     stream) is loaded non-temporally, bit 2 = the donor rows too
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(256) void k_packed_nt(const double* __restrict__ s0, const double* __restrict__ s1,
+                                                   const uint32_t* __restrict__ bits, uint32_t* __restrict__ bits_out, uint32_t N,
+                                                   double* __restrict__ w0, double* __restrict__ w1, double* __restrict__ st, int wfrac) {
+  __shared__ uint32_t s_acc[2];
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, r = gid >> 2; const int j = gid & 3;
+  if (threadIdx.x < 2) s_acc[threadIdx.x] = 0;
+  __syncthreads();
+  if (r < N) {
+    const uint32_t a = hash32(r * 2 + 1) % N, b = hash32(r * 2 + 2) % N;
+    const uint32_t bi = (bits[r >> 5] >> (r & 31)) & 1u, ba = (bits[a >> 5] >> (a & 31)) & 1u, bb = (bits[b >> 5] >> (b & 31)) & 1u;
+    const bool wr = (hash32(r * 7 + 3) % 100) < (uint32_t)wfrac;
+    double acc = st[r] + st[N + r];
+    const double* ri = (bi ? s1 : s0) + (size_t)r * D;
+    const double* ra = (ba ? s1 : s0) + (size_t)a * D;
+    const double* rb = (bb ? s1 : s0) + (size_t)b * D;
+    double* ro = (bi ? w0 : w1) + (size_t)r * D;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const d2v o = (MODE & 2) ? __builtin_nontemporal_load((const d2v*)(ri + m * 8 + 2 * j)) : *(const d2v*)(ri + m * 8 + 2 * j);
+      const d2v x = (MODE & 4) ? __builtin_nontemporal_load((const d2v*)(ra + m * 8 + 2 * j)) : *(const d2v*)(ra + m * 8 + 2 * j);
+      const d2v y = (MODE & 4) ? __builtin_nontemporal_load((const d2v*)(rb + m * 8 + 2 * j)) : *(const d2v*)(rb + m * 8 + 2 * j);
+      const d2v v = o + (x - y);
+      acc += v.x + v.y;
+      if (wr) { if (MODE & 1) __builtin_nontemporal_store(v, (d2v*)(ro + m * 8 + 2 * j)); else *(d2v*)(ro + m * 8 + 2 * j) = v; }
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    if (j == 0 && wr) {
+      st[r] = acc * 1e-300; st[N + r] = 2.0;
+      atomicOr(&s_acc[(threadIdx.x >> 2) >> 5], 1u << ((threadIdx.x >> 2) & 31));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) { const uint32_t w = blockIdx.x * 2 + threadIdx.x; if (w * 32 < N) bits_out[w] = bits[w] ^ s_acc[threadIdx.x]; }
+}
 // (B) component-major: thread per particle, component k at th[k*N + i]
 __global__ __launch_bounds__(256) void k_soa(const double* __restrict__ th, uint32_t N, double* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -195,7 +235,41 @@ __global__ __launch_bounds__(256) void k_rows_lds(const double* __restrict__ th,
   if (acc == 1.2345e300) out[i] = acc;
 }
 
-int main() {
+// --packed <prefix> <accepted %> [positions]: only variant P at that operating point, one JSON line (bench.py runs this on the
+// GPU it has just timed: the ceiling of the sweep's access pattern on THAT part, in THAT thermal state)
+static int packed_only(uint32_t N, uint32_t M, int wf) {
+  const size_t bytes = (size_t)N * D * 8;
+  double *q0, *q1, *nlp; uint32_t *bits, *bo;
+  CHECK(hipMalloc(&q0, bytes)); CHECK(hipMalloc(&q1, bytes)); CHECK(hipMemset(q0, 0, bytes)); CHECK(hipMemset(q1, 0, bytes));
+  CHECK(hipMalloc(&nlp, (size_t)N * 16)); CHECK(hipMemset(nlp, 0, (size_t)N * 16));
+  CHECK(hipMalloc(&bits, N / 8)); CHECK(hipMalloc(&bo, N / 8));
+  { std::vector<uint32_t> h(N / 32); for (uint32_t k = 0; k < N / 32; ++k) h[k] = hash32(k * 977 + 5); CHECK(hipMemcpy(bits, h.data(), N / 8, hipMemcpyHostToDevice)); }
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const unsigned grid = (unsigned)(((uint64_t)M * 4 + 255) / 256);
+  float best = 1e30f, sum = 0.f;
+  const int reps = 5, inner = 20;
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+  CHECK(hipDeviceSynchronize());
+  for (int r = 0; r < reps; ++r) {
+    CHECK(hipEventRecord(e0));
+    for (int rr = 0; rr < inner; ++rr) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= inner;
+    best = ms < best ? ms : best; sum += ms;
+  }
+  printf("{\"variant\": \"P\", \"positions\": %u, \"prefix\": %u, \"accepted_percent\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, "
+         "\"particles_per_s\": %.4e, \"particles_per_s_best\": %.4e}\n", N, M, wf, sum / reps, best, M / (sum / reps * 1e-3), M / (best * 1e-3));
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4 && std::string(argv[1]) == "--packed") {
+    const uint32_t M = (uint32_t)strtoul(argv[2], nullptr, 10);
+    const int wf = atoi(argv[3]);
+    const uint32_t NN = argc >= 5 ? (uint32_t)strtoul(argv[4], nullptr, 10) : (1u << 22);
+    if (M < 64 || M > NN || (NN & 31u) || wf < 0 || wf > 100) { printf("bad arguments\n"); return 2; }
+    return packed_only(NN, M, wf);
+  }
   const uint32_t N = 1u << 22;
   const size_t bytes = (size_t)N * D * 8;
   double *th, *out;
@@ -255,6 +329,24 @@ int main() {
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
         printf("{\"variant\": \"%s\", \"ms\": %.4f, \"useful_GBps\": %.1f, \"particles_per_s\": %.4e}\n", name, ms, (double)M * 768 / ms / 1e6, M / (ms * 1e-3));
       }
+    }
+    {
+      const uint32_t M = 3u * (N / 4);
+      auto runq = [&](const char* nm, auto kern) {
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(M * 4 / 256), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, 15);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int rr = 0; rr < 20; ++rr) hipLaunchKernelGGL(kern, dim3(M * 4 / 256), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, 15);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+        printf("{\"variant\": \"Q packed, prefix 3/4 N, 15%% accepted, %s\", \"ms\": %.4f, \"particles_per_s\": %.4e}\n", nm, ms, M / (ms * 1e-3));
+      };
+      runq("plain loads and stores", k_packed_nt<0>);
+      runq("non-temporal row stores", k_packed_nt<1>);
+      runq("non-temporal own-row loads", k_packed_nt<2>);
+      runq("non-temporal own-row loads + row stores", k_packed_nt<3>);
+      runq("non-temporal donor loads", k_packed_nt<4>);
+      runq("all non-temporal", k_packed_nt<7>);
     }
     CHECK(hipFree(q0)); CHECK(hipFree(q1)); CHECK(hipFree(bits)); CHECK(hipFree(bo));
   }

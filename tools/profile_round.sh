@@ -15,8 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py --config $CFG > $R/gpurun_out/${TAG}_${CFG}_bench.log 2>&1
 MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG bash $R/tools/profile_config.sh
 if [ "${PMC:-0}" = "1" ]; then
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --steps 6 --warmup 2 > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --steps 6 --warmup 2 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > /dev/null 2>&1
   FC=$(find $R/gpurun_out/pmc_fetch_$CFG -name '*counter_collection.csv' | head -1)
   WC=$(find $R/gpurun_out/pmc_write_$CFG -name '*counter_collection.csv' | head -1)
   ACC=$(python3 -c "import json,sys;[print(json.loads(l)['roofline'].get('acceptance_rate',0)) for l in open('$R/gpurun_out/${TAG}_${CFG}_bench.log') if l.startswith('{')]" | tail -1)
