@@ -138,6 +138,18 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->device = device;
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
+  /* every real dimension a continuous Normal: the sweeps run the two-instruction log-density instead of the family
+   * dispatch (same arithmetic).  Padding dimensions get an all-zero descriptor: the Normal formula then yields +0.0 for them */
+  ctx->prior_plain = true;
+  for (int k = 0; k < ABZ_MAX_D; ++k) {
+    abz_prior_dim& pd = ctx->h_model.prior[k];
+    if (k < model->d) {
+      if (pd.family != ABZ_PRIOR_NORMAL || pd.discrete) ctx->prior_plain = false;
+    } else if (k < model->ld) {
+      if (pd.family != ABZ_PRIOR_PAD) ctx->prior_plain = false;
+      else { pd.discrete = 0; pd.p0 = pd.p1 = pd.c0 = pd.c1 = 0.0; }
+    }
+  }
   if (model->n_data > 0) {
     ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_data, (size_t)model->n_data * 8));
     ABZ_CTX_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));

@@ -24,6 +24,7 @@ struct abcdez_ctx {
   double* d_data = nullptr;
   abz_tables* d_tables = nullptr;
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
+  bool prior_plain = false;       /* all real dimensions continuous Normal priors (abz_api.hip)                 */
   /* device scalars + pinned host mirror */
   unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
   unsigned long long* h_scal = nullptr;   /* pinned + mapped: ABZ_S_N words + the sequence word of abz_publish */

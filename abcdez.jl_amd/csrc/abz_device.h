@@ -148,15 +148,24 @@ __device__ inline double group_tree_sum(const double (&x)[C]) {
 }
 
 /* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */
-template <int L, int C>
+/* PLAIN: every real dimension is a continuous Normal and the padding descriptors are all-zero (abcdez_ctx_create checks):
+ * push_p is the identity and the log-density is abz_prior_logpdf1's Normal branch without the family dispatch -- the
+ * same operations, so the same bits (tests/test_gpu_packed.py compares both against the oracle's generic evaluation) */
+template <int L, int C, bool PLAIN = false>
 __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entries */, int j, const double (&p)[C],
                                         double (&pp)[C]) {
   double lp[C];
 #pragma unroll
   for (int q = 0; q < C; ++q) {
     const abz_prior_dim* d = &pd[Lay<L, C>::comp(j, q / 2, q & 1)];
-    pp[q] = abz_push_p(d, p[q]);
-    lp[q] = abz_prior_logpdf1(d, pp[q]);
+    if constexpr (PLAIN) {
+      pp[q] = p[q];
+      const double z = (p[q] - d->p0) * d->c1;
+      lp[q] = abz_fma(-0.5 * z, z, d->c0);
+    } else {
+      pp[q] = abz_push_p(d, p[q]);
+      lp[q] = abz_prior_logpdf1(d, pp[q]);
+    }
   }
   return group_tree_sum<L, C>(lp);
 }
@@ -341,34 +350,53 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
  * the group in ONE pass of the instruction stream (the purpose tag is the only difference),
  * the Box-Muller radius of the jitter and the accept test share one log evaluation, and the
  * results are broadcast inside the group.  Same values as the straightforward evaluation. */
+/* In two steps, so that a kernel can issue the donors' loads before the sampler tables are staged: words() is pure
+ * integer work (Philox + the donor ranks), finish() the table-driven part (jitter normal, log of the accept uniform). */
+template <int L>
+struct ParticleDraws {
+  abz_u64x2 w, wa;        /* L >= 4: w = this lane's block (donor | jitter | accept); L < 4: w = jitter block, wa = accept block */
+  __device__ inline void words(uint64_t seed, uint32_t i, uint32_t sweep, int j, uint32_t n_pool, uint32_t ri, uint32_t* ra,
+                               uint32_t* rb) {
+    if constexpr (L >= 4) {
+      const uint32_t purpose = j == 0 ? (uint32_t)ABZ_RNG_DONOR : (j == 1 ? (uint32_t)ABZ_RNG_JITTER : (uint32_t)ABZ_RNG_ACCEPT);
+      w = abz_rng(seed, i, sweep, 0, purpose);
+      uint32_t a_, b_;
+      abz_donor_ranks(w, n_pool, ri, &a_, &b_);                 /* meaningful on lane 0 */
+      *ra = __shfl(a_, 0, L);
+      *rb = __shfl(b_, 0, L);
+    } else {
+      abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), n_pool, ri, ra, rb);
+      w = abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER);
+      wa = abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT);
+    }
+  }
+  __device__ inline void finish(const abz_tables* T, double gamma0, double gsig, double* g, double* log_u) const {
+    if constexpr (L >= 4) {
+      const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
+      double sn, cs;
+      abz_sincos2pi_tab(abz_u01_52(w.w1), T, &sn, &cs);
+      const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
+      const double g_ = gamma0 * (1.0 + z0 * gsig);
+      *g = __shfl(g_, 1, L);
+      *log_u = __shfl(lg, 2, L);
+    } else {
+      double z0, z1;
+      abz_normal_pair(w, T, &z0, &z1);
+      *g = gamma0 * (1.0 + z0 * gsig);
+      /* the SAME function as the L >= 4 branch and the oracle (abz_log_tab): the accept variate must not
+       * depend on the lane shape -- the polynomial abz_log differs from it in ~19 % of arguments by an ulp */
+      *log_u = abz_log_tab(abz_u01_open(wa.w0), T);
+    }
+  }
+};
 template <int L>
 __device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32_t i, uint32_t sweep, int j,
                                       uint32_t n_pool, uint32_t ri,
                                       double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g,
                                       double* log_u) {
-  if constexpr (L >= 4) {
-    const uint32_t purpose = j == 0 ? (uint32_t)ABZ_RNG_DONOR : (j == 1 ? (uint32_t)ABZ_RNG_JITTER : (uint32_t)ABZ_RNG_ACCEPT);
-    const abz_u64x2 w = abz_rng(seed, i, sweep, 0, purpose);
-    uint32_t a_, b_;
-    abz_donor_ranks(w, n_pool, ri, &a_, &b_);                 /* meaningful on lane 0 */
-    const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
-    double sn, cs;
-    abz_sincos2pi_tab(abz_u01_52(w.w1), T, &sn, &cs);
-    const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
-    const double g_ = gamma0 * (1.0 + z0 * gsig);
-    *ra = __shfl(a_, 0, L);
-    *rb = __shfl(b_, 0, L);
-    *g = __shfl(g_, 1, L);
-    *log_u = __shfl(lg, 2, L);
-  } else {
-    abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), n_pool, ri, ra, rb);
-    double z0, z1;
-    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), T, &z0, &z1);
-    *g = gamma0 * (1.0 + z0 * gsig);
-    /* the SAME function as the L >= 4 branch and the oracle (abz_log_tab): the accept variate must not
-     * depend on the lane shape -- the polynomial abz_log differs from it in ~19 % of arguments by an ulp */
-    *log_u = abz_log_tab(abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), T);
-  }
+  ParticleDraws<L> d;
+  d.words(seed, i, sweep, j, n_pool, ri, ra, rb);
+  d.finish(T, gamma0, gsig, g, log_u);
 }
 
 /* ---- block-level integer counters: wave ballot -> LDS -> two agent-scope atomic ADDS per block into one of

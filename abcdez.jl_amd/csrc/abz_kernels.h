@@ -101,7 +101,7 @@ struct SmcPackedArgs {
 
 __device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
 
-template <int SIM, int L, int C>
+template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
   constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
@@ -117,32 +117,35 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   __shared__ ModelLds<LD> s_model;
   __shared__ uint32_t s_acc[PB / 32];
 
-  /* own row + state */
-  const uint32_t bi = packed_bit(a.bits, ri);
-  double ti[C];
-  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+  /* Order of issue = order of need.  Nothing below waits for the model tables before the rows are on their way:
+   *   slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot bits   (one L2 round trip)
+   *   the three rows, log-prior, distance                                                                (one HBM round trip)
+   *   meanwhile: tables staged in LDS, gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145)              */
+  ModelStage<SIM, LD> stage;
+  stage.load(M);
+  const uint32_t wi = a.bits[ri >> 5];
+  ParticleDraws<L> draws;
+  uint32_t ra, rb;
+  draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
+  const uint32_t wa = a.bits[ra >> 5], wb = a.bits[rb >> 5];
   const double lpi = a.logpi[ri];
   const double dli = a.delta[ri];
-  ModelStage<SIM, LD> stage;                 /* model tables: loads in flight with the row loads */
-  stage.load(M);
   if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
-
-  /* donors a, b (smc:119-126), gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
-  stage.store(s_model);
-  __syncthreads();                                                /* sampler + model tables staged */
-  uint32_t ra, rb;
-  double g, log_u;
-  particle_draws<L>(&s_model.tab, M.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
-  const uint32_t ba = packed_bit(a.bits, ra), bb = packed_bit(a.bits, rb);
-  double ta[C], tb[C];
+  const uint32_t bi = (wi >> (ri & 31u)) & 1u, ba = (wa >> (ra & 31u)) & 1u, bb = (wb >> (rb & 31u)) & 1u;
+  double ti[C], ta[C], tb[C];
+  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
   load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
   load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged */
+  double g, log_u;
+  draws.finish(&s_model.tab, a.gamma0, a.gsig, &g, &log_u);
 
   double tp[C], pp[C];
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);   /* smc:134 */
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);   /* smc:134 */
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   bool acc = false;
   double dp = dli;

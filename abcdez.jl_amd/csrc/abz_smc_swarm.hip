@@ -17,9 +17,9 @@
 #include "abz_kernels.h"
 
 /* ================================================================ packed population (abz_kernels.h) */
-template <int SIM, int L, int C>
+template <int SIM, int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_packed_kernel(const SmcPackedArgs a) {
-  smc_swarm_packed_body<SIM, L, C>(a);
+  smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
 template <int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcReplayPackedArgs a) {
@@ -48,8 +48,12 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
     if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
-      if constexpr (LL() <= 8)
-        hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      if constexpr (LL() <= 8) {
+        if (ctx->prior_plain)
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+        else
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      }
     });
   }
   abz_time_end(ctx, tk, a.n_work);
