@@ -190,7 +190,7 @@ struct SmcReplayPackedArgs {
   uint32_t n_alive, skip_lo, skip_hi, sweep;
 };
 
-template <int L, int C>
+template <int L, int C, bool PLAIN = false>
 __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
   constexpr int LD = L * C;
   __shared__ ModelLds<LD> s_model;
@@ -260,7 +260,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
-    const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                       /* what the owner stored, smc:147 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);                /* what the owner stored, smc:147 */
     if (on) {
       store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
       if (j == 0) {
@@ -301,7 +301,7 @@ __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_
   return lo;
 }
 
-template <int SIM, int L, int C>
+template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   constexpr int LD = L * C;
   const HotModel& M = a.hm;
@@ -343,7 +343,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C>(s_model.prior, j, tp, pp);                     /* mc:41 */
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);              /* mc:41 */
   const double w_prior = lp - lpi;                                        /* mc:42 */
   const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
   double mn = w_prior < 0.0 ? w_prior : 0.0;

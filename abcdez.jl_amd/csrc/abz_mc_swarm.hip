@@ -10,9 +10,9 @@
 #include "abz_dispatch.h"
 #include "abz_kernels.h"
 
-template <int SIM, int L, int C>
+template <int SIM, int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a) {
-  mc_swarm_kernel_body<SIM, L, C>(a);
+  mc_swarm_kernel_body<SIM, L, C, PLAIN>(a);
 }
 
 int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, uint32_t N,
@@ -38,7 +38,10 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
     if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
-      hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      if (ctx->prior_plain)
+        hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
     });
   }
   abz_time_end(ctx, tk, n_local);

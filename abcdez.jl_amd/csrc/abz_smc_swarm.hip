@@ -17,13 +17,18 @@
 #include "abz_kernels.h"
 
 /* ================================================================ packed population (abz_kernels.h) */
+#ifndef ABZ_SWEEP_WAVES
+#define ABZ_SWEEP_WAVES_ATTR
+#else
+#define ABZ_SWEEP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ABZ_SWEEP_WAVES, ABZ_SWEEP_WAVES)))
+#endif
 template <int SIM, int L, int C, bool PLAIN>
-__global__ __launch_bounds__(ABZ_BLOCK) void smc_swarm_packed_kernel(const SmcPackedArgs a) {
+__global__ __launch_bounds__(ABZ_BLOCK) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
   smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
-template <int L, int C>
+template <int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcReplayPackedArgs a) {
-  smc_replay_packed_body<L, C>(a);
+  smc_replay_packed_body<L, C, PLAIN>(a);
 }
 
 int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, uint32_t n_alive, uint32_t r_lo,
@@ -100,7 +105,10 @@ int abz_launch_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t
   a.gamma0 = gamma0; a.gsig = gsig; a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_hi = skip_hi; a.sweep = sweep;
   const unsigned nblocks = (unsigned)(((uint64_t)n_alive + ABZ_REPLAY_CHUNK - 1) / ABZ_REPLAY_CHUNK);
   bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
-    hipLaunchKernelGGL((smc_replay_packed_kernel<LL(), CC()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+    if (ctx->prior_plain)
+      hipLaunchKernelGGL((smc_replay_packed_kernel<LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((smc_replay_packed_kernel<LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
   });
   if (!ok) { abz_set_error("smc_replay_packed: unsupported layout"); return -3; }
   ABZ_HIP_CHECK(hipGetLastError());

@@ -318,7 +318,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
         out["traffic"] = None
     if args_config == "smc32" and ld == 32:
         what = ("the sweep's memory-access pattern with all arithmetic removed (tools/layout_bench.hip, variant P), same "
-                "population layout; the exact algorithm cannot run faster on this part")
+                "population layout: a reference point, not a strict bound -- its rate depends on how many waves are in flight")
         live = pattern_ceiling_live(int(round(upl)), int(round(100 * acc_rate))) if PATTERN_LIVE else None
         pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json")
         if live:
@@ -326,7 +326,8 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
                                       "kernel_over_ceiling": rate / live["particles_per_s"],
                                       "source": f"measured in this run on this GPU right after the timed window: tools/layout_bench --packed "
                                                 f"{live['prefix']} {live['accepted_percent']} (prefix = mean alive count of the timed "
-                                                f"sweeps, accepted = their acceptance rate; mean of 5 x 20 launches)", "what": what}
+                                                f"sweeps, accepted = their acceptance rate; mean of 5 x 20 launches; best of four occupancy "
+                                                f"caps: {live['waves_per_simd_cap'] or 8} waves per SIMD)", "what": what}
         elif pc:
             out["pattern_ceiling"] = {"updates_per_s": pc["updates_per_s"], "read_frac": pc["updates_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
                                       "source": "NOT measured in this run: " + pc.get("source", f"profiles/{PROFILE_TAG}_pattern_ceiling.json"),
@@ -343,11 +344,17 @@ def pattern_ceiling_live(prefix, accepted_percent):
     exe = os.path.join(ROOT, "tools", "layout_bench")
     if not os.path.exists(exe) or prefix < 64:
         return None
-    try:
-        r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent)], capture_output=True, text=True, timeout=120)
-        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
-    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-        return None
+    best = None
+    for cap in (0, 5, 4, 3):        # the pattern itself runs fastest at 4 waves per SIMD (fewer streams in flight): take the best
+        try:
+            r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent), str(1 << 22), str(cap)], capture_output=True,
+                               text=True, timeout=120)
+            v = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+        except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+            v = None
+        if v and (best is None or v["particles_per_s"] > best["particles_per_s"]):
+            best = v
+    return best
 
 
 args_config = "smc32"

@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256) void k_rows_lds(const double* __restrict__ th,
 
 // --packed <prefix> <accepted %> [positions]: only variant P at that operating point, one JSON line (bench.py runs this on the
 // GPU it has just timed: the ceiling of the sweep's access pattern on THAT part, in THAT thermal state)
-static int packed_only(uint32_t N, uint32_t M, int wf) {
+static int packed_only(uint32_t N, uint32_t M, int wf, int occ = 0) {
+  // occ > 0: at most `occ` blocks (= waves per SIMD) resident per CU, enforced with dynamic LDS the kernel never touches
+  const size_t dyn_lds = occ > 0 ? (size_t)(160 * 1024 / occ - 1024) / 256 * 256 : 0;
+  if (dyn_lds > 64 * 1024) CHECK(hipFuncSetAttribute((const void*)k_packed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   const size_t bytes = (size_t)N * D * 8;
   double *q0, *q1, *nlp; uint32_t *bits, *bo;
   CHECK(hipMalloc(&q0, bytes)); CHECK(hipMalloc(&q1, bytes)); CHECK(hipMemset(q0, 0, bytes)); CHECK(hipMemset(q1, 0, bytes));
@@ -248,17 +251,17 @@ static int packed_only(uint32_t N, uint32_t M, int wf) {
   const unsigned grid = (unsigned)(((uint64_t)M * 4 + 255) / 256);
   float best = 1e30f, sum = 0.f;
   const int reps = 5, inner = 20;
-  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+  for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), dyn_lds, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
   CHECK(hipDeviceSynchronize());
   for (int r = 0; r < reps; ++r) {
     CHECK(hipEventRecord(e0));
-    for (int rr = 0; rr < inner; ++rr) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), 0, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+    for (int rr = 0; rr < inner; ++rr) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), dyn_lds, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= inner;
     best = ms < best ? ms : best; sum += ms;
   }
-  printf("{\"variant\": \"P\", \"positions\": %u, \"prefix\": %u, \"accepted_percent\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, "
-         "\"particles_per_s\": %.4e, \"particles_per_s_best\": %.4e}\n", N, M, wf, sum / reps, best, M / (sum / reps * 1e-3), M / (best * 1e-3));
+  printf("{\"variant\": \"P\", \"positions\": %u, \"prefix\": %u, \"accepted_percent\": %d, \"waves_per_simd_cap\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, "
+         "\"particles_per_s\": %.4e, \"particles_per_s_best\": %.4e}\n", N, M, wf, occ, sum / reps, best, M / (sum / reps * 1e-3), M / (best * 1e-3));
   return 0;
 }
 
@@ -268,7 +271,7 @@ int main(int argc, char** argv) {
     const int wf = atoi(argv[3]);
     const uint32_t NN = argc >= 5 ? (uint32_t)strtoul(argv[4], nullptr, 10) : (1u << 22);
     if (M < 64 || M > NN || (NN & 31u) || wf < 0 || wf > 100) { printf("bad arguments\n"); return 2; }
-    return packed_only(NN, M, wf);
+    return packed_only(NN, M, wf, argc >= 6 ? atoi(argv[5]) : 0);
   }
   const uint32_t N = 1u << 22;
   const size_t bytes = (size_t)N * D * 8;
