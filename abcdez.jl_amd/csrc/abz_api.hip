@@ -138,9 +138,9 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->device = device;
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
-  /* every real dimension a continuous Normal: the sweeps run the two-instruction log-density instead of the family
-   * dispatch (same arithmetic).  Padding dimensions get an all-zero descriptor: the Normal formula then yields +0.0 for them */
-  ctx->prior_plain = true;
+  /* every dimension of the row a continuous Normal (d == ld, no padding): the sweeps run the two-instruction log-density
+   * instead of the family dispatch and the MVN simulator drops its padding selects (same arithmetic) */
+  ctx->prior_plain = model->d == model->ld;
   for (int k = 0; k < ABZ_MAX_D; ++k) {
     abz_prior_dim& pd = ctx->h_model.prior[k];
     if (k < model->d) {

@@ -193,7 +193,8 @@ __device__ double abz_user_dist(const double* theta, int d, const double* data, 
 __device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data, const double* sim_p,
                               abz_user_rng& rng, double* blob, int n_blob);
 
-template <int SIM, int L, int C, bool BLOB = false>
+/* FULL: d == ld (no padding components), so the MVN simulator skips its `k < d` selects -- same values */
+template <int SIM, int L, int C, bool BLOB = false, bool FULL = false>
 __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j, const double (&th)[C],
                                   const double* y /* LDS, ld */, uint32_t i, uint32_t epoch, uint32_t purpose,
                                   double* blob = nullptr) {
@@ -225,7 +226,7 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
           const int k = Lay<L, C>::comp(j, m, c);
           double v = 0.0;
           if constexpr (BLOB) blob[2 * m + c] = 0.0;
-          if (k < d) {
+          if (FULL || k < d) {
             const double x = abz_fma(sg, z[c], th[2 * m + c]);
             if constexpr (BLOB) blob[2 * m + c] = x;
             const double e = x - y[k];

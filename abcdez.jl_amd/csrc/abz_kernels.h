@@ -150,7 +150,7 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   bool acc = false;
   double dp = dli;
   if (insupport) {
-    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    dp = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
     const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
     acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
   }
