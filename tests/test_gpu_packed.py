@@ -260,3 +260,21 @@ def test_grouped_sweeps_equal_sweep_by_sweep(oracle, name):
     assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5)
     assert hip.smc_sweeps(eps, g0, 1e-5, 2, 9.0) == orc.smc_sweeps(eps, g0, 1e-5, 2, 9.0)
     assert_equal(hip, orc, "mixed calls")
+
+
+def test_plain_prior_path_is_chosen_only_for_unpadded_normal_rows(oracle):
+    """all-Normal rows without padding take the sweep's short log-density path (abz_api.hip: prior_plain); a Uniform or
+    discrete dimension, or a padded row (d < ld), takes the family dispatch -- both reproduce the oracle's generic
+    evaluation (the parity tests above run mvn32 / mvn8 on the first path, mvn3 / socks / normdu on the second)"""
+    N, g0 = 4096, 0.3
+    for fams, sim in (([A.Normal(0.0, 1.0)] * 8, A.MVNormal((1.0,) * 8)),                     # plain
+                      ([A.Normal(0.0, 1.0)] * 7 + [A.Uniform(-4.0, 4.0)], A.MVNormal((1.0,) * 8)),      # a Uniform: generic
+                      ([A.Normal(0.0, 1.0)] * 7, A.MVNormal((1.0,) * 7))):                    # padded row: generic
+        spec = A.ModelSpec(A.Factored(*fams), sim, seed=5)
+        hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+        orc = PopulationEngine(spec, N, ops=oracle.OracleOps(spec), storage="packed")
+        for e in (hip, orc):
+            e.init_population(); e.reset_weights(); e.alive_compact()
+        for k in range(3):
+            assert hip.smc_swarm(3.0, g0, 1e-5) == orc.smc_swarm(3.0, g0, 1e-5)
+        assert_equal(hip, orc, f"{len(fams)} dims")

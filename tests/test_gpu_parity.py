@@ -503,6 +503,18 @@ def test_c_abi_error_paths():
     badblob = A.ModelSpec(prior, sim, seed=1).cstruct(host_data.ctypes.data)
     badblob.n_blob = 5                                                          # the MVN simulator's blob is d = 8 doubles
     assert lib.abcdez_ctx_create(C.byref(badblob), 0, C.byref(ctx)) != 0 and b"n_blob" in lib.abcdez_last_error()
+    # the grouped sweeps and the asynchronous abcdemc generation validate their arguments like the calls they are made of
+    nk, dn = (C.c_int64 * 20)(), C.c_int32()
+    grp = lambda k, kmin, b1=None: lib.abcdez_smc_sweeps_packed(
+        ops.ctx, b_in.data_ptr(), (b1 if b1 is not None else b_out).data_ptr(), 1000, s0.data_ptr(), s1.data_ptr(),
+        lp.data_ptr(), dl.data_ptr(), 2.5, 0.5, 1e-5, 0, k, kmin, nk, nk, C.byref(dn))
+    assert grp(0, 1.0) != 0 and grp(17, 1.0) != 0 and b"k_max" in lib.abcdez_last_error()
+    assert grp(2, -1.0) != 0 and grp(2, 1.0, b_in) != 0
+    tk = C.c_int64()
+    assert lib.abcdez_mc_generation_async(ops.ctx, 1000, s0.data_ptr(), lp.data_ptr(), dl.data_ptr(), s0.data_ptr(), lp.data_ptr(),
+                                          dl.data_ptr(), eng.inds.data_ptr(), dl.data_ptr(), eng.inds.data_ptr(), 0.0, 0.3, None, 1,
+                                          0.5, 1e-5, 0, C.byref(tk)) != 0 and b"in/out arrays must differ" in lib.abcdez_last_error()
+    assert lib.abcdez_mc_generation_wait(ops.ctx, 0, C.byref(tk), None, None, None, None) != 0
     # lane groups wider than 8 cannot own whole bitmap words
     spec32 = A.ModelSpec(*models()["mvn32"][:2], seed=1)
     e16 = PopulationEngine(spec32, 1000, ops=HipOps(spec32, lanes=16))
