@@ -312,29 +312,31 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   const uint32_t i = a.i0 + (active ? grp : 0u);
   const uint64_t seed = M.seed;
   __shared__ ModelLds<LD> s_model;
-  {
-    ModelStage<SIM, LD> stage;
-    stage.load(M);
-    stage.store(s_model);
-  }
-  __syncthreads();
-
+  /* Order of issue = order of need: three dependent round trips (state + candidate count | order[] | rows) instead of five;
+   * the Philox words need no memory, the model tables are staged while the rows are in flight */
+  ModelStage<SIM, LD> stage;
+  stage.load(M);
   const double lpi = a.logpi[i];
   const double di = a.delta[i];
+  const uint32_t cnt_i = a.cnt[i];                                        /* meaningful only where di > eps (abz_sort.hip) */
   const double eps_pop = a.eps_pop_dev ? abz_u2d(*a.eps_pop_dev) : a.eps_pop;
+  const abz_u64x2 w_better = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER);
+  const abz_u64x2 w_donor = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR);
   const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
   uint32_t s = i;
   if (di > eps) {                                                         /* mc:20-24 */
-    s = a.order[abz_randint(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER).w0, a.cnt[i])];
+    s = a.order[abz_randint(w_better.w0, cnt_i)];
   }
   uint32_t ia, ib;                                                        /* mc:25-32 */
-  abz_donor_ranks(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR), a.N, s, &ia, &ib);
+  abz_donor_ranks(w_donor, a.N, s, &ia, &ib);
 
   double ti[C], ts[C], ta[C], tb[C];
   load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
   load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
   load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
   load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
+  stage.store(s_model);
+  __syncthreads();
 
   double z0, z1;
   abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
