@@ -300,8 +300,8 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
         const double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
         const double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
         const double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
-        x = abz_fma(h6, (k1x + 2.0 * k2x) + (2.0 * k3x + k4x), x);
-        y = abz_fma(h6, (k1y + 2.0 * k2y) + (2.0 * k3y + k4y), y);
+        x = abz_fma(h6, abz_fma(2.0, k2x, k1x) + abz_fma(2.0, k3x, k4x), x);   /* 2 k is exact: the same bits as (k1 + 2 k2) + (2 k3 + k4) */
+        y = abz_fma(h6, abz_fma(2.0, k2y, k1y) + abz_fma(2.0, k3y, k4y), y);
       }
     }
     return abz_sqrt(acc);

@@ -262,8 +262,8 @@ def cpu_baseline(A, args, cfg):
 
 # ---------------------------------------------------------------------------------------------- roofline
 def lv_flops_per_update(sim):
-    """fp64 flops of one Lotka-Volterra particle-update (abz_device.h sim_dist<ABZ_SIM_LV>): per RK4 step 16 fma
-    (2 flop) + 12 mul + 6 add = 50 flop in 34 VALU instructions; per observation 2 fma (noise) + 2 sub + 2 fma
+    """fp64 flops of one Lotka-Volterra particle-update (abz_device.h sim_dist<ABZ_SIM_LV>): per RK4 step 20 fma
+    (2 flop) + 8 mul + 2 add = 50 flop in 30 VALU instructions; per observation 2 fma (noise) + 2 sub + 2 fma
     (squared error) = 10 flop, Box-Muller pair not counted."""
     nobs = len(sim.obs) // 2
     return (nobs - 1) * sim.steps_per_obs * 50 + nobs * 10
