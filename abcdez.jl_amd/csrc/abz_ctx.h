@@ -97,6 +97,7 @@ enum {
   ABZ_S_MCGT = 23, ABZ_S_MCMIN = 24, ABZ_S_MCMAX = 25,
   ABZ_S_PART_H = 26, ABZ_S_PART_F = 27, ABZ_S_PART_ERR = 28,
   ABZ_S_EPS = 29, ABZ_S_QVAL = 30,       /* fused prologue: eps of smc:301 and the quantile behind it (f64) */   /* partition: #holes, #fillers (must agree), error flag */   /* abcdemc sweep: #(Ds > eps_target), extrema of the new distances */
+  ABZ_S_PARITY = 31,                     /* resampling of double-buffered rows: the slot parity every position gets */
   ABZ_S_SCALARS = 32,
   /* Sweep counters (smc:138,150,352; mc:44,156): every block of a sweep / replay kernel ADDS its counts to one of
    * ABZ_CSLOTS slots (one 64-byte line each, chosen by block index; agent-scope atomics, fire and forget).  The

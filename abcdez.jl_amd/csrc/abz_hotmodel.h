@@ -19,6 +19,8 @@ struct HotModel {
 
 /* cumulative sweep-counter slots (abz_ctx.h, ABZ_S_CSLOT0): ABZ_CSLOTS slots of ABZ_CSTRIDE u64 (one 64-B line);
  * inside a slot: counter classes */
+/* rows of at most two doubles are kept double-buffered by the packed sweeps (abz_kernels.h, smc_swarm_packed_body) */
+#define ABZ_ROWS_DOUBLE_BUFFERED(ld) ((ld) <= 2)
 #define ABZ_CSLOTS 256
 #define ABZ_CSTRIDE 8
 #define ABZ_C_NACC 0      /* sweep: accepted (smc:150)                     */

@@ -121,17 +121,25 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
    *   slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot bits   (one L2 round trip)
    *   the three rows, log-prior, distance                                                                (one HBM round trip)
    *   meanwhile: tables staged in LDS, gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145)              */
+  /* Rows of at most two doubles are DOUBLE-BUFFERED (ABZ_ROWS_DOUBLE_BUFFERED): a sweep writes every swept position's row
+   * to its other slot (the proposal, or a copy of the row) and flips every swept bit, so the alive prefix always shares ONE
+   * slot parity and the donors need no bit look-up -- at 8 or 16 bytes per row the two random 4-byte look-ups cost as
+   * much as the donor rows themselves (the d = 1 sweep is bound by the gather rate of the CU's address unit), and copying a
+   * rejected row is a coalesced 8 bytes. */
+  constexpr bool DBUF = ABZ_ROWS_DOUBLE_BUFFERED(LD);
   ModelStage<SIM, LD> stage;
   stage.load(M);
   const uint32_t wi = a.bits[ri >> 5];
   ParticleDraws<L> draws;
   uint32_t ra, rb;
   draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
-  const uint32_t wa = a.bits[ra >> 5], wb = a.bits[rb >> 5];
+  uint32_t wa = 0u, wb = 0u;
+  if constexpr (!DBUF) { wa = a.bits[ra >> 5]; wb = a.bits[rb >> 5]; }
   const double lpi = a.logpi[ri];
   const double dli = a.delta[ri];
   if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
-  const uint32_t bi = (wi >> (ri & 31u)) & 1u, ba = (wa >> (ra & 31u)) & 1u, bb = (wb >> (rb & 31u)) & 1u;
+  const uint32_t bi = (wi >> (ri & 31u)) & 1u;
+  const uint32_t ba = DBUF ? bi : (wa >> (ra & 31u)) & 1u, bb = DBUF ? bi : (wb >> (rb & 31u)) & 1u;
   double ti[C], ta[C], tb[C];
   load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
   load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
@@ -149,19 +157,35 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   bool acc = false;
   double dp = dli;
-  if (insupport) {
-    dp = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
-    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, dp) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
-    acc = (0.0 <= w) || (log_u < w);                              /* smc:145 */
+  /* Narrow rows with a Normal prior (in support for every finite proposal): the simulator is not put behind a branch --
+   * its random numbers do not depend on the proposal and can be produced while the rows are in flight, which shortens
+   * the dependent chain these latency-bound kernels run on; the result is used only when the proposal is in support,
+   * as in the branch.  Wide rows keep the branch: hoisting costs the d = 32 kernel its fifth wave (88 -> 99 VGPRs). */
+  constexpr bool UNBRANCH = PLAIN && LD <= 4;
+  if (UNBRANCH || insupport) {
+    const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, ds) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
+    if (insupport) {
+      dp = ds;
+      acc = (0.0 <= w) || (log_u < w);                            /* smc:145 */
+    }
   }
   acc = acc && active;
-  if (acc) {                                                      /* smc:146-150 */
-    store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
-    if (j == 0) {
-      a.logpi[ri] = lp; a.delta[ri] = dp;
-      if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
-      atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+  if constexpr (DBUF) {
+    if (active) {
+      double to[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, to);
+      if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
     }
+  } else if (acc) {                                               /* smc:146-150 */
+    store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
+    if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+  }
+  if (acc && j == 0) {
+    a.logpi[ri] = lp; a.delta[ri] = dp;
+    if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
   }
   if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
   block_count2(j == 0 && acc, active && j == 0 && insupport, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
@@ -223,10 +247,22 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     const bool foreign_blk = !(r0 >= a.skip_lo && r0 < a.skip_hi);
     const bool acc = foreign_blk && (f & 1u) != 0u;
     const unsigned long long m = __ballot(acc);
+    unsigned long long flip = m;
+    if constexpr (ABZ_ROWS_DOUBLE_BUFFERED(LD)) {         /* every swept position moves to its other slot (smc_swarm_packed_body) */
+      const bool in = foreign_blk && r < a.n_alive;
+      flip = __ballot(in);
+      if (in && !acc) {
+        const uint32_t b = packed_bit(a.bits, r);
+        const double* src = (b ? a.slot1 : a.slot0) + (size_t)r * LD;
+        double* dst = (b ? a.slot0 : a.slot1) + (size_t)r * LD;
+#pragma unroll
+        for (int q = 0; q < LD; ++q) dst[q] = src[q];
+      }
+    }
     if (foreign_blk && lane == 0u) {                      /* the wave's 64 positions = two words of the bitmap */
       const uint32_t w = (r - lane) >> 5;
-      if (w * 32u < a.n_alive) a.bits_out[w] = a.bits[w] ^ (uint32_t)m;
-      if ((w + 1u) * 32u < a.n_alive) a.bits_out[w + 1u] = a.bits[w + 1u] ^ (uint32_t)(m >> 32);
+      if (w * 32u < a.n_alive) a.bits_out[w] = a.bits[w] ^ (uint32_t)flip;
+      if ((w + 1u) * 32u < a.n_alive) a.bits_out[w + 1u] = a.bits[w + 1u] ^ (uint32_t)(flip >> 32);
     }
     const unsigned cnt = (unsigned)__popcll(m);
     unsigned int at = 0u;

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void resample_gather_packed_kernel(
   const int j = (int)(gid % L);
   if (s >= N) return;
   const uint32_t src = inds[s];
-  const uint32_t bs = (bits[src >> 5] >> (src & 31u)) & 1u, bd = ((bits[s >> 5] >> (s & 31u)) & 1u) ^ 1u;
+  uint32_t bs = (bits[src >> 5] >> (src & 31u)) & 1u, bd = ((bits[s >> 5] >> (s & 31u)) & 1u) ^ 1u;
+  /* double-buffered rows: the sources (alive, so inside the prefix) all live in the prefix's slot P = bit of position 0;
+   * EVERY destination is the other slot, whatever a dead position's stale bit says -- bits_set_kernel then gives all N
+   * positions that one parity, and the sweeps' donors can keep assuming it */
+  if constexpr (ABZ_ROWS_DOUBLE_BUFFERED(LD)) { bs = bits[0] & 1u; bd = bs ^ 1u; }
   double t[C];
   load_row<L, C>((bs ? slot1 : slot0) + (size_t)src * LD, j, t);
   store_row<L, C>((bd ? slot1 : slot0) + (size_t)s * LD, j, t);
@@ -82,6 +86,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void bits_flip_kernel(uint32_t* __restri
   const uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   if (w < nwords) { const uint32_t v = ~bits[w]; bits[w] = v; other[w] = v; }
 }
+/* double-buffered rows: after a resampling every position's current slot is the one the gather wrote, 1 - P (P was read from
+ * word 0 BEFORE this launch: it is passed by value) */
+__global__ __launch_bounds__(ABZ_BLOCK) void bits_set_kernel(uint32_t* __restrict__ bits, uint32_t* __restrict__ other,
+                                                             uint32_t nwords, const uint32_t* __restrict__ parity_src) {
+  const uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t v = (parity_src[0] & 1u) ? 0xFFFFFFFFu : 0u;
+  if (w < nwords) { bits[w] = v; other[w] = v; }
+}
+__global__ void bits_parity_kernel(const uint32_t* __restrict__ bits, uint32_t* __restrict__ out) { out[0] = (bits[0] & 1u) ^ 1u; }
 template <int L, int C>
 __global__ __launch_bounds__(ABZ_BLOCK) void packed_gather_kernel(const uint32_t* __restrict__ bits, uint32_t N,
                                                                   const double* __restrict__ slot0,
@@ -108,7 +121,14 @@ int abz_launch_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, uin
   });
   if (!ok) { abz_set_error("resample_gather_packed: unsupported layout"); return -3; }
   const uint32_t nwords = (N + 31u) / 32u;
-  hipLaunchKernelGGL(bits_flip_kernel, dim3(abz_grid(nwords)), dim3(ABZ_BLOCK), 0, ctx->stream, bits, bits_other, nwords);
+  if (ABZ_ROWS_DOUBLE_BUFFERED(ctx->h_model.ld)) {
+    uint32_t* par = (uint32_t*)(ctx->d_scal + ABZ_S_PARITY);       /* 1 - P */
+    hipLaunchKernelGGL(bits_parity_kernel, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)bits, par);
+    hipLaunchKernelGGL(bits_set_kernel, dim3(abz_grid(nwords)), dim3(ABZ_BLOCK), 0, ctx->stream, bits, bits_other, nwords,
+                       (const uint32_t*)par);
+  } else {
+    hipLaunchKernelGGL(bits_flip_kernel, dim3(abz_grid(nwords)), dim3(ABZ_BLOCK), 0, ctx->stream, bits, bits_other, nwords);
+  }
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -120,7 +120,13 @@ ABCDEZ_API int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint
  *   prefix from the flags.  One byte per particle and sweep crosses xGMI instead of 8 ld + 16.
  * smc_resample_gather_packed: S8; source = current row of inds[s], destination = the other slot of s; afterwards
  *   every bit is flipped in both bit arrays; nlogpi / ndelta receive the gathered log-priors / distances.
- * packed_gather: the current rows as one dense array out[N][ld] (results, checkpoints).                          */
+ * packed_gather: the current rows as one dense array out[N][ld] (results, checkpoints).
+ * Rows of at most two doubles (ld <= 2) are kept DOUBLE-BUFFERED: a sweep (and its replay) writes every swept position's
+ *   row to the other slot -- the accepted proposal or a copy -- and flips every swept bit; a resampling writes every
+ *   position's new row to the slot the alive prefix is not in and gives all N bits that parity.  The alive prefix then
+ *   always shares one parity and the sweep takes its donors' slot from the own position's bit (two random look-ups
+ *   fewer per update, which is what bounds 8-byte rows).  Callers see no difference: the same arrays, the same calls;
+ *   the invariant holds for every population made by abcdez_init + these entry points.                          */
 ABCDEZ_API int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new,
                                     const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1,
                                     double* logpi, double* delta, double* wns);

@@ -652,6 +652,10 @@ ORC_API int64_t orc_smc_partition(const abz_model* M, int64_t n_prev, uint8_t* a
  * updated in place.  Checker for abcdez_smc_partition / abcdez_smc_swarm_packed / abcdez_smc_replay_packed /
  * abcdez_smc_resample_gather_packed / abcdez_packed_gather (include/abcdez_hip.h).                               */
 #define ORC_PBIT(bits, p) (((bits)[(p) >> 5] >> ((p) & 31)) & 1u)
+/* rows of at most two doubles are kept DOUBLE-BUFFERED by the packed sweeps (csrc/abz_kernels.h, smc_swarm_packed_body): every
+ * swept position moves to its other slot -- the proposal or a copy -- so the alive prefix shares one slot parity; the
+ * kernel then takes the donors' parity from the own position, THIS restatement keeps reading every position's own bit */
+#define ORC_DBUF(ld) ((ld) <= 2)
 #define ORC_PROW(slot0, slot1, bit, p, ld) ((bit) ? (slot1) : (slot0)) + (int64_t)(p) * (ld)
 
 ORC_API int64_t orc_packed_partition(const abz_model* M, int64_t N, int64_t n_prev, uint8_t* alive, const uint32_t* bits,
@@ -733,13 +737,18 @@ ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint
         nacc += 1;
       }
     }
+    if (!acc && ORC_DBUF(ld)) {        /* double-buffered rows: a rejected particle's row is COPIED to its other slot */
+      const double* from = ORC_PROW(slot0, slot1, ORC_PBIT(bits, i), i, ld);
+      double* to = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, i) ^ 1u, i, ld));
+      for (int k = 0; k < ld; ++k) to[k] = from[k];
+    }
     acc_tmp[r - r_lo] = (uint8_t)acc;
     if (flags) flags[i] = (uint8_t)(acc | (simulated << 1));
   }
   for (int64_t r = r_lo; r < r_hi; ++r) {          /* sequential: several positions share a word */
     const uint32_t m = 1u << (r & 31);
     const uint32_t cur = bits[r >> 5] & m;
-    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | (acc_tmp[r - r_lo] ? (cur ^ m) : cur);
+    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | ((acc_tmp[r - r_lo] || ORC_DBUF(ld)) ? (cur ^ m) : cur);
   }
   free(acc_tmp);
   *nacc_out = nacc; *nsim_out = nsim;
@@ -766,13 +775,17 @@ ORC_API void orc_smc_replay_packed(const abz_model* M, const uint32_t* bits, uin
       push_row(M, tp, pp);
       logpi[r] = logprior_tree(M, pp);              /* the owner stored the same value (smc:147) */
       if (g_stamp_cur) g_stamp_cur[r] = abz_stamp((uint32_t)r, sweep, 0);
+    } else if (ORC_DBUF(ld)) {
+      const double* from = ORC_PROW(slot0, slot1, ORC_PBIT(bits, r), r, ld);
+      double* to = (double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, r) ^ 1u, r, ld));
+      for (int k = 0; k < ld; ++k) to[k] = from[k];
     }
   }
   for (int64_t r = 0; r < n_alive; ++r) {
     if (r >= skip_lo && r < skip_hi) continue;
     const uint32_t m = 1u << (r & 31);
     const uint32_t cur = bits[r >> 5] & m;
-    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | ((flags[r] & 1) ? (cur ^ m) : cur);
+    bits_out[r >> 5] = (bits_out[r >> 5] & ~m) | (((flags[r] & 1) || ORC_DBUF(ld)) ? (cur ^ m) : cur);
   }
   *nacc_out = nacc; *nsim_out = nsim;
 }
@@ -784,10 +797,14 @@ ORC_API void orc_smc_resample_gather_packed(const abz_model* M, const uint32_t* 
                                             const double* delta, double* nlogpi, double* ndelta, double* wns,
                                             uint8_t* alive) {
   const int ld = M->ld;
+  /* double-buffered rows: every destination is the slot the alive prefix is NOT in (parity of position 0), whatever a
+   * dead position's stale bit says; afterwards all N positions have that parity */
+  const uint32_t newp = (bits[0] & 1u) ^ 1u;
 #pragma omp parallel for schedule(static)
   for (int64_t s = 0; s < N; ++s) {
     const int64_t j = inds[s];
-    memcpy((double*)(ORC_PROW(slot0, slot1, ORC_PBIT(bits, s) ^ 1u, s, ld)), ORC_PROW(slot0, slot1, ORC_PBIT(bits, j), j, ld),
+    const uint32_t dst = ORC_DBUF(ld) ? newp : (ORC_PBIT(bits, s) ^ 1u);
+    memcpy((double*)(ORC_PROW(slot0, slot1, dst, s, ld)), ORC_PROW(slot0, slot1, ORC_PBIT(bits, j), j, ld),
            (size_t)ld * sizeof(double));                                   /* smc:96 */
     nlogpi[s] = logpi[j];                                                  /* smc:97 */
     ndelta[s] = delta[j];                                                  /* smc:98 */
@@ -795,7 +812,10 @@ ORC_API void orc_smc_resample_gather_packed(const abz_model* M, const uint32_t* 
     wns[s] = 1.0 / (double)N;                                              /* smc:102 */
     alive[s] = 1;                                                          /* smc:103 */
   }
-  for (int64_t w = 0; w < (N + 31) / 32; ++w) { bits[w] = ~bits[w]; bits_other[w] = bits[w]; }
+  for (int64_t w = 0; w < (N + 31) / 32; ++w) {
+    bits[w] = ORC_DBUF(ld) ? (newp ? 0xFFFFFFFFu : 0u) : ~bits[w];
+    bits_other[w] = bits[w];
+  }
 }
 
 /* ---------------------------------------------------------------- S9: quantile(Ds[alive], alpha)  (smc:301)

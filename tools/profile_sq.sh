@@ -5,8 +5,10 @@ set -x
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r02}; CFG=${CFG:-smc32}; KERNEL=${KERNEL:-smc_swarm_packed_kernel}
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
+COUNTERS=${COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU}
+OUT=${OUT:-sq_counters}
+timeout 500 rocprofv3 --pmc $COUNTERS \
   --output-format csv -d $R/gpurun_out/sq_$CFG -o sq -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 8 --warmup 4 > $R/gpurun_out/${TAG}_${CFG}_sq_bench.log 2>&1
 F=$(find $R/gpurun_out/sq_$CFG -name 'sq_counter_collection.csv' | head -1)
-python3 $R/tools/sq_summary.py $F $KERNEL > $R/gpurun_out/${TAG}_${CFG}_sq_counters.json
+python3 $R/tools/sq_summary.py $F $KERNEL > $R/gpurun_out/${TAG}_${CFG}_${OUT}.json
 rm -rf $R/gpurun_out/sq_$CFG
