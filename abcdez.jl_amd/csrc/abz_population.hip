@@ -113,26 +113,82 @@ __global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
   if (t == 0) a.partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-/* sums `n` elements under MODE; leaves the result in *d_out (device).  Uses ws. */
+/* The upper levels of the tile tree in ONE launch (the recursion used to be one launch per level and per sum): block b
+ * finishes tree b -- level-1 tiles of its n_b partials one after the other (results in LDS), then the one level-2 tile --
+ * with the operations and the order of tile_sum_kernel<LOAD_PLAIN>, so the same bits.  n_b <= 2048 * 2048 partials. */
+struct FinishArgs {
+  const double* part[2];
+  double* out[2];
+  int64_t n[2];
+};
+__device__ inline double finish_tile(const double* __restrict__ x, int64_t n, int64_t base, double* s_w) {
+  const int t = threadIdx.x;
+  double e[8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int64_t k = base + m * 512 + 2 * t;
+    e[2 * m] = k < n ? x[k] : 0.0;
+    e[2 * m + 1] = k + 1 < n ? x[k + 1] : 0.0;
+  }
+  double s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s = s + shfl_xor_f64(s, off);
+  __syncthreads();                                     /* s_w is reused from tile to tile */
+  if ((t & 63) == 0) s_w[t >> 6] = s;
+  __syncthreads();
+  return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);        /* every thread gets the tile's sum */
+}
+__global__ __launch_bounds__(ABZ_BLOCK) void tree_finish_kernel(const FinishArgs a) {
+  __shared__ double s_w[4];
+  __shared__ double s_l1[ABZ_TILE];
+  const double* x = a.part[blockIdx.x];
+  const int64_t n = a.n[blockIdx.x];
+  const int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
+  if (nt == 1) {
+    const double r = finish_tile(x, n, 0, s_w);
+    if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
+    return;
+  }
+  for (int64_t tile = 0; tile < nt; ++tile) {
+    const double r = finish_tile(x, n, tile * ABZ_TILE, s_w);
+    if (threadIdx.x == 0) s_l1[tile] = r;
+  }
+  __syncthreads();
+  const double r = finish_tile(s_l1, nt, 0, s_w);
+  if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
+}
+
+/* sums `n` elements under MODE: launches the element pass; the result is in *d_out if that was one tile, else `*pending`
+ * partials wait in part0 for tree_finish.  Uses ws. */
 template <int MODE>
-static int tree_sum_device(abcdez_ctx* ctx, TileArgs a, double* d_out, double* part0, double* part1) {
-  int64_t n = a.n;
-  int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
+static int tree_sum_begin(abcdez_ctx* ctx, TileArgs a, double* d_out, double* part0, int64_t* pending) {
+  const int64_t nt = (a.n + ABZ_TILE - 1) / ABZ_TILE;
   a.partials = nt == 1 ? d_out : part0;
   hipLaunchKernelGGL((tile_sum_kernel<MODE>), dim3((unsigned)nt), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-  double* cur = part0;
-  double* nxt = part1;
-  while (nt > 1) {
-    TileArgs b{};
-    b.x = cur; b.n = nt;
-    const int64_t nt2 = (nt + ABZ_TILE - 1) / ABZ_TILE;
-    b.partials = nt2 == 1 ? d_out : nxt;
-    hipLaunchKernelGGL((tile_sum_kernel<LOAD_PLAIN>), dim3((unsigned)nt2), dim3(ABZ_BLOCK), 0, ctx->stream, b);
-    nt = nt2;
-    double* t = cur; cur = nxt; nxt = t;
-  }
+  ABZ_HIP_CHECK(hipGetLastError());
+  *pending = nt == 1 ? 0 : nt;
+  return 0;
+}
+/* finishes up to two trees in one launch (n = 0: nothing to do for that tree) */
+static int tree_finish(abcdez_ctx* ctx, const double* pa, int64_t na, double* outa, const double* pb = nullptr, int64_t nb = 0,
+                       double* outb = nullptr) {
+  FinishArgs f{};
+  int k = 0;
+  if (na > 0) { f.part[k] = pa; f.n[k] = na; f.out[k] = outa; ++k; }
+  if (nb > 0) { f.part[k] = pb; f.n[k] = nb; f.out[k] = outb; ++k; }
+  if (k == 0) return 0;
+  for (int q = 0; q < k; ++q)
+    if (f.n[q] > (int64_t)ABZ_TILE * ABZ_TILE) { abz_set_error("tile tree: too many partials for one finishing block"); return -3; }
+  hipLaunchKernelGGL(tree_finish_kernel, dim3((unsigned)k), dim3(ABZ_BLOCK), 0, ctx->stream, f);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
+}
+template <int MODE>
+static int tree_sum_device(abcdez_ctx* ctx, TileArgs a, double* d_out, double* part0, double* /*part1*/) {
+  int64_t pending = 0;
+  int rc = tree_sum_begin<MODE>(ctx, a, d_out, part0, &pending);
+  if (rc) return rc;
+  return tree_finish(ctx, part0, pending, d_out);
 }
 
 __global__ __launch_bounds__(ABZ_BLOCK) void publish_kernel(const unsigned long long* __restrict__ scal,
@@ -211,11 +267,12 @@ static int reweight_enqueue(abcdez_ctx* ctx, const double* delta, double* wns, u
   b.n = N; b.x = wprod; b.wns = wns; b.alive = alive;
   b.wnorm = (const double*)(ctx->d_scal + ABZ_S_WNORM);
   b.tile_alive = tile_alive;
-  rc = tree_sum_device<LOAD_NORMALISE>(ctx, b, (double*)(ctx->d_scal + ABZ_S_SUMSQ), p0, p1);
+  int64_t pending = 0;
+  rc = tree_sum_begin<LOAD_NORMALISE>(ctx, b, (double*)(ctx->d_scal + ABZ_S_SUMSQ), p0, &pending);
   if (rc) return rc;
-  TileArgs c{};
-  c.x = tile_alive; c.n = (int64_t)ntile;      /* integers < 2^53: the f64 tree sum is exact */
-  return tree_sum_device<LOAD_PLAIN>(ctx, c, (double*)(ctx->d_scal + ABZ_S_NALIVE), p0, p1);
+  /* sum(Wns^2) and sum(alive) (tile counts: integers < 2^53, the f64 tree sum is exact) finish in one launch */
+  return tree_finish(ctx, p0, pending, (double*)(ctx->d_scal + ABZ_S_SUMSQ), tile_alive, (int64_t)ntile,
+                     (double*)(ctx->d_scal + ABZ_S_NALIVE));
 }
 int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
                       double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
