@@ -659,13 +659,17 @@ __device__ inline unsigned long long qs_fat_min(unsigned long long v, unsigned l
 }
 
 /* pass 1: histogram of the alive keys in the window's bins; smallest alive key per block -> bmin[block] */
+/* n_all > 0 (fused prologue): extrema(Ds) over ALL n_all positions, alive or not (smc:364), ride along -- the positions past the
+ * alive prefix are read for this only; per-block results -> ball[block], ball[grid + block], folded by qs_final_kernel */
 __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __restrict__ delta,
                                                              const uint8_t* __restrict__ alive, int64_t N,
                                                              const unsigned long long* __restrict__ st,
                                                              uint32_t* __restrict__ hist,
-                                                             unsigned long long* __restrict__ bmin) {
+                                                             unsigned long long* __restrict__ bmin, int64_t n_all,
+                                                             unsigned long long* __restrict__ ball) {
   __shared__ uint32_t s_h[ABZ_QS_BINS];
   __shared__ unsigned long long s_w[ABZ_QS_FAT / 64];
+  unsigned long long alo = ~0ull, ahi = 0ull;
   for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_FAT) s_h[b] = 0;
   const unsigned long long klo = QS(ABZ_S_SEL_HLO);
   const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
@@ -684,17 +688,31 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 8; ++u) {
+      if (n_all > 0 && k0 + u * stride < N) { alo = key[u] < alo ? key[u] : alo; ahi = key[u] > ahi ? key[u] : ahi; }
       if (al[u]) {
         atomicAdd(&s_h[qs_bin(key[u], klo, shift)], 1u);
         lo = key[u] < lo ? key[u] : lo;
       }
+    }
+  }
+  for (int64_t k = N + (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x; k < n_all; k += stride) {   /* the dead tail */
+    const unsigned long long key = f64_order_key(delta[k]);
+    alo = key < alo ? key : alo;
+    ahi = key > ahi ? key : ahi;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_FAT)
     if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
   lo = qs_fat_min(lo, s_w);
   if (threadIdx.x == 0) bmin[blockIdx.x] = lo;
+  if (n_all > 0) {
+    __syncthreads();
+    alo = qs_fat_min(alo, s_w);
+    __syncthreads();
+    ahi = ~qs_fat_min(~ahi, s_w);
+    if (threadIdx.x == 0) { ball[blockIdx.x] = alo; ball[gridDim.x + blockIdx.x] = ahi; }
+  }
 }
 
 /* pass 2.  Every block finds the bin of rank k0 itself (2048 counters from L2: cheaper than a launch); keys of that
@@ -822,11 +840,19 @@ __device__ inline void qs_block_reduce(unsigned long long& cnt, unsigned long lo
 /* finish: rank k of the buffered bin, starting from the sub-histogram pass 2 took of it.  Rounds over the candidates (in LDS when they fit): count / min / max; all
  * equal -> done; <= 64 left -> rank them against each other; else 2048 sub-bins of [min, max], keep the one holding
  * the rank.  Every round strips 11 bits off the key range.                                                          */
+/* fused prologue: what used to be two more launches rides at the end of the finish kernel */
+struct QsTail {
+  int eps_on;                 /* smc:301 on the device: q = x_(j) + g (x_(j+1) - x_(j)); eps = max(min(q, eps_prev), eps_target) */
+  int single;
+  unsigned long long k0;
+  double g, eps_prev, eps_target;
+  const unsigned long long* ball;   /* per-block extrema of ALL distances from qs_hist_kernel, or NULL */
+};
 __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long* __restrict__ buf,
                                                         unsigned long long* __restrict__ st, uint32_t* __restrict__ hist,
                                                         const unsigned long long* __restrict__ bmin,
                                                         const unsigned long long* __restrict__ babove, int nblk,
-                                                        uint32_t* __restrict__ hist2) {
+                                                        uint32_t* __restrict__ hist2, const QsTail tail) {
   __shared__ uint32_t s_h[ABZ_QS_BINS];
   __shared__ unsigned long long s_keys[ABZ_QS_LDSKEYS];
   __shared__ unsigned long long s_cand[64];
@@ -993,6 +1019,22 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
       QS(ABZ_S_SEL_HHI) = nxt != ~0ull ? nxt : key;
     }
     QS(ABZ_S_SEL_NBUF) = 0;
+    if (tail.eps_on) {
+      unsigned long long* scal = st - ABZ_S_SEL_PREFIX;
+      const double a = f64_from_order_key_dev(key);
+      const double b = (tail.single || tail.k0 + 1ull < less + eq || nxt == ~0ull) ? a : f64_from_order_key_dev(nxt);
+      const double q = a + tail.g * (b - a);
+      double e = q < tail.eps_prev ? q : tail.eps_prev;   /* min(q, eps): Julia's min propagates NaN; distances are never NaN */
+      e = e > tail.eps_target ? e : tail.eps_target;
+      scal[ABZ_S_QVAL] = abz_d2u(q);
+      scal[ABZ_S_EPS] = abz_d2u(e);
+    }
+  }
+  if (tail.ball) {
+    unsigned long long c0 = 0, lo = ~0ull, hi = 0ull;
+    if (t < nblk) { lo = tail.ball[t]; hi = tail.ball[nblk + t]; }
+    qs_block_reduce(c0, lo, hi, s_red);
+    if (t == 0) { unsigned long long* scal = st - ABZ_S_SEL_PREFIX; scal[ABZ_S_MIN] = lo; scal[ABZ_S_MAX] = hi; }
   }
 }
 #undef QS
@@ -1004,30 +1046,15 @@ __device__ inline double dev_from_order_key(unsigned long long k) {
   return (k >> 63) ? abz_u2d(k & 0x7FFFFFFFFFFFFFFFull) : abz_u2d(~k);
 }
 
-/* the driver's smc:301 on the device, right behind the select: q = x_(j) + g (x_(j+1) - x_(j)) (Julia quantile, type 7;
- * j, g from the host, which knows n), eps = max(min(q, eps_prev), eps_target) -> scal[ABZ_S_EPS].  The host owns the
- * schedule: it passes eps_prev / eps_target in and reads eps back with the other scalars.                        */
-__global__ void qs_eps_kernel(unsigned long long* __restrict__ scal, unsigned long long k0, double g, int single,
-                              double eps_prev, double eps_target) {
-  const unsigned long long key = scal[ABZ_S_SEL_PREFIX], less = scal[ABZ_S_SEL_LESS], eq = scal[ABZ_S_SEL_EQ];
-  const unsigned long long next = scal[ABZ_S_SEL_NEXT];
-  const double a = dev_from_order_key(key);
-  const double b = (single || k0 + 1ull < less + eq || next == ~0ull) ? a : dev_from_order_key(next);
-  const double q = a + g * (b - a);
-  double e = q < eps_prev ? q : eps_prev;             /* min(q, eps): Julia's min propagates NaN; distances are never NaN */
-  e = e > eps_target ? e : eps_target;
-  scal[ABZ_S_QVAL] = abz_d2u(q);
-  scal[ABZ_S_EPS] = abz_d2u(e);
-}
-
 /* enqueue the three passes of the select for rank k0 (0-based) among the alive distances; results stay on the device */
-static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0) {
+static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
+                          const QsTail* tail_in = nullptr, int64_t n_all = 0) {
   int rc = abz_ws_reserve(ctx, abz_align((size_t)N * 8));
   if (rc) return rc;
   unsigned long long* buf = (unsigned long long*)ctx->ws;
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
   if (!ctx->sel_hist) {        /* histogram + sub-histogram (left zeroed by every call) + per-block minima of the two passes */
-    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, 2 * ABZ_QS_BINS * 4 + 4 * ABZ_QS_GRID * 8));
+    ABZ_HIP_CHECK(hipMalloc((void**)&ctx->sel_hist, 2 * ABZ_QS_BINS * 4 + 6 * ABZ_QS_GRID * 8));
     ctx->sel_clean = false;
   }
   uint32_t* hist2 = ctx->sel_hist + ABZ_QS_BINS;
@@ -1048,11 +1075,16 @@ static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* a
   ctx->sel_clean = false;
   unsigned grid = (unsigned)((N + 8 * ABZ_QS_FAT - 1) / (8 * ABZ_QS_FAT));
   if (grid > ABZ_QS_GRID) grid = ABZ_QS_GRID;
-  hipLaunchKernelGGL(qs_hist_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist, bmin);
+  unsigned long long* ball = babove + 3 * ABZ_QS_GRID;      /* after the three arrays of qs_compact_kernel */
+  QsTail tail{};
+  if (tail_in) tail = *tail_in;
+  tail.ball = n_all > 0 ? ball : nullptr;
+  hipLaunchKernelGGL(qs_hist_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist, bmin,
+                     n_all, ball);
   hipLaunchKernelGGL(qs_compact_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N,
                      (unsigned long long)k0, ctx->sel_hist, st, buf, babove, hist2);
   hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist, bmin, babove, (int)grid,
-                     hist2);
+                     hist2, tail);
   ABZ_HIP_CHECK(hipGetLastError());
   ctx->sel_delta = delta; ctx->sel_alive = alive; ctx->sel_N = N;
   return 0;
@@ -1211,8 +1243,7 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
                              const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
                              double* delta_rw, double* out /* eps, q, wnorm, ess, lo, hi */, int64_t* n_alive,
                              int32_t* partitioned) {
-  int rc = extrema_enqueue(ctx, delta_all, N);
-  if (rc) return rc;
+  int rc = 0;
   /* Julia Statistics.quantile, type 7, over the n_prev alive distances: h = (n-1) p + 1, j = clamp(floor(h), 1, n-1), g = h - j */
   const int64_t n = n_prev;
   const double h = (double)(n - 1) * alpha + 1.0;
@@ -1220,10 +1251,11 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   if (j < 1) j = 1;
   if (j > n - 1) j = n - 1 > 1 ? n - 1 : 1;
   const double g = h - (double)j;
-  rc = select_enqueue(ctx, delta_all, alive, n_prev, j - 1);
+  QsTail tail{};
+  tail.eps_on = 1; tail.single = n == 1 ? 1 : 0; tail.k0 = (unsigned long long)(j - 1); tail.g = g;
+  tail.eps_prev = eps_prev; tail.eps_target = eps_target;
+  rc = select_enqueue(ctx, delta_all, alive, n_prev, j - 1, &tail, N);   /* + extrema(Ds) over all N, + eps of smc:301 */
   if (rc) return rc;
-  hipLaunchKernelGGL(qs_eps_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scal, (unsigned long long)(j - 1), g, n == 1 ? 1 : 0,
-                     eps_prev, eps_target);
   rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS));
   if (rc) return rc;
   rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min);
