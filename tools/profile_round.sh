@@ -6,9 +6,9 @@ set -x
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r02}; CFG=${CFG:-smc32}
 case $CFG in
-  smc32) MARK=extrema_kernel; LANES=4; LD=32; KERN=smc_swarm_packed_kernel;;
-  lv) MARK=extrema_kernel; LANES=1; LD=4; KERN=smc_swarm_packed_kernel;;
-  evidence1d) MARK=extrema_kernel; LANES=1; LD=1; KERN=smc_swarm_packed_kernel;;
+  smc32) MARK=qs_hist_kernel; LANES=4; LD=32; KERN=smc_swarm_packed_kernel;;
+  lv) MARK=qs_hist_kernel; LANES=1; LD=4; KERN=smc_swarm_packed_kernel;;
+  evidence1d) MARK=qs_hist_kernel; LANES=1; LD=1; KERN=smc_swarm_packed_kernel;;
   mc1d) MARK=mc_swarm_kernel; LANES=1; LD=1; KERN=mc_swarm_kernel;;
 esac
 cd /tmp && export TMPDIR=/tmp
