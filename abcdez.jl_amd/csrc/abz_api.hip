@@ -623,6 +623,7 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   const int bank = ctx->mm_bank;
   if (n_local > 0) ctx->mm_bank = 1 - bank;          /* the kernel reset the other bank for the next sweep */
   ctx->mc_have_bank = (i0 == 0 && n_local == N);     /* the bank holds the extrema of the whole population */
+  ctx->mc_window_ready = false;
   rc = read_counters(ctx);
   if (rc) return rc;
   *nsim = (int64_t)ctx->h_scal[ABZ_S_COUNT];
@@ -671,8 +672,11 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     memset(ctx->h_ring, 0, (size_t)ABZ_MC_RING * ABZ_RING_WORDS * 8);
     ABZ_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
   }
-  int rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
-  if (rc) return rc;
+  int rc = 0;
+  if (lo_hi || !ctx->mc_window_ready || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target) {
+    rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
+    if (rc) return rc;
+  }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
   const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
   if (do_rank) {                     /* mc:20-24 is only reached while some Ds[i] > eps */
     rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win);
@@ -683,8 +687,10 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   if (rc) return rc;
   const int slot = (int)(ctx->mc_issued % ABZ_MC_RING);
   ctx->ring_folded[slot] = false;
-  rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull);
+  rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull,
+                              alpha, eps_target);
   if (rc) return rc;
+  ctx->mc_window_ready = true; ctx->mc_alpha = alpha; ctx->mc_eps_target = eps_target;
   ctx->mm_bank = 1 - ctx->mm_bank;   /* the kernel reset the other bank for the next sweep */
   ctx->mc_have_bank = true;
   *ticket = (int64_t)ctx->mc_issued;

@@ -61,7 +61,9 @@ struct abcdez_ctx {
   bool ring_folded[ABZ_MC_RING] = {false};
   long long ring_res[ABZ_MC_RING][2] = {{0, 0}};  /* (nsim, #above target) once folded */
   long long mc_issued = 0, mc_waited = 0;
-  bool mc_have_bank = false;                      /* a sweep of this context has left extrema in a bank */
+  bool mc_have_bank = false;
+  bool mc_window_ready = false;                   /* the last snapshot kernel left the next generation's window for (mc_alpha, mc_eps_target) */
+  double mc_alpha = 0.0, mc_eps_target = 0.0;                      /* a sweep of this context has left extrema in a bank */
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
 };
@@ -139,7 +141,7 @@ int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t, const unsigned long long*);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
-int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq);
+int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha, double eps_target);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
 /* Read-back of the first `nwords` device scalars WITHOUT the copy engine and without a stream synchronisation: a one-block

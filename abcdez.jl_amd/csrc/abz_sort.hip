@@ -236,6 +236,22 @@ static inline unsigned long long host_order_key(double x) {
 /* The generation's eps_pop (mc:147) and the binning window of the rank pass, made ON THE DEVICE from the extrema the
  * previous sweep left in its min / max bank (bank >= 0) or from host values (bank < 0): abcdez_mc_generation_async.
  * eps_pop = max(eps_target, lo + alpha (hi - lo)) with the host driver's operations (two roundings, `b > a ? b : a`). */
+__device__ inline void mc_window_write(unsigned long long* __restrict__ scal, double lo, double hi, double alpha, double eps_target) {
+  const double v = lo + alpha * (hi - lo);
+  const double eps_pop = v > eps_target ? v : eps_target;
+  const unsigned long long klo = f64_order_key(eps_pop);
+  unsigned long long khi = f64_order_key(hi);
+  if (!(hi > eps_pop)) khi = klo + 1ull;
+  const unsigned long long range = khi - klo;
+  int bits = 0;
+  while (bits < 64 && (range >> bits) != 0ull) ++bits;
+  unsigned long long* w = scal + ABZ_S_MCW_EPS;
+  w[0] = abz_d2u(eps_pop);
+  w[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS] = klo;
+  w[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS] = (unsigned long long)(bits > MCR_BITS ? bits - MCR_BITS : 0);
+  w[ABZ_S_MCW_LO - ABZ_S_MCW_EPS] = abz_d2u(lo);
+  w[ABZ_S_MCW_HI - ABZ_S_MCW_EPS] = abz_d2u(hi);
+}
 __global__ __launch_bounds__(64) void mc_window_kernel(unsigned long long* __restrict__ scal, int bank, double lo_h, double hi_h,
                                                        double alpha, double eps_target) {
   double lo = lo_h, hi = hi_h;
@@ -252,20 +268,7 @@ __global__ __launch_bounds__(64) void mc_window_kernel(unsigned long long* __res
     hi = f64_from_order_key_dev(mx);
   }
   if (threadIdx.x != 0) return;
-  const double v = lo + alpha * (hi - lo);
-  const double eps_pop = v > eps_target ? v : eps_target;
-  const unsigned long long klo = f64_order_key(eps_pop);
-  unsigned long long khi = f64_order_key(hi);
-  if (!(hi > eps_pop)) khi = klo + 1ull;
-  const unsigned long long range = khi - klo;
-  int bits = 0;
-  while (bits < 64 && (range >> bits) != 0ull) ++bits;
-  unsigned long long* w = scal + ABZ_S_MCW_EPS;
-  w[0] = abz_d2u(eps_pop);
-  w[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS] = klo;
-  w[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS] = (unsigned long long)(bits > MCR_BITS ? bits - MCR_BITS : 0);
-  w[ABZ_S_MCW_LO - ABZ_S_MCW_EPS] = abz_d2u(lo);
-  w[ABZ_S_MCW_HI - ABZ_S_MCW_EPS] = abz_d2u(hi);
+  mc_window_write(scal, lo, hi, alpha, eps_target);
 }
 int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double alpha, double eps_target) {
   static_assert(ABZ_MMSLOTS == 64, "mc_window_kernel folds one slot per lane");
@@ -277,8 +280,11 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
 /* What the driver reads of a generation (mc:156, mc:146, nsims), folded on the device and written STRAIGHT into pinned
  * host memory: totals of the two cumulative counter classes, extrema of the bank the sweep reduced into, eps_pop; the
  * ticket word last, behind a system-scope fence -- the host polls it (no copy engine, no event, no stream synchronisation) */
-__global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(const unsigned long long* __restrict__ scal, int bank,
-                                                                 unsigned long long* __restrict__ out, unsigned long long seq) {
+/* It also prepares the NEXT generation: the extrema it has just folded are that generation's mc:146, so eps_pop and the
+ * binning window (mc_window_write) are made here and the next generation starts without a window launch.            */
+__global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
+                                                                 unsigned long long* __restrict__ out, unsigned long long seq,
+                                                                 double alpha, double eps_target) {
   __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
   unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
@@ -303,11 +309,13 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(const unsigned 
     out[4] = scal[ABZ_S_MCW_EPS];
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
   }
 }
-int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq) {
+int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha,
+                           double eps_target) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
-  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq);
+  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
