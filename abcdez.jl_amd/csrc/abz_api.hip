@@ -323,17 +323,19 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   ctx->ring_folded[slot] = true;
 }
 /* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
- * end early: the later launches return at once and are not launches of the roofline figure); -1 = all of them,
- * -2 = the number the group reports */
-static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
-  if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
-  /* generations still in the ring (complete: the stream was synchronised): their counters come first, their results
-   * stay redeemable */
+ * end early: the later launches return at once and are not launches of the roofline figure); < 0 = all of them */
+/* second half of a counter read-back (the scalars are in h_scal): ring generations first, baseline, timing events */
+static int read_counters_finish(abcdez_ctx* ctx, int ran_limit) {
+  /* generations still in the ring (complete: everything before the publish kernel has run): their counters come first,
+   * their results stay redeemable */
   for (long long t = ctx->mc_waited; t < ctx->mc_issued; ++t) ring_fold(ctx, t);
   abz_fold_counters(ctx);
-  if (ran_limit == -2) ran_limit = (int)ctx->h_scal[ABZ_S_GRP_DONE];
   const long long n_ev = ctx->ev_tail - ctx->ev_head;
   return timing_consume(ctx, n_ev, ran_limit < 0 ? n_ev : ran_limit);
+}
+static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
+  if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
+  return read_counters_finish(ctx, ran_limit);
 }
 
 int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
@@ -467,17 +469,29 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
                                          nullptr, eps, gamma0, gamma_sigma, sweep0 + (uint32_t)k, 1,
                                          k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
     if (rc) return rc;
-    rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min);
-    if (rc) return rc;
+    if (k + 1 < k_max) {             /* nothing is decided after the last sweep: its counters are the totals the host reads anyway */
+      rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min);
+      if (rc) return rc;
+    }
   }
-  int rc = read_counters(ctx, -2);
-  if (rc) return rc;
-  const int done = (int)ctx->h_scal[ABZ_S_GRP_DONE];
+  if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
+  /* totals of the two counter classes now; how many sweeps ran: the test held after sweep `GRP_DONE` (stop flag set by one of
+   * the k_max - 1 checks), or never -- then the last sweep ran too */
+  unsigned long long tot_acc = 0, tot_sim = 0;
+  for (int q = 0; q < ABZ_CSLOTS; ++q) {
+    tot_acc += ctx->h_scal[ABZ_S_CSLOT0 + q * ABZ_CSTRIDE + ABZ_C_NACC];
+    tot_sim += ctx->h_scal[ABZ_S_CSLOT0 + q * ABZ_CSTRIDE + ABZ_C_NSIM];
+  }
+  const bool stopped = k_max > 1 && ctx->h_scal[ABZ_S_GRP_STOP] != 0;
+  const int done = stopped ? (int)ctx->h_scal[ABZ_S_GRP_DONE] : k_max;
   ABZ_REQUIRE(1 <= done && done <= k_max, "smc_sweeps_packed: inconsistent sweep count read back");
+  if (int rc = read_counters_finish(ctx, done)) return rc;
   unsigned long long pa = base_acc, ps = base_sim;
   for (int k = 0; k < k_max; ++k) {
     if (k < done) {
-      const unsigned long long ca = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k], cs = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k + 1];
+      const bool last_unchecked = !stopped && k == k_max - 1;
+      const unsigned long long ca = last_unchecked ? tot_acc : ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k];
+      const unsigned long long cs = last_unchecked ? tot_sim : ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k + 1];
       nacc[k] = (int64_t)(ca - pa); nsim[k] = (int64_t)(cs - ps);
       pa = ca; ps = cs;
     } else {
