@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 from .kernels import IndicatorStrict0toϵ, kernel_kind
-from .priors import PRIOR_NEGBIN, PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
+from .priors import Product, PRIOR_NEGBIN, PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
 from .simulators import DeviceSimulator
 
 MAX_D = 64
@@ -80,6 +80,10 @@ class ModelSpec:
             raise ValueError(f"blobs of {self.n_blob} doubles exceed the supported maximum 64")
         self.discrete = tuple(bool(f.discrete) for f in factors)
         self._desc = [f.descriptor() for f in factors]
+        if isinstance(prior, Product):
+            # push_p broadcasts the whole product over the vector (types.jl:21): one rule for every component
+            self.discrete = tuple(bool(prior.discrete) for _ in factors)
+            self._desc = [(fam, int(prior.discrete), p0, p1, c0) for (fam, _, p0, p1, c0) in self._desc]
         self._c1 = [f.c1() if f.family == PRIOR_NEGBIN else None for f in factors]
 
     def cstruct(self, data_ptr: Optional[int]) -> Model:

@@ -224,6 +224,28 @@ class Factored:
         return "Factored(" + ", ".join(repr(p) for p in self.p) + ")"
 
 
+class Product(Factored):
+    """``product_distribution([...])`` of Distributions.jl in the ``prior`` position: a multivariate distribution over a
+    VECTOR of independent univariate components (test/runtests.jl:45).  Same densities and draws as :class:`Factored`;
+    what differs is ``push_p`` -- the reference broadcasts the WHOLE distribution over the vector
+    (``push_p(density::Distribution, p) = push_p.(Ref(density), p)``, src/abcdez_types.jl:21), so a product with any
+    continuous component casts every element to float, and only an all-discrete product rounds."""
+
+    def __init__(self, dists: Sequence[UnivariateDistribution]):
+        super().__init__(*tuple(dists))
+        self.discrete = all(d.discrete for d in self.p)
+
+    def rand(self, rng) -> list:
+        return [p.rand(rng) for p in self.p]
+
+    def __repr__(self) -> str:
+        return "product_distribution([" + ", ".join(repr(p) for p in self.p) + "])"
+
+
+def product_distribution(dists: Sequence[UnivariateDistribution]) -> Product:
+    return Product(dists)
+
+
 Prior = Union[UnivariateDistribution, Factored]
 
 
@@ -245,6 +267,8 @@ def push_p(density, p):
     continuous -> ``float(p)``; discrete -> ``round(Int, p)`` (ties to even);
     ``Factored`` / sequences broadcast.
     """
+    if isinstance(density, Product):           # the whole (multivariate) distribution is broadcast over the vector
+        return [int(_rint(float(v))) if density.discrete else float(v) for v in p]
     if isinstance(density, Factored):
         return tuple(push_p(d, v) for d, v in zip(density.p, p))
     if isinstance(p, (tuple, list)):

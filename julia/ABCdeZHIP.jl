@@ -104,6 +104,11 @@ nblob(s::DeviceSimulator, d) = s.blobs ? blobsize(s, d) : 0
 
 factors(p::Factored) = collect(p.p)
 factors(p::UnivariateDistribution) = [p]
+# product_distribution([...]) in the prior position (test/runtests.jl:45): the same descriptors; push_p broadcasts the WHOLE
+# distribution over the vector (types.jl:21), so every component follows the product's value support
+factors(p::Distributions.Product) = collect(p.v)
+pushrule(p, k, dflt) = dflt
+pushrule(p::Distributions.Product, k, dflt) = Int32(p isa DiscreteDistribution ? 1 : 0)
 const PAD = AbzPriorDim(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0)
 const lgam = Distributions.SpecialFunctions.loggamma
 descriptor(p::Normal) = AbzPriorDim(1, 0, p.μ, p.σ, -log(p.σ) - 0.5 * log(2π), 1 / p.σ, 0.0)
@@ -138,7 +143,7 @@ function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
     data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d)
     m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), nb,
                  ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), isempty(data) ? C_NULL : pointer(data),
-                 ntuple(k -> k <= d ? descriptor(fs[k]) : PAD, 64))
+                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 64))
     ctx = Ref{Ptr{Cvoid}}()
     GC.@preserve data begin
         if sim isa UserSimulator

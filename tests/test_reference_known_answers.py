@@ -109,8 +109,26 @@ def test_push_p_factored_and_vector():
     f = A.Factored(A.Normal(), A.DiscreteUniform())
     out = A.push_p(f, (2, 1.0))
     assert out == (2.0, 1) and isinstance(out[0], float) and isinstance(out[1], int)
-    out = A.push_p(A.Normal(), [2, 1])            # product_distribution analogue: broadcast over a vector
+    out = A.push_p(A.Normal(), [2, 1])            # a univariate distribution broadcast over a vector
     assert out == [2.0, 1.0] and all(isinstance(v, float) for v in out)
+    out = A.push_p(A.product_distribution([A.Normal(), A.Normal()]), [2, 1])      # test/runtests.jl:45
+    assert out == [2.0, 1.0] and all(isinstance(v, float) for v in out)
+    # the whole product is broadcast (types.jl:21): one continuous component makes every element a float ...
+    out = A.push_p(A.product_distribution([A.Normal(), A.DiscreteUniform(1, 10)]), [2, 3])
+    assert out == [2.0, 3.0] and all(isinstance(v, float) for v in out)
+    # ... and only an all-discrete product rounds (ties to even)
+    out = A.push_p(A.product_distribution([A.DiscreteUniform(1, 10), A.DiscreteUniform(1, 10)]), [2.5, 3.5])
+    assert out == [2, 4] and all(isinstance(v, int) for v in out)
+
+
+def test_product_distribution_prior_runs_like_factored(oracle):
+    """a product_distribution of the supported univariate families in the `prior` position uses the same device descriptors
+    as Factored: same run, bit for bit (continuous components), P as an [N, d] array"""
+    sim = A.MVNormal((1.0, 0.5, 0.2))
+    fams = [A.Normal(0, 1), A.Uniform(-3, 3), A.Normal(1, 2)]
+    a = A.abcdesmc(A.Factored(*fams), sim, 1.0, None, nparticles=600, verbose=False, rng=3, engine=oracle.oracle_engine)
+    b = A.abcdesmc(A.product_distribution(fams), sim, 1.0, None, nparticles=600, verbose=False, rng=3, engine=oracle.oracle_engine)
+    assert a.logZ == b.logZ and np.array_equal(a.P, b.P) and np.array_equal(a.Wns, b.Wns) and b.P.shape == (600, 3)
 
 
 def test_prior_descriptor_logpdf_matches_host(oracle):
