@@ -278,3 +278,46 @@ def test_plain_prior_path_is_chosen_only_for_unpadded_normal_rows(oracle):
         for k in range(3):
             assert hip.smc_swarm(3.0, g0, 1e-5) == orc.smc_swarm(3.0, g0, 1e-5)
         assert_equal(hip, orc, f"{len(fams)} dims")
+
+
+@pytest.mark.parametrize("name", ["normal1d", "quad2d_inf", "socks"])
+def test_narrow_rows_keep_one_slot_parity_over_the_prefix(oracle, name):
+    """rows of one or two doubles are double-buffered (include/abcdez_hip.h): after every prologue, resampling and sweep all
+    positions of the alive prefix name the same slot -- the invariant that lets the sweep take its donors' slot from the own
+    position's bit -- and a rejected particle's row is present in BOTH slots right after a sweep"""
+    prior, sim, eps_target = models()[name]
+    N = 5000
+    spec = A.ModelSpec(prior, sim, seed=21)
+    assert spec.ld <= 2
+    hip = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    orc = PopulationEngine(spec, N, ops=oracle.OracleOps(spec), storage="packed")
+    for e in (hip, orc):
+        e.init_population()
+        e.reset_weights()
+
+    def prefix_bits(e):
+        w = e.bits[e.bc].cpu().numpy().astype(np.uint32)
+        return ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[: e.n_alive]
+
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps, eps_k, resampled = math.inf, math.inf, 0
+    for gen in range(14):
+        want = orc.smc_prologue(0.8, eps, eps_target, eps_k, 0.5 * N)
+        assert hip.smc_prologue(0.8, eps, eps_target, eps_k, 0.5 * N) == want
+        eps, _, ess, n_alive, _ = want
+        if n_alive > 0 and ess < 0.5 * N:
+            hip.smc_resample(); orc.smc_resample()
+            resampled += 1
+        if hip.n_alive < 3:
+            break
+        hip.alive_compact(); orc.alive_compact()
+        b = prefix_bits(hip)
+        assert b.min() == b.max(), f"gen {gen}: the prefix is split over both slots before the sweeps"
+        for k in range(2):
+            assert hip.smc_swarm(eps, g0, 1e-5) == orc.smc_swarm(eps, g0, 1e-5)
+            b2 = prefix_bits(hip)
+            assert b2.min() == b2.max() and b2[0] != b[0], f"gen {gen} sweep {k}: every swept position moves to its other slot"
+            b = b2
+        assert_equal(hip, orc, f"gen {gen}")
+        eps_k = eps
+    assert resampled >= 1
