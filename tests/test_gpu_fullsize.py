@@ -523,3 +523,21 @@ def test_config3_full_run_logz_and_posterior():
     assert abs(m.mean() - m2.mean()) < 0.01 and abs(r.logZ - r2.logZ) < 0.03
     print(f"config3 full run: iters={r.iters} nsims={r.nsims} logZ={r.logZ:.5f} (exact {gold['Z_mvn32_eps6']['logZ']:.5f}) "
           f"posterior mean per component={m.mean():.5f}")
+
+
+def test_reference_minimal_example_script():
+    """examples/minimal_example.py = the reference's examples/minimal_example.jl statement for statement: posteriors,
+    evidences and model probabilities against the example's own analytic values (finite-eps evidence: within 10 %)"""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "minimal_example.py")
+    spec = importlib.util.spec_from_file_location("minimal_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(nparticles=200_000, verbose=False)
+    for m in ("1", "2"):
+        mean, std = out["posterior" + m]
+        mean_x, std_x = out["posterior" + m + "_exact"]
+        assert abs(mean - mean_x) < 0.02 and abs(std - std_x) < 0.02          # eps = 0.3 widens the posterior slightly
+        assert abs(out["evidence" + m] / out["evidence" + m + "_expected"] - 1.0) < 0.10
+    assert abs(out["mposterior1"] - out["mposterior1_exact"]) < 0.02
+    assert abs(out["mposterior1"] + out["mposterior2"] - 1.0) < 1e-12
