@@ -375,7 +375,7 @@ struct ParticleDraws {
     if constexpr (L >= 4) {
       const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
       double sn, cs;
-      abz_sincos2pi_tab(abz_u01_52(w.w1), T, &sn, &cs);
+      abz_sincos2pi_tab_w(w.w1, T, &sn, &cs);
       const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
       const double g_ = gamma0 * (1.0 + z0 * gsig);
       *g = __shfl(g_, 1, L);

@@ -228,11 +228,15 @@ static const abz_tables abz_tables_host = ABZ_TABLES_INIT;   /* host copy; kerne
  * top 7 mantissa bits; r = z c_i - 1 (one fma), |r| < 3.9e-3; log z = T_i + log1p(r), Taylor to
  * r^7.  <= 2 ulp (tests/test_spec_math.py).                                                 */
 ABZ_HD double abz_log_tab(double x, const abz_tables* T) {
+  /* tmp = bits(x) - OFF; k = (int64) tmp >> 52; i = (tmp >> 45) & 127; z = bits(x) - (tmp & 0xFFF0...0) -- written on the two
+   * 32-bit words (OFF's low word is zero, so neither subtraction borrows): the compilers otherwise carry a 64-bit
+   * subtract and convert k as a 64-bit integer, 6 instructions per call on the device for the same values */
   const uint64_t ix = abz_d2u(x);
-  const uint64_t tmp = ix - ABZ_LOG_TAB_OFF;
-  const int k = (int)((int64_t)tmp >> 52);
-  const uint32_t i = (uint32_t)(tmp >> (52 - ABZ_LOG_TAB_BITS)) & (ABZ_LOG_TAB_N - 1);
-  const double z = abz_u2d(ix - (tmp & 0xFFF0000000000000ull));
+  const uint32_t xh = (uint32_t)(ix >> 32);
+  const uint32_t th = xh - (uint32_t)(ABZ_LOG_TAB_OFF >> 32);
+  const int k = (int)((int32_t)th >> 20);
+  const uint32_t i = (th >> (20 - ABZ_LOG_TAB_BITS)) & (ABZ_LOG_TAB_N - 1);
+  const double z = abz_u2d(((uint64_t)(xh - (th & 0xFFF00000u)) << 32) | (uint32_t)ix);
   const double* e = T->logt[i];
   const double r = abz_fma(z, e[0], -1.0);
   double p = 0x1.2492492492492p-3;            /*  1/7 */
@@ -264,6 +268,26 @@ ABZ_HD void abz_sincos2pi_tab(double u, const abz_tables* T, double* sn, double*
   *cs = C + abz_fma(-S, sd, C * cm1);
 }
 
+/* the same for u = (w >> 12) 2^-52 taken straight from a random word: t = 256 u is built in [256, 512) and the integer
+ * part is read off the bits of t + 0x1.8p52 -- two instructions fewer than abz_sincos2pi_tab(abz_u01_52(w)) for the same values
+ * (256 u is exact either way; (t256 - 256) + 0x1.8p52 and t256 + (0x1.8p52 - 256) round the same real number) */
+ABZ_HD void abz_sincos2pi_tab_w(uint64_t w, const abz_tables* T, double* sn, double* cs) {
+  const double t256 = abz_u2d(0x4070000000000000ull | (w >> 12));
+  const double t = t256 - 256.0;
+  const double tc = t256 + (0x1.8p52 - 256.0);
+  const double tr = tc - 0x1.8p52;                      /* nearest integer, 0..256 */
+  const int j = (int)((uint32_t)abz_d2u(tc) & (ABZ_SC_TAB_N - 1));
+  const double dl = (t - tr) * 0x1.921fb54442d18p-6;    /* 2 pi / 256 */
+  const double z = dl * dl;
+  const double ps = abz_fma(abz_fma(-0x1.a01a01a01a01ap-13, z, 0x1.1111111111111p-7), z, -0x1.5555555555555p-3);
+  const double pc = abz_fma(abz_fma(-0x1.6c16c16c16c17p-10, z, 0x1.5555555555555p-5), z, -0.5);
+  const double sd = abz_fma(dl * z, ps, dl);
+  const double cm1 = z * pc;
+  const double S = T->sc[j][0], C = T->sc[j][1];
+  *sn = S + abz_fma(S, cm1, C * sd);
+  *cs = C + abz_fma(-S, sd, C * cm1);
+}
+
 /* sqrt(x) for x in the normal range far from over/underflow (here: -2 log u in [2e-16, 74]).
  * Device: v_rsq_f64 seed + the two Goldschmidt/Newton steps and two residual corrections the
  * compiler's own correctly rounded expansion uses, minus its range scaling.  Host: sqrt().  */
@@ -286,10 +310,9 @@ ABZ_HD double abz_sqrt_pn(double x) {
 /* Box-Muller: one Philox block -> two independent N(0,1).  (randn, smc:128)       */
 ABZ_HD void abz_normal_pair(abz_u64x2 w, const abz_tables* T, double* z0, double* z1) {
   const double u1 = abz_u01_open(w.w0);
-  const double u2 = abz_u01_52(w.w1);
   const double r = abz_sqrt_pn(-2.0 * abz_log_tab(u1, T));
   double sn, cs;
-  abz_sincos2pi_tab(u2, T, &sn, &cs);
+  abz_sincos2pi_tab_w(w.w1, T, &sn, &cs);                 /* == abz_sincos2pi_tab(abz_u01_52(w.w1), ...) */
   *z0 = r * cs;
   *z1 = r * sn;
 }
