@@ -46,7 +46,7 @@ struct abcdez_ctx {
   /* min / max slot bank the NEXT abcdemc sweep reduces into (the sweep resets the other one) */
   int mm_bank = 0;
   /* blob stamps of the current / next generation (abcdez_ctx_set_stamps); null = blobs off.  The launchers that
-   * take (logpi, nlogpi)-style pairs use (stamp_cur, stamp_nxt) alongside; row-store calls update stamp_cur in place */
+   * take (logpi, nlogpi)-style pairs use (stamp_cur, stamp_nxt) alongside; the packed sweeps update stamp_cur in place */
   uint64_t* stamp_cur = nullptr;
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
@@ -95,7 +95,7 @@ enum {
   ABZ_S_SEL_NBUF = 15, ABZ_S_SEL_PAD = 16, ABZ_S_SEL_HLO = 17, ABZ_S_SEL_HHI = 18, ABZ_S_SEL_BIN = 19,
   ABZ_S_SEL_END = 20,
   ABZ_S_INITBAD = 20,
-  ABZ_S_RACC = 21, ABZ_S_RSIM = 22,      /* counters of the replayed ranks (sharded row store) */
+  ABZ_S_RACC = 21, ABZ_S_RSIM = 22,      /* counters of the replayed ranks (sharded packed population) */
   ABZ_S_MCGT = 23, ABZ_S_MCMIN = 24, ABZ_S_MCMAX = 25,
   ABZ_S_PART_H = 26, ABZ_S_PART_F = 27, ABZ_S_PART_ERR = 28,
   ABZ_S_EPS = 29, ABZ_S_QVAL = 30,       /* fused prologue: eps of smc:301 and the quantile behind it (f64) */   /* partition: #holes, #fillers (must agree), error flag */   /* abcdemc sweep: #(Ds > eps_target), extrema of the new distances */

@@ -490,7 +490,7 @@ def main():
                 "step_includes": ("extrema(Ds), eps-quantile, reweight, ESS, partition (one call), resample when ESS < N/2, "
                                   "<= Kmcmc sweeps with their counter read-backs (smc:301-364)") if cfg["kind"] == "smc" else
                                  "rank pass (while max Ds > eps_target), one sweep with nsim / completion / extrema folded in (mc:140-161)",
-                "parallelism": (f"particle-shard x{world}, replicated row store: per-sweep accept-flag all-gather + replay, "
+                "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
             "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate),

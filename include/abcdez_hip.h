@@ -86,7 +86,7 @@ ABCDEZ_API int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double
  * particle, RNG epoch, init-or-sweep stream) of the simulator call that produced it (abz_stamp, abcdez_spec.h) --
  * written at init and on every accept, copied / gathered exactly like Ds and blobs in the reference (smc:99,
  * 337-340).  abcdez_ctx_set_stamps names the stamp arrays of the current and the next generation (u64[N] each;
- * the (logpi, nlogpi)-style entry points use them alongside, the row-store ones update stamp_cur in place; NULL,
+ * the (logpi, nlogpi)-style entry points use them alongside, the packed sweeps update stamp_cur in place; NULL,
  * NULL = off).  abcdez_blob_eval re-runs that one simulator call for each of N particles on dense current rows
  * theta[N][ld] and writes blob[N][width] (abcdez_blob_width: ld for the MVN simulator, n_blob otherwise) and the
  * distance of the re-run, which must equal the stored distance bit for bit.                                    */
