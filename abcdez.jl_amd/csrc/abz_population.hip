@@ -199,10 +199,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void publish_kernel(const unsigned long 
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(host + ABZ_S_N, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int abz_publish(abcdez_ctx* ctx, int nwords) {
+int abz_publish_launch(abcdez_ctx* ctx, int nwords, unsigned long long* seq_out) {
   const unsigned long long seq = ++ctx->pub_seq;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(ABZ_BLOCK), 0, ctx->stream, ctx->d_scal, ctx->h_scal_dev, nwords, seq);
   ABZ_HIP_CHECK(hipGetLastError());
+  *seq_out = seq;
+  return 0;
+}
+/* waits for THAT publish kernel only: work enqueued behind it may still be running when this returns */
+int abz_publish_wait(abcdez_ctx* ctx, int nwords, unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   while (__atomic_load_n(ctx->h_scal + ABZ_S_N, __ATOMIC_ACQUIRE) != seq) {
@@ -217,6 +222,11 @@ int abz_publish(abcdez_ctx* ctx, int nwords) {
     }
   }
   return 0;
+}
+int abz_publish(abcdez_ctx* ctx, int nwords) {
+  unsigned long long seq = 0;
+  if (int rc = abz_publish_launch(ctx, nwords, &seq)) return rc;
+  return abz_publish_wait(ctx, nwords, seq);
 }
 static int read_scalars(abcdez_ctx* ctx) {        /* the plain scalars only; the counter slots are read by abz_api.hip */
   return abz_publish(ctx, ABZ_S_SCALARS);
@@ -1258,9 +1268,15 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   if (rc) return rc;
   rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS));
   if (rc) return rc;
+  /* everything the host needs is known here: the scalars are published BEFORE the partition is enqueued, and the host returns
+   * (and enqueues the generation's sweeps) while the partition kernels are still running -- the round trip hides behind them.
+   * A partition error (flags that do not describe a prefix) is reported by the next counter read-back instead. */
+  unsigned long long seq = 0;
+  rc = abz_publish_launch(ctx, ABZ_S_SCALARS, &seq);
+  if (rc) return rc;
   rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min);
   if (rc) return rc;
-  rc = read_scalars(ctx);
+  rc = abz_publish_wait(ctx, ABZ_S_SCALARS, seq);
   if (rc) return rc;
   rc = select_finish(ctx, j - 1, nullptr, nullptr, nullptr);
   if (rc) return rc;
@@ -1272,7 +1288,6 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   out[5] = f64_from_order_key(ctx->h_scal[ABZ_S_MAX]);
   *n_alive = (int64_t)scal_f64(ctx, ABZ_S_NALIVE);
   *partitioned = !(*n_alive > 0 && out[3] < ess_min);
-  if (ctx->h_scal[ABZ_S_PART_ERR]) { abz_set_error("smc_prologue_packed: the alive flags did not describe a prefix of length n_prev"); return -1; }
   return 0;
 }
 
