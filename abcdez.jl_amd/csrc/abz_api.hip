@@ -383,6 +383,7 @@ int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp
 
 int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
   ABZ_REQUIRE(ctx && theta && logpi && delta, "init: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= ABZ_MAX_N, "init: range out of bounds");
   ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_INITBAD, 0, 8, ctx->stream));
   int rc = abz_launch_init(ctx, theta, logpi, delta, i0, n);
@@ -397,6 +398,7 @@ int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, in
 int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
                          uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
   ABZ_REQUIRE(ctx && alive && bits && bits_other && slot0 && slot1 && logpi && delta && wns, "smc_partition: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 0 <= n_new && n_new <= n_prev && n_prev <= N, "smc_partition: need 0 <= n_new <= n_prev <= N");
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_partition: the two bit arrays / slots must differ");
   return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns, nullptr, 0.0);
@@ -428,6 +430,7 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
                             int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags,
                             double eps, double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && delta, "smc_swarm_packed: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_packed: pass both counters or neither");
   /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
@@ -450,6 +453,19 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   return 0;
 }
 
+/* Arms the NEXT abcdez_smc_sweeps_packed call: behind its last sweep it also enqueues the first third of the next generation's
+ * prologue (extrema, rank select, eps of smc:301 with eps_prev = the sweeps' eps and n_prev = their n_alive), which only reads the
+ * distances and flags -- so the device works on it while the host reads the sweeps' counters and applies its stop rules.  A
+ * following abcdez_smc_prologue_packed with the same arguments starts at the reweight; any other call discards the work. */
+int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double alpha, double eps_target) {
+  ABZ_REQUIRE(ctx && delta && alive, "smc_select_ahead: null argument");
+  ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && alpha >= 0.0 && alpha <= 1.0 && eps_target >= 0.0, "smc_select_ahead: bad argument");
+  ctx->ahead = abz_ahead{};
+  ctx->ahead.armed = true;
+  ctx->ahead.delta = delta; ctx->ahead.alive = alive; ctx->ahead.N = N; ctx->ahead.alpha = alpha; ctx->ahead.eps_target = eps_target;
+  return 0;
+}
+
 /* The sweeps of one generation (smc:336-353) in ONE enqueue and ONE read-back: sweep k+1 is launched behind a device-side
  * evaluation of the early-exit test `sum(naccs) / n_alive >= Kmcmc_min` (smc:352) on the counters of sweeps 1..k, and
  * returns at once when it holds.  Same arithmetic as the host's test (one IEEE division of exactly represented integers). */
@@ -462,6 +478,8 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   ABZ_REQUIRE(slot0 != slot1 && bits_a != bits_b, "smc_sweeps_packed: the two slots / bit arrays must differ");
   ABZ_REQUIRE(kmcmc_min >= 0.0, "smc_sweeps_packed: Kmcmc_min must not be negative");
   const unsigned long long base_acc = ctx->cnt_prev[ABZ_C_NACC], base_sim = ctx->cnt_prev[ABZ_C_NSIM];
+  const abz_ahead armed = ctx->ahead;
+  ctx->ahead = abz_ahead{};
   for (int k = 0; k < k_max; ++k) {
     uint32_t* in = (k & 1) ? bits_b : bits_a;
     uint32_t* out = (k & 1) ? bits_a : bits_b;
@@ -474,7 +492,16 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
       if (rc) return rc;
     }
   }
-  if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
+  unsigned long long pub = 0;
+  if (int rc = abz_publish_launch(ctx, ABZ_S_N, &pub)) return rc;
+  if (armed.armed && armed.delta == delta && n_alive <= armed.N) {
+    abz_ahead a = armed;
+    a.n_prev = n_alive; a.eps_prev = eps;
+    if (int rc = abz_prologue_select_enqueue(ctx, a.delta, a.alive, a.N, a.n_prev, a.alpha, a.eps_prev, a.eps_target, &a.j)) return rc;
+    a.armed = false; a.valid = true;
+    ctx->ahead = a;
+  }
+  if (int rc = abz_publish_wait(ctx, ABZ_S_N, pub)) return rc;
   /* totals of the two counter classes now; how many sweeps ran: the test held after sweep `GRP_DONE` (stop flag set by one of
    * the k_max - 1 checks), or never -- then the last sweep ran too */
   unsigned long long tot_acc = 0, tot_sim = 0;
@@ -511,6 +538,7 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
                              int64_t skip_hi, double* slot0, double* slot1, double* logpi, const uint8_t* flags,
                              double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags && nacc && nsim, "smc_replay_packed: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
   ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
@@ -531,6 +559,7 @@ int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int
                                       double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
   ABZ_REQUIRE(ctx && inds && bits && bits_other && slot0 && slot1 && logpi && delta && nlogpi && ndelta && wns && alive,
               "smc_resample_gather_packed: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_packed: N out of range");
   ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1 && bits != bits_other,
               "smc_resample_gather_packed: in/out arrays must differ");
@@ -548,6 +577,7 @@ int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const
 int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
                         double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
   ABZ_REQUIRE(ctx && delta && wns && alive && wnorm && ess && n_alive, "smc_reweight: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_reweight: N out of range");
   ABZ_REQUIRE(eps_old >= 0.0 && eps_new >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
   return abz_reweight_impl(ctx, delta, wns, alive, N, eps_old, eps_new, wnorm, ess, n_alive);
@@ -578,6 +608,7 @@ int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uin
 int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t n_alive_hint,
                           double p, double* q, double* xj, double* xj1) {
   ABZ_REQUIRE(ctx && delta && alive && q, "quantile_alive: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "quantile_alive: N out of range");
   ABZ_REQUIRE(p >= 0.0 && p <= 1.0, "quantile_alive: p must be in [0, 1]");
   int64_t n = n_alive_hint, n_le;
@@ -628,6 +659,7 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
                     uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax) {
   ABZ_REQUIRE(ctx && order && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
               "mc_swarm: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
@@ -676,6 +708,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
                                double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket) {
   ABZ_REQUIRE(ctx && order && sorted_delta && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && ticket,
               "mc_generation_async: null argument");
+  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
   ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0 && eps_target >= 0.0, "mc_generation_async: need 0 <= alpha <= 1 and eps_target >= 0");

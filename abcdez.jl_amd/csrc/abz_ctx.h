@@ -15,6 +15,16 @@
 #define ABZ_MC_RING 8       /* abcdemc generations in flight (abcdez_mc_generation_async) */
 #define ABZ_RING_WORDS 8    /* per generation: total #(Ds > eps_target), total nsim (cumulative), min key, max key, eps_pop, -, -, ticket + 1 */
 
+/* abcdez_smc_select_ahead: armed = start the next generation's select behind the next grouped sweeps; valid = it has been
+ * enqueued for exactly these arguments and nothing has touched the distances / flags since */
+struct abz_ahead {
+  bool armed = false, valid = false;
+  const double* delta = nullptr;
+  const uint8_t* alive = nullptr;
+  int64_t N = 0, n_prev = 0, j = 0;
+  double alpha = 0.0, eps_prev = 0.0, eps_target = 0.0;
+};
+
 struct abcdez_ctx {
   int device = 0;
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
@@ -24,6 +34,7 @@ struct abcdez_ctx {
   double* d_data = nullptr;
   abz_tables* d_tables = nullptr;
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
+  abz_ahead ahead;
   bool prior_plain = false;       /* all real dimensions continuous Normal priors (abz_api.hip)                 */
   /* device scalars + pinned host mirror */
   unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
@@ -148,6 +159,10 @@ void abz_fold_counters(abcdez_ctx*);
  * kernel writes them straight into the pinned host mirror and stores a sequence word last (system-scope release); the
  * host polls that word.  Returns when everything enqueued before it has completed.                                  */
 int abz_publish(abcdez_ctx* ctx, int nwords);
+int abz_publish_launch(abcdez_ctx* ctx, int nwords, unsigned long long* seq_out);
+int abz_publish_wait(abcdez_ctx* ctx, int nwords, unsigned long long seq);
+int abz_prologue_select_enqueue(abcdez_ctx* ctx, const double* delta_all, const uint8_t* alive, int64_t N, int64_t n_prev,
+                                double alpha, double eps_prev, double eps_target, int64_t* j_out);
 void abz_fold_minmax(abcdez_ctx*, int bank, double* lo, double* hi);
 int abz_jit_build(abcdez_ctx*, const char* user_source);
 void abz_jit_destroy(abcdez_ctx*);

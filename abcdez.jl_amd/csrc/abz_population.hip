@@ -1248,12 +1248,11 @@ void abz_fold_minmax(abcdez_ctx* ctx, int bank, double* lo, double* hi) {
  *   partition of the packed population, unless ESS < ess_min  (then the host resamples: smc:323-326)
  * The host still owns the schedule: it passes the previous eps and the target in and gets eps, wnorm (for logZ), ESS and
  * n_alive back.  Four blocking read-backs become one.                                                            */
-int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N, int64_t n_prev, double* wns, uint8_t* alive,
-                             double alpha, double eps_prev, double eps_target, double eps_k_old, double ess_min,
-                             const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
-                             double* delta_rw, double* out /* eps, q, wnorm, ess, lo, hi */, int64_t* n_alive,
-                             int32_t* partitioned) {
-  int rc = 0;
+/* the first third of the prologue -- extrema(Ds) over all N, the rank select over the alive prefix, eps of smc:301 -- reads the
+ * distances and the alive flags and writes only the select's scratch and scalars: it can be enqueued as soon as the last sweep
+ * of a generation is (abcdez_smc_select_ahead), before the host has decided that there will be a next generation */
+int abz_prologue_select_enqueue(abcdez_ctx* ctx, const double* delta_all, const uint8_t* alive, int64_t N, int64_t n_prev,
+                                double alpha, double eps_prev, double eps_target, int64_t* j_out) {
   /* Julia Statistics.quantile, type 7, over the n_prev alive distances: h = (n-1) p + 1, j = clamp(floor(h), 1, n-1), g = h - j */
   const int64_t n = n_prev;
   const double h = (double)(n - 1) * alpha + 1.0;
@@ -1264,8 +1263,25 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   QsTail tail{};
   tail.eps_on = 1; tail.single = n == 1 ? 1 : 0; tail.k0 = (unsigned long long)(j - 1); tail.g = g;
   tail.eps_prev = eps_prev; tail.eps_target = eps_target;
-  rc = select_enqueue(ctx, delta_all, alive, n_prev, j - 1, &tail, N);   /* + extrema(Ds) over all N, + eps of smc:301 */
-  if (rc) return rc;
+  *j_out = j;
+  return select_enqueue(ctx, delta_all, alive, n_prev, j - 1, &tail, N);   /* + extrema(Ds) over all N, + eps of smc:301 */
+}
+int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N, int64_t n_prev, double* wns, uint8_t* alive,
+                             double alpha, double eps_prev, double eps_target, double eps_k_old, double ess_min,
+                             const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
+                             double* delta_rw, double* out /* eps, q, wnorm, ess, lo, hi */, int64_t* n_alive,
+                             int32_t* partitioned) {
+  int rc = 0;
+  int64_t j = 0;
+  const abz_ahead& ah = ctx->ahead;
+  if (ah.valid && ah.delta == delta_all && ah.alive == alive && ah.N == N && ah.n_prev == n_prev && ah.alpha == alpha &&
+      ah.eps_prev == eps_prev && ah.eps_target == eps_target) {
+    j = ah.j;                         /* the select (and the extrema, and eps) were enqueued behind the sweeps of the generation before */
+  } else {
+    rc = abz_prologue_select_enqueue(ctx, delta_all, alive, N, n_prev, alpha, eps_prev, eps_target, &j);
+    if (rc) return rc;
+  }
+  ctx->ahead.valid = false;
   rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS));
   if (rc) return rc;
   /* everything the host needs is known here: the scalars are published BEFORE the partition is enqueued, and the host returns

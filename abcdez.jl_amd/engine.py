@@ -150,6 +150,10 @@ class HipOps:
             gsig, sweep0, k_max, kmcmc_min, nacc, nsim, C.byref(done)))
         return list(nacc[:done.value]), list(nsim[:done.value]), done.value
 
+    def smc_select_ahead(self, delta, alive, alpha, eps_target):
+        """arm the next grouped sweeps: they also start the next generation's select (include/abcdez_hip.h)"""
+        _lib.check(self.lib, self.lib.abcdez_smc_select_ahead(self.ctx, _ptr(delta), _ptr(alive), delta.numel(), alpha, eps_target))
+
     def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_replay_packed(
@@ -616,7 +620,7 @@ class PopulationEngine:
         self._delta_stale = True
         return counts                                    # global (nacc, nsim), counted from the flags
 
-    def smc_sweeps(self, eps: float, gamma0: float, gsig: float, Kmcmc: int, Kmcmc_min: float):
+    def smc_sweeps(self, eps: float, gamma0: float, gsig: float, Kmcmc: int, Kmcmc_min: float, next_prologue=None):
         """The sweeps of one generation, `for i in 1:Kmcmc ... (sum(naccs) / n_alive >= Kmcmc_min) && break`
         (smc:336-353) -> (naccs per sweep, nsims per sweep, Ki).  On an unsharded HIP population the whole group is one
         library call with the test of smc:352 evaluated on the device between the sweeps (one host synchronisation);
@@ -627,6 +631,10 @@ class PopulationEngine:
             self._stream()
             self._bind_stamps()
             cur = self.buf[self.cur]
+            if next_prologue is not None and hasattr(self.ops, "smc_select_ahead"):
+                # (alpha, eps_target) of the next smc_prologue: its select is enqueued behind these sweeps (same results;
+                # the device works on it while the host reads the counters and applies its stop rules)
+                self.ops.smc_select_ahead(cur[2], self.alive, next_prologue[0], next_prologue[1])
             naccs, nsims, Ki = self.ops.smc_sweeps_packed(self.bits[self.bc], self.bits[1 - self.bc], self.n_alive,
                                                           self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
                                                           self.sweep, Kmcmc, Kmcmc_min)

@@ -227,7 +227,10 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             eng.alive_compact()
             # for i in 1:Kmcmc: sweep; naccs, nsims; (naccs / n_alive >= Kmcmc_min) && (Ki = i; break)   smc:336-353 (S2, S3)
             # -- one engine call; on the HIP population the test of :352 runs on the device between the sweeps
-            naccs_i, nsims_i, Ki = eng.smc_sweeps(ϵ, γ0, γσ, Kmcmc, Kmcmc_min)
+            # (next_prologue: unless this is known to be the last generation, the engine may start the next generation's
+            # quantile select behind these sweeps -- it only reads Δs; the values it will be asked for are α and ϵ_target)
+            naccs_i, nsims_i, Ki = eng.smc_sweeps(ϵ, γ0, γσ, Kmcmc, Kmcmc_min,
+                                                   next_prologue=(α, ϵ_target) if ϵ > ϵ_target and iters < max_iters else None)
             naccs += sum(naccs_i)
             nsims += sum(nsims_i)
             updates += n_alive * Ki

@@ -93,7 +93,8 @@ class Generation:
             n_alive = e.N
             self.resamples += 1
         e.alive_compact()
-        naccs_i, nsims_i, Ki = e.smc_sweeps(self.eps, self.gamma0, 1e-5, self.Kmcmc, self.Kmcmc_min)   # smc:336-353
+        naccs_i, nsims_i, Ki = e.smc_sweeps(self.eps, self.gamma0, 1e-5, self.Kmcmc, self.Kmcmc_min,     # smc:336-353
+                                            next_prologue=(self.alpha, self.eps_target) if self.eps > self.eps_target else None)
         self.naccs += sum(naccs_i)
         self.nsims += sum(nsims_i)
         self.updates += n_alive * Ki

@@ -154,6 +154,14 @@ ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, ui
  * the host's) and the sweeps enqueued behind a test that held do nothing.  Returns the per-sweep counters
  * nacc[0 .. k_max), nsim[0 .. k_max) (zero for sweeps that did not run) and *k_done = Ki of :352; the current bit array
  * afterwards is bits_b when *k_done is odd, bits_a when it is even.                                                */
+/* Arms the NEXT abcdez_smc_sweeps_packed: behind its last sweep it also enqueues the first third of the next generation's
+ * prologue -- extrema(Ds) (smc:364), the rank select and eps = max(min(quantile, eps), eps_target) (smc:301) with eps_prev = the
+ * sweeps' eps and n_prev = their n_alive -- which only reads the distances and the alive flags, so the device works on it while
+ * the host reads the sweeps' counters and applies its stop rules (smc:375-376).  An abcdez_smc_prologue_packed that follows with
+ * the same (delta, alive, N, n_prev, alpha, eps_prev, eps_target) starts at the reweight; every other call discards the work.
+ * Results are the same either way. */
+ABCDEZ_API int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double alpha,
+                                       double eps_target);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,

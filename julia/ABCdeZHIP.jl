@@ -227,8 +227,11 @@ function smc_swarm!(e, ϵ, γ0, γσ)                                           
 end
 # the sweeps of one generation, `for i in 1:Kmcmc ... (sum(naccs) / n_alive ≥ Kmcmc_min) && break` (smc:336-353), in one
 # call: the test of :352 runs on the device between the sweeps -> (Σnaccs, Σnsims, Ki); Kmcmc ≤ 16 per call
-function smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min)
+function smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min; next_prologue=nothing)
     nacc = zeros(Int64, Kmcmc); nsim = zeros(Int64, Kmcmc); done = Ref(Int32(0)); bind_stamps!(e)
+    # (α, ϵ_target) of the next prologue!: its quantile select is enqueued behind these sweeps (it only reads Δs; same results)
+    next_prologue === nothing || check(ccall((:abcdez_smc_select_ahead, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64),
+                                             e.ctx, e.delta[e.cur], e.alive, e.N, next_prologue[1], next_prologue[2]))
     check(ccall((:abcdez_smc_sweeps_packed, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
                  Float64, Float64, Float64, UInt32, Int32, Float64, Ptr{Int64}, Ptr{Int64}, Ref{Int32}),
@@ -312,7 +315,8 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                 resample!(e); ess = get_ess(e); n_alive = nparticles
             end
             if n_alive ≥ 3 && Kmcmc ≤ 16
-                naccs, nsim, Ki = smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min)                # smc:336-353, one call
+                naccs, nsim, Ki = smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min;               # smc:336-353, one call
+                                              next_prologue = ϵ > ϵ_target ? (α, ϵ_target) : nothing)
                 nsims += nsim
             elseif n_alive ≥ 3
                 for i in 1:Kmcmc                                                            # smc:336-353

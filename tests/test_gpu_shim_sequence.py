@@ -118,9 +118,11 @@ class ShimEngine:
         self.bc = 1 - self.bc
         return nacc.value, nsim.value
 
-    def smc_sweeps(self, eps, g0, gs, Kmcmc, Kmcmc_min):
+    def smc_sweeps(self, eps, g0, gs, Kmcmc, Kmcmc_min, next_prologue=None):
         nacc, nsim, done = (C.c_int64 * Kmcmc)(), (C.c_int64 * Kmcmc)(), C.c_int32()
         self.bind_stamps()
+        if next_prologue is not None:
+            self.ck(self.lib.abcdez_smc_select_ahead(self.ctx, self.delta[self.cur], self.alive, self.N, next_prologue[0], next_prologue[1]))
         self.ck(self.lib.abcdez_smc_sweeps_packed(
             self.ctx, self.bits[self.bc], self.bits[1 - self.bc], self.n_alive, self.slot[0], self.slot[1],
             self.logpi[self.cur], self.delta[self.cur], eps, g0, gs, self.sweep, Kmcmc, Kmcmc_min, nacc, nsim, C.byref(done)))
@@ -225,7 +227,7 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
             ess = e.get_ess()
             n_alive = N
         if n_alive >= 3 and Kmcmc <= 16:
-            naccs, nsim, Ki = e.smc_sweeps(eps, g0, gs, Kmcmc, Kmcmc_min)
+            naccs, nsim, Ki = e.smc_sweeps(eps, g0, gs, Kmcmc, Kmcmc_min, (alpha, eps_target) if eps > eps_target else None)
             nsims += nsim
         elif n_alive >= 3:
             for i in range(1, Kmcmc + 1):
