@@ -29,7 +29,7 @@ for gen in range(40):
         timed("resample", e.smc_resample); n_alive = N
     timed("compact", e.alive_compact)
     if GROUP:
-        timed("sweep", e.smc_sweeps, eps, g0, 1e-5, 3, 1.0)
+        timed("sweep", e.smc_sweeps, eps, g0, 1e-5, 3, 1.0, (0.95, 6.0))     # + the next generation's select enqueued ahead
     else:
         for k in range(3):
             timed("sweep", e.smc_swarm, eps, g0, 1e-5)
