@@ -343,6 +343,7 @@ int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
   if (on && !ctx->ev[0])
     for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreate(&e));
   ctx->timing = on != 0;
+  ctx->timing_first_only = on == 2;    /* 2: of a group of sweeps only the first is bracketed (each event pair costs ~6 us of queue time) */
   ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_head = ctx->ev_tail;
   return 0;
 }
@@ -483,9 +484,12 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   for (int k = 0; k < k_max; ++k) {
     uint32_t* in = (k & 1) ? bits_b : bits_a;
     uint32_t* out = (k & 1) ? bits_a : bits_b;
+    const bool timing = ctx->timing;
+    if (k > 0 && ctx->timing_first_only) ctx->timing = false;
     int rc = abz_launch_smc_swarm_packed(ctx, in, out, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, slot1, logpi, delta,
                                          nullptr, eps, gamma0, gamma_sigma, sweep0 + (uint32_t)k, 1,
                                          k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
+    ctx->timing = timing;
     if (rc) return rc;
     if (k + 1 < k_max) {             /* nothing is decided after the last sweep: its counters are the totals the host reads anyway */
       rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min);

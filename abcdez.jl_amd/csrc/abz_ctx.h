@@ -61,7 +61,7 @@ struct abcdez_ctx {
   uint64_t* stamp_cur = nullptr;
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
-  bool timing = false;
+  bool timing = false, timing_first_only = false;
   long long ev_head = 0, ev_tail = 0;             /* FIFO of sweeps timed but not yet read: pair k lives in slot k % ABZ_GROUP_MAX */
   hipEvent_t ev[2 * ABZ_GROUP_MAX] = {nullptr};
   long long ev_units[ABZ_GROUP_MAX] = {0};

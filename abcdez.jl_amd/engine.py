@@ -86,7 +86,8 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
         return ld.value, L.value, Cc.value
 
-    def set_timing(self, on: bool):
+    def set_timing(self, on):
+        """True / 1: every sweep launch; 2: the first sweep of every grouped call; False: off"""
         _lib.check(self.lib, self.lib.abcdez_ctx_set_timing(self.ctx, int(on)))
 
     def get_timing(self):

@@ -302,6 +302,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
                    "/ average launch time / 8 TB/s",
         "bytes_read_per_update": b_read, "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches,
         "kernel_updates_per_s": rate,
+        "launches_are": "abcdesmc: the first sweep of every timed generation (its siblings run on the same alive count); abcdemc: every sweep",
         "total_bytes_frac": to_gbs(b_read + b_write) / HBM_PEAK_GBS,
         "total_bytes_note": f"SURVEY.md 8d total-bytes variant: {b_read + b_write} B per update, charging every update a full "
                             "row write (the double-buffered reference layout)",
@@ -412,7 +413,7 @@ def main():
         gen.step()
     if hasattr(gen, "flush"):
         gen.flush()
-    eng.ops.set_timing(True)
+    eng.ops.set_timing(2)              # HIP events around the first sweep of every generation (around all three: -1 % of value)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()

@@ -9,11 +9,11 @@ case $CFG in
   smc32) MARK=qs_hist_kernel; LANES=4; LD=32; KERN=smc_swarm_packed_kernel;;
   lv) MARK=qs_hist_kernel; LANES=1; LD=4; KERN=smc_swarm_packed_kernel;;
   evidence1d) MARK=qs_hist_kernel; LANES=1; LD=1; KERN=smc_swarm_packed_kernel;;
-  mc1d) MARK=mc_swarm_kernel; LANES=1; LD=1; KERN=mc_swarm_kernel;;
+  mc1d) MARK=mc_swarm_kernel; LANES=1; LD=1; KERN=mc_swarm_kernel; PER_STEP=1;;
 esac
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py --config $CFG > $R/gpurun_out/${TAG}_${CFG}_bench.log 2>&1
-MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG KERN=$KERN bash $R/tools/profile_config.sh
+MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG KERN=$KERN PER_STEP=${PER_STEP:-3} bash $R/tools/profile_config.sh
 if [ "${PMC:-0}" = "1" ]; then
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > /dev/null 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > /dev/null 2>&1
