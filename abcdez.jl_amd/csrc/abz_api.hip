@@ -639,6 +639,7 @@ int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* a
 
 int abcdez_extrema(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, double* hi) {
   ABZ_REQUIRE(ctx && delta && lo && hi, "extrema: null argument");
+  ctx->ahead = abz_ahead{};            /* shares the extrema scalars with a select enqueued ahead */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "extrema: N out of range");
   return abz_extrema_impl(ctx, delta, N, lo, hi);
 }
