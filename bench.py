@@ -5,8 +5,8 @@ Default workload = BASELINE.json configs[2], the configuration the metric is quo
 d = 32 MVN simulator (prior 32 x N(0,1), x = theta + z, y = 1-vector, Euclidean distance),
 abcdesmc with alpha = 0.95, delta_ess = 0.5, Kmcmc = 3, IndicatorStrict, 2^22 particles per GPU
 (weak scaling).  One *step* = one SMC generation of the reference's main loop
-(src/abcdez_smc.jl:295-377): eps-quantile, reweight, (resample), alive compaction, up to Kmcmc
-DE-Metropolis sweeps and the extrema(Ds) of the history (smc:364).  One particle-update = one alive
+(src/abcdez_smc.jl:295-377): extrema(Ds) of the history (smc:364), eps-quantile, reweight, ESS, partition of the packed
+population (one library call), (resample), up to Kmcmc DE-Metropolis sweeps (one library call).  One particle-update = one alive
 particle through one sweep.  State is resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config smc32|mc1d|lv|evidence1d]
