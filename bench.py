@@ -270,7 +270,7 @@ def lv_flops_per_update(sim):
     return (nobs - 1) * sim.steps_per_obs * 50 + nobs * 10
 
 
-def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
+def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 22):
     avg_ms = kern_ms / max(launches, 1)
     upl = units / max(launches, 1)
     rate = upl / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
@@ -321,7 +321,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
     if args_config == "smc32" and ld == 32:
         what = ("the sweep's memory-access pattern with all arithmetic removed (tools/layout_bench.hip, variant P), same "
                 "population layout: a reference point, not a strict bound -- its rate depends on how many waves are in flight")
-        live = pattern_ceiling_live(int(round(upl)), int(round(100 * acc_rate))) if PATTERN_LIVE else None
+        live = pattern_ceiling_live(int(round(upl)), int(round(100 * acc_rate)), positions) if PATTERN_LIVE else None
         pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json")
         if live:
             out["pattern_ceiling"] = {"updates_per_s": live["particles_per_s"], "read_frac": live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
@@ -340,7 +340,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate):
 PATTERN_LIVE = True
 
 
-def pattern_ceiling_live(prefix, accepted_percent):
+def pattern_ceiling_live(prefix, accepted_percent, positions):
     """runs the arithmetic-free access pattern on the same GPU (a child process; ~1 s); None if the tool is not built"""
     import subprocess
     exe = os.path.join(ROOT, "tools", "layout_bench")
@@ -349,7 +349,7 @@ def pattern_ceiling_live(prefix, accepted_percent):
     best = None
     for cap in (0, 5, 4, 3):        # the pattern itself runs fastest at 4 waves per SIMD (fewer streams in flight): take the best
         try:
-            r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent), str(1 << 22), str(cap)], capture_output=True,
+            r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent), str(positions), str(cap)], capture_output=True,
                                text=True, timeout=120)
             v = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
         except (OSError, ValueError, IndexError, subprocess.SubprocessError):
@@ -495,7 +495,7 @@ def main():
                 "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
-            "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate),
+            "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N),
         }
         if cfg["kind"] == "mc":
             out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
