@@ -326,7 +326,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         if live:
             out["pattern_ceiling"] = {"updates_per_s": live["particles_per_s"], "read_frac": live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
                                       "kernel_over_ceiling": rate / live["particles_per_s"],
-                                      "source": f"measured in this run on this GPU right after the timed window: tools/layout_bench --packed "
+                                      "source": f"measured in this run on this GPU right after the timed window, in process: tools/layout_bench.hip (packed pattern) "
                                                 f"{live['prefix']} {live['accepted_percent']} (prefix = mean alive count of the timed "
                                                 f"sweeps, accepted = their acceptance rate; mean of 5 x 20 launches; best of four occupancy "
                                                 f"caps: {live['waves_per_simd_cap'] or 8} waves per SIMD)", "what": what}
@@ -341,20 +341,27 @@ PATTERN_LIVE = True
 
 
 def pattern_ceiling_live(prefix, accepted_percent, positions):
-    """runs the arithmetic-free access pattern on the same GPU (a child process; ~1 s); None if the tool is not built"""
-    import subprocess
-    exe = os.path.join(ROOT, "tools", "layout_bench")
-    if not os.path.exists(exe) or prefix < 64:
+    """runs the arithmetic-free access pattern on the same GPU, in this process (tools/liblayout_bench.so, ~2 s); None if the
+    tool is not built"""
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "liblayout_bench.so")
+    if not os.path.exists(path) or prefix < 64 or prefix > positions or positions % 32:
+        return None
+    try:
+        lib = C.CDLL(path)
+        fn = lib.layout_bench_packed
+        fn.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        fn.restype = C.c_int
+    except (OSError, AttributeError):
         return None
     best = None
     for cap in (0, 5, 4, 3):        # the pattern itself runs fastest at 4 waves per SIMD (fewer streams in flight): take the best
-        try:
-            r = subprocess.run([exe, "--packed", str(prefix), str(accepted_percent), str(positions), str(cap)], capture_output=True,
-                               text=True, timeout=120)
-            v = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
-        except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-            v = None
-        if v and (best is None or v["particles_per_s"] > best["particles_per_s"]):
+        mean, mn = C.c_double(), C.c_double()
+        if fn(positions, prefix, accepted_percent, cap, 5, 20, C.byref(mean), C.byref(mn)) != 0 or not mean.value > 0:
+            continue
+        v = {"prefix": prefix, "accepted_percent": accepted_percent, "waves_per_simd_cap": cap, "ms_mean": mean.value,
+             "particles_per_s": prefix / (mean.value * 1e-3)}
+        if best is None or v["particles_per_s"] > best["particles_per_s"]:
             best = v
     return best
 

@@ -265,6 +265,45 @@ static int packed_only(uint32_t N, uint32_t M, int wf, int occ = 0) {
   return 0;
 }
 
+// The same measurement as an in-process entry point (tools/liblayout_bench.so, loaded by bench.py with ctypes): no child
+// process, nothing on stdout, every allocation released, errors as a return code.
+extern "C" __attribute__((visibility("default"))) int layout_bench_packed(uint32_t N, uint32_t M, int wf, int occ, int reps, int inner,
+                                                                        double* ms_mean, double* ms_best) {
+#define LB(x) do { if ((x) != hipSuccess) { rc = -1; goto done; } } while (0)
+  int rc = 0;
+  double *q0 = nullptr, *q1 = nullptr, *nlp = nullptr; uint32_t *bits = nullptr, *bo = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (M < 64 || M > N || (N & 31u) || wf < 0 || wf > 100 || reps < 1 || inner < 1) return -2;
+  {
+    const size_t dyn_lds = occ > 0 ? (size_t)(160 * 1024 / occ - 1024) / 256 * 256 : 0;
+    const size_t bytes = (size_t)N * D * 8;
+    const unsigned grid = (unsigned)(((uint64_t)M * 4 + 255) / 256);
+    float best = 1e30f, sum = 0.f;
+    if (dyn_lds > 64 * 1024) LB(hipFuncSetAttribute((const void*)k_packed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+    LB(hipMalloc(&q0, bytes)); LB(hipMalloc(&q1, bytes)); LB(hipMemset(q0, 0, bytes)); LB(hipMemset(q1, 0, bytes));
+    LB(hipMalloc(&nlp, (size_t)N * 16)); LB(hipMemset(nlp, 0, (size_t)N * 16));
+    LB(hipMalloc(&bits, N / 8)); LB(hipMalloc(&bo, N / 8));
+    { std::vector<uint32_t> h(N / 32); for (uint32_t k = 0; k < N / 32; ++k) h[k] = hash32(k * 977 + 5); LB(hipMemcpy(bits, h.data(), N / 8, hipMemcpyHostToDevice)); }
+    LB(hipEventCreate(&e0)); LB(hipEventCreate(&e1));
+    for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), dyn_lds, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+    LB(hipDeviceSynchronize());
+    for (int r = 0; r < reps; ++r) {
+      LB(hipEventRecord(e0, 0));
+      for (int rr = 0; rr < inner; ++rr) hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), dyn_lds, 0, q0, q1, bits, bo, M, q0, q1, nlp, wf);
+      LB(hipEventRecord(e1, 0)); LB(hipEventSynchronize(e1));
+      float ms; LB(hipEventElapsedTime(&ms, e0, e1)); ms /= inner;
+      best = ms < best ? ms : best; sum += ms;
+    }
+    *ms_mean = sum / reps; *ms_best = best;
+  }
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(q0); (void)hipFree(q1); (void)hipFree(nlp); (void)hipFree(bits); (void)hipFree(bo);
+  return rc;
+#undef LB
+}
+
 int main(int argc, char** argv) {
   if (argc >= 4 && std::string(argv[1]) == "--packed") {
     const uint32_t M = (uint32_t)strtoul(argv[2], nullptr, 10);
