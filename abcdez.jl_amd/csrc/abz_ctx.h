@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <unordered_map>
 
 #include "abcdez_spec.h"
 #include "abz_hotmodel.h"
@@ -32,7 +33,10 @@ struct abcdez_ctx {
   abz_model h_model;              /* host copy; .data points at d_data          */
   abz_model* d_model = nullptr;
   double* d_data = nullptr;
-  abz_tables* d_tables = nullptr;
+  abz_tables* d_tables = nullptr;     /* log table + hot part of the inverse normal CDF + pointer to ... */
+  abz_f64x2* d_icdf_all = nullptr;    /* ... the whole inverse-CDF table [ABZ_ICDF_PIECES][ABZ_ICDF_ROWS] */
+  int n_cu = 1;                       /* compute units of the device */
+  std::unordered_map<const void*, int> occ;   /* kernel -> resident workgroups per CU (abz_persistent_grid) */
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
   abz_ahead ahead;
   bool prior_plain = false;       /* all real dimensions continuous Normal priors (abz_api.hip)                 */
@@ -89,6 +93,30 @@ void abz_set_error(const std::string& msg);
       return -2;                                                                         \
     }                                                                                    \
   } while (0)
+
+/* Grid of a kernel whose workgroups loop over tiles (ABZ_TILE_LOOP): as many workgroups as the device holds at once --
+ * compute units x the occupancy the runtime reports for this kernel -- each with the same number of tiles (+-1), so the
+ * sampler tables are staged into LDS once per resident workgroup and no second round of workgroups trails the first. */
+static inline unsigned abz_tiles_to_grid(uint64_t ntiles, uint64_t resident) {
+  if (resident < 1) resident = 1;
+  if (ntiles <= resident) return (unsigned)(ntiles ? ntiles : 1);
+  const uint64_t per = (ntiles + resident - 1) / resident;
+  return (unsigned)((ntiles + per - 1) / per);
+}
+template <class K>
+static inline unsigned abz_persistent_grid(abcdez_ctx* ctx, K kernel, uint64_t ntiles, int block) {
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = ctx->occ.find(key);
+  int per_cu;
+  if (it != ctx->occ.end()) per_cu = it->second;
+  else {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
+    per_cu = nb;
+    ctx->occ.emplace(key, per_cu);
+  }
+  return abz_tiles_to_grid(ntiles, (uint64_t)ctx->n_cu * (uint64_t)per_cu);
+}
 
 /* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
@@ -171,7 +199,7 @@ int abz_jit_launch_blob(abcdez_ctx*, const double* theta, const uint64_t* stamp,
                         double* delta_out, uint32_t nbw);
 int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp, int64_t n, double* blob,
                          double* delta_out, uint32_t nbw);
-int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned nblocks);
-int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
+int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned ntiles);
+int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned ntiles);
 
 #endif

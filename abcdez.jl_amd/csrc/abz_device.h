@@ -56,71 +56,84 @@ __device__ inline void store_row(double* __restrict__ row, int j, const double (
   }
 }
 
-/* The read-mostly model tables (prior descriptors, data vector) are staged in LDS once per
- * workgroup: every group of a block reads the same ld entries, so this turns ~10 dependent
- * global loads per component into broadcast LDS reads and keeps them out of the VGPR budget. */
+/* The read-mostly model tables (sampler tables, prior descriptors, data vector) are staged in LDS ONCE PER WORKGROUP: every
+ * group of a block reads the same ld descriptor entries (broadcast LDS reads instead of ~10 dependent global loads per
+ * component), and the sampler's tables -- the log table and the hot part of the inverse-normal-CDF table, 28 KB -- are
+ * looked up by random row.  A workgroup therefore works through MANY tiles of ABZ_BLOCK threads (ABZ_TILE_LOOP below; the
+ * launchers size the grid to what is resident at once, abz_persistent_grid): staging costs 30 KB per ~36 tiles instead of
+ * 10 KB per tile as in round 2. */
 template <int LD>
 struct ModelLds {
-  abz_tables tab;              /* log / sincos tables of the sampler (8 KB) */
+  abz_tables tab;              /* log table + first ABZ_ICDF_HOT_BINADES binades of the inverse normal CDF + pointer to all of it */
   abz_prior_dim prior[LD];
   double y[LD];
 };
 
-/* two phases so the global loads can be issued early (before the wave's dependent loads)
- * and the LDS writes + barrier placed right before the first use */
-template <int SIM, int LD>
-struct ModelStage {
-  static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
-  static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
-  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);   /* 16-byte pieces per thread */
-  static_assert(sizeof(abz_tables) % (16 * ABZ_BLOCK) == 0, "table size must tile the block");
-  uint64_t w[NW];
-  double2 tb[NT];
-  double y;
-  __device__ inline void load(const HotModel& M) {
-    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
-#pragma unroll
-    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
-    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-      const int t = threadIdx.x + q * ABZ_BLOCK;
-      w[q] = t < W ? src[t] : 0ull;
-    }
-    y = 0.0;
-    if constexpr (SIM == ABZ_SIM_MVN) {
-      if ((int)threadIdx.x < LD && (int)threadIdx.x < M.d) y = M.data[threadIdx.x];
-    }
-  }
-  __device__ inline void store(ModelLds<LD>& s) const {
-    double2* tdst = reinterpret_cast<double2*>(&s.tab);
-#pragma unroll
-    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
-    uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-      const int t = threadIdx.x + q * ABZ_BLOCK;
-      if (t < W) dst[t] = w[q];
-    }
-    if ((int)threadIdx.x < LD) s.y[threadIdx.x] = y;
-  }
-};
+__device__ inline void stage_tables(abz_tables& dst, const abz_tables* __restrict__ src) {
+  static_assert(sizeof(abz_tables) % 16 == 0, "table struct is copied in 16-byte pieces");
+  constexpr int NP = (int)(sizeof(abz_tables) / 16);
+  const double2* __restrict__ s = reinterpret_cast<const double2*>(src);
+  double2* d = reinterpret_cast<double2*>(&dst);
+  for (int q = threadIdx.x; q < NP; q += ABZ_BLOCK) d[q] = s[q];
+}
 
-/* the sampler tables alone (kernels that draw but neither evaluate the prior nor simulate) */
-struct TabStage {
-  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);
-  double2 tb[NT];
-  __device__ inline void load(const HotModel& M) {
-    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
-#pragma unroll
-    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+/* SIM < 0: no simulator data (kernels that draw and evaluate the prior only).  The caller synchronises. */
+template <int SIM, int LD>
+__device__ inline void stage_model(ModelLds<LD>& s, const HotModel& M) {
+  stage_tables(s.tab, M.tables);
+  constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
+  const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
+  uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
+  for (int t = threadIdx.x; t < W; t += ABZ_BLOCK) dst[t] = src[t];
+  if ((int)threadIdx.x < LD) {
+    double y = 0.0;
+    if constexpr (SIM == ABZ_SIM_MVN) {
+      if ((int)threadIdx.x < M.d) y = M.data[threadIdx.x];
+    }
+    s.y[threadIdx.x] = y;
   }
-  __device__ inline void store(abz_tables& s) const {
-    double2* tdst = reinterpret_cast<double2*>(&s);
-#pragma unroll
-    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+}
+
+/* tiles of ABZ_BLOCK threads dealt round-robin to the resident workgroups: at any moment the grid streams one contiguous
+ * window of the population, as a plain launch would */
+#define ABZ_TILE_LOOP(tile, ntiles) for (uint32_t tile = blockIdx.x; tile < (ntiles); tile += gridDim.x)
+/* The lane's index inside its group, made opaque once per tile: everything derived from it (Philox partial products of the
+ * lane's sub-counters, LDS addresses of its prior descriptors) is then computed where it is used instead of being hoisted
+ * out of the tile loop into registers that live across the whole body -- the hoisting cost the d = 32 sweep 70 VGPRs and
+ * with them three of its five waves per SIMD. */
+__device__ inline int tile_lane(int j) {
+  asm volatile("" : "+v"(j));
+  return j;
+}
+
+/* ---- abz_kernel_logpdf (abcdez_spec.h, types.jl:26-73) as the sweep evaluates it: the indicator kernels (the default, every
+ * BASELINE configuration) are two compares; the Epanechnikov kernels' log(1 - (x/eps)^2) is kept OUT OF LINE so that its
+ * dozen polynomial constants do not sit in registers across the tile loop of a sweep that never uses them.  Same function. */
+__device__ __attribute__((noinline)) inline double kernel_logpdf_epa(double eps, double x) {
+  const double t = x / eps;
+  return abz_log(1.0 - t * t);
+}
+__device__ inline double kernel_logpdf_dev(int kind, double eps, double x) {
+  if (!abz_kernel_insupport(kind, eps, x)) return ABZ_NINF;
+  if (kind < ABZ_K_EPA) return 0.0;
+  return kernel_logpdf_epa(eps, x);
+}
+
+/* ---- abz_normal_icdf (abcdez_spec.h) as the kernels evaluate it: every lane runs the LDS path on a clamped row -- straight-line
+ * code, no branch around the table reads -- and the lanes whose binade is deeper than the LDS copy (2^-12 of the draws)
+ * redo the polynomial with their row of the global table.  Same table, same operations, same bits. */
+__device__ inline double normal_icdf_dev(uint64_t w, const abz_tables* T /* LDS */, const abz_f64x2* __restrict__ all /* global */) {
+  uint32_t row;
+  double tau;
+  abz_icdf_index(w, &row, &tau);
+  const uint32_t rh = row < (uint32_t)ABZ_ICDF_HOT_ROWS ? row : (uint32_t)(ABZ_ICDF_HOT_ROWS - 1);
+  double z = abz_icdf_poly(tau, T->icdf_hot[0][rh], T->icdf_hot[1][rh], T->icdf_hot[2][rh], T->icdf_hot[3][rh], w);
+  if (__builtin_expect(row >= (uint32_t)ABZ_ICDF_HOT_ROWS, 0)) {
+    const abz_f64x2* __restrict__ c = all + row;
+    z = abz_icdf_poly(tau, c[0], c[ABZ_ICDF_ROWS], c[2 * ABZ_ICDF_ROWS], c[3 * ABZ_ICDF_ROWS], w);
   }
-};
+  return z;
+}
 
 /* ---- canonical per-particle tree sum ------------------------------------------- */
 __device__ inline double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
@@ -208,35 +221,46 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
   } else if constexpr (SIM == ABZ_SIM_MVN) {
     const double sg = M.sim_p[0];
     const int d = M.d;
-    double sq[C];
     if constexpr (C == 1) {
-      double z0, z1;
-      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
+      const double z0 = normal_icdf_dev(abz_rng(seed, i, epoch, 0, purpose).w0, T, M.icdf_all);
       const double x = abz_fma(sg, z0, th[0]);
       if constexpr (BLOB) blob[0] = x;
       const double e = x - y[0];
-      sq[0] = e * e;
+      return abz_sqrt(e * e);
     } else {
+      /* the canonical tree (abcdez_spec.h) evaluated as the squares become available: level 0 inside the lane, butterfly over the
+       * L lanes, binary tree over m -- the operations of group_tree_sum<L, C> in the same association, but with two
+       * partial sums alive instead of C squares, and (wide rows) one normal's eight coefficients in registers at a time */
+      constexpr int MM = C / 2;
+      double s[MM];
 #pragma unroll
-      for (int m = 0; m < C / 2; ++m) {
-        double z[2];
-        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose), T, &z[0], &z[1]);
+      for (int m = 0; m < MM; ++m) {
+        const abz_u64x2 w = abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose);
+        double v[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
+          const double z = normal_icdf_dev(c ? w.w1 : w.w0, T, M.icdf_all);
           const int k = Lay<L, C>::comp(j, m, c);
-          double v = 0.0;
+          v[c] = 0.0;
           if constexpr (BLOB) blob[2 * m + c] = 0.0;
           if (FULL || k < d) {
-            const double x = abz_fma(sg, z[c], th[2 * m + c]);
+            const double x = abz_fma(sg, z, th[2 * m + c]);
             if constexpr (BLOB) blob[2 * m + c] = x;
             const double e = x - y[k];
-            v = e * e;
+            v[c] = e * e;
           }
-          sq[2 * m + c] = v;
+          if constexpr (C >= 8) __builtin_amdgcn_sched_barrier(0);
         }
+        double t = v[0] + v[1];                          /* level 0: (2t, 2t+1)            */
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) t = t + shfl_xor_f64(t, off);   /* over lanes */
+        s[m] = t;
+#pragma unroll
+        for (int st = 1; st < MM; st <<= 1)              /* over m: node (m - 2 st + 1 .. m) closes when its right child does */
+          if ((m & (2 * st - 1)) == 2 * st - 1) s[m - 2 * st + 1] = s[m - 2 * st + 1] + s[m - st + 1];
       }
+      return abz_sqrt(s[0]);
     }
-    return abz_sqrt(group_tree_sum<L, C>(sq));
   } else if constexpr (SIM == ABZ_SIM_DIRAC) {
     const double x = th[0] * th[0] + 1.0;
     if constexpr (BLOB) blob[0] = x;
@@ -349,9 +373,8 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
 /* ---- per-particle scalar draws of one sweep: donor ranks, gamma jitter, log(accept uniform).
  * With L >= 4 lanes per particle the three Philox blocks are evaluated by lanes 0, 1, 2 of
  * the group in ONE pass of the instruction stream (the purpose tag is the only difference),
- * the Box-Muller radius of the jitter and the accept test share one log evaluation, and the
- * results are broadcast inside the group.  Same values as the straightforward evaluation. */
-/* In two steps, so that a kernel can issue the donors' loads before the sampler tables are staged: words() is pure
+ * and the results are broadcast inside the group.  Same values as the straightforward evaluation. */
+/* In two steps, so that a kernel can issue the donors' loads before it needs the sampler tables: words() is pure
  * integer work (Philox + the donor ranks), finish() the table-driven part (jitter normal, log of the accept uniform). */
 template <int L>
 struct ParticleDraws {
@@ -371,19 +394,16 @@ struct ParticleDraws {
       wa = abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT);
     }
   }
-  __device__ inline void finish(const abz_tables* T, double gamma0, double gsig, double* g, double* log_u) const {
+  __device__ inline void finish(const abz_tables* T, const abz_f64x2* __restrict__ all, double gamma0, double gsig, double* g,
+                                double* log_u) const {
     if constexpr (L >= 4) {
-      const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
-      double sn, cs;
-      abz_sincos2pi_tab_w(w.w1, T, &sn, &cs);
-      const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
+      const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* meaningful on lane 2: the accept uniform (smc:145) */
+      const double z0 = normal_icdf_dev(w.w0, T, all);          /* meaningful on lane 1: randn of smc:128 */
       const double g_ = gamma0 * (1.0 + z0 * gsig);
       *g = __shfl(g_, 1, L);
       *log_u = __shfl(lg, 2, L);
     } else {
-      double z0, z1;
-      abz_normal_pair(w, T, &z0, &z1);
-      *g = gamma0 * (1.0 + z0 * gsig);
+      *g = gamma0 * (1.0 + normal_icdf_dev(w.w0, T, all) * gsig);
       /* the SAME function as the L >= 4 branch and the oracle (abz_log_tab): the accept variate must not
        * depend on the lane shape -- the polynomial abz_log differs from it in ~19 % of arguments by an ulp */
       *log_u = abz_log_tab(abz_u01_open(wa.w0), T);
@@ -391,33 +411,32 @@ struct ParticleDraws {
   }
 };
 template <int L>
-__device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32_t i, uint32_t sweep, int j,
-                                      uint32_t n_pool, uint32_t ri,
+__device__ inline void particle_draws(const abz_tables* T, const abz_f64x2* __restrict__ all, uint64_t seed, uint32_t i,
+                                      uint32_t sweep, int j, uint32_t n_pool, uint32_t ri,
                                       double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g,
                                       double* log_u) {
   ParticleDraws<L> d;
   d.words(seed, i, sweep, j, n_pool, ri, ra, rb);
-  d.finish(T, gamma0, gsig, g, log_u);
+  d.finish(T, all, gamma0, gsig, g, log_u);
 }
 
-/* ---- block-level integer counters: wave ballot -> LDS -> two agent-scope atomic ADDS per block into one of
- * ABZ_CSLOTS cumulative slots (abz_hotmodel.h).  Same-address atomics serialise (10^5 of them on ONE address per
- * launch were the bottleneck of the first build, ~15 ns each); spread over 256 lines they overlap the kernel, and
- * because the slots are cumulative nothing has to be zeroed or reduced by another launch.                      */
-__device__ inline void block_count2(bool f0, bool f1, unsigned long long* __restrict__ cslots, uint32_t cls) {
+/* ---- block-level integer counters: every thread counts over its tiles in two registers; at the end of the block a wave
+ * reduction -> LDS -> two agent-scope atomic ADDS per block into one of ABZ_CSLOTS cumulative slots (abz_hotmodel.h).
+ * Same-address atomics serialise (10^5 of them on ONE address per launch were the bottleneck of the first build, ~15 ns
+ * each); spread over 256 lines they overlap the kernel, and because the slots are cumulative nothing has to be zeroed or
+ * reduced by another launch.  Ends with no barrier pending; must be reached by every thread of the block.       */
+__device__ inline void block_count2(unsigned int x, unsigned int y, unsigned long long* __restrict__ cslots, uint32_t cls) {
   __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
-  const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
-  if ((threadIdx.x & 63) == 0) {
-    s_cnt[0][threadIdx.x >> 6] = (unsigned int)__popcll(b0);
-    s_cnt[1][threadIdx.x >> 6] = (unsigned int)__popcll(b1);
-  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) { x += __shfl_xor(x, off, 64); y += __shfl_xor(y, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = x; s_cnt[1][threadIdx.x >> 6] = y; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-    const unsigned long long y = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    const unsigned long long xs = (unsigned long long)s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const unsigned long long ys = (unsigned long long)s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
     unsigned long long* s = cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE + cls;
-    if (x) (void)__hip_atomic_fetch_add(s, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (y) (void)__hip_atomic_fetch_add(s + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (xs) (void)__hip_atomic_fetch_add(s, xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ys) (void)__hip_atomic_fetch_add(s + 1, ys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

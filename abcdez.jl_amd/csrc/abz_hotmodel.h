@@ -12,7 +12,8 @@ struct HotModel {
   uint64_t seed;
   const abz_prior_dim* prior;   /* device, ld entries */
   const double* data;           /* device, n_data values */
-  const abz_tables* tables;     /* device copy of the sampler tables */
+  const abz_tables* tables;     /* device copy of the sampler tables (what a workgroup stages into LDS) */
+  const abz_f64x2* icdf_all;    /* the whole inverse-normal-CDF table, global memory (== tables->icdf_all) */
   double sim_p[8];
   int32_t d, abck, n_data, n_blob;
 };

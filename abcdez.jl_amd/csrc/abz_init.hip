@@ -23,7 +23,8 @@ int abz_launch_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta
   if (ctx->h_model.sim_id == ABZ_SIM_USER)
     return abz_jit_launch_init(ctx, theta, logpi, delta, (uint32_t)i0, (uint32_t)n, ctx->d_scal + ABZ_S_INITBAD, stamp);
   bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
-    hipLaunchKernelGGL((init_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)n * LL())), dim3(ABZ_BLOCK), 0,
+    auto kern = init_kernel<S(), LL(), CC()>;
+    hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, abz_grid((uint64_t)n * LL()), ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
                        ctx->stream, ctx->hot, theta, logpi, delta, (uint32_t)i0, (uint32_t)n,
                        ctx->d_scal + ABZ_S_INITBAD, stamp);
   });
@@ -46,7 +47,8 @@ int abz_launch_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* s
   if (n <= 0) return 0;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) return abz_jit_launch_blob(ctx, theta, stamp, (uint32_t)n, blob, delta_out, nbw);
   bool ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
-    hipLaunchKernelGGL((blob_eval_kernel<S(), LL(), CC()>), dim3(abz_grid((uint64_t)n * LL())), dim3(ABZ_BLOCK), 0,
+    auto kern = blob_eval_kernel<S(), LL(), CC()>;
+    hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, abz_grid((uint64_t)n * LL()), ABZ_BLOCK)), dim3(ABZ_BLOCK), 0,
                        ctx->stream, ctx->hot, theta, stamp, (uint32_t)n, blob, delta_out, nbw);
   });
   if (!ok) { abz_set_error("blob_eval: no kernel for this (simulator, ld, lanes) combination"); return -3; }

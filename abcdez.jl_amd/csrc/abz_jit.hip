@@ -24,6 +24,21 @@ struct AbzUserModule {
   hipFunction_t f_init = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
 };
 
+/* the user kernels loop over tiles like the built-in ones (ABZ_TILE_LOOP): grid = what is resident at once */
+static unsigned jit_grid(abcdez_ctx* ctx, hipFunction_t f, uint64_t ntiles) {
+  const void* key = reinterpret_cast<const void*>(f);
+  auto it = ctx->occ.find(key);
+  int per_cu;
+  if (it != ctx->occ.end()) per_cu = it->second;
+  else {
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, ABZ_BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
+    per_cu = nb;
+    ctx->occ.emplace(key, per_cu);
+  }
+  return abz_tiles_to_grid(ntiles, (uint64_t)ctx->n_cu * (uint64_t)per_cu);
+}
+
 #define ABZ_RTC_CHECK(expr)                                                                \
   do {                                                                                     \
     hiprtcResult _r = (expr);                                                              \
@@ -99,8 +114,8 @@ int abz_jit_launch_init(abcdez_ctx* ctx, double* theta, double* logpi, double* d
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   HotModel M = ctx->hot;
   void* params[] = {&M, &theta, &logpi, &delta, &i0, &n, &bad, &stamp};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
-                                      params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, jit_grid(ctx, um->f_init, (n + ABZ_BLOCK - 1) / ABZ_BLOCK), 1, 1, ABZ_BLOCK, 1, 1,
+                                      0, ctx->stream, params, nullptr));
   return 0;
 }
 int abz_jit_launch_blob(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp, uint32_t n, double* blob,
@@ -109,19 +124,19 @@ int abz_jit_launch_blob(abcdez_ctx* ctx, const double* theta, const uint64_t* st
   if (!um || !um->f_blob) { abz_set_error("blob_eval: the user simulator was built without blobs (n_blob = 0)"); return -3; }
   HotModel M = ctx->hot;
   void* params[] = {&M, &theta, &stamp, &n, &blob, &delta_out, &nbw};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_blob, (n + ABZ_BLOCK - 1) / ABZ_BLOCK, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream,
-                                      params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_blob, jit_grid(ctx, um->f_blob, (n + ABZ_BLOCK - 1) / ABZ_BLOCK), 1, 1, ABZ_BLOCK, 1, 1,
+                                      0, ctx->stream, params, nullptr));
   return 0;
 }
-int abz_jit_launch_mc(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
+int abz_jit_launch_mc(abcdez_ctx* ctx, const void* args, unsigned ntiles) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   void* params[] = {const_cast<void*>(args)};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_mc, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_mc, jit_grid(ctx, um->f_mc, ntiles), 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }
-int abz_jit_launch_smc_packed(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
+int abz_jit_launch_smc_packed(abcdez_ctx* ctx, const void* args, unsigned ntiles) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   void* params[] = {const_cast<void*>(args)};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smcp, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smcp, jit_grid(ctx, um->f_smcp, ntiles), 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }

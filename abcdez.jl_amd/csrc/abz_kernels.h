@@ -21,58 +21,57 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
                                                          uint32_t i0, uint32_t n, unsigned long long* __restrict__ bad,
                                                          uint64_t* __restrict__ stamp = nullptr) {
   constexpr int LD = L * C;
+  constexpr uint32_t PB = ABZ_BLOCK / L;
   __shared__ ModelLds<LD> s_model;
-  {
-    ModelStage<SIM, LD> stage;
-    stage.load(M);
-    stage.store(s_model);
-  }
+  stage_model<SIM, LD>(s_model, M);
   __syncthreads();
   const abz_prior_dim* pd = s_model.prior;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  if (grp >= n) return;                       /* whole groups leave together */
-  const uint32_t i = i0 + grp;
+  const int j = (int)(threadIdx.x % L);
   const uint64_t seed = M.seed;
-  double th[C], pp[C];
-  double lp, dl;
-  uint32_t retry = 0;
-  for (;;) {
-    if constexpr (C == 1) {
-      const abz_u64x2 w = abz_rng(seed, i, retry, 0, ABZ_RNG_INIT_PRIOR);
-      double z0, z1;
-      abz_normal_pair(w, &s_model.tab, &z0, &z1);
-      th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
-      if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_ext(&pd[0], seed, i, retry, 0u, &s_model.tab);
-    } else {
-#pragma unroll
-      for (int m = 0; m < C / 2; ++m) {
-        const abz_u64x2 w = abz_rng(seed, i, retry, (uint32_t)(m * L + j), ABZ_RNG_INIT_PRIOR);
+  const uint32_t ntiles = (n + PB - 1) / PB;
+  ABZ_TILE_LOOP(tile, ntiles) {
+    const uint32_t grp = tile * PB + threadIdx.x / L;
+    if (grp >= n) continue;                     /* whole groups leave together; no barrier inside the loop */
+    const uint32_t i = i0 + grp;
+    double th[C], pp[C];
+    double lp, dl;
+    uint32_t retry = 0;
+    for (;;) {
+      if constexpr (C == 1) {
+        const abz_u64x2 w = abz_rng(seed, i, retry, 0, ABZ_RNG_INIT_PRIOR);
         double z0, z1;
         abz_normal_pair(w, &s_model.tab, &z0, &z1);
-        const int k = Lay<L, C>::comp(j, m, 0);
-        th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
-        th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
-        if (pd[k].family >= ABZ_PRIOR_BETA)
-          th[2 * m] = abz_prior_draw_ext(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab);
-        if (pd[k + 1].family >= ABZ_PRIOR_BETA)
-          th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
+        th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
+        if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_ext(&pd[0], seed, i, retry, 0u, &s_model.tab);
+      } else {
+#pragma unroll
+        for (int m = 0; m < C / 2; ++m) {
+          const abz_u64x2 w = abz_rng(seed, i, retry, (uint32_t)(m * L + j), ABZ_RNG_INIT_PRIOR);
+          double z0, z1;
+          abz_normal_pair(w, &s_model.tab, &z0, &z1);
+          const int k = Lay<L, C>::comp(j, m, 0);
+          th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
+          th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
+          if (pd[k].family >= ABZ_PRIOR_BETA)
+            th[2 * m] = abz_prior_draw_ext(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab);
+          if (pd[k + 1].family >= ABZ_PRIOR_BETA)
+            th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
+        }
+      }
+      lp = group_logprior<L, C>(pd, j, th, pp);
+      dl = ABZ_NAN;
+      if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
+      if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
+      if (++retry >= ABZ_MAX_RETRY) {
+        if (j == 0) atomicAdd(bad, 1ull);
+        break;
       }
     }
-    lp = group_logprior<L, C>(pd, j, th, pp);
-    dl = ABZ_NAN;
-    if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
-    if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
-    if (++retry >= ABZ_MAX_RETRY) {
-      if (j == 0) atomicAdd(bad, 1ull);
-      break;
+    store_row<L, C>(theta + (size_t)i * LD, j, th);
+    if (j == 0) {
+      logpi[i] = lp; delta[i] = dl;
+      if (stamp) stamp[i] = abz_stamp(i, retry, 1);              /* which simulator call made this distance (blobs) */
     }
-  }
-  store_row<L, C>(theta + (size_t)i * LD, j, th);
-  if (j == 0) {
-    logpi[i] = lp; delta[i] = dl;
-    if (stamp) stamp[i] = abz_stamp(i, retry, 1);              /* which simulator call made this distance (blobs) */
   }
 }
 
@@ -104,95 +103,111 @@ __device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
-  constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
-  static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
+  constexpr uint32_t PB = ABZ_BLOCK / L;            /* positions per tile: whole words of the bitmap */
+  constexpr uint32_t NW = PB / 32;
+  static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per tile (lanes <= 8)");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_work;
-  const uint32_t ri = a.r_lo + (active ? grp : 0u);
 
   __shared__ ModelLds<LD> s_model;
-  __shared__ uint32_t s_acc[PB / 32];
+  __shared__ uint32_t s_acc[2][NW];                 /* accepted positions of a tile, by tile parity (one barrier per tile) */
+  stage_model<SIM, LD>(s_model, M);
+  if (threadIdx.x < 2 * NW) (&s_acc[0][0])[threadIdx.x] = 0u;
+  __syncthreads();                                  /* sampler + model tables staged: once per workgroup */
 
-  /* Order of issue = order of need.  Nothing below waits for the model tables before the rows are on their way:
-   *   slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot bits   (one L2 round trip)
-   *   the three rows, log-prior, distance                                                                (one HBM round trip)
-   *   meanwhile: tables staged in LDS, gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145)              */
-  /* Rows of at most two doubles are DOUBLE-BUFFERED (ABZ_ROWS_DOUBLE_BUFFERED): a sweep writes every swept position's row
-   * to its other slot (the proposal, or a copy of the row) and flips every swept bit, so the alive prefix always shares ONE
-   * slot parity and the donors need no bit look-up -- at 8 or 16 bytes per row the two random 4-byte look-ups cost as
-   * much as the donor rows themselves (the d = 1 sweep is bound by the gather rate of the CU's address unit), and copying a
-   * rejected row is a coalesced 8 bytes. */
-  constexpr bool DBUF = ABZ_ROWS_DOUBLE_BUFFERED(LD);
-  ModelStage<SIM, LD> stage;
-  stage.load(M);
-  const uint32_t wi = a.bits[ri >> 5];
-  ParticleDraws<L> draws;
-  uint32_t ra, rb;
-  draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
-  uint32_t wa = 0u, wb = 0u;
-  if constexpr (!DBUF) { wa = a.bits[ra >> 5]; wb = a.bits[rb >> 5]; }
-  const double lpi = a.logpi[ri];
-  const double dli = a.delta[ri];
-  if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
-  const uint32_t bi = (wi >> (ri & 31u)) & 1u;
-  const uint32_t ba = DBUF ? bi : (wa >> (ra & 31u)) & 1u, bb = DBUF ? bi : (wb >> (rb & 31u)) & 1u;
-  double ti[C], ta[C], tb[C];
-  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
-  load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
-  load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
-  stage.store(s_model);
-  __syncthreads();                                                /* sampler + model tables staged */
-  double g, log_u;
-  draws.finish(&s_model.tab, a.gamma0, a.gsig, &g, &log_u);
+  const int j0 = (int)(threadIdx.x % L);
+  const uint32_t ntiles = (a.n_work + PB - 1) / PB;
+  unsigned int n_acc = 0u, n_sim = 0u;              /* this thread's counts over its tiles (smc:138,150) */
+  uint32_t par = 0u;
+  ABZ_TILE_LOOP(tile, ntiles) {
+    const int j = tile_lane(j0);
+    const uint32_t grp = tile * PB + threadIdx.x / L;
+    const bool active = grp < a.n_work;
+    const uint32_t ri = a.r_lo + (active ? grp : 0u);
 
-  double tp[C], pp[C];
+    /* Order of issue = order of need:
+     *   slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot bits   (one L2 round trip)
+     *   meanwhile: gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145), log-prior, distance
+     *   the three rows                                                                                     (one HBM round trip) */
+    /* Rows of at most two doubles are DOUBLE-BUFFERED (ABZ_ROWS_DOUBLE_BUFFERED): a sweep writes every swept position's row
+     * to its other slot (the proposal, or a copy of the row) and flips every swept bit, so the alive prefix always shares ONE
+     * slot parity and the donors need no bit look-up -- at 8 or 16 bytes per row the two random 4-byte look-ups cost as
+     * much as the donor rows themselves (the d = 1 sweep is bound by the gather rate of the CU's address unit), and copying a
+     * rejected row is a coalesced 8 bytes. */
+    constexpr bool DBUF = ABZ_ROWS_DOUBLE_BUFFERED(LD);
+    const uint32_t wi = a.bits[ri >> 5];
+    ParticleDraws<L> draws;
+    uint32_t ra, rb;
+    draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
+    uint32_t wa = 0u, wb = 0u;
+    if constexpr (!DBUF) { wa = a.bits[ra >> 5]; wb = a.bits[rb >> 5]; }
+    const double lpi = a.logpi[ri];
+    const double dli = a.delta[ri];
+    /* the table-driven draws run in the shadow of the slot-bit loads; wide rows: BEFORE the three rows are requested, so that
+     * the rows' 48 registers and the draws' table entries are never alive together (96 VGPRs = 5 waves per SIMD) */
+    double g, log_u;
+    draws.finish(&s_model.tab, M.icdf_all, a.gamma0, a.gsig, &g, &log_u);
+    if constexpr (C >= 8) __builtin_amdgcn_sched_barrier(0);
+    const uint32_t bi = (wi >> (ri & 31u)) & 1u;
+    const uint32_t ba = DBUF ? bi : (wa >> (ra & 31u)) & 1u, bb = DBUF ? bi : (wb >> (rb & 31u)) & 1u;
+    double ti[C], ta[C], tb[C];
+    load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+    load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+    load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+
+    double tp[C], pp[C];
 #pragma unroll
-  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
+    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);   /* smc:134 */
-  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
-  bool acc = false;
-  double dp = dli;
-  /* Narrow rows with a Normal prior (in support for every finite proposal): the simulator is not put behind a branch --
-   * its random numbers do not depend on the proposal and can be produced while the rows are in flight, which shortens
-   * the dependent chain these latency-bound kernels run on; the result is used only when the proposal is in support,
-   * as in the branch.  Wide rows keep the branch: hoisting costs the d = 32 kernel its fifth wave (88 -> 99 VGPRs). */
-  constexpr bool UNBRANCH = PLAIN && LD <= 4;
-  if (UNBRANCH || insupport) {
-    const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
-    const double w = (lp - lpi) + (abz_kernel_logpdf(M.abck, a.eps, ds) - abz_kernel_logpdf(M.abck, a.eps, dli)); /* smc:140-141 */
-    if (insupport) {
-      dp = ds;
-      acc = (0.0 <= w) || (log_u < w);                            /* smc:145 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);   /* smc:134 */
+    const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+    bool acc = false;
+    double dp = dli;
+    /* Narrow rows with a Normal prior (in support for every finite proposal): the simulator is not put behind a branch --
+     * its random numbers do not depend on the proposal and can be produced while the rows are in flight, which shortens
+     * the dependent chain these latency-bound kernels run on; the result is used only when the proposal is in support,
+     * as in the branch.  Wide rows keep the branch. */
+    constexpr bool UNBRANCH = PLAIN && LD <= 4;
+    if (UNBRANCH || insupport) {
+      const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+      const double w = (lp - lpi) + (kernel_logpdf_dev(M.abck, a.eps, ds) - kernel_logpdf_dev(M.abck, a.eps, dli)); /* smc:140-141 */
+      if (insupport) {
+        dp = ds;
+        acc = (0.0 <= w) || (log_u < w);                            /* smc:145 */
+      }
     }
-  }
-  acc = acc && active;
-  if constexpr (DBUF) {
-    if (active) {
-      double to[C];
+    acc = acc && active;
+    if constexpr (DBUF) {
+      if (active) {
+        double to[C];
 #pragma unroll
-      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, to);
-      if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+        for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+        store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, to);
+        if (j == 0) atomicOr(&s_acc[par][(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+      }
+    } else if (acc) {                                               /* smc:146-150 */
+      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
+      if (j == 0) atomicOr(&s_acc[par][(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
     }
-  } else if (acc) {                                               /* smc:146-150 */
-    store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
-    if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+    if (acc && j == 0) {
+      a.logpi[ri] = lp; a.delta[ri] = dp;
+      if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
+    }
+    if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
+    n_acc += (j == 0 && acc) ? 1u : 0u;
+    n_sim += (active && j == 0 && insupport) ? 1u : 0u;
+    /* ONE barrier per tile: it publishes the tile's accepted-position words.  They are read, written out and cleared behind it
+     * by NW threads; the words of the other parity collect the next tile's bits meanwhile (a word is reused two tiles later,
+     * i.e. behind the next barrier, which its clearing thread has to reach first). */
+    __syncthreads();
+    if (threadIdx.x < NW) {
+      const uint32_t w = (a.r_lo + tile * PB) / 32u + threadIdx.x;
+      if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[par][threadIdx.x];
+      s_acc[par][threadIdx.x] = 0u;
+    }
+    par ^= 1u;
   }
-  if (acc && j == 0) {
-    a.logpi[ri] = lp; a.delta[ri] = dp;
-    if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
-  }
-  if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
-  block_count2(j == 0 && acc, active && j == 0 && insupport, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
-  if (threadIdx.x < PB / 32) {
-    const uint32_t w = (a.r_lo + blockIdx.x * PB) / 32u + threadIdx.x;
-    if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
-  }
+  block_count2(n_acc, n_sim, a.cslots, a.c_cls);
 }
 
 /* replay of a packed sweep on a replica (multi-GPU): every rank keeps the whole population, rank r sweeps a range of
@@ -222,8 +237,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
   __shared__ unsigned int s_n;
   __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
 
-  ModelStage<-1, LD> stage;                               /* sampler tables + prior descriptors (no simulator data) */
-  stage.load(a.hm);
+  stage_model<-1, LD>(s_model, a.hm);                     /* sampler tables + prior descriptors (no simulator data): 30 KB per 2048 positions */
   if (threadIdx.x == 0) s_n = 0u;
   __syncthreads();
 
@@ -271,7 +285,6 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     if (acc) s_list[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = r;
   }
   if (lane == 0u) { s_cnt[0][threadIdx.x >> 6] = wacc; s_cnt[1][threadIdx.x >> 6] = wsim; }
-  stage.store(s_model);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
@@ -288,7 +301,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     const uint32_t ri = s_list[on ? t : 0u];
     uint32_t ra, rb;
     double g, log_u;
-    particle_draws<L>(&s_model.tab, a.hm.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+    particle_draws<L>(&s_model.tab, a.hm.icdf_all, a.hm.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
     const uint32_t bi = packed_bit(a.bits, ri), ba = packed_bit(a.bits, ra), bb = packed_bit(a.bits, rb);
     double ti[C], ta[C], tb[C], tp[C], pp[C];
     load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
@@ -340,79 +353,86 @@ __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   constexpr int LD = L * C;
+  constexpr uint32_t PB = ABZ_BLOCK / L;
   const HotModel& M = a.hm;
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t grp = gid / L;
-  const int j = (int)(gid % L);
-  const bool active = grp < a.n_local;
-  const uint32_t i = a.i0 + (active ? grp : 0u);
   const uint64_t seed = M.seed;
   __shared__ ModelLds<LD> s_model;
-  /* Order of issue = order of need: three dependent round trips (state + candidate count | order[] | rows) instead of five;
-   * the Philox words need no memory, the model tables are staged while the rows are in flight */
-  ModelStage<SIM, LD> stage;
-  stage.load(M);
-  const double lpi = a.logpi[i];
-  const double di = a.delta[i];
-  const uint32_t cnt_i = a.cnt[i];                                        /* meaningful only where di > eps (abz_sort.hip) */
+  stage_model<SIM, LD>(s_model, M);
+  __syncthreads();                                                          /* once per workgroup */
+  const int j = (int)(threadIdx.x % L);
   const double eps_pop = a.eps_pop_dev ? abz_u2d(*a.eps_pop_dev) : a.eps_pop;
-  const abz_u64x2 w_better = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER);
-  const abz_u64x2 w_donor = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR);
-  const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
-  uint32_t s = i;
-  if (di > eps) {                                                         /* mc:20-24 */
-    s = a.order[abz_randint(w_better.w0, cnt_i)];
-  }
-  uint32_t ia, ib;                                                        /* mc:25-32 */
-  abz_donor_ranks(w_donor, a.N, s, &ia, &ib);
+  const uint32_t ntiles = (a.n_local + PB - 1) / PB;
+  /* driver reductions of the generation this sweep leaves behind (mc:146,156,163), carried over the workgroup's tiles:
+   * #(Ds > eps_target), nsims, extrema(Ds) as order keys */
+  unsigned int n_gt = 0u, n_sim = 0u;
+  unsigned long long lo = ~0ull, hi = 0ull;
+  ABZ_TILE_LOOP(tile, ntiles) {
+    const uint32_t grp = tile * PB + threadIdx.x / L;
+    const bool active = grp < a.n_local;
+    const uint32_t i = a.i0 + (active ? grp : 0u);
+    /* Order of issue = order of need: three dependent round trips (state + candidate count | order[] | rows); the Philox
+     * words need no memory */
+    const double lpi = a.logpi[i];
+    const double di = a.delta[i];
+    const uint32_t cnt_i = a.cnt[i];                                        /* meaningful only where di > eps (abz_sort.hip) */
+    const abz_u64x2 w_better = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER);
+    const abz_u64x2 w_donor = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR);
+    const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
+    uint32_t s = i;
+    if (di > eps) {                                                         /* mc:20-24 */
+      s = a.order[abz_randint(w_better.w0, cnt_i)];
+    }
+    uint32_t ia, ib;                                                        /* mc:25-32 */
+    abz_donor_ranks(w_donor, a.N, s, &ia, &ib);
 
-  double ti[C], ts[C], ta[C], tb[C];
-  load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
-  load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
-  load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
-  load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
-  stage.store(s_model);
-  __syncthreads();
+    double ti[C], ts[C], ta[C], tb[C];
+    load_row<L, C>(a.theta + (size_t)i * LD, j, ti);
+    load_row<L, C>(a.theta + (size_t)s * LD, j, ts);
+    load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
+    load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
 
-  double z0, z1;
-  abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
-  const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
-  double tp[C], pp[C];
+    const double z0 = normal_icdf_dev(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER).w0, &s_model.tab, M.icdf_all);
+    const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
+    double tp[C], pp[C];
 #pragma unroll
-  for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
+    for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);              /* mc:41 */
-  const double w_prior = lp - lpi;                                        /* mc:42 */
-  const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
-  double mn = w_prior < 0.0 ? w_prior : 0.0;
-  if (abz_isnan(w_prior)) mn = w_prior;
-  const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
-  bool acc = false;
-  double dp = di;
-  if (simulate) {
-    dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
-    const double thr = eps > di ? eps : di;
-    acc = dp <= thr;                                                      /* mc:54 */
-  }
-  if (active) {
-    double to[C];
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);              /* mc:41 */
+    const double w_prior = lp - lpi;                                        /* mc:42 */
+    const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
+    double mn = w_prior < 0.0 ? w_prior : 0.0;
+    if (abz_isnan(w_prior)) mn = w_prior;
+    const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
+    bool acc = false;
+    double dp = di;
+    if (simulate) {
+      dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
+      const double thr = eps > di ? eps : di;
+      acc = dp <= thr;                                                      /* mc:54 */
+    }
+    if (active) {
+      double to[C];
 #pragma unroll
-    for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
-    store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
-    if (j == 0) {
-      a.nlogpi[i] = acc ? lp : lpi;
-      a.ndelta[i] = acc ? dp : di;
-      if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
+      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+      store_row<L, C>(a.ntheta + (size_t)i * LD, j, to);
+      if (j == 0) {
+        a.nlogpi[i] = acc ? lp : lpi;
+        a.ndelta[i] = acc ? dp : di;
+        if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
+      }
+    }
+    const double dn = acc ? dp : di;
+    if (active && j == 0) {
+      n_gt += dn > a.eps_target ? 1u : 0u;
+      n_sim += simulate ? 1u : 0u;
+      const unsigned long long key = f64_order_key(dn);
+      lo = key < lo ? key : lo;
+      hi = key > hi ? key : hi;
     }
   }
-  /* driver reductions of the generation this sweep leaves behind, folded in (mc:146,156,163): #(Ds > eps_target) and
-   * extrema(Ds) over this call's particles */
-  const double dn = acc ? dp : di;
-  const bool lead = active && j == 0;
-  block_count2(lead && dn > a.eps_target, lead && simulate, a.cslots, ABZ_C_MCGT);   /* (MCGT, MCSIM) */
+  block_count2(n_gt, n_sim, a.cslots, ABZ_C_MCGT);   /* (MCGT, MCSIM) */
   {
     __shared__ unsigned long long s_mm[2][ABZ_BLOCK / 64];
-    unsigned long long lo = lead ? f64_order_key(dn) : ~0ull, hi = lead ? f64_order_key(dn) : 0ull;
     for (int off = 32; off; off >>= 1) {
       const unsigned long long x = __shfl_xor(lo, off, 64), y = __shfl_xor(hi, off, 64);
       lo = x < lo ? x : lo;
@@ -448,36 +468,35 @@ __device__ inline void blob_eval_kernel_body(const HotModel& M, const double* __
                                              const uint64_t* __restrict__ stamp, uint32_t n,
                                              double* __restrict__ blob, double* __restrict__ delta_out, uint32_t nbw) {
   constexpr int LD = L * C;
+  constexpr uint32_t PB = ABZ_BLOCK / L;
   __shared__ ModelLds<LD> s_model;
-  {
-    ModelStage<SIM, LD> stage;
-    stage.load(M);
-    stage.store(s_model);
-  }
+  stage_model<SIM, LD>(s_model, M);
   __syncthreads();
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  const uint32_t s = gid / L;
-  const int j = (int)(gid % L);
-  if (s >= n) return;                         /* whole groups leave together */
-  double th[C], pp[C];
-  load_row<L, C>(theta + (size_t)s * LD, j, th);
-  (void)group_logprior<L, C>(s_model.prior, j, th, pp);        /* push_p (types.jl:20-23) */
-  const uint64_t st = stamp[s];
-  const uint32_t purpose = abz_stamp_is_init(st) ? (uint32_t)ABZ_RNG_INIT_SIM : (uint32_t)ABZ_RNG_SIM;
-  if constexpr (SIM == ABZ_SIM_MVN) {
-    double b[C];
-    const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
-                                                abz_stamp_epoch(st), purpose, b);
-    store_row<L, C>(blob + (size_t)s * nbw, j, b);             /* nbw == LD */
-    if (j == 0) delta_out[s] = dl;
-  } else {
-    static_assert(SIM == ABZ_SIM_MVN || L == 1, "only the MVN simulator spreads a row over lanes");
-    double b[BlobLocal<SIM>::N];
-    const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
-                                                abz_stamp_epoch(st), purpose, b);
-    const int nb = M.n_blob < BlobLocal<SIM>::N ? M.n_blob : BlobLocal<SIM>::N;
-    for (int q = 0; q < nb; ++q) blob[(size_t)s * nbw + q] = b[q];
-    delta_out[s] = dl;
+  const int j = (int)(threadIdx.x % L);
+  const uint32_t ntiles = (n + PB - 1) / PB;
+  ABZ_TILE_LOOP(tile, ntiles) {
+    const uint32_t s = tile * PB + threadIdx.x / L;
+    if (s >= n) continue;                       /* whole groups leave together; no barrier inside the loop */
+    double th[C], pp[C];
+    load_row<L, C>(theta + (size_t)s * LD, j, th);
+    (void)group_logprior<L, C>(s_model.prior, j, th, pp);        /* push_p (types.jl:20-23) */
+    const uint64_t st = stamp[s];
+    const uint32_t purpose = abz_stamp_is_init(st) ? (uint32_t)ABZ_RNG_INIT_SIM : (uint32_t)ABZ_RNG_SIM;
+    if constexpr (SIM == ABZ_SIM_MVN) {
+      double b[C];
+      const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
+                                                  abz_stamp_epoch(st), purpose, b);
+      store_row<L, C>(blob + (size_t)s * nbw, j, b);             /* nbw == LD */
+      if (j == 0) delta_out[s] = dl;
+    } else {
+      static_assert(SIM == ABZ_SIM_MVN || L == 1, "only the MVN simulator spreads a row over lanes");
+      double b[BlobLocal<SIM>::N];
+      const double dl = sim_dist<SIM, L, C, true>(M, &s_model.tab, j, pp, s_model.y, abz_stamp_origin(st),
+                                                  abz_stamp_epoch(st), purpose, b);
+      const int nb = M.n_blob < BlobLocal<SIM>::N ? M.n_blob : BlobLocal<SIM>::N;
+      for (int q = 0; q < nb; ++q) blob[(size_t)s * nbw + q] = b[q];
+      delta_out[s] = dl;
+    }
   }
 }
 

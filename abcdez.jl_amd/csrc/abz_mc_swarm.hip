@@ -24,7 +24,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   a.hm = ctx->hot; a.order = order; a.cnt = cnt;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;
-  const unsigned nblocks = abz_grid((uint64_t)n_local * (uint64_t)ctx->L);
+  const unsigned ntiles = abz_grid((uint64_t)n_local * (uint64_t)ctx->L);       /* tiles of ABZ_BLOCK threads; the workgroups loop over them */
   a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
   a.mm_cur = ctx->d_scal + ABZ_S_MM0 + (size_t)ctx->mm_bank * 2 * ABZ_MMSLOTS;
   a.mm_nxt = ctx->d_scal + ABZ_S_MM0 + (size_t)(1 - ctx->mm_bank) * 2 * ABZ_MMSLOTS;
@@ -35,13 +35,16 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   bool ok = true;
   const int tk = abz_time_begin(ctx);
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
-    if (int rc = abz_jit_launch_mc(ctx, &a, nblocks)) return rc;
+    if (int rc = abz_jit_launch_mc(ctx, &a, ntiles)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {
-      if (ctx->prior_plain)
-        hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-      else
-        hipLaunchKernelGGL((mc_swarm_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      if (ctx->prior_plain) {
+        auto kern = mc_swarm_kernel<S(), LL(), CC(), true>;
+        hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      } else {
+        auto kern = mc_swarm_kernel<S(), LL(), CC(), false>;
+        hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+      }
     });
   }
   abz_time_end(ctx, tk, n_local);

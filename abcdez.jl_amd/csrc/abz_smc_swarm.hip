@@ -10,20 +10,26 @@
  *
  * HBM roofline: per update 3 rows of 8 ld bytes read (own row, two donor rows) + 16 B state, and for an
  * accepted proposal one row + 16 B written.  Everything that does not depend on loaded data (prior descriptors,
- * data vector, model scalars, sampler tables) is fetched before the first dependent load, so a wave waits on two
- * memory round trips: slot bits (an L2-resident bitmap) -> rows.
+ * data vector, sampler tables) is staged into LDS once per workgroup, which then loops over tiles of the prefix
+ * (abz_persistent_grid); per tile a wave waits on two memory round trips: slot bits (an L2-resident bitmap) -> rows.
  */
 #include "abz_dispatch.h"
 #include "abz_kernels.h"
 
 /* ================================================================ packed population (abz_kernels.h) */
-#ifndef ABZ_SWEEP_WAVES
-#define ABZ_SWEEP_WAVES_ATTR
-#else
-#define ABZ_SWEEP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ABZ_SWEEP_WAVES, ABZ_SWEEP_WAVES)))
-#endif
+/* Wide rows (8 components per lane: the d = 32 configuration): the body needs 94 VGPRs when it is compiled for five waves
+ * per SIMD and without machine-LICM (csrc/Makefile: the tile loop's invariants -- polynomial constants, partial Philox
+ * products -- otherwise sit in registers across the whole body: 139 VGPRs, 3 waves); the register allocator has to be told,
+ * it does not find the schedule by itself.  The kernel is fastest at 5 (profiles/r02_pattern_occupancy.jsonl). */
+template <int L, int C>
+struct SweepWaves {
+  static constexpr bool wide = C == 8 && L >= 4;    /* the shapes default_shape() picks for ld >= 32 */
+  static constexpr int lo = wide ? 5 : 1;
+  static constexpr int hi = wide ? 5 : 8;
+};
 template <int SIM, int L, int C, bool PLAIN>
-__global__ __launch_bounds__(ABZ_BLOCK) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
+__global__ __launch_bounds__(ABZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SweepWaves<L, C>::lo, SweepWaves<L, C>::hi)))
+void smc_swarm_packed_kernel(const SmcPackedArgs a) {
   smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
 template <int L, int C, bool PLAIN>
@@ -46,18 +52,21 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   if (a.n_work == 0) return 0;
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
-  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+  const unsigned ntiles = abz_grid((uint64_t)a.n_work * (uint64_t)L);           /* tiles of ABZ_BLOCK threads; the workgroups loop over them */
   const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
-    if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+    if (int rc = abz_jit_launch_smc_packed(ctx, &a, ntiles)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {
-        if (ctx->prior_plain)
-          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-        else
-          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+        if (ctx->prior_plain) {
+          auto kern = smc_swarm_packed_kernel<S(), LL(), CC(), true>;
+          hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+        } else {
+          auto kern = smc_swarm_packed_kernel<S(), LL(), CC(), false>;
+          hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+        }
       }
     });
   }

@@ -68,6 +68,9 @@ def lib():
     L.orc_kernel_logpdf.restype = _f64
     L.orc_kernel_logpdf.argtypes = [C.c_int, _f64, _f64]
     L.orc_philox.argtypes = [_vp, _vp, _vp]
+    L.orc_philox_r.argtypes = [C.c_int, _vp, _vp, _vp]
+    L.orc_philox_rounds.restype = C.c_int
+    L.orc_normal_icdf.argtypes = [_vp, _i64, _vp, _vp, _vp]
     L.orc_donor_ranks.argtypes = [_u64, _u64, _u32, _u32, _vp, _vp]
     L.orc_weight_fix.restype = _u64
     L.orc_weight_fix.argtypes = [_f64, _u32]

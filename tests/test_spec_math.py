@@ -12,11 +12,14 @@ M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 
 
-def py_philox4x32_10(ctr, key):
-    """Independent restatement of Philox4x32-10 (Salmon et al., SC'11)."""
+ROUNDS = 7      # ABZ_PHILOX_ROUNDS (abcdez_spec.h): the smallest Crush-resistant Philox4x32 of Salmon et al. (SC'11)
+
+
+def py_philox4x32(ctr, key, rounds=ROUNDS):
+    """Independent restatement of Philox4x32-R (Salmon et al., SC'11)."""
     c = list(ctr)
     k = list(key)
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c[0]
         p1 = M1 * c[2]
         c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & MASK, (p0 >> 32) ^ c[3] ^ k[1], p0 & MASK]
@@ -24,11 +27,14 @@ def py_philox4x32_10(ctr, key):
     return c
 
 
-def c_philox(O, ctr, key):
+def c_philox(O, ctr, key, rounds=None):
     c = np.array(ctr, dtype=np.uint32)
     k = np.array(key, dtype=np.uint32)
     out = np.zeros(4, dtype=np.uint32)
-    O.lib().orc_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    if rounds is None:
+        O.lib().orc_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)            # the product's stream
+    else:
+        O.lib().orc_philox_r(rounds, c.ctypes.data, k.ctypes.data, out.ctypes.data)  # the same round function, any count
     return [int(v) for v in out]
 
 
@@ -43,8 +49,13 @@ KAT = [
 
 @pytest.mark.parametrize("ctr,key,expect", KAT)
 def test_philox_known_answers(oracle, ctr, key, expect):
-    assert c_philox(oracle, ctr, key) == expect
-    assert py_philox4x32_10(ctr, key) == expect
+    """the round function and key schedule against the published 10-round vectors; the product runs the same code for 7"""
+    assert c_philox(oracle, ctr, key, rounds=10) == expect
+    assert py_philox4x32(ctr, key, rounds=10) == expect
+
+
+def test_philox_rounds_constant(oracle):
+    assert oracle.lib().orc_philox_rounds() == ROUNDS
 
 
 def test_philox_vs_independent_python(oracle):
@@ -52,14 +63,63 @@ def test_philox_vs_independent_python(oracle):
     for _ in range(300):
         ctr = [int(v) for v in rng.integers(0, 1 << 32, 4)]
         key = [int(v) for v in rng.integers(0, 1 << 32, 2)]
-        assert c_philox(oracle, ctr, key) == py_philox4x32_10(ctr, key)
+        assert c_philox(oracle, ctr, key) == py_philox4x32(ctr, key)
+        for r in (1, 3, 10):
+            assert c_philox(oracle, ctr, key, rounds=r) == py_philox4x32(ctr, key, rounds=r)
 
 
 def test_rng_word_packing(oracle):
     out = np.zeros(2, dtype=np.uint64)
     oracle.lib().orc_rng_words(0x0123456789ABCDEF, 7, 11, 3, 6, out.ctypes.data)
-    r = py_philox4x32_10([7, 11, 3, 6], [0x89ABCDEF, 0x01234567])
+    r = py_philox4x32([7, 11, 3, 6], [0x89ABCDEF, 0x01234567])
     assert int(out[0]) == (r[1] << 32) | r[0] and int(out[1]) == (r[3] << 32) | r[2]
+
+
+def _stream_words(oracle, seed, idx, epoch, sub, purpose):
+    """(n, 2) u64 words of the product's RNG for broadcastable counter arrays"""
+    idx, epoch, sub, purpose = np.broadcast_arrays(idx, epoch, sub, purpose)
+    out = np.zeros((idx.size, 2), dtype=np.uint64)
+    o = np.zeros(2, dtype=np.uint64)
+    L = oracle.lib()
+    for k, (a, b, c, d) in enumerate(zip(idx.ravel(), epoch.ravel(), sub.ravel(), purpose.ravel())):
+        L.orc_rng_words(seed, int(a), int(b), int(c), int(d), o.ctypes.data)
+        out[k] = o
+    return out
+
+
+def test_philox7_stream_battery(oracle):
+    """A sanity battery on the 7-round stream as the product addresses it (consecutive counters, one key) -- no substitute
+    for TestU01 (the round count rests on Salmon et al.'s BigCrush result), but it would catch a botched round function:
+    bit frequencies, byte chi-square, lag-1 correlation along each counter axis, avalanche of a one-bit counter change."""
+    n = 60000
+    w = _stream_words(oracle, 0x9E3779B97F4A7C15, np.arange(n), 3, 0, 6)
+    bits = np.unpackbits(w.view(np.uint8).reshape(n, 16), axis=1)            # n x 128
+    freq = bits.mean(axis=0)
+    assert np.all(np.abs(freq - 0.5) < 5 / (2 * np.sqrt(n)))                   # every output bit is fair (5 sigma)
+    byt = w.view(np.uint8).ravel()
+    assert stats.chisquare(np.bincount(byt, minlength=256)).pvalue > 1e-4
+    u = (w[:, 0] >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(n)             # neighbouring particles
+    for axis in ("epoch", "sub", "purpose"):
+        kw = dict(idx=7, epoch=1, sub=0, purpose=6)
+        kw[axis] = np.arange(20000)
+        v = _stream_words(oracle, 12345, kw["idx"], kw["epoch"], kw["sub"], kw["purpose"])
+        x = (v[:, 0] >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5 / np.sqrt(x.size), axis
+        assert stats.kstest(x, "uniform").pvalue > 1e-4, axis
+    # avalanche: flipping one counter bit flips ~half of the 128 output bits
+    rng = np.random.default_rng(2)
+    flips = []
+    for _ in range(400):
+        ctr = [int(v) for v in rng.integers(0, 1 << 32, 4)]
+        key = [int(v) for v in rng.integers(0, 1 << 32, 2)]
+        a = c_philox(oracle, ctr, key)
+        word, bit = int(rng.integers(0, 4)), int(rng.integers(0, 32))
+        ctr2 = list(ctr)
+        ctr2[word] ^= 1 << bit
+        b = c_philox(oracle, ctr2, key)
+        flips.append(sum(bin(x ^ y).count("1") for x, y in zip(a, b)))
+    assert abs(np.mean(flips) - 64) < 1.5 and min(flips) > 30
 
 
 def ulp_err(y, ref_mp):
@@ -153,35 +213,82 @@ def test_table_log_accuracy(oracle):
     assert np.max(np.abs(a - b) / np.spacing(np.abs(b))) <= 3
 
 
-def test_table_sincos_accuracy(oracle):
+def _icdf(oracle, w, want_index=False):
+    w = np.ascontiguousarray(w, dtype=np.uint64)
+    z = np.zeros(w.size)
+    row = np.zeros(w.size, dtype=np.uint32)
+    tau = np.zeros(w.size)
+    oracle.lib().orc_normal_icdf(w.ctypes.data, w.size, z.ctypes.data, row.ctypes.data, tau.ctypes.data)
+    return (z, row, tau) if want_index else z
+
+
+def _icdf_exact(w):
+    """what abz_normal_icdf approximates, from its definition (abcdez_spec.h), in mpmath"""
+    w = int(w)
+    sgn = -1 if w >> 63 else 1
+    v = (w << 1) & ((1 << 64) - 1)
+    lz = 63 if v == 0 else 64 - v.bit_length()
+    A = ((v << lz) << 1) & ((1 << 64) - 1)
+    i = A >> 59
+    m52 = ((A << 5) & ((1 << 64) - 1)) >> 12
+    t = (mpmath.mpf(i) + mpmath.mpf(m52) / 2 ** 52) / 32
+    p = mpmath.ldexp(1 + t, -(lz + 1)) / 2                               # upper-tail probability
+    x = mpmath.mpf(float(stats.norm.isf(float(p)))) if p > mpmath.mpf(10) ** -300 else mpmath.sqrt(-2 * mpmath.log(p))
+    for _ in range(6):                                                    # Newton on erfc at 200 bits
+        q = mpmath.erfc(x / mpmath.sqrt(2)) / 2
+        x = x + (q - p) * mpmath.sqrt(2 * mpmath.pi) * mpmath.exp(x * x / 2)
+    return sgn * x, lz * 32 + i
+
+
+def test_normal_icdf_accuracy(oracle):
+    """abz_normal_icdf against the exact quantile, every binade of the table: random words plus words forced into each of
+    the 63 binades and the corners; error relative to max(|x|, 1/4)"""
     mpmath.mp.prec = 200
     rng = np.random.default_rng(13)
-    u = np.concatenate([rng.integers(0, 1 << 52, 4000).astype(np.float64) * 2.0 ** -52,
-                        np.arange(0, 256) / 256.0, (np.arange(0, 256) + 0.5) / 256.0, [1 - 2.0 ** -52, 2.0 ** -52]])
-    s, c = eval_fn(oracle, 8, u)
+    ws = [int(v) for v in rng.integers(0, 1 << 64, 2500, dtype=np.uint64)]
+    for lz in range(63):
+        for _ in range(24):
+            r = int(rng.integers(0, 1 << 63, dtype=np.uint64)) | (1 << 62)
+            ws.append((r >> lz) | (int(rng.integers(0, 2)) << 63))
+    ws += [0, 1 << 63, (1 << 63) - 1, (1 << 64) - 1, 1, 2, 3, 1 << 62, (1 << 62) - 1]
+    z, row, tau = _icdf(oracle, np.array(ws, dtype=np.uint64), want_index=True)
     worst = 0.0
-    for ui, si, ci in zip(u, s, c):
-        a = 2 * mpmath.pi * mpmath.mpf(float(ui))
-        worst = max(worst, float(abs(mpmath.mpf(float(si)) - mpmath.sin(a))), float(abs(mpmath.mpf(float(ci)) - mpmath.cos(a))))
-    assert worst < 2.3e-16, worst                     # absolute, i.e. ~1 ulp of values near 1
-    assert np.all(np.abs(s * s + c * c - 1) < 5e-16)
-    e = eval_fn(oracle, 8, np.array([0.0, 0.25, 0.5, 0.75]))
-    assert list(e[0]) == [0.0, 1.0, 0.0, -1.0] and list(e[1]) == [1.0, 0.0, -1.0, 0.0]
+    for wi, zi, ri in zip(ws, z, row):
+        ex, rr = _icdf_exact(wi)
+        assert rr == ri
+        worst = max(worst, float(abs(mpmath.mpf(float(zi)) - ex) / max(abs(ex), mpmath.mpf(0.25))))
+    assert worst < 2.5e-16, worst
+    assert np.all(np.abs(tau) <= 0.5) and row.max() == 63 * 32
+    # sign symmetry and monotonicity in the uniform the word encodes
+    w = rng.integers(0, 1 << 63, 100000, dtype=np.uint64)
+    assert np.array_equal(_icdf(oracle, w), -_icdf(oracle, w | np.uint64(1 << 63)))
+    ws = np.sort(w)
+    zs = _icdf(oracle, ws)
+    assert np.all(np.diff(zs) <= 1e-15)                                   # larger field = larger U = smaller |x| (to rounding at the seams)
+    assert abs(_icdf(oracle, np.array([0], dtype=np.uint64))[0] - 9.155293772686072) < 1e-12     # deepest point of the table
 
 
-def test_sqrt_pn_is_sqrt_on_host(oracle):
+def test_normal_icdf_distribution(oracle):
+    """10^7 draws: moments, Kolmogorov-Smirnov against the normal CDF, tail counts against their binomial expectations"""
     rng = np.random.default_rng(14)
-    x = np.exp(rng.uniform(-37, 5, 100000))
-    assert np.array_equal(eval_fn(oracle, 9, x)[0], np.sqrt(x))
+    n = 10_000_000
+    z = _icdf(oracle, rng.integers(0, 1 << 64, n, dtype=np.uint64))
+    assert abs(z.mean()) < 4 / np.sqrt(n)
+    assert abs(z.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 4 * np.sqrt(6 / n)
+    assert abs(stats.kurtosis(z)) < 4 * np.sqrt(24 / n)
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    for thr in (2.0, 3.0, 4.0, 4.5):
+        cnt = int(np.sum(np.abs(z) > thr))
+        exp = n * 2 * stats.norm.sf(thr)
+        assert abs(cnt - exp) < 5 * np.sqrt(exp) + 1, (thr, cnt, exp)
 
 
 def test_uniform_conversions(oracle):
     L = oracle.lib()
-    assert L.orc_u01(0, 2) == 0.0 and L.orc_u01((1 << 64) - 1, 2) == 1 - 2.0 ** -52
     rng = np.random.default_rng(15)
     for w in (int(v) for v in rng.integers(0, 1 << 64, 2000, dtype=np.uint64)):
         assert L.orc_u01(w, 1) == ((w >> 12) + 0.5) * 2.0 ** -52        # bit trick == the defining formula
-        assert L.orc_u01(w, 2) == (w >> 12) * 2.0 ** -52
     assert L.orc_u01(0, 1) == 2.0 ** -53 and L.orc_u01((1 << 64) - 1, 1) == 1 - 2.0 ** -53
     assert L.orc_u01(0, 0) == 0.0 and L.orc_u01((1 << 64) - 1, 0) == 1 - 2.0 ** -53
     assert L.orc_randint(0, 10) == 0 and L.orc_randint((1 << 64) - 1, 10) == 9
@@ -197,7 +304,7 @@ def test_normal_pairs_are_standard_normal(oracle):
     assert abs(stats.kurtosis(z)) < 0.03
     assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
     assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01          # the two outputs of a pair are independent
-    assert np.abs(z).max() < 8.6                                   # sqrt(-2 log 2^-53)
+    assert np.abs(z).max() < 9.2                                   # the table ends at 9.155 (P = 2^-64)
     assert stats.kstest(z[200000:400000] ** 2 + z[400000:600000] ** 2, 'chi2', args=(2,)).pvalue > 1e-3
 
 
