@@ -259,6 +259,7 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
 int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
   ABZ_REQUIRE(ctx, "set_stream: null context");
   ctx->stream = (hipStream_t)hip_stream;
+  ctx->ahead = abz_ahead{};            /* a select enqueued ahead sits on the old stream */
   return 0;
 }
 
@@ -381,6 +382,7 @@ int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_
   ABZ_REQUIRE(stamp_cur == nullptr || stamp_cur != stamp_nxt, "set_stamps: the two arrays must differ");
   ABZ_REQUIRE(stamp_cur == nullptr || ctx->h_model.n_blob > 0, "set_stamps: the model was created with n_blob = 0");
   ctx->stamp_cur = stamp_cur; ctx->stamp_nxt = stamp_nxt;
+  ctx->ahead = abz_ahead{};
   return 0;
 }
 
@@ -484,6 +486,15 @@ int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t*
   return 0;
 }
 
+/* Forget a select enqueued (or armed) ahead.  The library does so itself in every entry point that changes the distances or
+ * the flags; a host that writes them by other means (a copy into the arrays, a resumed checkpoint) or that ends a run says so
+ * here -- otherwise a later prologue with equal arguments would reuse eps and extrema made from the old contents. */
+int abcdez_smc_select_discard(abcdez_ctx* ctx) {
+  ABZ_REQUIRE(ctx, "smc_select_discard: null context");
+  ctx->ahead = abz_ahead{};
+  return 0;
+}
+
 /* The sweeps of one generation (smc:336-353) in ONE enqueue and ONE read-back: sweep k+1 is launched behind a device-side
  * evaluation of the early-exit test `sum(naccs) / n_alive >= Kmcmc_min` (smc:352) on the counters of sweeps 1..k, and
  * returns at once when it holds.  Same arithmetic as the host's test (one IEEE division of exactly represented integers). */
@@ -495,6 +506,9 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   ABZ_REQUIRE(1 <= k_max && k_max <= ABZ_GROUP_MAX, "smc_sweeps_packed: 1 <= k_max <= 16 sweeps per call");
   ABZ_REQUIRE(slot0 != slot1 && bits_a != bits_b, "smc_sweeps_packed: the two slots / bit arrays must differ");
   ABZ_REQUIRE(kmcmc_min >= 0.0, "smc_sweeps_packed: Kmcmc_min must not be negative");
+  /* the group's acceptances are counted from the (nacc, nsim) slot totals at the last read-back.  Every call that adds to those
+   * two classes reads them back before it returns; a sweep launched WITHOUT counters (abcdez_smc_swarm_packed with nacc = NULL,
+   * the sharded path) adds to the ABZ_C_DISCARD classes instead, so it cannot leak into the device-side test of smc:352 */
   const unsigned long long base_acc = ctx->cnt_prev[ABZ_C_NACC], base_sim = ctx->cnt_prev[ABZ_C_NSIM];
   const abz_ahead armed = ctx->ahead;
   ctx->ahead = abz_ahead{};
@@ -777,18 +791,11 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   const int slot = (int)(ticket % ABZ_MC_RING);
   const volatile unsigned long long* snap = ctx->h_ring + (size_t)slot * ABZ_RING_WORDS;
   if (!ctx->ring_folded[slot]) {
-    /* the snapshot kernel stores the ticket word last (system-scope release): poll it; a failed launch cannot hang us */
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (__atomic_load_n(ctx->h_ring + (size_t)slot * ABZ_RING_WORDS + ABZ_RING_WORDS - 1, __ATOMIC_ACQUIRE) != (unsigned long long)ticket + 1ull) {
-      if ((++spins & 1023u) == 0) {
-        if (hipStreamQuery(ctx->stream) == hipSuccess &&
-            __atomic_load_n(ctx->h_ring + (size_t)slot * ABZ_RING_WORDS + ABZ_RING_WORDS - 1, __ATOMIC_ACQUIRE) != (unsigned long long)ticket + 1ull) {
-          abz_set_error("mc_generation_wait: the stream drained without the generation's snapshot"); return -2;
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { abz_set_error("mc_generation_wait: timed out"); return -2; }
-      }
-    }
+    /* the snapshot kernel stores the ticket word last (system-scope release): poll it; a failed launch cannot hang us, and a
+     * failure leaves the ring as it was (the ticket stays unredeemed) */
+    const int rc = abz_poll_word(ctx, ctx->h_ring + (size_t)slot * ABZ_RING_WORDS + ABZ_RING_WORDS - 1, (unsigned long long)ticket + 1ull);
+    if (rc < 0) return rc;
+    if (rc == 1) { abz_set_error("mc_generation_wait: the stream drained without the generation's snapshot"); return -2; }
   }
   ring_fold(ctx, ticket);
   ctx->mc_waited += 1;

@@ -8,6 +8,7 @@
  * All HBM-streaming, a few bytes per particle per generation.
  */
 #include <chrono>
+#include <sched.h>
 #include <string.h>
 
 #include "abz_ctx.h"
@@ -206,20 +207,33 @@ int abz_publish_launch(abcdez_ctx* ctx, int nwords, unsigned long long* seq_out)
   *seq_out = seq;
   return 0;
 }
+int abz_poll_word(abcdez_ctx* ctx, const unsigned long long* word, unsigned long long expected) {
+  unsigned spins = 0;
+  std::chrono::steady_clock::time_point t0;
+  for (;;) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == expected) return 0;
+    ++spins;
+    if (spins < 2048u) { __builtin_ia32_pause(); continue; }       /* ~20 us: a read-back behind one kernel arrives within this */
+    if (spins == 2048u) t0 = std::chrono::steady_clock::now();
+    sched_yield();                                                  /* longer waits (a whole group of sweeps): give the core away */
+    if ((spins & 63u) != 0u) continue;
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2);
+    if (q == hipSuccess || late) {
+      if (late) ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));   /* heavy user simulators, huge populations: block, however long */
+      return __atomic_load_n(word, __ATOMIC_ACQUIRE) == expected ? 0 : 1;
+    }
+    if (q != hipErrorNotReady) ABZ_HIP_CHECK(q);
+  }
+}
 /* waits for THAT publish kernel only: work enqueued behind it may still be running when this returns */
 int abz_publish_wait(abcdez_ctx* ctx, int nwords, unsigned long long seq) {
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  while (__atomic_load_n(ctx->h_scal + ABZ_S_N, __ATOMIC_ACQUIRE) != seq) {
-    if ((++spins & 4095u) == 0) {
-      if (hipStreamQuery(ctx->stream) == hipSuccess && __atomic_load_n(ctx->h_scal + ABZ_S_N, __ATOMIC_ACQUIRE) != seq) {
-        /* the stream drained without the word (a failed launch): fall back to the copy engine so that the error surfaces */
-        ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, (size_t)nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        return 0;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) { abz_set_error("read-back timed out"); return -2; }
-    }
+  const int rc = abz_poll_word(ctx, ctx->h_scal + ABZ_S_N, seq);
+  if (rc < 0) return rc;
+  if (rc == 1) {
+    /* the stream drained without the word (a failed launch): fall back to the copy engine so that the error surfaces */
+    ABZ_HIP_CHECK(hipMemcpyAsync(ctx->h_scal, ctx->d_scal, (size_t)nwords * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
   return 0;
 }

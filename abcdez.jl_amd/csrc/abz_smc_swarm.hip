@@ -17,15 +17,16 @@
 #include "abz_kernels.h"
 
 /* ================================================================ packed population (abz_kernels.h) */
-/* Wide rows (8 components per lane: the d = 32 configuration): the body needs 94 VGPRs when it is compiled for five waves
- * per SIMD and without machine-LICM (csrc/Makefile: the tile loop's invariants -- polynomial constants, partial Philox
- * products -- otherwise sit in registers across the whole body: 139 VGPRs, 3 waves); the register allocator has to be told,
- * it does not find the schedule by itself.  The kernel is fastest at 5 (profiles/r02_pattern_occupancy.jsonl). */
+/* Wide rows (8 components per lane: the d = 32 configuration) are compiled for FOUR waves per SIMD (128 VGPRs): the LDS
+ * tables (38 KB per workgroup) allow four workgroups per CU anyway, the prefetch of the next round's slot bits needs nine
+ * registers across the simulator, and with the sampler's arithmetic halved a fifth wave no longer pays
+ * (tools/sweep_variants.hip, profiles/r03_sweep_variants.jsonl: 4 waves + prefetch 0.4385 ms, 5 waves without 0.4510 ms,
+ * 5 waves + prefetch spills and takes 0.485 ms; the kernel's memory side alone 0.4197 ms, its arithmetic alone 0.4026 ms). */
 template <int L, int C>
 struct SweepWaves {
   static constexpr bool wide = C == 8 && L >= 4;    /* the shapes default_shape() picks for ld >= 32 */
-  static constexpr int lo = wide ? 5 : 1;
-  static constexpr int hi = wide ? 5 : 8;
+  static constexpr int lo = wide ? 4 : 1;
+  static constexpr int hi = wide ? 4 : 8;
 };
 template <int SIM, int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SweepWaves<L, C>::lo, SweepWaves<L, C>::hi)))
@@ -52,7 +53,9 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   if (a.n_work == 0) return 0;
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
-  const unsigned ntiles = abz_grid((uint64_t)a.n_work * (uint64_t)L);           /* tiles of ABZ_BLOCK threads; the workgroups loop over them */
+  /* loop trips of one workgroup = groups of ABZ_BLOCK / 64 wave-tiles (abz_kernels.h, SweepTile); the workgroups loop over them */
+  const unsigned pb = (L == 1 ? 64u : 32u) * (ABZ_BLOCK / 64);
+  const unsigned ntiles = (unsigned)(((uint64_t)a.n_work + pb - 1) / pb);
   const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {

@@ -155,6 +155,10 @@ class HipOps:
         """arm the next grouped sweeps: they also start the next generation's select (include/abcdez_hip.h)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_ahead(self.ctx, _ptr(delta), _ptr(alive), delta.numel(), alpha, eps_target))
 
+    def smc_select_discard(self):
+        """forget a select armed / enqueued ahead (the population was written by other means, or the run ends)"""
+        _lib.check(self.lib, self.lib.abcdez_smc_select_discard(self.ctx))
+
     def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_replay_packed(
@@ -481,8 +485,15 @@ class PopulationEngine:
             raise RuntimeError(f"{what} needs storage='packed' (abcdesmc); this engine holds abcdemc's double buffer")
 
     # ------------------------------------------------------------------ S1
+    def discard_select_ahead(self):
+        """A select enqueued ahead of its prologue describes the distances / flags as the library last wrote them: every
+        write from the host side (torch copies below) and the end of a run invalidate it."""
+        if hasattr(self.ops, "smc_select_discard"):
+            self.ops.smc_select_discard()
+
     def init_population(self):
         self._stream()
+        self.discard_select_ahead()
         if self._delta_work is not None:
             self._delta_work.wait()
             self._delta_work = None
@@ -497,6 +508,7 @@ class PopulationEngine:
         self._allgather_state(self.buf[self.cur] + ((self.stamp[self.cur],) if self.blob_on else ()))
 
     def reset_weights(self):  # smc:266-270
+        self.discard_select_ahead()
         self.wns.fill_(1.0 / self.N)
         self.alive.fill_(1)
         self.n_alive = self.N
@@ -763,6 +775,7 @@ class PopulationEngine:
 
     def upload_state(self, st: dict):
         """Inverse of :meth:`download_state` (every rank uploads the full arrays)."""
+        self.discard_select_ahead()
         if self._delta_work is not None:
             self._delta_work.wait()
             self._delta_work = None

@@ -250,6 +250,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             break
         if ϵ <= ϵ_target or nsims >= nsims_max or facc < facc_stop:   # smc:376
             break
+    eng.discard_select_ahead()             # a run that stops on nsims_max / facc_stop leaves the next select armed
     if verboseout and len(ranges_ϵ) < len(ϵs):
         ranges_ϵ.append(eng.extrema())     # smc:364 for the last generation
 

@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-whole-run", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="default run only: skip the other single-GPU configurations (mc1d, lv, evidence1d) reported as other_configs")
     p.add_argument("--storage", default=None, choices=["packed"], help="abcdesmc storage (one choice left: the packed population)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
@@ -326,6 +328,11 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         if live:
             out["pattern_ceiling"] = {"updates_per_s": live["particles_per_s"], "read_frac": live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
                                       "kernel_over_ceiling": rate / live["particles_per_s"],
+                                      "updates_per_s_single_launches": live.get("best_single_launches"),
+                                      "kernel_over_ceiling_single_launches": (rate / live["best_single_launches"]) if live.get("best_single_launches") else None,
+                                      "single_launches_are": "the same pattern kernel, 20 launches each between its own pair of events -- how the sweep "
+                                                             "kernel's avg_launch_ms is taken (launch gaps in, no overlap between consecutive launches); "
+                                                             "best of the same occupancy caps",
                                       "source": f"measured in this run on this GPU right after the timed window, in process: tools/layout_bench.hip (packed pattern) "
                                                 f"{live['prefix']} {live['accepted_percent']} (prefix = mean alive count of the timed "
                                                 f"sweeps, accepted = their acceptance rate; mean of 5 x 20 launches; best of four occupancy "
@@ -354,24 +361,30 @@ def pattern_ceiling_live(prefix, accepted_percent, positions):
         fn.restype = C.c_int
     except (OSError, AttributeError):
         return None
-    best = None
+    best, best_single = None, 0.0
     for cap in (0, 5, 4, 3):        # the pattern itself runs fastest at 4 waves per SIMD (fewer streams in flight): take the best
         mean, mn = C.c_double(), C.c_double()
         if fn(positions, prefix, accepted_percent, cap, 5, 20, C.byref(mean), C.byref(mn)) != 0 or not mean.value > 0:
             continue
         v = {"prefix": prefix, "accepted_percent": accepted_percent, "waves_per_simd_cap": cap, "ms_mean": mean.value,
              "particles_per_s": prefix / (mean.value * 1e-3)}
+        # the same pattern timed the way the sweep kernel is timed: one launch between two events (launch gaps included, no
+        # overlap of one launch's tail with the next one's head)
+        if fn(positions, prefix, accepted_percent, cap, 20, 1, C.byref(mean), C.byref(mn)) == 0 and mean.value > 0:
+            best_single = max(best_single, prefix / (mean.value * 1e-3))
         if best is None or v["particles_per_s"] > best["particles_per_s"]:
             best = v
+    if best is not None and best_single > 0:
+        best["best_single_launches"] = best_single
     return best
 
 
 args_config = "smc32"
 
 
-def main():
+def run_config(args):
+    """one configuration: engine, warm-up, timed window, roofline, whole run, CPU baseline -> (result dict on rank 0 else None, pg)"""
     global args_config, PATTERN_LIVE
-    args = parse()
     args_config = args.config
     PATTERN_LIVE = not args.no_pattern and args.gpus == 1
     import torch
@@ -496,6 +509,7 @@ def main():
                 "workload": f"{cfg['workload']}; {ppg} particles/GPU", "name": args.config,
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
                 "timed_window": window,
+                "launched_incl_warmup": {"sweeps": gen.sweeps, "updates": gen.updates},     # what a profiler sees of the sweep kernel
                 "step_includes": ("extrema(Ds), eps-quantile, reweight, ESS, partition (one call), resample when ESS < N/2, "
                                   "<= Kmcmc sweeps with their counter read-backs (smc:301-364)") if cfg["kind"] == "smc" else
                                  "rank pass (while max Ds > eps_target), one sweep with nsim / completion / extrema folded in (mc:140-161)",
@@ -514,6 +528,51 @@ def main():
             faithful, out["cpu_baseline"] = cpu_baseline(A, args, cfg)
             if faithful:
                 out["cpu_baseline_reference_faithful"] = faithful
+        return out, pg
+    return None, pg
+
+
+OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "updates_per_launch",
+              "kernel_updates_per_s", "traffic", "traffic_over_moved_bytes", "traffic_source", "acceptance_rate", "flops_per_update",
+              "rk4_steps_per_s", "bytes_read_per_update")
+
+
+def other_config(args, name):
+    """the other single-GPU configurations of BASELINE.json, each with its own engine, window and (reduced) CPU sample"""
+    import copy
+    import gc
+
+    import torch
+    a = copy.copy(args)
+    a.config, a.steps, a.warmup, a.particles_per_gpu, a.lanes, a.dim = name, None, None, None, 0, 32
+    a.cpu_particles, a.no_pattern = None, True
+    a.cpu_steps = {"mc1d": 4, "lv": 3, "evidence1d": 3}[name]
+    a.no_whole_run = name != "evidence1d"          # the evidence configuration's result IS the whole run: both logZ, the Bayes factor
+    r, _ = run_config(a)
+    gc.collect()
+    torch.cuda.empty_cache()
+    out = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype") if k in r}
+    out["workload"] = r["config"]["workload"]
+    out["timed_window"] = r["config"]["timed_window"]
+    out["roofline"] = {k: r["roofline"][k] for k in OTHER_KEYS if k in r["roofline"]}
+    for k in ("cpu_baseline", "whole_run"):
+        if k in r:
+            out[k] = r[k]
+    return out
+
+
+def main():
+    args = parse()
+    out, pg = run_config(args)
+    if out is not None and args.config == "smc32" and out["n_gpus"] == 1 and not args.no_other_configs and not args.force_collectives:
+        # every other single-GPU configuration BASELINE.json names, in the same run (the headline stays configs[2])
+        out["other_configs"] = {}
+        for name in ("mc1d", "lv", "evidence1d"):
+            try:
+                out["other_configs"][name] = other_config(args, name)
+            except Exception as e:                     # a failing side configuration must not cost the headline line
+                out["other_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
+    if out is not None:
         try:                      # RCCL's start-up banner sits in libc's stdio buffer: push it out BEFORE the result line
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -521,6 +580,7 @@ def main():
             pass
         print(json.dumps(out), flush=True)
     if pg is not None:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

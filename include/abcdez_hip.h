@@ -163,6 +163,9 @@ ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, ui
  * Results are the same either way. */
 ABCDEZ_API int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double alpha,
                                        double eps_target);
+/* Forget a select armed or enqueued ahead.  Every library call that changes the distances or the flags does so itself; a host that
+ * writes those arrays by other means (a copy, a resumed checkpoint), changes the stream, or ends a run calls this. */
+ABCDEZ_API int abcdez_smc_select_discard(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,

@@ -331,6 +331,7 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
             n_alive ≥ 3 || (@warn("No alive particles"); break)                             # smc:375
             (ϵ ≤ ϵ_target || nsims ≥ nsims_max || facc < facc_stop) && break                # smc:376
         end
+        check(ccall((:abcdez_smc_select_discard, LIB), Cint, (Ptr{Cvoid},), e.ctx))        # the run ends: nothing is left armed
         push!(ranges_ϵ, extrema_dev(e))                                                     # smc:364 of the last generation
         P, Wns, Δs, blobs = download(e; packed=true)                                        # smc:382
         return verboseout ? (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs, ϵs = ϵs, ranges_ϵ = ranges_ϵ,

@@ -395,7 +395,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
     if (lp < 0.0 && !abz_isfinite(lp) && !abz_isnan(lp)) continue;  /* smc:135 */
     double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM);   /* smc:137 */
     nsim += 1;                                                      /* smc:138 */
-    double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i])); /* smc:140-141 */
+    double w = ((lp - logpi[i]) + abz_kernel_logpdf(M->abck, eps, dp)) - abz_kernel_logpdf(M->abck, eps, delta[i]);  /* smc:140-141, left to right */
     int acc = (0.0 <= w);
     if (!acc) {                                                     /* smc:145 */
       double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
@@ -738,7 +738,7 @@ ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint
       const double dp = sim_dist(M, pp, i, sweep, ABZ_RNG_SIM);                      /* smc:137 */
       nsim += 1;
       simulated = 1;
-      const double w = (lp - logpi[i]) + (abz_kernel_logpdf(M->abck, eps, dp) - abz_kernel_logpdf(M->abck, eps, delta[i]));
+      const double w = ((lp - logpi[i]) + abz_kernel_logpdf(M->abck, eps, dp)) - abz_kernel_logpdf(M->abck, eps, delta[i]);   /* smc:140-141, left to right */
       acc = (0.0 <= w);
       if (!acc) acc = abz_log_tab(abz_u01_open(abz_rng(M->seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T) < w;  /* smc:145 */
       if (acc) {                                                                     /* smc:146-150 */

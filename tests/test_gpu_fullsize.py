@@ -362,26 +362,30 @@ def test_config2_abcdemc_one_million_particles(oracle):
             nsim_g, n_above, lo_g, hi_g = eng.mc_swarm(max(0.3, lo), 0.3, g0, 1e-5)
             assert (lo_g, hi_g) == eng.extrema() and n_above == eng.count_gt(0.3)      # reductions folded into the sweep
     assert eng.count_gt(0.3) <= 0.02 * N                                 # completion >= 98 % after 60 generations (mc:156)
-    assert eng.extrema()[1] == 1.0790868611451696                        # same value the CPU oracle reaches (seed 3; oracle.run_abcdemc)
+    assert eng.extrema()[1] == 1.0504658598780852                        # the value the CPU oracle reaches: oracle.run_abcdemc(spec, 1 << 20, 0.3, 60)['C'].max(), seed 3
     post = eng.state[0][:, 0]
     assert abs(float(post.mean()) - 30 / 11) < 0.015     # finite-eps bias 0.0075 + Monte Carlo error
     assert abs(float(post.std()) - math.sqrt(10 / 11)) < 0.03
 
 
-def test_config5_two_model_evidence_large_n():
-    """BASELINE.json configs[4] (single-GPU slice): the two models of examples/minimal_example.jl at N = 2^21;
-    logZ against the exact finite-eps evidences, Bayes factor 2.104."""
+@pytest.mark.parametrize("logn,tol_logz,tol_bf", [(21, 0.02, 0.05), (23, 0.01, 0.025)])
+def test_config5_two_model_evidence_large_n(logn, tol_logz, tol_bf):
+    """BASELINE.json configs[4]: the two models of examples/minimal_example.jl (:10-56) at N = 2^21 and at the stated
+    N = 2^23 = 8 M particles (on ONE GPU: at d = 1 the whole population is 0.4 GB): logZ against the exact finite-eps
+    evidences, Bayes factor 2.1043, posterior means; the tolerances tighten with the population."""
     gold = json.load(open(os.path.join(GOLD_DIR, "reference_known_answers.json"), encoding="utf-8"))["analytic"]
-    N = 1 << 21
+    N = 1 << logn
     out = []
     for s2, key in ((10, "Z_exact_finite_eps_sigma2_10"), (100, "Z_exact_finite_eps_sigma2_100")):
         r = A.abcdesmc(A.Normal(0, math.sqrt(s2)), A.Normal1D(3.0), 0.3, None, nparticles=N, verbose=False, rng=s2,
                        nsims_max=10 ** 12)
-        assert abs(r.logZ - gold[key]["logZ"]) < 0.02, (s2, r.logZ)     # fp64 tolerance stated: |Δ logZ| < 0.02
+        assert abs(r.logZ - gold[key]["logZ"]) < tol_logz, (s2, r.logZ)  # fp64 tolerance stated: |Δ logZ| < 0.02 / 0.01
         out.append(r.logZ)
         al = r.Wns > 0
-        assert abs(r.P[al].mean() - 3 * s2 / (s2 + 1)) < 0.02
-    assert abs(math.exp(out[0] - out[1]) - 2.1043) < 0.05
+        assert al.sum() >= 0.49 * N                                      # ESS < N / 2 resamples (smc:323-324): at least half are alive at the end
+        assert abs(r.P[al].mean() - 3 * s2 / (s2 + 1)) < tol_logz
+        assert float(r.C[al].max()) < 0.3                                # every alive distance inside the strict kernel
+    assert abs(math.exp(out[0] - out[1]) - 2.1043) < tol_bf
 
 
 def test_epanechnikov_kernel_at_scale(oracle):

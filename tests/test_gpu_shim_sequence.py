@@ -242,6 +242,7 @@ def shim_abcdesmc(prior, sim, eps_target, N, seed, ABCk=A.IndicatorStrict0toϵ, 
         eps_hist.append(eps)
         if n_alive < 3 or eps <= eps_target or nsims >= nsims_max:
             break
+    e.ck(e.lib.abcdez_smc_select_discard(e.ctx))                 # as the shim does when the run ends
     ranges.append(e.extrema())
     P, W, D, blobs = e.download(packed=True)
     e.close()

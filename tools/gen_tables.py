@@ -32,7 +32,7 @@ ICDF_SUB_BITS = 5
 ICDF_SUB = 1 << ICDF_SUB_BITS     # sub-intervals per binade
 ICDF_BINADES = 64                 # j = 0 .. 63 (63 = all 63 bits zero)
 ICDF_DEG = 7
-ICDF_HOT_BINADES = 12             # binades kept in LDS by the kernels (P(deeper) = 2^-12 per draw)
+ICDF_HOT_BINADES = 16             # binades kept in LDS by the kernels (P(deeper) = 2^-16 per draw): 32 KB, four workgroups per CU
 ICDF_ROWS = ICDF_BINADES * ICDF_SUB
 
 
