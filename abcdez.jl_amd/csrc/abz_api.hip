@@ -18,7 +18,7 @@ int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
 int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
-int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*, int64_t);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
@@ -338,6 +338,7 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
   ctx->cnt_prev[ABZ_C_MCSIM] = ts;
   ctx->cnt_prev[ABZ_C_MCGT] = tg;
+  if (snap[5] != ~0ull) ctx->mc_tail_hint = (long long)snap[5];     /* the next rank pass sizes its long-tail launches from this */
   ctx->ring_folded[slot] = true;
 }
 /* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
@@ -686,7 +687,7 @@ int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, doub
   ABZ_REQUIRE(ctx && delta && order && sorted_delta && cnt, "mc_rank_prepare: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
   ABZ_REQUIRE(eps_pop == eps_pop, "mc_rank_prepare: eps_pop is NaN");
-  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt, nullptr);
+  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt, nullptr, -1);
 }
 
 int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, int64_t N, const double* theta,
@@ -762,7 +763,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
   const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
   if (do_rank) {                     /* mc:20-24 is only reached while some Ds[i] > eps */
-    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win);
+    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint);
     if (rc) return rc;
   }
   rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
@@ -771,7 +772,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   const int slot = (int)(ctx->mc_issued % ABZ_MC_RING);
   ctx->ring_folded[slot] = false;
   rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull,
-                              alpha, eps_target);
+                              alpha, eps_target, do_rank ? ctx->mc_rank_state : nullptr);
   if (rc) return rc;
   ctx->mc_window_ready = true; ctx->mc_alpha = alpha; ctx->mc_eps_target = eps_target;
   ctx->mm_bank = 1 - ctx->mm_bank;   /* the kernel reset the other bank for the next sweep */

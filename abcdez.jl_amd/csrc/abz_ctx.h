@@ -79,6 +79,8 @@ struct abcdez_ctx {
   bool mc_have_bank = false;
   bool mc_window_ready = false;                   /* the last snapshot kernel left the next generation's window for (mc_alpha, mc_eps_target) */
   double mc_alpha = 0.0, mc_eps_target = 0.0;                      /* a sweep of this context has left extrema in a bank */
+  const uint32_t* mc_rank_state = nullptr;        /* state words of the last rank pass (abz_sort.hip), in the workspace */
+  long long mc_tail_hint = -1;                    /* particles that drew in the last generation the host has seen; -1 = unknown */
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
 };
@@ -180,7 +182,8 @@ int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t, const unsigned long long*);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
-int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha, double eps_target);
+int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha, double eps_target,
+                           const uint32_t* rank_state);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
 /* Read-back of the first `nwords` device scalars WITHOUT the copy engine and without a stream synchronisation: a one-block

@@ -122,13 +122,36 @@ __device__ inline double kernel_logpdf_dev(int kind, double eps, double x) {
 /* ---- abz_normal_icdf (abcdez_spec.h) as the kernels evaluate it: every lane runs the LDS path on a clamped row -- straight-line
  * code, no branch around the table reads -- and the lanes whose binade is deeper than the LDS copy (2^-12 of the draws)
  * redo the polynomial with their row of the global table.  Same table, same operations, same bits. */
+/* abz_icdf_index for the binades the LDS copy holds, on 32-bit words: the leading zeros of the 63-bit field are those of the
+ * high word's low 31 bits whenever that word is >= 2^15 (binade <= 15), and the 64-bit shifts of the definition become one
+ * v_alignbit each -- 13 integer instructions instead of 19, same (row, tau).  Returns false (row, tau untouched) for a
+ * deeper binade: the caller then runs the 64-bit definition.  ABZ_ICDF_HOT_BINADES <= 16 is what makes the test exact. */
+__device__ inline bool icdf_index_hot(uint32_t h, uint32_t l, uint32_t* row, double* tau) {
+  static_assert(ABZ_ICDF_HOT_BINADES <= 16 && ABZ_ICDF_SUB_BITS == 5, "hot-path index math assumes 32 sub-intervals, binades 0..15");
+  const uint32_t f = (uint32_t)__builtin_clz((h & 0x7FFFFFFFu) | 1u);       /* = binade + 1 (1 .. 16 on the hot path; 31 or 32 else) */
+  const uint32_t s = 31u - f;                                               /* field << (binade + 1), read off (h : l) >> s */
+  const uint32_t ah = __builtin_amdgcn_alignbit(h, l, s);                   /* high word of the bits behind the leading one */
+  const uint32_t al = l << ((f + 1u) & 31u);                                /* low word */
+  *row = (f << ABZ_ICDF_SUB_BITS) + (ah >> 27) - (uint32_t)ABZ_ICDF_SUB;
+  const uint32_t mh = ((ah >> 7) & 0x000FFFFFu) | 0x3FF00000u;              /* ((A << 5) >> 12) | bits(1.0), high word */
+  const uint32_t ml = __builtin_amdgcn_alignbit(ah, al, 7u);
+  *tau = abz_u2d(((uint64_t)mh << 32) | ml) - 1.5;
+  return f <= (uint32_t)ABZ_ICDF_HOT_BINADES;
+}
+
 __device__ inline double normal_icdf_dev(uint64_t w, const abz_tables* T /* LDS */, const abz_f64x2* __restrict__ all /* global */) {
   uint32_t row;
   double tau;
+#ifdef ABZ_ICDF_GENERIC_INDEX      /* tools/sweep_variants.hip: the 64-bit definition on every lane (what round 3 first shipped) */
   abz_icdf_index(w, &row, &tau);
+  const bool hot = row < (uint32_t)ABZ_ICDF_HOT_ROWS;
+#else
+  const bool hot = icdf_index_hot((uint32_t)(w >> 32), (uint32_t)w, &row, &tau);
+#endif
   const uint32_t rh = row < (uint32_t)ABZ_ICDF_HOT_ROWS ? row : (uint32_t)(ABZ_ICDF_HOT_ROWS - 1);
   double z = abz_icdf_poly(tau, T->icdf_hot[0][rh], T->icdf_hot[1][rh], T->icdf_hot[2][rh], T->icdf_hot[3][rh], w);
-  if (__builtin_expect(row >= (uint32_t)ABZ_ICDF_HOT_ROWS, 0)) {
+  if (__builtin_expect(!hot, 0)) {
+    abz_icdf_index(w, &row, &tau);
     const abz_f64x2* __restrict__ c = all + row;
     z = abz_icdf_poly(tau, c[0], c[ABZ_ICDF_ROWS], c[2 * ABZ_ICDF_ROWS], c[3 * ABZ_ICDF_ROWS], w);
   }

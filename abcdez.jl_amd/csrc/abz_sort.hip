@@ -5,20 +5,24 @@
  * order[0 .. nA)  : the particles with Ds <= eps_pop, in index order (they belong to the candidate set of EVERY
  *                   particle that draws -- a draw happens only for Ds[i] > eps_pop, mc:19-20 -- so their relative
  *                   order is immaterial and a stable partition is enough);
- * order[nA .. N)  : the others sorted by (Ds, index);
+ * order[nA .. N)  : the others -- the TAIL: the particles that draw -- sorted by (Ds, index);
  * sorted_delta[p] = max(Ds[order[p]], eps_pop): non-decreasing, so the candidate set of particle i is
  *                   order[0 .. upper_bound(sorted_delta, Ds[i])) exactly as in the reference's mask;
- * cnt[i]          = that upper bound, #{j : Ds[j] <= Ds[i]}, for every particle outside the first block (the sweep
- *                   reads it coalesced instead of searching sorted_delta: 20 dependent loads per particle).
+ * cnt[i]          = that upper bound, #{j : Ds[j] <= Ds[i]}, for every particle of the tail (the sweep reads it
+ *                   coalesced instead of searching sorted_delta: 20 dependent loads per particle).
  *
- * Hand-written for this path instead of a library sort of 64-bit keys:
- *   1. every particle gets a 24-bit BUCKET id: 0 for Ds <= eps_pop, else 1 + ((key - key(eps_pop) - 1) >> shift),
- *      clamped -- a monotone binning of the order-preserving bit pattern over the window (eps_pop, max Ds] the
- *      driver already knows (mc:146); at N = 2^20 a bucket holds 0.06 particles on average;
- *   2. a stable LSD radix sort of (bucket, index) pairs, three passes of 8 bits; one wavefront owns a tile and ranks
- *      its elements with ballots (no atomics anywhere, so the result is deterministic);
- *   3. a fix-up pass puts the few buckets that hold more than one distinct distance into (Ds, index) order.
- * Any binning is correct (the fix-up sorts whatever shares a bucket); a fitting one is fast.
+ * RANK ONLY WHO DRAWS.  eps_pop sits at 95 % of the RANGE of the distances (mc:147), so the tail is the worst few
+ * particles -- a handful to a few thousand of a million, and it shrinks as the population converges.  The head needs a
+ * compaction, not a sort:
+ *   1. mcr_count / mcr_offsets / mcr_split: tail flags by wave ballots, exclusive scan of the tile counts, then every
+ *      head particle goes to order[i - #tail before i] and every tail particle's (order key, index) pair to a compact
+ *      list -- three launches, the population's distances read twice (no atomics: deterministic);
+ *   2. a tail of up to MCR_SMALL pairs is sorted by ONE workgroup in LDS (bitonic network on (key, index)), which also
+ *      finds every particle's upper bound among equal distances -- one launch;
+ *   3. a longer tail (distances bounded away from a heavy tail, or a population far from convergence) goes through the
+ *      stable LSD radix sort of (24-bit bucket, index) pairs + fix-up of round 2, now over the compact list only; its
+ *      launches are sized from the tail the host last saw (the kernels stride over their tiles, so any size is
+ *      correct) and return at once when step 2 has done the work.
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -30,72 +34,209 @@
 #define MCR_ROUND 64                    /* one wave-round */
 #define MCR_WAVES (ABZ_BLOCK / 64)
 #define MCR_BATCH 8                     /* rounds whose loads are issued together */
+#define MCR_SMALL 4096                  /* tail pairs one workgroup sorts in LDS */
+#define MCR_SMALL_THREADS 1024
+#define MCR_TILE (MCR_BATCH * MCR_ROUND)   /* elements per wave-tile of the LSD passes over the tail */
 
-__device__ inline uint32_t mcr_bucket(double d, unsigned long long klo, int shift) {
-  const unsigned long long key = f64_order_key(d);
-  if (key <= klo) return 0u;
+/* state of one rank pass, in the workspace: [0] n_tail, [1] n_head */
+#define MCR_ST_NTAIL 0
+#define MCR_ST_NHEAD 1
+
+__device__ inline uint32_t mcr_bucket_of_key(unsigned long long key, unsigned long long klo, int shift) {   /* key > klo */
   const unsigned long long t = (key - klo - 1ull) >> shift;
   return t < (1ull << MCR_BITS) - 2ull ? (uint32_t)t + 1u : (1u << MCR_BITS) - 1u;
 }
 
-/* tile histogram of one 8-bit digit.  PASS 0 also makes the (bucket, index) pairs from the distances.
- * table[digit * ntiles + tile]; one wave per tile of `rounds` x 64 consecutive elements.                 */
-template <int PASS>
-__global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const double* __restrict__ delta, uint32_t n,
-                                                             unsigned long long klo, int shift,
-                                                             uint32_t* __restrict__ key, uint32_t* __restrict__ val,
-                                                             uint32_t* __restrict__ table, uint32_t ntiles,
-                                                             uint32_t rounds, const unsigned long long* __restrict__ win) {
-  __shared__ uint32_t s_h[MCR_WAVES][256];
-  if (PASS == 0 && win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; shift = (int)win[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS]; }
+/* ---- step 1a: tail particles per tile (one wave per tile of rounds x 64 consecutive particles) */
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_count_kernel(const double* __restrict__ delta, uint32_t n, unsigned long long klo,
+                                                              uint32_t* __restrict__ tile_cnt, uint32_t ntiles, uint32_t rounds,
+                                                              const unsigned long long* __restrict__ win) {
+  if (win) klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
-  for (int b = lane; b < 256; b += 64) s_h[wave][b] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  if (tile < ntiles) {
-    const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
-    for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {        /* rounds is a multiple of MCR_BATCH */
-      uint32_t k[MCR_BATCH];
-      bool in[MCR_BATCH];
+  if (tile >= ntiles) return;
+  const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
+  uint32_t c = 0;
+  for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {          /* rounds is a multiple of MCR_BATCH */
+    double x[MCR_BATCH];
+    bool in[MCR_BATCH];
 #pragma unroll
-      for (int u = 0; u < MCR_BATCH; ++u) {                      /* MCR_BATCH independent loads in flight */
-        const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
-        in[u] = i < n;
-        if constexpr (PASS == 0) {
-          k[u] = in[u] ? mcr_bucket(delta[i], klo, shift) : 0u;
-        } else {
-          k[u] = in[u] ? key[i] : 0u;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < MCR_BATCH; ++u) {
-        if (in[u]) {
-          if constexpr (PASS == 0) {
-            const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
-            key[i] = k[u];
-            val[i] = (uint32_t)i;
-          }
-        }
-        /* bucket 0 (Ds <= eps_pop: most of the population late in a run) has digit 0 in every pass: counted with one
-         * ballot instead of up to 64 colliding LDS atomics */
-        const unsigned long long z = __ballot(in[u] && k[u] == 0u);
-        if (lane == 0 && z) atomicAdd(&s_h[wave][0], (uint32_t)__popcll(z));
-        if (in[u] && k[u] != 0u) atomicAdd(&s_h[wave][(k[u] >> (8 * PASS)) & 255u], 1u);
-      }
+    for (int u = 0; u < MCR_BATCH; ++u) {
+      const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
+      in[u] = i < n;
+      x[u] = in[u] ? delta[i] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < MCR_BATCH; ++u) c += (uint32_t)__popcll(__ballot(in[u] && f64_order_key(x[u]) > klo));
   }
-  __builtin_amdgcn_wave_barrier();
-  if (tile < ntiles)
-    for (int b = lane; b < 256; b += 64) table[(size_t)b * ntiles + tile] = s_h[wave][b];
+  if (lane == 0) tile_cnt[tile] = c;
 }
 
-/* offsets, step 1: block d turns the tile counts of digit d (contiguous in the digit-major table: coalesced) into
- * their exclusive prefix over the tiles and leaves the digit's total in totals[d].  Step 2 -- the exclusive scan of
- * the 256 totals -- is done by every scattering wave for itself (mcr_scatter_kernel).  256 small blocks instead of
- * one block walking the whole table with a 512-byte stride (that cost 0.2 ms per pass).                        */
-__global__ __launch_bounds__(ABZ_BLOCK) void mcr_scan_kernel(uint32_t* __restrict__ table, uint32_t ntiles,
+/* ---- step 1b: exclusive scan of the tile counts (one workgroup), totals into the state */
+__global__ __launch_bounds__(MCR_SMALL_THREADS) void mcr_offsets_kernel(uint32_t* __restrict__ tile_cnt, uint32_t ntiles, uint32_t n,
+                                                                        uint32_t* __restrict__ state) {
+  __shared__ uint32_t s_part[MCR_SMALL_THREADS];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (ntiles + MCR_SMALL_THREADS - 1) / MCR_SMALL_THREADS;
+  const uint32_t lo = t * per < ntiles ? t * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += tile_cnt[k];
+  s_part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < MCR_SMALL_THREADS; off <<= 1) {
+    const uint32_t add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = tile_cnt[k]; tile_cnt[k] = run; run += c; }
+  if (t == MCR_SMALL_THREADS - 1) { state[MCR_ST_NTAIL] = s_part[t]; state[MCR_ST_NHEAD] = n - s_part[t]; }
+}
+
+/* ---- step 1c: the head in index order, the tail as a compact list of (order key, index) pairs */
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_split_kernel(const double* __restrict__ delta, uint32_t n, unsigned long long klo,
+                                                              double eps_pop, const uint32_t* __restrict__ tile_off, uint32_t ntiles,
+                                                              uint32_t rounds, uint32_t* __restrict__ order,
+                                                              double* __restrict__ sorted_delta, unsigned long long* __restrict__ tk,
+                                                              uint32_t* __restrict__ tv, const unsigned long long* __restrict__ win) {
+  if (win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; eps_pop = abz_u2d(win[0]); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
+  if (tile >= ntiles) return;
+  const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t running = tile_off[tile];                 /* tail particles in front of this round (wave-uniform) */
+  for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {
+    double x[MCR_BATCH];
+    bool in[MCR_BATCH];
+#pragma unroll
+    for (int u = 0; u < MCR_BATCH; ++u) {
+      const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
+      in[u] = i < n;
+      x[u] = in[u] ? delta[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < MCR_BATCH; ++u) {
+      const uint32_t i = (uint32_t)(base + (uint64_t)(r0 + u) * MCR_ROUND + lane);
+      const unsigned long long key = f64_order_key(x[u]);
+      const bool tail = in[u] && key > klo;
+      const unsigned long long mt = __ballot(tail);
+      const uint32_t tb = running + (uint32_t)__popcll(mt & below);   /* tail particles with a smaller index */
+      if (tail) { tk[tb] = key; tv[tb] = i; }
+      else if (in[u]) { order[i - tb] = i; sorted_delta[i - tb] = eps_pop; }
+      running += (uint32_t)__popcll(mt);
+    }
+  }
+}
+
+/* ---- step 2: a short tail, sorted by (key, index) in LDS by one workgroup; cnt = upper bound among equal distances */
+__global__ __launch_bounds__(MCR_SMALL_THREADS) void mcr_tail_small_kernel(const uint32_t* __restrict__ state,
+                                                                           const unsigned long long* __restrict__ tk,
+                                                                           const uint32_t* __restrict__ tv,
+                                                                           uint32_t* __restrict__ order,
+                                                                           double* __restrict__ sorted_delta,
+                                                                           uint32_t* __restrict__ cnt) {
+  __shared__ unsigned long long s_k[MCR_SMALL];
+  __shared__ uint32_t s_v[MCR_SMALL];
+  __shared__ uint32_t s_e[MCR_SMALL];
+  const uint32_t nt = state[MCR_ST_NTAIL], nh = state[MCR_ST_NHEAD];
+  if (nt == 0u || nt > MCR_SMALL) return;            /* nothing to sort / the LSD passes do it */
+  uint32_t P = 64u;
+  while (P < nt) P <<= 1;
+  const uint32_t t = threadIdx.x;
+  for (uint32_t p = t; p < P; p += MCR_SMALL_THREADS) {
+    s_k[p] = p < nt ? tk[p] : ~0ull;                 /* padding sorts behind every real key */
+    s_v[p] = p < nt ? tv[p] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t l = t; l < P / 2; l += MCR_SMALL_THREADS) {
+        const uint32_t i = ((l & ~(j - 1u)) << 1) | (l & (j - 1u)), q = i | j;
+        const unsigned long long ka = s_k[i], kb = s_k[q];
+        const uint32_t va = s_v[i], vb = s_v[q];
+        const bool gt = ka > kb || (ka == kb && va > vb);
+        if (gt == ((i & k) == 0u)) { s_k[i] = kb; s_k[q] = ka; s_v[i] = vb; s_v[q] = va; }
+      }
+      __syncthreads();
+    }
+  }
+  /* end of every run of equal keys, brought to each of its members by a suffix-minimum scan (in place: a step's partner
+   * values wait in registers across the barrier) */
+  for (uint32_t p = t; p < P; p += MCR_SMALL_THREADS)
+    s_e[p] = (p + 1u >= nt || s_k[p] != s_k[p + 1u]) ? p + 1u : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t off = 1; off < P; off <<= 1) {
+    uint32_t b[MCR_SMALL / MCR_SMALL_THREADS];
+#pragma unroll
+    for (uint32_t q = 0; q < MCR_SMALL / MCR_SMALL_THREADS; ++q) {
+      const uint32_t p = t + q * MCR_SMALL_THREADS;
+      b[q] = (p < P && p + off < P) ? s_e[p + off] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < MCR_SMALL / MCR_SMALL_THREADS; ++q) {
+      const uint32_t p = t + q * MCR_SMALL_THREADS;
+      if (p < P && b[q] < s_e[p]) s_e[p] = b[q];
+    }
+    __syncthreads();
+  }
+  for (uint32_t p = t; p < nt; p += MCR_SMALL_THREADS) {
+    const uint32_t v = s_v[p];
+    order[nh + p] = v;
+    sorted_delta[nh + p] = f64_from_order_key_dev(s_k[p]);
+    cnt[v] = nh + s_e[p];
+  }
+}
+
+/* ---- step 3: a long tail -- stable LSD radix sort of (bucket, index) pairs over the compact list.  The kernels read the
+ * list's length from the state, stride over their tiles (any grid is correct) and leave when step 2 did the work. */
+/* tile histogram of one 8-bit digit.  PASS 0 also makes the buckets from the keys.  table[digit * ntiles + tile]. */
+template <int PASS>
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const uint32_t* __restrict__ state, const unsigned long long* __restrict__ tk,
+                                                             unsigned long long klo, int shift, uint32_t* __restrict__ key,
+                                                             uint32_t* __restrict__ table, const unsigned long long* __restrict__ win) {
+  __shared__ uint32_t s_h[MCR_WAVES][256];
+  const uint32_t n = state[MCR_ST_NTAIL];
+  if (n <= MCR_SMALL) return;
+  if (PASS == 0 && win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; shift = (int)win[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS]; }
+  const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t tile = blockIdx.x * MCR_WAVES + wave; tile < ntiles; tile += gridDim.x * MCR_WAVES) {
+    for (int b = lane; b < 256; b += 64) s_h[wave][b] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t base = tile * MCR_TILE;
+    uint32_t k[MCR_BATCH];
+    bool in[MCR_BATCH];
+#pragma unroll
+    for (int u = 0; u < MCR_BATCH; ++u) {
+      const uint32_t i = base + (uint32_t)u * MCR_ROUND + lane;
+      in[u] = i < n;
+      if constexpr (PASS == 0) k[u] = in[u] ? mcr_bucket_of_key(tk[i], klo, shift) : 0u;
+      else k[u] = in[u] ? key[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < MCR_BATCH; ++u) {
+      if (in[u]) {
+        if constexpr (PASS == 0) key[base + (uint32_t)u * MCR_ROUND + lane] = k[u];
+        atomicAdd(&s_h[wave][(k[u] >> (8 * PASS)) & 255u], 1u);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int b = lane; b < 256; b += 64) table[(size_t)b * ntiles + tile] = s_h[wave][b];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+/* offsets, step 1: block d turns the tile counts of digit d into their exclusive prefix over the tiles and leaves the digit's
+ * total in totals[d].  Step 2 -- the exclusive scan of the 256 totals -- is done by every scattering wave for itself. */
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_scan_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ totals) {
   __shared__ uint32_t s_part[ABZ_BLOCK];
+  const uint32_t n = state[MCR_ST_NTAIL];
+  if (n <= MCR_SMALL) return;
+  const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
   uint32_t* v = table + (size_t)blockIdx.x * ntiles;
   const uint32_t t = threadIdx.x;
   const uint32_t per = (ntiles + ABZ_BLOCK - 1) / ABZ_BLOCK;
@@ -115,54 +256,49 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scan_kernel(uint32_t* __restric
   if (t == ABZ_BLOCK - 1) totals[blockIdx.x] = s_part[ABZ_BLOCK - 1];
 }
 
-/* stable scatter of one digit.  The wave walks its tile in index order, 64 elements per round; lanes holding the
- * same digit find each other with 8 ballots, take consecutive slots behind the digit's running offset (LDS, private
- * to the wave) and the last of them advances it.  LAST: the pairs end as order[] / bucket[] and the clamped
- * distance of every position is gathered.                                                               */
+/* stable scatter of one digit.  The wave walks its tile in list order, 64 elements per round; lanes holding the same digit
+ * find each other with 8 ballots, take consecutive slots behind the digit's running offset (LDS, private to the wave) and
+ * the last of them advances it.  LAST: the pairs end as order[nA + .] / bucket[] with the distance of every position. */
 template <int PASS, bool LAST>
-__global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* __restrict__ key_in,
-                                                                const uint32_t* __restrict__ val_in, uint32_t n,
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* __restrict__ state, const uint32_t* __restrict__ key_in,
+                                                                const uint32_t* __restrict__ val_in,
                                                                 const uint32_t* __restrict__ table,
-                                                                const uint32_t* __restrict__ totals, uint32_t ntiles,
-                                                                uint32_t rounds, uint32_t* __restrict__ key_out,
+                                                                const uint32_t* __restrict__ totals, uint32_t* __restrict__ key_out,
                                                                 uint32_t* __restrict__ val_out,
-                                                                const double* __restrict__ delta, double eps_pop,
-                                                                double* __restrict__ sorted_delta,
-                                                                uint32_t* __restrict__ cnt_of,
-                                                                const unsigned long long* __restrict__ win) {
+                                                                const double* __restrict__ delta, uint32_t* __restrict__ order,
+                                                                double* __restrict__ sorted_delta, uint32_t* __restrict__ cnt_of) {
   __shared__ uint32_t s_run[MCR_WAVES][256];
-  if (LAST && win) eps_pop = abz_u2d(win[0]);
+  const uint32_t n = state[MCR_ST_NTAIL], nh = state[MCR_ST_NHEAD];
+  if (n <= MCR_SMALL) return;
+  const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
-  if (tile >= ntiles) return;                         /* whole waves leave; no block-level barrier below */
   volatile uint32_t* run = s_run[wave];
-  {   /* start of digit d = exclusive scan of the 256 digit totals (lane l owns digits 4l .. 4l+3) + this tile's prefix */
-    const uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
-    uint32_t inc = t0 + t1 + t2 + t3;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += o;
-    }
-    const uint32_t s0 = inc - (t0 + t1 + t2 + t3);
-    run[4 * lane] = s0 + table[(size_t)(4 * lane) * ntiles + tile];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  /* start of digit d = exclusive scan of the 256 digit totals (lane l owns digits 4l .. 4l+3) */
+  const uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
+  uint32_t inc = t0 + t1 + t2 + t3;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  const uint32_t s0 = inc - (t0 + t1 + t2 + t3);
+  for (uint32_t tile = blockIdx.x * MCR_WAVES + wave; tile < ntiles; tile += gridDim.x * MCR_WAVES) {
+    run[4 * lane] = s0 + table[(size_t)(4 * lane) * ntiles + tile];          /* + this tile's prefix inside the digit */
     run[4 * lane + 1] = s0 + t0 + table[(size_t)(4 * lane + 1) * ntiles + tile];
     run[4 * lane + 2] = s0 + t0 + t1 + table[(size_t)(4 * lane + 2) * ntiles + tile];
     run[4 * lane + 3] = s0 + t0 + t1 + t2 + table[(size_t)(4 * lane + 3) * ntiles + tile];
-  }
-  __builtin_amdgcn_wave_barrier();
-  const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {          /* rounds is a multiple of MCR_BATCH */
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t base = tile * MCR_TILE;
     uint32_t kk[MCR_BATCH], vv[MCR_BATCH];
 #pragma unroll
-    for (int u = 0; u < MCR_BATCH; ++u) {                        /* the batch's loads go out together ... */
-      const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
+    for (int u = 0; u < MCR_BATCH; ++u) {                        /* the tile's loads go out together ... */
+      const uint32_t i = base + (uint32_t)u * MCR_ROUND + lane;
       kk[u] = i < n ? key_in[i] : 0u;
       vv[u] = i < n ? val_in[i] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < MCR_BATCH; ++u) {                        /* ... the rounds are ranked one after the other */
-      const uint64_t i = base + (uint64_t)(r0 + u) * MCR_ROUND + lane;
+      const uint32_t i = base + (uint32_t)u * MCR_ROUND + lane;
       const bool valid = i < n;
       const uint32_t k = kk[u], v = vv[u];
       const uint32_t d = (k >> (8 * PASS)) & 255u;
@@ -178,11 +314,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
       __builtin_amdgcn_wave_barrier();
       if (valid) {
         key_out[pos] = k;
-        val_out[pos] = v;
         if constexpr (LAST) {
-          const double x = delta[v];
-          sorted_delta[pos] = k == 0u ? eps_pop : x;
-          cnt_of[v] = pos + 1u;                       /* right for a bucket of one; shared buckets: mcr_fixup_kernel */
+          order[nh + pos] = v;
+          sorted_delta[nh + pos] = delta[v];
+          cnt_of[v] = nh + pos + 1u;                  /* right for a bucket of one; shared buckets: mcr_fixup_kernel */
+        } else {
+          val_out[pos] = v;
         }
         if (rank + 1u == cnt) run[d] = pos + 1u;
       }
@@ -193,37 +330,41 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
 
 /* buckets holding several particles: put them into (Ds, index) order.  One thread per run start; runs of one
  * element (nearly all) and runs of equal distances (atoms of a discrete distance: the stable sort already left them
- * in index order) cost one pass over the run; bucket 0 (Ds <= eps_pop) keeps its index order by definition.   */
-__global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __restrict__ bucket, uint32_t n,
-                                                              uint32_t* __restrict__ order,
-                                                              double* __restrict__ sorted_delta,
+ * in index order) cost one pass over the run.   */
+__global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __restrict__ state, const uint32_t* __restrict__ bucket,
+                                                              uint32_t* __restrict__ order_all,
+                                                              double* __restrict__ sorted_delta_all,
                                                               uint32_t* __restrict__ cnt) {
-  const uint32_t p = blockIdx.x * ABZ_BLOCK + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t b = bucket[p];
-  if (b == 0u || (p > 0u && bucket[p - 1u] == b)) return;
-  uint32_t e = p + 1u;
-  while (e < n && bucket[e] == b) ++e;
-  if (e == p + 1u) return;                            /* a bucket of one: nothing to do */
-  for (uint32_t q = p + 1u; q < e; ++q) {             /* insertion sort: linear on sorted input */
-    const double x = sorted_delta[q];
-    const uint32_t ix = order[q];
-    uint32_t at = q;
-    while (at > p) {
-      const double y = sorted_delta[at - 1u];
-      const uint32_t iy = order[at - 1u];
-      if (y < x || (y == x && iy < ix)) break;
-      sorted_delta[at] = y;
-      order[at] = iy;
-      --at;
+  const uint32_t n = state[MCR_ST_NTAIL], nh = state[MCR_ST_NHEAD];
+  if (n <= MCR_SMALL) return;
+  uint32_t* order = order_all + nh;
+  double* sorted_delta = sorted_delta_all + nh;
+  for (uint32_t p = blockIdx.x * ABZ_BLOCK + threadIdx.x; p < n; p += gridDim.x * ABZ_BLOCK) {
+    const uint32_t b = bucket[p];
+    if (p > 0u && bucket[p - 1u] == b) continue;
+    uint32_t e = p + 1u;
+    while (e < n && bucket[e] == b) ++e;
+    if (e == p + 1u) continue;                          /* a bucket of one: nothing to do */
+    for (uint32_t q = p + 1u; q < e; ++q) {             /* insertion sort: linear on sorted input */
+      const double x = sorted_delta[q];
+      const uint32_t ix = order[q];
+      uint32_t at = q;
+      while (at > p) {
+        const double y = sorted_delta[at - 1u];
+        const uint32_t iy = order[at - 1u];
+        if (y < x || (y == x && iy < ix)) break;
+        sorted_delta[at] = y;
+        order[at] = iy;
+        --at;
+      }
+      if (at != q) { sorted_delta[at] = x; order[at] = ix; }
     }
-    if (at != q) { sorted_delta[at] = x; order[at] = ix; }
-  }
-  /* cnt of a particle = end of its run of EQUAL distances (upper bound), walking the sorted bucket from the back */
-  uint32_t end = e;
-  for (uint32_t q = e; q-- > p;) {
-    if (q + 1u < e && sorted_delta[q] != sorted_delta[q + 1u]) end = q + 1u;
-    cnt[order[q]] = end;
+    /* cnt of a particle = end of its run of EQUAL distances (upper bound), walking the sorted bucket from the back */
+    uint32_t end = e;
+    for (uint32_t q = e; q-- > p;) {
+      if (q + 1u < e && sorted_delta[q] != sorted_delta[q + 1u]) end = q + 1u;
+      cnt[order[q]] = nh + end;
+    }
   }
 }
 
@@ -284,7 +425,7 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
  * binning window (mc_window_write) are made here and the next generation starts without a window launch.            */
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
                                                                  unsigned long long* __restrict__ out, unsigned long long seq,
-                                                                 double alpha, double eps_target) {
+                                                                 double alpha, double eps_target, const uint32_t* __restrict__ rank_state) {
   __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
   unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
@@ -307,22 +448,24 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
     for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { tg += s_g[w]; ts += s_s[w]; }
     out[0] = tg; out[1] = ts; out[2] = mn; out[3] = mx;        /* wave 0 holds the bank's extrema */
     out[4] = scal[ABZ_S_MCW_EPS];
+    out[5] = rank_state ? (unsigned long long)rank_state[MCR_ST_NTAIL] : ~0ull;   /* how many particles drew (sizes the next rank pass) */
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
   }
 }
 int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha,
-                           double eps_target) {
+                           double eps_target, const uint32_t* rank_state) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
-  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target);
+  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target, rank_state);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
-/* win: NULL = (eps_pop, dmax_hint) are host values; else the device window mc_window_kernel wrote (the two host values are ignored) */
+/* win: NULL = (eps_pop, dmax_hint) are host values; else the device window mc_window_kernel wrote (the two host values are
+ * ignored).  tail_hint: the length of the tail the host last saw (< 0: unknown) -- sizes the launches of the long-tail path. */
 int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                          uint32_t* order, double* sorted_delta, uint32_t* cnt, const unsigned long long* win) {
+                          uint32_t* order, double* sorted_delta, uint32_t* cnt, const unsigned long long* win, int64_t tail_hint) {
   const uint32_t n = (uint32_t)N;
   /* window of the binning: (eps_pop, dmax_hint] in key space -> 2^24 - 2 buckets */
   const unsigned long long klo = host_order_key(eps_pop);
@@ -332,37 +475,55 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   int bits = 0;
   while (bits < 64 && (range >> bits) != 0ull) ++bits;   /* range < 2^bits */
   const int shift = bits > MCR_BITS ? bits - MCR_BITS : 0;
-  /* one wave per tile of rounds x 64 elements; short tiles = many waves in flight (each walks its rounds one after the
-   * other), at most 4096 tiles so that the count table stays small */
+  /* step 1: one wave per tile of rounds x 64 particles, at most 4096 tiles (one workgroup scans their counts) */
   uint32_t rounds = MCR_BATCH;
   while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;
   const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
-  const size_t pb = abz_align((size_t)n * 4), tb = abz_align((size_t)256 * ntiles * 4 + 256 * 4);
-  int rc = abz_ws_reserve(ctx, 3 * pb + tb);
+  /* step 3 is sized for the tail the host expects (4 x the last one seen, at least 16 K pairs; everything when it knows
+   * nothing); its kernels stride, so a longer tail is sorted correctly, only slower */
+  uint64_t expect = tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
+  if (expect > n) expect = n;
+  const uint32_t ltiles_max = (n + MCR_TILE - 1) / MCR_TILE;                 /* tiles of a tail that is the whole population */
+  uint32_t ltiles = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
+  if (ltiles < 1u) ltiles = 1u;
+  const size_t pb = abz_align((size_t)n * 4), kb = abz_align((size_t)n * 8);
+  const size_t tb = abz_align((size_t)256 * ltiles_max * 4 + 256 * 4), cb = abz_align((size_t)ntiles * 4), sb = abz_align(64);
+  int rc = abz_ws_reserve(ctx, kb + 4 * pb + tb + cb + sb);
   if (rc) return rc;
   char* w = (char*)ctx->ws;
+  unsigned long long* tk = (unsigned long long*)w; w += kb;
+  uint32_t* tv = (uint32_t*)w; w += pb;
   uint32_t* keyA = (uint32_t*)w; w += pb;
-  uint32_t* valA = (uint32_t*)w; w += pb;
   uint32_t* keyB = (uint32_t*)w; w += pb;
+  uint32_t* valB = (uint32_t*)w; w += pb;
   uint32_t* table = (uint32_t*)w;
-  uint32_t* totals = table + (size_t)256 * ntiles;
-  uint32_t* valB = order;                                /* pass 0 -> (keyB, order), pass 1 -> (keyA, valA), pass 2 -> (keyB, order) */
+  uint32_t* totals = table + (size_t)256 * ltiles_max; w += tb;
+  uint32_t* tile_cnt = (uint32_t*)w; w += cb;
+  uint32_t* state = (uint32_t*)w;
   const unsigned grid = (ntiles + MCR_WAVES - 1) / MCR_WAVES;
+  const unsigned lgrid = (ltiles + MCR_WAVES - 1) / MCR_WAVES;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, valB, delta, eps_pop, sorted_delta, cnt, win);
-  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyB, valB, table, ntiles, rounds, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyB, valB, n, table, totals, ntiles, rounds,
-                     keyA, valA, delta, eps_pop, sorted_delta, cnt, win);
-  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, shift, keyA, valA, table, ntiles, rounds, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, table, ntiles, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(grid), dim3(ABZ_BLOCK), 0, st, keyA, valA, n, table, totals, ntiles, rounds,
-                     keyB, order, delta, eps_pop, sorted_delta, cnt, win);
-  hipLaunchKernelGGL(mcr_fixup_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, st, keyB, n, order,
-                     sorted_delta, cnt);
+  hipLaunchKernelGGL(mcr_count_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, tile_cnt, ntiles, rounds, win);
+  hipLaunchKernelGGL(mcr_offsets_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, tile_cnt, ntiles, n, state);
+  hipLaunchKernelGGL(mcr_split_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, eps_pop, tile_cnt, ntiles, rounds, order,
+                     sorted_delta, tk, tv, win);
+  hipLaunchKernelGGL(mcr_tail_small_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, state, tk, tv, order, sorted_delta, cnt);
+  /* the long-tail path: pass 0 (tk -> keyA; tv) -> (keyB, valB); pass 1 -> (keyA, tv); pass 2 -> (keyB = buckets, order) */
+  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
+  hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
+                     order, sorted_delta, cnt);
+  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyB, table, win);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
+  hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyB, valB, table, totals, keyA, tv, delta,
+                     order, sorted_delta, cnt);
+  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win);
+  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
+  hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
+                     order, sorted_delta, cnt);
+  hipLaunchKernelGGL(mcr_fixup_kernel, dim3((unsigned)(((uint64_t)ltiles * MCR_TILE + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, st,
+                     state, keyB, order, sorted_delta, cnt);
+  ctx->mc_rank_state = state;       /* the snapshot kernel of an asynchronous generation reports the tail's length from here */
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

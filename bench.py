@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming, 5.5-5.8 random rows)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (FMA = 2 flop): half the 157.3 TFLOP/s fp32 vector rate of the guide
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def profile_json(name):

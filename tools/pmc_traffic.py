@@ -2,12 +2,13 @@
 """HBM traffic of a sweep kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
 MI355X_MICROARCH.md prescribes) -> profiles/<round>_hbm_traffic_<config>.json, the file bench.py's roofline.traffic reads.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel substring> <lanes> <ld> [accept rate]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel substring> <lanes> <ld> [accept rate] [updates fetch pass] [updates write pass]
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half
 the bytes of 16-byte-per-lane coalesced reads, so it is doubled.  Particle-updates per dispatch = grid size / lanes
-per particle (the kernel maps one alive particle to `lanes` consecutive threads; the last block is padded, < 64
-particles of error).  Infinity-Cache hits are counted by FETCH_SIZE (it counts the L2's fabric requests)."""
+per particle -- or, for kernels whose workgroups loop over tiles (round 3: the grid is what is resident, not the work),
+the particle-updates bench.py reports for that very run (`config.launched_incl_warmup.updates`), passed as the last two
+arguments.  Infinity-Cache hits are counted by FETCH_SIZE (it counts the L2's fabric requests)."""
 import csv
 import json
 import sys
@@ -28,10 +29,12 @@ def main():
     fetch_csv, write_csv, out, kernel = sys.argv[1:5]
     lanes, ld = int(sys.argv[5]), int(sys.argv[6])
     acc = float(sys.argv[7]) if len(sys.argv) > 7 else None
+    upd_f = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
+    upd_w = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
     f, gu, nf = collect(fetch_csv, "FETCH_SIZE", kernel)
     w, gw, nw = collect(write_csv, "WRITE_SIZE", kernel)
-    rd = 2.0 * f * 1024.0 / (gu / lanes)
-    wr = w * 1024.0 / (gw / lanes)
+    rd = 2.0 * f * 1024.0 / (upd_f if upd_f > 0 else gu / lanes)
+    wr = w * 1024.0 / (upd_w if upd_w > 0 else gw / lanes)
     b_read, b_write = 24 * ld + 17, 8 * ld + 16
     res = {
         "kernel": kernel, "lanes": lanes, "ld": ld,
@@ -39,6 +42,7 @@ def main():
         "method": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports "
                   "half the bytes of 16-B-per-lane coalesced reads). Infinity-Cache hits are counted.",
         "dispatches": nf, "dispatches_write_pass": nw,
+        "updates_are": "bench.py's count of the profiled run" if upd_f > 0 else "grid size / lanes",
         "read_bytes_per_update": rd, "write_bytes_per_update": wr,
         "algorithmic_read_bytes_per_update": b_read, "algorithmic_write_bytes_per_update": b_write,
         "total_bytes_per_update": rd + wr, "ratio_to_algorithmic_total": (rd + wr) / (b_read + b_write),

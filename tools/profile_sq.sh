@@ -10,6 +10,6 @@ OUT=${OUT:-sq_counters}
 timeout 500 rocprofv3 --pmc $COUNTERS \
   --output-format csv -d $R/gpurun_out/sq_$CFG -o sq -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 8 --warmup 4 > $R/gpurun_out/${TAG}_${CFG}_sq_bench.log 2>&1
 F=$(find $R/gpurun_out/sq_$CFG -name 'sq_counter_collection.csv' | head -1)
-UPD=$(python3 -c "import json,sys; print(json.loads(open('$R/gpurun_out/${TAG}_${CFG}_sq_bench.log').read().strip().splitlines()[-1])['config']['launched_incl_warmup']['updates'])" 2>/dev/null || echo 0)
+UPD=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_sq_bench.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
 python3 $R/tools/sq_summary.py $F $KERNEL $UPD > $R/gpurun_out/${TAG}_${CFG}_${OUT}.json
 rm -rf $R/gpurun_out/sq_$CFG

@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
   const uint32_t n_alive = argc > 1 ? (uint32_t)atoll(argv[1]) : 2965608u;
   const int rounds = argc > 2 ? atoi(argv[2]) : 12;
   const double target_acc = argc > 3 ? atof(argv[3]) : 0.147;
+  const int inner = argc > 4 ? atoi(argv[4]) : 1;    // launches back to back between the two events (sustained clocks, no idle gaps)
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
 
@@ -127,17 +128,17 @@ int main(int argc, char** argv) {
       const int caps[3] = {0, 4, 5};
       for (int c = 0; c < 3; ++c) {
         double mm = 0, mb = 0;
-        if (layout_bench_packed(N, n_alive, (int)std::lround(acc * 100), caps[c], 3, 1, &mm, &mb) == 0) pat[c].push_back((float)mm);
+        if (layout_bench_packed(N, n_alive, (int)std::lround(acc * 100), caps[c], inner > 1 ? 1 : 3, inner, &mm, &mb) == 0) pat[c].push_back((float)mm);
       }
     }
     for (int v = 0; v < nv; ++v) {
       reset(); fill_f64<<<N / 256, 256>>>(delta, N, 1e9); CK(hipDeviceSynchronize());
       const unsigned g = grid_of(variants[v]);
       CK(hipEventRecord(e0, 0));
-      variants[v].launch(&a, g, 0);
+      for (int k = 0; k < inner; ++k) variants[v].launch(&a, g, 0);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float t; CK(hipEventElapsedTime(&t, e0, e1));
-      if (rd > 0) ms[v].push_back(t);            // round 0 = warm-up (code objects, caches)
+      if (rd > 0) ms[v].push_back(t / inner);    // round 0 = warm-up (code objects, caches)
     }
   }
   for (int v = 0; v < nv; ++v) {

@@ -58,8 +58,9 @@ def main():
             print(f"  {k:46s} {v / n:8.1f} us")
 
 
-    if sweeps and len(sys.argv) > 4:
-        # sweep kernel: rate against the number of alive particles (threads / lanes per particle)
+    if sweeps and len(sys.argv) > 4 and int(sys.argv[4]) > 0:
+        # sweep kernel: rate against the number of alive particles (threads / lanes per particle).  Only for kernels launched
+        # with one thread group per particle (rounds 1-2); round 3's sweeps loop over tiles: pass lanes = 0
         lanes = int(sys.argv[4])
         print("\nsweep launches: alive particles, us, updates/s, alive rows MB")
         for grid, ns in sweeps:
