@@ -44,6 +44,10 @@ PROTOTYPES = {
     "abcdez_smc_sweeps_packed": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _i32, _f64, _pi64, _pi64,
                                  C.POINTER(_i32)],
     "abcdez_smc_replay_packed": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
+    "abcdez_smc_group_begin": [_vp, _i64, _f64],
+    "abcdez_smc_group_replay": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32],
+    "abcdez_smc_group_publish": [_vp],
+    "abcdez_smc_group_end": [_vp, _pi64, _pi64, C.POINTER(_i32)],
     "abcdez_smc_resample_gather_packed": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_packed_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
     "abcdez_smc_reweight": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64],

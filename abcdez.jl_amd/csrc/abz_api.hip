@@ -23,8 +23,8 @@ int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
 int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int, const unsigned long long*);
-int abz_launch_group_check(abcdez_ctx*, int, unsigned long long, uint32_t, double);
-int abz_launch_smc_replay_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, const uint8_t*, double, double, uint32_t);
+int abz_launch_group_check(abcdez_ctx*, int, unsigned long long, uint32_t, double, int);
+int abz_launch_smc_replay_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, const uint8_t*, double, double, uint32_t, const unsigned long long*);
 int abz_launch_resample_gather_packed(abcdez_ctx*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, double*, double*, const double*, const double*, double*, double*, double*, uint8_t*);
 int abz_launch_packed_gather(abcdez_ctx*, const uint32_t*, uint32_t, const double*, const double*, double*);
 int abz_draws_eval_impl(abcdez_ctx*, int, uint32_t, uint32_t, uint32_t, uint32_t, double, double, uint32_t*, uint32_t*, double*, double*);
@@ -459,8 +459,13 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   ABZ_REQUIRE((r_lo % ABZ_PACKED_ALIGN == 0 || r_lo == n_alive) && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
               "smc_swarm_packed: a sub-range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_swarm_packed: the two slots / bit arrays must differ");
+  const unsigned long long* stop = nullptr;
+  if (ctx->grp_k >= 0) {            /* inside abcdez_smc_group_begin / _end: sweep k > 0 runs only while the test of smc:352 has not held */
+    ABZ_REQUIRE(nacc == nullptr, "smc_swarm_packed: inside a group of sweeps the counters come from abcdez_smc_group_end");
+    if (ctx->grp_k > 0) stop = ctx->d_scal + ABZ_S_GRP_STOP;
+  }
   int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
-                                       logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr, nullptr);
+                                       logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr, stop);
   if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_packed reports totals) */
   rc = read_counters(ctx);
   if (rc) return rc;
@@ -524,7 +529,7 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
     ctx->timing = timing;
     if (rc) return rc;
     if (k + 1 < k_max) {             /* nothing is decided after the last sweep: its counters are the totals the host reads anyway */
-      rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min);
+      rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min, ABZ_C_NACC);
       if (rc) return rc;
     }
   }
@@ -580,13 +585,81 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
   ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
               "smc_replay_packed: the own range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_replay_packed: the two slots / bit arrays must differ");
+  ABZ_REQUIRE(ctx->grp_k < 0, "smc_replay_packed: inside a group of sweeps use abcdez_smc_group_replay");
   int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0,
-                                        slot1, logpi, flags, gamma0, gamma_sigma, sweep);
+                                        slot1, logpi, flags, gamma0, gamma_sigma, sweep, nullptr);
   if (rc) return rc;
   rc = read_counters(ctx);
   if (rc) return rc;
   *nacc = (int64_t)ctx->h_scal[ABZ_S_RACC];
   *nsim = (int64_t)ctx->h_scal[ABZ_S_RSIM];
+  return 0;
+}
+
+/* ---- the sweeps of one generation on a SHARDED population in one host synchronisation (smc:336-353).
+ *   abcdez_smc_group_begin(n_alive, Kmcmc_min)
+ *   k = 0 .. Kmcmc-1:  abcdez_smc_swarm_packed(own range, flags, nacc = NULL)   -- sweep k > 0 is gated by the stop flag
+ *                      [the host all-gathers the flag bytes: a collective every rank executes, stopped or not]
+ *                      abcdez_smc_group_replay(...)                              -- gated too; counts both flag bits over the prefix
+ *                                                                                  and evaluates the test of smc:352 on the device
+ *   abcdez_smc_group_publish()     -- enqueue the read-back (the host may enqueue more work -- the distance exchange -- behind it)
+ *   abcdez_smc_group_end(nacc[], nsim[], &k_done)
+ * Every replica counts the same flags, so every rank takes the same decision without talking to the others. */
+int abcdez_smc_group_begin(abcdez_ctx* ctx, int64_t n_alive, double kmcmc_min) {
+  ABZ_REQUIRE(ctx, "smc_group_begin: null context");
+  ABZ_REQUIRE(ctx->grp_k < 0, "smc_group_begin: a group is already open");
+  ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N && kmcmc_min >= 0.0, "smc_group_begin: bad argument");
+  ctx->ahead = abz_ahead{};
+  ctx->grp_k = 0; ctx->grp_n_alive = n_alive; ctx->grp_kmin = kmcmc_min; ctx->grp_pub = 0;
+  ctx->grp_base_acc = ctx->cnt_prev[ABZ_C_RACC]; ctx->grp_base_sim = ctx->cnt_prev[ABZ_C_RSIM];
+  return 0;
+}
+int abcdez_smc_group_replay(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t skip_lo, int64_t skip_hi, double* slot0,
+                            double* slot1, double* logpi, const uint8_t* flags, double gamma0, double gamma_sigma, uint32_t sweep) {
+  ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags, "smc_group_replay: null argument");
+  ABZ_REQUIRE(ctx->grp_k >= 0 && ctx->grp_k < ABZ_GROUP_MAX, "smc_group_replay: no group open (or more than 16 sweeps)");
+  const int64_t n_alive = ctx->grp_n_alive;
+  ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_group_replay: position range out of bounds");
+  ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
+              "smc_group_replay: the own range must start and end at multiples of 64 positions (or at n_alive)");
+  ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_group_replay: the two slots / bit arrays must differ");
+  const int k = ctx->grp_k;
+  int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0, slot1,
+                                        logpi, flags, gamma0, gamma_sigma, sweep, k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
+  if (rc) return rc;
+  rc = abz_launch_group_check(ctx, k, ctx->grp_base_acc, (uint32_t)n_alive, ctx->grp_kmin, ABZ_C_RACC);
+  if (rc) return rc;
+  ctx->grp_k = k + 1;
+  return 0;
+}
+int abcdez_smc_group_publish(abcdez_ctx* ctx) {
+  ABZ_REQUIRE(ctx && ctx->grp_k > 0 && ctx->grp_pub == 0, "smc_group_publish: needs an open group with at least one sweep");
+  return abz_publish_launch(ctx, ABZ_S_N, &ctx->grp_pub);
+}
+int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t* k_done) {
+  ABZ_REQUIRE(ctx && nacc && nsim && k_done, "smc_group_end: null argument");
+  ABZ_REQUIRE(ctx->grp_k > 0, "smc_group_end: no group open, or no sweep in it");
+  const int k_max = ctx->grp_k;
+  ctx->grp_k = -1;
+  if (ctx->grp_pub == 0)
+    if (int rc = abz_publish_launch(ctx, ABZ_S_N, &ctx->grp_pub)) return rc;
+  if (int rc = abz_publish_wait(ctx, ABZ_S_N, ctx->grp_pub)) return rc;
+  /* every replay is followed by a check, so snapshot k holds the totals after sweep k; the stop flag says whether the test
+   * held after sweep GRP_DONE (the later launches returned at once) */
+  const int done = (int)ctx->h_scal[ABZ_S_GRP_DONE];
+  ABZ_REQUIRE(1 <= done && done <= k_max, "smc_group_end: inconsistent sweep count read back");
+  if (int rc = read_counters_finish(ctx, -1)) return rc;
+  unsigned long long pa = ctx->grp_base_acc, ps = ctx->grp_base_sim;
+  for (int k = 0; k < k_max; ++k) {
+    if (k < done) {
+      const unsigned long long ca = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k], cs = ctx->h_scal[ABZ_S_GRP_SNAP + 2 * k + 1];
+      nacc[k] = (int64_t)(ca - pa); nsim[k] = (int64_t)(cs - ps);
+      pa = ca; ps = cs;
+    } else {
+      nacc[k] = 0; nsim[k] = 0;
+    }
+  }
+  *k_done = done;
   return 0;
 }
 

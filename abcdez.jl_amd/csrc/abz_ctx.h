@@ -79,6 +79,11 @@ struct abcdez_ctx {
   bool mc_have_bank = false;
   bool mc_window_ready = false;                   /* the last snapshot kernel left the next generation's window for (mc_alpha, mc_eps_target) */
   double mc_alpha = 0.0, mc_eps_target = 0.0;                      /* a sweep of this context has left extrema in a bank */
+  /* an open group of sharded sweeps (abcdez_smc_group_begin .. _end): sweeps enqueued so far (-1 = none open) */
+  int grp_k = -1;
+  int64_t grp_n_alive = 0;
+  double grp_kmin = 0.0;
+  unsigned long long grp_base_acc = 0, grp_base_sim = 0, grp_pub = 0;
   const uint32_t* mc_rank_state = nullptr;        /* state words of the last rank pass (abz_sort.hip), in the workspace */
   long long mc_tail_hint = -1;                    /* particles that drew in the last generation the host has seen; -1 = unknown */
   double swarm_ms = 0.0;

@@ -282,6 +282,7 @@ struct SmcReplayPackedArgs {
   double* logpi;
   uint64_t* stamp;              /* blob stamps (in place), NULL when blobs are off */
   unsigned long long* cslots;   /* (nacc, nsim) over ALL positions of the prefix -> ABZ_C_RACC, ABZ_C_RSIM */
+  const unsigned long long* stop;   /* group of sweeps: non-zero = the early exit of smc:352 held before this sweep; NULL = always run */
   double gamma0, gsig;
   uint32_t n_alive, skip_lo, skip_hi, sweep;
 };
@@ -289,6 +290,7 @@ struct SmcReplayPackedArgs {
 template <int L, int C, bool PLAIN = false>
 __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
   constexpr int LD = L * C;
+  if (a.stop && *a.stop) return;                          /* grid-uniform: the sweep this replay belongs to did not run */
   __shared__ ModelLds<LD> s_model;
   __shared__ uint32_t s_list[ABZ_REPLAY_CHUNK];           /* accepted foreign positions of this block */
   __shared__ unsigned int s_n;

@@ -82,10 +82,10 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
 /* After sweep k of a group: totals of the (nacc, nsim) slots -> snapshot k; the test of smc:352 on the group's
  * acceptances so far -> stop flag for the sweeps enqueued behind it.  One block. */
 __global__ __launch_bounds__(ABZ_CSLOTS) void group_check_kernel(unsigned long long* __restrict__ scal, int k,
-                                                                 unsigned long long base_acc, uint32_t n_alive, double kmin) {
+                                                                 unsigned long long base_acc, uint32_t n_alive, double kmin, int cls) {
   __shared__ unsigned long long s_a[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
-  unsigned long long va = cs[ABZ_C_NACC], vs = cs[ABZ_C_NSIM];
+  unsigned long long va = cs[cls], vs = cs[cls + 1];     /* (nacc, nsim) of the sweeps, or of the replays of a sharded run */
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { va += __shfl_xor(va, o); vs += __shfl_xor(vs, o); }
   if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = va; s_s[threadIdx.x >> 6] = vs; }
@@ -101,16 +101,17 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void group_check_kernel(unsigned long l
     }
   }
 }
-int abz_launch_group_check(abcdez_ctx* ctx, int k, unsigned long long base_acc, uint32_t n_alive, double kmin) {
-  hipLaunchKernelGGL(group_check_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, k, base_acc, n_alive, kmin);
+int abz_launch_group_check(abcdez_ctx* ctx, int k, unsigned long long base_acc, uint32_t n_alive, double kmin, int cls) {
+  hipLaunchKernelGGL(group_check_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, k, base_acc, n_alive, kmin, cls);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 int abz_launch_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, uint32_t n_alive,
                                  uint32_t skip_lo, uint32_t skip_hi, double* slot0, double* slot1, double* logpi,
-                                 const uint8_t* flags, double gamma0, double gsig, uint32_t sweep) {
+                                 const uint8_t* flags, double gamma0, double gsig, uint32_t sweep, const unsigned long long* stop) {
   SmcReplayPackedArgs a;
+  a.stop = stop;
   a.hm = ctx->hot; a.bits = bits; a.bits_out = bits_out; a.flags = flags; a.slot0 = slot0; a.slot1 = slot1; a.logpi = logpi;
   a.stamp = ctx->stamp_cur;
   a.cslots = ctx->d_scal + ABZ_S_CSLOT0;

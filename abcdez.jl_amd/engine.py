@@ -155,6 +155,22 @@ class HipOps:
         """arm the next grouped sweeps: they also start the next generation's select (include/abcdez_hip.h)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_ahead(self.ctx, _ptr(delta), _ptr(alive), delta.numel(), alpha, eps_target))
 
+    # the sweeps of a generation on a sharded population, one host synchronisation (include/abcdez_hip.h)
+    def smc_group_begin(self, n_alive, kmcmc_min):
+        _lib.check(self.lib, self.lib.abcdez_smc_group_begin(self.ctx, n_alive, kmcmc_min))
+
+    def smc_group_replay(self, bits, bits_out, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
+        _lib.check(self.lib, self.lib.abcdez_smc_group_replay(self.ctx, _ptr(bits), _ptr(bits_out), skip_lo, skip_hi, _ptr(slot0),
+                                                              _ptr(slot1), _ptr(logpi), _ptr(flags), gamma0, gsig, sweep))
+
+    def smc_group_publish(self):
+        _lib.check(self.lib, self.lib.abcdez_smc_group_publish(self.ctx))
+
+    def smc_group_end(self, k_max):
+        nacc, nsim, done = (C.c_int64 * k_max)(), (C.c_int64 * k_max)(), C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_smc_group_end(self.ctx, nacc, nsim, C.byref(done)))
+        return list(nacc[:done.value]), list(nsim[:done.value]), done.value
+
     def smc_select_discard(self):
         """forget a select armed / enqueued ahead (the population was written by other means, or the run ends)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_discard(self.ctx))
@@ -655,6 +671,8 @@ class PopulationEngine:
             if Ki & 1:
                 self.bc = 1 - self.bc
             return naccs, nsims, Ki
+        if self.sharded_packed and hasattr(self.ops, "smc_group_begin") and Kmcmc <= self.ops.SWEEPS_MAX and Kmcmc_min >= 0.0:
+            return self._smc_sweeps_sharded_group(eps, gamma0, gsig, Kmcmc, Kmcmc_min)
         naccs, nsims = [], []
         for i in range(1, Kmcmc + 1):
             nacc, nsim = self.smc_swarm(eps, gamma0, gsig, last=(i == Kmcmc))
@@ -663,6 +681,40 @@ class PopulationEngine:
             if sum(naccs) / self.n_alive >= Kmcmc_min:   # smc:352
                 break
         return naccs, nsims, len(naccs)
+
+    def _smc_sweeps_sharded_group(self, eps, gamma0, gsig, Kmcmc, Kmcmc_min):
+        """sharded population: all Kmcmc sweeps enqueued back to back -- own range, flag all-gather, replay + the device-side
+        test of smc:352 -- and ONE read-back; every replica counts the same flags, so all ranks stop after the same sweep."""
+        self._stream()
+        self._bind_stamps()
+        if self._delta_work is not None:
+            self._delta_work.wait()
+            self._delta_work = None
+        cur = self.buf[self.cur]
+        self.ops.smc_group_begin(self.n_alive, Kmcmc_min)
+        bc = self.bc
+        for k in range(Kmcmc):
+            b_in, b_out = self.bits[bc], self.bits[1 - bc]
+            self._mark("own_sweep", 0)
+            self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                      cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep + k, want_counts=False)
+            self._mark("own_sweep", 1)
+            self._mark("flag_allgather", 0)
+            self._allgather_chunks(self.flags)               # executed by every rank whether or not the sweep ran
+            self._mark("flag_allgather", 1)
+            self._mark("replay", 0)
+            self.ops.smc_group_replay(b_in, b_out, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0], cur[1], self.flags,
+                                      gamma0, gsig, self.sweep + k)
+            self._mark("replay", 1)
+            bc = 1 - bc
+        self.ops.smc_group_publish()
+        self._delta_stale = True
+        self._start_delta_allgather()                        # behind the read-back: travels while the host applies its rules
+        naccs, nsims, Ki = self.ops.smc_group_end(Kmcmc)
+        self.sweep += Ki
+        if Ki & 1:
+            self.bc = 1 - self.bc
+        return naccs, nsims, Ki
 
     # ------------------------------------------------------------------ S4
     def _mc_arrays(self):

@@ -174,6 +174,19 @@ ABCDEZ_API int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, u
                                         int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, double* logpi,
                                         const uint8_t* flags, double gamma0, double gamma_sigma, uint32_t sweep,
                                         int64_t* nacc, int64_t* nsim);
+/* The sweeps of one generation on a SHARDED population with ONE host synchronisation (smc:336-353; the unsharded counterpart is
+ * abcdez_smc_sweeps_packed).  Between group_begin and group_end: per sweep abcdez_smc_swarm_packed on the own range with
+ * nacc = NULL (sweep k > 0 returns at once when the test of smc:352 held), the host's all-gather of the flag bytes (every
+ * rank executes it, stopped or not), abcdez_smc_group_replay (gated the same way; counts both flag bits over the whole prefix and
+ * evaluates `sum(naccs) / n_alive >= Kmcmc_min` on the device).  group_publish enqueues the read-back so that the host can put
+ * the distance exchange behind it; group_end waits and returns the per-sweep counters and the number of sweeps that ran.
+ * Every replica sees the same flags, so all ranks stop after the same sweep without a collective. */
+ABCDEZ_API int abcdez_smc_group_begin(abcdez_ctx* ctx, int64_t n_alive, double kmcmc_min);
+ABCDEZ_API int abcdez_smc_group_replay(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t skip_lo, int64_t skip_hi,
+                                       double* slot0, double* slot1, double* logpi, const uint8_t* flags, double gamma0,
+                                       double gamma_sigma, uint32_t sweep);
+ABCDEZ_API int abcdez_smc_group_publish(abcdez_ctx* ctx);
+ABCDEZ_API int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t* k_done);
 ABCDEZ_API int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* bits,
                                                  uint32_t* bits_other, double* slot0, double* slot1, const double* logpi,
                                                  const double* delta, double* nlogpi, double* ndelta, double* wns,

@@ -611,6 +611,29 @@ typedef struct abz_model {
   double sim_p[8];
   const double* data; /* n_data doubles: host memory for the oracle, device memory for the HIP library */
   abz_prior_dim prior[ABZ_MAX_D]; /* entries d..ld-1 are ABZ_PRIOR_PAD             */
+  const double* mv;   /* NULL, or the maps of a correlated Normal prior (below): host memory for the oracle; the HIP library
+                         copies them to the device at context creation                                                    */
 } abz_model;
+
+/* ---- a multivariate prior that is not a product (a Distributions.MvNormal in the `prior` position, src/abcdez_types.jl:16,21:
+ * particles are vectors, push_p casts every element to float).  theta = mu + L z with z ~ N(0, I) and Sigma = L L^T, so
+ *   logpdf(theta) = sum_k [ -z_k^2 / 2 - log L_kk - log(2 pi) / 2 ],   z = W (theta - mu),  W = L^-1 (lower triangular)
+ * i.e. the SAME per-component tree as a product of standard Normals, over the whitened components: the per-dimension
+ * descriptors of such a model are Normal(0, 1) with c0 = -log L_kk - log(2 pi) / 2, and mv = [mu[ld] | W[ld][ld] | L[ld][ld]]
+ * (row-major, zero above the diagonal and in the padding).  Sums run left to right over m <= k with fma.                     */
+ABZ_HD double abz_mv_whiten1(const double* mv, int ld, int k, const double* theta) {
+  const double* mu = mv;
+  const double* W = mv + ld + (size_t)k * ld;
+  double z = 0.0;
+  for (int m = 0; m <= k; ++m) z = abz_fma(W[m], theta[m] - mu[m], z);
+  return z;
+}
+ABZ_HD double abz_mv_forward1(const double* mv, int ld, int k, const double* z) {
+  const double* L = mv + ld + (size_t)ld * ld + (size_t)k * ld;
+  double t = 0.0;
+  for (int m = 0; m <= k; ++m) t = abz_fma(L[m], z[m], t);
+  return mv[k] + t;
+}
+#define ABZ_MV_DOUBLES(ld) ((size_t)(ld) + 2u * (size_t)(ld) * (size_t)(ld))
 
 #endif /* ABCDEZ_SPEC_H */

@@ -123,16 +123,25 @@ ORC_API double orc_kernel_logpdf(int kind, double eps, double x) { return abz_ke
 static void push_row(const abz_model* M, const double* th, double* out) {
   for (int k = 0; k < M->ld; ++k) out[k] = abz_push_p(&M->prior[k], th[k]);
 }
+/* a correlated Normal prior (abcdez_spec.h, abz_model.mv): the components the per-dimension log-densities are taken of */
+static const double* whitened(const abz_model* M, const double* pushed, double* z) {
+  if (!M->mv) return pushed;
+  for (int k = 0; k < M->ld; ++k) z[k] = k < M->d ? abz_mv_whiten1(M->mv, M->ld, k, pushed) : 0.0;
+  return z;
+}
 /* spec: pairwise tree over components */
 static double logprior_tree(const abz_model* M, const double* pushed) {
-  double t[ABZ_MAX_D];
-  for (int k = 0; k < M->ld; ++k) t[k] = abz_prior_logpdf1(&M->prior[k], pushed[k]);
+  double t[ABZ_MAX_D], zb[ABZ_MAX_D];
+  const double* x = whitened(M, pushed, zb);
+  for (int k = 0; k < M->ld; ++k) t[k] = abz_prior_logpdf1(&M->prior[k], x[k]);
   return abz_tree_sum_small(t, M->ld);
 }
 /* literal: left-to-right sum, priors.jl:41-45 */
 static double logprior_seq(const abz_model* M, const double* pushed) {
-  double s = abz_prior_logpdf1(&M->prior[0], pushed[0]);
-  for (int k = 1; k < M->d; ++k) s += abz_prior_logpdf1(&M->prior[k], pushed[k]);
+  double zb[ABZ_MAX_D];
+  const double* x = whitened(M, pushed, zb);
+  double s = abz_prior_logpdf1(&M->prior[0], x[0]);
+  for (int k = 1; k < M->d; ++k) s += abz_prior_logpdf1(&M->prior[k], x[k]);
   return s;
 }
 ORC_API void orc_push_p(const abz_model* M, const double* theta, int64_t n, double* out) {
@@ -322,6 +331,11 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
     for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c)
       if (M->prior[2 * m + c].family >= ABZ_PRIOR_BETA)
         th[2 * m + c] = abz_prior_draw_ext(&M->prior[2 * m + c], M->seed, i, retry, (uint32_t)(2 * m + c), ORC_T);
+  }
+  if (M->mv) {                     /* correlated Normal prior: the row drawn so far is z ~ N(0, I); theta = mu + L z */
+    double z[ABZ_MAX_D];
+    for (int k = 0; k < M->ld; ++k) z[k] = th[k];
+    for (int k = 0; k < M->ld; ++k) th[k] = k < M->d ? abz_mv_forward1(M->mv, M->ld, k, z) : 0.0;
   }
 }
 /* fills rows [i0, i0+n) of the FULL arrays theta / logpi / delta */

@@ -189,6 +189,8 @@ class OracleOps:
 
     def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
                          sweep, want_counts=True):
+        if getattr(self, "_grp", None) and self._grp["stop"]:
+            return None                               # inside a group whose early-exit test has held: this sweep does not run
         nacc, nsim = _i64(), _i64()
         self.L.orc_smc_swarm_packed(self.m.ptr, _p(bits), _p(bits_out), n_alive, r_lo, r_hi, _p(slot0), _p(slot1),
                                     _p(logpi), _p(delta), _p(flags), eps, gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
@@ -199,6 +201,30 @@ class OracleOps:
         self.L.orc_smc_replay_packed(self.m.ptr, _p(bits), _p(bits_out), n_alive, skip_lo, skip_hi, _p(slot0), _p(slot1),
                                      _p(logpi), _p(flags), gamma0, gsig, sweep, C.byref(nacc), C.byref(nsim))
         return nacc.value, nsim.value
+
+    # the grouped sweeps of a sharded population (include/abcdez_hip.h: abcdez_smc_group_*), restated synchronously: a sweep /
+    # replay behind a held test of smc:352 does nothing, exactly like the launches that return at once on the device
+    SWEEPS_MAX = 16
+
+    def smc_group_begin(self, n_alive, kmcmc_min):
+        self._grp = dict(n_alive=n_alive, kmin=kmcmc_min, nacc=[], nsim=[], stop=False)
+
+    def smc_group_replay(self, bits, bits_out, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
+        g = self._grp
+        if g["stop"]:
+            return
+        nacc, nsim = self.smc_replay_packed(bits, bits_out, g["n_alive"], skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0,
+                                            gsig, sweep)
+        g["nacc"].append(nacc)
+        g["nsim"].append(nsim)
+        g["stop"] = sum(g["nacc"]) / g["n_alive"] >= g["kmin"]          # smc:352
+
+    def smc_group_publish(self):
+        pass
+
+    def smc_group_end(self, k_max):
+        g, self._grp = self._grp, None
+        return g["nacc"], g["nsim"], len(g["nacc"])
 
     def smc_resample_gather_packed(self, inds, bits, bits_other, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
         self.L.orc_smc_resample_gather_packed(self.m.ptr, _p(inds), inds.numel(), _p(bits), _p(bits_other), _p(slot0),

@@ -5,7 +5,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r02}; CFG=${CFG:-smc32}; MARK=${MARK:-qs_hist_kernel}; LANES=${LANES:-4}
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$CFG -o kt -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern $EXTRA > $R/gpurun_out/${TAG}_${CFG}_prof_bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$CFG -o kt -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs $EXTRA > $R/gpurun_out/${TAG}_${CFG}_prof_bench.log 2>&1
 F=$(find $R/gpurun_out/prof_$CFG -name 'kt_kernel_trace.csv' | head -1)
 python3 $R/tools/timeline_gaps.py $F $MARK 3 $LANES > $R/gpurun_out/${TAG}_${CFG}_timeline.txt 2>&1
 cp $(find $R/gpurun_out/prof_$CFG -name 'kt_kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_${CFG}_kernel_stats.csv

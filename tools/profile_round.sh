@@ -15,8 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py --config $CFG --no-other-configs > $R/gpurun_out/${TAG}_${CFG}_bench.log 2>&1
 MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG KERN=$KERN PER_STEP=${PER_STEP:-3} bash $R/tools/profile_config.sh
 if [ "${PMC:-0}" = "1" ]; then
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_f.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_w.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_f.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_w.log 2>&1
   UF=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_pmc_f.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
   UW=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_pmc_w.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
   FC=$(find $R/gpurun_out/pmc_fetch_$CFG -name '*counter_collection.csv' | head -1)

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 COUNTERS=${COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU}
 OUT=${OUT:-sq_counters}
 timeout 500 rocprofv3 --pmc $COUNTERS \
-  --output-format csv -d $R/gpurun_out/sq_$CFG -o sq -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --steps 8 --warmup 4 > $R/gpurun_out/${TAG}_${CFG}_sq_bench.log 2>&1
+  --output-format csv -d $R/gpurun_out/sq_$CFG -o sq -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs --steps 8 --warmup 4 > $R/gpurun_out/${TAG}_${CFG}_sq_bench.log 2>&1
 F=$(find $R/gpurun_out/sq_$CFG -name 'sq_counter_collection.csv' | head -1)
 UPD=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_sq_bench.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
 python3 $R/tools/sq_summary.py $F $KERNEL $UPD > $R/gpurun_out/${TAG}_${CFG}_${OUT}.json
