@@ -14,7 +14,7 @@ from .kernels import (  # noqa: F401
     IndicatorStrict0toeps, IndicatorStrict0toϵ,
 )
 from .model import ModelSpec  # noqa: F401
-from .priors import (Beta, DiscreteUniform, Factored, NegativeBinomial, Normal, Product, Uniform,  # noqa: F401
+from .priors import (Beta, DiscreteUniform, Factored, MvNormal, NegativeBinomial, Normal, Product, Uniform,  # noqa: F401
                      product_distribution, push_p)
 from .simulators import (  # noqa: F401
     DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, UserSimulator, WienerRMS,

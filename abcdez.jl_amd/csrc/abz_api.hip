@@ -77,7 +77,7 @@ int abcdez_abi_layout(int32_t* out, int n) {
       (int32_t)sizeof(abz_model), (int32_t)offsetof(abz_model, d), (int32_t)offsetof(abz_model, ld),
       (int32_t)offsetof(abz_model, sim_id), (int32_t)offsetof(abz_model, abck), (int32_t)offsetof(abz_model, seed),
       (int32_t)offsetof(abz_model, n_data), (int32_t)offsetof(abz_model, n_blob), (int32_t)offsetof(abz_model, sim_p),
-      (int32_t)offsetof(abz_model, data), (int32_t)offsetof(abz_model, prior)};
+      (int32_t)offsetof(abz_model, data), (int32_t)offsetof(abz_model, prior), (int32_t)offsetof(abz_model, mv)};
   const int m = (int)(sizeof(lay) / sizeof(lay[0]));
   for (int k = 0; k < m && k < n; ++k) out[k] = lay[k];
   return m;
@@ -156,6 +156,13 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     ABZ_CTX_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));
   }
   ctx->h_model.data = ctx->d_data;
+  if (model->mv) {                   /* correlated Normal prior: [mu | W | L] travels to the device; no plain-Normal shortcut */
+    const size_t nb = ABZ_MV_DOUBLES(model->ld) * 8;
+    ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_mv, nb));
+    ABZ_CTX_CHECK(hipMemcpy(ctx->d_mv, model->mv, nb, hipMemcpyHostToDevice));
+    ctx->prior_plain = false;
+  }
+  ctx->h_model.mv = ctx->d_mv;
   ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
   ABZ_CTX_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
   {   /* sampler tables: the whole inverse-normal-CDF table, and the struct the kernels stage into LDS (log table, the
@@ -176,6 +183,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   }
   ctx->hot.tables = ctx->d_tables;
   ctx->hot.icdf_all = ctx->d_icdf_all;
+  ctx->hot.mv = ctx->d_mv;
   ctx->hot.seed = model->seed;
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
@@ -222,6 +230,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->d_model) (void)hipFree(ctx->d_model);
   if (ctx->d_data) (void)hipFree(ctx->d_data);
+  if (ctx->d_mv) (void)hipFree(ctx->d_mv);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->d_icdf_all) (void)hipFree(ctx->d_icdf_all);
   delete ctx;

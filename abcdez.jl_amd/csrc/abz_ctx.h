@@ -33,6 +33,7 @@ struct abcdez_ctx {
   abz_model h_model;              /* host copy; .data points at d_data          */
   abz_model* d_model = nullptr;
   double* d_data = nullptr;
+  double* d_mv = nullptr;             /* maps of a correlated Normal prior (abz_model.mv), else null */
   abz_tables* d_tables = nullptr;     /* log table + hot part of the inverse normal CDF + pointer to ... */
   abz_f64x2* d_icdf_all = nullptr;    /* ... the whole inverse-CDF table [ABZ_ICDF_PIECES][ABZ_ICDF_ROWS] */
   int n_cu = 1;                       /* compute units of the device */

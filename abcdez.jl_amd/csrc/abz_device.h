@@ -183,14 +183,58 @@ __device__ inline double group_tree_sum(const double (&x)[C]) {
   }
 }
 
+/* ---- correlated Normal prior (abcdez_spec.h, abz_model.mv): out_k = sum_{m <= k} mat[k][m] in_m for the lane's components k,
+ * accumulated left to right with fma exactly as abz_mv_whiten1 / abz_mv_forward1 do.  The group's vector is spread over its
+ * L lanes, so component m is fetched from its owner by one shuffle; the loops run over m in ascending order with compile-time
+ * (owner lane, register) -- no dynamic register indexing.  Only the kernels of non-plain priors contain this code. */
+template <int L, int C>
+__device__ inline void group_lower_matvec(const double* __restrict__ mat, int j, const double (&in)[C], double (&out)[C]) {
+  constexpr int LD = L * C;
+#pragma unroll
+  for (int q = 0; q < C; ++q) out[q] = 0.0;
+  constexpr int MM = C == 1 ? 1 : C / 2;
+#pragma unroll
+  for (int mm = 0; mm < MM; ++mm)
+#pragma unroll
+    for (int sj = 0; sj < L; ++sj)
+#pragma unroll
+      for (int c = 0; c < (C == 1 ? 1 : 2); ++c) {
+        const int m = Lay<L, C>::comp(sj, mm, c);                         /* ascending over the three loops */
+        const double xm = L == 1 ? in[2 * mm + c] : __shfl(in[2 * mm + c], sj, L);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+          const int k = Lay<L, C>::comp(j, q / 2, q & 1);
+          const double t = abz_fma(mat[(size_t)k * LD + m], xm, out[q]);
+          out[q] = m <= k ? t : out[q];
+        }
+      }
+}
+
 /* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */
 /* PLAIN: every real dimension is a continuous Normal and the padding descriptors are all-zero (abcdez_ctx_create checks):
  * push_p is the identity and the log-density is abz_prior_logpdf1's Normal branch without the family dispatch -- the
  * same operations, so the same bits (tests/test_gpu_packed.py compares both against the oracle's generic evaluation) */
+/* mv (generic instantiation only): the maps of a correlated Normal prior -- the per-dimension log-densities are then taken of
+ * the whitened components z = W (theta - mu) (abcdez_spec.h) */
 template <int L, int C, bool PLAIN = false>
 __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entries */, int j, const double (&p)[C],
-                                        double (&pp)[C]) {
+                                        double (&pp)[C], const double* __restrict__ mv = nullptr) {
   double lp[C];
+  if constexpr (!PLAIN) {
+    if (mv) {
+      constexpr int LD = L * C;
+      double df[C], z[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        pp[q] = p[q];                                                    /* continuous: push_p is the identity */
+        df[q] = p[q] - mv[Lay<L, C>::comp(j, q / 2, q & 1)];
+      }
+      group_lower_matvec<L, C>(mv + LD, j, df, z);
+#pragma unroll
+      for (int q = 0; q < C; ++q) lp[q] = abz_prior_logpdf1(&pd[Lay<L, C>::comp(j, q / 2, q & 1)], z[q]);
+      return group_tree_sum<L, C>(lp);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < C; ++q) {
     const abz_prior_dim* d = &pd[Lay<L, C>::comp(j, q / 2, q & 1)];

@@ -58,7 +58,18 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
             th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
         }
       }
-      lp = group_logprior<L, C>(pd, j, th, pp);
+      if (M.mv) {                     /* correlated Normal prior: the row drawn so far is z ~ N(0, I); theta = mu + L z */
+        double zz[C];
+#pragma unroll
+        for (int q = 0; q < C; ++q) zz[q] = th[q];
+        group_lower_matvec<L, C>(M.mv + LD + (size_t)LD * LD, j, zz, th);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+          const int k = Lay<L, C>::comp(j, q / 2, q & 1);
+          th[q] = k < M.d ? M.mv[k] + th[q] : 0.0;
+        }
+      }
+      lp = group_logprior<L, C>(pd, j, th, pp, M.mv);
       dl = ABZ_NAN;
       if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
       if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
@@ -210,7 +221,7 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
       if (have2) request(nx, wt2, r2, j);
     }
 
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);   /* smc:134 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
     const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
     bool acc = false;
     double dp = dli;
@@ -368,7 +379,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);                /* what the owner stored, smc:147 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, a.hm.mv);      /* what the owner stored, smc:147 */
     if (on) {
       store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
       if (j == 0) {
@@ -456,7 +467,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
 
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp);              /* mc:41 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);        /* mc:41 */
     const double w_prior = lp - lpi;                                        /* mc:42 */
     const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
     double mn = w_prior < 0.0 ? w_prior : 0.0;
@@ -538,7 +549,7 @@ __device__ inline void blob_eval_kernel_body(const HotModel& M, const double* __
     if (s >= n) continue;                       /* whole groups leave together; no barrier inside the loop */
     double th[C], pp[C];
     load_row<L, C>(theta + (size_t)s * LD, j, th);
-    (void)group_logprior<L, C>(s_model.prior, j, th, pp);        /* push_p (types.jl:20-23) */
+    (void)group_logprior<L, C>(s_model.prior, j, th, pp, M.mv);  /* push_p (types.jl:20-23) */
     const uint64_t st = stamp[s];
     const uint32_t purpose = abz_stamp_is_init(st) ? (uint32_t)ABZ_RNG_INIT_SIM : (uint32_t)ABZ_RNG_SIM;
     if constexpr (SIM == ABZ_SIM_MVN) {

@@ -42,6 +42,7 @@ class Model(C.Structure):
         ("sim_p", C.c_double * 8),
         ("data", C.c_void_p),
         ("prior", PriorDim * MAX_D),
+        ("mv", C.c_void_p),
     ]
 
 
@@ -85,6 +86,8 @@ class ModelSpec:
             self.discrete = tuple(bool(prior.discrete) for _ in factors)
             self._desc = [(fam, int(prior.discrete), p0, p1, c0) for (fam, _, p0, p1, c0) in self._desc]
         self._c1 = [f.c1() if f.family == PRIOR_NEGBIN else None for f in factors]
+        # a correlated Normal prior (priors.MvNormal): [mu | L^-1 | L], host memory -- the library copies it to the device
+        self.mv = prior.mv_maps(self.ld) if hasattr(prior, "mv_maps") else None
 
     def cstruct(self, data_ptr: Optional[int]) -> Model:
         m = Model()
@@ -104,4 +107,5 @@ class ModelSpec:
             m.prior[k].family, m.prior[k].discrete = fam, disc
             m.prior[k].p0, m.prior[k].p1, m.prior[k].c0 = p0, p1, c0
             m.prior[k].c1 = 1.0 / p1 if fam == PRIOR_NORMAL else (self._c1[k] if fam == PRIOR_NEGBIN else 0.0)
+        m.mv = self.mv.ctypes.data if self.mv is not None else None
         return m

@@ -246,6 +246,72 @@ def product_distribution(dists: Sequence[UnivariateDistribution]) -> Product:
     return Product(dists)
 
 
+class _WhitenedNormal(Normal):
+    """one component of a correlated Normal prior after whitening: Normal(0, 1) carrying -log L_kk - log(2 pi)/2"""
+
+    def __init__(self, c0: float):
+        object.__setattr__(self, "mu", 0.0)
+        object.__setattr__(self, "sigma", 1.0)
+        object.__setattr__(self, "_c0", float(c0))
+
+    def descriptor(self):
+        return (PRIOR_NORMAL, 0, 0.0, 1.0, self._c0)
+
+
+class MvNormal(Product):
+    """``Distributions.MvNormal(mu, Sigma)`` in the ``prior`` position: a multivariate prior that is NOT a product.  Particles
+    are vectors, ``push_p`` casts every element to float (src/abcdez_types.jl:16,21).  With Sigma = L L^T (Cholesky),
+    theta = mu + L z, z ~ N(0, I), and logpdf(theta) = sum_k [-z_k^2 / 2 - log L_kk - log(2 pi)/2] with z = L^-1 (theta - mu):
+    the device evaluates the per-dimension Normal tree over the WHITENED components (include/abcdez_spec.h, abz_model.mv)."""
+
+    def __init__(self, mu: Sequence[float], cov):
+        import numpy as np
+
+        self.mu = np.ascontiguousarray(np.asarray(mu, dtype=np.float64))
+        self.cov = np.ascontiguousarray(np.asarray(cov, dtype=np.float64))
+        d = self.mu.size
+        if self.cov.shape != (d, d) or not np.allclose(self.cov, self.cov.T):
+            raise ValueError("MvNormal: cov must be a symmetric d x d matrix matching mu")
+        try:
+            self.L = np.linalg.cholesky(self.cov)
+        except np.linalg.LinAlgError as e:
+            raise ValueError("MvNormal: cov must be positive definite") from e
+        W = np.linalg.solve(self.L, np.eye(d))                 # L^-1, lower triangular up to rounding
+        self.W = np.tril(W)
+        super().__init__([_WhitenedNormal(-math.log(self.L[k, k]) - _HALF_LOG_2PI) for k in range(d)])
+        self.discrete = False
+
+    def mv_maps(self, ld: int):
+        """[mu[ld] | W[ld][ld] | L[ld][ld]] row-major, zero-padded: what abz_model.mv points at"""
+        import numpy as np
+
+        d = self.mu.size
+        out = np.zeros(ld + 2 * ld * ld)
+        out[:d] = self.mu
+        Wp, Lp = np.zeros((ld, ld)), np.zeros((ld, ld))
+        Wp[:d, :d], Lp[:d, :d] = self.W, np.tril(self.L)
+        out[ld:ld + ld * ld] = Wp.ravel()
+        out[ld + ld * ld:] = Lp.ravel()
+        return np.ascontiguousarray(out)
+
+    def logpdf(self, x) -> float:
+        import numpy as np
+
+        z = self.W @ (np.asarray(x, dtype=np.float64) - self.mu)
+        return float(sum(-0.5 * zk * zk + f._c0 for zk, f in zip(z, self.p)))
+
+    def insupport(self, x) -> bool:
+        return all(math.isfinite(float(v)) for v in x)
+
+    def rand(self, rng) -> list:
+        import numpy as np
+
+        return list(self.mu + self.L @ rng.standard_normal(self.mu.size))
+
+    def __repr__(self) -> str:
+        return f"MvNormal(mu={self.mu.tolist()}, cov={self.cov.tolist()})"
+
+
 Prior = Union[UnivariateDistribution, Factored]
 
 

@@ -36,7 +36,7 @@ typedef struct abcdez_ctx abcdez_ctx;
 
 ABCDEZ_API int abcdez_version(void);
 /* Layout of the structs that cross the boundary: fills out[0 .. n) with { sizeof(abz_prior_dim), offsetof of its 7 fields
- * in declaration order, sizeof(abz_model), offsetof of its 10 fields in declaration order } and returns how many
+ * in declaration order, sizeof(abz_model), offsetof of its 11 fields in declaration order } and returns how many
  * values there are (19).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
 ABCDEZ_API int abcdez_abi_layout(int32_t* out, int n);
 ABCDEZ_API const char* abcdez_last_error(void);

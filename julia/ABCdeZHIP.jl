@@ -22,7 +22,7 @@
 # reference for the order of the calls.
 module ABCdeZHIP
 
-using ABCdeZ, Distributions
+using ABCdeZ, Distributions, LinearAlgebra
 import ABCdeZ: abcdesmc!, abcdemc!
 
 export DeviceSimulator, Normal1D, MVNormalSim, DiracSquare, Quad2D, Mixture01, NormalTimesDU, WienerRMS,
@@ -42,13 +42,14 @@ struct AbzModel
     sim_p::NTuple{8,Float64}
     data::Ptr{Float64}
     prior::NTuple{64,AbzPriorDim}
+    mv::Ptr{Float64}                      # C_NULL, or [μ | L⁻¹ | L] of an MvNormal prior (include/abcdez_spec.h)
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
 function check_abi()
     lay = Vector{Int32}(undef, 32)
     n = ccall((:abcdez_abi_layout, LIB), Cint, (Ptr{Int32}, Cint), lay, length(lay))
     mine = Int32[sizeof(AbzPriorDim), fieldoffset.(AbzPriorDim, 1:7)...,
-                 sizeof(AbzModel), fieldoffset.(AbzModel, 1:10)...]
+                 sizeof(AbzModel), fieldoffset.(AbzModel, 1:11)...]
     (n == length(mine) && lay[1:n] == mine) || error("ABCdeZHIP: struct layout differs from libabcdez_hip.so (abcdez_abi_layout)")
 end
 
@@ -107,6 +108,23 @@ factors(p::UnivariateDistribution) = [p]
 # product_distribution([...]) in the prior position (test/runtests.jl:45): the same descriptors; push_p broadcasts the WHOLE
 # distribution over the vector (types.jl:21), so every component follows the product's value support
 factors(p::Distributions.Product) = collect(p.v)
+# MvNormal(μ, Σ) in the prior position -- not a product: Σ = L Lᵀ, θ = μ + L z; the device takes the per-dimension Normal tree
+# over the whitened components z = L⁻¹(θ - μ): descriptors Normal(0, 1) with c0 = -log L_kk - log(2π)/2, maps in AbzModel.mv
+struct WhitenedNormal; c0::Float64; end
+descriptor(p::WhitenedNormal) = AbzPriorDim(1, 0, 0.0, 1.0, p.c0, 1.0, 0.0)
+function factors(p::Distributions.AbstractMvNormal)
+    L = Matrix(cholesky(Symmetric(Matrix(cov(p)))).L)
+    [WhitenedNormal(-log(L[k, k]) - 0.5 * log(2π)) for k in 1:length(p)]
+end
+mvmaps(p, ld) = Float64[]
+function mvmaps(p::Distributions.AbstractMvNormal, ld)
+    d = length(p); L = Matrix(cholesky(Symmetric(Matrix(cov(p)))).L); W = inv(LowerTriangular(L))
+    out = zeros(ld + 2ld^2); out[1:d] = mean(p)
+    for k in 1:d, m in 1:k                                   # row-major ld x ld blocks, zero above the diagonal
+        out[ld + (k - 1) * ld + m] = W[k, m]; out[ld + ld^2 + (k - 1) * ld + m] = L[k, m]
+    end
+    out
+end
 pushrule(p, k, dflt) = dflt
 pushrule(p::Distributions.Product, k, dflt) = Int32(p isa DiscreteDistribution ? 1 : 0)
 const PAD = AbzPriorDim(0, 0, 0.0, 0.0, 0.0, 0.0, 0.0)
@@ -140,12 +158,13 @@ d2h(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoi
 function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
     check_abi()
     fs = factors(prior); d = length(fs); ld = nextpow(2, d)
-    data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d)
+    data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d); mv = mvmaps(prior, ld)
     m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), nb,
                  ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), isempty(data) ? C_NULL : pointer(data),
-                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 64))
+                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 64),
+                 isempty(mv) ? C_NULL : pointer(mv))
     ctx = Ref{Ptr{Cvoid}}()
-    GC.@preserve data begin
+    GC.@preserve data mv begin
         if sim isa UserSimulator
             check(ccall((:abcdez_ctx_create_user, LIB), Cint, (Ref{AbzModel}, Cstring, Cint, Ptr{Ptr{Cvoid}}), m, sim.source, 0, ctx))
         else

@@ -132,7 +132,7 @@ def test_abi_layout_of_the_hand_mirrored_structs():
     n = lib.abcdez_abi_layout(out, 32)
     mine = [ctypes.sizeof(PriorDim)] + [getattr(PriorDim, f).offset for f, _ in PriorDim._fields_] + \
            [ctypes.sizeof(Model)] + [getattr(Model, f).offset for f, _ in Model._fields_]
-    assert n == len(mine) == 19 and list(out[:n]) == mine
+    assert n == len(mine) == 20 and list(out[:n]) == mine
     jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
     body = lambda name: re.search(r"struct %s\n(.*?)\nend" % name, jl, re.S).group(1)
     fields = lambda name: re.findall(r"(\w+)::", re.sub(r"#.*", "", body(name)))
