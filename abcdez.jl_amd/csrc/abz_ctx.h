@@ -196,10 +196,10 @@ void abz_fold_counters(abcdez_ctx*);
  * kernel writes them straight into the pinned host mirror and stores a sequence word last (system-scope release); the
  * host polls that word.  Returns when everything enqueued before it has completed.                                  */
 int abz_publish(abcdez_ctx* ctx, int nwords);
-/* Host side of a read-back through pinned memory: waits until *word == expected.  Spins with a pause instruction, yields the
- * core after ~20 us of that, and when the stream has drained -- or after 2 s, by blocking in hipStreamSynchronize like the
- * copy-engine path would, with no limit of its own -- looks once more.  0 = the word arrived, 1 = the stream drained without
- * it (a failed launch), < 0 = HIP error. */
+/* Host side of a read-back through pinned memory: waits until *word == expected.  Spins with a pause instruction for up to
+ * 4 ms (the waits of the hot loop), then yields the core between looks, asks the stream now and then, and after 2 s blocks in
+ * hipStreamSynchronize like the copy-engine path would, with no limit of its own.  0 = the word arrived, 1 = the stream
+ * drained without it (a failed launch), < 0 = HIP error. */
 int abz_poll_word(abcdez_ctx* ctx, const unsigned long long* word, unsigned long long expected);
 int abz_publish_launch(abcdez_ctx* ctx, int nwords, unsigned long long* seq_out);
 int abz_publish_wait(abcdez_ctx* ctx, int nwords, unsigned long long seq);

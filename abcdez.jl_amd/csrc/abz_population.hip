@@ -208,19 +208,26 @@ int abz_publish_launch(abcdez_ctx* ctx, int nwords, unsigned long long* seq_out)
   return 0;
 }
 int abz_poll_word(abcdez_ctx* ctx, const unsigned long long* word, unsigned long long expected) {
+  /* The waits of the hot loop are 0.1 - 1.5 ms (a prologue, a group of sweeps) and every microsecond of wake-up latency is a
+   * microsecond of idle GPU: those are spun through with `pause` (kind to the core's other hardware thread), exactly as long as
+   * the bare spin of round 2 took.  Only a wait beyond 4 ms (a heavy user simulator, a huge population) starts giving the core
+   * away, asks the stream now and then, and after 2 s blocks in hipStreamSynchronize like the copy-engine path would. */
+  const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  std::chrono::steady_clock::time_point t0;
   for (;;) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == expected) return 0;
-    ++spins;
-    if (spins < 2048u) { __builtin_ia32_pause(); continue; }       /* ~20 us: a read-back behind one kernel arrives within this */
-    if (spins == 2048u) t0 = std::chrono::steady_clock::now();
-    sched_yield();                                                  /* longer waits (a whole group of sweeps): give the core away */
-    if ((spins & 63u) != 0u) continue;
+    __builtin_ia32_pause();
+    if ((++spins & 1023u) != 0u) continue;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) break;
+  }
+  for (spins = 0;; ++spins) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == expected) return 0;
+    sched_yield();
+    if ((spins & 1023u) != 1023u) continue;
     const hipError_t q = hipStreamQuery(ctx->stream);
     const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2);
     if (q == hipSuccess || late) {
-      if (late) ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));   /* heavy user simulators, huge populations: block, however long */
+      if (late) ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));   /* block, however long it takes */
       return __atomic_load_n(word, __ATOMIC_ACQUIRE) == expected ? 0 : 1;
     }
     if (q != hipErrorNotReady) ABZ_HIP_CHECK(q);

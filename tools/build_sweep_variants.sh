@@ -25,7 +25,12 @@ while IFS='|' read -r name what flags; do
   OBJS="$OBJS $B/$name.o"
 done <<< "$VARIANTS"
 wait
-/opt/rocm/bin/hipcc $COMMON $INC -c tools/sweep_variants.hip -o $B/main.o
+R02=""
+if [ -d _r02/abcdez.jl_amd/csrc ]; then      # round 2's kernel, when its worktree is there:  git worktree add _r02 <round-2 commit>
+  /opt/rocm/bin/hipcc $COMMON -I_r02/abcdez.jl_amd/csrc -I_r02/include -c tools/sweep_variant_r02.hip -o $B/r02.o
+  OBJS="$OBJS $B/r02.o"; R02="-DWITH_R02"
+fi
+/opt/rocm/bin/hipcc $COMMON $INC $R02 -c tools/sweep_variants.hip -o $B/main.o
 [ -f tools/liblayout_bench.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/liblayout_bench.so tools/layout_bench.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $B/main.o $OBJS -Ltools -llayout_bench -Wl,-rpath,'$ORIGIN' -o tools/sweep_variants
 echo built tools/sweep_variants

@@ -18,12 +18,36 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Variant { const char* name; const char* what; int (*occ)(); void (*launch)(const SmcPackedArgs*, unsigned, hipStream_t); };
+#ifdef WITH_R02      // round 2's kernel from a git worktree (tools/sweep_variant_r02.hip): its own grid, argument struct and tables
+extern "C" int sweep_occ_r02();
+extern "C" void sweep_launch_r02_raw(const uint32_t*, uint32_t*, double*, double*, double*, double*, unsigned long long*, const void*, const double*,
+                                     double, double, double, uint32_t, uint32_t, hipStream_t);
+static void sweep_launch_r02(const SmcPackedArgs* a, unsigned, hipStream_t st) {
+  sweep_launch_r02_raw(a->bits, a->bits_out, a->slot0, a->slot1, a->logpi, a->delta, a->cslots, a->hm.prior, a->hm.data, a->eps, a->gamma0,
+                       a->gsig, a->n_alive, a->sweep, st);
+}
+#endif
+#ifdef WITH_R02P7    // the same with Philox4x32-7 (a patched copy of the worktree): what 12 instructions per Philox block are worth there
+extern "C" int sweep_occ_r02p7();
+extern "C" void sweep_launch_r02p7_raw(const uint32_t*, uint32_t*, double*, double*, double*, double*, unsigned long long*, const void*, const double*,
+                                       double, double, double, uint32_t, uint32_t, hipStream_t);
+static void sweep_launch_r02p7(const SmcPackedArgs* a, unsigned, hipStream_t st) {
+  sweep_launch_r02p7_raw(a->bits, a->bits_out, a->slot0, a->slot1, a->logpi, a->delta, a->cslots, a->hm.prior, a->hm.data, a->eps, a->gamma0,
+                         a->gsig, a->n_alive, a->sweep, st);
+}
+#endif
 #define V(name, what) extern "C" int sweep_occ_##name(); extern "C" void sweep_launch_##name(const SmcPackedArgs*, unsigned, hipStream_t);
 #include "variants.inc"
 #undef V
 #define V(name, what) {#name, what, sweep_occ_##name, sweep_launch_##name},
 static const Variant variants[] = {
 #include "variants.inc"
+#ifdef WITH_R02
+    {"r02", "round 2's kernel: Box-Muller + Philox-10, one tile per workgroup, 5 waves (git worktree _r02)", sweep_occ_r02, sweep_launch_r02},
+#endif
+#ifdef WITH_R02P7
+    {"r02p7", "round 2's kernel with Philox4x32-7", sweep_occ_r02p7, sweep_launch_r02p7},
+#endif
 };
 #undef V
 
@@ -101,7 +125,8 @@ int main(int argc, char** argv) {
   const unsigned ntiles = (n_alive + 127) / 128;     // positions per workgroup and loop trip (L = 4: SweepTile<4>::PB)
   auto grid_of = [&](const Variant& v) {
     const int occ = v.occ();
-    const uint64_t res = (uint64_t)ncu * (uint64_t)(occ > 0 ? occ : 1);
+    const int mul = getenv("GRIDMUL") ? atoi(getenv("GRIDMUL")) : 1;       // > 1: more workgroups than are resident, the hardware deals them out as slots free up
+    const uint64_t res = (uint64_t)ncu * (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(mul > 0 ? mul : 1);
     if (ntiles <= res) return (unsigned)ntiles;
     const uint64_t per = (ntiles + res - 1) / res;
     return (unsigned)((ntiles + per - 1) / per);
