@@ -9,7 +9,6 @@
 #include "../../include/abcdez_hip.h"
 #include <chrono>
 #include "abz_ctx.h"
-#include "../../include/abcdez_tables_data.h"
 
 int abz_tree_sum_impl(abcdez_ctx*, const double*, int64_t, int, double*);
 int abz_reweight_impl(abcdez_ctx*, const double*, double*, uint8_t*, int64_t, double, double, double*, double*, int64_t*);
@@ -165,24 +164,14 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->h_model.mv = ctx->d_mv;
   ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_model, sizeof(abz_model)));
   ABZ_CTX_CHECK(hipMemcpy(ctx->d_model, &ctx->h_model, sizeof(abz_model), hipMemcpyHostToDevice));
-  {   /* sampler tables: the whole inverse-normal-CDF table, and the struct the kernels stage into LDS (log table, the
-         first ABZ_ICDF_HOT_BINADES binades of every piece, the pointer to the whole table) */
-    ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_icdf_all, sizeof(abz_icdf_all_data)));
-    ABZ_CTX_CHECK(hipMemcpy(ctx->d_icdf_all, abz_icdf_all_data, sizeof(abz_icdf_all_data), hipMemcpyHostToDevice));
-    abz_tables* ht = new abz_tables(abz_tables_host);
-    for (int q = 0; q < ABZ_ICDF_PIECES; ++q)
-      for (int r = 0; r < ABZ_ICDF_HOT_ROWS; ++r) ht->icdf_hot[q][r] = abz_icdf_all_data[q][r];
-    ht->icdf_all = ctx->d_icdf_all;
-    hipError_t e1 = hipMalloc((void**)&ctx->d_tables, sizeof(abz_tables));
-    if (e1 == hipSuccess) e1 = hipMemcpy(ctx->d_tables, ht, sizeof(abz_tables), hipMemcpyHostToDevice);
-    delete ht;
-    ABZ_CTX_CHECK(e1);
+  ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_tables, sizeof(abz_tables)));
+  ABZ_CTX_CHECK(hipMemcpy(ctx->d_tables, &abz_tables_host, sizeof(abz_tables), hipMemcpyHostToDevice));
+  {
     int ncu = 0;
     ABZ_CTX_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
     ctx->n_cu = ncu > 0 ? ncu : 1;
   }
   ctx->hot.tables = ctx->d_tables;
-  ctx->hot.icdf_all = ctx->d_icdf_all;
   ctx->hot.mv = ctx->d_mv;
   ctx->hot.seed = model->seed;
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
@@ -232,7 +221,6 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (ctx->d_data) (void)hipFree(ctx->d_data);
   if (ctx->d_mv) (void)hipFree(ctx->d_mv);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-  if (ctx->d_icdf_all) (void)hipFree(ctx->d_icdf_all);
   delete ctx;
   return 0;
 }

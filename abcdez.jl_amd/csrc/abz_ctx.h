@@ -34,8 +34,7 @@ struct abcdez_ctx {
   abz_model* d_model = nullptr;
   double* d_data = nullptr;
   double* d_mv = nullptr;             /* maps of a correlated Normal prior (abz_model.mv), else null */
-  abz_tables* d_tables = nullptr;     /* log table + hot part of the inverse normal CDF + pointer to ... */
-  abz_f64x2* d_icdf_all = nullptr;    /* ... the whole inverse-CDF table [ABZ_ICDF_PIECES][ABZ_ICDF_ROWS] */
+  abz_tables* d_tables = nullptr;
   int n_cu = 1;                       /* compute units of the device */
   std::unordered_map<const void*, int> occ;   /* kernel -> resident workgroups per CU (abz_persistent_grid) */
   int L = 1, C = 1;               /* lane-group shape: ld = L*C                 */
@@ -104,7 +103,10 @@ void abz_set_error(const std::string& msg);
 
 /* Grid of a kernel whose workgroups loop over tiles (ABZ_TILE_LOOP): as many workgroups as the device holds at once --
  * compute units x the occupancy the runtime reports for this kernel -- each with the same number of tiles (+-1), so the
- * sampler tables are staged into LDS once per resident workgroup and no second round of workgroups trails the first. */
+ * model tables are staged into LDS once per resident workgroup.  Used by the kernels that are not memory-bound on long rows
+ * (initial population, abcdemc sweep, blobs); the SMC sweep keeps one tile per workgroup: the hardware's dynamic dispatch of
+ * many small workgroups keeps every CU busy to the end of the launch, which a static deal of ~18 tiles per wavefront does not
+ * (profiles/r03_bench_ab_round2_vs_icdf_persistent.json). */
 static inline unsigned abz_tiles_to_grid(uint64_t ntiles, uint64_t resident) {
   if (resident < 1) resident = 1;
   if (ntiles <= resident) return (unsigned)(ntiles ? ntiles : 1);
@@ -214,6 +216,6 @@ int abz_jit_launch_blob(abcdez_ctx*, const double* theta, const uint64_t* stamp,
 int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp, int64_t n, double* blob,
                          double* delta_out, uint32_t nbw);
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned ntiles);
-int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned ntiles);
+int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
 
 #endif

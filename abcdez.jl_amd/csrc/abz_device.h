@@ -56,55 +56,75 @@ __device__ inline void store_row(double* __restrict__ row, int j, const double (
   }
 }
 
-/* The read-mostly model tables (sampler tables, prior descriptors, data vector) are staged in LDS ONCE PER WORKGROUP: every
- * group of a block reads the same ld descriptor entries (broadcast LDS reads instead of ~10 dependent global loads per
- * component), and the sampler's tables -- the log table and the hot part of the inverse-normal-CDF table, 28 KB -- are
- * looked up by random row.  A workgroup therefore works through MANY tiles of ABZ_BLOCK threads (ABZ_TILE_LOOP below; the
- * launchers size the grid to what is resident at once, abz_persistent_grid): staging costs 30 KB per ~36 tiles instead of
- * 10 KB per tile as in round 2. */
+/* The read-mostly model tables (prior descriptors, data vector) are staged in LDS once per
+ * workgroup: every group of a block reads the same ld entries, so this turns ~10 dependent
+ * global loads per component into broadcast LDS reads and keeps them out of the VGPR budget. */
 template <int LD>
 struct ModelLds {
-  abz_tables tab;              /* log table + first ABZ_ICDF_HOT_BINADES binades of the inverse normal CDF + pointer to all of it */
+  abz_tables tab;              /* log / sincos tables of the sampler (8 KB) */
   abz_prior_dim prior[LD];
   double y[LD];
 };
 
-__device__ inline void stage_tables(abz_tables& dst, const abz_tables* __restrict__ src) {
-  static_assert(sizeof(abz_tables) % 16 == 0, "table struct is copied in 16-byte pieces");
-  constexpr int NP = (int)(sizeof(abz_tables) / 16);
-  const double2* __restrict__ s = reinterpret_cast<const double2*>(src);
-  double2* d = reinterpret_cast<double2*>(&dst);
-  for (int q = threadIdx.x; q < NP; q += ABZ_BLOCK) d[q] = s[q];
-}
-
-/* SIM < 0: no simulator data (kernels that draw and evaluate the prior only).  The caller synchronises. */
+/* two phases so the global loads can be issued early (before the wave's dependent loads)
+ * and the LDS writes + barrier placed right before the first use */
 template <int SIM, int LD>
-__device__ inline void stage_model(ModelLds<LD>& s, const HotModel& M) {
-  stage_tables(s.tab, M.tables);
-  constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
-  const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
-  uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
-  for (int t = threadIdx.x; t < W; t += ABZ_BLOCK) dst[t] = src[t];
-  if ((int)threadIdx.x < LD) {
-    double y = 0.0;
-    if constexpr (SIM == ABZ_SIM_MVN) {
-      if ((int)threadIdx.x < M.d) y = M.data[threadIdx.x];
+struct ModelStage {
+  static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
+  static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
+  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);   /* 16-byte pieces per thread */
+  static_assert(sizeof(abz_tables) % (16 * ABZ_BLOCK) == 0, "table size must tile the block");
+  uint64_t w[NW];
+  double2 tb[NT];
+  double y;
+  __device__ inline void load(const HotModel& M) {
+    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      w[q] = t < W ? src[t] : 0ull;
     }
-    s.y[threadIdx.x] = y;
+    y = 0.0;
+    if constexpr (SIM == ABZ_SIM_MVN) {
+      if ((int)threadIdx.x < LD && (int)threadIdx.x < M.d) y = M.data[threadIdx.x];
+    }
   }
-}
+  __device__ inline void store(ModelLds<LD>& s) const {
+    double2* tdst = reinterpret_cast<double2*>(&s.tab);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+    uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (t < W) dst[t] = w[q];
+    }
+    if ((int)threadIdx.x < LD) s.y[threadIdx.x] = y;
+  }
+};
 
-/* tiles of ABZ_BLOCK threads dealt round-robin to the resident workgroups: at any moment the grid streams one contiguous
- * window of the population, as a plain launch would */
+/* the sampler tables alone (kernels that draw but neither evaluate the prior nor simulate) */
+struct TabStage {
+  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);
+  double2 tb[NT];
+  __device__ inline void load(const HotModel& M) {
+    const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+  }
+  __device__ inline void store(abz_tables& s) const {
+    double2* tdst = reinterpret_cast<double2*>(&s);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+  }
+};
+
+/* kernels whose workgroups loop over tiles of ABZ_BLOCK threads (init, abcdemc sweep, blobs): tiles dealt round-robin to the
+ * workgroups the launcher sized to what is resident at once (abz_persistent_grid), tables staged once per workgroup */
 #define ABZ_TILE_LOOP(tile, ntiles) for (uint32_t tile = blockIdx.x; tile < (ntiles); tile += gridDim.x)
-/* The lane's index inside its group, made opaque once per tile: everything derived from it (Philox partial products of the
- * lane's sub-counters, LDS addresses of its prior descriptors) is then computed where it is used instead of being hoisted
- * out of the tile loop into registers that live across the whole body -- the hoisting cost the d = 32 sweep 70 VGPRs and
- * with them three of its five waves per SIMD. */
-__device__ inline int tile_lane(int j) {
-  asm volatile("" : "+v"(j));
-  return j;
-}
 
 /* ---- abz_kernel_logpdf (abcdez_spec.h, types.jl:26-73) as the sweep evaluates it: the indicator kernels (the default, every
  * BASELINE configuration) are two compares; the Epanechnikov kernels' log(1 - (x/eps)^2) is kept OUT OF LINE so that its
@@ -117,45 +137,6 @@ __device__ inline double kernel_logpdf_dev(int kind, double eps, double x) {
   if (!abz_kernel_insupport(kind, eps, x)) return ABZ_NINF;
   if (kind < ABZ_K_EPA) return 0.0;
   return kernel_logpdf_epa(eps, x);
-}
-
-/* ---- abz_normal_icdf (abcdez_spec.h) as the kernels evaluate it: every lane runs the LDS path on a clamped row -- straight-line
- * code, no branch around the table reads -- and the lanes whose binade is deeper than the LDS copy (2^-12 of the draws)
- * redo the polynomial with their row of the global table.  Same table, same operations, same bits. */
-/* abz_icdf_index for the binades the LDS copy holds, on 32-bit words: the leading zeros of the 63-bit field are those of the
- * high word's low 31 bits whenever that word is >= 2^15 (binade <= 15), and the 64-bit shifts of the definition become one
- * v_alignbit each -- 13 integer instructions instead of 19, same (row, tau).  Returns false (row, tau untouched) for a
- * deeper binade: the caller then runs the 64-bit definition.  ABZ_ICDF_HOT_BINADES <= 16 is what makes the test exact. */
-__device__ inline bool icdf_index_hot(uint32_t h, uint32_t l, uint32_t* row, double* tau) {
-  static_assert(ABZ_ICDF_HOT_BINADES <= 16 && ABZ_ICDF_SUB_BITS == 5, "hot-path index math assumes 32 sub-intervals, binades 0..15");
-  const uint32_t f = (uint32_t)__builtin_clz((h & 0x7FFFFFFFu) | 1u);       /* = binade + 1 (1 .. 16 on the hot path; 31 or 32 else) */
-  const uint32_t s = 31u - f;                                               /* field << (binade + 1), read off (h : l) >> s */
-  const uint32_t ah = __builtin_amdgcn_alignbit(h, l, s);                   /* high word of the bits behind the leading one */
-  const uint32_t al = l << ((f + 1u) & 31u);                                /* low word */
-  *row = (f << ABZ_ICDF_SUB_BITS) + (ah >> 27) - (uint32_t)ABZ_ICDF_SUB;
-  const uint32_t mh = ((ah >> 7) & 0x000FFFFFu) | 0x3FF00000u;              /* ((A << 5) >> 12) | bits(1.0), high word */
-  const uint32_t ml = __builtin_amdgcn_alignbit(ah, al, 7u);
-  *tau = abz_u2d(((uint64_t)mh << 32) | ml) - 1.5;
-  return f <= (uint32_t)ABZ_ICDF_HOT_BINADES;
-}
-
-__device__ inline double normal_icdf_dev(uint64_t w, const abz_tables* T /* LDS */, const abz_f64x2* __restrict__ all /* global */) {
-  uint32_t row;
-  double tau;
-#ifdef ABZ_ICDF_GENERIC_INDEX      /* tools/sweep_variants.hip: the 64-bit definition on every lane (what round 3 first shipped) */
-  abz_icdf_index(w, &row, &tau);
-  const bool hot = row < (uint32_t)ABZ_ICDF_HOT_ROWS;
-#else
-  const bool hot = icdf_index_hot((uint32_t)(w >> 32), (uint32_t)w, &row, &tau);
-#endif
-  const uint32_t rh = row < (uint32_t)ABZ_ICDF_HOT_ROWS ? row : (uint32_t)(ABZ_ICDF_HOT_ROWS - 1);
-  double z = abz_icdf_poly(tau, T->icdf_hot[0][rh], T->icdf_hot[1][rh], T->icdf_hot[2][rh], T->icdf_hot[3][rh], w);
-  if (__builtin_expect(!hot, 0)) {
-    abz_icdf_index(w, &row, &tau);
-    const abz_f64x2* __restrict__ c = all + row;
-    z = abz_icdf_poly(tau, c[0], c[ABZ_ICDF_ROWS], c[2 * ABZ_ICDF_ROWS], c[3 * ABZ_ICDF_ROWS], w);
-  }
-  return z;
 }
 
 /* ---- canonical per-particle tree sum ------------------------------------------- */
@@ -185,29 +166,28 @@ __device__ inline double group_tree_sum(const double (&x)[C]) {
 
 /* ---- correlated Normal prior (abcdez_spec.h, abz_model.mv): out_k = sum_{m <= k} mat[k][m] in_m for the lane's components k,
  * accumulated left to right with fma exactly as abz_mv_whiten1 / abz_mv_forward1 do.  The group's vector is spread over its
- * L lanes, so component m is fetched from its owner by one shuffle; the loops run over m in ascending order with compile-time
- * (owner lane, register) -- no dynamic register indexing.  Only the kernels of non-plain priors contain this code. */
+ * L lanes: it is exchanged through a per-group LDS row (a group sits inside one wavefront, whose LDS operations execute in
+ * order, so no barrier is needed) and the sum runs as a plain loop over m -- small code, few registers; only the kernels of
+ * non-plain priors contain it. */
 template <int L, int C>
 __device__ inline void group_lower_matvec(const double* __restrict__ mat, int j, const double (&in)[C], double (&out)[C]) {
   constexpr int LD = L * C;
+  __shared__ double s_vec[ABZ_BLOCK / L][LD];
+  double* row = s_vec[threadIdx.x / L];
 #pragma unroll
-  for (int q = 0; q < C; ++q) out[q] = 0.0;
-  constexpr int MM = C == 1 ? 1 : C / 2;
+  for (int q = 0; q < C; ++q) { row[Lay<L, C>::comp(j, q / 2, q & 1)] = in[q]; out[q] = 0.0; }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int m = 0; m < LD; ++m) {
+    const double xm = row[m];
 #pragma unroll
-  for (int mm = 0; mm < MM; ++mm)
-#pragma unroll
-    for (int sj = 0; sj < L; ++sj)
-#pragma unroll
-      for (int c = 0; c < (C == 1 ? 1 : 2); ++c) {
-        const int m = Lay<L, C>::comp(sj, mm, c);                         /* ascending over the three loops */
-        const double xm = L == 1 ? in[2 * mm + c] : __shfl(in[2 * mm + c], sj, L);
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-          const int k = Lay<L, C>::comp(j, q / 2, q & 1);
-          const double t = abz_fma(mat[(size_t)k * LD + m], xm, out[q]);
-          out[q] = m <= k ? t : out[q];
-        }
-      }
+    for (int q = 0; q < C; ++q) {
+      const int k = Lay<L, C>::comp(j, q / 2, q & 1);
+      const double t = abz_fma(mat[(size_t)k * LD + m], xm, out[q]);
+      out[q] = m <= k ? t : out[q];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 /* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */
@@ -288,46 +268,35 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
   } else if constexpr (SIM == ABZ_SIM_MVN) {
     const double sg = M.sim_p[0];
     const int d = M.d;
+    double sq[C];
     if constexpr (C == 1) {
-      const double z0 = normal_icdf_dev(abz_rng(seed, i, epoch, 0, purpose).w0, T, M.icdf_all);
+      double z0, z1;
+      abz_normal_pair(abz_rng(seed, i, epoch, 0, purpose), T, &z0, &z1);
       const double x = abz_fma(sg, z0, th[0]);
       if constexpr (BLOB) blob[0] = x;
       const double e = x - y[0];
-      return abz_sqrt(e * e);
+      sq[0] = e * e;
     } else {
-      /* the canonical tree (abcdez_spec.h) evaluated as the squares become available: level 0 inside the lane, butterfly over the
-       * L lanes, binary tree over m -- the operations of group_tree_sum<L, C> in the same association, but with two
-       * partial sums alive instead of C squares, and (wide rows) one normal's eight coefficients in registers at a time */
-      constexpr int MM = C / 2;
-      double s[MM];
 #pragma unroll
-      for (int m = 0; m < MM; ++m) {
-        const abz_u64x2 w = abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose);
-        double v[2];
+      for (int m = 0; m < C / 2; ++m) {
+        double z[2];
+        abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)(m * L + j), purpose), T, &z[0], &z[1]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const double z = normal_icdf_dev(c ? w.w1 : w.w0, T, M.icdf_all);
           const int k = Lay<L, C>::comp(j, m, c);
-          v[c] = 0.0;
+          double v = 0.0;
           if constexpr (BLOB) blob[2 * m + c] = 0.0;
           if (FULL || k < d) {
-            const double x = abz_fma(sg, z, th[2 * m + c]);
+            const double x = abz_fma(sg, z[c], th[2 * m + c]);
             if constexpr (BLOB) blob[2 * m + c] = x;
             const double e = x - y[k];
-            v[c] = e * e;
+            v = e * e;
           }
-          if constexpr (C >= 8) __builtin_amdgcn_sched_barrier(0);
+          sq[2 * m + c] = v;
         }
-        double t = v[0] + v[1];                          /* level 0: (2t, 2t+1)            */
-#pragma unroll
-        for (int off = 1; off < L; off <<= 1) t = t + shfl_xor_f64(t, off);   /* over lanes */
-        s[m] = t;
-#pragma unroll
-        for (int st = 1; st < MM; st <<= 1)              /* over m: node (m - 2 st + 1 .. m) closes when its right child does */
-          if ((m & (2 * st - 1)) == 2 * st - 1) s[m - 2 * st + 1] = s[m - 2 * st + 1] + s[m - st + 1];
       }
-      return abz_sqrt(s[0]);
     }
+    return abz_sqrt(group_tree_sum<L, C>(sq));
   } else if constexpr (SIM == ABZ_SIM_DIRAC) {
     const double x = th[0] * th[0] + 1.0;
     if constexpr (BLOB) blob[0] = x;
@@ -440,8 +409,9 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
 /* ---- per-particle scalar draws of one sweep: donor ranks, gamma jitter, log(accept uniform).
  * With L >= 4 lanes per particle the three Philox blocks are evaluated by lanes 0, 1, 2 of
  * the group in ONE pass of the instruction stream (the purpose tag is the only difference),
- * and the results are broadcast inside the group.  Same values as the straightforward evaluation. */
-/* In two steps, so that a kernel can issue the donors' loads before it needs the sampler tables: words() is pure
+ * the Box-Muller radius of the jitter and the accept test share one log evaluation, and the
+ * results are broadcast inside the group.  Same values as the straightforward evaluation. */
+/* In two steps, so that a kernel can issue the donors' loads before the sampler tables are staged: words() is pure
  * integer work (Philox + the donor ranks), finish() the table-driven part (jitter normal, log of the accept uniform). */
 template <int L>
 struct ParticleDraws {
@@ -461,16 +431,19 @@ struct ParticleDraws {
       wa = abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT);
     }
   }
-  __device__ inline void finish(const abz_tables* T, const abz_f64x2* __restrict__ all, double gamma0, double gsig, double* g,
-                                double* log_u) const {
+  __device__ inline void finish(const abz_tables* T, double gamma0, double gsig, double* g, double* log_u) const {
     if constexpr (L >= 4) {
-      const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* meaningful on lane 2: the accept uniform (smc:145) */
-      const double z0 = normal_icdf_dev(w.w0, T, all);          /* meaningful on lane 1: randn of smc:128 */
+      const double lg = abz_log_tab(abz_u01_open(w.w0), T);     /* lane 1: BM radius, lane 2: accept */
+      double sn, cs;
+      abz_sincos2pi_tab_w(w.w1, T, &sn, &cs);
+      const double z0 = abz_sqrt_pn(-2.0 * lg) * cs;            /* meaningful on lane 1 */
       const double g_ = gamma0 * (1.0 + z0 * gsig);
       *g = __shfl(g_, 1, L);
       *log_u = __shfl(lg, 2, L);
     } else {
-      *g = gamma0 * (1.0 + normal_icdf_dev(w.w0, T, all) * gsig);
+      double z0, z1;
+      abz_normal_pair(w, T, &z0, &z1);
+      *g = gamma0 * (1.0 + z0 * gsig);
       /* the SAME function as the L >= 4 branch and the oracle (abz_log_tab): the accept variate must not
        * depend on the lane shape -- the polynomial abz_log differs from it in ~19 % of arguments by an ulp */
       *log_u = abz_log_tab(abz_u01_open(wa.w0), T);
@@ -478,13 +451,13 @@ struct ParticleDraws {
   }
 };
 template <int L>
-__device__ inline void particle_draws(const abz_tables* T, const abz_f64x2* __restrict__ all, uint64_t seed, uint32_t i,
-                                      uint32_t sweep, int j, uint32_t n_pool, uint32_t ri,
+__device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32_t i, uint32_t sweep, int j,
+                                      uint32_t n_pool, uint32_t ri,
                                       double gamma0, double gsig, uint32_t* ra, uint32_t* rb, double* g,
                                       double* log_u) {
   ParticleDraws<L> d;
   d.words(seed, i, sweep, j, n_pool, ri, ra, rb);
-  d.finish(T, all, gamma0, gsig, g, log_u);
+  d.finish(T, gamma0, gsig, g, log_u);
 }
 
 /* ---- block-level integer counters: every thread counts over its tiles in two registers; at the end of the block a wave

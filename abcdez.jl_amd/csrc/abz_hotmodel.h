@@ -12,8 +12,7 @@ struct HotModel {
   uint64_t seed;
   const abz_prior_dim* prior;   /* device, ld entries */
   const double* data;           /* device, n_data values */
-  const abz_tables* tables;     /* device copy of the sampler tables (what a workgroup stages into LDS) */
-  const abz_f64x2* icdf_all;    /* the whole inverse-normal-CDF table, global memory (== tables->icdf_all) */
+  const abz_tables* tables;     /* device copy of the sampler tables */
   const double* mv;             /* NULL, or [mu | W | L] of a correlated Normal prior (abcdez_spec.h), device memory */
   double sim_p[8];
   int32_t d, abck, n_data, n_blob;

@@ -134,9 +134,9 @@ int abz_jit_launch_mc(abcdez_ctx* ctx, const void* args, unsigned ntiles) {
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_mc, jit_grid(ctx, um->f_mc, ntiles), 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }
-int abz_jit_launch_smc_packed(abcdez_ctx* ctx, const void* args, unsigned ntiles) {
+int abz_jit_launch_smc_packed(abcdez_ctx* ctx, const void* args, unsigned nblocks) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   void* params[] = {const_cast<void*>(args)};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smcp, jit_grid(ctx, um->f_smcp, ntiles), 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smcp, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }

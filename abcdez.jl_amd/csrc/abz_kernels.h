@@ -23,7 +23,11 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
   constexpr int LD = L * C;
   constexpr uint32_t PB = ABZ_BLOCK / L;
   __shared__ ModelLds<LD> s_model;
-  stage_model<SIM, LD>(s_model, M);
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
   __syncthreads();
   const abz_prior_dim* pd = s_model.prior;
   const int j = (int)(threadIdx.x % L);
@@ -111,171 +115,98 @@ struct SmcPackedArgs {
 
 __device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
 
-/* Work units.  A wavefront is on its own from the staging barrier to the counter epilogue: it loops over WAVE-TILES of PW
- * positions -- whole words of the slot bitmap -- in R rounds of PR = 64 / L positions, assembles the word(s) of its tile from
- * wave ballots and writes them itself.  No barrier, no LDS atomics inside the loop: the four wavefronts of a workgroup sit on four
- * different SIMDs and a barrier per tile made every one of them wait for the slowest. */
-template <int L>
-struct SweepTile {
-  static constexpr uint32_t PR = 64 / L;                       /* positions per round */
-  static constexpr uint32_t R = PR >= 32 ? 1 : 32 / PR;        /* rounds per tile */
-  static constexpr uint32_t PW = PR * R;                       /* positions per wave-tile: 64 (L = 1) or 32 */
-  static constexpr uint32_t PB = PW * (ABZ_BLOCK / 64);        /* positions per workgroup and loop trip */
-};
-
-/* compile-time knobs of the sweep (tools/sweep_variants.hip times the alternatives against each other on one GPU) */
-#ifndef ABZ_SWEEP_PREFETCH
-#define ABZ_SWEEP_PREFETCH 1      /* fetch the NEXT round's slot bits (and make its Philox words) behind this round's simulator */
-#endif
-#ifndef ABZ_SWEEP_SCHED
-#define ABZ_SWEEP_SCHED 1         /* wide rows: pin the table-driven draws in front of the row loads (register pressure) */
-#endif
-
-/* what a round needs before it can request its rows: position, donors, their slot-bit words, the table-driven draws */
-template <int L>
-struct SweepRound {
-  uint32_t ri, ra, rb, wi, wa, wb;
-  bool active;
-  ParticleDraws<L> draws;
-  double g, log_u;
-};
-
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
-  using ST = SweepTile<L>;
-  static_assert(L <= 8, "packed sweeps: at most 8 lanes per particle");
+  constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
+  static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
+  const HotModel& M = a.hm;
+  if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
+  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+
+  __shared__ ModelLds<LD> s_model;
+  __shared__ uint32_t s_acc[PB / 32];
+
+  /* Order of issue = order of need.  Nothing below waits for the model tables before the rows are on their way:
+   *   slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot bits   (one L2 round trip)
+   *   the three rows, log-prior, distance                                                                (one HBM round trip)
+   *   meanwhile: tables staged in LDS, gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145)              */
   /* Rows of at most two doubles are DOUBLE-BUFFERED (ABZ_ROWS_DOUBLE_BUFFERED): a sweep writes every swept position's row
    * to its other slot (the proposal, or a copy of the row) and flips every swept bit, so the alive prefix always shares ONE
    * slot parity and the donors need no bit look-up -- at 8 or 16 bytes per row the two random 4-byte look-ups cost as
    * much as the donor rows themselves (the d = 1 sweep is bound by the gather rate of the CU's address unit), and copying a
    * rejected row is a coalesced 8 bytes. */
   constexpr bool DBUF = ABZ_ROWS_DOUBLE_BUFFERED(LD);
-  constexpr bool PREF = ABZ_SWEEP_PREFETCH != 0;
-  const HotModel& M = a.hm;
-  if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
+  ModelStage<SIM, LD> stage;
+  stage.load(M);
+  const uint32_t wi = a.bits[ri >> 5];
+  ParticleDraws<L> draws;
+  uint32_t ra, rb;
+  draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
+  uint32_t wa = 0u, wb = 0u;
+  if constexpr (!DBUF) { wa = a.bits[ra >> 5]; wb = a.bits[rb >> 5]; }
+  const double lpi = a.logpi[ri];
+  const double dli = a.delta[ri];
+  if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
+  const uint32_t bi = (wi >> (ri & 31u)) & 1u;
+  const uint32_t ba = DBUF ? bi : (wa >> (ra & 31u)) & 1u, bb = DBUF ? bi : (wb >> (rb & 31u)) & 1u;
+  double ti[C], ta[C], tb[C];
+  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+  load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+  load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged */
+  double g, log_u;
+  draws.finish(&s_model.tab, a.gamma0, a.gsig, &g, &log_u);
 
-  __shared__ ModelLds<LD> s_model;
-  stage_model<SIM, LD>(s_model, M);
-  __syncthreads();                                  /* sampler + model tables staged: once per workgroup */
-
-  const uint32_t lane = threadIdx.x & 63u;
-  const int j0 = (int)(lane % L);
-  const uint32_t nwt = (a.n_work + ST::PW - 1) / ST::PW;
-  const uint32_t stride = gridDim.x * (ABZ_BLOCK / 64);
-  unsigned int n_acc = 0u, n_sim = 0u;              /* this wavefront's counts over its tiles (smc:138,150): wave-uniform */
-
-  /* slot bit of the own position | Philox words -> donor positions (smc:119-126) -> their slot-bit words: issued ... */
-  auto request = [&](SweepRound<L>& q, uint32_t wt, uint32_t r, int j) {
-    const uint32_t grp = wt * ST::PW + r * ST::PR + lane / L;
-    q.active = grp < a.n_work;
-    q.ri = a.r_lo + (q.active ? grp : 0u);
-    q.wi = a.bits[q.ri >> 5];
-    q.draws.words(M.seed, q.ri, a.sweep, j, a.n_alive, q.ri, &q.ra, &q.rb);
-    q.wa = 0u; q.wb = 0u;
-    if constexpr (!DBUF) { q.wa = a.bits[q.ra >> 5]; q.wb = a.bits[q.rb >> 5]; }
-  };
-  /* ... and the table-driven draws: gamma = gamma0 (1 + randn gamma_sigma) (smc:128), log(rand) (smc:145) */
-  auto draw = [&](SweepRound<L>& q) { q.draws.finish(&s_model.tab, M.icdf_all, a.gamma0, a.gsig, &q.g, &q.log_u); };
-
-  uint32_t wt = blockIdx.x * (ABZ_BLOCK / 64) + (threadIdx.x >> 6), r = 0u;
-  bool have = wt < nwt;
-  SweepRound<L> nx;
-  if (PREF && have) { request(nx, wt, 0u, tile_lane(j0)); draw(nx); }
-  unsigned long long accw = 0ull;                   /* flipped slot bits of the current tile (wave-uniform) */
-  while (have) {
-    const int j = tile_lane(j0);
-    /* Order of issue = order of need.  With ABZ_SWEEP_PREFETCH a round finds its slot-bit words and draws made by the round
-     * before (behind that round's simulator), so a wavefront waits on ONE memory round trip per round -- the rows -- instead
-     * of two (L2: bits, then HBM: rows); without it the words are requested here and the draws run in their shadow. */
-    SweepRound<L> q;
-    if constexpr (PREF) q = nx;
-    else {
-      request(q, wt, r, j);
-      draw(q);
-      if constexpr (C >= 8 && ABZ_SWEEP_SCHED) __builtin_amdgcn_sched_barrier(0);   /* wide rows: the draws' table entries and the
-                                                                                     rows' 48 registers never alive together */
-    }
-    const bool active = q.active;
-    const uint32_t ri = q.ri, ra = q.ra, rb = q.rb;
-    const double lpi = a.logpi[ri];
-    const double dli = a.delta[ri];
-    const uint32_t bi = (q.wi >> (ri & 31u)) & 1u;
-    const uint32_t ba = DBUF ? bi : (q.wa >> (ra & 31u)) & 1u, bb = DBUF ? bi : (q.wb >> (rb & 31u)) & 1u;
-    double ti[C], ta[C], tb[C];
-    load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
-    load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
-    load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
-    const double g = q.g, log_u = q.log_u;
-
-    double tp[C], pp[C];
+  double tp[C], pp[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) tp[c] = ti[c] + (ta[c] - tb[c]) * g;
+  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-    /* the round after this one */
-    uint32_t r2 = r + 1u, wt2 = wt;
-    if (r2 == ST::R) { r2 = 0u; wt2 = wt + stride; }
-    const bool have2 = wt2 < nwt;
-    if constexpr (PREF) {
-      if constexpr (C >= 8 && ABZ_SWEEP_SCHED) __builtin_amdgcn_sched_barrier(0);   /* behind the rows' use, in front of the simulator */
-      if (have2) request(nx, wt2, r2, j);
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
+  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+  bool acc = false;
+  double dp = dli;
+  /* Narrow rows with a Normal prior (in support for every finite proposal): the simulator is not put behind a branch --
+   * its random numbers do not depend on the proposal and can be produced while the rows are in flight, which shortens
+   * the dependent chain these latency-bound kernels run on; the result is used only when the proposal is in support,
+   * as in the branch.  Wide rows keep the branch: hoisting costs the d = 32 kernel its fifth wave (88 -> 99 VGPRs). */
+  constexpr bool UNBRANCH = PLAIN && LD <= 4;
+  if (UNBRANCH || insupport) {
+    const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+    const double w = ((lp - lpi) + kernel_logpdf_dev(M.abck, a.eps, ds)) - kernel_logpdf_dev(M.abck, a.eps, dli);  /* smc:140-141, left to right as the reference */
+    if (insupport) {
+      dp = ds;
+      acc = (0.0 <= w) || (log_u < w);                            /* smc:145 */
     }
-
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
-    const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
-    bool acc = false;
-    double dp = dli;
-    /* Narrow rows with a Normal prior (in support for every finite proposal): the simulator is not put behind a branch --
-     * its random numbers do not depend on the proposal and can be produced while the rows are in flight, which shortens
-     * the dependent chain these latency-bound kernels run on; the result is used only when the proposal is in support,
-     * as in the branch.  Wide rows keep the branch. */
-    constexpr bool UNBRANCH = PLAIN && LD <= 4;
-    if (UNBRANCH || insupport) {
-      const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pp, s_model.y, ri, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
-      const double w = ((lp - lpi) + kernel_logpdf_dev(M.abck, a.eps, ds)) - kernel_logpdf_dev(M.abck, a.eps, dli);  /* smc:140-141, left to right as the reference */
-      if (insupport) {
-        dp = ds;
-        acc = (0.0 <= w) || (log_u < w);                            /* smc:145 */
-      }
-    }
-    acc = acc && active;
-    if constexpr (DBUF) {
-      if (active) {
-        double to[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) to[c] = acc ? tp[c] : ti[c];
-        store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, to);
-      }
-    } else if (acc) {                                               /* smc:146-150 */
-      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
-    }
-    if (acc && j == 0) {
-      a.logpi[ri] = lp; a.delta[ri] = dp;
-      if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
-    }
-    if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
-    n_acc += (unsigned int)__popcll(__ballot(j == 0 && acc));
-    n_sim += (unsigned int)__popcll(__ballot(active && j == 0 && insupport));
-    /* the round's flipped bits, one per position: lane g takes the flag of lane g L (the leader of group g) */
-    const int flip = DBUF ? (active ? 1 : 0) : (acc ? 1 : 0);
-    unsigned long long m;
-    if constexpr (L == 1) m = __ballot(flip != 0);
-    else m = __ballot(__shfl(flip, (int)((lane * L) & 63u), 64) != 0 && lane < ST::PR);
-    accw |= m << (r * ST::PR);
-    if (r == ST::R - 1u) {                              /* the tile's word(s) of the bitmap: this wavefront owns them */
-      if (lane == 0u) {
-        const uint32_t w0 = (a.r_lo + wt * ST::PW) >> 5;
-        if (w0 * 32u < a.r_lo + a.n_work) a.bits_out[w0] = a.bits[w0] ^ (uint32_t)accw;
-        if (ST::PW == 64u && (w0 + 1u) * 32u < a.r_lo + a.n_work) a.bits_out[w0 + 1u] = a.bits[w0 + 1u] ^ (uint32_t)(accw >> 32);
-      }
-      accw = 0ull;
-    }
-    if constexpr (PREF) {
-      if (have2) draw(nx);
-    }
-    wt = wt2; r = r2; have = have2;
   }
-  block_count2(lane == 0u ? n_acc : 0u, lane == 0u ? n_sim : 0u, a.cslots, a.c_cls);
+  acc = acc && active;
+  if constexpr (DBUF) {
+    if (active) {
+      double to[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) to[q] = acc ? tp[q] : ti[q];
+      store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, to);
+      if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+    }
+  } else if (acc) {                                               /* smc:146-150 */
+    store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
+    if (j == 0) atomicOr(&s_acc[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
+  }
+  if (acc && j == 0) {
+    a.logpi[ri] = lp; a.delta[ri] = dp;
+    if (a.stamp) a.stamp[ri] = abz_stamp(ri, a.sweep, 0);
+  }
+  if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
+  block_count2((j == 0 && acc) ? 1u : 0u, (active && j == 0 && insupport) ? 1u : 0u, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
+  if (threadIdx.x < PB / 32) {
+    const uint32_t w = (a.r_lo + blockIdx.x * PB) / 32u + threadIdx.x;
+    if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
+  }
 }
 
 /* replay of a packed sweep on a replica (multi-GPU): every rank keeps the whole population, rank r sweeps a range of
@@ -307,7 +238,8 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
   __shared__ unsigned int s_n;
   __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
 
-  stage_model<-1, LD>(s_model, a.hm);                     /* sampler tables + prior descriptors (no simulator data): 30 KB per 2048 positions */
+  ModelStage<-1, LD> stage;                               /* sampler tables + prior descriptors (no simulator data) */
+  stage.load(a.hm);
   if (threadIdx.x == 0) s_n = 0u;
   __syncthreads();
 
@@ -355,6 +287,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     if (acc) s_list[at + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = r;
   }
   if (lane == 0u) { s_cnt[0][threadIdx.x >> 6] = wacc; s_cnt[1][threadIdx.x >> 6] = wsim; }
+  stage.store(s_model);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long x = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
@@ -371,7 +304,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     const uint32_t ri = s_list[on ? t : 0u];
     uint32_t ra, rb;
     double g, log_u;
-    particle_draws<L>(&s_model.tab, a.hm.icdf_all, a.hm.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
+    particle_draws<L>(&s_model.tab, a.hm.seed, ri, a.sweep, j, a.n_alive, ri, a.gamma0, a.gsig, &ra, &rb, &g, &log_u);
     const uint32_t bi = packed_bit(a.bits, ri), ba = packed_bit(a.bits, ra), bb = packed_bit(a.bits, rb);
     double ti[C], ta[C], tb[C], tp[C], pp[C];
     load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
@@ -427,7 +360,11 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   const HotModel& M = a.hm;
   const uint64_t seed = M.seed;
   __shared__ ModelLds<LD> s_model;
-  stage_model<SIM, LD>(s_model, M);
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
   __syncthreads();                                                          /* once per workgroup */
   const int j = (int)(threadIdx.x % L);
   const double eps_pop = a.eps_pop_dev ? abz_u2d(*a.eps_pop_dev) : a.eps_pop;
@@ -461,7 +398,8 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
     load_row<L, C>(a.theta + (size_t)ia * LD, j, ta);
     load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
 
-    const double z0 = normal_icdf_dev(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER).w0, &s_model.tab, M.icdf_all);
+    double z0, z1;
+    abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
     const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
     double tp[C], pp[C];
 #pragma unroll
@@ -540,7 +478,11 @@ __device__ inline void blob_eval_kernel_body(const HotModel& M, const double* __
   constexpr int LD = L * C;
   constexpr uint32_t PB = ABZ_BLOCK / L;
   __shared__ ModelLds<LD> s_model;
-  stage_model<SIM, LD>(s_model, M);
+  {
+    ModelStage<SIM, LD> stage;
+    stage.load(M);
+    stage.store(s_model);
+  }
   __syncthreads();
   const int j = (int)(threadIdx.x % L);
   const uint32_t ntiles = (n + PB - 1) / PB;

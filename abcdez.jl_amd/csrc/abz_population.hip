@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_
     case 4: y[i] = abz_floor(x[i]); break;
     case 5: y[i] = abz_sqrt(x[i]); break;
     case 7: y[i] = abz_log_tab(x[i], T); break;
-    case 8: y[i] = abz_normal_icdf(abz_d2u(x[i]), T); break;        /* x[i] carries the 64-bit random word; T in global memory */
+    case 8: { double s, c; abz_sincos2pi_tab(x[i], T, &s, &c); y[i] = s; y2[i] = c; break; }
+    case 9: y[i] = abz_sqrt_pn(x[i]); break;
     case 10: y[i] = abz_lgamma(x[i]); break;
     case 11: y[i] = abz_prior_logpdf1(&M->prior[(int)y2[i]], x[i]); break;   /* log-density of prior factor y2[i] at x[i] */
     default: y[i] = x[i] / y2[i]; break;
@@ -1368,7 +1369,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void draws_eval_kernel(const HotModel M,
                                                                uint32_t* __restrict__ ra, uint32_t* __restrict__ rb,
                                                                double* __restrict__ g, double* __restrict__ log_u) {
   __shared__ abz_tables s_tab;
-  stage_tables(s_tab, M.tables);
+  {
+    TabStage st;
+    st.load(M);
+    st.store(s_tab);
+  }
   __syncthreads();
   const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void draws_eval_kernel(const HotModel M,
   const uint32_t i = i0 + (active ? grp : 0u);
   uint32_t a, b;
   double gg, lu;
-  particle_draws<L>(&s_tab, M.icdf_all, M.seed, i, sweep, j, n_pool, i, gamma0, gsig, &a, &b, &gg, &lu);
+  particle_draws<L>(&s_tab, M.seed, i, sweep, j, n_pool, i, gamma0, gsig, &a, &b, &gg, &lu);
   if (active && j == 0) { ra[grp] = a; rb[grp] = b; g[grp] = gg; log_u[grp] = lu; }
 }
 int abz_draws_eval_impl(abcdez_ctx* ctx, int lanes, uint32_t i0, uint32_t n, uint32_t n_pool, uint32_t sweep,

@@ -10,27 +10,20 @@
  *
  * HBM roofline: per update 3 rows of 8 ld bytes read (own row, two donor rows) + 16 B state, and for an
  * accepted proposal one row + 16 B written.  Everything that does not depend on loaded data (prior descriptors,
- * data vector, sampler tables) is staged into LDS once per workgroup, which then loops over tiles of the prefix
- * (abz_persistent_grid); per tile a wave waits on two memory round trips: slot bits (an L2-resident bitmap) -> rows.
+ * data vector, model scalars, sampler tables) is fetched before the first dependent load, so a wave waits on two
+ * memory round trips: slot bits (an L2-resident bitmap) -> rows.
  */
 #include "abz_dispatch.h"
 #include "abz_kernels.h"
 
 /* ================================================================ packed population (abz_kernels.h) */
-/* Wide rows (8 components per lane: the d = 32 configuration) are compiled for FOUR waves per SIMD (128 VGPRs): the LDS
- * tables (38 KB per workgroup) allow four workgroups per CU anyway, the prefetch of the next round's slot bits needs nine
- * registers across the simulator, and with the sampler's arithmetic halved a fifth wave no longer pays
- * (tools/sweep_variants.hip, profiles/r03_sweep_variants.jsonl: 4 waves + prefetch 0.4385 ms, 5 waves without 0.4510 ms,
- * 5 waves + prefetch spills and takes 0.485 ms; the kernel's memory side alone 0.4197 ms, its arithmetic alone 0.4026 ms). */
-template <int L, int C>
-struct SweepWaves {
-  static constexpr bool wide = C == 8 && L >= 4;    /* the shapes default_shape() picks for ld >= 32 */
-  static constexpr int lo = wide ? 4 : 1;
-  static constexpr int hi = wide ? 4 : 8;
-};
+#ifndef ABZ_SWEEP_WAVES
+#define ABZ_SWEEP_WAVES_ATTR
+#else
+#define ABZ_SWEEP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ABZ_SWEEP_WAVES, ABZ_SWEEP_WAVES)))
+#endif
 template <int SIM, int L, int C, bool PLAIN>
-__global__ __launch_bounds__(ABZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SweepWaves<L, C>::lo, SweepWaves<L, C>::hi)))
-void smc_swarm_packed_kernel(const SmcPackedArgs a) {
+__global__ __launch_bounds__(ABZ_BLOCK) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
   smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
 template <int L, int C, bool PLAIN>
@@ -53,23 +46,18 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   if (a.n_work == 0) return 0;
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
-  /* loop trips of one workgroup = groups of ABZ_BLOCK / 64 wave-tiles (abz_kernels.h, SweepTile); the workgroups loop over them */
-  const unsigned pb = (L == 1 ? 64u : 32u) * (ABZ_BLOCK / 64);
-  const unsigned ntiles = (unsigned)(((uint64_t)a.n_work + pb - 1) / pb);
+  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
   const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
-    if (int rc = abz_jit_launch_smc_packed(ctx, &a, ntiles)) return rc;
+    if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {
-        if (ctx->prior_plain) {
-          auto kern = smc_swarm_packed_kernel<S(), LL(), CC(), true>;
-          hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-        } else {
-          auto kern = smc_swarm_packed_kernel<S(), LL(), CC(), false>;
-          hipLaunchKernelGGL(kern, dim3(abz_persistent_grid(ctx, kern, ntiles, ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-        }
+        if (ctx->prior_plain)
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+        else
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
       }
     });
   }

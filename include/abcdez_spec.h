@@ -46,7 +46,7 @@ ABZ_HD int abz_isnan(double x) { return x != x; }
  * counter = (c0,c1,c2,c3), key = (k0,k1).  R = ABZ_PHILOX_ROUNDS = 7: the round count the paper reports as the smallest
  * Crush-resistant one for Philox4x32 (passes SmallCrush, Crush and BigCrush of TestU01, its section 5 / table 2: "Philox4x32-7");
  * Random123's default of 10 adds a safety margin the paper itself calls optional.  The sweep kernels are bound by
- * their vector ALU and 40 % of a Box-Muller-free normal is this function, hence 7.  tests/test_spec_math.py pins the round
+ * their vector ALU and a third of a Box-Muller pair is this function, hence 7.  tests/test_spec_math.py pins the round
  * function against Random123's published 10-round known answers (abz_philox4x32_r(10, ...)) and a pure-Python Philox,
  * and runs its own battery (bit frequencies, serial correlation across counters and keys, birthday spacings of the
  * 7-round stream).                                                                     */
@@ -99,7 +99,7 @@ enum {
   ABZ_RNG_INIT_PRIOR = 1, /* prior draw, block m covers components 2m,2m+1        */
   ABZ_RNG_INIT_SIM = 2,   /* simulator noise during init                          */
   ABZ_RNG_DONOR = 3,      /* word0 -> donor a, word1 -> donor b                   */
-  ABZ_RNG_JITTER = 4,     /* word0 -> the normal of the gamma jitter              */
+  ABZ_RNG_JITTER = 4,     /* Box-Muller pair, first normal = gamma jitter         */
   ABZ_RNG_ACCEPT = 5,     /* word0 -> accept uniform                              */
   ABZ_RNG_SIM = 6,        /* simulator noise during sweeps                        */
   ABZ_RNG_BETTER = 7,     /* abcdemc "better particle" draw (mc:23)               */
@@ -122,6 +122,8 @@ ABZ_HD abz_u64x2 abz_rng(uint64_t seed, uint32_t idx, uint32_t epoch, uint32_t s
 ABZ_HD double abz_u01_open(uint64_t w) {
   return abz_u2d(0x3FF0000000000000ull | (w >> 12)) - 0x1.fffffffffffffp-1;
 }
+/* uniform in [0,1) with 52 bits: k 2^-52 (the Box-Muller angle) */
+ABZ_HD double abz_u01_52(uint64_t w) { return abz_u2d(0x3FF0000000000000ull | (w >> 12)) - 1.0; }
 /* uniform in [0,1): k 2^-53, k = top 53 bits (what Julia's rand() returns in law). */
 ABZ_HD double abz_u01_co(uint64_t w) { return (double)(w >> 11) * 0x1p-53; }
 
@@ -231,9 +233,10 @@ ABZ_HD void abz_sincos2pi(double u, double* sn, double* cs) {
   *cs = abz_u2d(abz_d2u(c0) ^ c_neg);
 }
 
-/* ------------------------------------------------------------------ table-driven log and normal sampler
- * (tables: abcdez_tables.h, generated by tools/gen_tables.py; data in abcdez_tables_data.h).  The sweep kernel is
- * VALU-bound on exactly this code.                                                                                  */
+/* ------------------------------------------------------------------ table-driven log / sincos for the sampler
+ * (tables: abcdez_tables.h, generated by tools/gen_tables.py).  About half the instructions
+ * of the polynomial versions above; the sweep kernel is VALU-bound on exactly this code.   */
+static const abz_tables abz_tables_host = ABZ_TABLES_INIT;   /* host copy; kernels stage a device copy into LDS */
 
 /* log(x), x positive normal.  x = 2^k z, z in [~sqrt(1/2), ~sqrt(2)); interval i of z from the
  * top 7 mantissa bits; r = z c_i - 1 (one fma), |r| < 3.9e-3; log z = T_i + log1p(r), Taylor to
@@ -262,50 +265,70 @@ ABZ_HD double abz_log_tab(double x, const abz_tables* T) {
   return hi + (lo + abz_fma(r * r, p, r));
 }
 
-/* N(0,1) from ONE 64-bit random word, by inversion (randn, smc:128).
- *   bit 63           sign
- *   bits 62..0 = b   U = 2^-(j+1) (1 + t) in (0, 1): j = number of leading zeros of the 63-bit field (the binade: P(j) = 2^-(j+1)),
- *                    t in [0, 1) = the bits behind the leading one (62 - j of them, at least 52 kept for j <= 5);
- *   |x| = Q^-1(U / 2), the upper-tail quantile: U near 1 is the centre, small U the tail (j = 62: |x| = 9.0).
- * t is cut into ABZ_ICDF_SUB = 32 sub-intervals; on each |x| is a degree-7 polynomial in tau = frac(32 t) - 1/2, coefficients in the
- * generated table (row = 32 j + sub-interval, piece q = coefficients 2q, 2q+1), Horner with fma.  Max error against mpmath
- * 2e-16 relative to max(|x|, 1/4) (tests/test_spec_math.py); b = 0 (probability 2^-63) is binade 63 with t = 0.
- * No log, sqrt or sincos, no rejection, no branch in 99.98 % of the calls: the kernels keep the first ABZ_ICDF_HOT_BINADES
- * binades in LDS and fetch deeper rows from global memory (same table, same values).                                          */
-ABZ_HD void abz_icdf_index(uint64_t w, uint32_t* row, double* tau) {
-  const uint64_t v = w << 1;
-  const uint32_t lz = (uint32_t)__builtin_clzll(v | 1ull);                  /* bit 0 of v is clear: v = 0 -> 63, any other v unchanged */
-  const uint64_t A = (v << lz) << 1;                                        /* the bits behind the leading one, left-aligned */
-  *row = lz * (uint32_t)ABZ_ICDF_SUB + (uint32_t)(A >> (64 - ABZ_ICDF_SUB_BITS));
-  *tau = abz_u2d(0x3FF0000000000000ull | ((A << ABZ_ICDF_SUB_BITS) >> 12)) - 1.5;     /* exact */
-}
-ABZ_HD double abz_icdf_poly(double tau, abz_f64x2 c01, abz_f64x2 c23, abz_f64x2 c45, abz_f64x2 c67, uint64_t w) {
-  double p = c67.y;
-  p = abz_fma(p, tau, c67.x);
-  p = abz_fma(p, tau, c45.y);
-  p = abz_fma(p, tau, c45.x);
-  p = abz_fma(p, tau, c23.y);
-  p = abz_fma(p, tau, c23.x);
-  p = abz_fma(p, tau, c01.y);
-  p = abz_fma(p, tau, c01.x);
-  return abz_u2d((abz_d2u(p) & 0x7FFFFFFFFFFFFFFFull) | (w & 0x8000000000000000ull));
-}
-ABZ_HD double abz_normal_icdf(uint64_t w, const abz_tables* T) {
-  uint32_t row;
-  double tau;
-  abz_icdf_index(w, &row, &tau);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (__builtin_expect(row < (uint32_t)ABZ_ICDF_HOT_ROWS, 1))
-    return abz_icdf_poly(tau, T->icdf_hot[0][row], T->icdf_hot[1][row], T->icdf_hot[2][row], T->icdf_hot[3][row], w);
-#endif
-  const abz_f64x2* c = T->icdf_all + row;
-  return abz_icdf_poly(tau, c[0], c[ABZ_ICDF_ROWS], c[2 * ABZ_ICDF_ROWS], c[3 * ABZ_ICDF_ROWS], w);
+/* sincos(2 pi u), u = k 2^-52 in [0,1).  j = round(256 u); delta = 2 pi (u - j/256), |delta| <=
+ * pi/256; Taylor to delta^7 / delta^6; rotate the table entry (sin, cos)(2 pi j / 256).     */
+ABZ_HD void abz_sincos2pi_tab(double u, const abz_tables* T, double* sn, double* cs) {
+  const double t = u * 256.0;
+  const double tr = (t + 0x1.8p52) - 0x1.8p52;          /* nearest integer, 0..256 */
+  const int j = (int)tr & (ABZ_SC_TAB_N - 1);
+  const double dl = (t - tr) * 0x1.921fb54442d18p-6;    /* 2 pi / 256 */
+  const double z = dl * dl;
+  const double ps = abz_fma(abz_fma(-0x1.a01a01a01a01ap-13, z, 0x1.1111111111111p-7), z, -0x1.5555555555555p-3);
+  const double pc = abz_fma(abz_fma(-0x1.6c16c16c16c17p-10, z, 0x1.5555555555555p-5), z, -0.5);
+  const double sd = abz_fma(dl * z, ps, dl);            /* sin(delta)     */
+  const double cm1 = z * pc;                            /* cos(delta) - 1 */
+  const double S = T->sc[j][0], C = T->sc[j][1];
+  *sn = S + abz_fma(S, cm1, C * sd);
+  *cs = C + abz_fma(-S, sd, C * cm1);
 }
 
-/* one Philox block -> two independent N(0,1) (randn, smc:128) */
+/* the same for u = (w >> 12) 2^-52 taken straight from a random word: t = 256 u is built in [256, 512) and the integer
+ * part is read off the bits of t + 0x1.8p52 -- two instructions fewer than abz_sincos2pi_tab(abz_u01_52(w)) for the same values
+ * (256 u is exact either way; (t256 - 256) + 0x1.8p52 and t256 + (0x1.8p52 - 256) round the same real number) */
+ABZ_HD void abz_sincos2pi_tab_w(uint64_t w, const abz_tables* T, double* sn, double* cs) {
+  const double t256 = abz_u2d(0x4070000000000000ull | (w >> 12));
+  const double t = t256 - 256.0;
+  const double tc = t256 + (0x1.8p52 - 256.0);
+  const double tr = tc - 0x1.8p52;                      /* nearest integer, 0..256 */
+  const int j = (int)((uint32_t)abz_d2u(tc) & (ABZ_SC_TAB_N - 1));
+  const double dl = (t - tr) * 0x1.921fb54442d18p-6;    /* 2 pi / 256 */
+  const double z = dl * dl;
+  const double ps = abz_fma(abz_fma(-0x1.a01a01a01a01ap-13, z, 0x1.1111111111111p-7), z, -0x1.5555555555555p-3);
+  const double pc = abz_fma(abz_fma(-0x1.6c16c16c16c17p-10, z, 0x1.5555555555555p-5), z, -0.5);
+  const double sd = abz_fma(dl * z, ps, dl);
+  const double cm1 = z * pc;
+  const double S = T->sc[j][0], C = T->sc[j][1];
+  *sn = S + abz_fma(S, cm1, C * sd);
+  *cs = C + abz_fma(-S, sd, C * cm1);
+}
+
+/* sqrt(x) for x in the normal range far from over/underflow (here: -2 log u in [2e-16, 74]).
+ * Device: v_rsq_f64 seed + the two Goldschmidt/Newton steps and two residual corrections the
+ * compiler's own correctly rounded expansion uses, minus its range scaling.  Host: sqrt().  */
+ABZ_HD double abz_sqrt_pn(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
+/* Box-Muller: one Philox block -> two independent N(0,1).  (randn, smc:128)       */
 ABZ_HD void abz_normal_pair(abz_u64x2 w, const abz_tables* T, double* z0, double* z1) {
-  *z0 = abz_normal_icdf(w.w0, T);
-  *z1 = abz_normal_icdf(w.w1, T);
+  const double u1 = abz_u01_open(w.w0);
+  const double r = abz_sqrt_pn(-2.0 * abz_log_tab(u1, T));
+  double sn, cs;
+  abz_sincos2pi_tab_w(w.w1, T, &sn, &cs);                 /* == abz_sincos2pi_tab(abz_u01_52(w.w1), ...) */
+  *z0 = r * cs;
+  *z1 = r * sn;
 }
 
 /* round half to even == Julia round(Int, x) (types.jl:23) */
@@ -393,7 +416,7 @@ ABZ_HD double abz_prior_logpdf1(const abz_prior_dim* pd, double x) {
 }
 
 /* one prior draw for component pair (2m, 2m+1) uses one Philox block:
- *   normal: the block's two normals (z0 -> even component, z1 -> odd component)
+ *   normal: Box-Muller pair (z0 -> even component, z1 -> odd component)
  *   (d)uniform: w0 -> even component, w1 -> odd component                          */
 ABZ_HD double abz_prior_draw1(const abz_prior_dim* pd, uint64_t w, double z) {
   switch (pd->family) {

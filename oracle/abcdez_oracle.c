@@ -44,7 +44,6 @@
 #include <string.h>
 
 #include "../include/abcdez_spec.h"
-#include "../include/abcdez_tables_data.h"
 
 #define ORC_API __attribute__((visibility("default")))
 #define ORC_MAX_RETRY 100000u
@@ -61,13 +60,6 @@ ORC_API void orc_philox_r(int rounds, const uint32_t ctr[4], const uint32_t key[
   memcpy(out, r.v, 16);
 }
 ORC_API int orc_philox_rounds(void) { return ABZ_PHILOX_ROUNDS; }
-/* inverse-CDF normal of raw 64-bit words + the (row, tau) it evaluates the table at */
-ORC_API void orc_normal_icdf(const uint64_t* w, int64_t n, double* z, uint32_t* row, double* tau) {
-  for (int64_t i = 0; i < n; ++i) {
-    z[i] = abz_normal_icdf(w[i], ORC_T);
-    if (row) abz_icdf_index(w[i], &row[i], &tau[i]);
-  }
-}
 ORC_API void orc_math_eval(int fn, const double* x, double* y, double* y2, int64_t n) {
   for (int64_t i = 0; i < n; ++i) {
     switch (fn) {
@@ -78,7 +70,8 @@ ORC_API void orc_math_eval(int fn, const double* x, double* y, double* y2, int64
       case 4: y[i] = abz_floor(x[i]); break;
       case 5: y[i] = abz_sqrt(x[i]); break;
       case 7: y[i] = abz_log_tab(x[i], ORC_T); break;
-      case 8: y[i] = abz_normal_icdf(abz_d2u(x[i]), ORC_T); break;          /* x[i] carries the 64-bit random word */
+      case 8: abz_sincos2pi_tab(x[i], ORC_T, &y[i], &y2[i]); break;
+      case 9: y[i] = abz_sqrt_pn(x[i]); break;
       case 10: y[i] = abz_lgamma(x[i]); break;
       default: y[i] = x[i] / (y2 ? y2[i] : 1.0); break;
     }
@@ -113,7 +106,7 @@ ORC_API void orc_particle_draws(uint64_t seed, int64_t i0, int64_t n, int64_t n_
   }
 }
 ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w, n); }
-ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : abz_u01_co(w); }
+ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : (kind == 2 ? abz_u01_52(w) : abz_u01_co(w)); }
 ORC_API uint32_t orc_randint(uint64_t w, uint32_t n) { return abz_randint(w, n); }
 ORC_API double orc_prior_logpdf1(const abz_prior_dim* pd, double x) { return abz_prior_logpdf1(pd, x); }
 ORC_API double orc_kernel_pdf(int kind, double eps, double x) { return abz_kernel_pdf(kind, eps, x); }

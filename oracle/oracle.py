@@ -70,7 +70,6 @@ def lib():
     L.orc_philox.argtypes = [_vp, _vp, _vp]
     L.orc_philox_r.argtypes = [C.c_int, _vp, _vp, _vp]
     L.orc_philox_rounds.restype = C.c_int
-    L.orc_normal_icdf.argtypes = [_vp, _i64, _vp, _vp, _vp]
     L.orc_donor_ranks.argtypes = [_u64, _u64, _u32, _u32, _vp, _vp]
     L.orc_weight_fix.restype = _u64
     L.orc_weight_fix.argtypes = [_f64, _u32]

@@ -58,7 +58,7 @@ def assert_state_equal(hip, orc, what=""):
 # ---------------------------------------------------------------- spec arithmetic on the device
 @pytest.mark.parametrize("fn,gen", [
     (0, "pos"), (1, "exparg"), (2, "unit"), (3, "round"), (4, "round"), (5, "pos"), (6, "pair"),
-    (7, "posnormal"), (8, "words"), (10, "lgamma"),
+    (7, "posnormal"), (8, "unit52"), (9, "bmrange"), (10, "lgamma"),
 ])
 def test_math_bit_exact(oracle, fn, gen):
     rng = np.random.default_rng(100 + fn)
@@ -69,15 +69,13 @@ def test_math_bit_exact(oracle, fn, gen):
     elif gen == "posnormal":
         x = np.concatenate([np.exp(rng.uniform(-700, 700, n // 2)), (rng.integers(0, 1 << 52, n // 2) + 0.5) * 2.0 ** -52])
         x[:6] = [1.0, 2.0 ** -53, 1 - 2.0 ** -53, 0.5, 2.2250738585072014e-308, 1.7e308]
-    elif gen == "words":
-        # abz_normal_icdf: raw 64-bit words carried in the double array; 2^24 random ones plus every binade of the table
-        # (the kernels read binades >= 12 from global memory, the oracle reads one host table)
-        n = 1 << 24
-        w = rng.integers(0, 1 << 64, n, dtype=np.uint64)
-        deep = (rng.integers(0, 1 << 63, 64 * 4096, dtype=np.uint64) | np.uint64(1 << 62)) >> np.repeat(np.arange(64, dtype=np.uint64), 4096)
-        w[:deep.size] = deep | (rng.integers(0, 2, deep.size, dtype=np.uint64) << np.uint64(63))
-        w[deep.size:deep.size + 4] = [0, 1 << 63, (1 << 63) - 1, (1 << 64) - 1]
-        x = w.view(np.float64)
+    elif gen == "unit52":
+        x = rng.integers(0, 1 << 52, n).astype(np.float64) * 2.0 ** -52
+        x[:4] = [0.0, 0.125, 0.5, 1 - 2.0 ** -52]
+    elif gen == "bmrange":
+        n = 1 << 24                       # sqrt_pn replaces the compiler's expansion: check it hard
+        x = np.exp(rng.uniform(-37.0, 4.4, n))     # -2 log u for u in [2^-53, 1)
+        x[:4] = [2.0 ** -52, 73.5, 1.0, 2.0]
     elif gen == "lgamma":
         x = np.concatenate([rng.uniform(1e-3, 40, n // 2), np.exp(rng.uniform(0, 20, n // 2))])
     elif gen == "exparg":
@@ -103,8 +101,10 @@ def test_math_bit_exact(oracle, fn, gen):
     y2h = y2in.copy()
     oracle.lib().orc_math_eval(fn, x.ctypes.data, yh.ctypes.data, y2h.ctypes.data, n)
     assert np.array_equal(yd.cpu().numpy().view(np.int64), yh.view(np.int64))
-    if fn == 2:
+    if fn in (2, 8):
         assert np.array_equal(y2d.cpu().numpy().view(np.int64), y2h.view(np.int64))
+    if fn == 9:
+        assert np.array_equal(yh, np.sqrt(x))          # and both are the correctly rounded sqrt
 
 
 # ---------------------------------------------------------------- S1

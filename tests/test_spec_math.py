@@ -213,82 +213,35 @@ def test_table_log_accuracy(oracle):
     assert np.max(np.abs(a - b) / np.spacing(np.abs(b))) <= 3
 
 
-def _icdf(oracle, w, want_index=False):
-    w = np.ascontiguousarray(w, dtype=np.uint64)
-    z = np.zeros(w.size)
-    row = np.zeros(w.size, dtype=np.uint32)
-    tau = np.zeros(w.size)
-    oracle.lib().orc_normal_icdf(w.ctypes.data, w.size, z.ctypes.data, row.ctypes.data, tau.ctypes.data)
-    return (z, row, tau) if want_index else z
-
-
-def _icdf_exact(w):
-    """what abz_normal_icdf approximates, from its definition (abcdez_spec.h), in mpmath"""
-    w = int(w)
-    sgn = -1 if w >> 63 else 1
-    v = (w << 1) & ((1 << 64) - 1)
-    lz = 63 if v == 0 else 64 - v.bit_length()
-    A = ((v << lz) << 1) & ((1 << 64) - 1)
-    i = A >> 59
-    m52 = ((A << 5) & ((1 << 64) - 1)) >> 12
-    t = (mpmath.mpf(i) + mpmath.mpf(m52) / 2 ** 52) / 32
-    p = mpmath.ldexp(1 + t, -(lz + 1)) / 2                               # upper-tail probability
-    x = mpmath.mpf(float(stats.norm.isf(float(p)))) if p > mpmath.mpf(10) ** -300 else mpmath.sqrt(-2 * mpmath.log(p))
-    for _ in range(6):                                                    # Newton on erfc at 200 bits
-        q = mpmath.erfc(x / mpmath.sqrt(2)) / 2
-        x = x + (q - p) * mpmath.sqrt(2 * mpmath.pi) * mpmath.exp(x * x / 2)
-    return sgn * x, lz * 32 + i
-
-
-def test_normal_icdf_accuracy(oracle):
-    """abz_normal_icdf against the exact quantile, every binade of the table: random words plus words forced into each of
-    the 63 binades and the corners; error relative to max(|x|, 1/4)"""
+def test_table_sincos_accuracy(oracle):
     mpmath.mp.prec = 200
     rng = np.random.default_rng(13)
-    ws = [int(v) for v in rng.integers(0, 1 << 64, 2500, dtype=np.uint64)]
-    for lz in range(63):
-        for _ in range(24):
-            r = int(rng.integers(0, 1 << 63, dtype=np.uint64)) | (1 << 62)
-            ws.append((r >> lz) | (int(rng.integers(0, 2)) << 63))
-    ws += [0, 1 << 63, (1 << 63) - 1, (1 << 64) - 1, 1, 2, 3, 1 << 62, (1 << 62) - 1]
-    z, row, tau = _icdf(oracle, np.array(ws, dtype=np.uint64), want_index=True)
+    u = np.concatenate([rng.integers(0, 1 << 52, 4000).astype(np.float64) * 2.0 ** -52,
+                        np.arange(0, 256) / 256.0, (np.arange(0, 256) + 0.5) / 256.0, [1 - 2.0 ** -52, 2.0 ** -52]])
+    s, c = eval_fn(oracle, 8, u)
     worst = 0.0
-    for wi, zi, ri in zip(ws, z, row):
-        ex, rr = _icdf_exact(wi)
-        assert rr == ri
-        worst = max(worst, float(abs(mpmath.mpf(float(zi)) - ex) / max(abs(ex), mpmath.mpf(0.25))))
-    assert worst < 2.5e-16, worst
-    assert np.all(np.abs(tau) <= 0.5) and row.max() == 63 * 32
-    # sign symmetry and monotonicity in the uniform the word encodes
-    w = rng.integers(0, 1 << 63, 100000, dtype=np.uint64)
-    assert np.array_equal(_icdf(oracle, w), -_icdf(oracle, w | np.uint64(1 << 63)))
-    ws = np.sort(w)
-    zs = _icdf(oracle, ws)
-    assert np.all(np.diff(zs) <= 1e-15)                                   # larger field = larger U = smaller |x| (to rounding at the seams)
-    assert abs(_icdf(oracle, np.array([0], dtype=np.uint64))[0] - 9.155293772686072) < 1e-12     # deepest point of the table
+    for ui, si, ci in zip(u, s, c):
+        a = 2 * mpmath.pi * mpmath.mpf(float(ui))
+        worst = max(worst, float(abs(mpmath.mpf(float(si)) - mpmath.sin(a))), float(abs(mpmath.mpf(float(ci)) - mpmath.cos(a))))
+    assert worst < 2.3e-16, worst                     # absolute, i.e. ~1 ulp of values near 1
+    assert np.all(np.abs(s * s + c * c - 1) < 5e-16)
+    e = eval_fn(oracle, 8, np.array([0.0, 0.25, 0.5, 0.75]))
+    assert list(e[0]) == [0.0, 1.0, 0.0, -1.0] and list(e[1]) == [1.0, 0.0, -1.0, 0.0]
 
 
-def test_normal_icdf_distribution(oracle):
-    """10^7 draws: moments, Kolmogorov-Smirnov against the normal CDF, tail counts against their binomial expectations"""
+def test_sqrt_pn_is_sqrt_on_host(oracle):
     rng = np.random.default_rng(14)
-    n = 10_000_000
-    z = _icdf(oracle, rng.integers(0, 1 << 64, n, dtype=np.uint64))
-    assert abs(z.mean()) < 4 / np.sqrt(n)
-    assert abs(z.var() - 1) < 4 * np.sqrt(2 / n)
-    assert abs(stats.skew(z)) < 4 * np.sqrt(6 / n)
-    assert abs(stats.kurtosis(z)) < 4 * np.sqrt(24 / n)
-    assert stats.kstest(z, "norm").pvalue > 1e-3
-    for thr in (2.0, 3.0, 4.0, 4.5):
-        cnt = int(np.sum(np.abs(z) > thr))
-        exp = n * 2 * stats.norm.sf(thr)
-        assert abs(cnt - exp) < 5 * np.sqrt(exp) + 1, (thr, cnt, exp)
+    x = np.exp(rng.uniform(-37, 5, 100000))
+    assert np.array_equal(eval_fn(oracle, 9, x)[0], np.sqrt(x))
 
 
 def test_uniform_conversions(oracle):
     L = oracle.lib()
+    assert L.orc_u01(0, 2) == 0.0 and L.orc_u01((1 << 64) - 1, 2) == 1 - 2.0 ** -52
     rng = np.random.default_rng(15)
     for w in (int(v) for v in rng.integers(0, 1 << 64, 2000, dtype=np.uint64)):
         assert L.orc_u01(w, 1) == ((w >> 12) + 0.5) * 2.0 ** -52        # bit trick == the defining formula
+        assert L.orc_u01(w, 2) == (w >> 12) * 2.0 ** -52
     assert L.orc_u01(0, 1) == 2.0 ** -53 and L.orc_u01((1 << 64) - 1, 1) == 1 - 2.0 ** -53
     assert L.orc_u01(0, 0) == 0.0 and L.orc_u01((1 << 64) - 1, 0) == 1 - 2.0 ** -53
     assert L.orc_randint(0, 10) == 0 and L.orc_randint((1 << 64) - 1, 10) == 9
@@ -304,7 +257,7 @@ def test_normal_pairs_are_standard_normal(oracle):
     assert abs(stats.kurtosis(z)) < 0.03
     assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
     assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 0.01          # the two outputs of a pair are independent
-    assert np.abs(z).max() < 9.2                                   # the table ends at 9.155 (P = 2^-64)
+    assert np.abs(z).max() < 8.6                                   # sqrt(-2 log 2^-53)
     assert stats.kstest(z[200000:400000] ** 2 + z[400000:600000] ** 2, 'chi2', args=(2,)).pvalue > 1e-3
 
 

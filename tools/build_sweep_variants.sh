@@ -1,6 +1,9 @@
 #!/bin/bash
-# Builds tools/sweep_variants: the d = 32 sweep kernel in several compile-time variants, timed against each other
-# in one process (tools/sweep_variants.hip).  Each line of VARIANTS: name | what | hipcc flags
+# Builds tools/sweep_variants: the d = 32 sweep kernel in several variants, timed against each other in one process
+# (tools/sweep_variants.hip).
+#   VARIANTS: kernels of this tree, one per line:      name | what | hipcc flags
+#   TREES:    the kernel of other commits, one per line: name | what | worktree directory | hipcc flags
+#             (git worktree add _r02 79040f7;  git worktree add _icdf 4d39988;  _r02p7 = a copy of _r02 with ABZ_PHILOX_ROUNDS 7)
 set -e
 cd "$(dirname "$0")/.."
 B=tools/build_variants
@@ -8,15 +11,16 @@ mkdir -p $B
 INC="-Iabcdez.jl_amd/csrc -Iinclude -I$B"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math"
 VARIANTS=${VARIANTS:-"
-base|shipped: prefetch of the next round's slot bits, 5 waves, no machine-LICM|-DVWAVES=5 -mllvm -disable-machine-licm
-nopf|no prefetch, 5 waves|-DVWAVES=5 -DABZ_SWEEP_PREFETCH=0 -mllvm -disable-machine-licm
-pf4|prefetch, 4 waves (128 VGPRs)|-DVWAVES=4 -mllvm -disable-machine-licm
-nopf4|no prefetch, 4 waves, free scheduling|-DVWAVES=4 -DABZ_SWEEP_PREFETCH=0 -DABZ_SWEEP_SCHED=0 -mllvm -disable-machine-licm
-nosim|ABLATION no simulator (memory side of the real kernel), 5 waves no prefetch|-DVWAVES=5 -DABZ_SWEEP_PREFETCH=0 -DABZ_ABLATE_SIM -mllvm -disable-machine-licm
-nodon|ABLATION donors = own row (compute side of the real kernel), 5 waves no prefetch|-DVWAVES=5 -DABZ_SWEEP_PREFETCH=0 -DABZ_ABLATE_DONORS -mllvm -disable-machine-licm
-nosimpf|ABLATION no simulator, prefetch, 5 waves|-DVWAVES=5 -DABZ_ABLATE_SIM -mllvm -disable-machine-licm
+cur|shipped: Box-Muller + Philox4x32-7, one tile per workgroup, occupancy left to the compiler (5 waves)|
+cur4|shipped kernel held to 4 waves per SIMD|-DVWAVES=4
+"}
+TREES=${TREES:-"
+r02|round 2 (79040f7): Box-Muller + Philox4x32-10, one tile per workgroup, 5 waves|_r02|
+r02p7|round 2 with Philox4x32-7|_r02p7|
+icdf|round 3 experiment (4d39988): inverse-CDF normal + Philox4x32-7, looping workgroups, staged tables, prefetch, 4 waves|_icdf|-DTREE_ICDF -mllvm -disable-machine-licm
 "}
 : > $B/variants.inc
+: > $B/trees.inc
 OBJS=""
 while IFS='|' read -r name what flags; do
   [ -z "$name" ] && continue
@@ -24,13 +28,15 @@ while IFS='|' read -r name what flags; do
   /opt/rocm/bin/hipcc $COMMON $INC -DVNAME=$name $flags -c tools/sweep_variant_kernel.hip -o $B/$name.o &
   OBJS="$OBJS $B/$name.o"
 done <<< "$VARIANTS"
+while IFS='|' read -r name what tree flags; do
+  [ -z "$name" ] && continue
+  [ -d $tree/abcdez.jl_amd/csrc ] || { echo "skipping $name: no worktree $tree"; continue; }
+  echo "T($name, \"$what\")" >> $B/trees.inc
+  /opt/rocm/bin/hipcc $COMMON -I$tree/abcdez.jl_amd/csrc -I$tree/include -DTREE=$name $flags -c tools/sweep_variant_tree.hip -o $B/$name.o &
+  OBJS="$OBJS $B/$name.o"
+done <<< "$TREES"
 wait
-R02=""
-if [ -d _r02/abcdez.jl_amd/csrc ]; then      # round 2's kernel, when its worktree is there:  git worktree add _r02 <round-2 commit>
-  /opt/rocm/bin/hipcc $COMMON -I_r02/abcdez.jl_amd/csrc -I_r02/include -c tools/sweep_variant_r02.hip -o $B/r02.o
-  OBJS="$OBJS $B/r02.o"; R02="-DWITH_R02"
-fi
-/opt/rocm/bin/hipcc $COMMON $INC $R02 -c tools/sweep_variants.hip -o $B/main.o
+/opt/rocm/bin/hipcc $COMMON $INC -c tools/sweep_variants.hip -o $B/main.o
 [ -f tools/liblayout_bench.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/liblayout_bench.so tools/layout_bench.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $B/main.o $OBJS -Ltools -llayout_bench -Wl,-rpath,'$ORIGIN' -o tools/sweep_variants
 echo built tools/sweep_variants

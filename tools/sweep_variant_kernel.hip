@@ -1,15 +1,16 @@
-// One compile-time variant of the d = 32 sweep kernel for tools/sweep_variants.hip: the library's own kernel body
-// (abcdez.jl_amd/csrc/abz_kernels.h) built with this translation unit's -D knobs.
-//   hipcc -c -DVNAME=v1 -DVWAVES=5 [-DABZ_SWEEP_PREFETCH=0 ...] tools/sweep_variant_kernel.hip
+// The shipped d = 32 sweep kernel for tools/sweep_variants.hip: the library's own kernel body (abcdez.jl_amd/csrc/abz_kernels.h),
+// optionally with a forced occupancy or other -D knobs of this translation unit.
+//   hipcc -c -DVNAME=cur [-DVWAVES=4] tools/sweep_variant_kernel.hip
 #include "abz_kernels.h"
 
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
-#ifndef VWAVES
-#define VWAVES 5
-#endif
 
+#ifdef VWAVES
 __global__ __launch_bounds__(ABZ_BLOCK) __attribute__((amdgpu_waves_per_eu(VWAVES, VWAVES)))
+#else
+__global__ __launch_bounds__(ABZ_BLOCK)
+#endif
 void CAT(sweep_kernel_, VNAME)(const SmcPackedArgs a) {
   smc_swarm_packed_body<ABZ_SIM_MVN, 4, 8, true>(a);
 }

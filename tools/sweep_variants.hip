@@ -1,8 +1,9 @@
 // sweep_variants.hip -- times compile-time variants of the d = 32 sweep kernel against each other and against the
 // arithmetic-free access pattern, in ONE process on ONE GPU, interleaved rounds (same data, same launch sizes):
 //   bash tools/build_sweep_variants.sh && tools/sweep_variants [n_alive] [rounds]
-// The variants are the library's kernel body compiled with different knobs (tools/sweep_variant_kernel.hip); the list
-// lives in tools/build_sweep_variants.sh, which generates variants.inc.  Output: one JSON line per variant.
+// The variants are the library's kernel body compiled with different knobs (tools/sweep_variant_kernel.hip) and the same kernel
+// of other commits from git worktrees (tools/sweep_variant_tree.hip); both lists live in tools/build_sweep_variants.sh, which
+// generates variants.inc / trees.inc.  Output: one JSON line per variant.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -13,43 +14,32 @@
 #include <vector>
 
 #include "abz_kernels.h"
-#include "abcdez_tables_data.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Variant { const char* name; const char* what; int (*occ)(); void (*launch)(const SmcPackedArgs*, unsigned, hipStream_t); };
-#ifdef WITH_R02      // round 2's kernel from a git worktree (tools/sweep_variant_r02.hip): its own grid, argument struct and tables
-extern "C" int sweep_occ_r02();
-extern "C" void sweep_launch_r02_raw(const uint32_t*, uint32_t*, double*, double*, double*, double*, unsigned long long*, const void*, const double*,
-                                     double, double, double, uint32_t, uint32_t, hipStream_t);
-static void sweep_launch_r02(const SmcPackedArgs* a, unsigned, hipStream_t st) {
-  sweep_launch_r02_raw(a->bits, a->bits_out, a->slot0, a->slot1, a->logpi, a->delta, a->cslots, a->hm.prior, a->hm.data, a->eps, a->gamma0,
-                       a->gsig, a->n_alive, a->sweep, st);
-}
-#endif
-#ifdef WITH_R02P7    // the same with Philox4x32-7 (a patched copy of the worktree): what 12 instructions per Philox block are worth there
-extern "C" int sweep_occ_r02p7();
-extern "C" void sweep_launch_r02p7_raw(const uint32_t*, uint32_t*, double*, double*, double*, double*, unsigned long long*, const void*, const double*,
-                                       double, double, double, uint32_t, uint32_t, hipStream_t);
-static void sweep_launch_r02p7(const SmcPackedArgs* a, unsigned, hipStream_t st) {
-  sweep_launch_r02p7_raw(a->bits, a->bits_out, a->slot0, a->slot1, a->logpi, a->delta, a->cslots, a->hm.prior, a->hm.data, a->eps, a->gamma0,
-                         a->gsig, a->n_alive, a->sweep, st);
-}
-#endif
+static int g_ncu = 256;
+// kernels of this tree (tools/sweep_variant_kernel.hip): the library's argument struct, grid = one tile per workgroup
 #define V(name, what) extern "C" int sweep_occ_##name(); extern "C" void sweep_launch_##name(const SmcPackedArgs*, unsigned, hipStream_t);
 #include "variants.inc"
 #undef V
+// kernels of other commits (tools/sweep_variant_tree.hip, git worktrees): their own grid, argument struct and tables
+#define T(name, what) extern "C" int sweep_occ_##name(); \
+  extern "C" void sweep_launch_##name##_raw(const uint32_t*, uint32_t*, double*, double*, double*, double*, unsigned long long*, const void*, const double*, \
+                                            double, double, double, uint32_t, uint32_t, int, hipStream_t); \
+  static void sweep_launch_##name(const SmcPackedArgs* a, unsigned, hipStream_t st) { \
+    sweep_launch_##name##_raw(a->bits, a->bits_out, a->slot0, a->slot1, a->logpi, a->delta, a->cslots, a->hm.prior, a->hm.data, a->eps, a->gamma0, \
+                              a->gsig, a->n_alive, a->sweep, g_ncu, st); }
+#include "trees.inc"
+#undef T
 #define V(name, what) {#name, what, sweep_occ_##name, sweep_launch_##name},
+#define T(name, what) {#name, what, sweep_occ_##name, sweep_launch_##name},
 static const Variant variants[] = {
 #include "variants.inc"
-#ifdef WITH_R02
-    {"r02", "round 2's kernel: Box-Muller + Philox-10, one tile per workgroup, 5 waves (git worktree _r02)", sweep_occ_r02, sweep_launch_r02},
-#endif
-#ifdef WITH_R02P7
-    {"r02p7", "round 2's kernel with Philox4x32-7", sweep_occ_r02p7, sweep_launch_r02p7},
-#endif
+#include "trees.inc"
 };
 #undef V
+#undef T
 
 // the arithmetic-free access pattern (tools/layout_bench.hip, variant P; tools/liblayout_bench.so)
 extern "C" int layout_bench_packed(uint32_t N, uint32_t M, int wf, int occ, int reps, int inner, double* ms_mean, double* ms_best);
@@ -89,7 +79,7 @@ int main(int argc, char** argv) {
   const double target_acc = argc > 3 ? atof(argv[3]) : 0.147;
   const int inner = argc > 4 ? atoi(argv[4]) : 1;    // launches back to back between the two events (sustained clocks, no idle gaps)
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
-  const int ncu = prop.multiProcessorCount;
+  const int ncu = prop.multiProcessorCount; g_ncu = ncu;
 
   double *s0, *s1, *logpi, *delta, *logpi0; uint32_t *bits, *bits_out; unsigned long long* cs;
   CK(hipMalloc(&s0, (size_t)N * 256)); CK(hipMalloc(&s1, (size_t)N * 256));
@@ -104,17 +94,13 @@ int main(int argc, char** argv) {
   abz_prior_dim hp[32]; memset(hp, 0, sizeof(hp));
   for (int k = 0; k < 32; ++k) { hp[k].family = ABZ_PRIOR_NORMAL; hp[k].p0 = 0.0; hp[k].p1 = 1.0; hp[k].c0 = -0.9189385332046727; hp[k].c1 = 1.0; }
   double hy[32]; for (int k = 0; k < 32; ++k) hy[k] = 1.0;
-  abz_prior_dim* dp; double* dy; abz_f64x2* dall; abz_tables* dtab;
+  abz_prior_dim* dp; double* dy; abz_tables* dtab;
   CK(hipMalloc(&dp, sizeof(hp))); CK(hipMemcpy(dp, hp, sizeof(hp), hipMemcpyHostToDevice));
   CK(hipMalloc(&dy, sizeof(hy))); CK(hipMemcpy(dy, hy, sizeof(hy), hipMemcpyHostToDevice));
-  CK(hipMalloc(&dall, sizeof(abz_icdf_all_data))); CK(hipMemcpy(dall, abz_icdf_all_data, sizeof(abz_icdf_all_data), hipMemcpyHostToDevice));
-  abz_tables* ht = new abz_tables(abz_tables_host);
-  for (int q = 0; q < ABZ_ICDF_PIECES; ++q) for (int r = 0; r < ABZ_ICDF_HOT_ROWS; ++r) ht->icdf_hot[q][r] = abz_icdf_all_data[q][r];
-  ht->icdf_all = dall;
-  CK(hipMalloc(&dtab, sizeof(abz_tables))); CK(hipMemcpy(dtab, ht, sizeof(abz_tables), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dtab, sizeof(abz_tables))); CK(hipMemcpy(dtab, &abz_tables_host, sizeof(abz_tables), hipMemcpyHostToDevice));
 
   SmcPackedArgs a; memset(&a, 0, sizeof(a));
-  a.hm.seed = 1; a.hm.prior = dp; a.hm.data = dy; a.hm.tables = dtab; a.hm.icdf_all = dall;
+  a.hm.seed = 1; a.hm.prior = dp; a.hm.data = dy; a.hm.tables = dtab;
   a.hm.sim_p[0] = 1.0; a.hm.d = 32; a.hm.abck = ABZ_K_INDICATOR_STRICT; a.hm.n_data = 32; a.hm.n_blob = 0;
   a.bits = bits; a.bits_out = bits_out; a.slot0 = s0; a.slot1 = s1; a.logpi = logpi; a.delta = delta;
   a.cslots = cs; a.flags = nullptr; a.stamp = nullptr; a.stop = nullptr;
@@ -122,15 +108,7 @@ int main(int argc, char** argv) {
   a.n_alive = n_alive; a.r_lo = 0; a.n_work = n_alive; a.sweep = 7; a.c_cls = ABZ_C_NACC;
 
   const int nv = (int)(sizeof(variants) / sizeof(variants[0]));
-  const unsigned ntiles = (n_alive + 127) / 128;     // positions per workgroup and loop trip (L = 4: SweepTile<4>::PB)
-  auto grid_of = [&](const Variant& v) {
-    const int occ = v.occ();
-    const int mul = getenv("GRIDMUL") ? atoi(getenv("GRIDMUL")) : 1;       // > 1: more workgroups than are resident, the hardware deals them out as slots free up
-    const uint64_t res = (uint64_t)ncu * (uint64_t)(occ > 0 ? occ : 1) * (uint64_t)(mul > 0 ? mul : 1);
-    if (ntiles <= res) return (unsigned)ntiles;
-    const uint64_t per = (ntiles + res - 1) / res;
-    return (unsigned)((ntiles + per - 1) / per);
-  };
+  auto grid_of = [&](const Variant&) { return (unsigned)(((uint64_t)n_alive * 4 + ABZ_BLOCK - 1) / ABZ_BLOCK); };   // this tree: one tile per workgroup
   auto reset = [&]() { CK(hipMemcpy(logpi, logpi0, (size_t)N * 8, hipMemcpyDeviceToDevice)); };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
