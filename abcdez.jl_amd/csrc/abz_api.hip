@@ -255,8 +255,8 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
 
 int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
   ABZ_REQUIRE(ctx, "set_stream: null context");
+  if (ctx->stream != (hipStream_t)hip_stream) ctx->ahead = abz_ahead{};      /* a select enqueued ahead sits on the old stream */
   ctx->stream = (hipStream_t)hip_stream;
-  ctx->ahead = abz_ahead{};            /* a select enqueued ahead sits on the old stream */
   return 0;
 }
 
@@ -379,8 +379,11 @@ int abcdez_ctx_set_stamps(abcdez_ctx* ctx, uint64_t* stamp_cur, uint64_t* stamp_
   ABZ_REQUIRE((stamp_cur == nullptr) == (stamp_nxt == nullptr), "set_stamps: pass both arrays or neither");
   ABZ_REQUIRE(stamp_cur == nullptr || stamp_cur != stamp_nxt, "set_stamps: the two arrays must differ");
   ABZ_REQUIRE(stamp_cur == nullptr || ctx->h_model.n_blob > 0, "set_stamps: the model was created with n_blob = 0");
+  /* hosts rebind the same arrays before every call: only a real change invalidates a select enqueued ahead (a SWAP of the two
+   * arrays follows a resample, which discards the select itself) */
+  if (!((ctx->stamp_cur == stamp_cur && ctx->stamp_nxt == stamp_nxt) || (ctx->stamp_cur == stamp_nxt && ctx->stamp_nxt == stamp_cur)))
+    ctx->ahead = abz_ahead{};
   ctx->stamp_cur = stamp_cur; ctx->stamp_nxt = stamp_nxt;
-  ctx->ahead = abz_ahead{};
   return 0;
 }
 
@@ -486,6 +489,14 @@ int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t*
   ctx->ahead = abz_ahead{};
   ctx->ahead.armed = true;
   ctx->ahead.delta = delta; ctx->ahead.alive = alive; ctx->ahead.N = N; ctx->ahead.alpha = alpha; ctx->ahead.eps_target = eps_target;
+  return 0;
+}
+
+/* Diagnostics: how many prologues found their select already enqueued behind the previous generation's sweeps, and how many had
+ * to run it themselves (the first generation, the one after a resample, or a host that invalidated it). */
+int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t* inline_runs) {
+  ABZ_REQUIRE(ctx && reused && inline_runs, "smc_select_stats: null argument");
+  *reused = ctx->n_select_reused; *inline_runs = ctx->n_select_inline;
   return 0;
 }
 

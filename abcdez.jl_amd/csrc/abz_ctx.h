@@ -28,6 +28,7 @@ struct abz_ahead {
 
 struct abcdez_ctx {
   int device = 0;
+  long long n_select_reused = 0, n_select_inline = 0;   /* prologues that found their select enqueued ahead / ran it themselves */
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
   hipStream_t stream = nullptr;
   abz_model h_model;              /* host copy; .data points at d_data          */

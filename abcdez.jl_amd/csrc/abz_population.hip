@@ -1298,7 +1298,9 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   if (ah.valid && ah.delta == delta_all && ah.alive == alive && ah.N == N && ah.n_prev == n_prev && ah.alpha == alpha &&
       ah.eps_prev == eps_prev && ah.eps_target == eps_target) {
     j = ah.j;                         /* the select (and the extrema, and eps) were enqueued behind the sweeps of the generation before */
+    ctx->n_select_reused++;
   } else {
+    ctx->n_select_inline++;
     rc = abz_prologue_select_enqueue(ctx, delta_all, alive, N, n_prev, alpha, eps_prev, eps_target, &j);
     if (rc) return rc;
   }

@@ -175,6 +175,12 @@ class HipOps:
         """forget a select armed / enqueued ahead (the population was written by other means, or the run ends)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_discard(self.ctx))
 
+    def smc_select_stats(self):
+        """(prologues that found their select enqueued ahead, prologues that ran it themselves)"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_smc_select_stats(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def smc_replay_packed(self, bits, bits_out, n_alive, skip_lo, skip_hi, slot0, slot1, logpi, flags, gamma0, gsig, sweep):
         nacc, nsim = C.c_int64(), C.c_int64()
         _lib.check(self.lib, self.lib.abcdez_smc_replay_packed(

@@ -166,6 +166,9 @@ ABCDEZ_API int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, con
 /* Forget a select armed or enqueued ahead.  Every library call that changes the distances or the flags does so itself; a host that
  * writes those arrays by other means (a copy, a resumed checkpoint), changes the stream, or ends a run calls this. */
 ABCDEZ_API int abcdez_smc_select_discard(abcdez_ctx* ctx);
+/* Diagnostics: prologues of this context that found their select enqueued ahead / that ran it themselves (the first generation,
+ * the one after a resample, after a discard).  A steady-state abcdesmc loop reuses one select per generation. */
+ABCDEZ_API int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t* inline_runs);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,

@@ -349,6 +349,17 @@ def test_abcdesmc_end_to_end_parity(oracle, name, N, abck):
     assert np.array_equal(res["alive"], c["alive"])
 
 
+def test_abcdesmc_reuses_the_select_enqueued_ahead():
+    """The rank select of generation g + 1 is enqueued behind the sweeps of generation g and the next prologue starts at the
+    reweight: only the first generation and the one after each resample run it themselves.  (Binding the same stream again
+    before every call, as the engine does, must not throw it away.)"""
+    prior, sim, eps = models()["mvn8"]
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=4096, verbose=False, rng=11, nsims_max=10 ** 8)
+    reused, inline = r.engine.ops.smc_select_stats()
+    assert abs(reused + inline - r.iters) <= 1, (reused, inline, r.iters)
+    assert reused >= (2 * r.iters) // 3, (reused, inline, r.iters)
+
+
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
                                          ("quad2d_inf", 500, 80)])
 def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
