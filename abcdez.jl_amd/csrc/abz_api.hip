@@ -180,6 +180,8 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.n_blob = model->n_blob;
   ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
   ABZ_CTX_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));
+  ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_sync, ABZ_SYNC_N * 4));
+  ABZ_CTX_CHECK(hipMemset(ctx->d_sync, 0, ABZ_SYNC_N * 4));
   {   /* both min / max banks start empty: (min key, max key) = (~0, 0) */
     unsigned long long mm[2 * ABZ_MMSLOTS * 2];
     for (int k = 0; k < 2 * ABZ_MMSLOTS * 2; ++k) mm[k] = (k & 1) ? 0ull : ~0ull;
@@ -220,6 +222,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (ctx->d_model) (void)hipFree(ctx->d_model);
   if (ctx->d_data) (void)hipFree(ctx->d_data);
   if (ctx->d_mv) (void)hipFree(ctx->d_mv);
+  if (ctx->d_sync) (void)hipFree(ctx->d_sync);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   delete ctx;
   return 0;

@@ -43,6 +43,7 @@ struct abcdez_ctx {
   bool prior_plain = false;       /* all real dimensions continuous Normal priors (abz_api.hip)                 */
   /* device scalars + pinned host mirror */
   unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
+  unsigned int* d_sync = nullptr;         /* ABZ_SYNC_N tickets of "the last block to finish does X" kernels, zero between launches */
   unsigned long long* h_scal = nullptr;   /* pinned + mapped: ABZ_S_N words + the sequence word of abz_publish */
   unsigned long long* h_scal_dev = nullptr;   /* the same memory as the device sees it */
   unsigned long long pub_seq = 0;
@@ -133,6 +134,9 @@ static inline unsigned abz_persistent_grid(abcdez_ctx* ctx, K kernel, uint64_t n
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
 
 static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+/* tickets in d_sync */
+enum { ABZ_SYNC_TILE = 0, ABZ_SYNC_N = 16 };
 
 /* scalar slots in d_scal / h_scal */
 enum {

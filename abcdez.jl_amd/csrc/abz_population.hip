@@ -121,6 +121,13 @@ struct FinishArgs {
   const double* part[2];
   double* out[2];
   int64_t n[2];
+  /* pub_host != null: the block that finishes last also publishes the scalar area to the host (what publish_kernel does):
+   * one launch and its dependency gap less per prologue */
+  unsigned int* ticket;
+  const unsigned long long* pub_scal;
+  unsigned long long* pub_host;
+  int pub_words;
+  unsigned long long pub_seq;
 };
 __device__ inline double finish_tile(const double* __restrict__ x, int64_t n, int64_t base, double* s_w) {
   const int t = threadIdx.x;
@@ -142,21 +149,36 @@ __device__ inline double finish_tile(const double* __restrict__ x, int64_t n, in
 __global__ __launch_bounds__(ABZ_BLOCK) void tree_finish_kernel(const FinishArgs a) {
   __shared__ double s_w[4];
   __shared__ double s_l1[ABZ_TILE];
+  __shared__ int s_last;
   const double* x = a.part[blockIdx.x];
   const int64_t n = a.n[blockIdx.x];
   const int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
+  double r;
   if (nt == 1) {
-    const double r = finish_tile(x, n, 0, s_w);
-    if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
-    return;
+    r = finish_tile(x, n, 0, s_w);
+  } else {
+    for (int64_t tile = 0; tile < nt; ++tile) {
+      const double v = finish_tile(x, n, tile * ABZ_TILE, s_w);
+      if (threadIdx.x == 0) s_l1[tile] = v;
+    }
+    __syncthreads();
+    r = finish_tile(s_l1, nt, 0, s_w);
   }
-  for (int64_t tile = 0; tile < nt; ++tile) {
-    const double r = finish_tile(x, n, tile * ABZ_TILE, s_w);
-    if (threadIdx.x == 0) s_l1[tile] = r;
+  if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
+  if (!a.pub_host) return;
+  if (threadIdx.x == 0) {
+    __threadfence();                                   /* this block's result before its ticket */
+    s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1u;
   }
   __syncthreads();
-  const double r = finish_tile(s_l1, nt, 0, s_w);
-  if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) *a.ticket = 0u;                /* for the next launch (same stream: nobody else is looking) */
+  for (int k = threadIdx.x; k < a.pub_words; k += ABZ_BLOCK)
+    a.pub_host[k] = __hip_atomic_load(a.pub_scal + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* past the vector L1 */
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(a.pub_host + ABZ_S_N, a.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* sums `n` elements under MODE: launches the element pass; the result is in *d_out if that was one tile, else `*pending`
@@ -172,12 +194,17 @@ static int tree_sum_begin(abcdez_ctx* ctx, TileArgs a, double* d_out, double* pa
 }
 /* finishes up to two trees in one launch (n = 0: nothing to do for that tree) */
 static int tree_finish(abcdez_ctx* ctx, const double* pa, int64_t na, double* outa, const double* pb = nullptr, int64_t nb = 0,
-                       double* outb = nullptr) {
+                       double* outb = nullptr, int pub_words = 0, unsigned long long* pub_seq = nullptr) {
   FinishArgs f{};
   int k = 0;
   if (na > 0) { f.part[k] = pa; f.n[k] = na; f.out[k] = outa; ++k; }
   if (nb > 0) { f.part[k] = pb; f.n[k] = nb; f.out[k] = outb; ++k; }
-  if (k == 0) return 0;
+  if (k == 0) return pub_seq ? abz_publish_launch(ctx, pub_words, pub_seq) : 0;
+  if (pub_seq) {
+    *pub_seq = ++ctx->pub_seq;
+    f.ticket = ctx->d_sync + ABZ_SYNC_TILE; f.pub_scal = ctx->d_scal; f.pub_host = ctx->h_scal_dev; f.pub_words = pub_words;
+    f.pub_seq = *pub_seq;
+  }
   for (int q = 0; q < k; ++q)
     if (f.n[q] > (int64_t)ABZ_TILE * ABZ_TILE) { abz_set_error("tile tree: too many partials for one finishing block"); return -3; }
   hipLaunchKernelGGL(tree_finish_kernel, dim3((unsigned)k), dim3(ABZ_BLOCK), 0, ctx->stream, f);
@@ -280,8 +307,9 @@ int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, d
   return 0;
 }
 
+/* pub_seq != null: the launch that finishes the sums also publishes the first ABZ_S_SCALARS scalars to the host */
 static int reweight_enqueue(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
-                            double eps_new, const double* eps_new_dev) {
+                            double eps_new, const double* eps_new_dev, unsigned long long* pub_seq = nullptr) {
   double *p0, *p1;
   char* rest;
   const size_t ntile = (size_t)((N + ABZ_TILE - 1) / ABZ_TILE);
@@ -303,7 +331,7 @@ static int reweight_enqueue(abcdez_ctx* ctx, const double* delta, double* wns, u
   if (rc) return rc;
   /* sum(Wns^2) and sum(alive) (tile counts: integers < 2^53, the f64 tree sum is exact) finish in one launch */
   return tree_finish(ctx, p0, pending, (double*)(ctx->d_scal + ABZ_S_SUMSQ), tile_alive, (int64_t)ntile,
-                     (double*)(ctx->d_scal + ABZ_S_NALIVE));
+                     (double*)(ctx->d_scal + ABZ_S_NALIVE), ABZ_S_SCALARS, pub_seq);
 }
 int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
                       double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
@@ -1305,14 +1333,12 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
     if (rc) return rc;
   }
   ctx->ahead.valid = false;
-  rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS));
+  unsigned long long seq = 0;
+  rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
   if (rc) return rc;
-  /* everything the host needs is known here: the scalars are published BEFORE the partition is enqueued, and the host returns
+  /* everything the host needs is known here: the scalars are published (by the launch that finishes the reweight's sums) BEFORE the partition is enqueued, and the host returns
    * (and enqueues the generation's sweeps) while the partition kernels are still running -- the round trip hides behind them.
    * A partition error (flags that do not describe a prefix) is reported by the next counter read-back instead. */
-  unsigned long long seq = 0;
-  rc = abz_publish_launch(ctx, ABZ_S_SCALARS, &seq);
-  if (rc) return rc;
   rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min);
   if (rc) return rc;
   rc = abz_publish_wait(ctx, ABZ_S_SCALARS, seq);
