@@ -11,15 +11,15 @@
  * cnt[i]          = that upper bound, #{j : Ds[j] <= Ds[i]}, for every particle of the tail (the sweep reads it
  *                   coalesced instead of searching sorted_delta: 20 dependent loads per particle).
  *
- * RANK ONLY WHO DRAWS.  eps_pop sits at 95 % of the RANGE of the distances (mc:147), so the tail is the worst few
- * particles -- a handful to a few thousand of a million, and it shrinks as the population converges.  The head needs a
- * compaction, not a sort:
+ * RANK ONLY WHO DRAWS.  abcdemc! passes alpha = 0 to mc:147, so eps_pop = max(eps_target, min Ds): the head is the converged
+ * particles, the tail everybody else -- 95 % of the population in the first generation of a run, a few per cent after forty, a
+ * handful at the end (17 % on average over the 100 generations of BASELINE configs[1]).  The head needs a compaction, not a sort:
  *   1. mcr_count / mcr_offsets / mcr_split: tail flags by wave ballots, exclusive scan of the tile counts, then every
  *      head particle goes to order[i - #tail before i] and every tail particle's (order key, index) pair to a compact
  *      list -- three launches, the population's distances read twice (no atomics: deterministic);
  *   2. a tail of up to MCR_SMALL pairs is sorted by ONE workgroup in LDS (bitonic network on (key, index)), which also
  *      finds every particle's upper bound among equal distances -- one launch;
- *   3. a longer tail (distances bounded away from a heavy tail, or a population far from convergence) goes through the
+ *   3. a longer tail (most generations of a run) goes through the
  *      stable LSD radix sort of (24-bit bucket, index) pairs + fix-up of round 2, now over the compact list only; its
  *      launches are sized from the tail the host last saw (the kernels stride over their tiles, so any size is
  *      correct) and return at once when step 2 has done the work.
