@@ -60,6 +60,9 @@ def parse():
     p.add_argument("--no-other-configs", action="store_true",
                    help="default run only: skip the other single-GPU configurations (mc1d, lv, evidence1d) reported as other_configs")
     p.add_argument("--storage", default=None, choices=["packed"], help="abcdesmc storage (one choice left: the packed population)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL, one rank per GPU (the contract); gloo = rehearsal of the N > 1 path on a box with fewer GPUs "
+                        "than ranks: the ranks share the visible GPUs, collectives go through the host")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -406,12 +409,16 @@ def run_config(args):
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.dist_backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     pg = None
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device), rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     d = cfg["d"]

@@ -33,3 +33,40 @@ def test_bench_prints_one_json_line_with_the_contract_fields(cfg, particles, ste
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["value"] > 0
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("cfg,particles", [("smc32", 32768), ("mc1d", 65536)])
+def test_bench_two_ranks_print_one_line(cfg, particles):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one JSON line from rank 0, aggregate value), rehearsed
+    on the one GPU of the test box: both ranks share it and the collectives go through gloo (`--dist-backend gloo`)."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", cfg, "--particles-per-gpu", str(particles), "--dist-backend", "gloo", "--no-cpu-baseline", "--no-whole-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
+    assert "x2" in d["config"]["parallelism"]
+    if cfg == "smc32":
+        assert d["config"]["particles_total"] == 2 * particles
+        assert set(d["sharded_phases_ms"]) >= {"own_sweep", "flag_allgather", "replay"}
+
+
+def test_bench_sharded_path_in_a_one_rank_rccl_group():
+    """the sharded code path of the bench (flag all-gather + replay + grouped sweeps) over RCCL itself, in a group of one rank"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--particles-per-gpu", "65536",
+           "--force-collectives", "--no-cpu-baseline", "--no-whole-run", "--no-pattern"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "sharded_phases_ms" in d
