@@ -177,6 +177,8 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
   for (int q = 0; q < 8; ++q) ctx->hot.sim_p[q] = model->sim_p[q];
+  ctx->hot.sim_i[0] = model->sim_id == ABZ_SIM_LV ? (int32_t)model->sim_p[3] : 0;
+  ctx->hot.sim_i[1] = 0;
   ctx->hot.d = model->d; ctx->hot.abck = model->abck; ctx->hot.n_data = model->n_data; ctx->hot.n_blob = model->n_blob;
   ABZ_CTX_CHECK(hipMalloc((void**)&ctx->d_scal, ABZ_S_N * 8));
   ABZ_CTX_CHECK(hipMemset(ctx->d_scal, 0, ABZ_S_N * 8));

@@ -338,7 +338,10 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     const double a = th[0], b = th[1], c = th[2], e = th[3];
     double x = M.sim_p[0], y = M.sim_p[1];
     const double h = M.sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
-    const int steps = (int)M.sim_p[3];
+    /* the trip count as an integer kernel argument (scalar register): taken from the f64 parameter it would be born in a vector
+     * register -- there is no scalar f64 -> i32 conversion -- and the compiler would keep the loop counter there, two of the loop's
+     * 32 vector instructions */
+    const int steps = M.sim_i[0];
     const double sn = M.sim_p[4];
     const int nobs = M.n_data / 2;
     double acc = 0.0;

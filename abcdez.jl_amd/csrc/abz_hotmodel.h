@@ -16,6 +16,7 @@ struct HotModel {
   const double* mv;             /* NULL, or [mu | W | L] of a correlated Normal prior (abcdez_spec.h), device memory */
   double sim_p[8];
   int32_t d, abck, n_data, n_blob;
+  int32_t sim_i[2];             /* integer forms of simulator parameters: [0] = RK4 steps per observation (Lotka-Volterra, sim_p[3]) */
 };
 
 /* cumulative sweep-counter slots (abz_ctx.h, ABZ_S_CSLOT0): ABZ_CSLOTS slots of ABZ_CSTRIDE u64 (one 64-B line);
