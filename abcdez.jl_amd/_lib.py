@@ -42,6 +42,7 @@ PROTOTYPES = {
     "abcdez_smc_select_ahead": [_vp, _vp, _vp, _i64, _f64, _f64],
     "abcdez_smc_select_discard": [_vp],
     "abcdez_smc_select_stats": [_vp, _pi64, _pi64],
+    "abcdez_mc_rank_stats": [_vp, _pi64, _pi64, _pi64],
     "abcdez_smc_sweeps_packed": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _i32, _f64, _pi64, _pi64,
                                  C.POINTER(_i32)],
     "abcdez_smc_replay_packed": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],

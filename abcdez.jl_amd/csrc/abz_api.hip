@@ -17,7 +17,7 @@ int abz_select_impl(abcdez_ctx*, const double*, const uint8_t*, int64_t, int64_t
 int abz_extrema_impl(abcdez_ctx*, const double*, int64_t, double*, double*);
 int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
-int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*, int64_t);
+int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*, int64_t, int64_t);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
 int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
@@ -60,6 +60,14 @@ static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static void default_shape(const abz_model& m, int* L, int* C) {
   if (m.sim_id == ABZ_SIM_MVN && m.ld > 8) { *C = 8; *L = m.ld / 8; }
   else { *L = 1; *C = m.ld; }
+}
+
+/* the population was written by something other than the next asynchronous abcdemc generation */
+static inline void abz_population_written(abcdez_ctx* ctx) {
+  ctx->ahead = abz_ahead{};
+  ctx->mc_chain += 1;
+  ctx->mc_tail_bound = -1;
+  ctx->mc_tail_hint = -1;
 }
 
 extern "C" {
@@ -340,7 +348,13 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
   ctx->cnt_prev[ABZ_C_MCSIM] = ts;
   ctx->cnt_prev[ABZ_C_MCGT] = tg;
-  if (snap[5] != ~0ull) ctx->mc_tail_hint = (long long)snap[5];     /* the next rank pass sizes its long-tail launches from this */
+  if (snap[5] != ~0ull && ctx->ring_chain[slot] == ctx->mc_chain) {
+    ctx->mc_tail_hint = (long long)snap[5];        /* the next rank pass sizes its long-tail launches from this */
+    double eps_pop;
+    const unsigned long long e = snap[4];
+    memcpy(&eps_pop, &e, 8);
+    if (eps_pop == ctx->ring_eps_target[slot]) ctx->mc_tail_bound = (long long)snap[5];   /* abz_ctx.h: from here on the tail only shrinks */
+  }
   ctx->ring_folded[slot] = true;
 }
 /* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
@@ -409,7 +423,7 @@ int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp
 
 int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
   ABZ_REQUIRE(ctx && theta && logpi && delta, "init: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= ABZ_MAX_N, "init: range out of bounds");
   ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_INITBAD, 0, 8, ctx->stream));
   int rc = abz_launch_init(ctx, theta, logpi, delta, i0, n);
@@ -424,7 +438,7 @@ int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, in
 int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
                          uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns) {
   ABZ_REQUIRE(ctx && alive && bits && bits_other && slot0 && slot1 && logpi && delta && wns, "smc_partition: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 0 <= n_new && n_new <= n_prev && n_prev <= N, "smc_partition: need 0 <= n_new <= n_prev <= N");
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_partition: the two bit arrays / slots must differ");
   return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns, nullptr, 0.0);
@@ -456,7 +470,7 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
                             int64_t r_hi, double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags,
                             double eps, double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && delta, "smc_swarm_packed: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_packed: pass both counters or neither");
   /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
@@ -502,6 +516,14 @@ int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t*
 int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t* inline_runs) {
   ABZ_REQUIRE(ctx && reused && inline_runs, "smc_select_stats: null argument");
   *reused = ctx->n_select_reused; *inline_runs = ctx->n_select_inline;
+  return 0;
+}
+
+/* Diagnostics: rank passes of abcdemc generations that launched both sorts of the tail / only the one-workgroup LDS sort / only the
+ * radix sort (the host launches one alone when it holds a proved bound of the tail's length, abcdez_mc_generation_async). */
+int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, int64_t* long_only) {
+  ABZ_REQUIRE(ctx && both && small_only && long_only, "mc_rank_stats: null argument");
+  *both = ctx->n_rank_paths[0]; *small_only = ctx->n_rank_paths[1]; *long_only = ctx->n_rank_paths[2];
   return 0;
 }
 
@@ -592,7 +614,7 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
                              int64_t skip_hi, double* slot0, double* slot1, double* logpi, const uint8_t* flags,
                              double gamma0, double gamma_sigma, uint32_t sweep, int64_t* nacc, int64_t* nsim) {
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags && nacc && nsim, "smc_replay_packed: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
   ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
@@ -681,7 +703,7 @@ int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int
                                       double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
   ABZ_REQUIRE(ctx && inds && bits && bits_other && slot0 && slot1 && logpi && delta && nlogpi && ndelta && wns && alive,
               "smc_resample_gather_packed: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_packed: N out of range");
   ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1 && bits != bits_other,
               "smc_resample_gather_packed: in/out arrays must differ");
@@ -699,7 +721,7 @@ int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const
 int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_old,
                         double eps_new, double* wnorm, double* ess, int64_t* n_alive) {
   ABZ_REQUIRE(ctx && delta && wns && alive && wnorm && ess && n_alive, "smc_reweight: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_reweight: N out of range");
   ABZ_REQUIRE(eps_old >= 0.0 && eps_new >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
   return abz_reweight_impl(ctx, delta, wns, alive, N, eps_old, eps_new, wnorm, ess, n_alive);
@@ -730,7 +752,7 @@ int abcdez_wsample_stratified(abcdez_ctx* ctx, const double* wns, int64_t N, uin
 int abcdez_quantile_alive(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t n_alive_hint,
                           double p, double* q, double* xj, double* xj1) {
   ABZ_REQUIRE(ctx && delta && alive && q, "quantile_alive: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "quantile_alive: N out of range");
   ABZ_REQUIRE(p >= 0.0 && p <= 1.0, "quantile_alive: p must be in [0, 1]");
   int64_t n = n_alive_hint, n_le;
@@ -773,7 +795,7 @@ int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, doub
   ABZ_REQUIRE(ctx && delta && order && sorted_delta && cnt, "mc_rank_prepare: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "mc_rank_prepare: N out of range");
   ABZ_REQUIRE(eps_pop == eps_pop, "mc_rank_prepare: eps_pop is NaN");
-  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt, nullptr, -1);
+  return abz_rank_prepare_impl(ctx, delta, N, eps_pop, dmax_hint, order, sorted_delta, cnt, nullptr, -1, -1);
 }
 
 int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, int64_t N, const double* theta,
@@ -782,7 +804,7 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
                     uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax) {
   ABZ_REQUIRE(ctx && order && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
               "mc_swarm: null argument");
-  ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
+  abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
@@ -843,13 +865,18 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     ABZ_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
   }
   int rc = 0;
+  /* a new chain: host-given extrema (the first generation of a run), other parameters, another population than the one the
+   * generation before wrote (its outputs are this generation's inputs) */
+  if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N) {
+    ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1;
+  }
   if (lo_hi || !ctx->mc_window_ready || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target) {
     rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
     if (rc) return rc;
   }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
   const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
   if (do_rank) {                     /* mc:20-24 is only reached while some Ds[i] > eps */
-    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint);
+    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound);
     if (rc) return rc;
   }
   rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
@@ -857,6 +884,8 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   if (rc) return rc;
   const int slot = (int)(ctx->mc_issued % ABZ_MC_RING);
   ctx->ring_folded[slot] = false;
+  ctx->ring_chain[slot] = ctx->mc_chain; ctx->ring_eps_target[slot] = eps_target;
+  ctx->mc_last_out = (const void*)ndelta; ctx->mc_last_N = N;
   rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull,
                               alpha, eps_target, do_rank ? ctx->mc_rank_state : nullptr);
   if (rc) return rc;

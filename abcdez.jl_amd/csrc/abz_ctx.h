@@ -77,6 +77,18 @@ struct abcdez_ctx {
   unsigned long long* d_ring = nullptr;           /* the same memory as the device sees it */
   bool ring_folded[ABZ_MC_RING] = {false};
   long long ring_res[ABZ_MC_RING][2] = {{0, 0}};  /* (nsim, #above target) once folded */
+  long long ring_chain[ABZ_MC_RING] = {0};        /* which chain of generations the ticket belongs to (mc_chain when it was issued) */
+  double ring_eps_target[ABZ_MC_RING] = {0.0};
+  /* A chain = consecutive asynchronous generations on one population with one (alpha, eps_target); anything else that writes
+   * distances breaks it.  Once a generation of the chain ran with eps_pop == eps_target, the particles that draw (Ds > eps_pop)
+   * can only become fewer: the converged ones never leave (they accept only dp <= eps_target, mc:52), the others accept only
+   * dp <= Ds[i], and lo + alpha (hi - lo) does not grow -- so that generation's tail length BOUNDS every later one's, and the
+   * rank pass launches only the path that bound calls for (abz_sort.hip). */
+  long long mc_chain = 0;
+  const void* mc_last_out = nullptr;              /* distances the last asynchronous generation wrote, and their length */
+  int64_t mc_last_N = 0;
+  long long n_rank_paths[3] = {0, 0, 0};          /* rank passes that launched both sorts / only the LDS sort / only the radix sort */
+  long long mc_tail_bound = -1;                   /* proved upper bound of the tail length of the chain's next generations; -1 = none */
   long long mc_issued = 0, mc_waited = 0;
   bool mc_have_bank = false;
   bool mc_window_ready = false;                   /* the last snapshot kernel left the next generation's window for (mc_alpha, mc_eps_target) */

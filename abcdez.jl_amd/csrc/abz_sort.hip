@@ -196,10 +196,11 @@ __global__ __launch_bounds__(MCR_SMALL_THREADS) void mcr_tail_small_kernel(const
 template <int PASS>
 __global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const uint32_t* __restrict__ state, const unsigned long long* __restrict__ tk,
                                                              unsigned long long klo, int shift, uint32_t* __restrict__ key,
-                                                             uint32_t* __restrict__ table, const unsigned long long* __restrict__ win) {
+                                                             uint32_t* __restrict__ table, const unsigned long long* __restrict__ win,
+                                                             uint32_t small_limit) {
   __shared__ uint32_t s_h[MCR_WAVES][256];
   const uint32_t n = state[MCR_ST_NTAIL];
-  if (n <= MCR_SMALL) return;
+  if (n <= small_limit) return;
   if (PASS == 0 && win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; shift = (int)win[ABZ_S_MCW_SHIFT - ABZ_S_MCW_EPS]; }
   const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -232,10 +233,10 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_hist_kernel(const uint32_t* __r
 /* offsets, step 1: block d turns the tile counts of digit d into their exclusive prefix over the tiles and leaves the digit's
  * total in totals[d].  Step 2 -- the exclusive scan of the 256 totals -- is done by every scattering wave for itself. */
 __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scan_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ table,
-                                                             uint32_t* __restrict__ totals) {
+                                                             uint32_t* __restrict__ totals, uint32_t small_limit) {
   __shared__ uint32_t s_part[ABZ_BLOCK];
   const uint32_t n = state[MCR_ST_NTAIL];
-  if (n <= MCR_SMALL) return;
+  if (n <= small_limit) return;
   const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
   uint32_t* v = table + (size_t)blockIdx.x * ntiles;
   const uint32_t t = threadIdx.x;
@@ -266,10 +267,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ totals, uint32_t* __restrict__ key_out,
                                                                 uint32_t* __restrict__ val_out,
                                                                 const double* __restrict__ delta, uint32_t* __restrict__ order,
-                                                                double* __restrict__ sorted_delta, uint32_t* __restrict__ cnt_of) {
+                                                                double* __restrict__ sorted_delta, uint32_t* __restrict__ cnt_of,
+                                                                uint32_t small_limit) {
   __shared__ uint32_t s_run[MCR_WAVES][256];
   const uint32_t n = state[MCR_ST_NTAIL], nh = state[MCR_ST_NHEAD];
-  if (n <= MCR_SMALL) return;
+  if (n <= small_limit) return;
   const uint32_t ntiles = (n + MCR_TILE - 1) / MCR_TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   volatile uint32_t* run = s_run[wave];
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_scatter_kernel(const uint32_t* 
 __global__ __launch_bounds__(ABZ_BLOCK) void mcr_fixup_kernel(const uint32_t* __restrict__ state, const uint32_t* __restrict__ bucket,
                                                               uint32_t* __restrict__ order_all,
                                                               double* __restrict__ sorted_delta_all,
-                                                              uint32_t* __restrict__ cnt) {
+                                                              uint32_t* __restrict__ cnt, uint32_t small_limit) {
   const uint32_t n = state[MCR_ST_NTAIL], nh = state[MCR_ST_NHEAD];
-  if (n <= MCR_SMALL) return;
+  if (n <= small_limit) return;
   uint32_t* order = order_all + nh;
   double* sorted_delta = sorted_delta_all + nh;
   for (uint32_t p = blockIdx.x * ABZ_BLOCK + threadIdx.x; p < n; p += gridDim.x * ABZ_BLOCK) {
@@ -465,7 +467,8 @@ int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot
 /* win: NULL = (eps_pop, dmax_hint) are host values; else the device window mc_window_kernel wrote (the two host values are
  * ignored).  tail_hint: the length of the tail the host last saw (< 0: unknown) -- sizes the launches of the long-tail path. */
 int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
-                          uint32_t* order, double* sorted_delta, uint32_t* cnt, const unsigned long long* win, int64_t tail_hint) {
+                          uint32_t* order, double* sorted_delta, uint32_t* cnt, const unsigned long long* win, int64_t tail_hint,
+                          int64_t tail_bound) {
   const uint32_t n = (uint32_t)N;
   /* window of the binning: (eps_pop, dmax_hint] in key space -> 2^24 - 2 buckets */
   const unsigned long long klo = host_order_key(eps_pop);
@@ -480,8 +483,8 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;
   const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
   /* step 3 is sized for the tail the host expects (4 x the last one seen, at least 16 K pairs; everything when it knows
-   * nothing); its kernels stride, so a longer tail is sorted correctly, only slower */
-  uint64_t expect = tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
+   * nothing; a proved bound is exact); its kernels stride, so a longer tail is sorted correctly, only slower */
+  uint64_t expect = tail_bound >= 0 ? (uint64_t)tail_bound : tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
   if (expect > n) expect = n;
   const uint32_t ltiles_max = (n + MCR_TILE - 1) / MCR_TILE;                 /* tiles of a tail that is the whole population */
   uint32_t ltiles = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
@@ -507,22 +510,31 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   hipLaunchKernelGGL(mcr_offsets_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, tile_cnt, ntiles, n, state);
   hipLaunchKernelGGL(mcr_split_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, eps_pop, tile_cnt, ntiles, rounds, order,
                      sorted_delta, tk, tv, win);
-  hipLaunchKernelGGL(mcr_tail_small_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, state, tk, tv, order, sorted_delta, cnt);
-  /* the long-tail path: pass 0 (tk -> keyA; tv) -> (keyB, valB); pass 1 -> (keyA, tv); pass 2 -> (keyB = buckets, order) */
-  hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
-                     order, sorted_delta, cnt);
-  hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyB, table, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyB, valB, table, totals, keyA, tv, delta,
-                     order, sorted_delta, cnt);
-  hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win);
-  hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals);
-  hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
-                     order, sorted_delta, cnt);
-  hipLaunchKernelGGL(mcr_fixup_kernel, dim3((unsigned)(((uint64_t)ltiles * MCR_TILE + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, st,
-                     state, keyB, order, sorted_delta, cnt);
+  /* which sort: both paths are launched (each looks at the tail's length on the device and the wrong one returns at once) unless
+   * the host holds a PROVED upper bound of that length (abz_ctx.h, mc_tail_bound): then only the path the bound calls for */
+  const bool small_path = tail_bound < 0 || tail_bound <= (int64_t)MCR_SMALL;
+  const bool long_path = tail_bound < 0 || tail_bound > (int64_t)MCR_SMALL;
+  ctx->n_rank_paths[small_path && long_path ? 0 : small_path ? 1 : 2] += 1;
+  const uint32_t lim = small_path ? (uint32_t)MCR_SMALL : 0u;      /* tails up to here are the LDS sort's; 0: the radix sort takes any length */
+  if (small_path)
+    hipLaunchKernelGGL(mcr_tail_small_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, state, tk, tv, order, sorted_delta, cnt);
+  if (long_path) {
+    /* pass 0 (tk -> keyA; tv) -> (keyB, valB); pass 1 -> (keyA, tv); pass 2 -> (keyB = buckets, order) */
+    hipLaunchKernelGGL((mcr_hist_kernel<0>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win, lim);
+    hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals, lim);
+    hipLaunchKernelGGL((mcr_scatter_kernel<0, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
+                       order, sorted_delta, cnt, lim);
+    hipLaunchKernelGGL((mcr_hist_kernel<1>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyB, table, win, lim);
+    hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals, lim);
+    hipLaunchKernelGGL((mcr_scatter_kernel<1, false>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyB, valB, table, totals, keyA, tv, delta,
+                       order, sorted_delta, cnt, lim);
+    hipLaunchKernelGGL((mcr_hist_kernel<2>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, tk, klo, shift, keyA, table, win, lim);
+    hipLaunchKernelGGL(mcr_scan_kernel, dim3(256), dim3(ABZ_BLOCK), 0, st, state, table, totals, lim);
+    hipLaunchKernelGGL((mcr_scatter_kernel<2, true>), dim3(lgrid), dim3(ABZ_BLOCK), 0, st, state, keyA, tv, table, totals, keyB, valB, delta,
+                       order, sorted_delta, cnt, lim);
+    hipLaunchKernelGGL(mcr_fixup_kernel, dim3((unsigned)(((uint64_t)ltiles * MCR_TILE + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, st,
+                       state, keyB, order, sorted_delta, cnt, lim);
+  }
   ctx->mc_rank_state = state;       /* the snapshot kernel of an asynchronous generation reports the tail's length from here */
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;

@@ -175,6 +175,12 @@ class HipOps:
         """forget a select armed / enqueued ahead (the population was written by other means, or the run ends)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_discard(self.ctx))
 
+    def mc_rank_stats(self):
+        """rank passes that launched (both sorts, only the LDS sort, only the radix sort)"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_mc_rank_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def smc_select_stats(self):
         """(prologues that found their select enqueued ahead, prologues that ran it themselves)"""
         a, b = C.c_int64(), C.c_int64()

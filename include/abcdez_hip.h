@@ -169,6 +169,10 @@ ABCDEZ_API int abcdez_smc_select_discard(abcdez_ctx* ctx);
 /* Diagnostics: prologues of this context that found their select enqueued ahead / that ran it themselves (the first generation,
  * the one after a resample, after a discard).  A steady-state abcdesmc loop reuses one select per generation. */
 ABCDEZ_API int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t* inline_runs);
+/* Diagnostics: rank passes (abcdez_mc_generation_async / abcdez_mc_rank_prepare) that launched both sorts of the tail, only the
+ * one-workgroup LDS sort, only the radix sort.  One alone is launched when the host holds a proved upper bound of the tail's length:
+ * once a generation of a chain of asynchronous generations ran with eps_pop == eps_target, the particles that draw only become fewer. */
+ABCDEZ_API int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, int64_t* long_only);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,

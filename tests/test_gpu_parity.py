@@ -361,14 +361,20 @@ def test_abcdesmc_reuses_the_select_enqueued_ahead():
 
 
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
-                                         ("quad2d_inf", 500, 80)])
+                                         ("quad2d_inf", 500, 80), ("normal1d", 60000, 70)])
 def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
+    """(N = 60000: the particles that draw go from 95 % of the population to below the 4096 one workgroup sorts in LDS while the run
+    is under way, so the rank pass is seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix
+    sort, on tails longer AND shorter than 4096, then only the LDS sort.)"""
     prior, sim, eps = models()[name]
     r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=gens, verbose=False, rng=13)
     c = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=13), N, eps, gens)
     res = r.engine.result()
     assert r.nsims == c["nsims"] and r.reached_ϵ == c["reached_eps"]
     assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"])
+    if N == 60000:
+        both, small_only, long_only = r.engine.ops.mc_rank_stats()
+        assert both >= 1 and small_only >= 1 and long_only >= 1, (both, small_only, long_only)
 
 
 def test_smoke_entry():
