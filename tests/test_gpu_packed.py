@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import abcdez_amd as A
+from abcdez_amd import _lib
 from abcdez_amd.engine import PACKED_ALIGN, HipOps, PopulationEngine
 
 pytestmark = pytest.mark.gpu
@@ -223,6 +224,80 @@ def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
         e.buf[0][0].copy_(full["s0"]); e.buf[1][0].copy_(full["s1"]); cur[1].copy_(full["lp"]); cur[2].copy_(full["dl"])
         e.bits[1 - e.bc].copy_(full["b"][1])
         e.bc = 1 - e.bc
+
+
+@pytest.mark.parametrize("name", ["mvn8", "normal1d"])
+def test_sharded_group_of_sweeps_on_three_replicas(oracle, name):
+    """abcdez_smc_group_begin / _replay / _publish / _end: three "ranks" (three contexts, three replicas on one GPU) enqueue the
+    Kmcmc sweeps of a generation back to back -- own range, merged flags, replay with the device-side test of smc:352 -- and read
+    back once.  Every rank must report the counters and the Ki of the single-GPU grouped sweeps (abcdez_smc_sweeps_packed) and
+    hold its population, for thresholds that stop after the first sweep, in the middle, and never; misuse is an error."""
+    prior, sim, eps_target = models()[name]
+    N, G = 20000 + 333, 3
+    spec = A.ModelSpec(prior, sim, seed=9)
+    e = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    e.init_population(); e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps = e.quantile_alive(0.7)
+    e.smc_reweight(math.inf, eps)
+    n = e.alive_compact()
+    chunk = -(-(-(-n // G)) // PACKED_ALIGN) * PACKED_ALIGN
+    cuts = [min(r * chunk, n) for r in range(G + 1)]
+    cur = e.buf[e.cur]
+    ranks = [HipOps(spec) for _ in range(G)]
+
+    def replica():
+        return dict(s0=e.buf[0][0].clone(), s1=e.buf[1][0].clone(), lp=cur[1].clone(), dl=cur[2].clone(),
+                    b=[e.bits[e.bc].clone(), e.bits[1 - e.bc].clone()], fl=torch.zeros(N + G * PACKED_ALIGN, dtype=torch.uint8, device="cuda"))
+
+    ops0 = ranks[0]
+    with pytest.raises(_lib.AbcdezError, match="no group open"):
+        ops0.smc_group_replay(e.bits[0], e.bits[1], 0, 64, e.buf[0][0], e.buf[1][0], cur[1], replica()["fl"], g0, 1e-5, 0)
+    with pytest.raises(_lib.AbcdezError, match="no group open"):
+        ops0.smc_group_end(3)
+    ops0.smc_group_begin(n, 1.0)
+    with pytest.raises(_lib.AbcdezError, match="already open"):
+        ops0.smc_group_begin(n, 1.0)
+    with pytest.raises(_lib.AbcdezError, match="no sweep"):
+        ops0.smc_group_end(3)                                   # (closes nothing: a group without a sweep cannot be read back)
+    full0 = replica()
+    with pytest.raises(_lib.AbcdezError, match="group_end"):    # inside a group the counters come from the group's read-back
+        ops0.smc_swarm_packed(full0["b"][0], full0["b"][1], n, 0, n, full0["s0"], full0["s1"], full0["lp"], full0["dl"], full0["fl"],
+                              eps, g0, 1e-5, e.sweep)
+    ranks[0] = HipOps(spec)                                     # (a fresh context for the runs below)
+
+    seen = set()
+    sweep0 = e.sweep
+    for K, kmin in ((3, 9.0), (3, 0.0), (4, 0.6), (5, 0.3), (6, 1.0)):
+        full = replica()
+        want = e.ops.smc_sweeps_packed(full["b"][0], full["b"][1], n, full["s0"], full["s1"], full["lp"], full["dl"], eps, g0, 1e-5,
+                                       sweep0, K, kmin)
+        reps = [replica() for _ in range(G)]
+        for ops in ranks:
+            ops.smc_group_begin(n, kmin)
+        for k in range(K):
+            i, o = k & 1, 1 - (k & 1)
+            for r, (ops, rep) in enumerate(zip(ranks, reps)):
+                assert ops.smc_swarm_packed(rep["b"][i], rep["b"][o], n, cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"], rep["dl"],
+                                            rep["fl"], eps, g0, 1e-5, sweep0 + k, want_counts=False) is None
+            merged = torch.zeros_like(full["fl"])               # the all-gather of the flag chunks (every rank takes part, stopped or not)
+            for r, rep in enumerate(reps):
+                merged[cuts[r]:cuts[r + 1]] = rep["fl"][cuts[r]:cuts[r + 1]]
+            for r, (ops, rep) in enumerate(zip(ranks, reps)):
+                ops.smc_group_replay(rep["b"][i], rep["b"][o], cuts[r], cuts[r + 1], rep["s0"], rep["s1"], rep["lp"], merged, g0, 1e-5,
+                                     sweep0 + k)
+        for r, (ops, rep) in enumerate(zip(ranks, reps)):
+            ops.smc_group_publish()
+            got = ops.smc_group_end(K)
+            assert got == want, (K, kmin, r, got, want)
+            Ki = got[2]
+            for key in ("s0", "s1", "lp"):
+                assert same(rep[key], full[key]), (K, kmin, r, key)
+            assert same(rep["b"][Ki & 1], full["b"][Ki & 1])
+            own = slice(cuts[r], cuts[r + 1])
+            assert same(rep["dl"][own], full["dl"][own])
+        seen.add("first" if want[2] == 1 else "all" if want[2] == K else "middle")
+    assert seen == {"first", "all", "middle"}, seen
 
 
 @pytest.mark.parametrize("name", ["normal1d", "mvn32", "mvn3"])
