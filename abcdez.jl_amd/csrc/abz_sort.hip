@@ -14,9 +14,9 @@
  * RANK ONLY WHO DRAWS.  abcdemc! passes alpha = 0 to mc:147, so eps_pop = max(eps_target, min Ds): the head is the converged
  * particles, the tail everybody else -- 95 % of the population in the first generation of a run, a few per cent after forty, a
  * handful at the end (17 % on average over the 100 generations of BASELINE configs[1]).  The head needs a compaction, not a sort:
- *   1. mcr_count / mcr_offsets / mcr_split: tail flags by wave ballots, exclusive scan of the tile counts, then every
- *      head particle goes to order[i - #tail before i] and every tail particle's (order key, index) pair to a compact
- *      list -- three launches, the population's distances read twice (no atomics: deterministic);
+ *   1. mcr_count / mcr_split: tail flags by wave ballots and per-tile counts, then -- every workgroup adds up the counts in front of
+ *      its tiles itself -- every head particle goes to order[i - #tail before i] and every tail particle's (order key, index)
+ *      pair to a compact list: two launches, the population's distances read twice (no atomics: deterministic);
  *   2. a tail of up to MCR_SMALL pairs is sorted by ONE workgroup in LDS (bitonic network on (key, index)), which also
  *      finds every particle's upper bound among equal distances -- one launch;
  *   3. a longer tail (most generations of a run) goes through the
@@ -72,41 +72,39 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_count_kernel(const double* __re
   if (lane == 0) tile_cnt[tile] = c;
 }
 
-/* ---- step 1b: exclusive scan of the tile counts (one workgroup), totals into the state */
-__global__ __launch_bounds__(MCR_SMALL_THREADS) void mcr_offsets_kernel(uint32_t* __restrict__ tile_cnt, uint32_t ntiles, uint32_t n,
-                                                                        uint32_t* __restrict__ state) {
-  __shared__ uint32_t s_part[MCR_SMALL_THREADS];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (ntiles + MCR_SMALL_THREADS - 1) / MCR_SMALL_THREADS;
-  const uint32_t lo = t * per < ntiles ? t * per : ntiles, hi = lo + per < ntiles ? lo + per : ntiles;
-  uint32_t s = 0;
-  for (uint32_t k = lo; k < hi; ++k) s += tile_cnt[k];
-  s_part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < MCR_SMALL_THREADS; off <<= 1) {
-    const uint32_t add = t >= off ? s_part[t - off] : 0;
-    __syncthreads();
-    s_part[t] += add;
-    __syncthreads();
-  }
-  uint32_t run = t ? s_part[t - 1] : 0;
-  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = tile_cnt[k]; tile_cnt[k] = run; run += c; }
-  if (t == MCR_SMALL_THREADS - 1) { state[MCR_ST_NTAIL] = s_part[t]; state[MCR_ST_NHEAD] = n - s_part[t]; }
-}
-
-/* ---- step 1c: the head in index order, the tail as a compact list of (order key, index) pairs */
+/* ---- step 1b: the head in index order, the tail as a compact list of (order key, index) pairs.  A workgroup adds up the counts of
+ * the tiles in front of its own (at most 4096 counts, 16 KB from L2 -- cheaper than the one-workgroup scan launch that used to sit
+ * between the two passes); the workgroup that holds the last tile leaves the totals in the state. */
 __global__ __launch_bounds__(ABZ_BLOCK) void mcr_split_kernel(const double* __restrict__ delta, uint32_t n, unsigned long long klo,
-                                                              double eps_pop, const uint32_t* __restrict__ tile_off, uint32_t ntiles,
+                                                              double eps_pop, const uint32_t* __restrict__ tile_cnt, uint32_t ntiles,
                                                               uint32_t rounds, uint32_t* __restrict__ order,
                                                               double* __restrict__ sorted_delta, unsigned long long* __restrict__ tk,
-                                                              uint32_t* __restrict__ tv, const unsigned long long* __restrict__ win) {
+                                                              uint32_t* __restrict__ tv, const unsigned long long* __restrict__ win,
+                                                              uint32_t* __restrict__ state) {
+  __shared__ uint32_t s_pre[MCR_WAVES];
   if (win) { klo = win[ABZ_S_MCW_KLO - ABZ_S_MCW_EPS]; eps_pop = abz_u2d(win[0]); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
+  const uint32_t tile0 = blockIdx.x * MCR_WAVES;
+  uint32_t before = 0;
+  for (uint32_t k = threadIdx.x; k < tile0; k += ABZ_BLOCK) before += tile_cnt[k];
+  for (int off = 32; off; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0) s_pre[wave] = before;
+  __syncthreads();
+  before = 0;
+  for (int w = 0; w < MCR_WAVES; ++w) before += s_pre[w];                       /* tail particles in front of the workgroup's tiles */
+  uint32_t own[MCR_WAVES];
+  for (int w = 0; w < MCR_WAVES; ++w) own[w] = tile0 + (uint32_t)w < ntiles ? tile_cnt[tile0 + (uint32_t)w] : 0u;
+  if (threadIdx.x == 0 && tile0 + MCR_WAVES >= ntiles) {                        /* the workgroup with the last tile */
+    uint32_t tot = before;
+    for (int w = 0; w < MCR_WAVES; ++w) tot += own[w];
+    state[MCR_ST_NTAIL] = tot; state[MCR_ST_NHEAD] = n - tot;
+  }
+  const uint32_t tile = tile0 + (uint32_t)wave;
   if (tile >= ntiles) return;
   const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t running = tile_off[tile];                 /* tail particles in front of this round (wave-uniform) */
+  uint32_t running = before;                         /* tail particles in front of this round (wave-uniform) */
+  for (int w = 0; w < wave; ++w) running += own[w];
   for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {
     double x[MCR_BATCH];
     bool in[MCR_BATCH];
@@ -507,9 +505,8 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   const unsigned lgrid = (ltiles + MCR_WAVES - 1) / MCR_WAVES;
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(mcr_count_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, tile_cnt, ntiles, rounds, win);
-  hipLaunchKernelGGL(mcr_offsets_kernel, dim3(1), dim3(MCR_SMALL_THREADS), 0, st, tile_cnt, ntiles, n, state);
   hipLaunchKernelGGL(mcr_split_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, eps_pop, tile_cnt, ntiles, rounds, order,
-                     sorted_delta, tk, tv, win);
+                     sorted_delta, tk, tv, win, state);
   /* which sort: both paths are launched (each looks at the tail's length on the device and the wrong one returns at once) unless
    * the host holds a PROVED upper bound of that length (abz_ctx.h, mc_tail_bound): then only the path the bound calls for */
   const bool small_path = tail_bound < 0 || tail_bound <= (int64_t)MCR_SMALL;
