@@ -68,6 +68,9 @@ struct abcdez_ctx {
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
   bool timing = false, timing_first_only = false;
+  int timing_stride = 1;                          /* of the launches that would be bracketed only every timing_stride-th is */
+  long long timing_seq = 0, timing_rot = 0;
+  bool ring_timed[ABZ_MC_RING] = {false};         /* was the sweep of that asynchronous generation bracketed */
   long long ev_head = 0, ev_tail = 0;             /* FIFO of sweeps timed but not yet read: pair k lives in slot k % ABZ_GROUP_MAX */
   hipEvent_t ev[2 * ABZ_GROUP_MAX] = {nullptr};
   long long ev_units[ABZ_GROUP_MAX] = {0};
@@ -193,6 +196,7 @@ int abz_launch_init(abcdez_ctx*, double*, double*, double*, int64_t, int64_t);
 /* HIP-event timing of the sweep kernels: bracket a launch; the pairs are read at the next counter read-back */
 static inline int abz_time_begin(abcdez_ctx* ctx) {
   if (!ctx->timing || ctx->ev_tail - ctx->ev_head >= ABZ_GROUP_MAX) return -1;
+  if (ctx->timing_stride > 1 && (ctx->timing_seq++ % ctx->timing_stride) != 0) return -1;
   const int k = (int)(ctx->ev_tail % ABZ_GROUP_MAX);
   (void)hipEventRecord(ctx->ev[2 * k], ctx->stream);
   return k;

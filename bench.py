@@ -440,7 +440,12 @@ def run_config(args):
         gen.step()
     if hasattr(gen, "flush"):
         gen.flush()
-    eng.ops.set_timing(2)              # HIP events around the first sweep of every generation (around all three: -1 % of value)
+    # HIP events around ONE sweep of every 2nd SMC generation (the 1st, 2nd, 3rd of the generation's sweeps in turn: the first runs
+    # on a population the partition has just moved and is a few per cent slower than its siblings) / the sweep of every 4th
+    # abcdemc generation: an event pair costs ~9 us of queue time (tools/launch_floor.hip) -- 0.6 % of an SMC generation, 7 % of
+    # an abcdemc generation
+    tstride = 2 if cfg["kind"] == "smc" else 4
+    eng.ops.set_timing(2 + 256 * tstride)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()
@@ -525,6 +530,7 @@ def run_config(args):
             },
             "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N),
         }
+        out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (around one of their sweeps, in turn)
         if cfg["kind"] == "mc":
             out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
         if whole is not None:
