@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# The CPU-baseline leg of one configuration runs the OpenMP oracle on every host core right before the next configuration's timed
+# window: idle OpenMP workers must sleep, not spin, or they compete with the thread that polls the GPU's read-backs.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
