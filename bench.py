@@ -454,8 +454,13 @@ def run_config(args):
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("ABZ_BENCH_TRACE_STEPS") else None       # diagnostic: per-step host times to stderr
     for _ in range(steps):
         gen.step()
+        if trace is not None:
+            trace.append(time.perf_counter())
+    if trace is not None:
+        print(args.config, "step ms:", [round((b - a) * 1e3, 3) for a, b in zip([t0] + trace[:-1], trace)], file=sys.stderr)
     if hasattr(gen, "flush"):
         gen.flush()                     # results of the generations still in flight (abcdemc runs ahead of its read-backs)
     barrier()
@@ -543,9 +548,13 @@ def run_config(args):
         if eng.sharded_packed:    # rank 0's device-event breakdown of the sharded sweep
             out["sharded_phases_ms"] = {k: {"calls": c, "avg_ms": (t / c if c else 0.0)} for k, (c, t) in phases.items()}
         if world == 1 and not args.no_cpu_baseline:
-            faithful, out["cpu_baseline"] = cpu_baseline(A, args, cfg)
-            if faithful:
-                out["cpu_baseline_reference_faithful"] = faithful
+            if getattr(args, "defer_cpu", None) is not None:
+                # the default run measures every configuration's GPU window first and the CPU legs afterwards: 256 OpenMP threads
+                # that have just finished (and the host memory they touched) disturbed the next configuration's window on some
+                # boxes of the pool (a 12 ms window took 29 ms)
+                args.defer_cpu.append((out, A, args, cfg))
+            else:
+                fill_cpu_baseline(out, A, args, cfg)
         return out, pg
     return None, pg
 
@@ -553,6 +562,12 @@ def run_config(args):
 OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "updates_per_launch",
               "kernel_updates_per_s", "traffic", "traffic_over_moved_bytes", "traffic_source", "acceptance_rate", "flops_per_update",
               "rk4_steps_per_s", "bytes_read_per_update")
+
+
+def fill_cpu_baseline(out, A, args, cfg):
+    faithful, out["cpu_baseline"] = cpu_baseline(A, args, cfg)
+    if faithful:
+        out["cpu_baseline_reference_faithful"] = faithful
 
 
 def other_config(args, name):
@@ -566,6 +581,8 @@ def other_config(args, name):
     a.cpu_particles, a.no_pattern = None, True
     a.cpu_steps = {"mc1d": 4, "lv": 3, "evidence1d": 3}[name]
     a.no_whole_run = name != "evidence1d"          # the evidence configuration's result IS the whole run: both logZ, the Bayes factor
+    deferred = []
+    a.defer_cpu = deferred if getattr(args, "defer_cpu", None) is not None else None
     r, _ = run_config(a)
     gc.collect()
     torch.cuda.empty_cache()
@@ -576,11 +593,14 @@ def other_config(args, name):
     for k in ("cpu_baseline", "whole_run"):
         if k in r:
             out[k] = r[k]
+    for (_, A, aa, cfg) in deferred:               # the CPU leg of this configuration fills the summary, later
+        args.defer_cpu.append((out, A, aa, cfg))
     return out
 
 
 def main():
     args = parse()
+    args.defer_cpu = []            # GPU windows of every configuration first, CPU baselines afterwards
     out, pg = run_config(args)
     if out is not None and args.config == "smc32" and out["n_gpus"] == 1 and not args.no_other_configs and not args.force_collectives:
         # every other single-GPU configuration BASELINE.json names, in the same run (the headline stays configs[2])
@@ -590,6 +610,11 @@ def main():
                 out["other_configs"][name] = other_config(args, name)
             except Exception as e:                     # a failing side configuration must not cost the headline line
                 out["other_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
+    for (o, A, aa, cfg) in args.defer_cpu:
+        try:
+            fill_cpu_baseline(o, A, aa, cfg)
+        except Exception as e:
+            o["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if out is not None:
         try:                      # RCCL's start-up banner sits in libc's stdio buffer: push it out BEFORE the result line
             import ctypes
