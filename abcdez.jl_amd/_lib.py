@@ -49,6 +49,7 @@ PROTOTYPES = {
     "abcdez_smc_group_begin": [_vp, _i64, _f64],
     "abcdez_smc_group_replay": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32],
     "abcdez_smc_group_publish": [_vp],
+    "abcdez_smc_group_abort": [_vp],
     "abcdez_smc_group_end": [_vp, _pi64, _pi64, C.POINTER(_i32)],
     "abcdez_smc_resample_gather_packed": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "abcdez_packed_gather": [_vp, _vp, _i64, _vp, _vp, _vp],
@@ -72,7 +73,7 @@ PROTOTYPES = {
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
 # symbols with a non-status return type
-OTHER_SYMBOLS = ("abcdez_version", "abcdez_last_error", "abcdez_abi_layout")
+OTHER_SYMBOLS = ("abcdez_version", "abcdez_rng_rounds", "abcdez_last_error", "abcdez_abi_layout")
 
 
 class AbcdezError(RuntimeError):
@@ -101,6 +102,7 @@ def load():
     lib.abcdez_abi_layout.argtypes = [C.POINTER(_i32), C.c_int]
     lib.abcdez_abi_layout.restype = C.c_int
     lib.abcdez_version.restype = C.c_int
+    lib.abcdez_rng_rounds.restype = C.c_int
     lib.abcdez_last_error.restype = C.c_char_p
     _LIB = lib
     return lib

@@ -62,17 +62,22 @@ static void default_shape(const abz_model& m, int* L, int* C) {
   else { *L = 1; *C = m.ld; }
 }
 
-/* the population was written by something other than the next asynchronous abcdemc generation */
-static inline void abz_population_written(abcdez_ctx* ctx) {
-  ctx->ahead = abz_ahead{};
+/* an abcdemc chain (abz_ctx.h) ends: its proved tail bound and hint were made for distances that are being rewritten */
+static inline void abz_mc_chain_break(abcdez_ctx* ctx) {
   ctx->mc_chain += 1;
   ctx->mc_tail_bound = -1;
   ctx->mc_tail_hint = -1;
 }
+/* the population was written by something other than the next asynchronous abcdemc generation */
+static inline void abz_population_written(abcdez_ctx* ctx) {
+  ctx->ahead = abz_ahead{};
+  abz_mc_chain_break(ctx);
+}
 
 extern "C" {
 
-int abcdez_version(void) { return 200; }
+int abcdez_version(void) { return 400; }       /* round 4: Philox4x32-10 again, abz_model.mv, group abort */
+int abcdez_rng_rounds(void) { return ABZ_PHILOX_ROUNDS; }
 
 /* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
  * shim, the ctypes binding) can assert its layout instead of trusting it */
@@ -325,11 +330,13 @@ static inline double f64_from_order_key_host(unsigned long long k) {
   const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
   double x; memcpy(&x, &u, 8); return x;
 }
-/* consumes up to `n` completed event pairs of the timing FIFO; only the first `count` of them are launches that did work */
-static int timing_consume(abcdez_ctx* ctx, long long n, long long count) {
+/* consumes up to `n` completed event pairs of the timing FIFO; a pair counts only if the sweep it brackets did work: its index
+ * inside its group of sweeps is below `done` (a group may end early -- the launches enqueued behind a test of smc:352 that
+ * held return at once and are not launches of the roofline figure); done < 0 = every pair counts */
+static int timing_consume(abcdez_ctx* ctx, long long n, long long done) {
   for (long long k = 0; k < n && ctx->ev_head < ctx->ev_tail; ++k, ++ctx->ev_head) {
-    if (k >= count) continue;
     const int slot = (int)(ctx->ev_head % ABZ_GROUP_MAX);
+    if (done >= 0 && ctx->ev_sweep[slot] >= done) continue;
     float ms = 0.f;
     ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
     ctx->swarm_ms += (double)ms;
@@ -357,8 +364,8 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   }
   ctx->ring_folded[slot] = true;
 }
-/* ran_limit: of the sweeps timed since the last read-back only the first ran_limit did work (a group of sweeps may
- * end early: the later launches return at once and are not launches of the roofline figure); < 0 = all of them */
+/* ran_limit: of the sweeps timed since the last read-back only those with an index below ran_limit inside their group did
+ * work; < 0 = all of them */
 /* second half of a counter read-back (the scalars are in h_scal): ring generations first, baseline, timing events */
 static int read_counters_finish(abcdez_ctx* ctx, int ran_limit) {
   /* generations still in the ring (complete: everything before the publish kernel has run): their counters come first,
@@ -366,7 +373,7 @@ static int read_counters_finish(abcdez_ctx* ctx, int ran_limit) {
   for (long long t = ctx->mc_waited; t < ctx->mc_issued; ++t) ring_fold(ctx, t);
   abz_fold_counters(ctx);
   const long long n_ev = ctx->ev_tail - ctx->ev_head;
-  return timing_consume(ctx, n_ev, ran_limit < 0 ? n_ev : ran_limit);
+  return timing_consume(ctx, n_ev, ran_limit);
 }
 static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
   if (int rc = abz_publish(ctx, ABZ_S_N)) return rc;
@@ -421,6 +428,7 @@ int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp
   ABZ_REQUIRE(ctx->h_model.n_blob > 0, "blob_eval: the model was created with n_blob = 0");
   ABZ_REQUIRE(N >= 0 && N <= ABZ_MAX_N, "blob_eval: N out of range");
   const uint32_t nbw = (uint32_t)(ctx->h_model.sim_id == ABZ_SIM_MVN ? ctx->h_model.ld : ctx->h_model.n_blob);
+  abz_population_written(ctx);         /* delta_out may be a distance array the library has state about */
   return abz_launch_blob_eval(ctx, theta, stamp, N, blob, delta_out, nbw);
 }
 
@@ -458,6 +466,7 @@ int abcdez_smc_prologue_packed(abcdez_ctx* ctx, double* delta, double* wns, uint
   ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0, "smc_prologue_packed: alpha must be in [0, 1]");
   ABZ_REQUIRE(eps_k_old >= 0.0 && eps_target >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_prologue_packed: the two bit arrays / slots must differ");
+  abz_mc_chain_break(ctx);             /* the partition moves distances: an abcdemc chain no longer describes them */
   double out[6];
   int rc = abz_prologue_packed_impl(ctx, delta, N, n_prev, wns, alive, alpha, eps_prev, eps_target, eps_k_old, ess_min, bits,
                                     bits_other, slot0, slot1, logpi, delta, out, n_alive, partitioned);
@@ -486,8 +495,10 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
     ABZ_REQUIRE(nacc == nullptr, "smc_swarm_packed: inside a group of sweeps the counters come from abcdez_smc_group_end");
     if (ctx->grp_k > 0) stop = ctx->d_scal + ABZ_S_GRP_STOP;
   }
+  ctx->cur_sweep_k = ctx->grp_k > 0 ? ctx->grp_k : 0;
   int rc = abz_launch_smc_swarm_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)r_lo, (uint32_t)r_hi, slot0, slot1,
                                        logpi, delta, flags, eps, gamma0, gamma_sigma, sweep, nacc != nullptr, stop);
+  ctx->cur_sweep_k = 0;
   if (rc || !nacc) return rc;       /* no counters wanted: no host synchronisation (smc_replay_packed reports totals) */
   rc = read_counters(ctx);
   if (rc) return rc;
@@ -535,7 +546,7 @@ int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, in
  * here -- otherwise a later prologue with equal arguments would reuse eps and extrema made from the old contents. */
 int abcdez_smc_select_discard(abcdez_ctx* ctx) {
   ABZ_REQUIRE(ctx, "smc_select_discard: null context");
-  ctx->ahead = abz_ahead{};
+  abz_population_written(ctx);         /* also ends an abcdemc chain: its tail bound was proved for the old distances */
   return 0;
 }
 
@@ -550,6 +561,7 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   ABZ_REQUIRE(1 <= k_max && k_max <= ABZ_GROUP_MAX, "smc_sweeps_packed: 1 <= k_max <= 16 sweeps per call");
   ABZ_REQUIRE(slot0 != slot1 && bits_a != bits_b, "smc_sweeps_packed: the two slots / bit arrays must differ");
   ABZ_REQUIRE(kmcmc_min >= 0.0, "smc_sweeps_packed: Kmcmc_min must not be negative");
+  abz_mc_chain_break(ctx);             /* the sweeps write distances */
   /* the group's acceptances are counted from the (nacc, nsim) slot totals at the last read-back.  Every call that adds to those
    * two classes reads them back before it returns; a sweep launched WITHOUT counters (abcdez_smc_swarm_packed with nacc = NULL,
    * the sharded path) adds to the ABZ_C_DISCARD classes instead, so it cannot leak into the device-side test of smc:352 */
@@ -564,10 +576,12 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
     uint32_t* out = (k & 1) ? bits_a : bits_b;
     const bool timing = ctx->timing;
     if (ctx->timing_first_only && k != timed_k) ctx->timing = false;
+    ctx->cur_sweep_k = k;
     int rc = abz_launch_smc_swarm_packed(ctx, in, out, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, slot1, logpi, delta,
                                          nullptr, eps, gamma0, gamma_sigma, sweep0 + (uint32_t)k, 1,
                                          k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
     ctx->timing = timing;
+    ctx->cur_sweep_k = 0;
     if (rc) return rc;
     if (k + 1 < k_max) {             /* nothing is decided after the last sweep: its counters are the totals the host reads anyway */
       rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min, ABZ_C_NACC);
@@ -594,8 +608,9 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   const bool stopped = k_max > 1 && ctx->h_scal[ABZ_S_GRP_STOP] != 0;
   const int done = stopped ? (int)ctx->h_scal[ABZ_S_GRP_DONE] : k_max;
   ABZ_REQUIRE(1 <= done && done <= k_max, "smc_sweeps_packed: inconsistent sweep count read back");
-  /* mode 2 brackets one sweep of the group; if the test of smc:352 held before it, that launch returned at once and is not counted */
-  if (int rc = read_counters_finish(ctx, ctx->timing_first_only ? (timed_k < done ? 1 : 0) : done)) return rc;
+  /* every event pair carries the index of the sweep it brackets: one enqueued behind a test of smc:352 that held returned at
+   * once and is not counted (whatever the timing mode and stride) */
+  if (int rc = read_counters_finish(ctx, done)) return rc;
   unsigned long long pa = base_acc, ps = base_sim;
   for (int k = 0; k < k_max; ++k) {
     if (k < done) {
@@ -666,6 +681,7 @@ int abcdez_smc_group_replay(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
               "smc_group_replay: the own range must start and end at multiples of 64 positions (or at n_alive)");
   ABZ_REQUIRE(slot0 != slot1 && bits != bits_out, "smc_group_replay: the two slots / bit arrays must differ");
   const int k = ctx->grp_k;
+  abz_mc_chain_break(ctx);
   int rc = abz_launch_smc_replay_packed(ctx, bits, bits_out, (uint32_t)n_alive, (uint32_t)skip_lo, (uint32_t)skip_hi, slot0, slot1,
                                         logpi, flags, gamma0, gamma_sigma, sweep, k ? ctx->d_scal + ABZ_S_GRP_STOP : nullptr);
   if (rc) return rc;
@@ -673,6 +689,18 @@ int abcdez_smc_group_replay(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   if (rc) return rc;
   ctx->grp_k = k + 1;
   return 0;
+}
+/* Abandon an open group (a collective or a launch failed between _begin and _end): the context accepts a new group and the
+ * counter-returning calls again.  Event pairs of the abandoned sweeps are dropped, the counter baselines re-read. */
+int abcdez_smc_group_abort(abcdez_ctx* ctx) {
+  ABZ_REQUIRE(ctx, "smc_group_abort: null context");
+  if (ctx->grp_k < 0) return 0;
+  ctx->grp_k = -1; ctx->grp_pub = 0;
+  abz_population_written(ctx);
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->ev_head = ctx->ev_tail;                               /* timing pairs of the abandoned sweeps */
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_GRP_STOP, 0, 16, ctx->stream));
+  return read_counters(ctx, 0);                              /* baselines := the slots' totals now */
 }
 int abcdez_smc_group_publish(abcdez_ctx* ctx) {
   ABZ_REQUIRE(ctx && ctx->grp_k > 0 && ctx->grp_pub == 0, "smc_group_publish: needs an open group with at least one sweep");
@@ -690,7 +718,7 @@ int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t*
    * held after sweep GRP_DONE (the later launches returned at once) */
   const int done = (int)ctx->h_scal[ABZ_S_GRP_DONE];
   ABZ_REQUIRE(1 <= done && done <= k_max, "smc_group_end: inconsistent sweep count read back");
-  if (int rc = read_counters_finish(ctx, -1)) return rc;
+  if (int rc = read_counters_finish(ctx, done)) return rc;      /* own-range sweeps behind a test that held are not launches that did work */
   unsigned long long pa = ctx->grp_base_acc, ps = ctx->grp_base_sim;
   for (int k = 0; k < k_max; ++k) {
     if (k < done) {
@@ -924,6 +952,15 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   }
   ring_fold(ctx, ticket);
   ctx->mc_waited += 1;
+  if (snap[6] != 0ull) {
+    /* only the one-workgroup sort was launched for this generation (a proved tail bound <= 4096) and the tail was longer: the
+     * distances were written behind the library's back.  The generation's sweep drew its better particles from a stale
+     * enumeration; nothing after it can be trusted.  (abcdez_population_written / abcdez_smc_select_discard tell the library.) */
+    abz_population_written(ctx);
+    abz_set_error("mc_generation_wait: the rank pass of this generation was launched for a tail bound that no longer held "
+                  "(the distances were written outside the library without abcdez_smc_select_discard); its results are invalid");
+    return -3;
+  }
   *nsim = (int64_t)ctx->ring_res[slot][0];
   if (n_above_target) *n_above_target = (int64_t)ctx->ring_res[slot][1];
   if (dmin) *dmin = f64_from_order_key_host(snap[2]);
@@ -931,7 +968,7 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   if (eps_pop) { const unsigned long long e = snap[4]; memcpy(eps_pop, &e, 8); }
   if (!ctx->timing || !ctx->ring_timed[slot]) return 0;
   ABZ_HIP_CHECK(hipEventSynchronize(ctx->ev[2 * (int)(ctx->ev_head % ABZ_GROUP_MAX) + 1]));   /* the sweep's own end event */
-  return timing_consume(ctx, 1, 1);
+  return timing_consume(ctx, 1, -1);
 }
 
 int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out) {

@@ -14,7 +14,7 @@
 
 #define ABZ_GROUP_MAX 16    /* sweeps per abcdez_smc_sweeps_packed call */
 #define ABZ_MC_RING 8       /* abcdemc generations in flight (abcdez_mc_generation_async) */
-#define ABZ_RING_WORDS 8    /* per generation: total #(Ds > eps_target), total nsim (cumulative), min key, max key, eps_pop, -, -, ticket + 1 */
+#define ABZ_RING_WORDS 8    /* per generation: total #(Ds > eps_target), total nsim (cumulative), min key, max key, eps_pop, tail length, rank-pass error, ticket + 1 */
 
 /* abcdez_smc_select_ahead: armed = start the next generation's select behind the next grouped sweeps; valid = it has been
  * enqueued for exactly these arguments and nothing has touched the distances / flags since */
@@ -74,6 +74,8 @@ struct abcdez_ctx {
   long long ev_head = 0, ev_tail = 0;             /* FIFO of sweeps timed but not yet read: pair k lives in slot k % ABZ_GROUP_MAX */
   hipEvent_t ev[2 * ABZ_GROUP_MAX] = {nullptr};
   long long ev_units[ABZ_GROUP_MAX] = {0};
+  int ev_sweep[ABZ_GROUP_MAX] = {0};              /* which sweep of its group the pair brackets (0 outside groups) */
+  int cur_sweep_k = 0;                            /* set by the callers of the sweep launcher */
   /* abcdemc generations enqueued without a host synchronisation (abcdez_mc_generation_async): a ring of pinned snapshots of
    * the scalar area, one per generation in flight, each behind its own event; tickets are issued and redeemed in order */
   unsigned long long* h_ring = nullptr;           /* ABZ_MC_RING x ABZ_RING_WORDS u64, pinned + mapped: written BY a kernel */
@@ -102,6 +104,7 @@ struct abcdez_ctx {
   double grp_kmin = 0.0;
   unsigned long long grp_base_acc = 0, grp_base_sim = 0, grp_pub = 0;
   const uint32_t* mc_rank_state = nullptr;        /* state words of the last rank pass (abz_sort.hip), in the workspace */
+  uint32_t mc_rank_limit = 0xFFFFFFFFu;           /* longest tail the sorts that pass launched can handle (only the LDS sort: 4096) */
   long long mc_tail_hint = -1;                    /* particles that drew in the last generation the host has seen; -1 = unknown */
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
@@ -205,6 +208,7 @@ static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
   if (k < 0) return;
   (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
   ctx->ev_units[k] = units;
+  ctx->ev_sweep[k] = ctx->cur_sweep_k;
   ctx->ev_tail += 1;
 }
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,

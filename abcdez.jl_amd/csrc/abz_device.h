@@ -165,29 +165,35 @@ __device__ inline double group_tree_sum(const double (&x)[C]) {
 }
 
 /* ---- correlated Normal prior (abcdez_spec.h, abz_model.mv): out_k = sum_{m <= k} mat[k][m] in_m for the lane's components k,
- * accumulated left to right with fma exactly as abz_mv_whiten1 / abz_mv_forward1 do.  The group's vector is spread over its
- * L lanes: it is exchanged through a per-group LDS row (a group sits inside one wavefront, whose LDS operations execute in
- * order, so no barrier is needed) and the sum runs as a plain loop over m -- small code, few registers; only the kernels of
- * non-plain priors contain it. */
+ * accumulated left to right (m ascending) with fma exactly as abz_mv_whiten1 / abz_mv_forward1 do.  The group's vector is spread
+ * over its L lanes; component m = mm 2L + 2 jl + b lives in register 2 mm + b of lane jl, so walking (mm, jl, b) in that order
+ * visits m in ascending order with compile-time register indices and one lane broadcast per component (ds_bpermute; a group sits
+ * inside one wavefront).  No LDS array: the kernels of priors that are not correlated carry the branch but pay nothing for it
+ * (round 3 exchanged the vector through a static 256 C 8-byte LDS row that every non-plain kernel was charged for). */
 template <int L, int C>
 __device__ inline void group_lower_matvec(const double* __restrict__ mat, int j, const double (&in)[C], double (&out)[C]) {
   constexpr int LD = L * C;
-  __shared__ double s_vec[ABZ_BLOCK / L][LD];
-  double* row = s_vec[threadIdx.x / L];
 #pragma unroll
-  for (int q = 0; q < C; ++q) { row[Lay<L, C>::comp(j, q / 2, q & 1)] = in[q]; out[q] = 0.0; }
-  __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < C; ++q) out[q] = 0.0;
+  const int lane0 = (int)(threadIdx.x & 63u) - j;          /* first lane of the group */
+#pragma unroll
+  for (int mm = 0; mm < (C + 1) / 2; ++mm) {
 #pragma unroll 1
-  for (int m = 0; m < LD; ++m) {
-    const double xm = row[m];
+    for (int jl = 0; jl < L; ++jl) {
 #pragma unroll
-    for (int q = 0; q < C; ++q) {
-      const int k = Lay<L, C>::comp(j, q / 2, q & 1);
-      const double t = abz_fma(mat[(size_t)k * LD + m], xm, out[q]);
-      out[q] = m <= k ? t : out[q];
+      for (int b = 0; b < 2; ++b) {
+        if (2 * mm + b >= C) continue;
+        const int m = Lay<L, C>::comp(jl, mm, b);
+        const double xm = L == 1 ? in[2 * mm + b] : __shfl(in[2 * mm + b], lane0 + jl, 64);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+          const int k = Lay<L, C>::comp(j, q / 2, q & 1);
+          const double t = abz_fma(mat[(size_t)k * LD + m], xm, out[q]);
+          out[q] = m <= k ? t : out[q];
+        }
+      }
     }
   }
-  __builtin_amdgcn_wave_barrier();
 }
 
 /* ---- push_p + log prior of the lane's components (priors.jl:40-46, types.jl:20-23) */

@@ -425,7 +425,8 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
  * binning window (mc_window_write) are made here and the next generation starts without a window launch.            */
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
                                                                  unsigned long long* __restrict__ out, unsigned long long seq,
-                                                                 double alpha, double eps_target, const uint32_t* __restrict__ rank_state) {
+                                                                 double alpha, double eps_target, const uint32_t* __restrict__ rank_state,
+                                                                 uint32_t rank_limit) {
   __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
   unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
@@ -449,6 +450,9 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
     out[0] = tg; out[1] = ts; out[2] = mn; out[3] = mx;        /* wave 0 holds the bank's extrema */
     out[4] = scal[ABZ_S_MCW_EPS];
     out[5] = rank_state ? (unsigned long long)rank_state[MCR_ST_NTAIL] : ~0ull;   /* how many particles drew (sizes the next rank pass) */
+    /* fail safe: the rank pass launched ONLY the LDS sort on the strength of a tail bound, and the tail turned out longer -- the
+     * enumeration the sweep drew from was not built.  The host turns this word into an error when it redeems the ticket.    */
+    out[6] = (rank_state && rank_state[MCR_ST_NTAIL] > rank_limit) ? 1ull : 0ull;
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
 int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha,
                            double eps_target, const uint32_t* rank_state) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
-  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target, rank_state);
+  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target, rank_state,
+                     ctx->mc_rank_limit);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -532,6 +537,7 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
     hipLaunchKernelGGL(mcr_fixup_kernel, dim3((unsigned)(((uint64_t)ltiles * MCR_TILE + ABZ_BLOCK - 1) / ABZ_BLOCK)), dim3(ABZ_BLOCK), 0, st,
                        state, keyB, order, sorted_delta, cnt, lim);
   }
+  ctx->mc_rank_limit = long_path ? 0xFFFFFFFFu : (uint32_t)MCR_SMALL;   /* longest tail the launched path(s) can sort */
   ctx->mc_rank_state = state;       /* the snapshot kernel of an asynchronous generation reports the tail's length from here */
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;

@@ -166,6 +166,14 @@ class HipOps:
     def smc_group_publish(self):
         _lib.check(self.lib, self.lib.abcdez_smc_group_publish(self.ctx))
 
+    def smc_group_abort(self):
+        """abandon an open group after a failure between begin and end (no-op when none is open)"""
+        _lib.check(self.lib, self.lib.abcdez_smc_group_abort(self.ctx))
+
+    def stream_version(self):
+        """(library version, Philox rounds): what every random number of a run depends on -- stored in checkpoints"""
+        return int(self.lib.abcdez_version()), int(self.lib.abcdez_rng_rounds())
+
     def smc_group_end(self, k_max):
         nacc, nsim, done = (C.c_int64 * k_max)(), (C.c_int64 * k_max)(), C.c_int32()
         _lib.check(self.lib, self.lib.abcdez_smc_group_end(self.ctx, nacc, nsim, C.byref(done)))
@@ -704,25 +712,34 @@ class PopulationEngine:
             self._delta_work = None
         cur = self.buf[self.cur]
         self.ops.smc_group_begin(self.n_alive, Kmcmc_min)
-        bc = self.bc
-        for k in range(Kmcmc):
-            b_in, b_out = self.bits[bc], self.bits[1 - bc]
-            self._mark("own_sweep", 0)
-            self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
-                                      cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep + k, want_counts=False)
-            self._mark("own_sweep", 1)
-            self._mark("flag_allgather", 0)
-            self._allgather_chunks(self.flags)               # executed by every rank whether or not the sweep ran
-            self._mark("flag_allgather", 1)
-            self._mark("replay", 0)
-            self.ops.smc_group_replay(b_in, b_out, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0], cur[1], self.flags,
-                                      gamma0, gsig, self.sweep + k)
-            self._mark("replay", 1)
-            bc = 1 - bc
-        self.ops.smc_group_publish()
-        self._delta_stale = True
-        self._start_delta_allgather()                        # behind the read-back: travels while the host applies its rules
-        naccs, nsims, Ki = self.ops.smc_group_end(Kmcmc)
+        try:
+            bc = self.bc
+            for k in range(Kmcmc):
+                b_in, b_out = self.bits[bc], self.bits[1 - bc]
+                self._mark("own_sweep", 0)
+                self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                          cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep + k, want_counts=False)
+                self._mark("own_sweep", 1)
+                self._mark("flag_allgather", 0)
+                self._allgather_chunks(self.flags)               # executed by every rank whether or not the sweep ran
+                self._mark("flag_allgather", 1)
+                self._mark("replay", 0)
+                self.ops.smc_group_replay(b_in, b_out, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0], cur[1], self.flags,
+                                          gamma0, gsig, self.sweep + k)
+                self._mark("replay", 1)
+                bc = 1 - bc
+            self.ops.smc_group_publish()
+            self._delta_stale = True
+            self._start_delta_allgather()                        # behind the read-back: travels while the host applies its rules
+            naccs, nsims, Ki = self.ops.smc_group_end(Kmcmc)
+        except BaseException:
+            # a collective or a launch failed half way: close the group, or every later call of this context is refused
+            if hasattr(self.ops, "smc_group_abort"):
+                try:
+                    self.ops.smc_group_abort()
+                except Exception:
+                    pass
+            raise
         self.sweep += Ki
         if Ki & 1:
             self.bc = 1 - self.bc
@@ -835,6 +852,8 @@ class PopulationEngine:
             "wns": self.wns.cpu().numpy().copy(), "alive": self.alive.cpu().numpy().copy(),
             "sweep": int(self.sweep), "draw": int(self.draw), "N": self.N, "ld": int(th.shape[1]),
             "seed": int(self.spec.seed),
+            # every random number after the resume depends on the library's stream: (ABI version, Philox rounds)
+            "stream_version": list(self.ops.stream_version()) if hasattr(self.ops, "stream_version") else None,
         }
 
     def upload_state(self, st: dict):
@@ -849,6 +868,15 @@ class PopulationEngine:
                              f"the engine expects {tuple(self.buf[0][0].shape)}")
         if int(st.get("seed", self.spec.seed)) != int(self.spec.seed):
             raise ValueError("checkpoint was written with a different seed: the run would not continue its own stream")
+        mine = list(self.ops.stream_version()) if hasattr(self.ops, "stream_version") else None
+        theirs = st.get("stream_version")
+        if mine is not None and theirs is not None and list(theirs)[1:] != mine[1:]:
+            raise ValueError(f"checkpoint was written by a build with Philox4x32-{list(theirs)[1]}, this library runs "
+                             f"Philox4x32-{mine[1]}: the run would not continue its own stream")
+        if mine is not None and theirs is None:
+            import warnings
+            warnings.warn("checkpoint carries no stream_version (written before round 4): it resumes bit for bit only if it "
+                          f"was written by a Philox4x32-{mine[1]} build", stacklevel=2)
         self.cur = 0
         cur = self.buf[0]
         cur[0].copy_(th)
@@ -871,6 +899,17 @@ class PopulationEngine:
         self._delta_stale = False
 
     # ------------------------------------------------------------------ results (smc:382-393, mc:166-171)
+    def posterior_mean(self) -> np.ndarray:
+        """Weighted mean of the population, sum(Wns theta) / sum(Wns) over the d parameters -- for the indicator kernels the
+        mean of the alive particles, what the reference's tests extract as mean(r.P[r.Wns .> 0.0]) (test/runtests.jl:159-162);
+        abcdemc (no weights): the plain mean.  A result / measurement helper (one torch reduction), not part of the loop."""
+        self._stream()
+        th = self.state[0][:, :self.spec.d]
+        if not self.packed:
+            return th.mean(dim=0).cpu().numpy()
+        w = self.wns
+        return ((w[:, None] * th).sum(dim=0) / w.sum()).cpu().numpy()
+
     def result(self):
         self._stream()
         th, lp, dl = self.state

@@ -16,7 +16,11 @@ The other single-GPU configurations of BASELINE.json print the same JSON shape:
     lv          configs[3]: Lotka-Volterra RK4 (dt 0.01, 1500 steps per update), abcdesmc, 2^20 particles
     evidence1d  configs[4]: the two models of examples/minimal_example.jl, abcdesmc, 2^23 particles
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+N > 1: `python bench.py --gpus N ...` starts its own ranks (a child `python -m torch.distributed.run`, one rank per GPU over
+RCCL; the parent never imports torch or touches a GPU) and relays rank 0's ONE JSON line and the children's exit code;
+launched under torch.distributed.run (WORLD_SIZE set) it is a rank.  `--scaling weak` (default for smc32 / mc1d): the
+configuration's population PER GPU; `--scaling strong` (default for lv / evidence1d, whose BASELINE sizes are totals over
+8 GPUs): the configuration's population in total, split over the ranks.
 """
 import argparse
 import json
@@ -35,7 +39,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming, 5.5-5.8 random rows)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (FMA = 2 flop): half the 157.3 TFLOP/s fp32 vector rate of the guide
-PROFILE_TAG = "r03"
+FP64_VALU_PEAK_ORIGIN = ("nominal: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s "
+                         "fp32 VECTOR rate MI355X_MICROARCH.md lists (the guide gives no fp64 vector figure; its 78.6 'FP64 matrix' "
+                         "entry is the same number); tools/valu_rate.hip measures 5.4 instead of 4 cycles per v_fma_f64 wave-instruction "
+                         "under dense fp64, so the sustained rate of the part is ~0.74 of this peak (profiles/r02_valu_rate.jsonl)")
+PROFILE_TAG = "r04"
 
 
 def profile_json(name):
@@ -56,6 +64,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--config", default="smc32", choices=sorted(CONFIGS))
     p.add_argument("--particles-per-gpu", type=int, default=None)
+    p.add_argument("--particles-total", type=int, default=None, help="strong scaling: the population split over the ranks")
+    p.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                   help="weak: the configuration's population per GPU; strong: in total (BASELINE.json configs[3] = --config lv "
+                        "--gpus 8, configs[4] = --config evidence1d --gpus 8).  Default: weak for smc32 / mc1d, strong for lv / evidence1d")
     p.add_argument("--dim", type=int, default=32, help="smc32 only")
     p.add_argument("--lanes", type=int, default=0, help="lanes per particle (0 = library default)")
     p.add_argument("--cpu-particles", type=int, default=None, help="population of the CPU-oracle baseline sample")
@@ -167,7 +179,8 @@ def cfg_smc32(A, args):
                 cpu_particles=1 << 22, cpu_steps=10, storage="packed",
                 workload=f"abcdesmc d={d} MVN simulator + Euclidean distance (BASELINE.json configs[2]); "
                          "alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
-                exact_logZ=-8.111642 if d == 32 else None)
+                exact_logZ=-8.111642 if d == 32 else None,
+                exact_post_mean=EXACT["post_mean_mvn32_eps6"] if d == 32 else None)
 
 
 def cfg_mc1d(A, args):
@@ -175,7 +188,7 @@ def cfg_mc1d(A, args):
                 steps=100, warmup=0, cpu_particles=1 << 20, cpu_steps=8, storage="classic",
                 workload="abcdemc 1-D Normal simulator, data 3, eps 0.3 (BASELINE.json configs[1]); steps = the run's "
                          "generations from the initial population on (rank pass while unconverged + one fused sweep)",
-                exact_logZ=None)
+                exact_logZ=None, exact_post_mean=EXACT["post_mean_normal1d_sigma2_10"])
 
 
 def cfg_lv(A, args):
@@ -186,7 +199,7 @@ def cfg_lv(A, args):
                 warmup=3, cpu_particles=1 << 15, cpu_steps=6, storage="packed",
                 workload="abcdesmc Lotka-Volterra RK4 on device, dt 0.01 x 1500 steps per particle-update, 16 noisy (x, y) "
                          "observations, Euclidean distance (BASELINE.json configs[3]); alpha=0.95 Kmcmc=3",
-                exact_logZ=None)
+                exact_logZ=None, exact_post_mean=None, scaling="strong")
 
 
 def cfg_evidence1d(A, args):
@@ -194,9 +207,22 @@ def cfg_evidence1d(A, args):
                 steps=12, warmup=3, cpu_particles=1 << 21, cpu_steps=6, storage="packed",
                 workload="abcdesmc two-model evidence of examples/minimal_example.jl (BASELINE.json configs[4]); timed: "
                          "generations of model 1 (prior N(0, sqrt 10)); both models then run to eps 0.3",
-                exact_logZ=-3.038051357)
+                exact_logZ=EXACT["logZ_normal1d_sigma2_10"], exact_post_mean=EXACT["post_mean_normal1d_sigma2_10"], scaling="strong")
 
 
+def _exact():
+    """closed forms of the BASELINE configurations (tests/golden/reference_known_answers.json, made by
+    tests/golden/make_golden.py with scipy): finite-eps evidences and posterior means"""
+    with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as f:
+        a = json.load(f)["analytic"]
+    return {"logZ_mvn32_eps6": a["Z_mvn32_eps6"]["logZ"], "post_mean_mvn32_eps6": a["Z_mvn32_eps6"]["posterior_mean_per_component"],
+            "logZ_normal1d_sigma2_10": a["Z_exact_finite_eps_sigma2_10"]["logZ"],
+            "logZ_normal1d_sigma2_100": a["Z_exact_finite_eps_sigma2_100"]["logZ"],
+            "post_mean_normal1d_sigma2_10": a["Z_exact_finite_eps_sigma2_10"]["posterior_mean"],
+            "post_mean_normal1d_sigma2_100": a["Z_exact_finite_eps_sigma2_100"]["posterior_mean"]}
+
+
+EXACT = _exact()
 CONFIGS = {"smc32": cfg_smc32, "mc1d": cfg_mc1d, "lv": cfg_lv, "evidence1d": cfg_evidence1d}
 
 
@@ -288,7 +314,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         fl = lv_flops_per_update(cfg["sim"])
         ach = fl * rate / 1e12
         return {"kernel": "smc_swarm_packed_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "peak_origin": FP64_VALU_PEAK_ORIGIN,
                 "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per update; the row traffic "
                         "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl,
                 "rk4_steps_per_s": rate * (len(cfg["sim"].obs) // 2 - 1) * cfg["sim"].steps_per_obs,
@@ -312,18 +338,31 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
                    "/ average launch time / 8 TB/s",
         "bytes_read_per_update": b_read, "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches,
         "kernel_updates_per_s": rate,
-        "launches_are": "abcdesmc: the first sweep of every timed generation (its siblings run on the same alive count); abcdemc: every sweep",
+        "launches_are": ("abcdesmc: ONE sweep of every 2nd timed generation between its own pair of HIP events on the library's stream -- the "
+                         "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 2; a pair costs ~9 us of queue "
+                         "time); abcdemc: the sweep of every 4th generation.  A bracketed launch starts on a drained queue, so this average "
+                         "is a few per cent ABOVE the un-instrumented kernel: frac_trace"),
         "total_bytes_frac": to_gbs(b_read + b_write) / HBM_PEAK_GBS,
         "total_bytes_note": f"SURVEY.md 8d total-bytes variant: {b_read + b_write} B per update, charging every update a full "
                             "row write (the double-buffered reference layout)",
         "moved_bytes_per_update": b_moved, "moved_bytes_frac": to_gbs(b_moved) / HBM_PEAK_GBS,
         "acceptance_rate": acc_rate,
     }
+    kc = profile_json(f"{PROFILE_TAG}_{args_config}_kernel_avg_check.json")
+    if kc and kc.get("trace_avg_ms_timed_sweeps") and kc.get("updates_per_launch_timed_sweeps"):
+        r_tr = kc["updates_per_launch_timed_sweeps"] / (kc["trace_avg_ms_timed_sweeps"] * 1e-3)
+        out["frac_trace"] = b_read * r_tr / 1e9 / HBM_PEAK_GBS
+        out["frac_trace_source"] = (f"NOT measured in this run: rocprofv3 --kernel-trace of this command on another box, average over EVERY sweep "
+                                    f"that ran in the timed steps ({kc.get('timed_sweeps')} launches, {kc['trace_avg_ms_timed_sweeps']:.4f} ms, "
+                                    f"{kc['updates_per_launch_timed_sweeps']:.0f} updates each; warm-up launches excluded), "
+                                    f"profiles/{PROFILE_TAG}_{args_config}_kernel_avg_check.json")
     tr = profile_json(f"{PROFILE_TAG}_hbm_traffic_{args_config}.json")
     if tr and tr.get("ld") == ld:
         out["traffic"] = tr["total_bytes_per_update"] * upl
         out["traffic_source"] = (f"NOT measured in this run: {tr['total_bytes_per_update']:.1f} B per update (FETCH_SIZE x2 + "
-                                 f"WRITE_SIZE, separate rocprofv3 --pmc passes of this command, profiles/{PROFILE_TAG}_hbm_traffic_"
+                                 f"WRITE_SIZE, separate rocprofv3 --pmc passes of this very command line, counted over the sweep "
+                                 f"dispatches of its TIMED steps only -- {tr.get('dispatches')} dispatches, acceptance "
+                                 f"{tr.get('acceptance_rate')} --, profiles/{PROFILE_TAG}_hbm_traffic_"
                                  f"{args_config}.json) x this run's updates per launch")
         out["traffic_over_moved_bytes"] = tr["total_bytes_per_update"] / b_moved
     else:
@@ -406,14 +445,19 @@ def run_config(args):
         cfg["storage"] = args.storage
     steps = args.steps if args.steps is not None else cfg["steps"]
     warmup = args.warmup if args.warmup is not None else cfg["warmup"]
-    ppg = args.particles_per_gpu or cfg["ppg"]
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        # main() starts the ranks itself when WORLD_SIZE is unset; reaching this line means a launcher with another world size
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher: it starts its own ranks)")
+    scaling = args.scaling or cfg.get("scaling", "weak")
+    if scaling == "strong" and not args.particles_per_gpu:
+        total = args.particles_total or cfg["ppg"]          # the configuration's stated population, in total
+        ppg = max(total // world, 64)
+    else:
+        ppg = args.particles_per_gpu or cfg["ppg"]
     device = local_rank if args.dist_backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
     pg = None
@@ -472,7 +516,9 @@ def run_config(args):
     updates = gen.updates - u0          # global particle-updates (all ranks)
     kern_ms, launches, units = eng.ops.get_timing()   # this rank's sweep kernel
     eng.ops.set_timing(False)
-    window = dict(sweeps=gen.sweeps - s0, resamples=getattr(gen, "resamples", 0) - r0,
+    window = dict(sweeps=gen.sweeps - s0, updates=updates, naccs=getattr(gen, "naccs", 0) - a0,
+                  sweep_launches=steps * (gen.Kmcmc if cfg["kind"] == "smc" else 1),     # dispatches of the sweep kernel a profiler sees in the window (a group enqueues Kmcmc; those behind a held test of smc:352 return at once)
+                  resamples=getattr(gen, "resamples", 0) - r0,
                   eps=getattr(gen, "eps", None), logZ=getattr(gen, "logZ", None))
     acc_rate = (gen.naccs - a0) / max(updates, 1) if cfg["kind"] == "smc" else 0.0
     phases = {}
@@ -483,14 +529,32 @@ def run_config(args):
         for _ in range(3):
             gen.step()
         phases = eng.phase_timing()
+        eng._prof = None                # no event pairs in the whole run below
 
-    # ---- the whole run next to the window: from a fresh population to eps_target (device-resident, no result download)
+    # ---- the whole run next to the window: from a fresh population to eps_target (device-resident, no result download) -- the
+    # second half of BASELINE.json's metric: log-Z and posterior-mean error against the closed forms (tests/golden)
     whole = None
-    if cfg["kind"] == "smc" and not args.no_whole_run and not eng.sharded_packed:
+
+    def post_err(e2, exact):
+        pm = e2.posterior_mean()
+        out = {"posterior_mean": float(pm.mean()), "posterior_mean_is": "mean over the alive particles (Wns-weighted), averaged over "
+               f"the {len(pm)} exchangeable components" if len(pm) > 1 else "mean over the alive particles (Wns-weighted)"}
+        if len(pm) > 1:
+            out["posterior_mean_components_min_max"] = [float(pm.min()), float(pm.max())]
+        if exact is not None:
+            out["posterior_mean_exact"] = exact
+            out["posterior_mean_err"] = float(pm.mean()) - exact
+            if len(pm) > 1:
+                out["posterior_mean_max_component_err"] = float(abs(pm - exact).max())
+        return out
+
+    if cfg["kind"] == "smc" and not args.no_whole_run:
         whole = {}
-        models = [("model", cfg["prior"])] if args.config != "evidence1d" else \
-            [("model1_prior_N(0,sqrt10)", cfg["prior"]), ("model2_prior_N(0,sqrt100)", A.Normal(0.0, math.sqrt(100.0)))]
-        for name, prior in models:
+        models = [("model", cfg["prior"], cfg["exact_logZ"], cfg["exact_post_mean"])] if args.config != "evidence1d" else \
+            [("model1_prior_N(0,sqrt10)", cfg["prior"], EXACT["logZ_normal1d_sigma2_10"], EXACT["post_mean_normal1d_sigma2_10"]),
+             ("model2_prior_N(0,sqrt100)", A.Normal(0.0, math.sqrt(100.0)), EXACT["logZ_normal1d_sigma2_100"],
+              EXACT["post_mean_normal1d_sigma2_100"])]
+        for name, prior, lz_exact, pm_exact in models:
             e2 = eng
             if prior is not cfg["prior"]:
                 e2 = HipEngine(A.ModelSpec(prior, cfg["sim"], seed=1), N, pg, lanes=args.lanes, storage=cfg["storage"])
@@ -506,12 +570,26 @@ def run_config(args):
             whole[name] = {"generations": g2.generations, "sweeps": g2.sweeps, "updates": g2.updates, "seconds": dtw,
                            "value": g2.updates / dtw, "logZ": g2.logZ, "eps": g2.eps, "resamples": g2.resamples,
                            "includes": "abcde_init! + every generation down to eps_target; not the result download"}
+            if lz_exact is not None:
+                whole[name]["logZ_exact"] = lz_exact
+                whole[name]["logZ_err"] = g2.logZ - lz_exact
+            if args.config != "lv":
+                whole[name].update(post_err(e2, pm_exact))
+            else:
+                pm = e2.posterior_mean()
+                whole[name]["posterior_mean"] = [float(v) for v in pm]
+                whole[name]["posterior_mean_is"] = ("(a, b, c, e) over the alive particles; no closed form -- the data were simulated "
+                                                    "at theta* = (1.0, 0.4, 1.0, 0.3) (tests/golden/lv_data.json)")
         if args.config == "evidence1d":
             z1, z2 = whole[models[0][0]]["logZ"], whole[models[1][0]]["logZ"]
+            bf_exact = math.exp(EXACT["logZ_normal1d_sigma2_10"] - EXACT["logZ_normal1d_sigma2_100"])
             whole["bayes_factor"] = math.exp(z1 - z2)
-            whole["exact"] = {"logZ1": -3.038051357, "logZ2": -3.782014144, "bayes_factor": 2.1043}
-        elif cfg["exact_logZ"] is not None:
-            whole["model"]["logZ_exact"] = cfg["exact_logZ"]
+            whole["exact"] = {"logZ1": EXACT["logZ_normal1d_sigma2_10"], "logZ2": EXACT["logZ_normal1d_sigma2_100"], "bayes_factor": bf_exact}
+            whole["bayes_factor_rel_err"] = whole["bayes_factor"] / bf_exact - 1.0
+    elif cfg["kind"] == "mc" and not args.no_whole_run and warmup == 0:
+        # abcdemc: the timed window IS the run (its generations from the initial population on); no evidence in abcdemc!
+        whole = {"model": {"generations": gen.generations, "updates": gen.updates, "seconds": dt, "completion": gen.complete,
+                           "max_distance": gen.hi, **post_err(eng, cfg["exact_post_mean"])}}
 
     if rank == 0:
         out = {
@@ -523,12 +601,13 @@ def run_config(args):
             "warmup": warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{cfg['workload']}; {ppg} particles/GPU", "name": args.config,
+                "workload": f"{cfg['workload']}; {ppg} particles/GPU" + (f" ({N} in total, strong scaling)" if scaling == "strong" and world > 1 else ""),
+                "name": args.config,
                 "particles_total": N, "d": d, "lanes_per_particle": L, "comps_per_lane": C,
                 "timed_window": window,
                 "launched_incl_warmup": {"sweeps": gen.sweeps, "updates": gen.updates},     # what a profiler sees of the sweep kernel
@@ -545,8 +624,18 @@ def run_config(args):
             out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
         if whole is not None:
             out["whole_run"] = whole
+            # the second half of BASELINE.json's metric ("posterior-mean & log-Z error vs ref"), from the whole run above
+            errs = {k: {kk: v[kk] for kk in ("logZ_err", "posterior_mean_err") if kk in v} for k, v in whole.items() if isinstance(v, dict)}
+            errs = {k: v for k, v in errs.items() if v}
+            if "bayes_factor_rel_err" in whole:
+                errs["bayes_factor_rel_err"] = whole["bayes_factor_rel_err"]
+            if errs:
+                out["errors_vs_exact"] = errs
         if eng.sharded_packed:    # rank 0's device-event breakdown of the sharded sweep
             out["sharded_phases_ms"] = {k: {"calls": c, "avg_ms": (t / c if c else 0.0)} for k, (c, t) in phases.items()}
+        if world > 1:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = "timed on rank 0 at N = 1 only (the contract): see the --gpus 1 line"
         if world == 1 and not args.no_cpu_baseline:
             if getattr(args, "defer_cpu", None) is not None:
                 # the default run measures every configuration's GPU window first and the CPU legs afterwards: 256 OpenMP threads
@@ -559,7 +648,7 @@ def run_config(args):
     return None, pg
 
 
-OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "updates_per_launch",
+OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_trace", "peak_origin", "avg_launch_ms", "launches", "updates_per_launch",
               "kernel_updates_per_s", "traffic", "traffic_over_moved_bytes", "traffic_source", "acceptance_rate", "flops_per_update",
               "rk4_steps_per_s", "bytes_read_per_update")
 
@@ -580,7 +669,7 @@ def other_config(args, name):
     a.config, a.steps, a.warmup, a.particles_per_gpu, a.lanes, a.dim = name, None, None, None, 0, 32
     a.cpu_particles, a.no_pattern = None, True
     a.cpu_steps = {"mc1d": 4, "lv": 3, "evidence1d": 3}[name]
-    a.no_whole_run = name != "evidence1d"          # the evidence configuration's result IS the whole run: both logZ, the Bayes factor
+    a.no_whole_run = args.no_whole_run             # every configuration's whole run: logZ / posterior-mean error (evidence1d: both models, the Bayes factor)
     deferred = []
     a.defer_cpu = deferred if getattr(args, "defer_cpu", None) is not None else None
     r, _ = run_config(a)
@@ -590,7 +679,7 @@ def other_config(args, name):
     out["workload"] = r["config"]["workload"]
     out["timed_window"] = r["config"]["timed_window"]
     out["roofline"] = {k: r["roofline"][k] for k in OTHER_KEYS if k in r["roofline"]}
-    for k in ("cpu_baseline", "whole_run"):
+    for k in ("cpu_baseline", "whole_run", "errors_vs_exact"):
         if k in r:
             out[k] = r[k]
     for (_, A, aa, cfg) in deferred:               # the CPU leg of this configuration fills the summary, later
@@ -598,8 +687,42 @@ def other_config(args, name):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process tree (python -m
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  This parent has not
+    imported torch and never touches a GPU (nothing is exec'ed or re-launched from a process that has); a failing rank
+    makes the launcher -- and this process -- exit non-zero; nothing is retried."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:                  # rank 0 prints one JSON line; anything else on the ranks' stdout (RCCL banners) goes to stderr
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     args.defer_cpu = []            # GPU windows of every configuration first, CPU baselines afterwards
     out, pg = run_config(args)
     if out is not None and args.config == "smc32" and out["n_gpus"] == 1 and not args.no_other_configs and not args.force_collectives:

@@ -35,9 +35,12 @@ extern "C" {
 typedef struct abcdez_ctx abcdez_ctx;
 
 ABCDEZ_API int abcdez_version(void);
+/* Rounds of the Philox4x32 stream this library was built with (ABZ_PHILOX_ROUNDS, abcdez_spec.h: 10).  Every random number of a
+ * run depends on it, so hosts store it in their checkpoints next to abcdez_version() and refuse to resume across a change. */
+ABCDEZ_API int abcdez_rng_rounds(void);
 /* Layout of the structs that cross the boundary: fills out[0 .. n) with { sizeof(abz_prior_dim), offsetof of its 7 fields
  * in declaration order, sizeof(abz_model), offsetof of its 11 fields in declaration order } and returns how many
- * values there are (19).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
+ * values there are (20).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
 ABCDEZ_API int abcdez_abi_layout(int32_t* out, int n);
 ABCDEZ_API const char* abcdez_last_error(void);
 
@@ -164,8 +167,11 @@ ABCDEZ_API int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, ui
  * Results are the same either way. */
 ABCDEZ_API int abcdez_smc_select_ahead(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, double alpha,
                                        double eps_target);
-/* Forget a select armed or enqueued ahead.  Every library call that changes the distances or the flags does so itself; a host that
- * writes those arrays by other means (a copy, a resumed checkpoint), changes the stream, or ends a run calls this. */
+/* "The population was written behind the library's back."  Forgets a select armed or enqueued ahead AND ends the chain of
+ * asynchronous abcdemc generations (the proved bound of the tail length that lets a rank pass launch a single sort was made
+ * for the old distances).  Every library call that changes the distances or the flags does so itself; a host that writes those
+ * arrays by other means (a copy, a resumed checkpoint), changes the stream, or ends a run calls this.  (Should a host forget:
+ * a rank pass whose bound no longer holds is detected on the device and abcdez_mc_generation_wait returns an error.) */
 ABCDEZ_API int abcdez_smc_select_discard(abcdez_ctx* ctx);
 /* Diagnostics: prologues of this context that found their select enqueued ahead / that ran it themselves (the first generation,
  * the one after a resample, after a discard).  A steady-state abcdesmc loop reuses one select per generation. */
@@ -194,6 +200,9 @@ ABCDEZ_API int abcdez_smc_group_replay(abcdez_ctx* ctx, const uint32_t* bits, ui
                                        double* slot0, double* slot1, double* logpi, const uint8_t* flags, double gamma0,
                                        double gamma_sigma, uint32_t sweep);
 ABCDEZ_API int abcdez_smc_group_publish(abcdez_ctx* ctx);
+/* Abandon an open group after a failure between _begin and _end (a collective raised, a launch failed): waits for the stream,
+ * drops the group's timing pairs and re-reads the counter baselines; a no-op when no group is open. */
+ABCDEZ_API int abcdez_smc_group_abort(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t* k_done);
 ABCDEZ_API int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* bits,
                                                  uint32_t* bits_other, double* slot0, double* slot1, const double* logpi,

@@ -11,7 +11,7 @@
  * (SURVEY.md section 8c): rand/randn (src/abcdez_smc.jl:128,145), log (smc:145,
  * types:36,61), exp (smc:79), prior logpdf (priors.jl:40-46), push_p (types.jl:20-23),
  * the four ABC kernels (types.jl:26-73).  Julia's task-local Xoshiro stream is not
- * reproducible on a GPU, so the build's RNG contract is a counter-based Philox4x32 (7 rounds, below).
+ * reproducible on a GPU, so the build's RNG contract is a counter-based Philox4x32-10 (below).
  *
  * Plain C99 / C++ / HIP.  No dependencies.
  */
@@ -41,18 +41,20 @@ ABZ_HD double abz_sqrt(double a) { return __builtin_sqrt(a); }
 ABZ_HD int abz_isfinite(double x) { return ((abz_d2u(x) >> 52) & 0x7FF) != 0x7FF; }
 ABZ_HD int abz_isnan(double x) { return x != x; }
 
-/* ------------------------------------------------------------------ Philox4x32-R
+/* ------------------------------------------------------------------ Philox4x32-10
  * Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11).
- * counter = (c0,c1,c2,c3), key = (k0,k1).  R = ABZ_PHILOX_ROUNDS = 7: the round count the paper reports as the smallest
- * Crush-resistant one for Philox4x32 (passes SmallCrush, Crush and BigCrush of TestU01, its section 5 / table 2: "Philox4x32-7");
- * Random123's default of 10 adds a safety margin the paper itself calls optional.  The sweep kernels are bound by
- * their vector ALU and a third of a Box-Muller pair is this function, hence 7.  tests/test_spec_math.py pins the round
- * function against Random123's published 10-round known answers (abz_philox4x32_r(10, ...)) and a pure-Python Philox,
- * and runs its own battery (bit frequencies, serial correlation across counters and keys, birthday spacings of the
- * 7-round stream).                                                                     */
+ * counter = (c0,c1,c2,c3), key = (k0,k1).  R = ABZ_PHILOX_ROUNDS = 10: Random123's default and SURVEY.md section 7's RNG
+ * contract.  (Round 3 shipped 7 rounds -- the paper's smallest Crush-resistant count -- for 0-1.5 % of sweep time; the
+ * counters here are maximally structured (position, sweep, sub-index, purpose tag), which is the case the extra rounds
+ * are the margin for, so the default is 10 again.  A build may override it with -DABZ_PHILOX_ROUNDS=7 on BOTH sides
+ * (library and oracle); the library reports the count it was built with, abcdez_abi_layout / abcdez_rng_rounds, and
+ * checkpoints carry it.)  tests/test_spec_math.py pins the round function against Random123's published 10-round known
+ * answers and a pure-Python Philox for every round count.                                   */
 typedef struct { uint32_t v[4]; } abz_u32x4;
 
-#define ABZ_PHILOX_ROUNDS 7
+#ifndef ABZ_PHILOX_ROUNDS
+#define ABZ_PHILOX_ROUNDS 10
+#endif
 #define ABZ_PHILOX_M0 0xD2511F53u
 #define ABZ_PHILOX_M1 0xCD9E8D57u
 #define ABZ_PHILOX_W0 0x9E3779B9u

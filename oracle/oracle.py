@@ -221,6 +221,13 @@ class OracleOps:
     def smc_group_publish(self):
         pass
 
+    def smc_group_abort(self):
+        self._grp = None
+
+    def stream_version(self):
+        """(0 = the oracle, Philox rounds of the shared spec header)"""
+        return 0, int(self.L.orc_philox_rounds())
+
     def smc_group_end(self, k_max):
         g, self._grp = self._grp, None
         return g["nacc"], g["nsim"], len(g["nacc"])

@@ -59,11 +59,20 @@ def analytic():
     for s2 in (10, 100):
         sd = math.sqrt(s2 + 1)
         z = stats.norm.cdf((3 + eps) / sd) - stats.norm.cdf((3 - eps) / sd)
-        out[f"Z_exact_finite_eps_sigma2_{s2}"] = dict(value=z, logZ=math.log(z))
+        # posterior mean at finite eps (what test/runtests.jl:159-162,214-217 compare with 30/11 "within one std"; exact here):
+        # x ~ N(0, s2 + 1) marginally, E[theta | x] = s2 / (s2 + 1) x, and the ABC posterior conditions on |x - 3| < eps:
+        # E[x | a < x < b] = sd (phi(a / sd) - phi(b / sd)) / (Phi(b / sd) - Phi(a / sd))
+        a_, b_ = (3 - eps) / sd, (3 + eps) / sd
+        ex = sd * (stats.norm.pdf(a_) - stats.norm.pdf(b_)) / z
+        out[f"Z_exact_finite_eps_sigma2_{s2}"] = dict(value=z, logZ=math.log(z), posterior_mean=s2 / (s2 + 1) * ex)
     # BASELINE.json config 3: d=32, prior N(0,I), x = theta + z, y = 1, eps = 6:
     # ||x - y||^2 / 2 ~ noncentral chi2(32, lambda = 32 / 2)
     z = stats.ncx2.cdf(36.0 / 2.0, 32, 16.0)
-    out["Z_mvn32_eps6"] = dict(value=z, logZ=math.log(z))
+    # posterior mean per component: x = 1 + u, v = u / sqrt 2 ~ N(-1 / sqrt 2, I_32), A = {|v|^2 < 18}; for a noncentral
+    # chi-square ball E[v | A] = mu F_{k+2}(r; lambda) / F_k(r; lambda), and E[theta | x] = x / 2
+    # => E[theta_k | A] = (1 - F_34(18; 16) / F_32(18; 16)) / 2
+    pm = 0.5 * (1.0 - stats.ncx2.cdf(18.0, 34, 16.0) / z)
+    out["Z_mvn32_eps6"] = dict(value=z, logZ=math.log(z), posterior_mean_per_component=pm)
     z8 = stats.ncx2.cdf(2.5 ** 2 / 2.0, 8, 4.0)
     out["Z_mvn8_eps2.5"] = dict(value=z8, logZ=math.log(z8))
     out["mixture_st_n"] = [0.0, 0.04680825481526908, 0.1057221226763449, 0.2682111969397526, 0.8309228020477986]  # :575-579

@@ -12,7 +12,7 @@ M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 
 
-ROUNDS = 7      # ABZ_PHILOX_ROUNDS (abcdez_spec.h): the smallest Crush-resistant Philox4x32 of Salmon et al. (SC'11)
+ROUNDS = 10     # ABZ_PHILOX_ROUNDS (abcdez_spec.h): Random123's default, SURVEY.md section 7's RNG contract
 
 
 def py_philox4x32(ctr, key, rounds=ROUNDS):
