@@ -37,6 +37,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._trace import rng as _rng
 from .model import ModelSpec
 
 PACKED_ALIGN = 64        # sub-ranges of the packed prefix start / end at multiples of this (include/abcdez_hip.h)
@@ -411,13 +412,15 @@ class PopulationEngine:
         """sharded packed: fetch the other ranks' distances (once per generation, before the first consumer)"""
         if self._delta_work is not None:          # started behind the generation's last replay: just join it
             self._mark("delta_allgather_wait", 0)
-            self._delta_work.wait()
+            with _rng("delta_allgather_wait"):
+                self._delta_work.wait()
             self._delta_work = None
             self._mark("delta_allgather_wait", 1)
             self._delta_stale = False
         if self._delta_stale:
             self._mark("delta_allgather", 0)
-            self._allgather_chunks(self._full[self.cur][1])
+            with _rng("delta_allgather"):
+                self._allgather_chunks(self._full[self.cur][1])
             self._mark("delta_allgather", 1)
             self._delta_stale = False
 
@@ -540,8 +543,10 @@ class PopulationEngine:
         self._delta_stale = False
         th, lp, dl = self.buf[self.cur]
         self._bind_stamps()
-        self.ops.init(th, lp, dl, self.lo, self.n_local)
-        self._allgather_state(self.buf[self.cur] + ((self.stamp[self.cur],) if self.blob_on else ()))
+        with _rng("init"):
+            self.ops.init(th, lp, dl, self.lo, self.n_local)
+        with _rng("init_allgather"):
+            self._allgather_state(self.buf[self.cur] + ((self.stamp[self.cur],) if self.blob_on else ()))
 
     def reset_weights(self):  # smc:266-270
         self.discard_select_ahead()
@@ -590,9 +595,10 @@ class PopulationEngine:
         self._sync_delta()
         self._bind_stamps()
         cur = self.buf[self.cur]
-        eps, wnorm, ess, n_alive, part, lo, hi = self.ops.smc_prologue_packed(
-            cur[2], self.wns, self.alive, self.n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, self.bits[self.bc],
-            self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0], cur[1])
+        with _rng("prologue"):
+            eps, wnorm, ess, n_alive, part, lo, hi = self.ops.smc_prologue_packed(
+                cur[2], self.wns, self.alive, self.n_prev, alpha, eps_prev, eps_target, eps_k, ess_min, self.bits[self.bc],
+                self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0], cur[1])
         self.n_alive = n_alive
         if part:
             self.n_prev = n_alive
@@ -602,13 +608,14 @@ class PopulationEngine:
     def smc_resample(self):
         self._need_packed("smc_resample")
         self._stream()
-        self.ops.wsample_stratified(self.wns, self.draw, self.inds)
-        self.draw += 1
-        self._bind_stamps()
-        self._sync_delta()
-        cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
-        self.ops.smc_resample_gather_packed(self.inds, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0],
-                                            self.buf[1][0], cur[1], cur[2], oth[1], oth[2], self.wns, self.alive)
+        with _rng("resample"):
+            self.ops.wsample_stratified(self.wns, self.draw, self.inds)
+            self.draw += 1
+            self._bind_stamps()
+            self._sync_delta()
+            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
+            self.ops.smc_resample_gather_packed(self.inds, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0],
+                                                self.buf[1][0], cur[1], cur[2], oth[1], oth[2], self.wns, self.alive)
         self._swap()
         self.n_alive = self.n_prev = self.N
 
@@ -684,9 +691,10 @@ class PopulationEngine:
                 # (alpha, eps_target) of the next smc_prologue: its select is enqueued behind these sweeps (same results;
                 # the device works on it while the host reads the counters and applies its stop rules)
                 self.ops.smc_select_ahead(cur[2], self.alive, next_prologue[0], next_prologue[1])
-            naccs, nsims, Ki = self.ops.smc_sweeps_packed(self.bits[self.bc], self.bits[1 - self.bc], self.n_alive,
-                                                          self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
-                                                          self.sweep, Kmcmc, Kmcmc_min)
+            with _rng("sweeps_group"):
+                naccs, nsims, Ki = self.ops.smc_sweeps_packed(self.bits[self.bc], self.bits[1 - self.bc], self.n_alive,
+                                                              self.buf[0][0], self.buf[1][0], cur[1], cur[2], eps, gamma0, gsig,
+                                                              self.sweep, Kmcmc, Kmcmc_min)
             self.sweep += Ki
             if Ki & 1:
                 self.bc = 1 - self.bc
@@ -717,21 +725,26 @@ class PopulationEngine:
             for k in range(Kmcmc):
                 b_in, b_out = self.bits[bc], self.bits[1 - bc]
                 self._mark("own_sweep", 0)
-                self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
-                                          cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep + k, want_counts=False)
+                with _rng("own_sweep"):
+                    self.ops.smc_swarm_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0],
+                                              cur[1], cur[2], self.flags, eps, gamma0, gsig, self.sweep + k, want_counts=False)
                 self._mark("own_sweep", 1)
                 self._mark("flag_allgather", 0)
-                self._allgather_chunks(self.flags)               # executed by every rank whether or not the sweep ran
+                with _rng("flag_allgather"):
+                    self._allgather_chunks(self.flags)           # executed by every rank whether or not the sweep ran
                 self._mark("flag_allgather", 1)
                 self._mark("replay", 0)
-                self.ops.smc_group_replay(b_in, b_out, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0], cur[1], self.flags,
-                                          gamma0, gsig, self.sweep + k)
+                with _rng("replay"):
+                    self.ops.smc_group_replay(b_in, b_out, self.r_lo, self.r_hi, self.buf[0][0], self.buf[1][0], cur[1], self.flags,
+                                              gamma0, gsig, self.sweep + k)
                 self._mark("replay", 1)
                 bc = 1 - bc
             self.ops.smc_group_publish()
             self._delta_stale = True
-            self._start_delta_allgather()                        # behind the read-back: travels while the host applies its rules
-            naccs, nsims, Ki = self.ops.smc_group_end(Kmcmc)
+            with _rng("delta_allgather_start"):
+                self._start_delta_allgather()                    # behind the read-back: travels while the host applies its rules
+            with _rng("group_readback"):
+                naccs, nsims, Ki = self.ops.smc_group_end(Kmcmc)
         except BaseException:
             # a collective or a launch failed half way: close the group, or every later call of this context is refused
             if hasattr(self.ops, "smc_group_abort"):
@@ -776,7 +789,8 @@ class PopulationEngine:
         nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.rank_cnt, self.state, self.other, eps_pop, eps_target,
                                               gamma0, gsig, self.lo, self.n_local, self.sweep)
         self.sweep += 1
-        self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
+        with _rng("mc_rows_allgather"):
+            self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
         self._swap()
         nsim, ngt = self._allreduce_counts(nsim, ngt)
         if self._collectives:
@@ -815,8 +829,9 @@ class PopulationEngine:
             self._mc_arrays()
             self._stream()
             self._bind_stamps()
-            t = self.ops.mc_generation_async(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, alpha,
-                                             eps_target, lo_hi, do_rank, gamma0, gsig, self.sweep)
+            with _rng("mc_generation"):
+                t = self.ops.mc_generation_async(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, alpha,
+                                                 eps_target, lo_hi, do_rank, gamma0, gsig, self.sweep)
             self.sweep += 1
             self._swap()
             self._mc_pending.append(("ticket", t))

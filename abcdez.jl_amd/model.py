@@ -53,6 +53,17 @@ def next_pow2(n: int) -> int:
     return p
 
 
+def philox_key(rng) -> int:
+    """`rng` of the reference signatures (src/abcdez_smc.jl:220, src/abcdez_mc.jl:104) -> the 64-bit Philox key: an int is the key
+    itself; a numpy Generator / RandomState (the host-language counterpart of the reference's AbstractRNG) gives it with one
+    draw, so seeding that generator makes the run reproducible the way seeding Julia's rng does for the CPU methods"""
+    if hasattr(rng, "integers"):                 # numpy.random.Generator
+        return int(rng.integers(0, 1 << 64, dtype="uint64"))
+    if hasattr(rng, "randint") and hasattr(rng, "bytes"):      # numpy.random.RandomState
+        return int.from_bytes(rng.bytes(8), "little")
+    return int(rng) & 0xFFFFFFFFFFFFFFFF
+
+
 class ModelSpec:
     """Host-side description; ``.cstruct(data_ptr)`` yields the C struct."""
 
@@ -74,7 +85,7 @@ class ModelSpec:
         self.ld = next_pow2(d)
         self.abck = kernel_kind(ABCk)
         self.ABCk = ABCk
-        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.seed = philox_key(seed)
         self.data = np.ascontiguousarray(np.asarray(sim.data(), dtype=np.float64))
         self.n_blob = int(sim.blob_size(d)) if getattr(sim, "blobs", False) else 0     # doubles per blob, 0 = off
         if self.n_blob > 64:

@@ -22,7 +22,7 @@
 # reference for the order of the calls.
 module ABCdeZHIP
 
-using ABCdeZ, Distributions, LinearAlgebra
+using ABCdeZ, Distributions, LinearAlgebra, Random
 import ABCdeZ: abcdesmc!, abcdemc!
 
 export DeviceSimulator, Normal1D, MVNormalSim, DiracSquare, Quad2D, Mixture01, NormalTimesDU, WienerRMS,
@@ -46,6 +46,7 @@ struct AbzModel
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
 function check_abi()
+    ccall((:abcdez_rng_rounds, LIB), Cint, ()) == 10 || @warn("libabcdez_hip.so was built with a non-default Philox round count: results differ from a default build's")
     lay = Vector{Int32}(undef, 32)
     n = ccall((:abcdez_abi_layout, LIB), Cint, (Ptr{Int32}, Cint), lay, length(lay))
     mine = Int32[sizeof(AbzPriorDim), fieldoffset.(AbzPriorDim, 1:7)...,
@@ -154,6 +155,13 @@ devalloc(bytes) = (p = Ref{Ptr{Cvoid}}(); check(ccall((:abcdez_dev_alloc, LIB), 
 devfree(p) = p == C_NULL || ccall((:abcdez_dev_free, LIB), Cint, (Ptr{Cvoid},), p)
 h2d(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
 d2h(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
+
+# `rng` of the reference signatures (src/abcdez_smc.jl:220, src/abcdez_mc.jl:104: `rng=Random.default_rng()`): the device stream
+# is a counter-based Philox4x32-10 keyed by 64 bits.  An AbstractRNG -- the reference's default included -- gives the key with one
+# draw, so seeding that rng makes the run reproducible exactly as it does for the CPU methods; an Integer is used as the key itself
+# (the Python host's convention, convenient for bit-for-bit comparisons with it).
+philox_key(rng::Integer) = rng % UInt64
+philox_key(rng::AbstractRNG) = rand(rng, UInt64)
 
 function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
     check_abi()
@@ -299,7 +307,10 @@ end
 function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                    nparticles::Int=100, α=0.95, δess=0.5, nsims_max::Int=10^7, Kmcmc::Int=3, Kmcmc_min=1.0,
                    ABCk=ABCdeZ.IndicatorStrict0toϵ, facc_stop=0.0, facc_min=0.0, facc_tune=0.975,
-                   verbose::Bool=true, verboseout::Bool=true, rng::Integer=1, parallel::Bool=false)
+                   verbose::Bool=true, verboseout::Bool=true, rng::Union{Integer,AbstractRNG}=Random.default_rng(),
+                   parallel::Bool=false)
+    # `varexternal` and `parallel` are accepted and ignored: the device simulator holds its own data (no per-task deepcopy,
+    # smc:166-173) and the whole population always runs in parallel on the GPU (smc:237's executor has no counterpart)
     0.0 ≤ α < 1.0 || error("α must be in 0 <= α < 1")                                  # smc:223-235
     0.0 ≤ δess ≤ 1.0 || error("δess must be in 0 <= δess <= 1")
     0.0 ≤ facc_stop ≤ 1.0 || error("facc_stop must be in 0 <= facc_stop <= 1")
@@ -313,7 +324,7 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
     nparticles_min = ceil(Int, 3 * length(prior) / (min(α, δess)))
     nparticles_min ≤ nparticles || error("nparticles must be at least $(nparticles_min)")
 
-    e = Engine(prior, dist!, ABCk, rng, nparticles)
+    e = Engine(prior, dist!, ABCk, philox_key(rng), nparticles)
     try
         init!(e)                                                                            # smc:242-252
         reset_weights!(e)                                                                   # smc:266-270
@@ -401,12 +412,13 @@ function mc_generation_collect!(e, ticket)
 end
 
 function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
-                  nparticles::Int=50, generations::Int=20, verbose=true, rng::Integer=1, parallel::Bool=false)
+                  nparticles::Int=50, generations::Int=20, verbose=true, rng::Union{Integer,AbstractRNG}=Random.default_rng(),
+                  parallel::Bool=false)
     α = 0.0                                                                              # mc:107
     0.0 ≤ ϵ_target || error("ϵ_target must be non-negative")
     5 ≤ nparticles || error("nparticles must be at least 5")
     1 ≤ generations || error("generations must be at least 1")
-    e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, rng, nparticles)
+    e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, philox_key(rng), nparticles)
     try
         init!(e)                                                                             # mc:117-125
         nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131

@@ -141,22 +141,110 @@ def test_abi_layout_of_the_hand_mirrored_structs():
     assert "abcdez_abi_layout" in jl and "check_abi()" in jl
 
 
-def test_julia_shim_binds_only_exported_symbols_with_the_declared_arity():
-    """every `ccall((:abcdez_x, LIB), Cint, (types...), args...)` of julia/ABCdeZHIP.jl names an exported function and
-    passes as many argument types as include/abcdez_hip.h declares parameters"""
+def _split_top(text):
+    """split at the commas that are not inside (), {} or []"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _julia_ccalls(jl):
+    """[(symbol, return type, [argument types])] of every `ccall((:abcdez_x, LIB), RET, (T1, T2, ...), ...)`"""
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(abcdez_\w+), LIB\),\s*(\w+),\s*\(", jl):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[i], 0)
+            i += 1
+        calls.append((m.group(1), m.group(2), _split_top(jl[m.end():i - 1])))
+    return calls
+
+
+# what a C parameter type of include/abcdez_hip.h may be bound to in a ccall signature
+def _c_class(ctype):
+    t = re.sub(r"\b(const|restrict|__restrict__)\b", "", ctype).strip()
+    t = re.sub(r"\s+", " ", t)
+    t = re.sub(r"\s*\w+$", "", t) if not t.endswith("*") else t         # drop the parameter name
+    t = t.replace(" *", "*").strip()
+    ptr = {"abcdez_ctx*": {"Ptr{Cvoid}"}, "abcdez_ctx**": {"Ptr{Ptr{Cvoid}}", "Ref{Ptr{Cvoid}}"},
+           "void*": {"Ptr{Cvoid}"}, "void**": {"Ptr{Ptr{Cvoid}}", "Ref{Ptr{Cvoid}}"},
+           "double*": {"Ptr{Cvoid}", "Ptr{Float64}", "Ref{Float64}"}, "uint8_t*": {"Ptr{Cvoid}", "Ptr{UInt8}"},
+           "uint32_t*": {"Ptr{Cvoid}", "Ptr{UInt32}"}, "uint64_t*": {"Ptr{Cvoid}", "Ptr{UInt64}"},
+           "int64_t*": {"Ptr{Int64}", "Ref{Int64}"}, "int32_t*": {"Ptr{Int32}", "Ref{Int32}", "Ref{Cint}", "Ptr{Cint}"},
+           "abz_model*": {"Ref{AbzModel}", "Ptr{AbzModel}"}, "char*": {"Cstring"}}
+    val = {"int64_t": {"Int64"}, "double": {"Float64"}, "uint32_t": {"UInt32"}, "int32_t": {"Int32", "Cint"},
+           "int": {"Cint", "Int32"}, "size_t": {"Csize_t"}}
+    return (ptr if t.endswith("*") else val)[t]
+
+
+def test_julia_shim_binds_only_exported_symbols_with_the_declared_types():
+    """every `ccall((:abcdez_x, LIB), RET, (types...), args...)` of julia/ABCdeZHIP.jl names an exported function and passes
+    the argument TYPES include/abcdez_hip.h declares, position by position (a Float64 where the header says int64_t, a
+    Ref{Int64} where it says double*, or a missing argument is what a shim nobody can run here would get wrong)"""
     jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
-    hdr = open(os.path.join(ROOT, "include", "abcdez_hip.h")).read()
-    calls = re.findall(r"ccall\(\(:(abcdez_\w+), LIB\), \w+,\s*\((.*?)\)\s*,", jl, re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "abcdez_hip.h")).read(), flags=re.S)
+    calls = _julia_ccalls(jl)
     assert len(calls) >= 20
-    for name, types in calls:
-        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, hdr, re.S)
+    for name, ret, types in calls:
+        m = re.search(r"ABCDEZ_API\s+([\w\s\*]+?)\b%s\s*\((.*?)\)\s*;" % name, hdr, re.S)
         assert m, f"{name} is not declared in include/abcdez_hip.h"
-        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
-        ntypes = len([t for t in re.sub(r"\{[^}]*\}", "", types).split(",") if t.strip()])
-        assert ntypes == len(params), (name, ntypes, len(params))
+        c_ret = m.group(1).strip()
+        assert ret == {"int": "Cint", "const char*": "Cstring"}.get(c_ret, None), (name, ret, c_ret)
+        params = [p.strip() for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        assert len(types) == len(params), (name, types, params)
+        for k, (jt, cp) in enumerate(zip(types, params)):
+            assert jt in _c_class(cp), f"{name}: argument {k + 1} is `{cp}` in the header, bound as {jt}"
     for need in ("abcdez_smc_prologue_packed", "abcdez_smc_swarm_packed", "abcdez_smc_resample_gather_packed",
-                 "abcdez_packed_gather", "abcdez_ctx_create_user", "abcdez_blob_eval", "abcdez_dev_free"):
+                 "abcdez_packed_gather", "abcdez_ctx_create_user", "abcdez_blob_eval", "abcdez_dev_free", "abcdez_rng_rounds"):
         assert any(c[0] == need for c in calls), need
+
+
+def test_julia_shim_keeps_the_reference_signatures():
+    """src/abcdez_smc.jl:215-220, src/abcdez_mc.jl:102-104: same keyword names and defaults; `rng` takes what the reference
+    takes (an AbstractRNG, default Random.default_rng()) and, as a convenience, an Integer key; `parallel` and `varexternal`
+    are accepted (and ignored)"""
+    jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    smc = re.search(r"function abcdesmc!\(prior, dist!::DeviceSimulator, ϵ_target, varexternal;(.*?)\)\n", jl, re.S).group(1)
+    mc = re.search(r"function abcdemc!\(prior, dist!::DeviceSimulator, ϵ_target, varexternal;(.*?)\)\n", jl, re.S).group(1)
+    for sig in (smc, mc):
+        assert "rng::Union{Integer,AbstractRNG}=Random.default_rng()" in sig and "parallel::Bool=false" in sig
+    for kw in ("nparticles::Int=100", "α=0.95", "δess=0.5", "nsims_max::Int=10^7", "Kmcmc::Int=3", "Kmcmc_min=1.0",
+               "ABCk=ABCdeZ.IndicatorStrict0toϵ", "facc_stop=0.0", "facc_min=0.0", "facc_tune=0.975", "verbose::Bool=true",
+               "verboseout::Bool=true"):
+        assert kw in smc, kw
+    for kw in ("nparticles::Int=50", "generations::Int=20", "verbose=true"):
+        assert kw in mc, kw
+    assert "philox_key(rng::AbstractRNG) = rand(rng, UInt64)" in jl and "using ABCdeZ, Distributions, LinearAlgebra, Random" in jl
+
+
+def test_roctx_ranges_cost_nothing_unless_asked_for(monkeypatch):
+    """abcdez_amd/_trace.py: a shared no-op object unless ABZ_ROCTX=1 / a rocprofv3 run; with ABZ_ROCTX=1 the roctx library
+    loads and push / pop are balanced"""
+    from abcdez_amd import _trace
+    monkeypatch.delenv("ABZ_ROCTX", raising=False)
+    monkeypatch.setenv("LD_PRELOAD", "")
+    for k in [k for k in os.environ if k.startswith("ROCPROF")]:
+        monkeypatch.delenv(k)
+    monkeypatch.setattr(_trace, "_ENABLED", None)
+    assert _trace.enabled() is False and _trace.rng("a") is _trace.rng("b")
+    monkeypatch.setenv("ABZ_ROCTX", "1")
+    monkeypatch.setattr(_trace, "_ENABLED", None)
+    if _trace.enabled():               # the roctx library of the ROCm image
+        with _trace.rng("outer"):
+            with _trace.rng("inner"):
+                pass
+    monkeypatch.setattr(_trace, "_ENABLED", None)
 
 
 def test_header_cites_the_reference_for_every_entry_point():

@@ -2,7 +2,12 @@
 """HBM traffic of a sweep kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass, as
 MI355X_MICROARCH.md prescribes) -> profiles/<round>_hbm_traffic_<config>.json, the file bench.py's roofline.traffic reads.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel substring> <lanes> <ld> [accept rate] [updates fetch pass] [updates write pass]
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <kernel substring> <lanes> <ld> [accept rate] [updates fetch pass] [updates write pass] [last-n dispatches]
+
+`last-n dispatches` (round 4): count only the LAST n dispatches of the kernel -- the sweep launches of bench.py's timed steps
+(`config.timed_window.sweep_launches`), with `updates` = `config.timed_window.updates` of that very pass and `accept rate` =
+timed_window.naccs / timed_window.updates: traffic, acceptance and bytes moved then describe the same launches as the bench
+line's timed window (the passes run the bench line's own --steps / --warmup).
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports half
 the bytes of 16-byte-per-lane coalesced reads, so it is doubled.  Particle-updates per dispatch = grid size / lanes
@@ -14,15 +19,16 @@ import json
 import sys
 
 
-def collect(path, counter, kernel):
-    tot, updates, n = 0.0, 0, 0
+def collect(path, counter, kernel, last_n=0):
+    rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
             if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                tot += float(row["Counter_Value"])
-                updates += int(row["Grid_Size"])
-                n += 1
-    return tot, updates, n
+                rows.append((int(row.get("Dispatch_Id") or len(rows)), float(row["Counter_Value"]), int(row["Grid_Size"])))
+    rows.sort()
+    if last_n > 0:
+        rows = rows[-last_n:]
+    return sum(r[1] for r in rows), sum(r[2] for r in rows), len(rows)
 
 
 def main():
@@ -31,8 +37,9 @@ def main():
     acc = float(sys.argv[7]) if len(sys.argv) > 7 else None
     upd_f = float(sys.argv[8]) if len(sys.argv) > 8 else 0.0
     upd_w = float(sys.argv[9]) if len(sys.argv) > 9 else 0.0
-    f, gu, nf = collect(fetch_csv, "FETCH_SIZE", kernel)
-    w, gw, nw = collect(write_csv, "WRITE_SIZE", kernel)
+    last_n = int(sys.argv[10]) if len(sys.argv) > 10 else 0
+    f, gu, nf = collect(fetch_csv, "FETCH_SIZE", kernel, last_n)
+    w, gw, nw = collect(write_csv, "WRITE_SIZE", kernel, last_n)
     rd = 2.0 * f * 1024.0 / (upd_f if upd_f > 0 else gu / lanes)
     wr = w * 1024.0 / (upd_w if upd_w > 0 else gw / lanes)
     b_read, b_write = 24 * ld + 17, 8 * ld + 16
@@ -42,6 +49,7 @@ def main():
         "method": "FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports "
                   "half the bytes of 16-B-per-lane coalesced reads). Infinity-Cache hits are counted.",
         "dispatches": nf, "dispatches_write_pass": nw,
+        "window": "the sweep dispatches of bench.py's timed steps only (warm-up excluded)" if last_n > 0 else "every dispatch of the run, warm-up included",
         "updates_are": "bench.py's count of the profiled run" if upd_f > 0 else "grid size / lanes",
         "read_bytes_per_update": rd, "write_bytes_per_update": wr,
         "algorithmic_read_bytes_per_update": b_read, "algorithmic_write_bytes_per_update": b_write,

@@ -15,14 +15,17 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py --config $CFG --no-other-configs > $R/gpurun_out/${TAG}_${CFG}_bench.log 2>&1
 MARK=$MARK LANES=$LANES TAG=$TAG CFG=$CFG KERN=$KERN PER_STEP=${PER_STEP:-3} bash $R/tools/profile_config.sh
 if [ "${PMC:-0}" = "1" ]; then
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_f.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs --steps 6 --warmup 2 > $R/gpurun_out/${TAG}_${CFG}_pmc_w.log 2>&1
-  UF=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_pmc_f.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
-  UW=$(python3 -c "import json;print([json.loads(l)['config']['launched_incl_warmup']['updates'] for l in open('$R/gpurun_out/${TAG}_${CFG}_pmc_w.log') if l.startswith('{')][-1])" 2>/dev/null || echo 0)
+  # the bench line's OWN window: default --steps / --warmup of the configuration; traffic is counted over the sweep dispatches of
+  # the timed steps only (tools/pmc_traffic.py last-n), with that pass's own updates and acceptance
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$CFG -o f -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs > $R/gpurun_out/${TAG}_${CFG}_pmc_f.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$CFG -o w -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-whole-run --no-pattern --no-other-configs > $R/gpurun_out/${TAG}_${CFG}_pmc_w.log 2>&1
+  win() { python3 -c "import json,sys;w=[json.loads(l)['config']['timed_window'] for l in open('$1') if l.startswith('{')][-1];print(w['$2'])" 2>/dev/null || echo 0; }
+  UF=$(win $R/gpurun_out/${TAG}_${CFG}_pmc_f.log updates); UW=$(win $R/gpurun_out/${TAG}_${CFG}_pmc_w.log updates)
+  NL=$(win $R/gpurun_out/${TAG}_${CFG}_pmc_f.log sweep_launches); NA=$(win $R/gpurun_out/${TAG}_${CFG}_pmc_f.log naccs)
   FC=$(find $R/gpurun_out/pmc_fetch_$CFG -name '*counter_collection.csv' | head -1)
   WC=$(find $R/gpurun_out/pmc_write_$CFG -name '*counter_collection.csv' | head -1)
-  ACC=$(python3 -c "import json,sys;[print(json.loads(l)['roofline'].get('acceptance_rate',0)) for l in open('$R/gpurun_out/${TAG}_${CFG}_bench.log') if l.startswith('{')]" | tail -1)
-  python3 $R/tools/pmc_traffic.py $FC $WC $R/gpurun_out/${TAG}_hbm_traffic_${CFG}.json $KERN $LANES $LD $ACC $UF $UW
+  ACC=$(python3 -c "print($NA / max($UF, 1))")
+  python3 $R/tools/pmc_traffic.py $FC $WC $R/gpurun_out/${TAG}_hbm_traffic_${CFG}.json $KERN $LANES $LD $ACC $UF $UW $NL
   cp $FC $R/gpurun_out/${TAG}_${CFG}_pmc_fetch_size.csv; cp $WC $R/gpurun_out/${TAG}_${CFG}_pmc_write_size.csv
   rm -rf $R/gpurun_out/pmc_fetch_$CFG $R/gpurun_out/pmc_write_$CFG
 fi
