@@ -149,6 +149,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   } while (0)
   abcdez_ctx* ctx = new abcdez_ctx();
   ctx->device = device;
+  if (const char* g = getenv("ABZ_GRAPHS")) ctx->graphs_on = !(g[0] == '0' && g[1] == 0);
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
   /* every dimension of the row a continuous Normal (d == ld, no padding): the sweeps run the two-instruction log-density
@@ -227,6 +228,8 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (abz_mc_graph& g : ctx->mc_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->mc_graphs.clear();
   abz_jit_destroy(ctx);
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
@@ -275,6 +278,19 @@ int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
   ABZ_REQUIRE(ctx, "set_stream: null context");
   if (ctx->stream != (hipStream_t)hip_stream) ctx->ahead = abz_ahead{};      /* a select enqueued ahead sits on the old stream */
   ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+/* Replay abcdemc generations as HIP graphs (default on).  Results do not depend on it. */
+int abcdez_ctx_set_graphs(abcdez_ctx* ctx, int on) {
+  ABZ_REQUIRE(ctx, "set_graphs: null context");
+  ctx->graphs_on = on != 0;
+  return 0;
+}
+/* Diagnostics: asynchronous abcdemc generations replayed from a graph / graphs captured / generations enqueued launch by launch. */
+int abcdez_graph_stats(abcdez_ctx* ctx, int64_t* replays, int64_t* captures, int64_t* direct) {
+  ABZ_REQUIRE(ctx && replays && captures && direct, "graph_stats: null argument");
+  *replays = ctx->n_graph_replays; *captures = ctx->n_graph_captures; *direct = ctx->n_graph_direct;
   return 0;
 }
 
@@ -900,32 +916,101 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     ABZ_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->d_ring, ctx->h_ring, 0));
   }
   int rc = 0;
+  if (ctx->mc_seq_dirty) {           /* an earlier generation failed between its launches: re-seat the device's generation counter */
+    const unsigned long long v = (unsigned long long)ctx->mc_issued;
+    ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ABZ_HIP_CHECK(hipMemcpy(ctx->d_scal + ABZ_S_MCSEQ, &v, 8, hipMemcpyHostToDevice));
+    ctx->mc_seq_dirty = false;
+  }
   /* a new chain: host-given extrema (the first generation of a run), other parameters, another population than the one the
    * generation before wrote (its outputs are this generation's inputs) */
   if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N) {
     ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1;
   }
-  if (lo_hi || !ctx->mc_window_ready || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target) {
-    rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
-    if (rc) return rc;
-  }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
+  const bool need_window = lo_hi || !ctx->mc_window_ready || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target;
   const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
-  if (do_rank) {                     /* mc:20-24 is only reached while some Ds[i] > eps */
-    rc = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound);
-    if (rc) return rc;
-  }
-  const long long ev_before = ctx->ev_tail;
-  rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
-                           gamma_sigma, 0u, (uint32_t)N, sweep, win);
-  if (rc) return rc;
+  const unsigned long long* seq_dev = ctx->d_scal + ABZ_S_MCSEQ;
+  const uint32_t sweep_base = sweep - (uint32_t)ctx->mc_issued;     /* the kernel adds the device's generation count back */
   const int slot = (int)(ctx->mc_issued % ABZ_MC_RING);
+  const abz_rank_plan plan = abz_rank_plan_for(N, ctx->mc_tail_hint, ctx->mc_tail_bound);
+  /* would the sweep of this generation carry an event pair (bench.py's kernel timing)?  Events cannot live in a graph. */
+  const bool timed_now = ctx->timing && ctx->ev_tail - ctx->ev_head < ABZ_GROUP_MAX &&
+                         !(ctx->timing_stride > 1 && (ctx->timing_seq % ctx->timing_stride) != 0);
+  /* the body of one generation as stream launches (also what gets captured) */
+  auto enqueue = [&]() -> int {
+    if (do_rank) {                   /* mc:20-24 is only reached while some Ds[i] > eps */
+      if (int r = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound)) return r;
+    }
+    if (int r = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
+                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev)) return r;
+    return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, do_rank ? ctx->mc_rank_state : nullptr);
+  };
+  const long long ev_before = ctx->ev_tail;
+  bool replayed = false;
+  if (ctx->graphs_on && ctx->stream != nullptr && !need_window && !timed_now) {      /* the legacy default stream cannot be captured */
+    abz_mc_graph_key key;
+    memset(&key, 0, sizeof(key));
+    key.theta = theta; key.logpi = logpi; key.delta = delta; key.ntheta = ntheta; key.nlogpi = nlogpi; key.ndelta = ndelta;
+    key.order = order; key.sorted_delta = sorted_delta; key.cnt = cnt; key.stamp_cur = ctx->stamp_cur; key.stamp_nxt = ctx->stamp_nxt;
+    key.stream = (const void*)ctx->stream; key.N = N; key.alpha = alpha; key.eps_target = eps_target; key.gamma0 = gamma0;
+    key.gsig = gamma_sigma; key.sweep_base = sweep_base; key.do_rank = do_rank ? 1 : 0;
+    key.path = do_rank ? (plan.small_path && plan.long_path ? 0 : plan.small_path ? 1 : 2) : -1;
+    key.ltiles = do_rank && plan.long_path ? plan.ltiles : 0u;
+    key.mm_bank = ctx->mm_bank; key.L = ctx->L; key.C = ctx->C;
+    if (do_rank) { if ((rc = abz_ws_reserve(ctx, plan.ws_bytes))) return rc; }     /* no allocation inside a capture */
+    key.ws = ctx->ws;
+    abz_mc_graph* g = nullptr;
+    for (abz_mc_graph& e : ctx->mc_graphs)
+      if (memcmp(&e.key, &key, sizeof(key)) == 0) { g = &e; break; }
+    if (!g) {
+      if (ctx->mc_graphs.size() >= 64) {           /* a host that keeps changing its arguments: start over */
+        for (abz_mc_graph& e : ctx->mc_graphs) (void)hipGraphExecDestroy(e.exec);
+        ctx->mc_graphs.clear();
+      }
+      const long long paths_before[3] = {ctx->n_rank_paths[0], ctx->n_rank_paths[1], ctx->n_rank_paths[2]};
+      const long long tseq = ctx->timing_seq;
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        const int r = enqueue();
+        e = hipStreamEndCapture(ctx->stream, &graph);            /* always: the stream must leave capture mode */
+        hipGraphExec_t exec = nullptr;
+        if (r == 0 && e == hipSuccess && graph) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (r == 0 && e == hipSuccess && exec) {
+          abz_mc_graph ng;
+          ng.key = key; ng.exec = exec; ng.rank_state = do_rank ? ctx->mc_rank_state : nullptr; ng.rank_limit = ctx->mc_rank_limit;
+          ctx->mc_graphs.push_back(ng);
+          g = &ctx->mc_graphs.back();
+          ctx->n_graph_captures += 1;
+        }
+      }
+      /* the capture ran the launchers' host-side bookkeeping once; the replay below does it again */
+      for (int q = 0; q < 3; ++q) ctx->n_rank_paths[q] = paths_before[q];
+      ctx->timing_seq = tseq;
+      if (!g) { (void)hipGetLastError(); ctx->graphs_on = false; }     /* capture is not available here: stream launches from now on */
+    }
+    if (g) {
+      ABZ_HIP_CHECK(hipGraphLaunch(g->exec, ctx->stream));
+      if (do_rank) { ctx->n_rank_paths[key.path] += 1; ctx->mc_rank_state = g->rank_state; ctx->mc_rank_limit = g->rank_limit; }
+      if (ctx->timing && ctx->timing_stride > 1) ctx->timing_seq += 1;      /* what abz_time_begin would have counted */
+      ctx->n_graph_replays += 1;
+      replayed = true;
+    }
+  }
+  if (!replayed) {
+    ctx->n_graph_direct += 1;
+    if (need_window) {
+      rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
+      if (rc) { ctx->mc_seq_dirty = true; return rc; }
+    }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
+    rc = enqueue();
+    if (rc) { ctx->mc_seq_dirty = true; return rc; }
+  }
   ctx->ring_timed[slot] = ctx->ev_tail != ev_before;
   ctx->ring_folded[slot] = false;
   ctx->ring_chain[slot] = ctx->mc_chain; ctx->ring_eps_target[slot] = eps_target;
   ctx->mc_last_out = (const void*)ndelta; ctx->mc_last_N = N;
-  rc = abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring + (size_t)slot * ABZ_RING_WORDS, (unsigned long long)ctx->mc_issued + 1ull,
-                              alpha, eps_target, do_rank ? ctx->mc_rank_state : nullptr);
-  if (rc) return rc;
   ctx->mc_window_ready = true; ctx->mc_alpha = alpha; ctx->mc_eps_target = eps_target;
   ctx->mm_bank = 1 - ctx->mm_bank;   /* the kernel reset the other bank for the next sweep */
   ctx->mc_have_bank = true;

@@ -8,6 +8,7 @@
 
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "abcdez_spec.h"
 #include "abz_hotmodel.h"
@@ -26,8 +27,32 @@ struct abz_ahead {
   double alpha = 0.0, eps_prev = 0.0, eps_target = 0.0;
 };
 
+/* One abcdemc generation (rank pass + sweep + snapshot: up to 15 dependent launches, no data-dependent host decision,
+ * src/abcdez_mc.jl:134-161) captured as a HIP graph.  A chain of dependent small kernels runs at ~3.2 us per kernel as stream
+ * launches and ~2.2 us as a graph (profiles/r03_launch_floor.jsonl).  Everything that changes from one generation to the next
+ * is either part of the key (buffer parity, the min / max bank, which sorts the rank pass launches and how large) or read on
+ * the device (the generation's sequence number ABZ_S_MCSEQ -> RNG epoch, ring slot, ticket): a replay needs no patching. */
+struct abz_mc_graph_key {
+  const void *theta, *logpi, *delta, *ntheta, *nlogpi, *ndelta, *order, *sorted_delta, *cnt, *stamp_cur, *stamp_nxt, *ws, *stream;
+  int64_t N;
+  double alpha, eps_target, gamma0, gsig;
+  uint32_t sweep_base, ltiles;
+  int32_t do_rank, path, mm_bank, L, C;
+};
+struct abz_mc_graph {
+  abz_mc_graph_key key;
+  hipGraphExec_t exec = nullptr;
+  const uint32_t* rank_state = nullptr;
+  uint32_t rank_limit = 0xFFFFFFFFu;
+};
+
 struct abcdez_ctx {
   int device = 0;
+  /* abcdez_ctx_set_graphs: replay abcdemc generations as HIP graphs (default on; ABZ_GRAPHS=0 in the environment turns it off) */
+  bool graphs_on = true;
+  std::vector<abz_mc_graph> mc_graphs;
+  long long n_graph_replays = 0, n_graph_captures = 0, n_graph_direct = 0;
+  bool mc_seq_dirty = false;        /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */
   long long n_select_reused = 0, n_select_inline = 0;   /* prologues that found their select enqueued ahead / ran it themselves */
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
   hipStream_t stream = nullptr;
@@ -191,6 +216,9 @@ enum {
   ABZ_S_MCW_EPS = ABZ_S_GRP_SNAP + 2 * ABZ_GROUP_MAX,
   ABZ_S_MCW_KLO = ABZ_S_MCW_EPS + 1, ABZ_S_MCW_SHIFT = ABZ_S_MCW_EPS + 2, ABZ_S_MCW_LO = ABZ_S_MCW_EPS + 3,
   ABZ_S_MCW_HI = ABZ_S_MCW_EPS + 4,
+  /* number of asynchronous abcdemc generations whose snapshot kernel has run (== the host's mc_issued when the next one
+   * executes): ring slot and ticket of the snapshot, RNG epoch of the sweep = base + this */
+  ABZ_S_MCSEQ = ABZ_S_MCW_EPS + 5,
   ABZ_S_N = ABZ_S_MCW_EPS + 6
 };
 
@@ -213,10 +241,14 @@ static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
 }
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
-                        uint32_t, uint32_t, uint32_t, const unsigned long long*);
+                        uint32_t, uint32_t, uint32_t, const unsigned long long*, const unsigned long long* seq_dev = nullptr);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
-int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha, double eps_target,
+int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_ring, double alpha, double eps_target,
                            const uint32_t* rank_state);
+/* which sorts a rank pass launches for a tail of the hinted / bounded length, and the grid of the long-tail kernels (a power of two
+ * of wave-tiles: the kernels stride, so any grid is correct -- few distinct values keep the graph cache small) */
+struct abz_rank_plan { bool small_path, long_path; uint32_t ltiles; size_t ws_bytes; };
+abz_rank_plan abz_rank_plan_for(int64_t N, int64_t tail_hint, int64_t tail_bound);
 int abz_launch_push_p(abcdez_ctx*, const double*, int64_t, double*);
 void abz_fold_counters(abcdez_ctx*);
 /* Read-back of the first `nwords` device scalars WITHOUT the copy engine and without a stream synchronisation: a one-block

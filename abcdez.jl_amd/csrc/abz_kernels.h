@@ -342,6 +342,7 @@ struct McSwarmArgs {
   uint32_t N, i0, n_local, sweep;
   const uint64_t* stamp;        /* blob stamps, both NULL when blobs are off */
   uint64_t* nstamp;
+  const unsigned long long* seq_dev;   /* non-NULL: the RNG epoch is sweep + *seq_dev (generations replayed as a graph, abz_ctx.h) */
 };
 
 __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
@@ -359,6 +360,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   constexpr uint32_t PB = ABZ_BLOCK / L;
   const HotModel& M = a.hm;
   const uint64_t seed = M.seed;
+  const uint32_t sweep = a.sweep + (a.seq_dev ? (uint32_t)*a.seq_dev : 0u);      /* wave-uniform: a scalar load */
   __shared__ ModelLds<LD> s_model;
   {
     ModelStage<SIM, LD> stage;
@@ -382,8 +384,8 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
     const double lpi = a.logpi[i];
     const double di = a.delta[i];
     const uint32_t cnt_i = a.cnt[i];                                        /* meaningful only where di > eps (abz_sort.hip) */
-    const abz_u64x2 w_better = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_BETTER);
-    const abz_u64x2 w_donor = abz_rng(seed, i, a.sweep, 0, ABZ_RNG_DONOR);
+    const abz_u64x2 w_better = abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER);
+    const abz_u64x2 w_donor = abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR);
     const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
     uint32_t s = i;
     if (di > eps) {                                                         /* mc:20-24 */
@@ -399,7 +401,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
     load_row<L, C>(a.theta + (size_t)ib * LD, j, tb);
 
     double z0, z1;
-    abz_normal_pair(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
+    abz_normal_pair(abz_rng(seed, i, sweep, 0, ABZ_RNG_JITTER), &s_model.tab, &z0, &z1);
     const double g = a.gamma0 * (1.0 + z0 * a.gsig);                        /* mc:34 */
     double tp[C], pp[C];
 #pragma unroll
@@ -407,14 +409,14 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
 
     const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);        /* mc:41 */
     const double w_prior = lp - lpi;                                        /* mc:42 */
-    const double u = abz_u01_open(abz_rng(seed, i, a.sweep, 0, ABZ_RNG_ACCEPT).w0);
+    const double u = abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0);
     double mn = w_prior < 0.0 ? w_prior : 0.0;
     if (abz_isnan(w_prior)) mn = w_prior;
     const bool simulate = !(abz_log_tab(u, &s_model.tab) > mn);                               /* mc:43 */
     bool acc = false;
     double dp = di;
     if (simulate) {
-      dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, a.sweep, ABZ_RNG_SIM);       /* mc:45 */
+      dp = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, sweep, ABZ_RNG_SIM);       /* mc:45 */
       const double thr = eps > di ? eps : di;
       acc = dp <= thr;                                                      /* mc:54 */
     }
@@ -426,7 +428,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
       if (j == 0) {
         a.nlogpi[i] = acc ? lp : lpi;
         a.ndelta[i] = acc ? dp : di;
-        if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, a.sweep, 0) : a.stamp[i];
+        if (a.nstamp) a.nstamp[i] = acc ? abz_stamp(i, sweep, 0) : a.stamp[i];
       }
     }
     const double dn = acc ? dp : di;

@@ -424,9 +424,14 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
 /* It also prepares the NEXT generation: the extrema it has just folded are that generation's mc:146, so eps_pop and the
  * binning window (mc_window_write) are made here and the next generation starts without a window launch.            */
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
-                                                                 unsigned long long* __restrict__ out, unsigned long long seq,
+                                                                 unsigned long long* __restrict__ ring,
                                                                  double alpha, double eps_target, const uint32_t* __restrict__ rank_state,
                                                                  uint32_t rank_limit) {
+  /* which generation this is: counted on the device (the host's mc_issued when it enqueued this launch -- or when it replays
+   * the graph this launch was captured into): ring slot and ticket follow from it */
+  const unsigned long long gen = scal[ABZ_S_MCSEQ];
+  unsigned long long* out = ring + (size_t)(gen % ABZ_MC_RING) * ABZ_RING_WORDS;
+  const unsigned long long seq = gen + 1ull;
   __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
   unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
@@ -456,15 +461,42 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
+    scal[ABZ_S_MCSEQ] = seq;
   }
 }
-int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_slot, unsigned long long seq, double alpha,
+int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_ring, double alpha,
                            double eps_target, const uint32_t* rank_state) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
-  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_slot, seq, alpha, eps_target, rank_state,
+  hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_ring, alpha, eps_target, rank_state,
                      ctx->mc_rank_limit);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+abz_rank_plan abz_rank_plan_for(int64_t N, int64_t tail_hint, int64_t tail_bound) {
+  const uint32_t n = (uint32_t)N;
+  abz_rank_plan p;
+  /* both paths are launched (each looks at the tail's length on the device and the wrong one returns at once) unless the host
+   * holds a PROVED upper bound of that length (abz_ctx.h, mc_tail_bound): then only the path the bound calls for */
+  p.small_path = tail_bound < 0 || tail_bound <= (int64_t)MCR_SMALL;
+  p.long_path = tail_bound < 0 || tail_bound > (int64_t)MCR_SMALL;
+  /* step 3 is sized for the tail the host expects (4 x the last one seen, at least 16 K pairs; everything when it knows
+   * nothing; a proved bound is exact); its kernels stride, so a longer tail is sorted correctly, only slower */
+  uint64_t expect = tail_bound >= 0 ? (uint64_t)tail_bound : tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
+  if (expect > n) expect = n;
+  const uint32_t ltiles_max = (n + MCR_TILE - 1) / MCR_TILE;                 /* tiles of a tail that is the whole population */
+  uint32_t lt = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
+  uint32_t q = MCR_WAVES;                                                    /* round up to a power of two of wave-tiles */
+  while (q < lt) q <<= 1;
+  p.ltiles = q < ltiles_max ? q : (ltiles_max > 0u ? ltiles_max : 1u);
+  if (p.ltiles < 1u) p.ltiles = 1u;
+  uint32_t rounds = MCR_BATCH;
+  while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;
+  const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
+  const size_t pb = abz_align((size_t)n * 4), kb = abz_align((size_t)n * 8);
+  const size_t tb = abz_align((size_t)256 * ltiles_max * 4 + 256 * 4), cb = abz_align((size_t)ntiles * 4), sb = abz_align(64);
+  p.ws_bytes = kb + 4 * pb + tb + cb + sb;
+  return p;
 }
 
 /* win: NULL = (eps_pop, dmax_hint) are host values; else the device window mc_window_kernel wrote (the two host values are
@@ -485,13 +517,9 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   uint32_t rounds = MCR_BATCH;
   while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;
   const uint32_t ntiles = (uint32_t)(((uint64_t)n + (uint64_t)rounds * MCR_ROUND - 1) / ((uint64_t)rounds * MCR_ROUND));
-  /* step 3 is sized for the tail the host expects (4 x the last one seen, at least 16 K pairs; everything when it knows
-   * nothing; a proved bound is exact); its kernels stride, so a longer tail is sorted correctly, only slower */
-  uint64_t expect = tail_bound >= 0 ? (uint64_t)tail_bound : tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
-  if (expect > n) expect = n;
+  const abz_rank_plan plan = abz_rank_plan_for(N, tail_hint, tail_bound);
   const uint32_t ltiles_max = (n + MCR_TILE - 1) / MCR_TILE;                 /* tiles of a tail that is the whole population */
-  uint32_t ltiles = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
-  if (ltiles < 1u) ltiles = 1u;
+  const uint32_t ltiles = plan.ltiles;
   const size_t pb = abz_align((size_t)n * 4), kb = abz_align((size_t)n * 8);
   const size_t tb = abz_align((size_t)256 * ltiles_max * 4 + 256 * 4), cb = abz_align((size_t)ntiles * 4), sb = abz_align(64);
   int rc = abz_ws_reserve(ctx, kb + 4 * pb + tb + cb + sb);
@@ -512,10 +540,8 @@ int abz_rank_prepare_impl(abcdez_ctx* ctx, const double* delta, int64_t N, doubl
   hipLaunchKernelGGL(mcr_count_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, tile_cnt, ntiles, rounds, win);
   hipLaunchKernelGGL(mcr_split_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, st, delta, n, klo, eps_pop, tile_cnt, ntiles, rounds, order,
                      sorted_delta, tk, tv, win, state);
-  /* which sort: both paths are launched (each looks at the tail's length on the device and the wrong one returns at once) unless
-   * the host holds a PROVED upper bound of that length (abz_ctx.h, mc_tail_bound): then only the path the bound calls for */
-  const bool small_path = tail_bound < 0 || tail_bound <= (int64_t)MCR_SMALL;
-  const bool long_path = tail_bound < 0 || tail_bound > (int64_t)MCR_SMALL;
+  /* which sort: abz_rank_plan_for */
+  const bool small_path = plan.small_path, long_path = plan.long_path;
   ctx->n_rank_paths[small_path && long_path ? 0 : small_path ? 1 : 2] += 1;
   const uint32_t lim = small_path ? (uint32_t)MCR_SMALL : 0u;      /* tails up to here are the LDS sort's; 0: the radix sort takes any length */
   if (small_path)

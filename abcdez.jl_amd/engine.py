@@ -87,6 +87,16 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
         return ld.value, L.value, Cc.value
 
+    def set_graphs(self, on: bool):
+        """replay abcdemc generations as HIP graphs (default on; results do not depend on it)"""
+        _lib.check(self.lib, self.lib.abcdez_ctx_set_graphs(self.ctx, 1 if on else 0))
+
+    def graph_stats(self):
+        """(generations replayed from a graph, graphs captured, generations enqueued launch by launch)"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_graph_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def set_timing(self, on):
         """True / 1: every sweep launch; 2: the first sweep of every grouped call; False: off"""
         _lib.check(self.lib, self.lib.abcdez_ctx_set_timing(self.ctx, int(on)))
@@ -383,6 +393,31 @@ class PopulationEngine:
         self.r_lo, self.r_hi = 0, N
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
+
+    def run_scope(self):
+        """Context manager for a whole run: work on a side stream of this engine when the caller's current stream is the
+        legacy default stream (which cannot be captured into a graph and serialises with every other blocking stream); the
+        side stream first waits for the caller's stream and the caller's stream waits for it at exit, so code around the
+        run sees ordinary stream order.  A caller that already runs on a stream of its own keeps it."""
+        import contextlib
+
+        if self.device.type != "cuda":
+            return contextlib.nullcontext()
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != 0:
+            return contextlib.nullcontext()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+
+        @contextlib.contextmanager
+        def scope():
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                try:
+                    yield
+                finally:
+                    cur.wait_stream(self._side)
+        return scope()
 
     def _stream(self):
         """the library launches on the stream that is current NOW: torch ops and collectives issued by this engine

@@ -6,6 +6,7 @@ Literal restatement of the reference's host loop ``abcdemc!``
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import math
 
@@ -33,6 +34,13 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
 
     spec = ModelSpec(prior, dist, seed=rng)
     eng = _make_engine(spec, nparticles, engine, process_group, storage="classic")
+    # the whole run on a stream of its own when the caller sits on the legacy default stream (engine.run_scope): generations
+    # are replayed as HIP graphs, which the default stream cannot capture
+    with (eng.run_scope() if hasattr(eng, "run_scope") else contextlib.nullcontext()):
+        return _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α)
+
+
+def _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α):
     if verbose:
         log.info("Running abcdemc with engine %s: ϵ_target=%s nparticles=%d generations=%d seed=%d",
                  type(eng).__name__, ϵ_target, nparticles, generations, spec.seed)

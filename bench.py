@@ -80,6 +80,8 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL, one rank per GPU (the contract); gloo = rehearsal of the N > 1 path on a box with fewer GPUs "
                         "than ranks: the ranks share the visible GPUs, collectives go through the host")
+    p.add_argument("--default-stream", action="store_true", help="diagnostic: run on the legacy default stream (no graph replay)")
+    p.add_argument("--no-graphs", action="store_true", help="diagnostic: abcdemc generations as stream launches, not graph replays")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -460,6 +462,10 @@ def run_config(args):
         ppg = args.particles_per_gpu or cfg["ppg"]
     device = local_rank if args.dist_backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
+    if not args.default_stream:
+        # everything on a stream of its own: the legacy default stream cannot be captured (abcdemc generations are replayed as
+        # HIP graphs) and serialises with every other blocking stream of the process
+        torch.cuda.set_stream(torch.cuda.Stream(device))
     pg = None
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -475,6 +481,8 @@ def run_config(args):
     spec = A.ModelSpec(cfg["prior"], cfg["sim"], seed=1)
     eng = HipEngine(spec, N, pg, lanes=args.lanes, storage=cfg["storage"], force_collectives=args.force_collectives)
     ld, L, C = eng.ops.layout()
+    if args.no_graphs:
+        eng.ops.set_graphs(False)
     eng.init_population()
     if cfg["kind"] == "smc":
         eng.reset_weights()
@@ -622,6 +630,11 @@ def run_config(args):
         out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (around one of their sweeps, in turn)
         if cfg["kind"] == "mc":
             out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
+            gr = eng.ops.graph_stats()
+            out["config"]["graph_replay"] = {"generations_replayed": gr[0], "graphs_captured": gr[1], "generations_stream_launched": gr[2],
+                                             "what": "one abcdemc generation (rank pass + sweep + snapshot, <= 15 dependent launches) is captured "
+                                                     "once per launch shape and replayed as a HIP graph; generations whose sweep carries the "
+                                                     "bench's event pair are enqueued launch by launch"}
         if whole is not None:
             out["whole_run"] = whole
             # the second half of BASELINE.json's metric ("posterior-mean & log-Z error vs ref"), from the whole run above

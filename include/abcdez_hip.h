@@ -65,6 +65,12 @@ ABCDEZ_API int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N);
 ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */
 ABCDEZ_API int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
+/* abcdemc generations enqueued by abcdez_mc_generation_async (up to 15 dependent launches, no host decision in between,
+ * src/abcdez_mc.jl:134-161) are captured once per launch shape and replayed as HIP graphs: ~1 us less per dependent kernel than
+ * stream launches.  on = 0 turns that off (so does ABZ_GRAPHS=0 in the environment); results do not depend on it.
+ * abcdez_graph_stats: generations replayed / graphs captured / generations enqueued launch by launch. */
+ABCDEZ_API int abcdez_ctx_set_graphs(abcdez_ctx* ctx, int on);
+ABCDEZ_API int abcdez_graph_stats(abcdez_ctx* ctx, int64_t* replays, int64_t* captures, int64_t* direct);
 ABCDEZ_API int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lanes, int32_t* comps_per_lane);
 ABCDEZ_API int abcdez_sync(abcdez_ctx* ctx);
 /* HIP-event timing of the sweep kernel on the context's stream (measurement only): accumulated kernel milliseconds,

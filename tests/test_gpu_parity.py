@@ -304,6 +304,84 @@ def test_mc_generations_issued_ahead_equal_the_step_by_step_oracle(oracle, name,
     assert hip.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5) == orc.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5)
 
 
+@pytest.mark.parametrize("name,N,gens", [("normal1d", 3000, 40), ("normal1d", 60000, 70), ("mvn8", 20000, 30)])
+def test_mc_generations_replayed_as_graphs_equal_the_oracle(oracle, name, N, gens):
+    """One abcdemc generation (rank pass + sweep + snapshot) is captured per launch shape and REPLAYED as a HIP graph
+    (abcdez_ctx_set_graphs; needs a stream of its own -- the legacy default stream cannot be captured): the RNG epoch, the
+    ring slot and the ticket come from the generation counter on the device.  Bit for bit the oracle's synchronous
+    generations, through every shape of the rank pass (both sorts, only the LDS sort, only the radix sort, none)."""
+    spec, hip, orc, eps_target = engines(name, N, oracle=oracle, storage="classic")
+    gamma0 = 2.38 / math.sqrt(2 * spec.d)
+    orc.init_population()
+    lo, hi = orc.extrema()
+    want = []
+    for gen in range(gens):
+        eps_pop = max(eps_target, lo)
+        nsim, ngt, lo, hi = orc.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5)
+        want.append((nsim, ngt, lo, hi, eps_pop))
+    with hip.run_scope():
+        assert torch.cuda.current_stream().cuda_stream != 0
+        hip.init_population()
+        first = hip.extrema()
+        got, converged = [], False
+        for gen in range(gens):
+            hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=not converged)
+            while hip.mc_generations_in_flight() > (gen % 5):
+                got.append(hip.mc_generation_collect())
+                converged = converged or got[-1][3] <= eps_target
+        while hip.mc_generations_in_flight():
+            got.append(hip.mc_generation_collect())
+        replays, captures, direct = hip.ops.graph_stats()
+        assert got == want
+        assert_state_equal(hip, orc, "after the replayed generations")
+    assert replays + direct == gens and direct >= 1 and replays >= gens // 2, (replays, captures, direct)
+    assert 1 <= captures <= 24, captures          # few launch shapes: buffer parity x rank-pass path x (quantised) grid
+    # the same run launch by launch gives the same population
+    spec2, hip2, _, _ = engines(name, N, oracle=oracle, storage="classic")
+    hip2.ops.set_graphs(False)
+    with hip2.run_scope():
+        hip2.init_population()
+        first = hip2.extrema()
+        conv = False
+        for gen in range(gens):
+            hip2.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=not conv)
+            conv = conv or hip2.mc_generation_collect()[3] <= eps_target
+        assert hip2.ops.graph_stats()[0] == 0
+        assert_state_equal(hip2, orc, "stream launches")
+
+
+def test_mc_rank_pass_with_a_stale_tail_bound_fails_loudly(oracle):
+    """once a chain of generations ran with eps_pop == eps_target the rank pass launches only the sort its
+    proved tail bound calls for.  Distances written behind the library's back (here: a torch copy, without
+    abcdez_smc_select_discard) make the bound stale -- the LDS sort alone cannot take the new tail.  The device notices and the
+    ticket's redemption raises instead of handing back a sweep that drew from a stale enumeration; after a discard the
+    context works again."""
+    N = 6000
+    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    hip.init_population()
+    gamma0 = 2.38 / math.sqrt(2)
+    first = hip.extrema()
+    conv = False
+    for gen in range(80):
+        hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=not conv)
+        out = hip.mc_generation_collect()
+        conv = conv or out[3] <= eps_target
+        if hip.ops.mc_rank_stats()[1] >= 2:        # two rank passes ran with only the LDS sort: the bound is <= 4096
+            break
+    assert hip.ops.mc_rank_stats()[1] >= 2 and not conv
+    hip.state[2].add_(10.0)                         # every particle is in the tail now: 6000 > 4096 pairs
+    hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, do_rank=True)
+    with pytest.raises(_lib.AbcdezError, match="tail bound that no longer held"):
+        hip.mc_generation_collect()
+    # telling the library (what upload_state / reset paths do) makes the same context usable again
+    hip.discard_select_ahead()
+    hip._mc_pending = []
+    lo_hi = hip.extrema()
+    hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=lo_hi, do_rank=True)
+    nsim, ngt, lo, hi, eps_pop = hip.mc_generation_collect()
+    assert hi >= lo and 0 <= ngt <= N and 0 <= nsim <= N and eps_pop >= eps_target
+
+
 def test_mc_generation_tickets_are_bounded_and_ordered(oracle):
     spec, hip, _, eps_target = engines("normal1d", 2000, oracle=oracle, storage="classic")
     hip.init_population()
