@@ -149,7 +149,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   } while (0)
   abcdez_ctx* ctx = new abcdez_ctx();
   ctx->device = device;
-  if (const char* g = getenv("ABZ_GRAPHS")) ctx->graphs_on = !(g[0] == '0' && g[1] == 0);
+  if (const char* g = getenv("ABZ_GRAPHS")) ctx->graphs_on = !(g[0] == '0' && g[1] == 0) && g[0] != 0;
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
   /* every dimension of the row a continuous Normal (d == ld, no padding): the sweeps run the two-instruction log-density
@@ -281,7 +281,7 @@ int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
   return 0;
 }
 
-/* Replay abcdemc generations as HIP graphs (default on).  Results do not depend on it. */
+/* Replay abcdemc generations as HIP graphs (default off: measured slower, abz_ctx.h).  Results do not depend on it. */
 int abcdez_ctx_set_graphs(abcdez_ctx* ctx, int on) {
   ABZ_REQUIRE(ctx, "set_graphs: null context");
   ctx->graphs_on = on != 0;

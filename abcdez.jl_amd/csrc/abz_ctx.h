@@ -48,8 +48,11 @@ struct abz_mc_graph {
 
 struct abcdez_ctx {
   int device = 0;
-  /* abcdez_ctx_set_graphs: replay abcdemc generations as HIP graphs (default on; ABZ_GRAPHS=0 in the environment turns it off) */
-  bool graphs_on = true;
+  /* abcdez_ctx_set_graphs: replay abcdemc generations as HIP graphs.  DEFAULT OFF: measured slower on ROCm 7.2 / MI355X -- a graph's
+   * kernel nodes take what the same kernels take as stream launches (the 4-5 us of a small dependent kernel are the dispatch itself,
+   * not the host) and every graph launch adds ~16 us before its first node: 0.140 against 0.125 ms per generation
+   * (profiles/r04_mc1d_graph_replay_ab.json, r04_mc1d_generation_timeline_graph_replay.txt).  ABZ_GRAPHS=1 turns it on. */
+  bool graphs_on = false;
   std::vector<abz_mc_graph> mc_graphs;
   long long n_graph_replays = 0, n_graph_captures = 0, n_graph_direct = 0;
   bool mc_seq_dirty = false;        /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */

@@ -485,10 +485,12 @@ abz_rank_plan abz_rank_plan_for(int64_t N, int64_t tail_hint, int64_t tail_bound
   uint64_t expect = tail_bound >= 0 ? (uint64_t)tail_bound : tail_hint < 0 ? (uint64_t)n : (uint64_t)tail_hint * 4u + 16384u;
   if (expect > n) expect = n;
   const uint32_t ltiles_max = (n + MCR_TILE - 1) / MCR_TILE;                 /* tiles of a tail that is the whole population */
-  uint32_t lt = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
-  uint32_t q = MCR_WAVES;                                                    /* round up to a power of two of wave-tiles */
-  while (q < lt) q <<= 1;
-  p.ltiles = q < ltiles_max ? q : (ltiles_max > 0u ? ltiles_max : 1u);
+  /* two grid sizes only (every distinct launch shape of a generation is a graph to capture, ~0.1 ms each): a short tail
+   * (<= 32 K pairs: 16 workgroups) or one wave-tile per 512 pairs of the whole population, capped at 1024 workgroups -- the
+   * kernels stride over their tiles and leave at once when there is nothing for them */
+  const uint32_t lt = (uint32_t)((expect + MCR_TILE - 1) / MCR_TILE);
+  const uint32_t big = ltiles_max < 1024u * MCR_WAVES ? ltiles_max : 1024u * MCR_WAVES;
+  p.ltiles = lt <= 64u ? (64u < big ? 64u : big) : big;
   if (p.ltiles < 1u) p.ltiles = 1u;
   uint32_t rounds = MCR_BATCH;
   while ((uint64_t)rounds * MCR_ROUND * 4096ull < (uint64_t)n) rounds *= 2;

@@ -88,7 +88,7 @@ class HipOps:
         return ld.value, L.value, Cc.value
 
     def set_graphs(self, on: bool):
-        """replay abcdemc generations as HIP graphs (default on; results do not depend on it)"""
+        """replay abcdemc generations as HIP graphs (default off: measured slower than stream launches; results do not depend on it)"""
         _lib.check(self.lib, self.lib.abcdez_ctx_set_graphs(self.ctx, 1 if on else 0))
 
     def graph_stats(self):

@@ -81,7 +81,7 @@ def parse():
                    help="nccl = RCCL, one rank per GPU (the contract); gloo = rehearsal of the N > 1 path on a box with fewer GPUs "
                         "than ranks: the ranks share the visible GPUs, collectives go through the host")
     p.add_argument("--default-stream", action="store_true", help="diagnostic: run on the legacy default stream (no graph replay)")
-    p.add_argument("--no-graphs", action="store_true", help="diagnostic: abcdemc generations as stream launches, not graph replays")
+    p.add_argument("--graphs", action="store_true", help="diagnostic: replay abcdemc generations as HIP graphs (off by default: measured slower)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -481,8 +481,8 @@ def run_config(args):
     spec = A.ModelSpec(cfg["prior"], cfg["sim"], seed=1)
     eng = HipEngine(spec, N, pg, lanes=args.lanes, storage=cfg["storage"], force_collectives=args.force_collectives)
     ld, L, C = eng.ops.layout()
-    if args.no_graphs:
-        eng.ops.set_graphs(False)
+    if args.graphs:
+        eng.ops.set_graphs(True)
     eng.init_population()
     if cfg["kind"] == "smc":
         eng.reset_weights()

@@ -66,9 +66,10 @@ ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */
 ABCDEZ_API int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
 /* abcdemc generations enqueued by abcdez_mc_generation_async (up to 15 dependent launches, no host decision in between,
- * src/abcdez_mc.jl:134-161) are captured once per launch shape and replayed as HIP graphs: ~1 us less per dependent kernel than
- * stream launches.  on = 0 turns that off (so does ABZ_GRAPHS=0 in the environment); results do not depend on it.
- * abcdez_graph_stats: generations replayed / graphs captured / generations enqueued launch by launch. */
+ * src/abcdez_mc.jl:134-161) CAN be captured once per launch shape and replayed as HIP graphs (on = 1, or ABZ_GRAPHS=1 in the
+ * environment; needs a stream other than the legacy default stream).  Off by default: on ROCm 7.2 / MI355X the replay is slower
+ * than the stream launches it replaces (0.140 against 0.125 ms per generation at 2^20 particles; profiles/r04_mc1d_graph_replay_ab.json).
+ * Results do not depend on it.  abcdez_graph_stats: generations replayed / graphs captured / generations enqueued launch by launch. */
 ABCDEZ_API int abcdez_ctx_set_graphs(abcdez_ctx* ctx, int on);
 ABCDEZ_API int abcdez_graph_stats(abcdez_ctx* ctx, int64_t* replays, int64_t* captures, int64_t* direct);
 ABCDEZ_API int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lanes, int32_t* comps_per_lane);

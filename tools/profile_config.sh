@@ -9,5 +9,6 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 F=$(find $R/gpurun_out/prof_$CFG -name 'kt_kernel_trace.csv' | head -1)
 python3 $R/tools/timeline_gaps.py $F $MARK 3 $LANES > $R/gpurun_out/${TAG}_${CFG}_timeline.txt 2>&1
 cp $(find $R/gpurun_out/prof_$CFG -name 'kt_kernel_stats.csv' | head -1) $R/gpurun_out/${TAG}_${CFG}_kernel_stats.csv
+python3 $R/tools/trace_window_stats.py $F $R/gpurun_out/${TAG}_${CFG}_prof_bench.log ${KERN:-smc_swarm_packed_kernel} > $R/gpurun_out/${TAG}_${CFG}_kernel_stats_timed_steps.csv 2>&1
 python3 $R/tools/kernel_avg_check.py $F $R/gpurun_out/${TAG}_${CFG}_prof_bench.log ${KERN:-smc_swarm_packed_kernel} ${PER_STEP:-3} > $R/gpurun_out/${TAG}_${CFG}_kernel_avg_check.json 2>&1
 rm -rf $R/gpurun_out/prof_$CFG
