@@ -181,7 +181,7 @@ def cfg_smc32(A, args):
                 cpu_particles=1 << 22, cpu_steps=10, storage="packed",
                 workload=f"abcdesmc d={d} MVN simulator + Euclidean distance (BASELINE.json configs[2]); "
                          "alpha=0.95 delta_ess=0.5 Kmcmc=3 IndicatorStrict",
-                exact_logZ=-8.111642 if d == 32 else None,
+                exact_logZ=EXACT["logZ_mvn32_eps6"] if d == 32 else None,
                 exact_post_mean=EXACT["post_mean_mvn32_eps6"] if d == 32 else None)
 
 
