@@ -264,7 +264,17 @@ def test_sharded_group_of_sweeps_on_three_replicas(oracle, name):
     with pytest.raises(_lib.AbcdezError, match="group_end"):    # inside a group the counters come from the group's read-back
         ops0.smc_swarm_packed(full0["b"][0], full0["b"][1], n, 0, n, full0["s0"], full0["s1"], full0["lp"], full0["dl"], full0["fl"],
                               eps, g0, 1e-5, e.sweep)
-    ranks[0] = HipOps(spec)                                     # (a fresh context for the runs below)
+    # an abandoned group (a collective or a launch failed between begin and end): abort closes it, and the SAME context takes a
+    # new group and the counter-returning calls again (it used to stay poisoned for the life of the context)
+    ops0.smc_group_abort()
+    ops0.smc_group_abort()                                      # no group open: a no-op
+    ab = replica()
+    got = ops0.smc_swarm_packed(ab["b"][0], ab["b"][1], n, 0, n, ab["s0"], ab["s1"], ab["lp"], ab["dl"], None, eps, g0, 1e-5, e.sweep)
+    ab2 = replica()
+    assert got == e.ops.smc_swarm_packed(ab2["b"][0], ab2["b"][1], n, 0, n, ab2["s0"], ab2["s1"], ab2["lp"], ab2["dl"], None, eps, g0,
+                                         1e-5, e.sweep)
+    ops0.smc_group_begin(n, 1.0)
+    ops0.smc_group_abort()
 
     seen = set()
     sweep0 = e.sweep

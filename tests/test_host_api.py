@@ -228,6 +228,19 @@ def test_julia_shim_keeps_the_reference_signatures():
     assert "philox_key(rng::AbstractRNG) = rand(rng, UInt64)" in jl and "using ABCdeZ, Distributions, LinearAlgebra, Random" in jl
 
 
+def test_rng_argument_takes_a_key_or_a_generator():
+    """`rng` of the reference signatures (src/abcdez_smc.jl:220): an int is the Philox key itself; a numpy Generator /
+    RandomState -- the host-language counterpart of an AbstractRNG -- gives the key with ONE draw, so seeding it makes a run
+    reproducible the way it does for the reference's CPU methods (the Julia shim: rand(rng, UInt64))"""
+    from abcdez_amd.model import philox_key
+    assert philox_key(5) == 5 and philox_key(-1) == 2 ** 64 - 1 and philox_key(2 ** 64 + 3) == 3
+    g1, g2 = np.random.default_rng(3), np.random.default_rng(3)
+    k = philox_key(g1)
+    assert 0 <= k < 2 ** 64 and k == philox_key(g2) and philox_key(g1) != k          # one draw per call
+    assert philox_key(np.random.RandomState(1)) == philox_key(np.random.RandomState(1))
+    assert A.ModelSpec(PRIOR, SIM, seed=np.random.default_rng(3)).seed == k
+
+
 def test_roctx_ranges_cost_nothing_unless_asked_for(monkeypatch):
     """abcdez_amd/_trace.py: a shared no-op object unless ABZ_ROCTX=1 / a rocprofv3 run; with ABZ_ROCTX=1 the roctx library
     loads and push / pop are balanced"""

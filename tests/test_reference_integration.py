@@ -257,6 +257,17 @@ def test_abcdesmc_resume_reproduces_the_uninterrupted_run(oracle, tmp_path, abck
         smc(oracle, prior, sim, 2.4, resume=part.checkpoint(), **dict(kw, rng=18))
     with pytest.raises(ValueError, match="not an abcdemc checkpoint"):
         mc(oracle, prior, sim, 2.4, nparticles=1500, rng=17, resume=part.checkpoint())
+    # a checkpoint records the stream it was written on -- (library version, Philox rounds) -- and a build with another round
+    # count refuses it: every random number after the resume would differ, silently
+    ck = part.checkpoint()
+    assert ck["state"]["stream_version"][1] == oracle.lib().orc_philox_rounds() == 10
+    ck["state"]["stream_version"] = [ck["state"]["stream_version"][0], 7]
+    with pytest.raises(ValueError, match="Philox4x32-7"):
+        smc(oracle, prior, sim, 2.4, resume=ck, **kw)
+    ck["state"]["stream_version"] = None                        # written before round 4: resumes, with a warning
+    with pytest.warns(UserWarning, match="stream_version"):
+        old = smc(oracle, prior, sim, 2.4, resume=ck, **kw)
+    assert old.logZ == full.logZ
 
 
 def test_abcdemc_resume_reproduces_the_uninterrupted_run(oracle, tmp_path):
