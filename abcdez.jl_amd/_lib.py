@@ -23,6 +23,8 @@ PROTOTYPES = {
     "abcdez_ctx_set_stream": [_vp, _vp],
     "abcdez_ctx_reserve": [_vp, _i64],
     "abcdez_ctx_set_lanes": [_vp, C.c_int],
+    "abcdez_ctx_set_uniform_weights": [_vp, C.c_int],
+    "abcdez_ctx_get_uniform_weights": [_vp, C.POINTER(_i32), _pi64],
     "abcdez_ctx_set_graphs": [_vp, C.c_int],
     "abcdez_graph_stats": [_vp, _pi64, _pi64, _pi64],
     "abcdez_ctx_get_layout": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],

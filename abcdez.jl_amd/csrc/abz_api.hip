@@ -19,7 +19,7 @@ int abz_count_gt_impl(abcdez_ctx*, const double*, int64_t, double, int64_t*);
 int abz_math_eval_impl(abcdez_ctx*, int, const double*, double*, double*, int64_t);
 int abz_rank_prepare_impl(abcdez_ctx*, const double*, int64_t, double, double, uint32_t*, double*, uint32_t*, const unsigned long long*, int64_t, int64_t);
 int abz_count_alive_impl(abcdez_ctx*, const uint8_t*, int64_t, int64_t*);
-int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double);
+int abz_partition_impl(abcdez_ctx*, uint8_t*, int64_t, int64_t, int64_t, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, const unsigned long long*, double, bool wfill = false);
 int abz_prologue_packed_impl(abcdez_ctx*, const double*, int64_t, int64_t, double*, uint8_t*, double, double, double, double, double, const uint32_t*, uint32_t*, double*, double*, double*, double*, double*, int64_t*, int32_t*);
 int abz_launch_smc_swarm_packed(abcdez_ctx*, const uint32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, double*, double*, double*, double*, uint8_t*, double, double, double, uint32_t, int, const unsigned long long*);
 int abz_launch_group_check(abcdez_ctx*, int, unsigned long long, uint32_t, double, int);
@@ -291,6 +291,22 @@ int abcdez_ctx_set_graphs(abcdez_ctx* ctx, int on) {
 int abcdez_graph_stats(abcdez_ctx* ctx, int64_t* replays, int64_t* captures, int64_t* direct) {
   ABZ_REQUIRE(ctx && replays && captures && direct, "graph_stats: null argument");
   *replays = ctx->n_graph_replays; *captures = ctx->n_graph_captures; *direct = ctx->n_graph_direct;
+  return 0;
+}
+
+/* "The alive particles' weights are uniform, Wns = 1 / n_alive" -- what a host asserts after it wrote them that way (smc:266-270).
+ * With an indicator kernel the prologue then uses the closed forms of the reweight (abz_population.hip, ind_reweight_kernel).
+ * The library keeps the flag itself afterwards: the indicator fast path keeps it, a resampling sets it (smc:102), a general
+ * reweight clears it. */
+int abcdez_ctx_set_uniform_weights(abcdez_ctx* ctx, int on) {
+  ABZ_REQUIRE(ctx, "set_uniform_weights: null context");
+  ctx->w_uniform = on != 0;
+  return 0;
+}
+int abcdez_ctx_get_uniform_weights(abcdez_ctx* ctx, int32_t* on, int64_t* fast_prologues) {
+  ABZ_REQUIRE(ctx && on, "get_uniform_weights: null argument");
+  *on = ctx->w_uniform ? 1 : 0;
+  if (fast_prologues) *fast_prologues = ctx->n_reweight_fast;
   return 0;
 }
 
@@ -758,6 +774,7 @@ int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_packed: N out of range");
   ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1 && bits != bits_other,
               "smc_resample_gather_packed: in/out arrays must differ");
+  ctx->w_uniform = true;                /* Wns .= 1/N (smc:102) */
   return abz_launch_resample_gather_packed(ctx, inds, (uint32_t)N, bits, bits_other, slot0, slot1, logpi, delta, nlogpi,
                                            ndelta, wns, alive);
 }
@@ -775,6 +792,7 @@ int abcdez_smc_reweight(abcdez_ctx* ctx, const double* delta, double* wns, uint8
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_reweight: N out of range");
   ABZ_REQUIRE(eps_old >= 0.0 && eps_new >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
+  ctx->w_uniform = false;               /* the general path: weights as its floating sums leave them */
   return abz_reweight_impl(ctx, delta, wns, alive, N, eps_old, eps_new, wnorm, ess, n_alive);
 }
 

@@ -55,7 +55,11 @@ struct abcdez_ctx {
   bool graphs_on = false;
   std::vector<abz_mc_graph> mc_graphs;
   long long n_graph_replays = 0, n_graph_captures = 0, n_graph_direct = 0;
-  bool mc_seq_dirty = false;        /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */
+  bool mc_seq_dirty = false;
+  /* the alive particles' weights are uniform, 1 / n_alive (abcdez_ctx_set_uniform_weights; kept by the indicator fast path of the
+   * prologue, set by a resampling, cleared by a general reweight): lets the prologue use the closed forms for indicator kernels */
+  bool w_uniform = false;
+  long long n_reweight_fast = 0;        /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */
   long long n_select_reused = 0, n_select_inline = 0;   /* prologues that found their select enqueued ahead / ran it themselves */
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
   hipStream_t stream = nullptr;

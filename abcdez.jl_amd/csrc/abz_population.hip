@@ -123,6 +123,11 @@ struct FinishArgs {
   int64_t n[2];
   /* pub_host != null: the block that finishes last also publishes the scalar area to the host (what publish_kernel does):
    * one launch and its dependency gap less per prologue */
+  /* ind_n_old > 0 (indicator kernel, uniform weights; one tree = the survivors' tile counts): the finishing block also leaves
+   * wnorm = n_new / n_old and sum(Wns^2) = 1 / n_new -- the closed forms of the reweight (abz_ind_reweight below) */
+  double ind_n_old;
+  double* ind_wnorm;
+  double* ind_sumsq;
   unsigned int* ticket;
   const unsigned long long* pub_scal;
   unsigned long long* pub_host;
@@ -164,7 +169,10 @@ __global__ __launch_bounds__(ABZ_BLOCK) void tree_finish_kernel(const FinishArgs
     __syncthreads();
     r = finish_tile(s_l1, nt, 0, s_w);
   }
-  if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
+  if (threadIdx.x == 0) {
+    *a.out[blockIdx.x] = r;
+    if (a.ind_n_old > 0.0 && blockIdx.x == 0) { *a.ind_wnorm = r / a.ind_n_old; *a.ind_sumsq = 1.0 / r; }
+  }
   if (!a.pub_host) return;
   if (threadIdx.x == 0) {
     __threadfence();                                   /* this block's result before its ticket */
@@ -194,8 +202,10 @@ static int tree_sum_begin(abcdez_ctx* ctx, TileArgs a, double* d_out, double* pa
 }
 /* finishes up to two trees in one launch (n = 0: nothing to do for that tree) */
 static int tree_finish(abcdez_ctx* ctx, const double* pa, int64_t na, double* outa, const double* pb = nullptr, int64_t nb = 0,
-                       double* outb = nullptr, int pub_words = 0, unsigned long long* pub_seq = nullptr) {
+                       double* outb = nullptr, int pub_words = 0, unsigned long long* pub_seq = nullptr, double ind_n_old = 0.0) {
   FinishArgs f{};
+  f.ind_n_old = ind_n_old;
+  f.ind_wnorm = (double*)(ctx->d_scal + ABZ_S_WNORM); f.ind_sumsq = (double*)(ctx->d_scal + ABZ_S_SUMSQ);
   int k = 0;
   if (na > 0) { f.part[k] = pa; f.n[k] = na; f.out[k] = outa; ++k; }
   if (nb > 0) { f.part[k] = pb; f.n[k] = nb; f.out[k] = outb; ++k; }
@@ -305,6 +315,57 @@ int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, d
   if (rc) return rc;
   *out = scal_f64(ctx, ABZ_S_SUM);
   return 0;
+}
+
+/* ---- the reweight of an INDICATOR kernel on UNIFORM weights (abcdez_ctx_set_uniform_weights; the oracle's
+ * orc_smc_reweight_uniform): ws[i] is 1 or 0 (types.jl:26-50) and Wns is 1 / n_alive on the alive particles, so
+ *     wnorm = n_new / n_old,   Wns = 1 / n_new on the survivors,   1 / sum(Wns.^2) = n_new
+ * (smc:308-311, :8) -- IEEE divisions of exactly represented integers instead of floating sums of n_new equal terms.  ONE pass
+ * writes the new flags and counts the survivors per tile (10 B per position instead of 26 + 17 in two passes); the finishing
+ * launch leaves n_new, wnorm and 1 / n_new in the scalar area and publishes; the weights themselves are a fill that rides in
+ * the partition's list pass (part_list_kernel).  Two launches instead of four. */
+__global__ __launch_bounds__(ABZ_BLOCK) void ind_reweight_kernel(const double* __restrict__ delta, uint8_t* __restrict__ alive, int64_t n,
+                                                                 int abck, const double* __restrict__ eps_dev, double eps_host,
+                                                                 double* __restrict__ tile_alive) {
+  const double eps = eps_dev ? *eps_dev : eps_host;
+  const int t = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * ABZ_TILE;
+  unsigned long long c = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int64_t k = base + m * 512 + 2 * t;               /* two consecutive positions per thread: 16-byte distance loads */
+    double d0 = 0.0, d1 = 0.0;
+    uint8_t a0 = 0, a1 = 0;
+    if (k + 1 < n) {
+      const double2 dd = *reinterpret_cast<const double2*>(delta + k);
+      const uchar2 aa = *reinterpret_cast<const uchar2*>(alive + k);
+      d0 = dd.x; d1 = dd.y; a0 = aa.x; a1 = aa.y;
+    } else if (k < n) { d0 = delta[k]; a0 = alive[k]; }
+    const bool s0 = a0 && abz_kernel_insupport(abck, eps, d0), s1 = a1 && abz_kernel_insupport(abck, eps, d1);
+    if (k + 1 < n) *reinterpret_cast<uchar2*>(alive + k) = make_uchar2((unsigned char)s0, (unsigned char)s1);
+    else if (k < n) alive[k] = (uint8_t)s0;
+    c += (unsigned long long)s0 + (unsigned long long)s1;
+  }
+  const unsigned long long bc = block_sum_u64(c);
+  if (t == 0) tile_alive[blockIdx.x] = (double)bc;
+}
+static int ind_reweight_enqueue(abcdez_ctx* ctx, const double* delta, uint8_t* alive, int64_t N, double eps_new,
+                                const double* eps_new_dev, unsigned long long* pub_seq) {
+  double *p0, *p1;
+  char* rest;
+  const size_t ntile = (size_t)((N + ABZ_TILE - 1) / ABZ_TILE);
+  int rc = partial_buffers(ctx, N, abz_align(ntile * 8), &p0, &p1, &rest);
+  if (rc) return rc;
+  double* tile_alive = (double*)rest;
+  hipLaunchKernelGGL(ind_reweight_kernel, dim3((unsigned)ntile), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, ctx->h_model.abck,
+                     eps_new_dev, eps_new, tile_alive);
+  ABZ_HIP_CHECK(hipGetLastError());
+  /* the tile counts (integers < 2^53: the f64 tree sum is exact) -> n_new; the finishing block adds wnorm and 1 / n_new */
+  if (ntile == 1) {          /* one tile: no tree to finish, but the closed forms and the publish still need their launch */
+    return tree_finish(ctx, tile_alive, 1, (double*)(ctx->d_scal + ABZ_S_NALIVE), nullptr, 0, nullptr, ABZ_S_SCALARS, pub_seq, (double)N);
+  }
+  return tree_finish(ctx, tile_alive, (int64_t)ntile, (double*)(ctx->d_scal + ABZ_S_NALIVE), nullptr, 0, nullptr, ABZ_S_SCALARS, pub_seq,
+                     (double)N);
 }
 
 /* pub_seq != null: the launch that finishes the sums also publishes the first ABZ_S_SCALARS scalars to the host */
@@ -420,10 +481,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __r
                                                               uint32_t* __restrict__ fillers,
                                                               const uint32_t* __restrict__ bits,
                                                               uint32_t* __restrict__ bits_other, uint32_t nwords,
-                                                              const unsigned long long* __restrict__ dyn, double ess_min) {
+                                                              const unsigned long long* __restrict__ dyn, double ess_min,
+                                                              double* __restrict__ wfill) {
   __shared__ uint32_t s_wave[2][4];
   bool go;
   const uint32_t n_new = part_n_new(dyn, n_new_h, n_prev, ess_min, &go);
+  /* wfill != null (indicator reweight on uniform weights, ind_reweight_kernel): the new weights are a fill -- 1 / n_new on the
+   * survivors, 0 on the others -- written here, where the flags of the whole prefix are read anyway (also when a resampling is
+   * ahead and nothing is listed: the resampling reads them) */
+  const double winv = wfill ? abz_u2d(dyn[ABZ_S_SUMSQ]) : 0.0;
   /* both bit arrays must agree wherever no sweep writes: positions that just left the prefix keep the bit of the
    * CURRENT array (their last sweep may have flipped it) */
   for (uint32_t w = blockIdx.x * ABZ_BLOCK + threadIdx.x; w < nwords; w += gridDim.x * ABZ_BLOCK) bits_other[w] = bits[w];
@@ -433,8 +499,11 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_list_kernel(const uint8_t* __r
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int it = 0; it < 4; ++it) {
     const uint32_t k = base + it * ABZ_BLOCK + threadIdx.x;
-    const bool in = go && k < n_prev;
-    const bool al = in && alive[k];
+    const bool inp = k < n_prev;
+    const bool alv = inp && alive[k];
+    if (wfill && inp) wfill[k] = alv ? winv : 0.0;
+    const bool in = go && inp;
+    const bool al = in && alv;
     const bool is_h = in && !al && k < n_new, is_f = al && k >= n_new;
     const unsigned long long bh = __ballot(is_h), bf = __ballot(is_f);
     if (lane == 0) { s_wave[0][wave] = (uint32_t)__popcll(bh); s_wave[1][wave] = (uint32_t)__popcll(bf); }
@@ -487,7 +556,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_swap_kernel(const uint32_t* __
 /* dyn != null: n_new and the "no resampling ahead" predicate are read from the device (fused prologue; n_new is ignored) */
 int abz_partition_impl(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_prev, int64_t n_new, const uint32_t* bits,
                        uint32_t* bits_other, double* slot0, double* slot1, double* logpi, double* delta, double* wns,
-                       const unsigned long long* dyn, double ess_min) {
+                       const unsigned long long* dyn, double ess_min, bool wfill) {
   const uint32_t np = (uint32_t)n_prev, nn = (uint32_t)n_new;
   const uint32_t nchunk = (np + ABZ_CHUNK - 1) / ABZ_CHUNK;
   const uint32_t bound = dyn ? np / 2 : (nn < np - nn ? nn : np - nn);             /* #swaps <= min(#dead, #alive) */
@@ -506,7 +575,7 @@ int abz_partition_impl(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_pre
                      ctx->d_scal + ABZ_S_PART_ERR);
   hipLaunchKernelGGL(part_scan_kernel, dim3(2), dim3(1024), 0, ctx->stream, cnt, nchunk, totals);
   hipLaunchKernelGGL(part_list_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, nn, cnt, nchunk, holes, fillers,
-                     bits, bits_other, nwords, dyn, ess_min);
+                     bits, bits_other, nwords, dyn, ess_min, wfill ? wns : nullptr);
   if (bound > 0) {
     bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
       uint64_t blocks = ((uint64_t)bound * LL() + ABZ_BLOCK - 1) / ABZ_BLOCK;
@@ -1334,12 +1403,17 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   }
   ctx->ahead.valid = false;
   unsigned long long seq = 0;
-  rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
+  /* indicator kernel on uniform weights: closed forms, two launches instead of four, the weights filled by the partition */
+  const bool fast = ctx->w_uniform && (ctx->h_model.abck == ABZ_K_INDICATOR || ctx->h_model.abck == ABZ_K_INDICATOR_STRICT);
+  if (fast) rc = ind_reweight_enqueue(ctx, delta_all, alive, n_prev, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
+  else rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
   if (rc) return rc;
+  ctx->w_uniform = fast;              /* the general path leaves the weights as its floating sums made them */
+  ctx->n_reweight_fast += fast ? 1 : 0;
   /* everything the host needs is known here: the scalars are published (by the launch that finishes the reweight's sums) BEFORE the partition is enqueued, and the host returns
    * (and enqueues the generation's sweeps) while the partition kernels are still running -- the round trip hides behind them.
    * A partition error (flags that do not describe a prefix) is reported by the next counter read-back instead. */
-  rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min);
+  rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min, fast);
   if (rc) return rc;
   rc = abz_publish_wait(ctx, ABZ_S_SCALARS, seq);
   if (rc) return rc;

@@ -87,6 +87,21 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_ctx_get_layout(self.ctx, C.byref(ld), C.byref(L), C.byref(Cc)))
         return ld.value, L.value, Cc.value
 
+    def set_uniform_weights(self, on: bool):
+        """the alive particles' weights are 1 / n_alive (the host wrote them so): with an indicator kernel the prologue uses the
+        closed forms of the reweight (include/abcdez_hip.h); the library keeps the flag itself afterwards"""
+        _lib.check(self.lib, self.lib.abcdez_ctx_set_uniform_weights(self.ctx, 1 if on else 0))
+
+    def get_uniform_weights(self) -> bool:
+        on = C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_ctx_get_uniform_weights(self.ctx, C.byref(on), None))
+        return bool(on.value)
+
+    def fast_prologues(self) -> int:
+        on, n = C.c_int32(), C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_ctx_get_uniform_weights(self.ctx, C.byref(on), C.byref(n)))
+        return n.value
+
     def set_graphs(self, on: bool):
         """replay abcdemc generations as HIP graphs (default off: measured slower than stream launches; results do not depend on it)"""
         _lib.check(self.lib, self.lib.abcdez_ctx_set_graphs(self.ctx, 1 if on else 0))
@@ -587,6 +602,8 @@ class PopulationEngine:
         self.discard_select_ahead()
         self.wns.fill_(1.0 / self.N)
         self.alive.fill_(1)
+        if hasattr(self.ops, "set_uniform_weights"):
+            self.ops.set_uniform_weights(True)       # Wns = 1/N on every particle: indicator kernels may use the closed forms
         self.n_alive = self.N
         if self.packed:
             self.n_prev = self.N
@@ -904,6 +921,8 @@ class PopulationEngine:
             "seed": int(self.spec.seed),
             # every random number after the resume depends on the library's stream: (ABI version, Philox rounds)
             "stream_version": list(self.ops.stream_version()) if hasattr(self.ops, "stream_version") else None,
+            # which path the next reweight of an indicator kernel takes (closed forms on uniform weights, or the general sums)
+            "w_uniform": bool(self.ops.get_uniform_weights()) if hasattr(self.ops, "get_uniform_weights") else False,
         }
 
     def upload_state(self, st: dict):
@@ -935,6 +954,8 @@ class PopulationEngine:
         self.wns.copy_(torch.as_tensor(np.ascontiguousarray(st["wns"], dtype=np.float64)))
         self.alive.copy_(torch.as_tensor(np.ascontiguousarray(st["alive"], dtype=np.uint8)))
         self.n_alive = int(self.alive.sum().item())
+        if hasattr(self.ops, "set_uniform_weights"):
+            self.ops.set_uniform_weights(bool(st.get("w_uniform", False)))
         self.sweep, self.draw = int(st["sweep"]), int(st["draw"])
         if self.blob_on:
             if "stamp" not in st:

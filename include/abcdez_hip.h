@@ -65,6 +65,17 @@ ABCDEZ_API int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N);
 ABCDEZ_API int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream);
 /* lanes per particle (power of two dividing ld, <= 16; 0 = default) -- tuning knob */
 ABCDEZ_API int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes);
+/* Uniform weights.  In every run of the reference's drivers with an INDICATOR kernel the alive particles' weights are uniform:
+ * 1/N at smc:266-270 and after every resampling (smc:102), 1/n_alive after every reweight (smc:310: equal products over their
+ * sum).  ws[i] is 1 or 0 (types.jl:26-50), so wnorm = n_new / n_old, Wns = 1 / n_new, 1 / sum(Wns.^2) = n_new in exact arithmetic.
+ * A host that has written uniform weights says so with set_uniform_weights(ctx, 1); abcdez_smc_prologue_packed then takes exactly
+ * those values (IEEE divisions of integers) instead of floating sums of n_new equal terms, in two launches instead of four, and
+ * the library keeps the flag from there (the fast path keeps it, abcdez_smc_resample_gather_packed sets it, a general reweight --
+ * another kernel family, or abcdez_smc_reweight -- clears it).  Without the call the general path runs: the reference's
+ * statements on whatever weights the arrays hold.  get_uniform_weights: the flag (a checkpoint must carry it for a resumed run
+ * to repeat the uninterrupted one bit for bit) and how many prologues took the fast path. */
+ABCDEZ_API int abcdez_ctx_set_uniform_weights(abcdez_ctx* ctx, int on);
+ABCDEZ_API int abcdez_ctx_get_uniform_weights(abcdez_ctx* ctx, int32_t* on, int64_t* fast_prologues);
 /* abcdemc generations enqueued by abcdez_mc_generation_async (up to 15 dependent launches, no host decision in between,
  * src/abcdez_mc.jl:134-161) CAN be captured once per launch shape and replayed as HIP graphs (on = 1, or ABZ_GRAPHS=1 in the
  * environment; needs a stream other than the legacy default stream).  Off by default: on ROCm 7.2 / MI355X the replay is slower

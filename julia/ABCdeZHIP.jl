@@ -207,6 +207,8 @@ end
 function reset_weights!(e)                                                                                # smc:266-270: Wns = 1/N, alive = true
     w = fill(1.0 / e.N, e.N); a = ones(UInt8, e.N)
     h2d(e, e.wns, w, 8e.N); h2d(e, e.alive, a, e.N)
+    # the weights are uniform now (and stay so under an indicator kernel): the prologue may take the closed forms of the reweight
+    check(ccall((:abcdez_ctx_set_uniform_weights, LIB), Cint, (Ptr{Cvoid}, Cint), e.ctx, 1))
     e.n_alive = e.n_prev = e.N
 end
 function extrema_dev(e)                                                                                   # smc:286,364

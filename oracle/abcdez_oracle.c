@@ -546,6 +546,31 @@ ORC_API void orc_smc_reweight(int abck, const double* delta, double* wns, uint8_
   *n_alive_out = na;
   free(wprod);
 }
+/* The same for an INDICATOR kernel when the weights are UNIFORM over the alive particles -- which they always are in the
+ * reference's own runs with an indicator kernel: smc:266-270 sets 1/N, smc:310 divides equal products by their sum, smc:102
+ * resets 1/N.  ws[i] is then 1 or 0 (types.jl:26-50), and in exact arithmetic
+ *     wnorm = n_new / n_old,   Wns = 1 / n_new on the survivors,   1 / sum(Wns.^2) = n_new.
+ * The reference's floating sums of n_new equal terms approximate these values to ~1e-16; the spec tier takes the values
+ * themselves (IEEE divisions of exactly represented integers), which needs no summation tree and no pass over the weights:
+ * one pass counts the survivors and writes the flags, the weights are a fill.  (The caller knows the weights are uniform;
+ * the incoming values of wns[] are not read.)                                                                         */
+ORC_API void orc_smc_reweight_uniform(int abck, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_new,
+                                      double* wnorm_out, double* ess_out, int64_t* n_alive_out) {
+  int64_t n_old = 0, n_new = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_old, n_new)
+  for (int64_t i = 0; i < N; ++i) {
+    const int was = alive[i] != 0;
+    const int is = was && abz_kernel_insupport(abck, eps_new, delta[i]);
+    alive[i] = (uint8_t)is;
+    n_old += was; n_new += is;
+  }
+  const double sumsq = 1.0 / (double)n_new;             /* = the weight of a survivor = sum(Wns.^2) in exact arithmetic */
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) wns[i] = alive[i] ? sumsq : 0.0;
+  *wnorm_out = (double)n_new / (double)n_old;
+  *ess_out = 1.0 / sumsq;
+  *n_alive_out = n_new;
+}
 ORC_API double orc_get_ess(const double* wns, int64_t N) {
   double* sq = (double*)malloc((size_t)N * sizeof(double));
   for (int64_t i = 0; i < N; ++i) sq[i] = wns[i] * wns[i];

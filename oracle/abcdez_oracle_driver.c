@@ -23,6 +23,7 @@ void orc_smc_swarm(const abz_model*, const uint32_t*, const uint32_t*, int64_t, 
                    const double*, double*, double*, double*, double, double, double, int64_t, int64_t, uint32_t,
                    int64_t*, int64_t*);
 void orc_smc_reweight(int, const double*, double*, uint8_t*, int64_t, double, double, double*, double*, int64_t*);
+void orc_smc_reweight_uniform(int, const double*, double*, uint8_t*, int64_t, double, double*, double*, int64_t*);
 double orc_get_ess(const double*, int64_t);
 void orc_wsample_stratified(uint64_t, const double*, int64_t, uint32_t, uint32_t*);
 void orc_smc_resample_gather(const abz_model*, const uint32_t*, int64_t, int64_t, int64_t, const double*,
@@ -98,7 +99,12 @@ ORC_API int orc_abcdesmc(const abz_model* M, orc_smc_run* R,
     double q = orc_quantile_alive(cur.delta, alive, N, R->alpha, 0, 0);
     eps = fmax(fmin(q, eps), R->eps_target);                        /* smc:301 */
     double wnorm; int64_t n_alive;
-    orc_smc_reweight(M->abck, cur.delta, wns, alive, N, eps_k, eps, &wnorm, &ess, &n_alive); /* smc:305-311 */
+    /* smc:305-311.  Indicator kernels: the weights are uniform over the alive particles throughout (1/N at smc:266-270 and
+     * after every resampling, 1/n_alive after every reweight), so the closed forms apply (abcdez_oracle.c) */
+    if (M->abck == ABZ_K_INDICATOR || M->abck == ABZ_K_INDICATOR_STRICT)
+      orc_smc_reweight_uniform(M->abck, cur.delta, wns, alive, N, eps, &wnorm, &ess, &n_alive);
+    else
+      orc_smc_reweight(M->abck, cur.delta, wns, alive, N, eps_k, eps, &wnorm, &ess, &n_alive);
     logZ += log(wnorm);                                             /* smc:315 */
     int64_t naccs = 0;                                              /* smc:318 */
     Ki = R->Kmcmc;

@@ -94,6 +94,7 @@ def lib():
     L.orc_tree_sum.restype = _f64
     L.orc_tree_sum.argtypes = [_vp, _i64]
     L.orc_smc_reweight.argtypes = [C.c_int, _vp, _vp, _vp, _i64, _f64, _f64, _pf64, _pf64, _pi64]
+    L.orc_smc_reweight_uniform.argtypes = [C.c_int, _vp, _vp, _vp, _i64, _f64, _pf64, _pf64, _pi64]
     L.orc_get_ess.restype = _f64
     L.orc_get_ess.argtypes = [_vp, _i64]
     L.ref_get_ess.restype = _f64
@@ -180,7 +181,15 @@ class OracleOps:
         lo, hi = self.extrema(delta)
         q = self.quantile_alive(delta[:n_prev], alive[:n_prev], alpha)[0]
         eps = max(min(q, eps_prev), eps_target)
-        wnorm, ess, n_alive = self.smc_reweight(delta[:n_prev], wns[:n_prev], alive[:n_prev], eps_k, eps)
+        if getattr(self, "w_uniform", False) and self.spec.abck in (0, 1):
+            # indicator kernel + uniform weights: the closed forms (abcdez_oracle.c, orc_smc_reweight_uniform) -- the library
+            # takes this path under the same two conditions (abcdez_ctx_set_uniform_weights); the weights stay uniform
+            wnorm, ess, na = C.c_double(), C.c_double(), _i64()
+            self.L.orc_smc_reweight_uniform(self.spec.abck, _p(delta[:n_prev]), _p(wns[:n_prev]), _p(alive[:n_prev]), n_prev, eps,
+                                            C.byref(wnorm), C.byref(ess), C.byref(na))
+            wnorm, ess, n_alive = wnorm.value, ess.value, na.value
+        else:
+            wnorm, ess, n_alive = self.smc_reweight(delta[:n_prev], wns[:n_prev], alive[:n_prev], eps_k, eps)
         part = not (n_alive > 0 and ess < ess_min)
         if part:
             self.smc_partition(n_prev, n_alive, alive, bits, bits_other, slot0, slot1, logpi, delta, wns)
@@ -232,7 +241,19 @@ class OracleOps:
         g, self._grp = self._grp, None
         return g["nacc"], g["nsim"], len(g["nacc"])
 
+    # uniform-weights state of the population (include/abcdez_hip.h, abcdez_ctx_set_uniform_weights): the same transitions as
+    # the library's -- set by the host after it wrote 1/N, kept by the indicator fast path, set by a resampling, cleared by a
+    # general reweight
+    w_uniform = False
+
+    def set_uniform_weights(self, on: bool):
+        self.w_uniform = bool(on)
+
+    def get_uniform_weights(self) -> bool:
+        return bool(self.w_uniform)
+
     def smc_resample_gather_packed(self, inds, bits, bits_other, slot0, slot1, logpi, delta, nlogpi, ndelta, wns, alive):
+        self.w_uniform = True                          # Wns .= 1/N (smc:102)
         self.L.orc_smc_resample_gather_packed(self.m.ptr, _p(inds), inds.numel(), _p(bits), _p(bits_other), _p(slot0),
                                               _p(slot1), _p(logpi), _p(delta), _p(nlogpi), _p(ndelta), _p(wns), _p(alive))
 
@@ -240,6 +261,7 @@ class OracleOps:
         self.L.orc_packed_gather(_p(bits), out.shape[0], self.spec.ld, _p(slot0), _p(slot1), _p(out))
 
     def smc_reweight(self, delta, wns, alive, eps_old, eps_new):
+        self.w_uniform = False                         # the general path: weights as the floating sums leave them
         wnorm, ess, na = _f64(), _f64(), _i64()
         self.L.orc_smc_reweight(self.spec.abck, _p(delta), _p(wns), _p(alive), delta.numel(), eps_old, eps_new,
                                 C.byref(wnorm), C.byref(ess), C.byref(na))

@@ -73,6 +73,7 @@ class ShimEngine:
         a = np.ones(self.N, dtype=np.uint8)
         self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.wns, w.ctypes.data, 8 * self.N))
         self.ck(self.lib.abcdez_memcpy_h2d(self.ctx, self.alive, a.ctypes.data, self.N))
+        self.ck(self.lib.abcdez_ctx_set_uniform_weights(self.ctx, 1))      # Wns = 1/N: indicator kernels take the closed forms
         self.n_alive = self.n_prev = self.N
 
     def extrema(self):
