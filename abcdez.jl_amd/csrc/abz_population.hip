@@ -123,11 +123,6 @@ struct FinishArgs {
   int64_t n[2];
   /* pub_host != null: the block that finishes last also publishes the scalar area to the host (what publish_kernel does):
    * one launch and its dependency gap less per prologue */
-  /* ind_n_old > 0 (indicator kernel, uniform weights; one tree = the survivors' tile counts): the finishing block also leaves
-   * wnorm = n_new / n_old and sum(Wns^2) = 1 / n_new -- the closed forms of the reweight (abz_ind_reweight below) */
-  double ind_n_old;
-  double* ind_wnorm;
-  double* ind_sumsq;
   unsigned int* ticket;
   const unsigned long long* pub_scal;
   unsigned long long* pub_host;
@@ -169,10 +164,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void tree_finish_kernel(const FinishArgs
     __syncthreads();
     r = finish_tile(s_l1, nt, 0, s_w);
   }
-  if (threadIdx.x == 0) {
-    *a.out[blockIdx.x] = r;
-    if (a.ind_n_old > 0.0 && blockIdx.x == 0) { *a.ind_wnorm = r / a.ind_n_old; *a.ind_sumsq = 1.0 / r; }
-  }
+  if (threadIdx.x == 0) *a.out[blockIdx.x] = r;
   if (!a.pub_host) return;
   if (threadIdx.x == 0) {
     __threadfence();                                   /* this block's result before its ticket */
@@ -202,10 +194,8 @@ static int tree_sum_begin(abcdez_ctx* ctx, TileArgs a, double* d_out, double* pa
 }
 /* finishes up to two trees in one launch (n = 0: nothing to do for that tree) */
 static int tree_finish(abcdez_ctx* ctx, const double* pa, int64_t na, double* outa, const double* pb = nullptr, int64_t nb = 0,
-                       double* outb = nullptr, int pub_words = 0, unsigned long long* pub_seq = nullptr, double ind_n_old = 0.0) {
+                       double* outb = nullptr, int pub_words = 0, unsigned long long* pub_seq = nullptr) {
   FinishArgs f{};
-  f.ind_n_old = ind_n_old;
-  f.ind_wnorm = (double*)(ctx->d_scal + ABZ_S_WNORM); f.ind_sumsq = (double*)(ctx->d_scal + ABZ_S_SUMSQ);
   int k = 0;
   if (na > 0) { f.part[k] = pa; f.n[k] = na; f.out[k] = outa; ++k; }
   if (nb > 0) { f.part[k] = pb; f.n[k] = nb; f.out[k] = outb; ++k; }
@@ -317,6 +307,8 @@ int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, d
   return 0;
 }
 
+#define ABZ_CHUNK 1024      /* positions per chunk of the partition's count / list passes */
+
 /* ---- the reweight of an INDICATOR kernel on UNIFORM weights (abcdez_ctx_set_uniform_weights; the oracle's
  * orc_smc_reweight_uniform): ws[i] is 1 or 0 (types.jl:26-50) and Wns is 1 / n_alive on the alive particles, so
  *     wnorm = n_new / n_old,   Wns = 1 / n_new on the survivors,   1 / sum(Wns.^2) = n_new
@@ -326,11 +318,11 @@ int abz_tree_sum_impl(abcdez_ctx* ctx, const double* x, int64_t n, int square, d
  * the partition's list pass (part_list_kernel).  Two launches instead of four. */
 __global__ __launch_bounds__(ABZ_BLOCK) void ind_reweight_kernel(const double* __restrict__ delta, uint8_t* __restrict__ alive, int64_t n,
                                                                  int abck, const double* __restrict__ eps_dev, double eps_host,
-                                                                 double* __restrict__ tile_alive) {
+                                                                 uint32_t* __restrict__ acnt) {
   const double eps = eps_dev ? *eps_dev : eps_host;
   const int t = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * ABZ_TILE;
-  unsigned long long c = 0;
+  unsigned long long c[2] = {0ull, 0ull};                   /* survivors of the tile's two 1024-chunks (the partition's chunks) */
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int64_t k = base + m * 512 + 2 * t;               /* two consecutive positions per thread: 16-byte distance loads */
@@ -344,28 +336,94 @@ __global__ __launch_bounds__(ABZ_BLOCK) void ind_reweight_kernel(const double* _
     const bool s0 = a0 && abz_kernel_insupport(abck, eps, d0), s1 = a1 && abz_kernel_insupport(abck, eps, d1);
     if (k + 1 < n) *reinterpret_cast<uchar2*>(alive + k) = make_uchar2((unsigned char)s0, (unsigned char)s1);
     else if (k < n) alive[k] = (uint8_t)s0;
-    c += (unsigned long long)s0 + (unsigned long long)s1;
+    c[m >> 1] += (unsigned long long)s0 + (unsigned long long)s1;
   }
-  const unsigned long long bc = block_sum_u64(c);
-  if (t == 0) tile_alive[blockIdx.x] = (double)bc;
+  static_assert(ABZ_TILE == 2048 && ABZ_BLOCK == 256, "a tile is two chunks of 1024 positions");
+  const unsigned long long b0 = block_sum_u64(c[0]);
+  __syncthreads();                                          /* block_sum_u64 reuses its LDS words */
+  const unsigned long long b1 = block_sum_u64(c[1]);
+  if (t == 0) {
+    const int64_t nchunk = (n + 1023) / 1024;
+    acnt[2 * blockIdx.x] = (uint32_t)b0;
+    if (2 * (int64_t)blockIdx.x + 1 < nchunk) acnt[2 * blockIdx.x + 1] = (uint32_t)b1;
+  }
 }
-static int ind_reweight_enqueue(abcdez_ctx* ctx, const double* delta, uint8_t* alive, int64_t N, double eps_new,
-                                const double* eps_new_dev, unsigned long long* pub_seq) {
-  double *p0, *p1;
-  char* rest;
-  const size_t ntile = (size_t)((N + ABZ_TILE - 1) / ABZ_TILE);
-  int rc = partial_buffers(ctx, N, abz_align(ntile * 8), &p0, &p1, &rest);
-  if (rc) return rc;
-  double* tile_alive = (double*)rest;
-  hipLaunchKernelGGL(ind_reweight_kernel, dim3((unsigned)ntile), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, ctx->h_model.abck,
-                     eps_new_dev, eps_new, tile_alive);
-  ABZ_HIP_CHECK(hipGetLastError());
-  /* the tile counts (integers < 2^53: the f64 tree sum is exact) -> n_new; the finishing block adds wnorm and 1 / n_new */
-  if (ntile == 1) {          /* one tile: no tree to finish, but the closed forms and the publish still need their launch */
-    return tree_finish(ctx, tile_alive, 1, (double*)(ctx->d_scal + ABZ_S_NALIVE), nullptr, 0, nullptr, ABZ_S_SCALARS, pub_seq, (double)N);
+
+/* finish + scan of the indicator fast path in ONE launch of two fat blocks (what tree_finish + part_count + part_scan do in three):
+ * every block adds up the chunk counts -> n_new; block 0 leaves n_new, wnorm = n_new / n_old, 1 / n_new in the scalar area and
+ * publishes the scalars to the host; block 0 then makes the exclusive offsets of the HOLES per chunk (dead positions below
+ * n_new), block 1 those of the FILLERS (alive positions at or above n_new) -- from the chunk counts alone, except for the one
+ * chunk n_new falls into, whose flags are read.  Nothing is listed when a resampling is ahead (ESS < ess_min, smc:323). */
+__global__ __launch_bounds__(1024) void ind_finish_scan_kernel(const uint32_t* __restrict__ acnt, uint32_t nchunk, uint32_t n_prev,
+                                                               double ess_min, const uint8_t* __restrict__ alive,
+                                                               uint32_t* __restrict__ cnt, unsigned long long* __restrict__ scal,
+                                                               unsigned long long* __restrict__ pub_host, int pub_words,
+                                                               unsigned long long pub_seq) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_below;
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (nchunk + 1023u) / 1024u;
+  const uint32_t lo = t * per < nchunk ? t * per : nchunk, hi = lo + per < nchunk ? lo + per : nchunk;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += acnt[k];
+  s_part[t] = s;
+  if (t == 0) s_below = 0u;
+  __syncthreads();
+  for (uint32_t off = 512; off; off >>= 1) {
+    if (t < off) s_part[t] += s_part[t + off];
+    __syncthreads();
   }
-  return tree_finish(ctx, tile_alive, (int64_t)ntile, (double*)(ctx->d_scal + ABZ_S_NALIVE), nullptr, 0, nullptr, ABZ_S_SCALARS, pub_seq,
-                     (double)N);
+  const uint32_t n_new = s_part[0];
+  __syncthreads();
+  const double nn = (double)n_new, sumsq = 1.0 / nn, ess = 1.0 / sumsq;
+  const bool go = !(nn > 0.0 && ess < ess_min);
+  if (blockIdx.x == 0 && t == 0) {
+    scal[ABZ_S_NALIVE] = abz_d2u(nn);
+    scal[ABZ_S_WNORM] = abz_d2u(nn / (double)n_prev);
+    scal[ABZ_S_SUMSQ] = abz_d2u(sumsq);
+    scal[ABZ_S_PART_ERR] = 0ull;
+  }
+  if (blockIdx.x == 0 && pub_host) {                   /* the host needs nothing of what follows */
+    __threadfence();
+    __syncthreads();
+    for (int k = (int)t; k < pub_words; k += 1024)
+      pub_host[k] = __hip_atomic_load(scal + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(pub_host + ABZ_S_N, pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  /* the chunk n_new falls into: alive positions in [ks 1024, n_new) */
+  const uint32_t ks = n_new / ABZ_CHUNK;
+  if (go && ks < nchunk && (n_new % ABZ_CHUNK) != 0u) {
+    const uint32_t k = ks * ABZ_CHUNK + t;
+    const bool a = k < n_new && alive[k];
+    const unsigned long long b = __ballot(a);
+    if ((t & 63u) == 0u && b) atomicAdd(&s_below, (uint32_t)__popcll(b));
+  }
+  __syncthreads();
+  const uint32_t below = s_below;
+  /* this block's per-chunk value: holes (block 0) or fillers (block 1) */
+  auto value = [&](uint32_t k) -> uint32_t {
+    if (!go) return 0u;
+    const uint32_t a = acnt[k];
+    const uint32_t len = (k + 1u) * ABZ_CHUNK <= n_prev ? (uint32_t)ABZ_CHUNK : n_prev - k * ABZ_CHUNK;
+    if (blockIdx.x == 0) return k < ks ? len - a : k == ks ? (n_new - ks * ABZ_CHUNK) - below : 0u;
+    return k < ks ? 0u : k == ks ? a - below : a;
+  };
+  uint32_t v = 0;
+  for (uint32_t k = lo; k < hi; ++k) v += value(k);
+  s_part[t] = v;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = t >= off ? s_part[t - off] : 0;
+    __syncthreads();
+    s_part[t] += add;
+    __syncthreads();
+  }
+  uint32_t run = t ? s_part[t - 1] : 0;
+  uint32_t* out = cnt + (size_t)blockIdx.x * nchunk;
+  for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = value(k); out[k] = run; run += c; }
+  if (t == 1023) scal[ABZ_S_PART_H + blockIdx.x] = (unsigned long long)s_part[1023];
 }
 
 /* pub_seq != null: the launch that finishes the sums also publishes the first ABZ_S_SCALARS scalars to the host */
@@ -406,7 +464,6 @@ int abz_reweight_impl(abcdez_ctx* ctx, const double* delta, double* wns, uint8_t
   return 0;
 }
 
-#define ABZ_CHUNK 1024
 
 /* ================================================================ partition of the packed population
  * After a reweight the alive flags of the prefix [0, n_prev) have holes; n_new = sum(alive) is known to the host.
@@ -582,6 +639,45 @@ int abz_partition_impl(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_pre
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL((part_swap_kernel<LL(), CC()>), dim3((unsigned)blocks), dim3(ABZ_BLOCK), 0, ctx->stream, holes, fillers,
                          totals, bits, slot0, slot1, logpi, delta, wns, alive, ctx->stamp_cur, ctx->d_scal + ABZ_S_PART_ERR);
+    });
+    if (!ok) { abz_set_error("smc_partition: unsupported layout"); return -3; }
+  }
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* The reweight + partition of the prologue for an indicator kernel on uniform weights: four launches (count pass, finish + scan,
+ * list + weight fill, swap) where the general path has eight. */
+int abz_ind_reweight_partition(abcdez_ctx* ctx, const double* delta_all, uint8_t* alive, int64_t N, int64_t n_prev, double ess_min,
+                               const uint32_t* bits, uint32_t* bits_other, double* slot0, double* slot1, double* logpi,
+                               double* delta_rw, double* wns, unsigned long long* pub_seq) {
+  const uint32_t np = (uint32_t)n_prev;
+  const uint32_t nchunk = (np + ABZ_CHUNK - 1) / ABZ_CHUNK;
+  const uint32_t ntile = (np + ABZ_TILE - 1) / ABZ_TILE;
+  const uint32_t bound = np / 2;                                                   /* #swaps <= min(#dead, #alive) */
+  const size_t cb = abz_align((size_t)2 * nchunk * 4), lb = abz_align((size_t)(bound + 1) * 4), ab = abz_align((size_t)(nchunk + 1) * 4);
+  int rc = abz_ws_reserve(ctx, cb + 2 * lb + ab);
+  if (rc) return rc;
+  char* base = (char*)ctx->ws;
+  uint32_t* cnt = (uint32_t*)base;
+  uint32_t* holes = (uint32_t*)(base + cb);
+  uint32_t* fillers = (uint32_t*)(base + cb + lb);
+  uint32_t* acnt = (uint32_t*)(base + cb + 2 * lb);
+  unsigned long long* totals = ctx->d_scal + ABZ_S_PART_H;
+  const uint32_t nwords = (uint32_t)((N + 31) / 32);
+  hipLaunchKernelGGL(ind_reweight_kernel, dim3(ntile), dim3(ABZ_BLOCK), 0, ctx->stream, delta_all, alive, n_prev, ctx->h_model.abck,
+                     (const double*)(ctx->d_scal + ABZ_S_EPS), 0.0, acnt);
+  *pub_seq = ++ctx->pub_seq;
+  hipLaunchKernelGGL(ind_finish_scan_kernel, dim3(2), dim3(1024), 0, ctx->stream, (const uint32_t*)acnt, nchunk, np, ess_min,
+                     (const uint8_t*)alive, cnt, ctx->d_scal, ctx->h_scal_dev, (int)ABZ_S_SCALARS, *pub_seq);
+  hipLaunchKernelGGL(part_list_kernel, dim3(nchunk), dim3(ABZ_BLOCK), 0, ctx->stream, alive, np, 0u, cnt, nchunk, holes, fillers,
+                     bits, bits_other, nwords, (const unsigned long long*)ctx->d_scal, ess_min, wns);
+  if (bound > 0) {
+    bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
+      uint64_t blocks = ((uint64_t)bound * LL() + ABZ_BLOCK - 1) / ABZ_BLOCK;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((part_swap_kernel<LL(), CC()>), dim3((unsigned)blocks), dim3(ABZ_BLOCK), 0, ctx->stream, holes, fillers,
+                         totals, bits, slot0, slot1, logpi, delta_rw, wns, alive, ctx->stamp_cur, ctx->d_scal + ABZ_S_PART_ERR);
     });
     if (!ok) { abz_set_error("smc_partition: unsupported layout"); return -3; }
   }
@@ -1405,16 +1501,21 @@ int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N
   unsigned long long seq = 0;
   /* indicator kernel on uniform weights: closed forms, two launches instead of four, the weights filled by the partition */
   const bool fast = ctx->w_uniform && (ctx->h_model.abck == ABZ_K_INDICATOR || ctx->h_model.abck == ABZ_K_INDICATOR_STRICT);
-  if (fast) rc = ind_reweight_enqueue(ctx, delta_all, alive, n_prev, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
-  else rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
-  if (rc) return rc;
   ctx->w_uniform = fast;              /* the general path leaves the weights as its floating sums made them */
   ctx->n_reweight_fast += fast ? 1 : 0;
-  /* everything the host needs is known here: the scalars are published (by the launch that finishes the reweight's sums) BEFORE the partition is enqueued, and the host returns
-   * (and enqueues the generation's sweeps) while the partition kernels are still running -- the round trip hides behind them.
-   * A partition error (flags that do not describe a prefix) is reported by the next counter read-back instead. */
-  rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min, fast);
-  if (rc) return rc;
+  if (fast) {
+    rc = abz_ind_reweight_partition(ctx, delta_all, alive, N, n_prev, ess_min, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, &seq);
+    if (rc) return rc;
+  } else {
+    rc = reweight_enqueue(ctx, delta_all, wns, alive, n_prev, eps_k_old, 0.0, (const double*)(ctx->d_scal + ABZ_S_EPS), &seq);
+    if (rc) return rc;
+    /* everything the host needs is known here: the scalars are published (by the launch that finishes the reweight's sums) BEFORE
+     * the partition is enqueued, and the host returns (and enqueues the generation's sweeps) while the partition kernels are still
+     * running -- the round trip hides behind them.  A partition error (flags that do not describe a prefix) is reported by the
+     * next counter read-back instead. */
+    rc = abz_partition_impl(ctx, alive, N, n_prev, 0, bits, bits_other, slot0, slot1, logpi, delta_rw, wns, ctx->d_scal, ess_min, false);
+    if (rc) return rc;
+  }
   rc = abz_publish_wait(ctx, ABZ_S_SCALARS, seq);
   if (rc) return rc;
   rc = select_finish(ctx, j - 1, nullptr, nullptr, nullptr);
