@@ -41,6 +41,48 @@ def assert_equal(hip, orc, what):
     assert same(hip.buf[0][0], orc.buf[0][0]) and same(hip.buf[1][0], orc.buf[1][0]), f"{what}: a slot array differs"
 
 
+@pytest.mark.parametrize("name,abck", [("normal1d", A.IndicatorStrict0toϵ), ("mvn32", A.Indicator0toϵ), ("quad2d_inf", A.IndicatorStrict0toϵ)])
+def test_indicator_closed_forms_agree_with_the_general_reweight(oracle, name, abck):
+    """Indicator kernel on uniform weights (abcdez_ctx_set_uniform_weights): the prologue's closed forms -- wnorm = n_new / n_old,
+    Wns = 1 / n_new, ESS = n_new (smc:308-311, :8 in exact arithmetic) -- against the general path (the reference's statements with
+    floating sums) on the same states: same epsilon, same survivors, same partition; weights / wnorm / ESS equal to rounding;
+    and the fast path is what a run takes (reset_weights says the weights are uniform, the library keeps the flag)."""
+    prior, sim, eps_target = models()[name]
+    N = 20000
+    spec = A.ModelSpec(prior, sim, abck, seed=11)
+    fast = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    gen_ = PopulationEngine(spec, N, ops=HipOps(spec), storage="packed")
+    for e in (fast, gen_):
+        e.init_population()
+        e.reset_weights()
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+    eps, eps_k = math.inf, math.inf
+    for gen in range(12):
+        gen_.ops.set_uniform_weights(False)                      # the general path, every generation
+        a = fast.smc_prologue(0.9, eps, eps_target, eps_k, 0.5 * N)
+        b = gen_.smc_prologue(0.9, eps, eps_target, eps_k, 0.5 * N)
+        assert fast.ops.get_uniform_weights() and not gen_.ops.get_uniform_weights()
+        assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4]            # eps, n_alive, extrema: the very same
+        assert abs(a[1] - b[1]) <= 1e-13 * b[1] and abs(a[2] - b[2]) <= 1e-10 * b[2]      # wnorm, ESS to rounding
+        assert a[2] == 1.0 / (1.0 / a[3])                                 # ESS = n_new through the two divisions of the spec
+        assert torch.equal(fast.alive, gen_.alive)
+        wf, wg = fast.wns.cpu().numpy(), gen_.wns.cpu().numpy()
+        al = fast.alive.cpu().numpy().astype(bool)
+        assert (wf[al] == 1.0 / a[3]).all() and (wf[~al] == 0.0).all()
+        assert np.allclose(wf, wg, rtol=1e-13, atol=0.0)
+        eps, _, ess, n_alive, _ = a
+        if n_alive > 0 and ess < 0.5 * N:
+            fast.smc_resample(); gen_.smc_resample()
+            n_alive = N
+        fast.alive_compact(); gen_.alive_compact()
+        for e in (fast, gen_):
+            e.smc_sweeps(eps, g0, 1e-5, 2, 1.0)
+        for k in range(3):
+            assert same(fast.state[k], gen_.state[k])                     # the populations stay identical: only weights' last bits differ
+        eps_k = eps
+    assert fast.ops.fast_prologues() == 12 and gen_.ops.fast_prologues() == 0
+
+
 @pytest.mark.parametrize("name", ["normal1d", "mvn32", "mvn3", "quad2d_inf", "socks"])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
 def test_packed_fused_prologue_parity(oracle, name, abck):
