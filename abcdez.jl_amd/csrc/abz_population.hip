@@ -836,7 +836,7 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 #define ABZ_QS_BINS 2048
 #define ABZ_QS_FAT 1024             /* passes 1 / 2: one fat block per CU -> few histogram flushes, few append atomics */
 #define ABZ_QS_GRID 256
-#define ABZ_QS_CAP 6144
+#define ABZ_QS_CAP 12288            /* keys a block of pass 2 stages in LDS (96 KB; one fat block per CU) */
 #define ABZ_QS_LDSKEYS 4096
 
 __device__ inline int qs_shift(unsigned long long klo, unsigned long long khi) {
@@ -900,30 +900,41 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
   __syncthreads();
   unsigned long long lo = ~0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
-  /* 8 independent (distance, flag) loads in flight per lane */
-  for (int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x; k0 < N; k0 += 8 * stride) {
-    unsigned long long key[8];
-    uint8_t al[8];
+  /* One fat block per CU: nothing else runs on the CU while this block waits for memory, so every trip puts all it can in
+   * flight at once -- 12 (distance, flag) pairs of the alive prefix AND 8 distances of the dead tail (read for the extrema
+   * only) per lane; at 2^22 particles that is the whole kernel in one round trip. */
+  constexpr int UM = 12, UT = 8;
+  int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x;                 /* cursor in the prefix */
+  int64_t t0 = N + (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x;             /* cursor in the dead tail */
+  while (k0 < N || t0 < n_all) {                                               /* block-uniform */
+    unsigned long long key[UM], tkey[UT];
+    uint8_t al[UM];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UM; ++u) {
       const int64_t k = k0 + u * stride;
       const bool in = k < N;
       key[u] = in ? f64_order_key(delta[k]) : 0ull;
       al[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UT; ++u) {
+      const int64_t k = t0 + u * stride;
+      tkey[u] = k < n_all ? f64_order_key(delta[k]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
       if (n_all > 0 && k0 + u * stride < N) { alo = key[u] < alo ? key[u] : alo; ahi = key[u] > ahi ? key[u] : ahi; }
       if (al[u]) {
         atomicAdd(&s_h[qs_bin(key[u], klo, shift)], 1u);
         lo = key[u] < lo ? key[u] : lo;
       }
     }
-  }
-  for (int64_t k = N + (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x; k < n_all; k += stride) {   /* the dead tail */
-    const unsigned long long key = f64_order_key(delta[k]);
-    alo = key < alo ? key : alo;
-    ahi = key > ahi ? key : ahi;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (t0 + u * stride < n_all) { alo = tkey[u] < alo ? tkey[u] : alo; ahi = tkey[u] > ahi ? tkey[u] : ahi; }
+    }
+    k0 += UM * stride;
+    t0 += UT * stride;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < ABZ_QS_BINS; b += ABZ_QS_FAT)
@@ -957,6 +968,19 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   __shared__ uint32_t s_n, s_bin;
   __shared__ unsigned long long s_base;
   const int t = threadIdx.x;
+  /* one fat block per CU: the first trip's loads go out before anything else -- they need neither the histogram nor the bin --
+   * and every later trip's loads go out before the trip in hand is processed (nothing else runs on this CU while it waits) */
+  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
+  unsigned long long key[8];
+  uint8_t al[8];
+  int64_t base = (int64_t)blockIdx.x * ABZ_QS_FAT;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int64_t k = base + t + u * stride;
+    const bool in = k < N;
+    key[u] = in ? f64_order_key(delta[k]) : 0ull;
+    al[u] = in ? alive[k] : (uint8_t)0;
+  }
   const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];      /* 2 consecutive bins per thread */
   const unsigned long long mine = (unsigned long long)h0 + h1;
   unsigned long long incl = mine;                      /* inclusive scan over the block */
@@ -992,7 +1016,6 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   const unsigned long long base2 = klo + ((unsigned long long)sel << shift);
   const int s2 = shift > 11 ? shift - 11 : 0;
   unsigned long long above = ~0ull, inmin = ~0ull, inmaxc = ~0ull;
-  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
   auto flush = [&]() {
     if (t == 0) s_base = atomicAdd(&QS(ABZ_S_SEL_NBUF), (unsigned long long)s_n);
     __syncthreads();
@@ -1002,30 +1025,34 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     if (t == 0) s_n = 0;
     __syncthreads();
   };
-  for (int64_t base = (int64_t)blockIdx.x * ABZ_QS_FAT; base < N; base += 4 * stride) {     /* block-uniform trips */
-    unsigned long long key[4];
-    uint8_t al[4];
+  while (base < N) {                                                                         /* block-uniform trips */
+    const int64_t nbase = base + 8 * stride;
+    unsigned long long nkey[8];
+    uint8_t nal[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t k = base + t + u * stride;
+    for (int u = 0; u < 8; ++u) {                                                           /* the next trip's loads */
+      const int64_t k = nbase + t + u * stride;
       const bool in = k < N;
-      key[u] = in ? f64_order_key(delta[k]) : 0ull;
-      al[u] = in ? alive[k] : (uint8_t)0;
+      nkey[u] = in ? f64_order_key(delta[k]) : 0ull;
+      nal[u] = in ? alive[k] : (uint8_t)0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (!al[u]) continue;
       const uint32_t b = qs_bin(key[u], klo, shift);
       if (b > sel && key[u] < above) above = key[u];
       if (b == sel) {
-        s_buf[atomicAdd(&s_n, 1u)] = key[u];                                /* room for 4 x 1024 guaranteed */
+        s_buf[atomicAdd(&s_n, 1u)] = key[u];                                /* room for 8 x 1024 guaranteed */
         atomicAdd(&s_h2[qs_sub(key[u], base2, s2)], 1u);
         inmin = key[u] < inmin ? key[u] : inmin;
         inmaxc = ~key[u] < inmaxc ? ~key[u] : inmaxc;
       }
     }
     __syncthreads();
-    if (s_n > ABZ_QS_CAP - 4 * ABZ_QS_FAT) flush();                         /* s_n is block-uniform here */
+    if (s_n > ABZ_QS_CAP - 8 * ABZ_QS_FAT) flush();                         /* s_n is block-uniform here */
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { key[u] = nkey[u]; al[u] = nal[u]; }
+    base = nbase;
   }
   if (s_n) flush();
   if (s_h2[2 * t]) atomicAdd(&hist2[2 * t], s_h2[2 * t]);
@@ -1090,6 +1117,11 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   const bool bad = QS(ABZ_S_SEL_PAD) != 0;
   const int64_t n = bad ? 0 : (int64_t)QS(ABZ_S_SEL_NBUF);
   unsigned long long k = QS(ABZ_S_SEL_K), less = QS(ABZ_S_SEL_LESS);
+  /* a single block: every memory round trip is exposed, so the first batch of buffered keys is requested now, before the
+   * reductions and the sub-bin scan that say which of them matter */
+  unsigned long long x0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) x0[u] = (int64_t)t + u * 1024 < n ? buf[t + u * 1024] : 0ull;
   unsigned long long above = ~0ull, kmin = ~0ull;
   unsigned long long binmin = ~0ull, binmax = 0ull;       /* smallest / largest key of the selected bin */
   for (int b = t; b < nblk; b += 1024) {
@@ -1140,7 +1172,7 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   for (int64_t i0 = t; i0 < (one_value ? 0 : n); i0 += 4 * 1024) {
     unsigned long long x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = i0 + u * 1024 < n ? buf[i0 + u * 1024] : 0ull;
+    for (int u = 0; u < 4; ++u) x[u] = i0 == (int64_t)t ? x0[u] : (i0 + u * 1024 < n ? buf[i0 + u * 1024] : 0ull);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (i0 + u * 1024 >= n) continue;
