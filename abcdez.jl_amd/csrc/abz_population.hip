@@ -359,21 +359,20 @@ __global__ __launch_bounds__(1024) void ind_finish_scan_kernel(const uint32_t* _
                                                                uint32_t* __restrict__ cnt, unsigned long long* __restrict__ scal,
                                                                unsigned long long* __restrict__ pub_host, int pub_words,
                                                                unsigned long long pub_seq) {
-  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_below;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint32_t per = (nchunk + 1023u) / 1024u;
   const uint32_t lo = t * per < nchunk ? t * per : nchunk, hi = lo + per < nchunk ? lo + per : nchunk;
   uint32_t s = 0;
   for (uint32_t k = lo; k < hi; ++k) s += acnt[k];
-  s_part[t] = s;
+  for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);          /* wave sums by shuffles, the 16 of them through LDS: */
+  if (lane == 0) s_wave[wave] = s;                                          /* two barriers where a tree over 1024 words takes ten */
   if (t == 0) s_below = 0u;
   __syncthreads();
-  for (uint32_t off = 512; off; off >>= 1) {
-    if (t < off) s_part[t] += s_part[t + off];
-    __syncthreads();
-  }
-  const uint32_t n_new = s_part[0];
+  uint32_t n_new = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) n_new += s_wave[w];
   __syncthreads();
   const double nn = (double)n_new, sumsq = 1.0 / nn, ess = 1.0 / sumsq;
   const bool go = !(nn > 0.0 && ess < ess_min);
@@ -412,18 +411,21 @@ __global__ __launch_bounds__(1024) void ind_finish_scan_kernel(const uint32_t* _
   };
   uint32_t v = 0;
   for (uint32_t k = lo; k < hi; ++k) v += value(k);
-  s_part[t] = v;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t add = t >= off ? s_part[t - off] : 0;
-    __syncthreads();
-    s_part[t] += add;
-    __syncthreads();
+  uint32_t inc = v;                                                         /* inclusive scan over the block: in the wave by shuffles ... */
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
   }
-  uint32_t run = t ? s_part[t - 1] : 0;
+  if (lane == 63u) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;                                           /* ... and over the 16 wave totals by everybody */
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const uint32_t x = s_wave[w]; before += (uint32_t)w < wave ? x : 0u; total += x; }
+  uint32_t run = before + inc - v;
   uint32_t* out = cnt + (size_t)blockIdx.x * nchunk;
   for (uint32_t k = lo; k < hi; ++k) { const uint32_t c = value(k); out[k] = run; run += c; }
-  if (t == 1023) scal[ABZ_S_PART_H + blockIdx.x] = (unsigned long long)s_part[1023];
+  if (t == 1023) scal[ABZ_S_PART_H + blockIdx.x] = (unsigned long long)total;
 }
 
 /* pub_seq != null: the launch that finishes the sums also publishes the first ABZ_S_SCALARS scalars to the host */
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __re
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
     const unsigned long long key = f64_order_key(delta[k]);
-    if (alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
+    if (!alive || alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
   }
   block_minmax_u64(lo, hi);
   if (threadIdx.x == 0 && lo <= hi) { atomicMin(&QS(ABZ_S_SEL_HLO), lo); atomicMax(&QS(ABZ_S_SEL_HHI), hi); }
@@ -882,6 +884,11 @@ __device__ inline unsigned long long qs_fat_min(unsigned long long v, unsigned l
   return v;
 }
 
+/* the contiguous range of n positions a block of passes 1 / 2 streams: n / grid rounded up to whole rounds of the block */
+__device__ inline int64_t qs_block_share(int64_t n, unsigned grid) {
+  const int64_t per = (n + (int64_t)grid - 1) / (int64_t)grid;
+  return (per + ABZ_QS_FAT - 1) / ABZ_QS_FAT * ABZ_QS_FAT;
+}
 /* pass 1: histogram of the alive keys in the window's bins; smallest alive key per block -> bmin[block] */
 /* n_all > 0 (fused prologue): extrema(Ds) over ALL n_all positions, alive or not (smc:364), ride along -- the positions past the
  * alive prefix are read for this only; per-block results -> ball[block], ball[grid + block], folded by qs_final_kernel */
@@ -899,31 +906,37 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
   const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
   __syncthreads();
   unsigned long long lo = ~0ull;
-  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
   /* One fat block per CU: nothing else runs on the CU while this block waits for memory, so every trip puts all it can in
    * flight at once -- 12 (distance, flag) pairs of the alive prefix AND 8 distances of the dead tail (read for the extrema
    * only) per lane; at 2^22 particles that is the whole kernel in one round trip. */
   constexpr int UM = 12, UT = 8;
-  int64_t k0 = (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x;                 /* cursor in the prefix */
-  int64_t t0 = N + (int64_t)blockIdx.x * ABZ_QS_FAT + threadIdx.x;             /* cursor in the dead tail */
-  while (k0 < N || t0 < n_all) {                                               /* block-uniform */
+  /* block b streams ONE contiguous range of the prefix and one of the tail (consecutive 8 KB pieces: blocks striding through
+   * the whole array touched a different 2 MB page with every load -- 3 us of 16, tools/qs_ablate.hip); alive == NULL: every
+   * position of the prefix is alive (the packed population's invariant: the flag bytes are not read, 1.3 us) */
+  const int64_t per = qs_block_share(N, gridDim.x), tper = qs_block_share(n_all > N ? n_all - N : 0, gridDim.x);
+  int64_t k0 = (int64_t)blockIdx.x * per + threadIdx.x;                        /* cursor in the prefix */
+  int64_t t0 = N + (int64_t)blockIdx.x * tper + threadIdx.x;                   /* cursor in the dead tail */
+  const int64_t kend = ((int64_t)blockIdx.x + 1) * per < N ? ((int64_t)blockIdx.x + 1) * per : N;
+  const int64_t tend = N + ((int64_t)blockIdx.x + 1) * tper < n_all ? N + ((int64_t)blockIdx.x + 1) * tper : n_all;
+  constexpr int64_t stride = ABZ_QS_FAT;
+  while (k0 < kend || t0 < tend) {                                             /* block-uniform */
     unsigned long long key[UM], tkey[UT];
     uint8_t al[UM];
 #pragma unroll
     for (int u = 0; u < UM; ++u) {
       const int64_t k = k0 + u * stride;
-      const bool in = k < N;
+      const bool in = k < kend;
       key[u] = in ? f64_order_key(delta[k]) : 0ull;
-      al[u] = in ? alive[k] : (uint8_t)0;
+      al[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
     }
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       const int64_t k = t0 + u * stride;
-      tkey[u] = k < n_all ? f64_order_key(delta[k]) : 0ull;
+      tkey[u] = k < tend ? f64_order_key(delta[k]) : 0ull;
     }
 #pragma unroll
     for (int u = 0; u < UM; ++u) {
-      if (n_all > 0 && k0 + u * stride < N) { alo = key[u] < alo ? key[u] : alo; ahi = key[u] > ahi ? key[u] : ahi; }
+      if (n_all > 0 && k0 + u * stride < kend) { alo = key[u] < alo ? key[u] : alo; ahi = key[u] > ahi ? key[u] : ahi; }
       if (al[u]) {
         atomicAdd(&s_h[qs_bin(key[u], klo, shift)], 1u);
         lo = key[u] < lo ? key[u] : lo;
@@ -931,7 +944,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
     }
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
-      if (t0 + u * stride < n_all) { alo = tkey[u] < alo ? tkey[u] : alo; ahi = tkey[u] > ahi ? tkey[u] : ahi; }
+      if (t0 + u * stride < tend) { alo = tkey[u] < alo ? tkey[u] : alo; ahi = tkey[u] > ahi ? tkey[u] : ahi; }
     }
     k0 += UM * stride;
     t0 += UT * stride;
@@ -970,16 +983,18 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   const int t = threadIdx.x;
   /* one fat block per CU: the first trip's loads go out before anything else -- they need neither the histogram nor the bin --
    * and every later trip's loads go out before the trip in hand is processed (nothing else runs on this CU while it waits) */
-  const int64_t stride = (int64_t)gridDim.x * ABZ_QS_FAT;
+  constexpr int64_t stride = ABZ_QS_FAT;                      /* a contiguous range per block, as in pass 1 */
+  const int64_t per = qs_block_share(N, gridDim.x);
+  const int64_t kend = ((int64_t)blockIdx.x + 1) * per < N ? ((int64_t)blockIdx.x + 1) * per : N;
   unsigned long long key[8];
   uint8_t al[8];
-  int64_t base = (int64_t)blockIdx.x * ABZ_QS_FAT;
+  int64_t base = (int64_t)blockIdx.x * per;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int64_t k = base + t + u * stride;
-    const bool in = k < N;
+    const bool in = k < kend;
     key[u] = in ? f64_order_key(delta[k]) : 0ull;
-    al[u] = in ? alive[k] : (uint8_t)0;
+    al[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
   }
   const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];      /* 2 consecutive bins per thread */
   const unsigned long long mine = (unsigned long long)h0 + h1;
@@ -1025,16 +1040,16 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     if (t == 0) s_n = 0;
     __syncthreads();
   };
-  while (base < N) {                                                                         /* block-uniform trips */
+  while (base < kend) {                                                                      /* block-uniform trips */
     const int64_t nbase = base + 8 * stride;
     unsigned long long nkey[8];
     uint8_t nal[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {                                                           /* the next trip's loads */
       const int64_t k = nbase + t + u * stride;
-      const bool in = k < N;
+      const bool in = k < kend;
       nkey[u] = in ? f64_order_key(delta[k]) : 0ull;
-      nal[u] = in ? alive[k] : (uint8_t)0;
+      nal[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1122,6 +1137,9 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   unsigned long long x0[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) x0[u] = (int64_t)t + u * 1024 < n ? buf[t + u * 1024] : 0ull;
+  const unsigned long long w_klo = QS(ABZ_S_SEL_HLO), w_khi = QS(ABZ_S_SEL_HHI), w_bin = QS(ABZ_S_SEL_BIN);   /* the window and the bin, for later */
+  unsigned long long ball_lo = ~0ull, ball_hi = 0ull;                     /* per-block extrema of all distances (pass 1), folded at the end */
+  if (tail.ball && t < nblk) { ball_lo = tail.ball[t]; ball_hi = tail.ball[nblk + t]; }
   unsigned long long above = ~0ull, kmin = ~0ull;
   unsigned long long binmin = ~0ull, binmax = 0ull;       /* smallest / largest key of the selected bin */
   for (int b = t; b < nblk; b += 1024) {
@@ -1158,9 +1176,9 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     const unsigned long long b2 = s_pick[0];
     less += s_pick[1];
     k -= s_pick[1];
-    const unsigned long long klo = QS(ABZ_S_SEL_HLO);
-    const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
-    const unsigned long long base2 = klo + (QS(ABZ_S_SEL_BIN) << shift);
+    const unsigned long long klo = w_klo;
+    const int shift = qs_shift(klo, w_khi);
+    const unsigned long long base2 = klo + (w_bin << shift);
     const int s2 = shift > 11 ? shift - 11 : 0;
     lo = b2 == 0 ? 0ull : base2 + (b2 << s2);
     hi = b2 == ABZ_QS_BINS - 1 ? ~0ull : base2 + ((b2 + 1) << s2) - 1ull;
@@ -1287,8 +1305,7 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     }
   }
   if (tail.ball) {
-    unsigned long long c0 = 0, lo = ~0ull, hi = 0ull;
-    if (t < nblk) { lo = tail.ball[t]; hi = tail.ball[nblk + t]; }
+    unsigned long long c0 = 0, lo = ball_lo, hi = ball_hi;
     qs_block_reduce(c0, lo, hi, s_red);
     if (t == 0) { unsigned long long* scal = st - ABZ_S_SEL_PREFIX; scal[ABZ_S_MIN] = lo; scal[ABZ_S_MAX] = hi; }
   }
@@ -1303,8 +1320,9 @@ __device__ inline double dev_from_order_key(unsigned long long k) {
 }
 
 /* enqueue the three passes of the select for rank k0 (0-based) among the alive distances; results stay on the device */
+/* all_alive: every one of the N positions is alive (the prefix of the packed population): the kernels do not read the flags */
 static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
-                          const QsTail* tail_in = nullptr, int64_t n_all = 0) {
+                          const QsTail* tail_in = nullptr, int64_t n_all = 0, bool all_alive = false) {
   int rc = abz_ws_reserve(ctx, abz_align((size_t)N * 8));
   if (rc) return rc;
   unsigned long long* buf = (unsigned long long*)ctx->ws;
@@ -1326,7 +1344,7 @@ static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* a
     ABZ_HIP_CHECK(hipMemsetAsync(ctx->sel_hist, 0, 2 * ABZ_QS_BINS * 4, ctx->stream));
     unsigned mgrid = (unsigned)((N + ABZ_BLOCK - 1) / ABZ_BLOCK);
     if (mgrid > ABZ_REDUCE_GRID) mgrid = ABZ_REDUCE_GRID;
-    hipLaunchKernelGGL(qs_minmax_kernel, dim3(mgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, alive, N, st);
+    hipLaunchKernelGGL(qs_minmax_kernel, dim3(mgrid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, all_alive ? nullptr : alive, N, st);
   }
   ctx->sel_clean = false;
   unsigned grid = (unsigned)((N + 8 * ABZ_QS_FAT - 1) / (8 * ABZ_QS_FAT));
@@ -1335,9 +1353,10 @@ static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* a
   QsTail tail{};
   if (tail_in) tail = *tail_in;
   tail.ball = n_all > 0 ? ball : nullptr;
-  hipLaunchKernelGGL(qs_hist_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N, st, ctx->sel_hist, bmin,
+  const uint8_t* flags = all_alive ? nullptr : alive;
+  hipLaunchKernelGGL(qs_hist_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, flags, N, st, ctx->sel_hist, bmin,
                      n_all, ball);
-  hipLaunchKernelGGL(qs_compact_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, alive, N,
+  hipLaunchKernelGGL(qs_compact_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, flags, N,
                      (unsigned long long)k0, ctx->sel_hist, st, buf, babove, hist2);
   hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist, bmin, babove, (int)grid,
                      hist2, tail);
@@ -1510,7 +1529,9 @@ int abz_prologue_select_enqueue(abcdez_ctx* ctx, const double* delta_all, const 
   tail.eps_on = 1; tail.single = n == 1 ? 1 : 0; tail.k0 = (unsigned long long)(j - 1); tail.g = g;
   tail.eps_prev = eps_prev; tail.eps_target = eps_target;
   *j_out = j;
-  return select_enqueue(ctx, delta_all, alive, n_prev, j - 1, &tail, N);   /* + extrema(Ds) over all N, + eps of smc:301 */
+  /* + extrema(Ds) over all N, + eps of smc:301; the n_prev positions of the prefix are the alive particles (the packed
+   * population's invariant, which the sweeps rely on too): their flags need not be read */
+  return select_enqueue(ctx, delta_all, alive, n_prev, j - 1, &tail, N, true);
 }
 int abz_prologue_packed_impl(abcdez_ctx* ctx, const double* delta_all, int64_t N, int64_t n_prev, double* wns, uint8_t* alive,
                              double alpha, double eps_prev, double eps_target, double eps_k_old, double ess_min,
