@@ -14,7 +14,12 @@ def show(name, d):
         print("            pattern ceiling %.4g (back to back) / %s (single launches): kernel over ceiling %.3f / %s" % (
             pc.get("updates_per_s", 0), "%.4g" % pc["updates_per_s_single_launches"] if pc.get("updates_per_s_single_launches") else "-",
             pc.get("kernel_over_ceiling", 0), "%.3f" % pc["kernel_over_ceiling_single_launches"] if pc.get("kernel_over_ceiling_single_launches") else "-"))
-    if "cpu_baseline" in d:
+    if r.get("frac_trace") is not None:
+        print("            frac_trace %.3f (kernel trace, committed file)  traffic / moved bytes %s" % (
+            r["frac_trace"], "%.3f" % r["traffic_over_moved_bytes"] if r.get("traffic_over_moved_bytes") else "-"))
+    if d.get("errors_vs_exact"):
+        print("            errors vs closed forms:", json.dumps(d["errors_vs_exact"]))
+    if d.get("cpu_baseline"):
         print("            cpu %.4g (%s cores) %s" % (d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["sample"][:80]))
     w = d.get("whole_run")
     if w:
