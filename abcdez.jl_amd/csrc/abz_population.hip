@@ -840,6 +840,9 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 #define ABZ_QS_GRID 256
 #define ABZ_QS_CAP 12288            /* keys a block of pass 2 stages in LDS (96 KB; one fat block per CU) */
 #define ABZ_QS_LDSKEYS 4096
+#ifndef ABZ_QS_FINAL_THREADS
+#define ABZ_QS_FINAL_THREADS 1024    /* threads of the finishing block of the select */
+#endif
 
 __device__ inline int qs_shift(unsigned long long klo, unsigned long long khi) {
   if (khi <= klo) return 0;
@@ -997,6 +1000,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     al[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
   }
   const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];      /* 2 consecutive bins per thread */
+  const unsigned long long klo = QS(ABZ_S_SEL_HLO), khi_w = QS(ABZ_S_SEL_HHI);   /* requested now, used after the bin is known */
   const unsigned long long mine = (unsigned long long)h0 + h1;
   unsigned long long incl = mine;                      /* inclusive scan over the block */
   for (int off = 1; off < 64; off <<= 1) {
@@ -1026,8 +1030,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     if (t == 0) { babove[blockIdx.x] = ~0ull; babove[gridDim.x + blockIdx.x] = ~0ull; babove[2 * gridDim.x + blockIdx.x] = ~0ull; }
     return;
   }
-  const unsigned long long klo = QS(ABZ_S_SEL_HLO);
-  const int shift = qs_shift(klo, QS(ABZ_S_SEL_HHI));
+  const int shift = qs_shift(klo, khi_w);
   const unsigned long long base2 = klo + ((unsigned long long)sel << shift);
   const int s2 = shift > 11 ? shift - 11 : 0;
   unsigned long long above = ~0ull, inmin = ~0ull, inmaxc = ~0ull;
@@ -1082,7 +1085,8 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   if (t == 0) babove[2 * gridDim.x + blockIdx.x] = inmaxc;
 }
 
-/* one block of 1024: sum / min / max over the block, result broadcast to every thread */
+/* one block of NT threads: sum / min / max over the block, result broadcast to every thread */
+template <int NT>
 __device__ inline void qs_block_reduce(unsigned long long& cnt, unsigned long long& mn, unsigned long long& mx,
                                        unsigned long long* s_red) {
   for (int off = 32; off; off >>= 1) {
@@ -1096,7 +1100,7 @@ __device__ inline void qs_block_reduce(unsigned long long& cnt, unsigned long lo
   if ((threadIdx.x & 63) == 0) { s_red[3 * w] = cnt; s_red[3 * w + 1] = mn; s_red[3 * w + 2] = mx; }
   __syncthreads();
   cnt = 0; mn = ~0ull; mx = 0ull;
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < NT / 64; ++q) {
     cnt += s_red[3 * q];
     mn = s_red[3 * q + 1] < mn ? s_red[3 * q + 1] : mn;
     mx = s_red[3 * q + 2] > mx ? s_red[3 * q + 2] : mx;
@@ -1114,7 +1118,12 @@ struct QsTail {
   double g, eps_prev, eps_target;
   const unsigned long long* ball;   /* per-block extrema of ALL distances from qs_hist_kernel, or NULL */
 };
-__global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long* __restrict__ buf,
+/* NT threads.  What this kernel costs is its ONE pass over the buffered keys of the selected bin -- 5 K to 20 K keys at 2^22
+ * particles (the 0.95-quantile sits where the distances are dense), read by a single block: 8 loads in flight per thread, the
+ * first batch requested before anything else.  (Timestamps inside the kernel, round 4: that pass was 4-14 us of its 10-20; 256
+ * threads instead of 1024 changed nothing -- the barriers are not what it waits for.) */
+template <int NT>
+__global__ __launch_bounds__(NT) void qs_final_kernel(const unsigned long long* __restrict__ buf,
                                                         unsigned long long* __restrict__ st, uint32_t* __restrict__ hist,
                                                         const unsigned long long* __restrict__ bmin,
                                                         const unsigned long long* __restrict__ babove, int nblk,
@@ -1126,23 +1135,31 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   __shared__ unsigned long long s_pick[4];            /* bin | key, count before it, (rank branch) hit flag, #equal */
   __shared__ uint32_t s_n;
   const int t = threadIdx.x;
-  for (int b = t; b < ABZ_QS_BINS; b += 1024) hist[b] = 0;               /* ready for the next call */
-  const uint32_t g0 = hist2[2 * t], g1 = hist2[2 * t + 1];
-  hist2[2 * t] = 0; hist2[2 * t + 1] = 0;
+  constexpr int BPT = ABZ_QS_BINS / NT;                                   /* consecutive bins per thread */
+  for (int b = t; b < ABZ_QS_BINS; b += NT) hist[b] = 0;                 /* ready for the next call */
+  uint32_t gb[BPT];
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) { gb[q] = hist2[BPT * t + q]; hist2[BPT * t + q] = 0; }
   const bool bad = QS(ABZ_S_SEL_PAD) != 0;
   const int64_t n = bad ? 0 : (int64_t)QS(ABZ_S_SEL_NBUF);
   unsigned long long k = QS(ABZ_S_SEL_K), less = QS(ABZ_S_SEL_LESS);
   /* a single block: every memory round trip is exposed, so the first batch of buffered keys is requested now, before the
    * reductions and the sub-bin scan that say which of them matter */
-  unsigned long long x0[4];
+  constexpr int UB = 8;                                     /* buffered keys in flight per thread */
+  unsigned long long x0[UB];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) x0[u] = (int64_t)t + u * 1024 < n ? buf[t + u * 1024] : 0ull;
+  for (int u = 0; u < UB; ++u) x0[u] = buf[t + u * NT];     /* unconditionally: not behind the load of n (the buffer holds at least UB NT words; words past n are never looked at) */
   const unsigned long long w_klo = QS(ABZ_S_SEL_HLO), w_khi = QS(ABZ_S_SEL_HHI), w_bin = QS(ABZ_S_SEL_BIN);   /* the window and the bin, for later */
   unsigned long long ball_lo = ~0ull, ball_hi = 0ull;                     /* per-block extrema of all distances (pass 1), folded at the end */
-  if (tail.ball && t < nblk) { ball_lo = tail.ball[t]; ball_hi = tail.ball[nblk + t]; }
+  if (tail.ball)
+    for (int b = t; b < nblk; b += NT) {
+      const unsigned long long a = tail.ball[b], c = tail.ball[nblk + b];
+      ball_lo = a < ball_lo ? a : ball_lo;
+      ball_hi = c > ball_hi ? c : ball_hi;
+    }
   unsigned long long above = ~0ull, kmin = ~0ull;
   unsigned long long binmin = ~0ull, binmax = 0ull;       /* smallest / largest key of the selected bin */
-  for (int b = t; b < nblk; b += 1024) {
+  for (int b = t; b < nblk; b += NT) {
     const unsigned long long a = babove[b], m = bmin[b], i0 = babove[nblk + b], i1 = babove[2 * nblk + b];
     above = a < above ? a : above;
     kmin = m < kmin ? m : kmin;
@@ -1154,13 +1171,16 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   bool found = false;
   {
     unsigned long long dcnt = 0;
-    qs_block_reduce(dcnt, binmin, binmax, s_red);
+    qs_block_reduce<NT>(dcnt, binmin, binmax, s_red);
   }
   /* the whole bin is one key value (tied / discrete distances): nothing to search, the buffer is not even read */
   const bool one_value = !bad && n > 0 && binmin == binmax;
   if (one_value) { key = binmin; eq = (unsigned long long)n; found = true; }
   if (!bad && !one_value) {                            /* sub-bin of the rank: 11 key bits without touching a key */
-    unsigned long long mine = (unsigned long long)g0 + g1, incl = mine;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) mine += gb[q];
+    unsigned long long incl = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned long long v = __shfl_up(incl, off, 64);
       if ((t & 63) >= off) incl += v;
@@ -1169,8 +1189,13 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     __syncthreads();
     unsigned long long before = incl - mine;
     for (int w = 0; w < (t >> 6); ++w) before += s_red[w];
-    if (k >= before && k < before + mine) {
-      if (k < before + g0) { s_pick[0] = 2 * t; s_pick[1] = before; } else { s_pick[0] = 2 * t + 1; s_pick[1] = before + g0; }
+    if (k >= before && k < before + mine) {                      /* exactly one thread: which of its bins holds rank k */
+      unsigned long long run = before;
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        if (k >= run && k < run + gb[q]) { s_pick[0] = (unsigned long long)(BPT * t + q); s_pick[1] = run; }
+        run += gb[q];
+      }
     }
     __syncthreads();
     const unsigned long long b2 = s_pick[0];
@@ -1187,13 +1212,13 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   /* the one pass over the buffer in global memory: the sub-bin's keys -> LDS (normally a handful), smallest key
    * beyond the sub-bin -> `above`.  Should they not fit, the rounds below read the whole buffer instead.        */
   unsigned long long cmin = ~0ull, cmax = 0ull;
-  for (int64_t i0 = t; i0 < (one_value ? 0 : n); i0 += 4 * 1024) {
-    unsigned long long x[4];
+  for (int64_t i0 = t; i0 < (one_value ? 0 : n); i0 += UB * NT) {
+    unsigned long long x[UB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = i0 == (int64_t)t ? x0[u] : (i0 + u * 1024 < n ? buf[i0 + u * 1024] : 0ull);
+    for (int u = 0; u < UB; ++u) x[u] = i0 == (int64_t)t ? x0[u] : (i0 + u * NT < n ? buf[i0 + u * NT] : 0ull);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (i0 + u * 1024 >= n) continue;
+    for (int u = 0; u < UB; ++u) {
+      if (i0 + u * NT >= n) continue;
       if (x[u] > hi) above = x[u] < above ? x[u] : above;
       if (x[u] >= lo && x[u] <= hi) {
         const uint32_t q = atomicAdd(&s_n, 1u);
@@ -1205,7 +1230,7 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   }
   {
     unsigned long long dcnt = 0;
-    qs_block_reduce(dcnt, cmin, cmax, s_red);      /* (its barriers also publish s_n and s_keys) */
+    qs_block_reduce<NT>(dcnt, cmin, cmax, s_red);      /* (its barriers also publish s_n and s_keys) */
   }
   /* the sub-bin is one key value (an atom of a discrete distance among others): done, however many copies there are */
   const bool one_cand = !bad && !one_value && s_n > 0 && cmin == cmax;
@@ -1216,17 +1241,17 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   __syncthreads();
   for (int round = 0; round < 16 && !bad && !one_value && !one_cand; ++round) {
     unsigned long long cnt = 0, mn = ~0ull, mx = 0ull;
-    for (int64_t i = t; i < nk; i += 1024) {
+    for (int64_t i = t; i < nk; i += NT) {
       const unsigned long long x = keys[i];
       if (x >= lo && x <= hi) { ++cnt; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
     }
-    qs_block_reduce(cnt, mn, mx, s_red);
+    qs_block_reduce<NT>(cnt, mn, mx, s_red);
     if (cnt == 0) break;                               /* cannot happen for k < count; reported as an error below */
     if (mn == mx) { key = mn; eq = cnt; found = true; break; }
     if (cnt <= 64) {
       if (t == 0) { s_n = 0; s_pick[2] = 0; }
       __syncthreads();
-      for (int64_t i = t; i < nk; i += 1024) {
+      for (int64_t i = t; i < nk; i += NT) {
         const unsigned long long x = keys[i];
         if (x >= lo && x <= hi) s_cand[atomicAdd(&s_n, 1u)] = x;
       }
@@ -1244,15 +1269,18 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     /* narrow: 2048 sub-bins of [mn, mx] */
     const int bl = 64 - __clzll((long long)(mx - mn));
     const int s = bl > 11 ? bl - 11 : 0;
-    for (int b = t; b < ABZ_QS_BINS; b += 1024) s_h[b] = 0;
+    for (int b = t; b < ABZ_QS_BINS; b += NT) s_h[b] = 0;
     __syncthreads();
-    for (int64_t i = t; i < nk; i += 1024) {
+    for (int64_t i = t; i < nk; i += NT) {
       const unsigned long long x = keys[i];
       if (x >= lo && x <= hi) atomicAdd(&s_h[(uint32_t)((x - mn) >> s)], 1u);
     }
     __syncthreads();
-    const uint32_t h0 = s_h[2 * t], h1 = s_h[2 * t + 1];
-    unsigned long long mine = (unsigned long long)h0 + h1, incl = mine;
+    uint32_t hb[BPT];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) { hb[q] = s_h[BPT * t + q]; mine += hb[q]; }
+    unsigned long long incl = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned long long v = __shfl_up(incl, off, 64);
       if ((t & 63) >= off) incl += v;
@@ -1262,7 +1290,12 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
     unsigned long long before = incl - mine;
     for (int w = 0; w < (t >> 6); ++w) before += s_red[w];
     if (k >= before && k < before + mine) {
-      if (k < before + h0) { s_pick[0] = 2 * t; s_pick[1] = before; } else { s_pick[0] = 2 * t + 1; s_pick[1] = before + h0; }
+      unsigned long long run = before;
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        if (k >= run && k < run + hb[q]) { s_pick[0] = (unsigned long long)(BPT * t + q); s_pick[1] = run; }
+        run += hb[q];
+      }
     }
     __syncthreads();
     const unsigned long long b = s_pick[0];
@@ -1275,13 +1308,13 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   /* smallest key strictly greater than the selected one: in the buffer, else the smallest key of a higher bin */
   unsigned long long nxt = above, dc = 0;
   if (found && !one_value && !one_cand)
-    for (int64_t i = t; i < nk; i += 1024) {
+    for (int64_t i = t; i < nk; i += NT) {
       const unsigned long long x = keys[i];
       if (x > key && x < nxt) nxt = x;
     }
   unsigned long long dm = 0, d0 = 0, d1 = 0;
-  qs_block_reduce(dc, nxt, dm, s_red);
-  qs_block_reduce(d0, kmin, d1, s_red);
+  qs_block_reduce<NT>(dc, nxt, dm, s_red);
+  qs_block_reduce<NT>(d0, kmin, d1, s_red);
   if (t == 0) {
     QS(ABZ_S_SEL_PREFIX) = key;
     QS(ABZ_S_SEL_LESS) = less;
@@ -1306,7 +1339,7 @@ __global__ __launch_bounds__(1024) void qs_final_kernel(const unsigned long long
   }
   if (tail.ball) {
     unsigned long long c0 = 0, lo = ball_lo, hi = ball_hi;
-    qs_block_reduce(c0, lo, hi, s_red);
+    qs_block_reduce<NT>(c0, lo, hi, s_red);
     if (t == 0) { unsigned long long* scal = st - ABZ_S_SEL_PREFIX; scal[ABZ_S_MIN] = lo; scal[ABZ_S_MAX] = hi; }
   }
 }
@@ -1323,7 +1356,8 @@ __device__ inline double dev_from_order_key(unsigned long long k) {
 /* all_alive: every one of the N positions is alive (the prefix of the packed population): the kernels do not read the flags */
 static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* alive, int64_t N, int64_t k0,
                           const QsTail* tail_in = nullptr, int64_t n_all = 0, bool all_alive = false) {
-  int rc = abz_ws_reserve(ctx, abz_align((size_t)N * 8));
+  const size_t buf_bytes = (size_t)N * 8 > (size_t)8 * ABZ_QS_FINAL_THREADS * 8 ? (size_t)N * 8 : (size_t)8 * ABZ_QS_FINAL_THREADS * 8;
+  int rc = abz_ws_reserve(ctx, abz_align(buf_bytes));         /* at least the 8 NT words the finishing block requests up front */
   if (rc) return rc;
   unsigned long long* buf = (unsigned long long*)ctx->ws;
   unsigned long long* st = ctx->d_scal + ABZ_S_SEL_PREFIX;
@@ -1358,8 +1392,8 @@ static int select_enqueue(abcdez_ctx* ctx, const double* delta, const uint8_t* a
                      n_all, ball);
   hipLaunchKernelGGL(qs_compact_kernel, dim3(grid), dim3(ABZ_QS_FAT), 0, ctx->stream, delta, flags, N,
                      (unsigned long long)k0, ctx->sel_hist, st, buf, babove, hist2);
-  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, buf, st, ctx->sel_hist, bmin, babove, (int)grid,
-                     hist2, tail);
+  hipLaunchKernelGGL((qs_final_kernel<ABZ_QS_FINAL_THREADS>), dim3(1), dim3(ABZ_QS_FINAL_THREADS), 0, ctx->stream, buf, st, ctx->sel_hist, bmin,
+                     babove, (int)grid, hist2, tail);
   ABZ_HIP_CHECK(hipGetLastError());
   ctx->sel_delta = delta; ctx->sel_alive = alive; ctx->sel_N = N;
   return 0;
