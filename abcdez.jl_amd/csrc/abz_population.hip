@@ -691,18 +691,29 @@ int abz_ind_reweight_partition(abcdez_ctx* ctx, const double* delta_all, uint8_t
  * integer weights (abz_weight_fix) -> inclusive scan in u64 -> per-stratum search. */
 #define ABZ_SCAN_TILE 2048 /* 256 threads x 8 consecutive elements */
 
+__device__ inline void wfix_load8(const double* __restrict__ wns, uint32_t base, uint32_t N, double (&w)[8]) {
+  if (base + 8u <= N) {                  /* base is a multiple of 8: 64-byte aligned */
+    const double4 a = *reinterpret_cast<const double4*>(wns + base), b = *reinterpret_cast<const double4*>(wns + base + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = base + (uint32_t)q < N ? wns[base + q] : 0.0;
+  }
+}
 __global__ __launch_bounds__(ABZ_BLOCK) void wfix_tile_sum_kernel(const double* __restrict__ wns, uint32_t N,
                                                                   unsigned long long* __restrict__ tile_sum,
-                                                                  unsigned long long* __restrict__ last_pos) {
+                                                                  uint32_t* __restrict__ tile_lp) {
   __shared__ unsigned long long s_w[4];
   const uint32_t base = blockIdx.x * ABZ_SCAN_TILE + threadIdx.x * 8;
   unsigned long long s = 0;
   uint32_t lp1 = 0;                      /* 1 + last index with positive weight, 0 = none */
+  double w8[8];
+  wfix_load8(wns, base, N, w8);          /* a thread's 8 consecutive weights as two 32-byte loads (eight 8-byte loads at a 64-byte lane stride cost the address unit eight requests per line) */
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const uint32_t k = base + q;
     if (k < N) {
-      const unsigned long long f = abz_weight_fix(wns[k], N);
+      const unsigned long long f = abz_weight_fix(w8[q], N);
       s += f;
       if (f) lp1 = k + 1;
     }
@@ -722,17 +733,26 @@ __global__ __launch_bounds__(ABZ_BLOCK) void wfix_tile_sum_kernel(const double* 
     tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     uint32_t m = s_lp[0];
     for (int w = 1; w < 4; ++w) m = s_lp[w] > m ? s_lp[w] : m;
-    if (m) atomicMax(last_pos, (unsigned long long)m);
+    tile_lp[blockIdx.x] = m;             /* folded by scan_u64_kernel (2048 atomicMax on one word cost more than this whole pass) */
   }
 }
 
-__global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long* __restrict__ v, uint32_t n) {
+/* exclusive scan of the tile sums (one block); tile_lp != NULL: also 1 + the last position with a positive weight = the
+ * maximum of the tiles' values -> *last_pos */
+__global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long* __restrict__ v, uint32_t n,
+                                                        const uint32_t* __restrict__ tile_lp, unsigned long long* __restrict__ last_pos) {
   __shared__ unsigned long long s_part[1024];
+  __shared__ uint32_t s_mx[16];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
   unsigned long long s = 0;
-  for (uint32_t k = lo; k < hi; ++k) s += v[k];
+  uint32_t mx = 0;
+  for (uint32_t k = lo; k < hi; ++k) { s += v[k]; if (tile_lp) { const uint32_t m = tile_lp[k]; mx = m > mx ? m : mx; } }
+  if (tile_lp) {
+    for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+    if ((t & 63u) == 0u) s_mx[t >> 6] = mx;
+  }
   s_part[t] = s;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -743,6 +763,11 @@ __global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long* __re
   }
   unsigned long long run = t ? s_part[t - 1] : 0;
   for (uint32_t k = lo; k < hi; ++k) { const unsigned long long c = v[k]; v[k] = run; run += c; }
+  if (tile_lp && t == 0) {               /* (s_mx was written before the scan's barriers) */
+    uint32_t m = 0;
+    for (int w = 0; w < 16; ++w) m = s_mx[w] > m ? s_mx[w] : m;
+    *last_pos = (unsigned long long)m;
+  }
 }
 
 __global__ __launch_bounds__(ABZ_BLOCK) void wfix_scan_kernel(const double* __restrict__ wns, uint32_t N,
@@ -752,10 +777,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void wfix_scan_kernel(const double* __re
   const uint32_t base = blockIdx.x * ABZ_SCAN_TILE + threadIdx.x * 8;
   unsigned long long f[8];
   unsigned long long s = 0;
+  double w8[8];
+  wfix_load8(wns, base, N, w8);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const uint32_t k = base + q;
-    f[q] = k < N ? abz_weight_fix(wns[k], N) : 0ull;
+    f[q] = k < N ? abz_weight_fix(w8[q], N) : 0ull;
     s += f[q];
   }
   /* inclusive scan of s over the wave */
@@ -769,11 +796,15 @@ __global__ __launch_bounds__(ABZ_BLOCK) void wfix_scan_kernel(const double* __re
   __syncthreads();
   unsigned long long run = tile_off[blockIdx.x] + (inc - s);
   for (int w = 0; w < wave; ++w) run += s_w[w];
+  unsigned long long c8[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const uint32_t k = base + q;
-    run += f[q];
-    if (k < N) cum[k] = run;
+  for (int q = 0; q < 8; ++q) { run += f[q]; c8[q] = run; }
+  if (base + 8u <= N) {                  /* two 32-byte stores */
+    *reinterpret_cast<ulonglong4*>(cum + base) = make_ulonglong4(c8[0], c8[1], c8[2], c8[3]);
+    *reinterpret_cast<ulonglong4*>(cum + base + 4) = make_ulonglong4(c8[4], c8[5], c8[6], c8[7]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (base + (uint32_t)q < N) cum[base + q] = c8[q];
   }
 }
 
@@ -798,14 +829,15 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
   const uint32_t n = (uint32_t)N;
   const uint32_t nt = (n + ABZ_SCAN_TILE - 1) / ABZ_SCAN_TILE;
   const size_t tb = abz_align((size_t)nt * 8);
-  int rc = abz_ws_reserve(ctx, tb + abz_align((size_t)n * 8));
+  const size_t lpb = abz_align((size_t)nt * 4);
+  int rc = abz_ws_reserve(ctx, tb + abz_align((size_t)n * 8) + lpb);
   if (rc) return rc;
   unsigned long long* tile = (unsigned long long*)ctx->ws;
   unsigned long long* cum = (unsigned long long*)((char*)ctx->ws + tb);
-  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_LASTPOS, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(wfix_tile_sum_kernel, dim3(nt), dim3(ABZ_BLOCK), 0, ctx->stream, wns, n, tile,
+  uint32_t* tile_lp = (uint32_t*)((char*)ctx->ws + tb + abz_align((size_t)n * 8));
+  hipLaunchKernelGGL(wfix_tile_sum_kernel, dim3(nt), dim3(ABZ_BLOCK), 0, ctx->stream, wns, n, tile, tile_lp);
+  hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile, nt, (const uint32_t*)tile_lp,
                      ctx->d_scal + ABZ_S_LASTPOS);
-  hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile, nt);
   hipLaunchKernelGGL(wfix_scan_kernel, dim3(nt), dim3(ABZ_BLOCK), 0, ctx->stream, wns, n, tile, cum);
   hipLaunchKernelGGL(stratified_search_kernel, dim3((n + ABZ_BLOCK - 1) / ABZ_BLOCK), dim3(ABZ_BLOCK), 0, ctx->stream,
                      cum, n, ctx->h_model.seed, draw, ctx->d_scal + ABZ_S_LASTPOS, inds);
