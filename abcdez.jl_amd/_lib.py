@@ -10,7 +10,8 @@ import os
 from .model import Model
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libabcdez_hip.so")
+# ABCDEZ_HIP_LIB: another build of the same library (the Julia shim reads the same variable) -- used for same-box A/B runs
+LIB_PATH = os.environ.get("ABCDEZ_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libabcdez_hip.so")
 
 _vp, _i64, _u32, _i32, _f64 = C.c_void_p, C.c_int64, C.c_uint32, C.c_int32, C.c_double
 _pi64, _pf64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
