@@ -67,6 +67,7 @@ static inline void abz_mc_chain_break(abcdez_ctx* ctx) {
   ctx->mc_chain += 1;
   ctx->mc_tail_bound = -1;
   ctx->mc_tail_hint = -1;
+  ctx->mc_reject_known = false;
 }
 /* the population was written by something other than the next asynchronous abcdemc generation */
 static inline void abz_population_written(abcdez_ctx* ctx) {
@@ -76,7 +77,7 @@ static inline void abz_population_written(abcdez_ctx* ctx) {
 
 extern "C" {
 
-int abcdez_version(void) { return 400; }       /* round 4: Philox4x32-10 again, abz_model.mv, group abort */
+int abcdez_version(void) { return 401; }       /* 400: Philox4x32-10 again, abz_model.mv, group abort; 401: abcdemc's better particle by rejection */
 int abcdez_rng_rounds(void) { return ABZ_PHILOX_ROUNDS; }
 
 /* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
@@ -387,6 +388,9 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
   ctx->cnt_prev[ABZ_C_MCSIM] = ts;
   ctx->cnt_prev[ABZ_C_MCGT] = tg;
+  /* at most half of the particles above eps_target after this generation: every later generation of the chain draws by
+   * rejection (abz_ctx.h, mc_reject_known) */
+  if (ctx->ring_chain[slot] == ctx->mc_chain && 2ll * ctx->ring_res[slot][1] <= (long long)ctx->mc_last_N) ctx->mc_reject_known = true;
   if (snap[5] != ~0ull && ctx->ring_chain[slot] == ctx->mc_chain) {
     ctx->mc_tail_hint = (long long)snap[5];        /* the next rank pass sizes its long-tail launches from this */
     double eps_pop;
@@ -570,6 +574,12 @@ int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t* inline_ru
 int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, int64_t* long_only) {
   ABZ_REQUIRE(ctx && both && small_only && long_only, "mc_rank_stats: null argument");
   *both = ctx->n_rank_paths[0]; *small_only = ctx->n_rank_paths[1]; *long_only = ctx->n_rank_paths[2];
+  return 0;
+}
+
+int abcdez_mc_draw_stats(abcdez_ctx* ctx, int64_t* by_rejection_no_rank_pass) {
+  ABZ_REQUIRE(ctx && by_rejection_no_rank_pass, "mc_draw_stats: null argument");
+  *by_rejection_no_rank_pass = ctx->n_mc_reject_gens;
   return 0;
 }
 
@@ -871,8 +881,9 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
                     const double* logpi, const double* delta, double* ntheta, double* nlogpi, double* ndelta,
                     double eps_pop, double eps_target, double gamma0, double gamma_sigma, int64_t i0, int64_t n_local,
                     uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax) {
-  ABZ_REQUIRE(ctx && order && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim,
-              "mc_swarm: null argument");
+  ABZ_REQUIRE(ctx && theta && logpi && delta && ntheta && nlogpi && ndelta && nsim, "mc_swarm: null argument");
+  /* order == cnt == NULL: the better particle of mc:23 by rejection (include/abcdez_spec.h says when a host may ask for it) */
+  ABZ_REQUIRE((order == nullptr) == (cnt == nullptr), "mc_swarm: pass both order and cnt (draws by rank) or neither (by rejection)");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
@@ -886,6 +897,12 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   ctx->mc_window_ready = false;
   rc = read_counters(ctx);
   if (rc) return rc;
+  if (ctx->h_scal[ABZ_S_MC_REJFAIL] != 0ull) {
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_MC_REJFAIL, 0, 8, ctx->stream));
+    abz_set_error("mc_swarm: a particle drawing its better particle by rejection (order = NULL) ran out of trials: more than half "
+                  "of the particles lie above eps_target -- such a generation draws by rank (include/abcdez_spec.h)");
+    return -3;
+  }
   *nsim = (int64_t)ctx->h_scal[ABZ_S_COUNT];
   if (n_above_target) *n_above_target = (int64_t)ctx->h_scal[ABZ_S_MCGT];
   if (dmin || dmax) {
@@ -900,15 +917,21 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
 /* one abcdemc generation in one call: the rank pass (when the population is not converged) and the sweep */
 int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta, uint32_t* cnt,
-                         double eps_pop, double eps_target, double dmax, double gamma0, double gamma_sigma, uint32_t sweep,
-                         int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out) {
-  ABZ_REQUIRE(ctx && order && sorted_delta && cnt, "mc_generation: null argument");
-  if (dmax > eps_target) {           /* mc:20-24 is only reached while some Ds[i] > eps */
+                         double eps_pop, double eps_target, double dmax, int64_t n_above, double gamma0, double gamma_sigma,
+                         uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out) {
+  ABZ_REQUIRE(ctx && order && sorted_delta && cnt && delta, "mc_generation: null argument");
+  ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE(n_above >= -1 && n_above <= N, "mc_generation: n_above = #(Ds > eps_target) of the distances read, or -1");
+  if (n_above < 0) {                 /* the caller does not carry mc:156 of the generation before: count */
+    if (int rc = abz_count_gt_impl(ctx, delta, N, eps_target, &n_above)) return rc;
+  }
+  const bool reject = abz_mc_draws_by_rejection((uint64_t)n_above, (uint64_t)N) != 0;
+  if (dmax > eps_target && !reject) {           /* mc:20-24 is only reached while some Ds[i] > eps */
     const int rc = abcdez_mc_rank_prepare(ctx, delta, N, eps_pop, dmax, order, sorted_delta, cnt);
     if (rc) return rc;
   }
-  return abcdez_mc_swarm(ctx, order, cnt, N, theta, logpi, delta, ntheta, nlogpi, ndelta, eps_pop, eps_target, gamma0,
-                         gamma_sigma, 0, N, sweep, nsim, n_above_target, dmin, dmax_out);
+  return abcdez_mc_swarm(ctx, reject ? nullptr : order, reject ? nullptr : cnt, N, theta, logpi, delta, ntheta, nlogpi, ndelta,
+                         eps_pop, eps_target, gamma0, gamma_sigma, 0, N, sweep, nsim, n_above_target, dmin, dmax_out);
 }
 
 /* abcdemc!'s loop body (mc:146-149) WITHOUT a host synchronisation.  The population extrema of mc:146 come from the
@@ -943,8 +966,18 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   /* a new chain: host-given extrema (the first generation of a run), other parameters, another population than the one the
    * generation before wrote (its outputs are this generation's inputs) */
   if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N) {
-    ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1;
+    ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1; ctx->mc_reject_known = false;
   }
+  /* how the chain's generations draw their better particles is decided on the device from #(Ds > eps_target): counted once
+   * here, carried from sweep to sweep by the snapshot kernel afterwards */
+  if (ctx->mc_nabove_chain != ctx->mc_chain) {
+    if (int r = abz_launch_mc_chain_start(ctx, delta, N, eps_target)) return r;
+    ctx->mc_nabove_chain = ctx->mc_chain;
+  }
+  /* the rank pass: not once the host has SEEN the chain switch to rejection (until then it is launched and, if the device
+   * has switched already, left unread) */
+  const bool launch_rank = do_rank && !ctx->mc_reject_known;
+  if (do_rank && !launch_rank) ctx->n_mc_reject_gens += 1;
   const bool need_window = lo_hi || !ctx->mc_window_ready || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target;
   const unsigned long long* win = ctx->d_scal + ABZ_S_MCW_EPS;
   const unsigned long long* seq_dev = ctx->d_scal + ABZ_S_MCSEQ;
@@ -956,12 +989,13 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
                          !(ctx->timing_stride > 1 && (ctx->timing_seq % ctx->timing_stride) != 0);
   /* the body of one generation as stream launches (also what gets captured) */
   auto enqueue = [&]() -> int {
-    if (do_rank) {                   /* mc:20-24 is only reached while some Ds[i] > eps */
+    if (launch_rank) {               /* mc:20-24 is only reached while some Ds[i] > eps */
       if (int r = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound)) return r;
     }
     if (int r = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
-                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev)) return r;
-    return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, do_rank ? ctx->mc_rank_state : nullptr);
+                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev, ctx->d_scal + ABZ_S_MC_NABOVE)) return r;
+    return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, launch_rank ? ctx->mc_rank_state : nullptr,
+                                  (uint32_t)N);
   };
   const long long ev_before = ctx->ev_tail;
   bool replayed = false;
@@ -971,11 +1005,11 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     key.theta = theta; key.logpi = logpi; key.delta = delta; key.ntheta = ntheta; key.nlogpi = nlogpi; key.ndelta = ndelta;
     key.order = order; key.sorted_delta = sorted_delta; key.cnt = cnt; key.stamp_cur = ctx->stamp_cur; key.stamp_nxt = ctx->stamp_nxt;
     key.stream = (const void*)ctx->stream; key.N = N; key.alpha = alpha; key.eps_target = eps_target; key.gamma0 = gamma0;
-    key.gsig = gamma_sigma; key.sweep_base = sweep_base; key.do_rank = do_rank ? 1 : 0;
-    key.path = do_rank ? (plan.small_path && plan.long_path ? 0 : plan.small_path ? 1 : 2) : -1;
-    key.ltiles = do_rank && plan.long_path ? plan.ltiles : 0u;
+    key.gsig = gamma_sigma; key.sweep_base = sweep_base; key.do_rank = launch_rank ? 1 : 0;
+    key.path = launch_rank ? (plan.small_path && plan.long_path ? 0 : plan.small_path ? 1 : 2) : -1;
+    key.ltiles = launch_rank && plan.long_path ? plan.ltiles : 0u;
     key.mm_bank = ctx->mm_bank; key.L = ctx->L; key.C = ctx->C;
-    if (do_rank) { if ((rc = abz_ws_reserve(ctx, plan.ws_bytes))) return rc; }     /* no allocation inside a capture */
+    if (launch_rank) { if ((rc = abz_ws_reserve(ctx, plan.ws_bytes))) return rc; }     /* no allocation inside a capture */
     key.ws = ctx->ws;
     abz_mc_graph* g = nullptr;
     for (abz_mc_graph& e : ctx->mc_graphs)
@@ -997,7 +1031,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
         if (graph) (void)hipGraphDestroy(graph);
         if (r == 0 && e == hipSuccess && exec) {
           abz_mc_graph ng;
-          ng.key = key; ng.exec = exec; ng.rank_state = do_rank ? ctx->mc_rank_state : nullptr; ng.rank_limit = ctx->mc_rank_limit;
+          ng.key = key; ng.exec = exec; ng.rank_state = launch_rank ? ctx->mc_rank_state : nullptr; ng.rank_limit = ctx->mc_rank_limit;
           ctx->mc_graphs.push_back(ng);
           g = &ctx->mc_graphs.back();
           ctx->n_graph_captures += 1;
@@ -1010,7 +1044,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     }
     if (g) {
       ABZ_HIP_CHECK(hipGraphLaunch(g->exec, ctx->stream));
-      if (do_rank) { ctx->n_rank_paths[key.path] += 1; ctx->mc_rank_state = g->rank_state; ctx->mc_rank_limit = g->rank_limit; }
+      if (launch_rank) { ctx->n_rank_paths[key.path] += 1; ctx->mc_rank_state = g->rank_state; ctx->mc_rank_limit = g->rank_limit; }
       if (ctx->timing && ctx->timing_stride > 1) ctx->timing_seq += 1;      /* what abz_time_begin would have counted */
       ctx->n_graph_replays += 1;
       replayed = true;
@@ -1055,6 +1089,14 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   }
   ring_fold(ctx, ticket);
   ctx->mc_waited += 1;
+  if (snap[6] == 2ull) {
+    /* the sweep drew its better particles by rejection and a particle found none in 1024 trials: with at least half of the
+     * population in every candidate set that does not happen -- the distances are not the ones the chain's count was made of */
+    abz_population_written(ctx);
+    abz_set_error("mc_generation_wait: a particle drawing its better particle by rejection ran out of trials: the distances were "
+                  "written outside the library without abcdez_smc_select_discard; the generation's results are invalid");
+    return -3;
+  }
   if (snap[6] != 0ull) {
     /* only the one-workgroup sort was launched for this generation (a proved tail bound <= 4096) and the tail was longer: the
      * distances were written behind the library's back.  The generation's sweep drew its better particles from a stale

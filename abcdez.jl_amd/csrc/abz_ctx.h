@@ -138,6 +138,12 @@ struct abcdez_ctx {
   const uint32_t* mc_rank_state = nullptr;        /* state words of the last rank pass (abz_sort.hip), in the workspace */
   uint32_t mc_rank_limit = 0xFFFFFFFFu;           /* longest tail the sorts that pass launched can handle (only the LDS sort: 4096) */
   long long mc_tail_hint = -1;                    /* particles that drew in the last generation the host has seen; -1 = unknown */
+  /* ABZ_S_MC_NABOVE describes the population of this chain (-1: count it before the next asynchronous generation) */
+  long long mc_nabove_chain = -1;
+  /* a redeemed generation of the chain left at most half of the particles above eps_target: from then on every generation
+   * of the chain draws by rejection (the count never grows, include/abcdez_spec.h) and no rank pass is launched */
+  bool mc_reject_known = false;
+  long long n_mc_reject_gens = 0;                 /* asynchronous generations issued without a rank pass for that reason */
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
 };
@@ -226,7 +232,12 @@ enum {
   /* number of asynchronous abcdemc generations whose snapshot kernel has run (== the host's mc_issued when the next one
    * executes): ring slot and ticket of the snapshot, RNG epoch of the sweep = base + this */
   ABZ_S_MCSEQ = ABZ_S_MCW_EPS + 5,
-  ABZ_S_N = ABZ_S_MCW_EPS + 6
+  /* how the next asynchronous generation draws its better particles (include/abcdez_spec.h, abz_mc_draws_by_rejection):
+   * #(Ds > eps_target) of the distances it reads -- counted at the start of a chain, afterwards the growth of the cumulative
+   * ABZ_C_MCGT slots over the sweep before (their total at the last snapshot is kept next to it) */
+  ABZ_S_MC_NABOVE = ABZ_S_MCW_EPS + 6, ABZ_S_MC_TGPREV = ABZ_S_MCW_EPS + 7,
+  ABZ_S_MC_REJFAIL = ABZ_S_MCW_EPS + 8,   /* a sweep drawing by rejection ran out of trials: the population was not what the rule assumed */
+  ABZ_S_N = ABZ_S_MCW_EPS + 9
 };
 
 /* kernel launchers implemented across the .hip files */
@@ -248,10 +259,12 @@ static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
 }
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
-                        uint32_t, uint32_t, uint32_t, const unsigned long long*, const unsigned long long* seq_dev = nullptr);
+                        uint32_t, uint32_t, uint32_t, const unsigned long long*, const unsigned long long* seq_dev = nullptr,
+                        const unsigned long long* nabove_dev = nullptr);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
 int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_ring, double alpha, double eps_target,
-                           const uint32_t* rank_state);
+                           const uint32_t* rank_state, uint32_t N);
+int abz_launch_mc_chain_start(abcdez_ctx*, const double* delta, int64_t N, double eps_target);
 /* which sorts a rank pass launches for a tail of the hinted / bounded length, and the grid of the long-tail kernels (a power of two
  * of wave-tiles: the kernels stride, so any grid is correct -- few distinct values keep the graph cache small) */
 struct abz_rank_plan { bool small_path, long_path; uint32_t ltiles; size_t ws_bytes; };

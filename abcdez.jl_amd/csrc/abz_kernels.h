@@ -343,6 +343,11 @@ struct McSwarmArgs {
   const uint64_t* stamp;        /* blob stamps, both NULL when blobs are off */
   uint64_t* nstamp;
   const unsigned long long* seq_dev;   /* non-NULL: the RNG epoch is sweep + *seq_dev (generations replayed as a graph, abz_ctx.h) */
+  /* the better particle of mc:23 by rank (order / cnt) or by rejection (include/abcdez_spec.h, abz_mc_draws_by_rejection):
+   * non-NULL = #(Ds > eps_target) of the distances this sweep reads, kept on the device -- the sweep applies the rule itself
+   * (abcdez_mc_generation_async); NULL = the caller applied it: by rejection iff order == NULL */
+  const unsigned long long* nabove_dev;
+  unsigned long long* reject_fail;     /* set when a particle found no better particle in 1024 trials (include/abcdez_spec.h) */
 };
 
 __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
@@ -370,6 +375,8 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
   __syncthreads();                                                          /* once per workgroup */
   const int j = (int)(threadIdx.x % L);
   const double eps_pop = a.eps_pop_dev ? abz_u2d(*a.eps_pop_dev) : a.eps_pop;
+  /* wave-uniform (scalar loads): how this generation draws its better particles */
+  const bool reject = a.nabove_dev ? abz_mc_draws_by_rejection(*a.nabove_dev, a.N) != 0 : a.order == nullptr;
   const uint32_t ntiles = (a.n_local + PB - 1) / PB;
   /* driver reductions of the generation this sweep leaves behind (mc:146,156,163), carried over the workgroup's tiles:
    * #(Ds > eps_target), nsims, extrema(Ds) as order keys */
@@ -383,13 +390,17 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
      * words need no memory */
     const double lpi = a.logpi[i];
     const double di = a.delta[i];
-    const uint32_t cnt_i = a.cnt[i];                                        /* meaningful only where di > eps (abz_sort.hip) */
-    const abz_u64x2 w_better = abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER);
+    const uint32_t cnt_i = reject ? 0u : a.cnt[i];                          /* meaningful only where di > eps (abz_sort.hip) */
     const abz_u64x2 w_donor = abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR);
     const double eps = di <= a.eps_target ? a.eps_target : eps_pop;         /* mc:19 */
     uint32_t s = i;
     if (di > eps) {                                                         /* mc:20-24 */
-      s = a.order[abz_randint(w_better.w0, cnt_i)];
+      if (reject) {
+        int exhausted;
+        s = abz_mc_better_by_rejection(seed, i, sweep, a.delta, a.N, di, &exhausted);
+        if (exhausted) *a.reject_fail = 1ull;     /* the rule's premise did not hold for the distances read: the host hears of it */
+      }
+      else s = a.order[abz_randint(abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_i)];
     }
     uint32_t ia, ib;                                                        /* mc:25-32 */
     abz_donor_ranks(w_donor, a.N, s, &ia, &ib);

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_swarm_kernel(const McSwarmArgs a
 int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt, uint32_t N,
                         const double* theta, const double* logpi, const double* delta, double* ntheta, double* nlogpi,
                         double* ndelta, double eps_pop, double eps_target, double gamma0, double gsig, uint32_t i0,
-                        uint32_t n_local, uint32_t sweep, const unsigned long long* eps_pop_dev, const unsigned long long* seq_dev) {
+                        uint32_t n_local, uint32_t sweep, const unsigned long long* eps_pop_dev, const unsigned long long* seq_dev,
+                        const unsigned long long* nabove_dev) {
   if (n_local == 0) return 0;
   McSwarmArgs a;
   a.hm = ctx->hot; a.order = order; a.cnt = cnt;
@@ -31,6 +32,8 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   a.eps_pop = eps_pop; a.eps_target = eps_target; a.gamma0 = gamma0; a.gsig = gsig;
   a.eps_pop_dev = eps_pop_dev;
   a.seq_dev = seq_dev;
+  a.nabove_dev = nabove_dev;
+  a.reject_fail = ctx->d_scal + ABZ_S_MC_REJFAIL;
   a.N = N; a.i0 = i0; a.n_local = n_local; a.sweep = sweep;
   a.stamp = ctx->stamp_cur; a.nstamp = ctx->stamp_cur ? ctx->stamp_nxt : nullptr;      /* blob stamps */
   bool ok = true;

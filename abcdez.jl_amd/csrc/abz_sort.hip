@@ -426,7 +426,7 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
                                                                  unsigned long long* __restrict__ ring,
                                                                  double alpha, double eps_target, const uint32_t* __restrict__ rank_state,
-                                                                 uint32_t rank_limit) {
+                                                                 uint32_t rank_limit, uint32_t N) {
   /* which generation this is: counted on the device (the host's mc_issued when it enqueued this launch -- or when it replays
    * the graph this launch was captured into): ring slot and ticket follow from it */
   const unsigned long long gen = scal[ABZ_S_MCSEQ];
@@ -458,6 +458,14 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
     /* fail safe: the rank pass launched ONLY the LDS sort on the strength of a tail bound, and the tail turned out longer -- the
      * enumeration the sweep drew from was not built.  The host turns this word into an error when it redeems the ticket.    */
     out[6] = (rank_state && rank_state[MCR_ST_NTAIL] > rank_limit) ? 1ull : 0ull;
+    /* how the sweep just run drew its better particles was decided from #(Ds > eps_target) of its input (ABZ_S_MC_NABOVE);
+     * by rank without a rank pass launched (a host that said do_rank = 0 of an unconverged population): same failure */
+    const unsigned long long n_in = scal[ABZ_S_MC_NABOVE];
+    if (!rank_state && n_in != 0ull && !abz_mc_draws_by_rejection(n_in, (unsigned long long)N)) out[6] = 1ull;
+    if (scal[ABZ_S_MC_REJFAIL] != 0ull) { out[6] = 2ull; scal[ABZ_S_MC_REJFAIL] = 0ull; }   /* drawn by rejection, trials exhausted */
+    /* ... and the next generation's: what this sweep added to the cumulative ABZ_C_MCGT slots */
+    scal[ABZ_S_MC_NABOVE] = tg - scal[ABZ_S_MC_TGPREV];
+    scal[ABZ_S_MC_TGPREV] = tg;
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
@@ -465,10 +473,49 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
   }
 }
 int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_ring, double alpha,
-                           double eps_target, const uint32_t* rank_state) {
+                           double eps_target, const uint32_t* rank_state, uint32_t N) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
   hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_ring, alpha, eps_target, rank_state,
-                     ctx->mc_rank_limit);
+                     ctx->mc_rank_limit, N);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+/* Start of a chain of asynchronous generations: #(Ds > eps_target) of the population it starts from -> ABZ_S_MC_NABOVE (the
+ * first sweep decides from it how to draw its better particles), and the total of the cumulative ABZ_C_MCGT slots as it
+ * stands -> ABZ_S_MC_TGPREV (the snapshot kernels take differences against it).  Once per chain.                    */
+__global__ __launch_bounds__(ABZ_BLOCK) void mc_chain_count_kernel(const double* __restrict__ delta, uint32_t n, double eps_target,
+                                                                   unsigned long long* __restrict__ scal) {
+  unsigned int c = 0u;
+  for (uint32_t k = blockIdx.x * ABZ_BLOCK + threadIdx.x; k < n; k += gridDim.x * ABZ_BLOCK) c += delta[k] > eps_target ? 1u : 0u;
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+  __shared__ unsigned int s_c[ABZ_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < ABZ_BLOCK / 64; ++w) t += s_c[w];
+    if (t) atomicAdd(scal + ABZ_S_MC_NABOVE, t);
+  }
+}
+__global__ __launch_bounds__(ABZ_CSLOTS) void mc_chain_total_kernel(unsigned long long* __restrict__ scal) {
+  __shared__ unsigned long long s_g[ABZ_CSLOTS / 64];
+  unsigned long long vg = scal[ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE + ABZ_C_MCGT];
+  for (int o = 32; o >= 1; o >>= 1) vg += __shfl_xor(vg, o);
+  if ((threadIdx.x & 63) == 0) s_g[threadIdx.x >> 6] = vg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tg = 0;
+    for (int w = 0; w < ABZ_CSLOTS / 64; ++w) tg += s_g[w];
+    scal[ABZ_S_MC_TGPREV] = tg;
+  }
+}
+int abz_launch_mc_chain_start(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_target) {
+  ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_MC_NABOVE, 0, 8, ctx->stream));
+  unsigned grid = (unsigned)((N + 4 * ABZ_BLOCK - 1) / (4 * ABZ_BLOCK));
+  if (grid > 256u) grid = 256u;              /* every block ends with one same-address atomic */
+  hipLaunchKernelGGL(mc_chain_count_kernel, dim3(grid), dim3(ABZ_BLOCK), 0, ctx->stream, delta, (uint32_t)N, eps_target, ctx->d_scal);
+  hipLaunchKernelGGL(mc_chain_total_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

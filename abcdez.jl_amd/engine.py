@@ -286,14 +286,21 @@ class HipOps:
             C.byref(nsim), C.byref(ngt), C.byref(lo), C.byref(hi)))
         return nsim.value, ngt.value, lo.value, hi.value
 
-    def mc_generation(self, cur, nxt, order, sorted_delta, cnt, eps_pop, eps_target, dmax, gamma0, gsig, sweep):
-        """rank pass (if dmax > eps_target) + sweep over all particles: one library call, one host sync"""
+    def mc_generation(self, cur, nxt, order, sorted_delta, cnt, eps_pop, eps_target, dmax, n_above, gamma0, gsig, sweep):
+        """rank pass (if dmax > eps_target and more than half of the particles lie above eps_target: n_above, or -1 = count
+        them here) + sweep over all particles: one library call, one host sync"""
         nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self.lib, self.lib.abcdez_mc_generation(
             self.ctx, cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]),
-            _ptr(order), _ptr(sorted_delta), _ptr(cnt), eps_pop, eps_target, dmax, gamma0, gsig, sweep, C.byref(nsim),
+            _ptr(order), _ptr(sorted_delta), _ptr(cnt), eps_pop, eps_target, dmax, n_above, gamma0, gsig, sweep, C.byref(nsim),
             C.byref(ngt), C.byref(lo), C.byref(hi)))
         return nsim.value, ngt.value, lo.value, hi.value
+
+    def mc_draw_stats(self) -> int:
+        """asynchronous generations that needed no rank pass because they draw their better particles by rejection"""
+        n = C.c_int64()
+        _lib.check(self.lib, self.lib.abcdez_mc_draw_stats(self.ctx, C.byref(n)))
+        return n.value
 
     MC_IN_FLIGHT = 8
 
@@ -832,14 +839,19 @@ class PopulationEngine:
             dmax_hint = hi if dmax_hint is None else dmax_hint
         self.ops.mc_rank_prepare(self.state[2], eps_pop, dmax_hint, self.order, self.sorted_delta, self.rank_cnt)
 
-    def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float):
+    def mc_draws_by_rejection(self, n_above: int) -> bool:
+        """the rule of include/abcdez_spec.h (abz_mc_draws_by_rejection): the better particle of mc:23 is drawn by rejection,
+        without a rank pass, once at most half of the particles lie above eps_target"""
+        return 2 * int(n_above) <= self.N
+
+    def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float, reject: bool = False):
         """one sweep of abcdemc_swarm! -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the generation it leaves
-        (mc:149,156,146,163), global over all ranks"""
+        (mc:149,156,146,163), global over all ranks.  reject: the better particle of mc:23 by rejection (no enumeration)"""
         self._mc_arrays()        # (a converged population never consults them)
         self._stream()
         self._bind_stamps()
-        nsim, ngt, lo, hi = self.ops.mc_swarm(self.order, self.rank_cnt, self.state, self.other, eps_pop, eps_target,
-                                              gamma0, gsig, self.lo, self.n_local, self.sweep)
+        nsim, ngt, lo, hi = self.ops.mc_swarm(None if reject else self.order, None if reject else self.rank_cnt, self.state,
+                                              self.other, eps_pop, eps_target, gamma0, gsig, self.lo, self.n_local, self.sweep)
         self.sweep += 1
         with _rng("mc_rows_allgather"):
             self._allgather_state(self.other + ((self.stamp[1 - self.cur],) if self.blob_on else ()))
@@ -853,21 +865,26 @@ class PopulationEngine:
             lo, hi = float(t[0]), -float(t[1])
         return nsim, ngt, lo, hi
 
-    def mc_generation(self, eps_pop: float, eps_target: float, dmax: float, gamma0: float, gsig: float):
-        """the body of abcdemc!'s loop (mc:140-156): rank pass while some Ds > eps_target, one sweep -> (nsim,
-        #(Ds > eps_target), min Ds, max Ds) of the new generation.  One library call on a single GPU."""
+    def mc_generation(self, eps_pop: float, eps_target: float, dmax: float, gamma0: float, gsig: float, n_above: int = None):
+        """the body of abcdemc!'s loop (mc:140-156): rank pass while some Ds > eps_target and the better particle is drawn by
+        rank, one sweep -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the new generation.  One library call on a single
+        GPU.  n_above = #(Ds > eps_target) of the current distances when the caller has it (mc:133 / mc:156 of the generation
+        before); counted here otherwise."""
         if not self._collectives and hasattr(self.ops, "mc_generation"):
             self._mc_arrays()
             self._stream()
             self._bind_stamps()
             out = self.ops.mc_generation(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, eps_pop,
-                                         eps_target, dmax, gamma0, gsig, self.sweep)
+                                         eps_target, dmax, -1 if n_above is None else int(n_above), gamma0, gsig, self.sweep)
             self.sweep += 1
             self._swap()
             return out
-        if dmax > eps_target:
+        if n_above is None:
+            n_above = self.count_gt(eps_target)
+        reject = self.mc_draws_by_rejection(n_above)
+        if dmax > eps_target and not reject:
             self.mc_rank_prepare(eps_pop, dmax)
-        return self.mc_swarm(eps_pop, eps_target, gamma0, gsig)
+        return self.mc_swarm(eps_pop, eps_target, gamma0, gsig, reject=reject)
 
     # abcdemc!'s loop has no data-dependent exit (mc:134): generations can be ENQUEUED ahead of their results
     def mc_generation_issue(self, alpha: float, eps_target: float, gamma0: float, gsig: float, lo_hi=None, do_rank: bool = True):
@@ -891,8 +908,12 @@ class PopulationEngine:
         lo, hi = lo_hi if lo_hi is not None else self._mc_last
         v = lo + alpha * (hi - lo)
         eps_pop = max(eps_target, v)                                                       # mc:147
-        nsim, ngt, nlo, nhi = self.mc_generation(eps_pop, eps_target, hi if do_rank else -math.inf, gamma0, gsig)
+        # #(Ds > eps_target) of the distances this generation reads: mc:156 of the generation before (for the same eps_target)
+        known = getattr(self, "_mc_above", None)
+        n_above = known[1] if lo_hi is None and known is not None and known[0] == eps_target else None
+        nsim, ngt, nlo, nhi = self.mc_generation(eps_pop, eps_target, hi if do_rank else -math.inf, gamma0, gsig, n_above=n_above)
         self._mc_last = (nlo, nhi)
+        self._mc_above = (eps_target, ngt)
         self._mc_pending.append(("done", (nsim, ngt, nlo, nhi, eps_pop)))
 
     def mc_generations_in_flight(self) -> int:

@@ -621,7 +621,7 @@ def run_config(args):
                 "launched_incl_warmup": {"sweeps": gen.sweeps, "updates": gen.updates},     # what a profiler sees of the sweep kernel
                 "step_includes": ("extrema(Ds), eps-quantile, reweight, ESS, partition (one call), resample when ESS < N/2, "
                                   "<= Kmcmc sweeps with their counter read-backs (smc:301-364)") if cfg["kind"] == "smc" else
-                                 "rank pass (while max Ds > eps_target), one sweep with nsim / completion / extrema folded in (mc:140-161)",
+                                 "rank pass (while max Ds > eps_target and more than half of the particles lie above it), one sweep with nsim / completion / extrema folded in (mc:140-161)",
                 "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
@@ -629,7 +629,12 @@ def run_config(args):
         }
         out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (around one of their sweeps, in turn)
         if cfg["kind"] == "mc":
-            out["config"]["timed_window"].update(ranked_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
+            out["config"]["timed_window"].update(unconverged_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
+            if hasattr(eng.ops, "mc_rank_stats"):
+                rs = eng.ops.mc_rank_stats()
+                out["config"]["better_particle_draws"] = {
+                    "generations_with_a_rank_pass": int(sum(rs)), "generations_by_rejection_without_one": int(eng.ops.mc_draw_stats()),
+                    "rule": "by rejection once at most half of the particles lie above eps_target (include/abcdez_spec.h)"}
             gr = eng.ops.graph_stats()
             out["config"]["graph_replay"] = {"generations_replayed": gr[0], "graphs_captured": gr[1], "generations_stream_launched": gr[2],
                                              "what": "one abcdemc generation (rank pass + sweep + snapshot, <= 15 dependent launches) is captured "

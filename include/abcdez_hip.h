@@ -198,6 +198,9 @@ ABCDEZ_API int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t
  * one-workgroup LDS sort, only the radix sort.  One alone is launched when the host holds a proved upper bound of the tail's length:
  * once a generation of a chain of asynchronous generations ran with eps_pop == eps_target, the particles that draw only become fewer. */
 ABCDEZ_API int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, int64_t* long_only);
+/* ... and asynchronous generations issued with do_rank != 0 for which no rank pass was launched, because a redeemed generation
+ * of the chain had left at most half of the particles above eps_target (they draw their better particles by rejection). */
+ABCDEZ_API int abcdez_mc_draw_stats(abcdez_ctx* ctx, int64_t* by_rejection_no_rank_pass);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,
@@ -260,6 +263,12 @@ ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, 
  *     -- with hand-written kernels (bucket ids over the window (eps_pop, dmax_hint], stable LSD radix passes, fix-up
  *     of shared buckets).  dmax_hint: maximum(Ds) as the driver knows it from mc:146; it only shapes the binning,
  *     any value gives the same result.  Asynchronous (no host synchronisation).
+ *     By rank or by rejection: mc:23 is a uniform draw from {j : Ds[j] <= Ds[i]}; order = cnt = NULL makes mc_swarm draw it
+ *     by rejection instead (uniform j over all particles until Ds[j] <= Ds[i]; include/abcdez_spec.h,
+ *     abz_mc_better_by_rejection) -- no rank pass at all.  The spec's rule: a generation draws by rejection iff at most half
+ *     of the particles it reads lie above eps_target (abz_mc_draws_by_rejection; then every candidate set holds at least
+ *     N / 2 particles).  mc_swarm takes the caller's word for it (and returns an error if a particle runs out of trials,
+ *     which under the rule does not happen); abcdez_mc_generation and abcdez_mc_generation_async apply the rule themselves.
  *     mc_swarm also returns the reductions the driver takes of the generation it leaves behind, over the
  *     particles [i0, i0+n_local): n_above_target = sum(nDs .> eps_target) (mc:156), (dmin, dmax) = extrema(nDs)
  *     (mc:146,163) -- any of the three pointers may be NULL.                                                    */
@@ -273,18 +282,22 @@ ABCDEZ_API int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uin
                     double* dmin, double* dmax);
 
 /* One generation of abcdemc!'s loop body (src/abcdez_mc.jl:140-156) on one GPU in one call: rank_prepare when
- * dmax > eps_target (the host passes the extrema it got from the previous generation, mc:146), then mc_swarm over
- * all N particles.  One host synchronisation per generation.                                                  */
+ * dmax > eps_target (the host passes the extrema it got from the previous generation, mc:146) and the generation draws by
+ * rank, then mc_swarm over all N particles.  n_above = #(Ds > eps_target) of the distances read (mc:133, or
+ * *n_above_target of the generation before, mc:156), -1 = count them here.  One host synchronisation per generation. */
 ABCDEZ_API int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
                          double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta, uint32_t* cnt,
-                         double eps_pop, double eps_target, double dmax, double gamma0, double gamma_sigma, uint32_t sweep,
-                         int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out);
+                         double eps_pop, double eps_target, double dmax, int64_t n_above, double gamma0, double gamma_sigma,
+                         uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out);
 /* The same loop body WITHOUT a host synchronisation -- abcdemc!'s loop (mc:134-161) has no data-dependent exit, so the
  * host may run ahead of the device.  The extrema of mc:146 are taken from the sweep before, on the device (lo_hi = NULL),
  * or from lo_hi[0..1] (first generation of a run / after anything else changed the population); eps_pop =
  * max(eps_target, lo + alpha (hi - lo)) (mc:147) is evaluated on the device with the host driver's operations; do_rank = 0
  * skips the rank pass (legal once a redeemed generation reported max Ds <= eps_target: converged populations stay
- * converged and nobody draws from mc:23's sets).  *ticket numbers the generation; at most 8 may be in flight.
+ * converged and nobody draws from mc:23's sets).  By rank or by rejection: decided on the device from #(Ds > eps_target),
+ * counted when a chain of generations starts and carried from sweep to sweep; once a redeemed generation has shown the
+ * switch to rejection (it is final, include/abcdez_spec.h) the library launches no rank pass any more -- abcdez_mc_draw_stats.
+ * *ticket numbers the generation; at most 8 may be in flight.
  * abcdez_mc_generation_wait redeems the tickets in issue order and waits for THAT generation only: nsim, #(new Ds >
  * eps_target) (mc:156), extrema of the new distances (mc:146, :163) and the eps_pop the generation ran with.          */
 ABCDEZ_API int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi,

@@ -512,6 +512,35 @@ ABZ_HD void abz_donor_ranks(abz_u64x2 w, uint32_t n_alive, uint32_t ri, uint32_t
   *ra = a; *rb = b;
 }
 
+/* ------------------------------------------------------------------ abcdemc's "better particle" (mc:20-24)
+ * s = rand(rng, (1:nparticles)[Ds .<= Ds[i]]): uniform over the candidate set {j : Ds[j] <= Ds[i]} (i itself belongs to it).
+ * Two formulations of the same law:
+ *   by rank       s = order[randint(cnt_i)] over an enumeration of the set (needs the particles that draw sorted by distance);
+ *   by rejection  uniform j over ALL particles until Ds[j] <= Ds[i]: the first hit is uniform over the set.  No sort, but
+ *                 N / |set| trials on average.
+ * The rule (a function of the generation's input distances only, so that every implementation takes the same branch): a
+ * generation draws by rejection iff at most half of its particles lie above eps_target.  Whoever draws has Ds[i] > eps_pop >=
+ * eps_target, so its candidate set contains every particle at or below eps_target: then at least N / 2 candidates, at most two
+ * trials on average -- and #(Ds > eps_target) never grows again (mc:54: a particle at or below eps_target accepts only dp <=
+ * eps_target, the others only dp <= max(eps_pop, Ds[i])), so a run switches once.
+ * Trial 2t is word 0, trial 2t + 1 word 1 of block t of the purpose ABZ_RNG_BETTER.  After 2 * ABZ_MC_REJECT_BLOCKS misses
+ * (probability <= 2^-1024 under the rule) the particle keeps itself, which is a member of its own candidate set.          */
+#define ABZ_MC_REJECT_BLOCKS 512u
+ABZ_HD int abz_mc_draws_by_rejection(uint64_t n_above_target, uint64_t n) { return 2u * n_above_target <= n; }
+ABZ_HD uint32_t abz_mc_better_by_rejection(uint64_t seed, uint32_t i, uint32_t sweep, const double* delta, uint32_t n, double di,
+                                           int* exhausted) {
+  *exhausted = 0;
+  for (uint32_t t = 0; t < ABZ_MC_REJECT_BLOCKS; ++t) {
+    const abz_u64x2 w = abz_rng(seed, i, sweep, t, ABZ_RNG_BETTER);
+    const uint32_t j0 = abz_randint(w.w0, n), j1 = abz_randint(w.w1, n);
+    const double d0 = delta[j0], d1 = delta[j1];          /* both reads in flight together */
+    if (d0 <= di) return j0;
+    if (d1 <= di) return j1;
+  }
+  *exhausted = 1;     /* under the rule: never.  An implementation may treat it as proof that the rule's premise did not hold. */
+  return i;
+}
+
 /* ------------------------------------------------------------------ resampling fixed point (smc:15-56)
  * The reference walks a sequentially accumulated fp cumsum; a parallel scan cannot
  * reproduce its roundings, so the spec accumulates in exact integers:

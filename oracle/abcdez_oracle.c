@@ -105,6 +105,17 @@ ORC_API void orc_particle_draws(uint64_t seed, int64_t i0, int64_t n, int64_t n_
     log_u[k] = abz_log_tab(abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0), ORC_T);
   }
 }
+/* abcdemc's better particle by rejection for particle i over `n` consecutive sweeps (test hook of the law: uniform over
+ * {j : delta[j] <= delta[i]}); trials[k] = 0 when the trials ran out */
+ORC_API void orc_mc_better_by_rejection(uint64_t seed, const double* delta, int64_t N, uint32_t i, uint32_t sweep0, int64_t n,
+                                        uint32_t* s_out, uint8_t* found) {
+  for (int64_t k = 0; k < n; ++k) {
+    int exhausted;
+    s_out[k] = abz_mc_better_by_rejection(seed, i, sweep0 + (uint32_t)k, delta, (uint32_t)N, delta[i], &exhausted);
+    found[k] = (uint8_t)!exhausted;
+  }
+}
+ORC_API int orc_mc_draws_by_rejection(int64_t n_above, int64_t N) { return abz_mc_draws_by_rejection((uint64_t)n_above, (uint64_t)N); }
 ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w, n); }
 ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : (kind == 2 ? abz_u01_52(w) : abz_u01_co(w)); }
 ORC_API uint32_t orc_randint(uint64_t w, uint32_t n) { return abz_randint(w, n); }
@@ -960,8 +971,11 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint3
     double di = delta[i];
     double eps = di <= eps_target ? eps_target : eps_pop;               /* mc:19 */
     uint32_t s = (uint32_t)i;
+    int exhausted = 0;
     if (di > eps) {                                                     /* mc:20-24 */
-      s = order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_of[i])];   /* mc:23 */
+      /* mc:23; order == NULL: by rejection (include/abcdez_spec.h, abz_mc_draws_by_rejection says when) */
+      s = order ? order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_of[i])]
+                : abz_mc_better_by_rejection(M->seed, (uint32_t)i, sweep, delta, (uint32_t)N, di, &exhausted);
     }
     uint32_t a, b;                                                      /* mc:25-32: uniform over all N */
     abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)N, s, &a, &b);

@@ -181,9 +181,11 @@ ORC_API int orc_abcdemc(const abz_model* M, orc_mc_run* R, double* theta_out, do
     double lo, hi;
     orc_extrema(cur.delta, N, &lo, &hi);                            /* mc:146 */
     double eps_pop = fmax(R->eps_target, lo + 0.0 * (hi - lo));     /* mc:147, alpha = 0 (mc:107) */
-    if (hi > R->eps_target) orc_mc_rank_prepare(cur.delta, N, eps_pop, order, sorted, cnt);   /* only consulted when D_i > eps */
+    /* the better particle of mc:23 by rank or by rejection: include/abcdez_spec.h, abz_mc_draws_by_rejection */
+    const int reject = abz_mc_draws_by_rejection((uint64_t)orc_count_gt(cur.delta, N, R->eps_target), (uint64_t)N);
+    if (hi > R->eps_target && !reject) orc_mc_rank_prepare(cur.delta, N, eps_pop, order, sorted, cnt);   /* only consulted when D_i > eps */
     int64_t nsim;
-    orc_mc_swarm(M, order, cnt, N, cur.theta, cur.logpi, cur.delta, nxt.theta, nxt.logpi, nxt.delta,
+    orc_mc_swarm(M, reject ? NULL : order, reject ? NULL : cnt, N, cur.theta, cur.logpi, cur.delta, nxt.theta, nxt.logpi, nxt.delta,
                  eps_pop, R->eps_target, gamma0, gsig, 0, N, (uint32_t)it, &nsim);           /* mc:149 */
     pop_swap(&cur, &nxt);                                           /* mc:152-155 */
     nsims += nsim;

@@ -79,6 +79,10 @@ def lib():
     L.orc_randint.argtypes = [_u64, _u32]
     L.orc_math_eval.argtypes = [C.c_int, _vp, _vp, _vp, _i64]
     L.orc_particle_draws.argtypes = [_u64, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp]
+    L.orc_mc_better_by_rejection.argtypes = [_u64, _vp, _i64, _u32, _u32, _i64, _vp, _vp]
+    L.orc_mc_better_by_rejection.restype = None
+    L.orc_mc_draws_by_rejection.argtypes = [_i64, _i64]
+    L.orc_mc_draws_by_rejection.restype = C.c_int
     L.orc_rng_words.argtypes = [_u64, _u32, _u32, _u32, _u32, _vp]
     L.orc_normal_pairs.argtypes = [_u64, _u32, _i64, _vp]
     L.orc_push_p.argtypes = [_vp, _vp, _i64, _vp]

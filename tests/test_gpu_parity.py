@@ -382,6 +382,87 @@ def test_mc_rank_pass_with_a_stale_tail_bound_fails_loudly(oracle):
     assert hi >= lo and 0 <= ngt <= N and 0 <= nsim <= N and eps_pop >= eps_target
 
 
+def test_mc_rank_passes_stop_once_the_chain_draws_by_rejection(oracle):
+    """include/abcdez_spec.h, abz_mc_draws_by_rejection: once at most half of the particles lie above eps_target the better
+    particle of mc:23 is drawn by rejection.  The asynchronous path decides that on the device (the host is generations behind)
+    and stops launching rank passes when a redeemed generation has shown the switch: every generation equals the oracle's
+    (which counts for itself), and the number of rank passes is the number of by-rank generations plus at most the lag."""
+    N, gens, ahead = 4000, 45, 3
+    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    hip.init_population(); orc.init_population()
+    gamma0 = 2.38 / math.sqrt(2)
+    lo, hi = orc.extrema()
+    want, by_rank = [], 0
+    for gen in range(gens):
+        by_rank += 0 if orc.mc_draws_by_rejection(orc.count_gt(eps_target)) else 1
+        eps_pop = max(eps_target, lo)
+        nsim, ngt, lo, hi = orc.mc_generation(eps_pop, eps_target, hi, gamma0, 1e-5)
+        want.append((nsim, ngt, lo, hi, eps_pop))
+    assert 3 < by_rank < gens - 10 and hi > eps_target          # the run crosses the switch and does not converge
+    first = hip.extrema()
+    got = []
+    for gen in range(gens):
+        hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=True)
+        while hip.mc_generations_in_flight() > ahead:
+            got.append(hip.mc_generation_collect())
+    while hip.mc_generations_in_flight():
+        got.append(hip.mc_generation_collect())
+    assert got == want
+    assert_state_equal(hip, orc, "across the switch to rejection")
+    ranked, skipped = sum(hip.ops.mc_rank_stats()), hip.ops.mc_draw_stats()
+    assert ranked + skipped == gens
+    assert by_rank <= ranked <= by_rank + ahead + 1, (by_rank, ranked, skipped)
+
+
+def test_mc_rejection_draws_on_distances_written_behind_the_library_fail_loudly(oracle):
+    """A chain that has switched to rejection launches no rank pass any more.  Distances written behind the library's back
+    (a torch copy, without abcdez_smc_select_discard) can break the rule's premise -- candidate sets of a few particles.  A
+    particle that finds no better particle in 1024 trials proves it: the ticket's redemption raises; after a discard the
+    context counts again and works."""
+    N = 6000
+    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    hip.init_population()
+    gamma0 = 2.38 / math.sqrt(2)
+    first = hip.extrema()
+    for gen in range(60):
+        hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=True)
+        hip.mc_generation_collect()
+        if hip.ops.mc_draw_stats() >= 2:
+            break
+    skipped = hip.ops.mc_draw_stats()
+    assert skipped >= 2
+    d = hip.state[2]
+    d.copy_(10.0 + torch.arange(N, dtype=torch.float64, device=d.device))      # particle k has k + 1 candidates; nobody converged
+    hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, do_rank=True)
+    with pytest.raises(_lib.AbcdezError, match="ran out of trials"):
+        hip.mc_generation_collect()
+    hip.discard_select_ahead()
+    hip._mc_pending = []
+    ranked = sum(hip.ops.mc_rank_stats())
+    assert 2 * hip.count_gt(eps_target) > N                 # (the failed generation's sweep ran: most particles are still far out)
+    hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=hip.extrema(), do_rank=True)
+    nsim, ngt, lo, hi, eps_pop = hip.mc_generation_collect()
+    # counted anew: the chain draws by rank again
+    assert 0 < ngt <= N and eps_pop >= eps_target and hip.ops.mc_draw_stats() == skipped + 1 and sum(hip.ops.mc_rank_stats()) == ranked + 1
+
+
+def test_mc_swarm_by_rejection_where_the_rule_calls_for_ranks_is_an_error(oracle):
+    """abcdez_mc_swarm with order = cnt = NULL takes the caller's word that the generation draws by rejection; on a
+    population far from eps_target whose candidate sets hold a few particles only the trials run out and the call says so."""
+    N = 5000
+    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    hip.init_population()
+    d = hip.state[2]
+    d.copy_(10.0 + torch.arange(N, dtype=torch.float64, device=d.device))      # particle k has k + 1 candidates
+    hip.discard_select_ahead()
+    assert not hip.mc_draws_by_rejection(hip.count_gt(eps_target))
+    lo, hi = hip.extrema()
+    with pytest.raises(_lib.AbcdezError, match="ran out of trials"):
+        hip.mc_swarm(max(eps_target, lo), eps_target, 2.38 / math.sqrt(2), 1e-5, reject=True)
+    with pytest.raises(_lib.AbcdezError, match="both order and cnt"):
+        hip.ops.mc_swarm(hip.order, None, hip.state, hip.other, 1.0, eps_target, 0.5, 1e-5, 0, N, 0)
+
+
 def test_mc_generation_tickets_are_bounded_and_ordered(oracle):
     spec, hip, _, eps_target = engines("normal1d", 2000, oracle=oracle, storage="classic")
     hip.init_population()
@@ -439,20 +520,24 @@ def test_abcdesmc_reuses_the_select_enqueued_ahead():
 
 
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
-                                         ("quad2d_inf", 500, 80), ("normal1d", 60000, 70)])
+                                         ("quad2d_inf", 500, 80), ("normal1d", 60000, 70), ("normal1d", 7000, 60)])
 def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
-    """(N = 60000: the particles that draw go from 95 % of the population to below the 4096 one workgroup sorts in LDS while the run
-    is under way, so the rank pass is seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix
-    sort, on tails longer AND shorter than 4096, then only the LDS sort.)"""
+    """(N = 60000: the particles that draw go from 93 % of the population to below half of it while the run is under way, so
+    the rank pass is seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix sort, then
+    none at all: the better particles are drawn by rejection.  N = 7000: the bound falls below the 4096 pairs one workgroup
+    sorts in LDS before half of the population has arrived, so the LDS sort runs alone for a few generations.)"""
     prior, sim, eps = models()[name]
     r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=gens, verbose=False, rng=13)
     c = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=13), N, eps, gens)
     res = r.engine.result()
     assert r.nsims == c["nsims"] and r.reached_ϵ == c["reached_eps"]
     assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"])
+    both, small_only, long_only = r.engine.ops.mc_rank_stats()
+    skipped = r.engine.ops.mc_draw_stats()
     if N == 60000:
-        both, small_only, long_only = r.engine.ops.mc_rank_stats()
-        assert both >= 1 and small_only >= 1 and long_only >= 1, (both, small_only, long_only)
+        assert both >= 1 and long_only >= 1 and skipped >= 10, (both, small_only, long_only, skipped)
+    if N == 7000:
+        assert both >= 1 and small_only >= 1 and skipped >= 10, (both, small_only, long_only, skipped)
 
 
 def test_smoke_entry():

@@ -253,6 +253,78 @@ def test_mc_better_particle_enumeration_is_the_reference_mask(oracle, kind):
         assert set(order[:cnt].tolist()) == set(np.flatnonzero(d <= d[i]).tolist())
 
 
+@pytest.mark.parametrize("kind", ["continuous", "ties"])
+def test_mc_better_particle_by_rejection_is_uniform_over_the_reference_mask(oracle, kind):
+    """The second formulation of mc:23 (include/abcdez_spec.h, abz_mc_better_by_rejection): uniform j over ALL particles until
+    Ds[j] <= Ds[i].  Every draw must lie in the reference's mask (1:N)[Ds .<= Ds[i]] and be uniform over it (chi-square) --
+    also for a particle whose candidate set is small (more trials, same law), and it may be the particle itself."""
+    from scipy import stats
+
+    rng = np.random.default_rng(11)
+    N = 97
+    d = np.abs(rng.normal(3.0, 2.0, N)) if kind == "continuous" else rng.integers(0, 9, N).astype(np.float64)
+    L = oracle.lib()
+    by_rank = np.argsort(d, kind="stable")
+    n = 60000
+    for i in (int(by_rank[N - 1]), int(by_rank[N // 2]), int(by_rank[6])):
+        mask = np.flatnonzero(d <= d[i])
+        s = np.zeros(n, dtype=np.uint32)
+        found = np.zeros(n, dtype=np.uint8)
+        L.orc_mc_better_by_rejection(1234, d.ctypes.data, N, i, 0, n, s.ctypes.data, found.ctypes.data)
+        assert found.all()
+        assert np.isin(s, mask).all() and i in mask
+        counts = np.bincount(s, minlength=N)[mask]
+        assert counts.min() > 0
+        assert stats.chisquare(counts).pvalue > 1e-4, (kind, i, len(mask))
+    # a particle with NO better particle but itself (the minimum) keeps itself when the trials run out or finds itself
+    i0 = int(by_rank[0]) if kind == "continuous" else None
+    if i0 is not None:
+        s = np.zeros(50, dtype=np.uint32); found = np.zeros(50, dtype=np.uint8)
+        L.orc_mc_better_by_rejection(1234, d.ctypes.data, N, i0, 0, 50, s.ctypes.data, found.ctypes.data)
+        assert (s == i0).all()
+
+
+def test_mc_generations_switch_to_rejection_by_the_rule_and_only_once(oracle):
+    """The rule of include/abcdez_spec.h: a generation draws its better particles by rejection iff at most half of the
+    particles it reads lie above eps_target.  Driven through the product's host code on the oracle: every generation takes the
+    branch the rule names, rank passes stop for good at the switch, and the C driver (oracle/abcdez_oracle_driver.c), which
+    counts for itself, arrives at the same population bit for bit."""
+    import abcdez_amd.engine as E
+    from oracle.oracle import OracleOps
+
+    prior, sim = A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0)
+    N, G, eps = 3000, 40, 0.3
+    log = []
+
+    class Spy(OracleOps):
+        def mc_rank_prepare(self, delta, *a):
+            log.append(["rank", None])
+            return super().mc_rank_prepare(delta, *a)
+
+        def mc_swarm(self, order, cnt, cur, nxt, eps_pop, eps_target, *a):
+            n_above = int((cur[2] > eps_target).sum())
+            log.append(["sweep", (order is None, n_above)])
+            return super().mc_swarm(order, cnt, cur, nxt, eps_pop, eps_target, *a)
+
+    eng = lambda spec, n, pg, storage="classic": E.PopulationEngine(spec, n, pg, ops=Spy(spec), storage=storage)
+    r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=G, verbose=False, rng=5, engine=eng)
+    sweeps = [v for k, v in log if k == "sweep"]
+    assert len(sweeps) == G
+    L = oracle.lib()
+    for by_rejection, n_above in sweeps:
+        assert by_rejection == bool(L.orc_mc_draws_by_rejection(n_above, N)) == (2 * n_above <= N)
+    modes = [m for m, _ in sweeps]
+    assert modes[0] is False and modes[-1] is True and modes == sorted(modes)         # one switch, never back
+    above = [n for _, n in sweeps]
+    assert all(b <= a for a, b in zip(above, above[1:]))                                # the count the rule reads never grows
+    # no rank pass after the switch; one before every sweep until then
+    kinds = [k for k, _ in log]
+    first_rej = modes.index(True)
+    assert kinds.count("rank") == first_rej
+    c = oracle.run_abcdemc(ModelSpec(prior, sim, seed=5), N, eps, G)
+    assert np.array_equal(np.asarray(r.C), c["C"]) and r.nsims == c["nsims"]
+
+
 @pytest.mark.parametrize("name", ["mvn8", "normal1d", "uniform1d", "quad2d"])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
 def test_packed_restatement_equals_dense_driver(oracle, name, abck):
