@@ -71,6 +71,7 @@ PROTOTYPES = {
     "abcdez_mc_generation": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _i64, _f64, _f64, _u32,
                              _pi64, _pi64, _pf64, _pf64],
     "abcdez_mc_draw_stats": [_vp, _pi64],
+    "abcdez_mc_draws_by_rejection": [_i64, _i64],
     "abcdez_mc_generation_async": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _pf64, _i32, _f64, _f64,
                                    _u32, _pi64],
     "abcdez_mc_generation_wait": [_vp, _i64, _pi64, _pi64, _pf64, _pf64, _pf64],

@@ -388,9 +388,11 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
   ctx->cnt_prev[ABZ_C_MCSIM] = ts;
   ctx->cnt_prev[ABZ_C_MCGT] = tg;
-  /* at most half of the particles above eps_target after this generation: every later generation of the chain draws by
+  /* at least 1 / 16 of the particles at or below eps_target after this generation: every later generation of the chain draws by
    * rejection (abz_ctx.h, mc_reject_known) */
-  if (ctx->ring_chain[slot] == ctx->mc_chain && 2ll * ctx->ring_res[slot][1] <= (long long)ctx->mc_last_N) ctx->mc_reject_known = true;
+  if (ctx->ring_chain[slot] == ctx->mc_chain && ctx->ring_res[slot][1] >= 0 &&
+      abz_mc_draws_by_rejection((uint64_t)ctx->ring_res[slot][1], (uint64_t)ctx->mc_last_N))
+    ctx->mc_reject_known = true;
   if (snap[5] != ~0ull && ctx->ring_chain[slot] == ctx->mc_chain) {
     ctx->mc_tail_hint = (long long)snap[5];        /* the next rank pass sizes its long-tail launches from this */
     double eps_pop;
@@ -577,6 +579,12 @@ int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, in
   return 0;
 }
 
+/* the spec's rule (include/abcdez_spec.h): does a generation that reads n_above distances > eps_target among N draw its
+ * better particles by rejection?  1 / 0; -1 for arguments out of range.  Pure function: no context. */
+int abcdez_mc_draws_by_rejection(int64_t n_above, int64_t N) {
+  if (n_above < 0 || N < 1 || n_above > N) return -1;
+  return abz_mc_draws_by_rejection((uint64_t)n_above, (uint64_t)N);
+}
 int abcdez_mc_draw_stats(abcdez_ctx* ctx, int64_t* by_rejection_no_rank_pass) {
   ABZ_REQUIRE(ctx && by_rejection_no_rank_pass, "mc_draw_stats: null argument");
   *by_rejection_no_rank_pass = ctx->n_mc_reject_gens;
@@ -899,8 +907,8 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   if (rc) return rc;
   if (ctx->h_scal[ABZ_S_MC_REJFAIL] != 0ull) {
     ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_MC_REJFAIL, 0, 8, ctx->stream));
-    abz_set_error("mc_swarm: a particle drawing its better particle by rejection (order = NULL) ran out of trials: more than half "
-                  "of the particles lie above eps_target -- such a generation draws by rank (include/abcdez_spec.h)");
+    abz_set_error("mc_swarm: a particle drawing its better particle by rejection (order = NULL) ran out of trials: fewer than "
+                  "1 / 16 of the particles lie at or below eps_target -- such a generation draws by rank (include/abcdez_spec.h)");
     return -3;
   }
   *nsim = (int64_t)ctx->h_scal[ABZ_S_COUNT];
@@ -1090,7 +1098,7 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   ring_fold(ctx, ticket);
   ctx->mc_waited += 1;
   if (snap[6] == 2ull) {
-    /* the sweep drew its better particles by rejection and a particle found none in 1024 trials: with at least half of the
+    /* the sweep drew its better particles by rejection and a particle found none in 1024 trials: with at least 1 / 16 of the
      * population in every candidate set that does not happen -- the distances are not the ones the chain's count was made of */
     abz_population_written(ctx);
     abz_set_error("mc_generation_wait: a particle drawing its better particle by rejection ran out of trials: the distances were "

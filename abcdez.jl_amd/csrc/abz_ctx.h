@@ -140,7 +140,7 @@ struct abcdez_ctx {
   long long mc_tail_hint = -1;                    /* particles that drew in the last generation the host has seen; -1 = unknown */
   /* ABZ_S_MC_NABOVE describes the population of this chain (-1: count it before the next asynchronous generation) */
   long long mc_nabove_chain = -1;
-  /* a redeemed generation of the chain left at most half of the particles above eps_target: from then on every generation
+  /* a redeemed generation of the chain left at least 1 / 16 of the particles at or below eps_target: from then on every generation
    * of the chain draws by rejection (the count never grows, include/abcdez_spec.h) and no rank pass is launched */
   bool mc_reject_known = false;
   long long n_mc_reject_gens = 0;                 /* asynchronous generations issued without a rank pass for that reason */

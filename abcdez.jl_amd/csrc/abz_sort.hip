@@ -55,6 +55,12 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_count_kernel(const double* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x * MCR_WAVES + wave;
   if (tile >= ntiles) return;
+  /* launched for a generation that draws by rejection (the host had not seen the switch yet, abz_ctx.h mc_reject_known):
+   * nobody will read the enumeration -- an empty tail, and every later kernel of the pass returns at once */
+  if (win && abz_mc_draws_by_rejection(win[ABZ_S_MC_NABOVE - ABZ_S_MCW_EPS], (unsigned long long)n)) {
+    if (lane == 0) tile_cnt[tile] = 0u;
+    return;
+  }
   const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;
   uint32_t c = 0;
   for (uint32_t r0 = 0; r0 < rounds; r0 += MCR_BATCH) {          /* rounds is a multiple of MCR_BATCH */
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mcr_split_kernel(const double* __re
     for (int w = 0; w < MCR_WAVES; ++w) tot += own[w];
     state[MCR_ST_NTAIL] = tot; state[MCR_ST_NHEAD] = n - tot;
   }
+  if (win && abz_mc_draws_by_rejection(win[ABZ_S_MC_NABOVE - ABZ_S_MCW_EPS], (unsigned long long)n)) return;   /* mcr_count_kernel */
   const uint32_t tile = tile0 + (uint32_t)wave;
   if (tile >= ntiles) return;
   const uint64_t base = (uint64_t)tile * rounds * MCR_ROUND;

@@ -287,7 +287,7 @@ class HipOps:
         return nsim.value, ngt.value, lo.value, hi.value
 
     def mc_generation(self, cur, nxt, order, sorted_delta, cnt, eps_pop, eps_target, dmax, n_above, gamma0, gsig, sweep):
-        """rank pass (if dmax > eps_target and more than half of the particles lie above eps_target: n_above, or -1 = count
+        """rank pass (if dmax > eps_target and fewer than 1 / 16 of the particles lie at or below eps_target: n_above above it, or -1 = count
         them here) + sweep over all particles: one library call, one host sync"""
         nsim, ngt, lo, hi = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self.lib, self.lib.abcdez_mc_generation(
@@ -295,6 +295,12 @@ class HipOps:
             _ptr(order), _ptr(sorted_delta), _ptr(cnt), eps_pop, eps_target, dmax, n_above, gamma0, gsig, sweep, C.byref(nsim),
             C.byref(ngt), C.byref(lo), C.byref(hi)))
         return nsim.value, ngt.value, lo.value, hi.value
+
+    def mc_draws_by_rejection(self, n_above: int, N: int) -> bool:
+        r = self.lib.abcdez_mc_draws_by_rejection(n_above, N)
+        if r < 0:
+            raise ValueError("mc_draws_by_rejection: need 0 <= n_above <= N, N >= 1")
+        return bool(r)
 
     def mc_draw_stats(self) -> int:
         """asynchronous generations that needed no rank pass because they draw their better particles by rejection"""
@@ -841,8 +847,8 @@ class PopulationEngine:
 
     def mc_draws_by_rejection(self, n_above: int) -> bool:
         """the rule of include/abcdez_spec.h (abz_mc_draws_by_rejection): the better particle of mc:23 is drawn by rejection,
-        without a rank pass, once at most half of the particles lie above eps_target"""
-        return 2 * int(n_above) <= self.N
+        without a rank pass, once at least 1 / 16 of the particles lie at or below eps_target"""
+        return bool(self.ops.mc_draws_by_rejection(int(n_above), self.N))
 
     def mc_swarm(self, eps_pop: float, eps_target: float, gamma0: float, gsig: float, reject: bool = False):
         """one sweep of abcdemc_swarm! -> (nsim, #(Ds > eps_target), min Ds, max Ds) of the generation it leaves

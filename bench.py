@@ -501,7 +501,7 @@ def run_config(args):
     # on a population the partition has just moved and is a few per cent slower than its siblings) / the sweep of every 4th
     # abcdemc generation: an event pair costs ~9 us of queue time (tools/launch_floor.hip) -- 0.6 % of an SMC generation, 7 % of
     # an abcdemc generation
-    tstride = 2 if cfg["kind"] == "smc" else 4
+    tstride = 2 if cfg["kind"] == "smc" else 10
     eng.ops.set_timing(2 + 256 * tstride)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
@@ -621,7 +621,7 @@ def run_config(args):
                 "launched_incl_warmup": {"sweeps": gen.sweeps, "updates": gen.updates},     # what a profiler sees of the sweep kernel
                 "step_includes": ("extrema(Ds), eps-quantile, reweight, ESS, partition (one call), resample when ESS < N/2, "
                                   "<= Kmcmc sweeps with their counter read-backs (smc:301-364)") if cfg["kind"] == "smc" else
-                                 "rank pass (while max Ds > eps_target and more than half of the particles lie above it), one sweep with nsim / completion / extrema folded in (mc:140-161)",
+                                 "rank pass (while max Ds > eps_target and fewer than 1 / 16 of the particles lie at or below it), one sweep with nsim / completion / extrema folded in (mc:140-161)",
                 "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
@@ -634,7 +634,7 @@ def run_config(args):
                 rs = eng.ops.mc_rank_stats()
                 out["config"]["better_particle_draws"] = {
                     "generations_with_a_rank_pass": int(sum(rs)), "generations_by_rejection_without_one": int(eng.ops.mc_draw_stats()),
-                    "rule": "by rejection once at most half of the particles lie above eps_target (include/abcdez_spec.h)"}
+                    "rule": "by rejection once at least 1 / 16 of the particles lie at or below eps_target (include/abcdez_spec.h)"}
             gr = eng.ops.graph_stats()
             out["config"]["graph_replay"] = {"generations_replayed": gr[0], "graphs_captured": gr[1], "generations_stream_launched": gr[2],
                                              "what": "one abcdemc generation (rank pass + sweep + snapshot, <= 15 dependent launches) is captured "

@@ -199,8 +199,12 @@ ABCDEZ_API int abcdez_smc_select_stats(abcdez_ctx* ctx, int64_t* reused, int64_t
  * once a generation of a chain of asynchronous generations ran with eps_pop == eps_target, the particles that draw only become fewer. */
 ABCDEZ_API int abcdez_mc_rank_stats(abcdez_ctx* ctx, int64_t* both, int64_t* small_only, int64_t* long_only);
 /* ... and asynchronous generations issued with do_rank != 0 for which no rank pass was launched, because a redeemed generation
- * of the chain had left at most half of the particles above eps_target (they draw their better particles by rejection). */
+ * of the chain had left at least 1 / 16 of the particles at or below eps_target (they draw their better particles by rejection). */
 ABCDEZ_API int abcdez_mc_draw_stats(abcdez_ctx* ctx, int64_t* by_rejection_no_rank_pass);
+/* The rule itself (include/abcdez_spec.h, abz_mc_draws_by_rejection): 1 if a generation that reads n_above distances above
+ * eps_target among N particles draws by rejection, 0 if by rank, -1 for arguments out of range.  A host that drives
+ * abcdez_mc_rank_prepare / abcdez_mc_swarm itself (the sharded path) asks here. */
+ABCDEZ_API int abcdez_mc_draws_by_rejection(int64_t n_above, int64_t N);
 ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive,
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,
@@ -265,9 +269,9 @@ ABCDEZ_API int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, 
  *     any value gives the same result.  Asynchronous (no host synchronisation).
  *     By rank or by rejection: mc:23 is a uniform draw from {j : Ds[j] <= Ds[i]}; order = cnt = NULL makes mc_swarm draw it
  *     by rejection instead (uniform j over all particles until Ds[j] <= Ds[i]; include/abcdez_spec.h,
- *     abz_mc_better_by_rejection) -- no rank pass at all.  The spec's rule: a generation draws by rejection iff at most half
- *     of the particles it reads lie above eps_target (abz_mc_draws_by_rejection; then every candidate set holds at least
- *     N / 2 particles).  mc_swarm takes the caller's word for it (and returns an error if a particle runs out of trials,
+ *     abz_mc_better_by_rejection) -- no rank pass at all.  The spec's rule: a generation draws by rejection iff at least 1 / 16
+ *     of the particles it reads lie at or below eps_target (abz_mc_draws_by_rejection; then every candidate set holds at
+ *     least N / 16 particles).  mc_swarm takes the caller's word for it (and returns an error if a particle runs out of trials,
  *     which under the rule does not happen); abcdez_mc_generation and abcdez_mc_generation_async apply the rule themselves.
  *     mc_swarm also returns the reductions the driver takes of the generation it leaves behind, over the
  *     particles [i0, i0+n_local): n_above_target = sum(nDs .> eps_target) (mc:156), (dmin, dmax) = extrema(nDs)

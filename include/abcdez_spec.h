@@ -519,14 +519,20 @@ ABZ_HD void abz_donor_ranks(abz_u64x2 w, uint32_t n_alive, uint32_t ri, uint32_t
  *   by rejection  uniform j over ALL particles until Ds[j] <= Ds[i]: the first hit is uniform over the set.  No sort, but
  *                 N / |set| trials on average.
  * The rule (a function of the generation's input distances only, so that every implementation takes the same branch): a
- * generation draws by rejection iff at most half of its particles lie above eps_target.  Whoever draws has Ds[i] > eps_pop >=
- * eps_target, so its candidate set contains every particle at or below eps_target: then at least N / 2 candidates, at most two
- * trials on average -- and #(Ds > eps_target) never grows again (mc:54: a particle at or below eps_target accepts only dp <=
+ * generation draws by rejection iff at least 1 / ABZ_MC_REJECT_DIV = 1 / 16 of its particles lie at or below eps_target.  Whoever
+ * draws has Ds[i] > eps_pop >= eps_target, so its candidate set contains every particle at or below eps_target: then at least
+ * N / 16 candidates, at most 16 trials on average (measured on MI355X at N = 2^20: 16 trials of two random 8-byte reads cost
+ * half of what the rank pass costs, profiles/r04_mc1d_reject_div_ab.txt) -- and #(Ds > eps_target) never grows again (mc:54: a particle at or below eps_target accepts only dp <=
  * eps_target, the others only dp <= max(eps_pop, Ds[i])), so a run switches once.
  * Trial 2t is word 0, trial 2t + 1 word 1 of block t of the purpose ABZ_RNG_BETTER.  After 2 * ABZ_MC_REJECT_BLOCKS misses
- * (probability <= 2^-1024 under the rule) the particle keeps itself, which is a member of its own candidate set.          */
+ * (probability (15/16)^1024 < 1e-28 under the rule) the particle keeps itself, which is a member of its own candidate set.          */
 #define ABZ_MC_REJECT_BLOCKS 512u
-ABZ_HD int abz_mc_draws_by_rejection(uint64_t n_above_target, uint64_t n) { return 2u * n_above_target <= n; }
+#ifndef ABZ_MC_REJECT_DIV
+#define ABZ_MC_REJECT_DIV 16u          /* part of the spec: library and oracle must agree (a build flag for experiments only) */
+#endif
+ABZ_HD int abz_mc_draws_by_rejection(uint64_t n_above_target, uint64_t n) {
+  return n_above_target <= n && (uint64_t)ABZ_MC_REJECT_DIV * (n - n_above_target) >= n;
+}
 ABZ_HD uint32_t abz_mc_better_by_rejection(uint64_t seed, uint32_t i, uint32_t sweep, const double* delta, uint32_t n, double di,
                                            int* exhausted) {
   *exhausted = 0;

@@ -293,6 +293,9 @@ class OracleOps:
     def count_gt(self, delta, thr) -> int:
         return self.L.orc_count_gt(_p(delta), delta.numel(), thr)
 
+    def mc_draws_by_rejection(self, n_above: int, N: int) -> bool:
+        return bool(self.L.orc_mc_draws_by_rejection(n_above, N))
+
     def mc_rank_prepare(self, delta, eps_pop, dmax_hint, order, sorted_delta, cnt):
         self.L.orc_mc_rank_prepare(_p(delta), delta.numel(), eps_pop, _p(order), _p(sorted_delta), _p(cnt))
 

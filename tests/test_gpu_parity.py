@@ -18,6 +18,8 @@ def models():
     return {
         "normal1d": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.3),
         "uniform1d": (A.Uniform(-10.0, 10.0), A.Normal1D(3.0), 0.3),
+        # a small eps_target: fewer than 1 / 16 of the particles at or below it for many generations (abcdemc draws by rank)
+        "normal1d_tight": (A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0), 0.02),
         "mvn32": (n32, A.MVNormal(tuple([1.0] * 32)), 6.0),
         "mvn8": (A.Factored(*[A.Normal(0.0, 1.0) for _ in range(8)]), A.MVNormal(tuple([1.0] * 8)), 2.5),
         "mvn3": (A.Factored(A.Normal(0, 1), A.Uniform(-3, 3), A.Normal(1, 2)), A.MVNormal((0.5, 0.2, 1.0)), 0.8),
@@ -355,21 +357,25 @@ def test_mc_rank_pass_with_a_stale_tail_bound_fails_loudly(oracle):
     proved tail bound calls for.  Distances written behind the library's back (here: a torch copy, without
     abcdez_smc_select_discard) make the bound stale -- the LDS sort alone cannot take the new tail.  The device notices and the
     ticket's redemption raises instead of handing back a sweep that drew from a stale enumeration; after a discard the
-    context works again."""
-    N = 6000
-    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    context works again.  (A population of 4300 with 4090 particles above an eps_target nobody reaches: drawn by rank -- fewer
+    than 1 / 16 at or below it -- with a tail the LDS sort takes.)"""
+    N, n_in = 4300, 210
+    spec, hip, orc, _ = engines("normal1d", N, oracle=oracle, storage="classic")
+    eps_target = 1e-9
     hip.init_population()
+    d = hip.state[2]
+    d.copy_(5.0 + 1e-3 * torch.arange(N, dtype=torch.float64, device=d.device))
+    d[:n_in] = 1e-10
+    hip.discard_select_ahead()
+    assert not hip.mc_draws_by_rejection(hip.count_gt(eps_target))
     gamma0 = 2.38 / math.sqrt(2)
     first = hip.extrema()
-    conv = False
-    for gen in range(80):
-        hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=not conv)
+    for gen in range(4):
+        hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=first if gen == 0 else None, do_rank=True)
         out = hip.mc_generation_collect()
-        conv = conv or out[3] <= eps_target
-        if hip.ops.mc_rank_stats()[1] >= 2:        # two rank passes ran with only the LDS sort: the bound is <= 4096
-            break
-    assert hip.ops.mc_rank_stats()[1] >= 2 and not conv
-    hip.state[2].add_(10.0)                         # every particle is in the tail now: 6000 > 4096 pairs
+        assert out[1] == N - n_in and out[4] == eps_target       # nobody arrives; eps_pop == eps_target bounds the tail
+    assert hip.ops.mc_rank_stats()[1] >= 2                        # rank passes with only the LDS sort: the bound is 4090 <= 4096
+    hip.state[2].add_(10.0)                         # every particle is in the tail now: 4300 > 4096 pairs
     hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, do_rank=True)
     with pytest.raises(_lib.AbcdezError, match="tail bound that no longer held"):
         hip.mc_generation_collect()
@@ -383,12 +389,12 @@ def test_mc_rank_pass_with_a_stale_tail_bound_fails_loudly(oracle):
 
 
 def test_mc_rank_passes_stop_once_the_chain_draws_by_rejection(oracle):
-    """include/abcdez_spec.h, abz_mc_draws_by_rejection: once at most half of the particles lie above eps_target the better
-    particle of mc:23 is drawn by rejection.  The asynchronous path decides that on the device (the host is generations behind)
+    """include/abcdez_spec.h, abz_mc_draws_by_rejection: once at least 1 / 16 of the particles lie at or below eps_target the
+    better particle of mc:23 is drawn by rejection.  The asynchronous path decides that on the device (the host is generations behind)
     and stops launching rank passes when a redeemed generation has shown the switch: every generation equals the oracle's
     (which counts for itself), and the number of rank passes is the number of by-rank generations plus at most the lag."""
-    N, gens, ahead = 4000, 45, 3
-    spec, hip, orc, eps_target = engines("normal1d", N, oracle=oracle, storage="classic")
+    N, gens, ahead = 4000, 60, 3
+    spec, hip, orc, eps_target = engines("normal1d_tight", N, oracle=oracle, storage="classic")
     hip.init_population(); orc.init_population()
     gamma0 = 2.38 / math.sqrt(2)
     lo, hi = orc.extrema()
@@ -439,7 +445,7 @@ def test_mc_rejection_draws_on_distances_written_behind_the_library_fail_loudly(
     hip.discard_select_ahead()
     hip._mc_pending = []
     ranked = sum(hip.ops.mc_rank_stats())
-    assert 2 * hip.count_gt(eps_target) > N                 # (the failed generation's sweep ran: most particles are still far out)
+    assert not hip.mc_draws_by_rejection(hip.count_gt(eps_target))   # (the failed generation's sweep ran: nearly all particles are still far out)
     hip.mc_generation_issue(0.0, eps_target, gamma0, 1e-5, lo_hi=hip.extrema(), do_rank=True)
     nsim, ngt, lo, hi, eps_pop = hip.mc_generation_collect()
     # counted anew: the chain draws by rank again
@@ -520,12 +526,13 @@ def test_abcdesmc_reuses_the_select_enqueued_ahead():
 
 
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
-                                         ("quad2d_inf", 500, 80), ("normal1d", 60000, 70), ("normal1d", 7000, 60)])
+                                         ("quad2d_inf", 500, 80), ("normal1d", 60000, 70), ("normal1d_tight", 60000, 60),
+                                         ("normal1d_tight", 3000, 60)])
 def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
-    """(N = 60000: the particles that draw go from 93 % of the population to below half of it while the run is under way, so
-    the rank pass is seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix sort, then
-    none at all: the better particles are drawn by rejection.  N = 7000: the bound falls below the 4096 pairs one workgroup
-    sorts in LDS before half of the population has arrived, so the LDS sort runs alone for a few generations.)"""
+    """(normal1d_tight: fewer than 1 / 16 of the particles at or below eps_target for the first generations, so the rank pass is
+    seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix sort (N = 60000) or only the
+    LDS sort (N = 3000 <= 4096), then none at all: the better particles are drawn by rejection.  normal1d at eps 0.3 starts
+    with 7 % of its particles there and draws by rejection from the first generation on.)"""
     prior, sim, eps = models()[name]
     r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=gens, verbose=False, rng=13)
     c = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=13), N, eps, gens)
@@ -534,10 +541,12 @@ def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
     assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"])
     both, small_only, long_only = r.engine.ops.mc_rank_stats()
     skipped = r.engine.ops.mc_draw_stats()
-    if N == 60000:
-        assert both >= 1 and long_only >= 1 and skipped >= 10, (both, small_only, long_only, skipped)
-    if N == 7000:
-        assert both >= 1 and small_only >= 1 and skipped >= 10, (both, small_only, long_only, skipped)
+    if name == "normal1d_tight" and N == 60000:
+        assert both >= 1 and long_only >= 3 and skipped >= 10, (both, small_only, long_only, skipped)
+    if name == "normal1d_tight" and N == 3000:
+        assert both >= 1 and small_only >= 3 and skipped >= 10, (both, small_only, long_only, skipped)
+    if name == "normal1d":
+        assert skipped >= gens - 10, (both, small_only, long_only, skipped)
 
 
 def test_smoke_entry():

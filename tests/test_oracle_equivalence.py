@@ -285,15 +285,15 @@ def test_mc_better_particle_by_rejection_is_uniform_over_the_reference_mask(orac
 
 
 def test_mc_generations_switch_to_rejection_by_the_rule_and_only_once(oracle):
-    """The rule of include/abcdez_spec.h: a generation draws its better particles by rejection iff at most half of the
-    particles it reads lie above eps_target.  Driven through the product's host code on the oracle: every generation takes the
+    """The rule of include/abcdez_spec.h: a generation draws its better particles by rejection iff at least 1 / 16 of the
+    particles it reads lie at or below eps_target.  Driven through the product's host code on the oracle: every generation takes the
     branch the rule names, rank passes stop for good at the switch, and the C driver (oracle/abcdez_oracle_driver.c), which
     counts for itself, arrives at the same population bit for bit."""
     import abcdez_amd.engine as E
     from oracle.oracle import OracleOps
 
     prior, sim = A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0)
-    N, G, eps = 3000, 40, 0.3
+    N, G, eps = 3000, 60, 0.02
     log = []
 
     class Spy(OracleOps):
@@ -312,7 +312,7 @@ def test_mc_generations_switch_to_rejection_by_the_rule_and_only_once(oracle):
     assert len(sweeps) == G
     L = oracle.lib()
     for by_rejection, n_above in sweeps:
-        assert by_rejection == bool(L.orc_mc_draws_by_rejection(n_above, N)) == (2 * n_above <= N)
+        assert by_rejection == bool(L.orc_mc_draws_by_rejection(n_above, N)) == (16 * (N - n_above) >= N)
     modes = [m for m, _ in sweeps]
     assert modes[0] is False and modes[-1] is True and modes == sorted(modes)         # one switch, never back
     above = [n for _, n in sweeps]
