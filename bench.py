@@ -283,7 +283,7 @@ def cpu_baseline(A, args, cfg):
         dt = time.perf_counter() - t0
         return None, {"value": g.updates / dt, "unit": "particle-updates/s", "cores": cores, "kind": "port",
                       "sample": f"the first {steps} generations of the same abcdemc run at {n} particles "
-                                f"(oracle/abcdez_oracle.c: qsort rank pass + OpenMP sweep, {dt:.1f} s)"}
+                                f"(oracle/abcdez_oracle.c: OpenMP sweep; qsort rank pass in the generations that draw by rank, {dt:.1f} s)"}
     eng.reset_weights()
     g = make_loop(cfg, eng)
     g.step()                                  # untimed warm-up generation
@@ -342,7 +342,7 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         "kernel_updates_per_s": rate,
         "launches_are": ("abcdesmc: ONE sweep of every 2nd timed generation between its own pair of HIP events on the library's stream -- the "
                          "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 2; a pair costs ~9 us of queue "
-                         "time); abcdemc: the sweep of every 4th generation.  A bracketed launch starts on a drained queue, so this average "
+                         "time); abcdemc: the sweep of every 10th generation.  A bracketed launch starts on a drained queue, so this average "
                          "is a few per cent ABOVE the un-instrumented kernel: frac_trace"),
         "total_bytes_frac": to_gbs(b_read + b_write) / HBM_PEAK_GBS,
         "total_bytes_note": f"SURVEY.md 8d total-bytes variant: {b_read + b_write} B per update, charging every update a full "

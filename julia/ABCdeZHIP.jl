@@ -381,6 +381,8 @@ function count_gt(e, thr)                                                       
 end
 rank_prepare!(e, ϵ_pop, ϵ_h) = check(ccall((:abcdez_mc_rank_prepare, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                                            e.ctx, e.delta[e.cur], e.N, ϵ_pop, ϵ_h, e.order, e.sorted, e.cnt))    # mc:23
+# (the synchronous pair: better particles of mc:23 BY RANK; C_NULL for order and cnt draws them by rejection instead -- the library's
+#  asynchronous generations below choose between the two themselves, include/abcdez_spec.h abz_mc_draws_by_rejection)
 function mc_swarm!(e, ϵ_pop, ϵ_target, γ0, γσ)                                                            # mc:5-61 + :140-143; also mc:156, :146
     nsim = Ref(Int64(0)); above = Ref(Int64(0)); lo = Ref(0.0); hi = Ref(0.0); o = other(e); bind_stamps!(e)
     check(ccall((:abcdez_mc_swarm, LIB), Cint,
