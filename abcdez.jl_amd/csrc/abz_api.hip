@@ -874,7 +874,10 @@ int abcdez_extrema(abcdez_ctx* ctx, const double* delta, int64_t N, double* lo, 
 int abcdez_count_gt(abcdez_ctx* ctx, const double* delta, int64_t N, double thr, int64_t* count) {
   ABZ_REQUIRE(ctx && delta && count, "count_gt: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "count_gt: N out of range");
-  return abz_count_gt_impl(ctx, delta, N, thr, count);
+  const int rc = abz_count_gt_impl(ctx, delta, N, thr, count);
+  if (rc == 0) { ctx->mc_count_seen.delta = delta; ctx->mc_count_seen.N = N; ctx->mc_count_seen.thr = thr;
+                 ctx->mc_count_seen.count = *count; ctx->mc_count_seen.chain = ctx->mc_chain; }     /* valid until something writes distances */
+  return rc;
 }
 
 int abcdez_mc_rank_prepare(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_pop, double dmax_hint,
@@ -974,7 +977,12 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   /* a new chain: host-given extrema (the first generation of a run), other parameters, another population than the one the
    * generation before wrote (its outputs are this generation's inputs) */
   if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N) {
-    ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1; ctx->mc_reject_known = false;
+    /* the driver counted these very distances against this eps_target (mc:133) and nothing has written them since: the
+     * chain's first count is known here too, and with it whether its generations need rank passes at all */
+    const auto& seen = ctx->mc_count_seen;
+    const bool counted = seen.count >= 0 && seen.delta == (const void*)delta && seen.N == N && seen.thr == eps_target && seen.chain == ctx->mc_chain;
+    ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1;
+    ctx->mc_reject_known = counted && abz_mc_draws_by_rejection((uint64_t)seen.count, (uint64_t)N) != 0;
   }
   /* how the chain's generations draw their better particles is decided on the device from #(Ds > eps_target): counted once
    * here, carried from sweep to sweep by the snapshot kernel afterwards */

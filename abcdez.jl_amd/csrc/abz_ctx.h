@@ -144,6 +144,9 @@ struct abcdez_ctx {
    * of the chain draws by rejection (the count never grows, include/abcdez_spec.h) and no rank pass is launched */
   bool mc_reject_known = false;
   long long n_mc_reject_gens = 0;                 /* asynchronous generations issued without a rank pass for that reason */
+  /* the last abcdez_count_gt (the driver's mc:133, right before its loop): if the next chain starts from these very distances
+   * with thr as its eps_target, the host side knows the chain's first count without waiting for a generation to be redeemed */
+  struct { const void* delta = nullptr; int64_t N = 0; double thr = 0.0; int64_t count = -1; long long chain = -1; } mc_count_seen;
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
 };

@@ -136,9 +136,9 @@ class McGeneration:
     def __init__(self, eng, d, eps_target):
         self.e, self.eps_target = eng, eps_target
         self.gamma0 = 2.38 / math.sqrt(2 * d)
+        self.complete = 1 - eng.count_gt(eps_target) / eng.N                               # mc:133, as the driver (abcdez_amd/mc.py)
         self.lo, self.hi = eng.extrema()                                                   # mc:146 (first generation)
         self.updates = self.sweeps = self.nsims = self.generations = self.ranked = 0
-        self.complete = 0.0
         self.first, self.converged = True, False
 
     AHEAD = 4      # abcdemc!'s loop has no data-dependent exit: the host may issue generations ahead of their results
