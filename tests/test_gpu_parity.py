@@ -532,7 +532,7 @@ def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
     """(normal1d_tight: fewer than 1 / 16 of the particles at or below eps_target for the first generations, so the rank pass is
     seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix sort (N = 60000) or only the
     LDS sort (N = 3000 <= 4096), then none at all: the better particles are drawn by rejection.  normal1d at eps 0.3 starts
-    with 7 % of its particles there and draws by rejection from the first generation on.)"""
+    with 5 % of its particles there, 7 % after one generation: by rejection from the second generation on.)"""
     prior, sim, eps = models()[name]
     r = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=gens, verbose=False, rng=13)
     c = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=13), N, eps, gens)
