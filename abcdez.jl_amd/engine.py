@@ -969,6 +969,12 @@ class PopulationEngine:
         if mine is not None and theirs is not None and list(theirs)[1:] != mine[1:]:
             raise ValueError(f"checkpoint was written by a build with Philox4x32-{list(theirs)[1]}, this library runs "
                              f"Philox4x32-{mine[1]}: the run would not continue its own stream")
+        if mine is not None and theirs is not None and mine[0] != 0 and list(theirs)[0] not in (0, mine[0]):
+            import warnings
+
+            warnings.warn(f"checkpoint was written by library version {list(theirs)[0]}, this is {mine[0]}: a version step may change "
+                          "which random numbers a generation consumes (401: abcdemc's better particle by rejection) -- the run "
+                          "continues, but not necessarily bit for bit", stacklevel=2)
         if mine is not None and theirs is None:
             import warnings
             warnings.warn("checkpoint carries no stream_version (written before round 4): it resumes bit for bit only if it "
