@@ -42,6 +42,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/abcdez_spec.h"
 
@@ -91,11 +94,23 @@ ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_
   abz_u64x2 w; w.w0 = w0; w.w1 = w1;
   abz_donor_ranks(w, n_alive, ri, ra, rb);
 }
+/* threads of a loop over n particles: a team of 256 costs ~1 ms per parallel region whatever it does -- the small populations of
+ * the parity tests (thousands of generations of a few thousand particles) spent minutes there on the GPU box's 256 cores */
+static int orc_threads(int64_t n) {
+#ifdef _OPENMP
+  const int t = omp_get_max_threads();
+  const int64_t want = n / 512 + 1;
+  return want < (int64_t)t ? (int)want : t;
+#else
+  (void)n;
+  return 1;
+#endif
+}
 /* the per-particle scalar draws of one sweep, straightforward evaluation (checker of abcdez_draws_eval):
  * donors smc:119-126, gamma smc:128, log(rand) smc:145; alive rank of particle i = i in a pool of n_pool */
 ORC_API void orc_particle_draws(uint64_t seed, int64_t i0, int64_t n, int64_t n_pool, uint32_t sweep, double gamma0,
                                 double gsig, uint32_t* ra, uint32_t* rb, double* g, double* log_u) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(n))
   for (int64_t k = 0; k < n; ++k) {
     const uint32_t i = (uint32_t)(i0 + k);
     abz_donor_ranks(abz_rng(seed, i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)n_pool, i, &ra[k], &rb[k]);
@@ -311,7 +326,7 @@ ORC_API void orc_set_stamps(uint64_t* cur, uint64_t* nxt) { g_stamp_cur = cur; g
 
 ORC_API void orc_blob_eval(const abz_model* M, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
                            int nbw, double* delta_out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(N))
   for (int64_t s = 0; s < N; ++s) {
     double p[ABZ_MAX_D], b[ABZ_MAX_BLOB];
     for (int q = 0; q < ABZ_MAX_BLOB; ++q) b[q] = 0.0;
@@ -345,7 +360,7 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
 /* fills rows [i0, i0+n) of the FULL arrays theta / logpi / delta */
 ORC_API int orc_init(const abz_model* M, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
   int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad)
+#pragma omp parallel for schedule(static) reduction(| : bad) num_threads(orc_threads(n))
   for (int64_t g = i0; g < i0 + n; ++g) {
     uint32_t i = (uint32_t)g;
     double* th = theta + g * M->ld;
@@ -388,7 +403,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
                            int64_t* nacc_out, int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(n_local))
   for (int64_t i = i0; i < i0 + n_local; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
@@ -451,7 +466,7 @@ ORC_API void ref_smc_swarm(const abz_model* M, const uint8_t* alive, int64_t N,
   int64_t n_alive = 0;
   for (int64_t i = 0; i < N; ++i) n_alive += alive[i];
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nacc, nsim)
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nacc, nsim) num_threads(orc_threads(N))
   for (int64_t i = 0; i < N; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
@@ -518,7 +533,7 @@ ORC_API double orc_tree_sum(const double* x, int64_t n) {
   if (n <= ABZ_TILE) return tile_sum(x, n);
   int64_t nt = (n + ABZ_TILE - 1) / ABZ_TILE;
   double* part = (double*)malloc((size_t)nt * sizeof(double));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(nt * 2048))
   for (int64_t t = 0; t < nt; ++t) {
     int64_t lo = t * ABZ_TILE, len = n - lo < ABZ_TILE ? n - lo : ABZ_TILE;
     part[t] = tile_sum(x + lo, len);
@@ -536,7 +551,7 @@ ORC_API void orc_smc_reweight(int abck, const double* delta, double* wns, uint8_
                               double eps_old, double eps_new,
                               double* wnorm_out, double* ess_out, int64_t* n_alive_out) {
   double* wprod = (double*)malloc((size_t)N * sizeof(double));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(N))
   for (int64_t i = 0; i < N; ++i) {
     double w = 0.0;
     if (alive[i]) w = abz_exp(abz_kernel_logpdf(abck, eps_new, delta[i]) - abz_kernel_logpdf(abck, eps_old, delta[i]));
@@ -544,7 +559,7 @@ ORC_API void orc_smc_reweight(int abck, const double* delta, double* wns, uint8_
   }
   double wnorm = orc_tree_sum(wprod, N);
   int64_t na = 0;
-#pragma omp parallel for schedule(static) reduction(+ : na)
+#pragma omp parallel for schedule(static) reduction(+ : na) num_threads(orc_threads(N))
   for (int64_t i = 0; i < N; ++i) {
     double W = wprod[i] / wnorm;
     wns[i] = W;
@@ -568,7 +583,7 @@ ORC_API void orc_smc_reweight(int abck, const double* delta, double* wns, uint8_
 ORC_API void orc_smc_reweight_uniform(int abck, const double* delta, double* wns, uint8_t* alive, int64_t N, double eps_new,
                                       double* wnorm_out, double* ess_out, int64_t* n_alive_out) {
   int64_t n_old = 0, n_new = 0;
-#pragma omp parallel for schedule(static) reduction(+ : n_old, n_new)
+#pragma omp parallel for schedule(static) reduction(+ : n_old, n_new) num_threads(orc_threads(N))
   for (int64_t i = 0; i < N; ++i) {
     const int was = alive[i] != 0;
     const int is = was && abz_kernel_insupport(abck, eps_new, delta[i]);
@@ -576,7 +591,7 @@ ORC_API void orc_smc_reweight_uniform(int abck, const double* delta, double* wns
     n_old += was; n_new += is;
   }
   const double sumsq = 1.0 / (double)n_new;             /* = the weight of a survivor = sum(Wns.^2) in exact arithmetic */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(N))
   for (int64_t i = 0; i < N; ++i) wns[i] = alive[i] ? sumsq : 0.0;
   *wnorm_out = (double)n_new / (double)n_old;
   *ess_out = 1.0 / sumsq;
@@ -655,7 +670,7 @@ ORC_API void orc_smc_resample_gather(const abz_model* M, const uint32_t* inds, i
                                      const double* theta, const double* logpi, const double* delta,
                                      double* ntheta, double* nlogpi, double* ndelta, double* wns, uint8_t* alive) {
   const int ld = M->ld;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(n_local))
   for (int64_t s = i0; s < i0 + n_local; ++s) {
     int64_t j = inds[s];
     memcpy(ntheta + s * ld, theta + j * ld, (size_t)ld * sizeof(double));  /* smc:96 */
@@ -769,7 +784,7 @@ ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
   uint8_t* acc_tmp = (uint8_t*)calloc((size_t)(r_hi - r_lo) + 1, 1);
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(r_hi - r_lo))
   for (int64_t r = r_lo; r < r_hi; ++r) {
     const uint32_t i = (uint32_t)r;
     double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
@@ -817,7 +832,7 @@ ORC_API void orc_smc_replay_packed(const abz_model* M, const uint32_t* bits, uin
                                    int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim)
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(n_alive))
   for (int64_t r = 0; r < n_alive; ++r) {
     nacc += flags[r] & 1;
     nsim += (flags[r] >> 1) & 1;
@@ -855,7 +870,7 @@ ORC_API void orc_smc_resample_gather_packed(const abz_model* M, const uint32_t* 
   /* double-buffered rows: every destination is the slot the alive prefix is NOT in (parity of position 0), whatever a
    * dead position's stale bit says; afterwards all N positions have that parity */
   const uint32_t newp = (bits[0] & 1u) ^ 1u;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_threads(N))
   for (int64_t s = 0; s < N; ++s) {
     const int64_t j = inds[s];
     const uint32_t dst = ORC_DBUF(ld) ? newp : (ORC_PBIT(bits, s) ^ 1u);
@@ -960,7 +975,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint3
                           int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nsim)
+#pragma omp parallel for schedule(static) reduction(+ : nsim) num_threads(orc_threads(n_local))
   for (int64_t i = i0; i < i0 + n_local; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
