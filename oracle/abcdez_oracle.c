@@ -96,6 +96,13 @@ ORC_API void orc_donor_ranks(uint64_t w0, uint64_t w1, uint32_t n_alive, uint32_
 }
 /* threads of a loop over n particles: a team of 256 costs ~1 ms per parallel region whatever it does -- the small populations of
  * the parity tests (thousands of generations of a few thousand particles) spent minutes there on the GPU box's 256 cores */
+static int orc_threads(int64_t n);
+/* ... of a loop that runs the simulator once per element: weighted by what one call costs (an ODE integration is thousands of
+ * times a 1-D normal draw) */
+static int orc_threads_sim(const abz_model* M, int64_t n) {
+  const int64_t w = M->sim_id == ABZ_SIM_LV || M->sim_id == ABZ_SIM_WIENER ? 4096 : M->ld > 4 ? M->ld / 4 : 1;
+  return orc_threads(n > (INT64_MAX >> 13) ? n : n * w);
+}
 static int orc_threads(int64_t n) {
 #ifdef _OPENMP
   const int t = omp_get_max_threads();
@@ -326,7 +333,7 @@ ORC_API void orc_set_stamps(uint64_t* cur, uint64_t* nxt) { g_stamp_cur = cur; g
 
 ORC_API void orc_blob_eval(const abz_model* M, const double* theta, const uint64_t* stamp, int64_t N, double* blob,
                            int nbw, double* delta_out) {
-#pragma omp parallel for schedule(static) num_threads(orc_threads(N))
+#pragma omp parallel for schedule(static) num_threads(orc_threads_sim(M, N))
   for (int64_t s = 0; s < N; ++s) {
     double p[ABZ_MAX_D], b[ABZ_MAX_BLOB];
     for (int q = 0; q < ABZ_MAX_BLOB; ++q) b[q] = 0.0;
@@ -360,7 +367,7 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
 /* fills rows [i0, i0+n) of the FULL arrays theta / logpi / delta */
 ORC_API int orc_init(const abz_model* M, double* theta, double* logpi, double* delta, int64_t i0, int64_t n) {
   int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad) num_threads(orc_threads(n))
+#pragma omp parallel for schedule(static) reduction(| : bad) num_threads(orc_threads_sim(M, n))
   for (int64_t g = i0; g < i0 + n; ++g) {
     uint32_t i = (uint32_t)g;
     double* th = theta + g * M->ld;
@@ -403,7 +410,7 @@ ORC_API void orc_smc_swarm(const abz_model* M, const uint32_t* alive_idx, const 
                            int64_t* nacc_out, int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(n_local))
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads_sim(M, n_local))
   for (int64_t i = i0; i < i0 + n_local; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
@@ -466,7 +473,7 @@ ORC_API void ref_smc_swarm(const abz_model* M, const uint8_t* alive, int64_t N,
   int64_t n_alive = 0;
   for (int64_t i = 0; i < N; ++i) n_alive += alive[i];
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nacc, nsim) num_threads(orc_threads(N))
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nacc, nsim) num_threads(orc_threads_sim(M, N))
   for (int64_t i = 0; i < N; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
@@ -784,7 +791,7 @@ ORC_API void orc_smc_swarm_packed(const abz_model* M, const uint32_t* bits, uint
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
   uint8_t* acc_tmp = (uint8_t*)calloc((size_t)(r_hi - r_lo) + 1, 1);
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(r_hi - r_lo))
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads_sim(M, r_hi - r_lo))
   for (int64_t r = r_lo; r < r_hi; ++r) {
     const uint32_t i = (uint32_t)r;
     double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
@@ -832,7 +839,7 @@ ORC_API void orc_smc_replay_packed(const abz_model* M, const uint32_t* bits, uin
                                    int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nacc = 0, nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads(n_alive))
+#pragma omp parallel for schedule(static) reduction(+ : nacc, nsim) num_threads(orc_threads_sim(M, n_alive))
   for (int64_t r = 0; r < n_alive; ++r) {
     nacc += flags[r] & 1;
     nsim += (flags[r] >> 1) & 1;
@@ -975,7 +982,7 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint3
                           int64_t i0, int64_t n_local, uint32_t sweep, int64_t* nsim_out) {
   const int ld = M->ld;
   int64_t nsim = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nsim) num_threads(orc_threads(n_local))
+#pragma omp parallel for schedule(static) reduction(+ : nsim) num_threads(orc_threads_sim(M, n_local))
   for (int64_t i = i0; i < i0 + n_local; ++i) {
     const double* ti = theta + i * ld;
     double* to = ntheta + i * ld;
