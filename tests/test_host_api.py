@@ -260,6 +260,24 @@ def test_roctx_ranges_cost_nothing_unless_asked_for(monkeypatch):
     monkeypatch.setattr(_trace, "_ENABLED", None)
 
 
+def test_the_rule_between_rank_and_rejection_draws_is_one_function_everywhere(oracle):
+    """include/abcdez_spec.h, abz_mc_draws_by_rejection: library (a pure function of the C ABI: callable without a GPU), oracle
+    and the closed statement `16 (N - n_above) >= N` agree at and around the boundary for small and large populations."""
+    lib = _lib.load()
+    L = oracle.lib()
+    for N in (5, 6, 15, 16, 17, 100, 3000, 4096, 65537, 1 << 20, (1 << 31) - 1):
+        k = -(-N // 16)                                    # ceil(N / 16): the smallest number at or below eps_target that qualifies
+        for n_above in {0, 1, N - k - 1, N - k, N - k + 1, N - 1, N} - {-1}:
+            if not 0 <= n_above <= N:
+                continue
+            want = 16 * (N - n_above) >= N
+            assert bool(lib.abcdez_mc_draws_by_rejection(n_above, N)) == want == bool(L.orc_mc_draws_by_rejection(n_above, N)), (N, n_above)
+        assert lib.abcdez_mc_draws_by_rejection(N, N) == 0           # nobody at or below eps_target: by rank
+        assert lib.abcdez_mc_draws_by_rejection(N - k, N) == 1 and lib.abcdez_mc_draws_by_rejection(N - k + 1, N) == 0
+    assert lib.abcdez_mc_draws_by_rejection(-1, 10) == -1 and lib.abcdez_mc_draws_by_rejection(11, 10) == -1
+    assert lib.abcdez_mc_draws_by_rejection(0, 0) == -1
+
+
 def test_header_cites_the_reference_for_every_entry_point():
     text = open(os.path.join(ROOT, "include", "abcdez_hip.h")).read()
     for ref in ("src/abcdez_init.jl:2-22", "src/abcdez_smc.jl:106-153", "src/abcdez_smc.jl:59-83",
