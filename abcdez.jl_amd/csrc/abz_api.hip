@@ -151,6 +151,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   abcdez_ctx* ctx = new abcdez_ctx();
   ctx->device = device;
   if (const char* g = getenv("ABZ_GRAPHS")) ctx->graphs_on = !(g[0] == '0' && g[1] == 0) && g[0] != 0;
+  if (const char* g = getenv("ABZ_SERPENTINE")) ctx->serpentine = !(g[0] == '0' && g[1] == 0);
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
   /* every dimension of the row a continuous Normal (d == ld, no padding): the sweeps run the two-instruction log-density
@@ -369,12 +370,15 @@ static inline double f64_from_order_key_host(unsigned long long k) {
 static int timing_consume(abcdez_ctx* ctx, long long n, long long done) {
   for (long long k = 0; k < n && ctx->ev_head < ctx->ev_tail; ++k, ++ctx->ev_head) {
     const int slot = (int)(ctx->ev_head % ABZ_GROUP_MAX);
-    if (done >= 0 && ctx->ev_sweep[slot] >= done) continue;
+    if (done >= 0 && !ctx->ev_group[slot] && ctx->ev_sweep[slot] >= done) continue;
     float ms = 0.f;
     ABZ_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2 * slot], ctx->ev[2 * slot + 1]));
+    /* a pair around a whole group of sweeps (mode 3) stands for the `done` launches that did work, each of ev_units updates; the
+     * one-block checks between them are inside the pair, so milliseconds / launches is an UPPER bound of the sweep's duration */
+    const long long nl = ctx->ev_group[slot] ? (done > 0 ? done : ctx->ev_group[slot]) : 1;
     ctx->swarm_ms += (double)ms;
-    ctx->swarm_launches += 1;
-    ctx->swarm_units += ctx->ev_units[slot];
+    ctx->swarm_launches += nl;
+    ctx->swarm_units += ctx->ev_units[slot] * nl;
   }
   return 0;
 }
@@ -423,8 +427,9 @@ int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
   if (on && !ctx->ev[0])
     for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreate(&e));
   const int mode = on & 0xFF, stride = on >> 8;
-  ABZ_REQUIRE(mode <= 2 && stride >= 0, "set_timing: on = mode (0, 1, 2) + 256 * stride");
+  ABZ_REQUIRE(mode <= 3 && stride >= 0, "set_timing: on = mode (0, 1, 2, 3) + 256 * stride");
   ctx->timing = mode != 0;
+  ctx->timing_group = mode == 3;       /* 3: one pair around ALL the sweeps of a grouped call (the launches run back to back inside it) */
   ctx->timing_first_only = mode == 2;  /* 2: of a group of sweeps only one is bracketed (an event pair costs ~9 us of queue time) */
   ctx->timing_stride = stride > 1 ? stride : 1; ctx->timing_seq = 0; ctx->timing_rot = 0;
   ctx->swarm_ms = 0.0; ctx->swarm_launches = 0; ctx->swarm_units = 0; ctx->ev_head = ctx->ev_tail;
@@ -621,11 +626,14 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
   /* timing mode 2: ONE sweep of the group carries the event pair, and which one rotates from call to call -- the first sweep of a
    * generation runs on a population the partition has just moved and is a few per cent slower than its siblings */
   const int timed_k = ctx->timing_first_only ? (int)(ctx->timing_rot++ % k_max) : -1;
+  /* timing mode 3: one event pair around the whole group -- sweeps 2 .. k_max start behind their predecessor like every
+   * un-instrumented launch does, instead of on the queue a pair of their own has just drained */
+  const int group_tk = ctx->timing_group ? abz_time_begin(ctx) : -1;
   for (int k = 0; k < k_max; ++k) {
     uint32_t* in = (k & 1) ? bits_b : bits_a;
     uint32_t* out = (k & 1) ? bits_a : bits_b;
     const bool timing = ctx->timing;
-    if (ctx->timing_first_only && k != timed_k) ctx->timing = false;
+    if ((ctx->timing_first_only && k != timed_k) || ctx->timing_group) ctx->timing = false;
     ctx->cur_sweep_k = k;
     int rc = abz_launch_smc_swarm_packed(ctx, in, out, (uint32_t)n_alive, 0u, (uint32_t)n_alive, slot0, slot1, logpi, delta,
                                          nullptr, eps, gamma0, gamma_sigma, sweep0 + (uint32_t)k, 1,
@@ -637,6 +645,10 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
       rc = abz_launch_group_check(ctx, k, base_acc, (uint32_t)n_alive, kmcmc_min, ABZ_C_NACC);
       if (rc) return rc;
     }
+  }
+  if (group_tk >= 0) {
+    abz_time_end(ctx, group_tk, (long long)n_alive);
+    ctx->ev_group[group_tk] = k_max;
   }
   unsigned long long pub = 0;
   if (int rc = abz_publish_launch(ctx, ABZ_S_N, &pub)) return rc;

@@ -100,6 +100,8 @@ struct abcdez_ctx {
   uint64_t* stamp_nxt = nullptr;
   /* optional HIP-event timing of the sweep kernel (bench.py's roofline figure) */
   bool timing = false, timing_first_only = false;
+  bool timing_group = false;                      /* mode 3: ONE pair around all the sweeps of an abcdez_smc_sweeps_packed call */
+  int ev_group[ABZ_GROUP_MAX] = {0};              /* the pair brackets a whole group: counts `done` launches of ev_units updates each */
   int timing_stride = 1;                          /* of the launches that would be bracketed only every timing_stride-th is */
   long long timing_seq = 0, timing_rot = 0;
   bool ring_timed[ABZ_MC_RING] = {false};         /* was the sweep of that asynchronous generation bracketed */
@@ -149,6 +151,10 @@ struct abcdez_ctx {
   struct { const void* delta = nullptr; int64_t N = 0; double thr = 0.0; int64_t count = -1; long long chain = -1; } mc_count_seen;
   double swarm_ms = 0.0;
   long long swarm_launches = 0, swarm_units = 0;
+  /* serpentine sweeps: every other launch of the packed sweep walks the prefix from its end (abz_kernels.h, SmcPackedArgs.rev);
+   * ABZ_SERPENTINE=0 in the environment keeps every launch front to back (same results; A/B measurements) */
+  bool serpentine = true;
+  long long sweep_launch_seq = 0;
 };
 
 void abz_set_error(const std::string& msg);
@@ -257,6 +263,7 @@ static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
   if (k < 0) return;
   (void)hipEventRecord(ctx->ev[2 * k + 1], ctx->stream);
   ctx->ev_units[k] = units;
+  ctx->ev_group[k] = 0;
   ctx->ev_sweep[k] = ctx->cur_sweep_k;
   ctx->ev_tail += 1;
 }

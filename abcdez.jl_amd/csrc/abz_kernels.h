@@ -111,6 +111,7 @@ struct SmcPackedArgs {
   const unsigned long long* stop;   /* group of sweeps: non-zero = the early exit of smc:352 held before this sweep; NULL = always run */
   double eps, gamma0, gsig;
   uint32_t n_alive, r_lo, n_work, sweep, c_cls;
+  uint32_t rev;                 /* non-zero: workgroup b owns tile gridDim.x - 1 - b (serpentine order, abz_smc_swarm.hip) */
 };
 
 __device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
@@ -122,7 +123,11 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
-  const uint32_t gid = blockIdx.x * ABZ_BLOCK + threadIdx.x;
+  /* Which tile a workgroup owns changes no result (everything is keyed by position).  Workgroups are dispatched in index
+   * order, so rev walks the prefix from its end: the rows the sweep before read LAST are the ones this sweep reads FIRST, while
+   * they still sit in the 256 MiB Infinity Cache (launcher: abz_launch_smc_swarm_packed). */
+  const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const uint32_t gid = tile * ABZ_BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
   const int j = (int)(gid % L);
   const bool active = grp < a.n_work;
@@ -204,7 +209,7 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
   if (active && j == 0 && a.flags) a.flags[ri] = (uint8_t)((acc ? 1 : 0) | (insupport ? 2 : 0));
   block_count2((j == 0 && acc) ? 1u : 0u, (active && j == 0 && insupport) ? 1u : 0u, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
   if (threadIdx.x < PB / 32) {
-    const uint32_t w = (a.r_lo + blockIdx.x * PB) / 32u + threadIdx.x;
+    const uint32_t w = (a.r_lo + tile * PB) / 32u + threadIdx.x;
     if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
   }
 }

@@ -44,6 +44,7 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   a.eps = eps; a.gamma0 = gamma0; a.gsig = gsig;
   a.n_alive = n_alive; a.r_lo = r_lo; a.n_work = r_hi - r_lo; a.sweep = sweep;
   if (a.n_work == 0) return 0;
+  a.rev = ctx->serpentine ? (uint32_t)(ctx->sweep_launch_seq++ & 1) : 0u;
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
   const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);

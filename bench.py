@@ -82,6 +82,9 @@ def parse():
                         "than ranks: the ranks share the visible GPUs, collectives go through the host")
     p.add_argument("--default-stream", action="store_true", help="diagnostic: run on the legacy default stream (no graph replay)")
     p.add_argument("--graphs", action="store_true", help="diagnostic: replay abcdemc generations as HIP graphs (off by default: measured slower)")
+    p.add_argument("--timing-mode", type=int, default=3, choices=[2, 3],
+                   help="abcdesmc kernel timing (abcdez_ctx_set_timing): 3 = one HIP-event pair around ALL the sweeps of every 2nd timed "
+                        "generation (default); 2 = a pair of its own around ONE sweep of every 2nd generation (rounds 2-4)")
     p.add_argument("--force-collectives", action="store_true",
                    help="diagnostic: run the sharded code path (RCCL flag all-gather + replay) in a group of one rank")
     return p.parse_args()
@@ -340,10 +343,8 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
                    "/ average launch time / 8 TB/s",
         "bytes_read_per_update": b_read, "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches,
         "kernel_updates_per_s": rate,
-        "launches_are": ("abcdesmc: ONE sweep of every 2nd timed generation between its own pair of HIP events on the library's stream -- the "
-                         "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 2; a pair costs ~9 us of queue "
-                         "time); abcdemc: the sweep of every 10th generation.  A bracketed launch starts on a drained queue, so this average "
-                         "is a few per cent ABOVE the un-instrumented kernel: frac_trace"),
+        "launches_are": (LAUNCHES_ARE[TIMING_MODE] if kind != "mc" else
+                         "abcdemc: the sweep of every 10th generation between its own pair of HIP events on the library's stream"),
         "total_bytes_frac": to_gbs(b_read + b_write) / HBM_PEAK_GBS,
         "total_bytes_note": f"SURVEY.md 8d total-bytes variant: {b_read + b_write} B per update, charging every update a full "
                             "row write (the double-buffered reference layout)",
@@ -394,6 +395,17 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
 
 
 PATTERN_LIVE = True
+TIMING_MODE = 3
+LAUNCHES_ARE = {
+    3: ("abcdesmc: ONE pair of HIP events on the library's stream around ALL the sweep launches of every 2nd timed generation "
+        "(abcdez_ctx_set_timing mode 3, stride 2): avg_launch_ms = elapsed / sweeps that ran.  The one-block group_check launches "
+        "between the sweeps (~5 us each) are INSIDE the pair, so this is an upper bound of the sweep kernel's duration; the sweeps "
+        "run back to back as they do un-instrumented (frac_trace: the rocprofv3 average of every sweep of the timed steps)"),
+    2: ("abcdesmc: ONE sweep of every 2nd timed generation between its own pair of HIP events on the library's stream -- the "
+        "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 2; a pair costs ~9 us of queue "
+        "time).  A bracketed launch starts on a drained queue, so this average is a few per cent ABOVE the un-instrumented "
+        "kernel: frac_trace"),
+}
 
 
 def pattern_ceiling_live(prefix, accepted_percent, positions):
@@ -433,8 +445,9 @@ args_config = "smc32"
 
 def run_config(args):
     """one configuration: engine, warm-up, timed window, roofline, whole run, CPU baseline -> (result dict on rank 0 else None, pg)"""
-    global args_config, PATTERN_LIVE
+    global args_config, PATTERN_LIVE, TIMING_MODE
     args_config = args.config
+    TIMING_MODE = args.timing_mode
     PATTERN_LIVE = not args.no_pattern and args.gpus == 1
     import torch
     import torch.distributed as dist
@@ -502,7 +515,7 @@ def run_config(args):
     # abcdemc generation: an event pair costs ~9 us of queue time (tools/launch_floor.hip) -- 0.6 % of an SMC generation, 7 % of
     # an abcdemc generation
     tstride = 2 if cfg["kind"] == "smc" else 10
-    eng.ops.set_timing(2 + 256 * tstride)
+    eng.ops.set_timing((args.timing_mode if cfg["kind"] == "smc" and not eng.sharded_packed else 2) + 256 * tstride)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     barrier()
     t0 = time.perf_counter()

@@ -87,7 +87,10 @@ ABCDEZ_API int abcdez_ctx_get_layout(abcdez_ctx* ctx, int32_t* ld, int32_t* lane
 ABCDEZ_API int abcdez_sync(abcdez_ctx* ctx);
 /* HIP-event timing of the sweep kernel on the context's stream (measurement only): accumulated kernel milliseconds,
  * launches and particle-updates since set_timing(on).  on = mode + 256 * stride.  mode 1: every sweep launch is bracketed by an
- * event pair; mode 2: of the sweeps of one abcdez_smc_sweeps_packed call only one, the 1st, 2nd, 3rd ... in turn.  stride > 1: of the launches the mode
+ * event pair; mode 2: of the sweeps of one abcdez_smc_sweeps_packed call only one, the 1st, 2nd, 3rd ... in turn;
+ * mode 3: ONE pair around all the sweeps of an abcdez_smc_sweeps_packed call -- it counts as the k_done launches that did work and its
+ * milliseconds include the one-block checks between them (an upper bound of the sweeps' duration; the launches run back to back as they
+ * do un-instrumented, where a pair of its own makes a launch start on a drained queue).  stride > 1: of the launches the mode
  * selects only every stride-th -- a pair costs ~9 us of queue time (tools/launch_floor.hip), 7 % of an abcdemc generation. */
 ABCDEZ_API int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on);
 ABCDEZ_API int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, int64_t* units);

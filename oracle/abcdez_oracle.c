@@ -975,6 +975,98 @@ static int64_t upper_bound_d(const double* v, int64_t n, double x) { /* #element
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v[mid] <= x) lo = mid + 1; else hi = mid; }
   return lo;
 }
+/* The three index draws of one proposal (mc:18-32), spec tier: better particle s by rank (order != NULL) or by rejection
+ * (order == NULL; include/abcdez_spec.h says when), donors (a, b) by rank-skip.  orc_mc_swarm calls this; the tests call it
+ * directly to compare its law with ref_mc_draws. */
+ORC_API void orc_mc_draws(const abz_model* M, const uint32_t* order, const uint32_t* cnt_of, int64_t N, const double* delta,
+                          double eps_pop, double eps_target, int64_t i, uint32_t sweep, uint32_t* s_out, uint32_t* a_out,
+                          uint32_t* b_out, int* exhausted_out) {
+  const double di = delta[i];
+  const double eps = di <= eps_target ? eps_target : eps_pop;           /* mc:19 */
+  uint32_t s = (uint32_t)i;
+  int exhausted = 0;
+  if (di > eps) {                                                       /* mc:20-24 */
+    /* mc:23; order == NULL: by rejection (include/abcdez_spec.h, abz_mc_draws_by_rejection says when) */
+    s = order ? order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_of[i])]
+              : abz_mc_better_by_rejection(M->seed, (uint32_t)i, sweep, delta, (uint32_t)N, di, &exhausted);
+  }
+  abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)N, s, a_out, b_out);   /* mc:25-32: uniform over all N */
+  *s_out = s;
+  if (exhausted_out) *exhausted_out = exhausted;
+}
+
+/* ---------------------------------------------------------------- S4, LITERAL tier: abcdemc_swarm! statement by statement (mc:5-61)
+ * What the spec tier replaces is kept here as the reference writes it:
+ *   mc:23     s = rand(rng, (1:nparticles)[Ds .<= Ds[i]]) -- the mask is materialised in INDEX order (an O(N) scan per
+ *             drawing particle) and one uniform picks its k-th member;
+ *   mc:25-32  a = s; while a == s: a = rand(rng, 1:N)   /   b = a; while b == a || b == s: b = rand(rng, 1:N) -- two
+ *             rejection loops, one fresh uniform integer per trial;
+ *   mc:41     logpdf summed left to right (priors.jl:40-46);
+ *   mc:43     log(rand(rng)) > min(0, w_prior) && continue -- the uniform is drawn for EVERY particle, libm log;
+ *   mc:54     dp <= max(eps, Ds[i]).
+ * It consumes the counter-based stream differently from the spec tier (one Philox block per trial, sub-index = trial
+ * number), so the two agree IN LAW only: tests/test_oracle_equivalence.py compares the joint law of (s, a, b) and the
+ * moved populations, for the spec's draw by rank and by rejection.  Test infrastructure / "reference-faithful" baseline. */
+ORC_API void ref_mc_draws(const abz_model* M, int64_t N, const double* delta, double eps_pop, double eps_target, int64_t i,
+                          uint32_t sweep, uint32_t* s_out, uint32_t* a_out, uint32_t* b_out, uint32_t* trials_out) {
+  uint32_t att = 0;
+  uint32_t s = (uint32_t)i;                                             /* mc:18 */
+  const double eps = delta[i] <= eps_target ? eps_target : eps_pop;     /* mc:19 */
+  if (delta[i] > eps) {                                                 /* mc:20 */
+    int64_t cnt = 0;                                                    /* mc:23: (1:N)[Ds .<= Ds[i]] */
+    for (int64_t j = 0; j < N; ++j) cnt += delta[j] <= delta[i];
+    const uint32_t pick = abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, (uint32_t)cnt);
+    int64_t seen = 0;
+    for (int64_t j = 0; j < N; ++j)
+      if (delta[j] <= delta[i]) { if (seen == (int64_t)pick) { s = (uint32_t)j; break; } ++seen; }
+  }
+  uint32_t a = s;                                                       /* mc:25 */
+  while (a == s) a = abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, att++, ABZ_RNG_DONOR).w0, (uint32_t)N);   /* mc:26-28 */
+  uint32_t b = a;                                                       /* mc:29 */
+  while (b == a || b == s) b = abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, att++, ABZ_RNG_DONOR).w0, (uint32_t)N);   /* mc:30-32 */
+  *s_out = s; *a_out = a; *b_out = b;
+  if (trials_out) *trials_out = att;
+}
+ORC_API void ref_mc_swarm(const abz_model* M, int64_t N, const double* theta, const double* logpi, const double* delta,
+                          double* ntheta, double* nlogpi, double* ndelta, double eps_pop, double eps_target, double gamma0,
+                          double gsig, uint32_t sweep, int64_t* nsim_out) {
+  const int ld = M->ld;
+  int64_t nsim = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : nsim) num_threads(orc_threads_sim(M, N))
+  for (int64_t i = 0; i < N; ++i) {
+    const double* ti = theta + i * ld;
+    double* to = ntheta + i * ld;
+    for (int k = 0; k < ld; ++k) to[k] = ti[k];                         /* nthetas = identity.(thetas) ..., mc:140-143 */
+    nlogpi[i] = logpi[i];
+    ndelta[i] = delta[i];
+    uint32_t s, a, b;
+    ref_mc_draws(M, N, delta, eps_pop, eps_target, i, sweep, &s, &a, &b, NULL);     /* mc:18-32 */
+    const double eps = delta[i] <= eps_target ? eps_target : eps_pop;  /* mc:19 */
+    const double* ts = theta + (int64_t)s * ld;
+    const double* ta = theta + (int64_t)a * ld;
+    const double* tb = theta + (int64_t)b * ld;
+    double z0, z1;
+    abz_normal_pair(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_JITTER), ORC_T, &z0, &z1);
+    const double g = gamma0 * (1.0 + z0 * gsig);                        /* mc:34 */
+    double tp[ABZ_MAX_D], pp[ABZ_MAX_D];
+    for (int k = 0; k < ld; ++k) tp[k] = ts[k] + (ta[k] - tb[k]) * g;   /* op(+, thetas[s], op(*, op(-, thetas[a], thetas[b]), gamma)) */
+    push_row(M, tp, pp);
+    const double lp = logprior_seq(M, pp);                              /* mc:41 */
+    const double w_prior = lp - logpi[i];                               /* mc:42 */
+    const double u = abz_u01_open(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_ACCEPT).w0);
+    const double mn = w_prior < 0.0 ? w_prior : 0.0;                    /* Julia's min(0, w_prior); NaN propagates ... */
+    if (!abz_isnan(w_prior) && log(u) > mn) continue;                   /* mc:43 (... and `x > NaN` is false: no continue) */
+    nsim += 1;                                                          /* mc:44 */
+    const double dp = sim_dist(M, pp, (uint32_t)i, sweep, ABZ_RNG_SIM); /* mc:45 */
+    if (dp <= (eps > delta[i] ? eps : delta[i])) {                      /* mc:54 */
+      ndelta[i] = dp;                                                   /* mc:55-57 */
+      for (int k = 0; k < ld; ++k) to[k] = tp[k];
+      nlogpi[i] = lp;
+    }
+  }
+  *nsim_out = nsim;
+}
+
 ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint32_t* cnt_of, int64_t N,
                           const double* theta, const double* logpi, const double* delta,
                           double* ntheta, double* nlogpi, double* ndelta,
@@ -992,15 +1084,8 @@ ORC_API void orc_mc_swarm(const abz_model* M, const uint32_t* order, const uint3
     if (g_stamp_nxt) g_stamp_nxt[i] = g_stamp_cur[i];
     double di = delta[i];
     double eps = di <= eps_target ? eps_target : eps_pop;               /* mc:19 */
-    uint32_t s = (uint32_t)i;
-    int exhausted = 0;
-    if (di > eps) {                                                     /* mc:20-24 */
-      /* mc:23; order == NULL: by rejection (include/abcdez_spec.h, abz_mc_draws_by_rejection says when) */
-      s = order ? order[abz_randint(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_of[i])]
-                : abz_mc_better_by_rejection(M->seed, (uint32_t)i, sweep, delta, (uint32_t)N, di, &exhausted);
-    }
-    uint32_t a, b;                                                      /* mc:25-32: uniform over all N */
-    abz_donor_ranks(abz_rng(M->seed, (uint32_t)i, sweep, 0, ABZ_RNG_DONOR), (uint32_t)N, s, &a, &b);
+    uint32_t s, a, b;                                                   /* mc:18-32 */
+    orc_mc_draws(M, order, cnt_of, N, delta, eps_pop, eps_target, i, sweep, &s, &a, &b, NULL);
     const double* ts = theta + (int64_t)s * ld;
     const double* ta = theta + (int64_t)a * ld;
     const double* tb = theta + (int64_t)b * ld;

@@ -127,6 +127,9 @@ def lib():
     L.orc_mc_rank_prepare.argtypes = [_vp, _i64, _f64, _vp, _vp, _vp]
     L.orc_mc_swarm.argtypes = [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i64, _i64,
                                _u32, _pi64]
+    L.orc_mc_draws.argtypes = [_vp, _vp, _vp, _i64, _vp, _f64, _f64, _i64, _u32, _vp, _vp, _vp, _vp]
+    L.ref_mc_draws.argtypes = [_vp, _i64, _vp, _f64, _f64, _i64, _u32, _vp, _vp, _vp, _vp]
+    L.ref_mc_swarm.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _u32, _pi64]
     L.orc_abcdesmc.argtypes = [_vp, C.POINTER(SmcRun)] + [_vp] * 13
     L.orc_abcdemc.argtypes = [_vp, C.POINTER(McRun), _vp, _vp, _vp]
     _LIB = L

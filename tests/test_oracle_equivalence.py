@@ -284,6 +284,108 @@ def test_mc_better_particle_by_rejection_is_uniform_over_the_reference_mask(orac
         assert (s == i0).all()
 
 
+@pytest.mark.parametrize("draw", ["by_rank", "by_rejection"])
+@pytest.mark.parametrize("kind", ["continuous", "ties"])
+def test_mc_index_draws_spec_equals_literal_in_law(oracle, kind, draw):
+    """abcdemc_swarm!'s three index draws (src/abcdez_mc.jl:18-32) -- the better particle s = rand(rng, (1:N)[Ds .<= Ds[i]])
+    (:23) and the donors from the two rejection loops around rand(rng, 1:N) (:25-32: a != s; b != a, b != s) -- as the LITERAL
+    tier restates them (ref_mc_draws: mask scanned in index order, one fresh integer per trial) against the SPEC tier
+    (orc_mc_draws: s by rank or by rejection, donors by rank-skip from one Philox block).  The joint law of (s, a, b) is
+    known in closed form -- s uniform over the mask, (a, b) uniform over the ordered pairs of distinct particles other than
+    s -- so both tiers are tested against it cell by cell (chi-square) and against each other (two-sample)."""
+    from scipy import stats
+
+    rng = np.random.default_rng(21)
+    N = 7
+    d = np.abs(rng.normal(3.0, 2.0, N)) if kind == "continuous" else np.array([2.0, 0.0, 2.0, 1.0, 3.0, 1.0, 2.0])
+    eps_target, eps_pop = 0.3, max(0.3, float(d.min()))
+    spec = ModelSpec(A.Normal(0.0, 1.0), A.Normal1D(0.0), seed=77)
+    L, m = oracle.lib(), oracle.OracleModel(spec)
+    order, sd, cnt_of = np.zeros(N, dtype=np.uint32), np.zeros(N), np.zeros(N, dtype=np.uint32)
+    L.orc_mc_rank_prepare(d.ctypes.data, N, eps_pop, order.ctypes.data, sd.ctypes.data, cnt_of.ctypes.data)
+    by_rank = np.argsort(d, kind="stable")
+    n = 40000
+    u32 = lambda: C.c_uint32()
+    for i in (int(by_rank[N - 1]), int(by_rank[N // 2]), int(by_rank[0])):      # largest mask, a middle one, a particle that keeps itself
+        mask = np.flatnonzero(d <= d[i]) if d[i] > (eps_target if d[i] <= eps_target else eps_pop) else np.array([i])
+        cells = {}
+        for s_ in mask:
+            for a_ in range(N):
+                for b_ in range(N):
+                    if a_ != s_ and b_ != a_ and b_ != s_:
+                        cells[(int(s_), a_, b_)] = len(cells)
+        tallies = []
+        for tier in ("spec", "literal"):
+            t = np.zeros(len(cells), dtype=np.int64)
+            trials = 0
+            for sweep in range(n):
+                s_, a_, b_, x = u32(), u32(), u32(), u32()
+                if tier == "spec":
+                    ex = C.c_int()
+                    L.orc_mc_draws(m.ptr, order.ctypes.data if draw == "by_rank" else None, cnt_of.ctypes.data if draw == "by_rank" else None,
+                                   N, d.ctypes.data, eps_pop, eps_target, i, sweep, C.byref(s_), C.byref(a_), C.byref(b_), C.byref(ex))
+                    assert ex.value == 0
+                else:
+                    L.ref_mc_draws(m.ptr, N, d.ctypes.data, eps_pop, eps_target, i, sweep, C.byref(s_), C.byref(a_), C.byref(b_), C.byref(x))
+                    trials += x.value
+                t[cells[(s_.value, a_.value, b_.value)]] += 1          # KeyError = a draw outside the reference's support
+            assert t.min() > 0
+            assert stats.chisquare(t).pvalue > 1e-4, (tier, draw, kind, i)
+            tallies.append(t)
+            if tier == "literal":         # the loops of mc:26-32 need 1 / (1 - 1/N) + 1 / (1 - 2/N) trials on average
+                assert abs(trials / n - (N / (N - 1) + N / (N - 2))) < 0.03
+        assert stats.chi2_contingency(np.stack(tallies))[1] > 1e-4, (draw, kind, i)
+
+
+@pytest.mark.parametrize("generation", [2, 12])
+def test_mc_sweep_spec_equals_literal_in_law(oracle, generation):
+    """abcdemc_swarm! as a whole (src/abcdez_mc.jl:5-61): the spec tier through BOTH formulations of mc:23's draw (by rank /
+    by rejection) against the literal tier (ref_mc_swarm: index-order mask, rejection loops for a and b, left-to-right
+    log-prior, libm log of an unconditionally drawn uniform, mc:43) on the same population mid-run -- generation 2: nearly
+    every particle still draws a better particle; generation 12: about half have arrived.  Same fraction simulated (mc:43-44),
+    same fraction moved (mc:54), same moments of the moved population, converged particles never leave eps_target (mc:19,52)."""
+    prior, sim = A.Normal(0.0, math.sqrt(10.0)), A.Normal1D(3.0)
+    N, eps_target = 40000, 0.3
+    spec = ModelSpec(prior, sim, seed=13)
+    eng = oracle.oracle_engine(spec, N, storage="classic")
+    eng.init_population()
+    g0 = 2.38 / math.sqrt(2.0)
+    lo, hi = eng.extrema()
+    for _ in range(generation):
+        nsim, ngt, lo, hi = eng.mc_generation(max(eps_target, lo), eps_target, hi, g0, 1e-5)
+    th, lp, dl = (t.numpy().copy() for t in eng.state)
+    eps_pop = max(eps_target, float(dl.min()))
+    L, m = oracle.lib(), oracle.OracleModel(spec)
+    order, sd, cnt_of = np.zeros(N, dtype=np.uint32), np.zeros(N), np.zeros(N, dtype=np.uint32)
+    L.orc_mc_rank_prepare(dl.ctypes.data, N, eps_pop, order.ctypes.data, sd.ctypes.data, cnt_of.ctypes.data)
+    arrived = dl <= eps_target
+    out = {}
+    for tier in ("by_rank", "by_rejection", "literal"):
+        nth, nlp, ndl = np.zeros_like(th), np.zeros_like(lp), np.zeros_like(dl)
+        nsim = C.c_int64()
+        if tier == "literal":
+            L.ref_mc_swarm(m.ptr, N, th.ctypes.data, lp.ctypes.data, dl.ctypes.data, nth.ctypes.data, nlp.ctypes.data,
+                           ndl.ctypes.data, eps_pop, eps_target, g0, 1e-5, 1000, C.byref(nsim))
+        else:
+            r = tier == "by_rank"
+            L.orc_mc_swarm(m.ptr, order.ctypes.data if r else None, cnt_of.ctypes.data if r else None, N, th.ctypes.data,
+                           lp.ctypes.data, dl.ctypes.data, nth.ctypes.data, nlp.ctypes.data, ndl.ctypes.data, eps_pop,
+                           eps_target, g0, 1e-5, 0, N, 1000, C.byref(nsim))
+        moved = ndl != dl
+        assert (ndl[arrived] <= eps_target).all()                         # mc:19,54: max(eps_target, Ds[i]) = eps_target
+        assert (ndl <= np.maximum(dl, eps_pop)).all()                     # mc:54
+        assert np.array_equal(nth[~moved], th[~moved]) and np.array_equal(nlp[~moved], lp[~moved])
+        out[tier] = (nsim.value / N, moved.mean(), moved[arrived].mean(), moved[~arrived].mean(), nth.mean(), nth.std(),
+                     ndl.mean(), float((ndl > eps_target).mean()))
+    # binomial / sampling tolerances at N = 40000: 5 sigma of a proportion is < 0.0125, of a mean of thetas (sd ~ 1.5) 0.04
+    for tier in ("by_rank", "by_rejection"):
+        a, b = out[tier], out["literal"]
+        assert abs(a[0] - b[0]) < 0.0125 and abs(a[1] - b[1]) < 0.0125, (tier, a, b)
+        assert abs(a[2] - b[2]) < 0.02 and abs(a[3] - b[3]) < 0.02, (tier, a, b)
+        assert abs(a[4] - b[4]) < 0.05 and abs(a[5] - b[5]) < 0.05 and abs(a[6] - b[6]) < 0.05, (tier, a, b)
+        assert abs(a[7] - b[7]) < 0.0125, (tier, a, b)
+
+
 def test_mc_generations_switch_to_rejection_by_the_rule_and_only_once(oracle):
     """The rule of include/abcdez_spec.h: a generation draws its better particles by rejection iff at least 1 / 16 of the
     particles it reads lie at or below eps_target.  Driven through the product's host code on the oracle: every generation takes the
