@@ -77,7 +77,11 @@ static inline void abz_population_written(abcdez_ctx* ctx) {
 
 extern "C" {
 
-int abcdez_version(void) { return 401; }       /* 400: Philox4x32-10 again, abz_model.mv, group abort; 401: abcdemc's better particle by rejection */
+/* 400: Philox4x32-10 again, abz_model.mv, group abort; 401: abcdemc's better particle by rejection;
+ * 500: abcdez_comm_* and abcdez_smc_sweeps_sharded (RCCL behind the ABI), timing mode 3.  Hosts refuse a library older than the
+ * header they were written against (abcdez.jl_amd/_lib.py, julia/ABCdeZHIP.jl check_abi): a signature that grew an argument links
+ * against an old binary without a diagnostic. */
+int abcdez_version(void) { return 500; }
 int abcdez_rng_rounds(void) { return ABZ_PHILOX_ROUNDS; }
 
 /* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
@@ -230,6 +234,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)abcdez_comm_destroy(ctx);
   for (abz_mc_graph& g : ctx->mc_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   ctx->mc_graphs.clear();
   abz_jit_destroy(ctx);
@@ -278,7 +283,13 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
 
 int abcdez_ctx_set_stream(abcdez_ctx* ctx, void* hip_stream) {
   ABZ_REQUIRE(ctx, "set_stream: null context");
-  if (ctx->stream != (hipStream_t)hip_stream) ctx->ahead = abz_ahead{};      /* a select enqueued ahead sits on the old stream */
+  if (ctx->stream != (hipStream_t)hip_stream) {
+    ctx->ahead = abz_ahead{};      /* a select enqueued ahead sits on the old stream */
+    /* asynchronous abcdemc generations take their ring slot, ticket and RNG epoch from a counter on the device: work of the same
+     * chain on two streams could run two snapshots at once.  Let the old stream finish what it holds and end the chain. */
+    if (ctx->mc_issued > ctx->mc_waited) ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    abz_mc_chain_break(ctx);
+  }
   ctx->stream = (hipStream_t)hip_stream;
   return 0;
 }
@@ -349,6 +360,7 @@ int abcdez_dev_free(void* ptr) {
 }
 int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
   ABZ_REQUIRE(ctx && dst && src, "memcpy_h2d: null argument");
+  abz_population_written(ctx);         /* the host writes device memory of its own choice -- possibly distances or flags */
   ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -995,7 +1007,12 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
     const bool counted = seen.count >= 0 && seen.delta == (const void*)delta && seen.N == N && seen.thr == eps_target && seen.chain == ctx->mc_chain;
     ctx->mc_chain += 1; ctx->mc_tail_bound = -1; ctx->mc_tail_hint = -1;
     ctx->mc_reject_known = counted && abz_mc_draws_by_rejection((uint64_t)seen.count, (uint64_t)N) != 0;
+    ctx->mc_count_seen.count = -1;     /* used once: a count describes the distances at the time it was taken */
   }
+  /* this generation writes ndelta: a count taken of that buffer earlier (generations ping-pong between two buffers without
+   * ending their chain) no longer describes it.  (A stale count could only over-state #(Ds > eps_target), which never grows,
+   * mc:54 -- it would cost a rank pass, not correctness; dropping it keeps the cache honest anyway.) */
+  if (ctx->mc_count_seen.delta == (const void*)ndelta) ctx->mc_count_seen.count = -1;
   /* how the chain's generations draw their better particles is decided on the device from #(Ds > eps_target): counted once
    * here, carried from sweep to sweep by the snapshot kernel afterwards */
   if (ctx->mc_nabove_chain != ctx->mc_chain) {
@@ -1021,7 +1038,8 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
       if (int r = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound)) return r;
     }
     if (int r = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
-                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev, ctx->d_scal + ABZ_S_MC_NABOVE)) return r;
+                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev, ctx->d_scal + ABZ_S_MC_NABOVE,
+                                    launch_rank ? 1 : 0)) return r;
     return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, launch_rank ? ctx->mc_rank_state : nullptr,
                                   (uint32_t)N);
   };
@@ -1044,6 +1062,7 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
       if (memcmp(&e.key, &key, sizeof(key)) == 0) { g = &e; break; }
     if (!g) {
       if (ctx->mc_graphs.size() >= 64) {           /* a host that keeps changing its arguments: start over */
+        ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));      /* a cached graph may still be executing */
         for (abz_mc_graph& e : ctx->mc_graphs) (void)hipGraphExecDestroy(e.exec);
         ctx->mc_graphs.clear();
       }
@@ -1117,6 +1136,10 @@ int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, in
   }
   ring_fold(ctx, ticket);
   ctx->mc_waited += 1;
+  if (snap[6] != 0ull && ctx->ring_timed[slot] && ctx->ev_head < ctx->ev_tail) {
+    ctx->ev_head += 1;               /* the failed generation's timing pair leaves the FIFO with it: later tickets keep their own pairs */
+    ctx->ring_timed[slot] = false;
+  }
   if (snap[6] == 2ull) {
     /* the sweep drew its better particles by rejection and a particle found none in 1024 trials: with at least 1 / 16 of the
      * population in every candidate set that does not happen -- the distances are not the ones the chain's count was made of */

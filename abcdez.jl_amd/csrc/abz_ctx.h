@@ -55,11 +55,11 @@ struct abcdez_ctx {
   bool graphs_on = false;
   std::vector<abz_mc_graph> mc_graphs;
   long long n_graph_replays = 0, n_graph_captures = 0, n_graph_direct = 0;
-  bool mc_seq_dirty = false;
+  bool mc_seq_dirty = false;            /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */
   /* the alive particles' weights are uniform, 1 / n_alive (abcdez_ctx_set_uniform_weights; kept by the indicator fast path of the
    * prologue, set by a resampling, cleared by a general reweight): lets the prologue use the closed forms for indicator kernels */
   bool w_uniform = false;
-  long long n_reweight_fast = 0;        /* a generation failed half way: ABZ_S_MCSEQ must be set to mc_issued again */
+  long long n_reweight_fast = 0;        /* prologues that took the closed forms of the indicator reweight */
   long long n_select_reused = 0, n_select_inline = 0;   /* prologues that found their select enqueued ahead / ran it themselves */
   HotModel hot;                   /* by-value kernel argument, pointers are device pointers */
   hipStream_t stream = nullptr;
@@ -155,6 +155,9 @@ struct abcdez_ctx {
    * ABZ_SERPENTINE=0 in the environment keeps every launch front to back (same results; A/B measurements) */
   bool serpentine = true;
   long long sweep_launch_seq = 0;
+  /* multi-GPU (abz_comm.hip): the RCCL communicator of this context's rank (an ncclComm_t), null on a single GPU */
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
 
 void abz_set_error(const std::string& msg);
@@ -270,7 +273,7 @@ static inline void abz_time_end(abcdez_ctx* ctx, int k, long long units) {
 int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t, const double*, const double*,
                         const double*, double*, double*, double*, double, double, double, double,
                         uint32_t, uint32_t, uint32_t, const unsigned long long*, const unsigned long long* seq_dev = nullptr,
-                        const unsigned long long* nabove_dev = nullptr);
+                        const unsigned long long* nabove_dev = nullptr, int rank_built = -1 /* -1: iff order and cnt are given */);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
 int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_ring, double alpha, double eps_target,
                            const uint32_t* rank_state, uint32_t N);

@@ -117,7 +117,7 @@ struct SmcPackedArgs {
 __device__ inline uint32_t packed_bit(const uint32_t* __restrict__ bits, uint32_t p) { return (bits[p >> 5] >> (p & 31u)) & 1u; }
 
 template <int SIM, int L, int C, bool PLAIN = false>
-__device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
+__device__ inline void smc_swarm_packed_body_1p(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
   constexpr int PB = ABZ_BLOCK / L;                 /* positions per block: whole words of the bitmap */
   static_assert(PB % 32 == 0, "packed sweeps need at least 32 particles per block (lanes <= 8)");
@@ -212,6 +212,166 @@ __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
     const uint32_t w = (a.r_lo + tile * PB) / 32u + threadIdx.x;
     if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
   }
+}
+
+/* ---- the same sweep in TWO PHASES, for rows spread over several lanes (the d = 32 kernel of BASELINE configs[2]).
+ *
+ * smc:137-145 simulate every in-support proposal and then accept iff  0 <= w  or  log(rand) < w,
+ *     w = ((lp - lpi) + K(dp)) - K(di)          (smc:140-141, evaluated left to right)
+ * K = logpdf of the ABC kernel, never positive (types.jl:26-73).  Rounding is monotone, so w <= w_max = ((lp - lpi) + 0) - K(di)
+ * for EVERY distance the simulator could return -- and when neither `0 <= w_max` nor `log(rand) < w_max` holds, the proposal is
+ * rejected whatever dist! returns: its call cannot change any output (the accept decision; nsims counts in-support proposals,
+ * smc:138; a blob is kept on acceptance only, smc:148; random numbers are addressed by counter, so nothing shifts).  With a
+ * Normal prior in 32 dimensions that is three proposals out of four (profiles/HISTORY.md, round 5), and the simulator -- four
+ * Philox blocks, four Box-Muller pairs, the distance -- is two thirds of the sweep's vector instructions.
+ *
+ * A skipped simulation only saves issue cycles when WHOLE WAVES skip it, hence two phases with a compaction in between:
+ *   phase 1, every lane group: slot bits -> rows -> proposal (smc:128) -> log-prior (smc:134) -> support (smc:135) -> w_max;
+ *            the proposals that may still be accepted are handed over through LDS (row + five scalars), packed densely;
+ *   phase 2, lane group k takes hand-over slot k: simulator + distance (smc:137) -> w -> accept (smc:145) -> row to the other slot.
+ *            Wavefronts whose groups all lie beyond the number of survivors wait at the workgroup's barrier and issue nothing.
+ * Same results bit for bit as the one-phase body (and the oracle, which simulates every proposal as the reference does). */
+template <int L, int C, int PB>
+struct SweepHand {
+  double tp[PB][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
+  double lp[PB], wl[PB], kdi[PB], logu[PB];
+  uint32_t pos[PB];             /* position | own slot bit << 31 */
+};
+template <int L, int C>
+__device__ inline int hand_unit(int slot, int m, int j) {   /* 16-byte unit of (load m, lane j) inside hand-over row `slot` */
+  constexpr int MM = C / 2;
+  return ((m ^ (slot & (MM - 1))) * L) + j;                 /* neighbouring slots start in different LDS bank quarters */
+}
+template <int L, int C>
+__device__ inline void group_push_p(const abz_prior_dim* pd, int j, const double (&p)[C], double (&pp)[C]) {
+#pragma unroll
+  for (int q = 0; q < C; ++q) pp[q] = abz_push_p(&pd[Lay<L, C>::comp(j, q / 2, q & 1)], p[q]);
+}
+
+template <int SIM, int L, int C, bool PLAIN = false>
+__device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
+  constexpr int LD = L * C;
+  constexpr int PB = ABZ_BLOCK / L;
+  constexpr int GW = 64 / L;                        /* lane groups per wavefront */
+  static_assert(PB % 32 == 0 && L >= 2 && C >= 2 && (C & 1) == 0, "two-phase sweep: 2 <= lanes <= 8, an even number of components per lane");
+  const HotModel& M = a.hm;
+  if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
+  const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;      /* serpentine order: smc_swarm_packed_body_1p */
+  const uint32_t gid = tile * ABZ_BLOCK + threadIdx.x;
+  const uint32_t grp = gid / L;
+  const int j = (int)(gid % L);
+  const bool active = grp < a.n_work;
+  const uint32_t tile_base = a.r_lo + tile * (uint32_t)PB;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+
+  __shared__ ModelLds<LD> s_model;
+  __shared__ SweepHand<L, C, PB> s_hand;
+  __shared__ uint32_t s_acc[PB / 32];
+  __shared__ uint32_t s_n;
+  __shared__ uint8_t s_flag[PB];
+
+  /* ---------------- phase 1: order of issue = order of need (smc_swarm_packed_body_1p) */
+  ModelStage<SIM, LD> stage;
+  stage.load(M);
+  const uint32_t wi = a.bits[ri >> 5];
+  ParticleDraws<L> draws;
+  uint32_t ra, rb;
+  draws.words(M.seed, ri, a.sweep, j, a.n_alive, ri, &ra, &rb);
+  const uint32_t wa = a.bits[ra >> 5], wb = a.bits[rb >> 5];
+  const double lpi = a.logpi[ri];
+  const double dli = a.delta[ri];
+  if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) s_n = 0u;
+  const uint32_t bi = (wi >> (ri & 31u)) & 1u, ba = (wa >> (ra & 31u)) & 1u, bb = (wb >> (rb & 31u)) & 1u;
+  double tp[C];
+  {
+    double ti[C], ta[C], tb[C];
+    load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+    load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+    load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+    stage.store(s_model);
+    __syncthreads();                                              /* sampler + model tables staged; s_acc, s_n zeroed */
+    double g, log_u;
+    draws.finish(&s_model.tab, a.gamma0, a.gsig, &g, &log_u);
+#pragma unroll
+    for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;              /* smc:128 */
+    double pp[C];
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
+    const bool insupport = !(lp == ABZ_NINF);                     /* smc:135 */
+    const double kdi = kernel_logpdf_dev(M.abck, a.eps, dli);
+    const double wl = lp - lpi;
+    const double w_max = (wl + 0.0) - kdi;                        /* smc:140-141 with K(dp) at its maximum */
+    const bool may = active && insupport && ((0.0 <= w_max) || (log_u < w_max));
+    /* compaction: the wave's surviving groups take consecutive hand-over slots from a workgroup counter */
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long mk = __ballot(may && j == 0);
+    unsigned int base = 0u;
+    if (lane == 0u && mk) base = atomicAdd(&s_n, (unsigned)__popcll(mk));
+    base = __shfl(base, 0, 64);
+    if (may) {
+      const int slot = (int)(base + (unsigned)__popcll(mk & ((1ull << (lane - (unsigned)j)) - 1ull)));
+      double2* row = reinterpret_cast<double2*>(s_hand.tp[slot]);
+#pragma unroll
+      for (int m = 0; m < C / 2; ++m) { double2 t; t.x = tp[2 * m]; t.y = tp[2 * m + 1]; row[hand_unit<L, C>(slot, m, j)] = t; }
+      if (j == 0) {
+        s_hand.lp[slot] = lp; s_hand.wl[slot] = wl; s_hand.kdi[slot] = kdi; s_hand.logu[slot] = log_u;
+        s_hand.pos[slot] = ri | (bi << 31);
+      }
+    }
+    if (active && j == 0 && a.flags) s_flag[threadIdx.x / L] = insupport ? 2 : 0;
+    /* nsims counts the in-support proposals (smc:138), simulated here or not */
+    const unsigned nsim1 = (active && j == 0 && insupport) ? 1u : 0u;
+    __syncthreads();                                              /* hand-over complete */
+
+    /* ---------------- phase 2: lane group k takes slot k */
+    const unsigned n = s_n;
+    const unsigned sg = threadIdx.x / L;
+    bool acc = false;
+    if ((threadIdx.x >> 6) * (unsigned)GW < n) {                  /* wave-uniform: this wavefront has at least one slot */
+      const bool on = sg < n;
+      const int slot = on ? (int)sg : 0;                          /* idle groups of a working wave shadow slot 0: shuffles stay converged */
+      const double2* row = reinterpret_cast<const double2*>(s_hand.tp[slot]);
+      double tq[C], pq[C];
+#pragma unroll
+      for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>(slot, m, j)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
+      if constexpr (PLAIN) {
+#pragma unroll
+        for (int q = 0; q < C; ++q) pq[q] = tq[q];
+      } else group_push_p<L, C>(s_model.prior, j, tq, pq);
+      const uint32_t pw = s_hand.pos[slot];
+      const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
+      const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
+      const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
+      acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
+      if (acc) {                                                  /* smc:146-150 */
+        store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, j, tq);
+        if (j == 0) {
+          const uint32_t t = rs - tile_base;
+          atomicOr(&s_acc[t >> 5], 1u << (t & 31u));
+          a.logpi[rs] = s_hand.lp[slot]; a.delta[rs] = ds;
+          if (a.stamp) a.stamp[rs] = abz_stamp(rs, a.sweep, 0);
+          if (a.flags) s_flag[t] |= 1;                            /* the position's only writer in this phase */
+        }
+      }
+    }
+    block_count2((j == 0 && acc) ? 1u : 0u, nsim1, a.cslots, a.c_cls);      /* (its barrier publishes s_acc and s_flag) */
+  }
+  if (threadIdx.x < PB / 32) {
+    const uint32_t w = tile_base / 32u + threadIdx.x;
+    if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
+  }
+  if (a.flags && threadIdx.x < PB && tile_base + threadIdx.x < a.r_lo + a.n_work) a.flags[tile_base + threadIdx.x] = s_flag[threadIdx.x];
+}
+
+/* one-phase body for rows held by a single lane (every simulator but the d-dimensional Normal) and for the widest lane groups;
+ * two phases wherever a row is spread over 2, 4 or 8 lanes.  ABZ_SWEEP_ONE_PHASE forces the former (A/B measurements). */
+template <int SIM, int L, int C, bool PLAIN = false>
+__device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
+#ifndef ABZ_SWEEP_ONE_PHASE
+  if constexpr (L >= 2 && L <= 8 && C >= 2 && C <= 8) smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
+  else
+#endif
+    smc_swarm_packed_body_1p<SIM, L, C, PLAIN>(a);
 }
 
 /* replay of a packed sweep on a replica (multi-GPU): every rank keeps the whole population, rank r sweeps a range of
@@ -353,6 +513,10 @@ struct McSwarmArgs {
    * (abcdez_mc_generation_async); NULL = the caller applied it: by rejection iff order == NULL */
   const unsigned long long* nabove_dev;
   unsigned long long* reject_fail;     /* set when a particle found no better particle in 1024 trials (include/abcdez_spec.h) */
+  /* a rank pass for THIS generation's distances has been enqueued before the sweep (order / cnt are its outputs).  The host decides
+   * whether to launch one, the device decides rank-or-rejection from nabove_dev: should the two ever disagree, order / cnt are not
+   * this generation's (or were never written) and must not be used as indices */
+  uint32_t rank_built;
 };
 
 __device__ inline uint32_t upper_bound_f64(const double* __restrict__ v, uint32_t n, double x) {
@@ -405,7 +569,10 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
         s = abz_mc_better_by_rejection(seed, i, sweep, a.delta, a.N, di, &exhausted);
         if (exhausted) *a.reject_fail = 1ull;     /* the rule's premise did not hold for the distances read: the host hears of it */
       }
-      else s = a.order[abz_randint(abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_i)];
+      else if (a.rank_built && cnt_i >= 1u && cnt_i <= a.N) {
+        const uint32_t t = a.order[abz_randint(abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_i)];
+        if (t < a.N) s = t; else *a.reject_fail = 1ull;
+      } else *a.reject_fail = 1ull;   /* no enumeration of this generation to draw from: keep s = i, the host hears of it (abcdez_mc_generation_wait) */
     }
     uint32_t ia, ib;                                                        /* mc:25-32 */
     abz_donor_ranks(w_donor, a.N, s, &ia, &ib);

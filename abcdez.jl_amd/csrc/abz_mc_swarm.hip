@@ -19,9 +19,10 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
                         const double* theta, const double* logpi, const double* delta, double* ntheta, double* nlogpi,
                         double* ndelta, double eps_pop, double eps_target, double gamma0, double gsig, uint32_t i0,
                         uint32_t n_local, uint32_t sweep, const unsigned long long* eps_pop_dev, const unsigned long long* seq_dev,
-                        const unsigned long long* nabove_dev) {
+                        const unsigned long long* nabove_dev, int rank_built) {
   if (n_local == 0) return 0;
   McSwarmArgs a;
+  a.rank_built = (rank_built < 0 ? (order != nullptr && cnt != nullptr) : rank_built != 0) ? 1u : 0u;
   a.hm = ctx->hot; a.order = order; a.cnt = cnt;
   a.theta = theta; a.logpi = logpi; a.delta = delta;
   a.ntheta = ntheta; a.nlogpi = nlogpi; a.ndelta = ndelta;

@@ -232,6 +232,35 @@ ABCDEZ_API int abcdez_smc_group_publish(abcdez_ctx* ctx);
  * drops the group's timing pairs and re-reads the counter baselines; a no-op when no group is open. */
 ABCDEZ_API int abcdez_smc_group_abort(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t* k_done);
+/* ---- Multi-GPU: the exchange steps behind the ABI (RCCL over xGMI on the context's own stream; csrc/abz_comm.hip).
+ * The reference parallelises its population loops over the threads of one process (`@floop ex for i in 1:nparticles`,
+ * src/abcdez_smc.jl:110, src/abcdez_mc.jl:7, src/abcdez_init.jl:6; `parallel=true`, smc:237); here one process per GPU owns a
+ * contiguous range of positions and what the threads share through memory is exchanged by collectives the LIBRARY issues.
+ *   comm_unique_id: rank 0 obtains the 128-byte rendezvous id; the host carries it to the other ranks (MPI.bcast, a file, torch's store).
+ *   comm_init:      every rank, once per context: joins the communicator of `world` ranks on the context's device.
+ *   comm_rank:      this context's (rank, world); returns 1 (and 0 of 1) when the context has no communicator.
+ *   comm_allgather: in place over `world` pieces of piece_bytes each, rank r's piece at buf + r * piece_bytes; enqueued on the
+ *                   context's stream (ordered with the kernels before and after it), does not wait.  Used for the rows / log-priors /
+ *                   distances of the initial population (init.jl:2-22) and of abcdemc's sweeps (mc:140-155).
+ *   comm_allreduce: in place over n elements; dtype 0 = int64, 1 = float64; op 0 = sum, 1 = min, 2 = max.
+ *   smc_sweeps_sharded: the sweeps of ONE generation (smc:336-353) on a population sharded by position -- the counterpart of
+ *                   abcdez_smc_sweeps_packed for world > 1, one call and one host synchronisation per generation: k_max times
+ *                   { sweep of the own chunk [rank chunk, (rank + 1) chunk) of the prefix -> all-gather of the flag bytes (1 B per
+ *                   position) -> replay of the other ranks' accepted proposals + the device-side test of smc:352 }, read-back, and the
+ *                   all-gather of the distance chunks behind it (8 B per position, once per generation).  chunk: a multiple of 64
+ *                   with world * chunk >= n_alive; `flags` (u8) and `delta` need room for world * chunk entries.  Counters as in
+ *                   abcdez_smc_sweeps_packed; every replica counts the same flags, so all ranks return the same k_done. */
+#define ABCDEZ_COMM_ID_BYTES 128
+ABCDEZ_API int abcdez_comm_unique_id(void* id_out, size_t bytes);
+ABCDEZ_API int abcdez_comm_init(abcdez_ctx* ctx, const void* unique_id, size_t bytes, int rank, int world);
+ABCDEZ_API int abcdez_comm_destroy(abcdez_ctx* ctx);
+ABCDEZ_API int abcdez_comm_rank(abcdez_ctx* ctx, int32_t* rank, int32_t* world);
+ABCDEZ_API int abcdez_comm_allgather(abcdez_ctx* ctx, void* buf, int64_t piece_bytes);
+ABCDEZ_API int abcdez_comm_allreduce(abcdez_ctx* ctx, void* buf, int64_t n, int dtype, int op);
+ABCDEZ_API int abcdez_smc_sweeps_sharded(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive, int64_t chunk,
+                                         double* slot0, double* slot1, double* logpi, double* delta, uint8_t* flags, double eps,
+                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max, double kmcmc_min,
+                                         int64_t* nacc, int64_t* nsim, int32_t* k_done);
 ABCDEZ_API int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int64_t N, uint32_t* bits,
                                                  uint32_t* bits_other, double* slot0, double* slot1, const double* logpi,
                                                  const double* delta, double* nlogpi, double* ndelta, double* wns,
