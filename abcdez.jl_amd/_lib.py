@@ -36,6 +36,9 @@ PROTOTYPES = {
     "abcdez_dev_free": [_vp],
     "abcdez_memcpy_h2d": [_vp, _vp, _vp, C.c_size_t],
     "abcdez_memcpy_d2h": [_vp, _vp, _vp, C.c_size_t],
+    "abcdez_host_alloc": [C.c_size_t, C.POINTER(_vp)],
+    "abcdez_host_free": [_vp],
+    "abcdez_memcpy_d2h_async": [_vp, _vp, _vp, C.c_size_t],
     "abcdez_init": [_vp, _vp, _vp, _vp, _i64, _i64],
     "abcdez_ctx_set_stamps": [_vp, _vp, _vp],
     "abcdez_blob_width": [_vp, _vp],
@@ -75,10 +78,19 @@ PROTOTYPES = {
     "abcdez_mc_generation_async": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _pf64, _i32, _f64, _f64,
                                    _u32, _pi64],
     "abcdez_mc_generation_wait": [_vp, _i64, _pi64, _pi64, _pf64, _pf64, _pf64],
+    "abcdez_comm_unique_id": [_vp, C.c_size_t],
+    "abcdez_comm_init": [_vp, _vp, C.c_size_t, C.c_int, C.c_int],
+    "abcdez_comm_destroy": [_vp],
+    "abcdez_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
+    "abcdez_comm_allgather": [_vp, _vp, _i64],
+    "abcdez_comm_allreduce": [_vp, _vp, _i64, C.c_int, C.c_int],
+    "abcdez_smc_sweeps_sharded": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _i32, _f64,
+                                  _pi64, _pi64, C.POINTER(_i32)],
     "abcdez_push_p": [_vp, _vp, _i64, _vp],
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
+MIN_VERSION = 500      # abcdez_comm_*, abcdez_smc_sweeps_sharded, timing mode 3 (include/abcdez_hip.h)
 # symbols with a non-status return type
 OTHER_SYMBOLS = ("abcdez_version", "abcdez_rng_rounds", "abcdez_last_error", "abcdez_abi_layout")
 
@@ -111,6 +123,11 @@ def load():
     lib.abcdez_version.restype = C.c_int
     lib.abcdez_rng_rounds.restype = C.c_int
     lib.abcdez_last_error.restype = C.c_char_p
+    # a library older than the header this binding was written against would link (C has no signature check) and misread
+    # arguments that were added since: refuse it
+    if lib.abcdez_version() < MIN_VERSION:
+        raise AbcdezError(f"{LIB_PATH} reports abcdez_version() = {lib.abcdez_version()}, this binding needs >= {MIN_VERSION}: "
+                          "rebuild it (`make -C abcdez.jl_amd/csrc`)")
     _LIB = lib
     return lib
 

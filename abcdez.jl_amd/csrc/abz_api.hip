@@ -365,6 +365,20 @@ int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes)
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
+int abcdez_host_alloc(size_t bytes, void** out) {
+  ABZ_REQUIRE(out, "host_alloc: null argument");
+  ABZ_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+int abcdez_host_free(void* ptr) {
+  if (ptr) ABZ_HIP_CHECK(hipHostFree(ptr));
+  return 0;
+}
+int abcdez_memcpy_d2h_async(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ABZ_REQUIRE(ctx && dst && src, "memcpy_d2h_async: null argument");
+  ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
 int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
   ABZ_REQUIRE(ctx && dst && src, "memcpy_d2h: null argument");
   ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -932,6 +946,12 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   ctx->mc_window_ready = false;
   rc = read_counters(ctx);
   if (rc) return rc;
+  if (ctx->h_scal[ABZ_S_MC_REJFAIL] == 2ull) {
+    ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_MC_REJFAIL, 0, 8, ctx->stream));
+    abz_set_error("mc_swarm: order / cnt do not enumerate this population (cnt[i] or order[] out of range): run abcdez_mc_rank_prepare "
+                  "on the distances the sweep reads");
+    return -3;
+  }
   if (ctx->h_scal[ABZ_S_MC_REJFAIL] != 0ull) {
     ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_MC_REJFAIL, 0, 8, ctx->stream));
     abz_set_error("mc_swarm: a particle drawing its better particle by rejection (order = NULL) ran out of trials: fewer than "

@@ -571,8 +571,8 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
       }
       else if (a.rank_built && cnt_i >= 1u && cnt_i <= a.N) {
         const uint32_t t = a.order[abz_randint(abz_rng(seed, i, sweep, 0, ABZ_RNG_BETTER).w0, cnt_i)];
-        if (t < a.N) s = t; else *a.reject_fail = 1ull;
-      } else *a.reject_fail = 1ull;   /* no enumeration of this generation to draw from: keep s = i, the host hears of it (abcdez_mc_generation_wait) */
+        if (t < a.N) s = t; else *a.reject_fail = 2ull;
+      } else *a.reject_fail = 2ull;   /* no enumeration of this generation to draw from: keep s = i, the host hears of it (abcdez_mc_generation_wait) */
     }
     uint32_t ia, ib;                                                        /* mc:25-32 */
     abz_donor_ranks(w_donor, a.N, s, &ia, &ib);

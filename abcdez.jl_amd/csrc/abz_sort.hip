@@ -469,7 +469,12 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
      * by rank without a rank pass launched (a host that said do_rank = 0 of an unconverged population): same failure */
     const unsigned long long n_in = scal[ABZ_S_MC_NABOVE];
     if (!rank_state && n_in != 0ull && !abz_mc_draws_by_rejection(n_in, (unsigned long long)N)) out[6] = 1ull;
-    if (scal[ABZ_S_MC_REJFAIL] != 0ull) { out[6] = 2ull; scal[ABZ_S_MC_REJFAIL] = 0ull; }   /* drawn by rejection, trials exhausted */
+    /* the sweep's own fail word: 1 = drawn by rejection, trials exhausted; 2 = drawn by rank from an enumeration that was not
+     * this generation's (no rank pass launched, or one that gave up: the sweep kept s = i for those particles) */
+    const unsigned long long rf = scal[ABZ_S_MC_REJFAIL];
+    if (rf == 1ull) out[6] = 2ull;
+    else if (rf != 0ull && out[6] == 0ull) out[6] = 1ull;
+    if (rf != 0ull) scal[ABZ_S_MC_REJFAIL] = 0ull;
     /* ... and the next generation's: what this sweep added to the cumulative ABZ_C_MCGT slots */
     scal[ABZ_S_MC_NABOVE] = tg - scal[ABZ_S_MC_TGPREV];
     scal[ABZ_S_MC_TGPREV] = tg;

@@ -206,6 +206,39 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_smc_group_end(self.ctx, nacc, nsim, C.byref(done)))
         return list(nacc[:done.value]), list(nsim[:done.value]), done.value
 
+    # ---- multi-GPU: RCCL behind the C ABI (include/abcdez_hip.h, csrc/abz_comm.hip) ----
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib, self.lib.abcdez_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        _lib.check(self.lib, self.lib.abcdez_comm_init(self.ctx, unique_id, len(unique_id), rank, world))
+
+    def comm_rank(self):
+        r, w = C.c_int32(), C.c_int32()
+        rc = self.lib.abcdez_comm_rank(self.ctx, C.byref(r), C.byref(w))
+        if rc < 0:
+            _lib.check(self.lib, rc)
+        return r.value, w.value, rc == 0
+
+    def comm_allgather(self, t, piece_elems: int):
+        """in place over `world` pieces of piece_elems elements of t (rank r's piece at t[r * piece_elems]); on the library's stream"""
+        _lib.check(self.lib, self.lib.abcdez_comm_allgather(self.ctx, _ptr(t), piece_elems * t.element_size()))
+
+    def comm_allreduce(self, t, op: str = "sum"):
+        dt = {torch.int64: 0, torch.float64: 1}[t.dtype]
+        _lib.check(self.lib, self.lib.abcdez_comm_allreduce(self.ctx, _ptr(t), t.numel(), dt, {"sum": 0, "min": 1, "max": 2}[op]))
+
+    def smc_sweeps_sharded(self, bits_a, bits_b, n_alive, chunk, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig, sweep0,
+                           k_max, kmcmc_min):
+        """the sweeps of one generation on a sharded population, collectives included: ONE call, ONE host sync"""
+        nacc, nsim, done = (C.c_int64 * k_max)(), (C.c_int64 * k_max)(), C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_smc_sweeps_sharded(
+            self.ctx, _ptr(bits_a), _ptr(bits_b), n_alive, chunk, _ptr(slot0), _ptr(slot1), _ptr(logpi), _ptr(delta), _ptr(flags),
+            eps, gamma0, gsig, sweep0, k_max, kmcmc_min, nacc, nsim, C.byref(done)))
+        return list(nacc[:done.value]), list(nsim[:done.value]), done.value
+
     def smc_select_discard(self):
         """forget a select armed / enqueued ahead (the population was written by other means, or the run ends)"""
         _lib.check(self.lib, self.lib.abcdez_smc_select_discard(self.ctx))
@@ -385,6 +418,21 @@ class PopulationEngine:
         self.ops = ops if ops is not None else HipOps(spec, lanes=lanes)
         if hasattr(self.ops, "reserve"):
             self.ops.reserve(self.N)
+        # Collectives: RCCL issued BY THE LIBRARY on its own stream (abcdez_comm_*), whenever the group's backend is RCCL and
+        # the ops are the HIP library; torch.distributed itself only for other backends (gloo: the CPU tests, rehearsals on one
+        # GPU) and when ABZ_COMM=torch asks for it (A/B).  The rendezvous id travels through the process group once.
+        self._native_comm = False
+        if (self.pg is not None and self._backend == "nccl" and hasattr(self.ops, "comm_init")
+                and os.environ.get("ABZ_COMM", "native") != "torch"
+                and (self.world > 1 or force_collectives)):
+            import torch.distributed as dist
+
+            idt = torch.zeros(128, dtype=torch.uint8, device=self.ops.device)
+            if self.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(self.ops.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0), group=self.pg)
+            self.ops.comm_init(bytes(idt.cpu().numpy().tobytes()), self.rank, self.world)
+            self._native_comm = True
         dev = self.ops.device
         self.device = dev
         N, ld = self.N, spec.ld
@@ -531,6 +579,10 @@ class PopulationEngine:
         so their all-gather goes out on the collective stream while this rank replays the other chunks."""
         import torch.distributed as dist
 
+        if self._native_comm:          # same stream as the kernels: ordered behind the sweep that made the distances final
+            self.ops.comm_allgather(self._full[self.cur][1], self.chunk)
+            self._delta_stale = False
+            return True
         if self._backend == "nccl" or self.device.type == "cpu":
             t = self._full[self.cur][1]
             self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
@@ -592,7 +644,9 @@ class PopulationEngine:
 
         direct = self._backend == "nccl" or self.device.type == "cpu"
         for t in bufs:
-            if direct:
+            if self._native_comm:
+                self.ops.comm_allgather(t, t.numel() // self.world)
+            elif direct:
                 dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
             else:
                 host = torch.empty(t.shape, dtype=t.dtype)
@@ -605,7 +659,9 @@ class PopulationEngine:
         import torch.distributed as dist
 
         c, g = self.chunk, self.world
-        if self._backend == "nccl" or self.device.type == "cpu":
+        if self._native_comm:
+            self.ops.comm_allgather(t, c)
+        elif self._backend == "nccl" or self.device.type == "cpu":
             dist.all_gather_into_tensor(t[:g * c], t[self.rank * c:(self.rank + 1) * c], group=self.pg)
         else:
             host = torch.empty(g * c, dtype=t.dtype)
@@ -618,7 +674,10 @@ class PopulationEngine:
         import torch.distributed as dist
 
         t = torch.tensor(vals, dtype=torch.int64, device=self.device if self._backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        if self._native_comm:
+            self.ops.comm_allreduce(t, "sum")
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
         return tuple(int(v) for v in t.tolist())
 
     def _need_packed(self, what):
@@ -769,15 +828,14 @@ class PopulationEngine:
         self._mark("flag_allgather", 0)
         self._allgather_chunks(self.flags)               # 1 byte per position: accepted | simulated << 1
         self._mark("flag_allgather", 1)
-        if last:
-            self._start_delta_allgather()
+        exchanged = bool(self._start_delta_allgather()) if last else False
         self._mark("replay", 0)
         counts = self.ops.smc_replay_packed(b_in, b_out, self.n_alive, self.r_lo, self.r_hi, self.buf[0][0],
                                             self.buf[1][0], cur[1], self.flags, gamma0, gsig, self.sweep)
         self._mark("replay", 1)
         self.sweep += 1
         self.bc = 1 - self.bc
-        self._delta_stale = True
+        self._delta_stale = not exchanged       # (the library's own all-gather is already in the stream, in order)
         return counts                                    # global (nacc, nsim), counted from the flags
 
     def smc_sweeps(self, eps: float, gamma0: float, gsig: float, Kmcmc: int, Kmcmc_min: float, next_prologue=None):
@@ -823,6 +881,18 @@ class PopulationEngine:
             self._delta_work.wait()
             self._delta_work = None
         cur = self.buf[self.cur]
+        if self._native_comm and self._prof is None:
+            # the whole group -- own chunk sweeps, flag all-gathers, replays, the device-side test of smc:352, the read-back and the
+            # distance all-gather -- is ONE library call on the library's stream (abcdez_smc_sweeps_sharded)
+            with _rng("sweeps_group_sharded"):
+                naccs, nsims, Ki = self.ops.smc_sweeps_sharded(self.bits[self.bc], self.bits[1 - self.bc], self.n_alive, self.chunk,
+                                                               self.buf[0][0], self.buf[1][0], cur[1], self._full[self.cur][1],
+                                                               self.flags, eps, gamma0, gsig, self.sweep, Kmcmc, Kmcmc_min)
+            self.sweep += Ki
+            if Ki & 1:
+                self.bc = 1 - self.bc
+            self._delta_stale = False
+            return naccs, nsims, Ki
         self.ops.smc_group_begin(self.n_alive, Kmcmc_min)
         try:
             bc = self.bc
@@ -906,7 +976,10 @@ class PopulationEngine:
             import torch.distributed as dist
 
             t = torch.tensor([lo, -hi], dtype=torch.float64, device=self.device if self._backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+            if self._native_comm:
+                self.ops.comm_allreduce(t, "min")
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
             lo, hi = float(t[0]), -float(t[1])
         return nsim, ngt, lo, hi
 
@@ -1053,16 +1126,34 @@ class PopulationEngine:
         w = self.wns
         return ((w[:, None] * th).sum(dim=0) / w.sum()).cpu().numpy()
 
+    def _to_host(self, tensors):
+        """device tensors -> numpy arrays.  On the GPU: contiguous copies into PINNED host memory, all enqueued back to back on
+        the engine's stream, one wait -- the copy engine runs at the link's rate (a pageable destination goes through the
+        runtime's bounce buffers at a quarter of it).  The arrays returned view the pinned blocks."""
+        if self.device.type != "cuda":
+            return [t.cpu().numpy() for t in tensors]
+        host = []
+        for t in tensors:
+            t = t if t.is_contiguous() else t.contiguous()         # (a column range of the rows: compacted on the device first)
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            host.append(h)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [h.numpy() for h in host]
+
     def result(self):
+        """the population as the drivers return it (smc:382-393, mc:166-171): P (push_p-cast), the internal rows, logpi, C, Wns,
+        alive and -- with blobs on -- the simulated data behind every distance.  Only the d real columns of the rows travel, and
+        when no dimension is discrete push_p is the identity (types.jl:20-23): P and theta are then ONE array, moved once."""
         self._stream()
         th, lp, dl = self.state
-        pushed = torch.empty_like(th)
-        self.ops.push_p(th, pushed)
         d = self.spec.d
-        P = pushed[:, :d].cpu().numpy()
-        if d == 1 and not hasattr(self.spec.prior, "p"):
-            P = P[:, 0]                      # univariate prior -> vector of scalars
+        discrete = any(getattr(self.spec, "discrete", (True,)))       # ModelSpec.discrete: push_p rule per dimension
+        if discrete:
+            pushed = torch.empty_like(th)
+            self.ops.push_p(th, pushed)
         blobs = None
+        blob_dev = None
         if self.blob_on:
             # rebuild the simulated data behind every particle's distance from its stamp; the re-run's distance
             # must be the stored one, bit for bit
@@ -1072,17 +1163,25 @@ class PopulationEngine:
             self.ops.blob_eval(th, self.stamp[self.cur], out, redo)
             if not torch.equal(redo.view(torch.int64), dl.view(torch.int64)):
                 raise RuntimeError("blobs: a re-run simulation does not reproduce the stored distance")
-            blobs = out[:, :nb].cpu().numpy()
-            if nb == 1:
+            blob_dev = out[:, :nb]
+        send = [th[:, :d], lp, dl, self.wns, self.alive] + ([pushed[:, :d]] if discrete else []) + ([blob_dev] if blob_dev is not None else [])
+        got = self._to_host(send)
+        theta, logpi, Cc, Wns, alive = got[:5]
+        P = got[5] if discrete else theta
+        if blob_dev is not None:
+            blobs = got[-1]
+            if blobs.shape[1] == 1:
                 blobs = blobs[:, 0]
+        if d == 1 and not hasattr(self.spec.prior, "p"):
+            P = P[:, 0]                      # univariate prior -> vector of scalars
         return {
             "blobs": blobs,
             "P": P,
-            "theta": th[:, :d].cpu().numpy(),  # internal (unrounded) state, mc:216-220
-            "logpi": lp.cpu().numpy(),
-            "C": dl.cpu().numpy(),
-            "Wns": self.wns.cpu().numpy(),
-            "alive": self.alive.cpu().numpy().astype(bool),
+            "theta": theta,                  # internal (unrounded) state, mc:216-220
+            "logpi": logpi,
+            "C": Cc,
+            "Wns": Wns,
+            "alive": alive.astype(bool),
         }
 
 

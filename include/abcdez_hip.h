@@ -100,6 +100,13 @@ ABCDEZ_API int abcdez_dev_alloc(size_t bytes, void** out);
 ABCDEZ_API int abcdez_dev_free(void* ptr);
 ABCDEZ_API int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 ABCDEZ_API int abcdez_memcpy_d2h(abcdez_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* The one bulk transfer of the path is the result download at the end of a run (P, Wns, C: src/abcdez_smc.jl:382-393, src/abcdez_mc.jl:166-171;
+ * 1.2 GB at BASELINE configs[2]).  Into pageable memory the runtime stages it through bounce buffers at ~12 GB/s; into PINNED host memory
+ * the copy engine writes at the link's rate.  host_alloc / host_free: page-locked host memory (hipHostMalloc); memcpy_d2h_async: enqueue
+ * the copy on the context's stream and return -- several arrays travel back to back, abcdez_sync waits for all of them. */
+ABCDEZ_API int abcdez_host_alloc(size_t bytes, void** out);
+ABCDEZ_API int abcdez_host_free(void* ptr);
+ABCDEZ_API int abcdez_memcpy_d2h_async(abcdez_ctx* ctx, void* dst_host_pinned, const void* src_dev, size_t bytes);
 
 /* S1  abcde_init!(prior, dist!, varexternal, thetas, logpi, Ds, nparticles, rng, ex, blobs)
  *     src/abcdez_init.jl:2-22, including the prior draws and log-priors of

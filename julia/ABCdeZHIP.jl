@@ -15,18 +15,20 @@
 # Dispatch: `abcdesmc!` / `abcdemc!` get a new method on a `DeviceSimulator` in the `dist!`
 # position; every other `dist!` (an ordinary closure) keeps hitting ABCdeZ.jl's CPU methods.
 #
-# Multi-GPU: the sharded entry points (abcdez_smc_swarm_packed on a sub-range with flags,
-# abcdez_smc_replay_packed) take plain device pointers; the collectives between them
-# (one all-gather of the flag bytes per sweep, one of the distances per generation) belong to the
-# host -- MPI.jl / NCCL.jl here, torch.distributed in abcdez_amd/engine.py, which is the
-# reference for the order of the calls.
+# Multi-GPU (one Julia process per GPU): the collectives are behind the C ABI too (RCCL over xGMI on the library's own
+# stream, csrc/abz_comm.hip).  The host only carries the 128-byte rendezvous id from rank 0 to the others, e.g.
+#     id = rank == 0 ? comm_unique_id() : Vector{UInt8}(undef, 128);  MPI.Bcast!(id, 0, MPI.COMM_WORLD)
+#     r = abcdesmc!(prior, sim, ϵ, nothing; nparticles = N, rng = 1, comm = (id = id, rank = rank, world = world))
+# and every rank returns the same result, bit for bit what one GPU returns (random numbers are keyed by position).  Per sweep one
+# byte per alive position crosses the fabric, per generation the distances; abcdez_smc_sweeps_sharded is the whole sharded
+# generation in one ccall (abcdez_amd/engine.py drives the same entry points and is the tested reference for their order).
 module ABCdeZHIP
 
 using ABCdeZ, Distributions, LinearAlgebra, Random
 import ABCdeZ: abcdesmc!, abcdemc!
 
 export DeviceSimulator, Normal1D, MVNormalSim, DiracSquare, Quad2D, Mixture01, NormalTimesDU, WienerRMS,
-       LotkaVolterraRK4, Socks, UserSimulator, abcdesmc!, abcdemc!
+       LotkaVolterraRK4, Socks, UserSimulator, abcdesmc!, abcdemc!, comm_unique_id
 
 const LIB = get(ENV, "ABCDEZ_HIP_LIB", joinpath(@__DIR__, "..", "abcdez.jl_amd", "lib", "libabcdez_hip.so"))
 
@@ -45,7 +47,11 @@ struct AbzModel
     mv::Ptr{Float64}                      # C_NULL, or [μ | L⁻¹ | L] of an MvNormal prior (include/abcdez_spec.h)
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
+const MIN_VERSION = 500        # abcdez_comm_*, abcdez_smc_sweeps_sharded (include/abcdez_hip.h)
 function check_abi()
+    # an older library would link -- C has no signature check -- and misread arguments added since
+    v = ccall((:abcdez_version, LIB), Cint, ())
+    v >= MIN_VERSION || error("ABCdeZHIP: libabcdez_hip.so reports version $v, this shim needs >= $MIN_VERSION (rebuild the library)")
     ccall((:abcdez_rng_rounds, LIB), Cint, ()) == 10 || @warn("libabcdez_hip.so was built with a non-default Philox round count: results differ from a default build's")
     lay = Vector{Int32}(undef, 32)
     n = ccall((:abcdez_abi_layout, LIB), Cint, (Ptr{Int32}, Cint), lay, length(lay))
@@ -149,12 +155,18 @@ mutable struct Engine
     stamp::Vector{Ptr{Cvoid}}
     wns::Ptr{Cvoid}; alive::Ptr{Cvoid}; inds::Ptr{Cvoid}; order::Ptr{Cvoid}; sorted::Ptr{Cvoid}; cnt::Ptr{Cvoid}
     cur::Int; bc::Int; sweep::UInt32; draw::UInt32; n_alive::Int; n_prev::Int
+    rank::Int; world::Int; flags::Ptr{Cvoid}        # multi-GPU: this process's rank, the number of ranks, one flag byte per position
 end
 
 devalloc(bytes) = (p = Ref{Ptr{Cvoid}}(); check(ccall((:abcdez_dev_alloc, LIB), Cint, (Csize_t, Ptr{Ptr{Cvoid}}), bytes, p)); p[])
 devfree(p) = p == C_NULL || ccall((:abcdez_dev_free, LIB), Cint, (Ptr{Cvoid},), p)
 h2d(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_h2d, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
 d2h(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
+# the bulk result download goes through page-locked staging memory: the copy engine then runs at the link's rate, and the arrays
+# of a result travel back to back behind one wait (include/abcdez_hip.h, abcdez_host_alloc / abcdez_memcpy_d2h_async)
+hostalloc(bytes) = (p = Ref{Ptr{Cvoid}}(); check(ccall((:abcdez_host_alloc, LIB), Cint, (Csize_t, Ptr{Ptr{Cvoid}}), bytes, p)); p[])
+hostfree(p) = p == C_NULL || ccall((:abcdez_host_free, LIB), Cint, (Ptr{Cvoid},), p)
+d2h_async(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h_async, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), e.ctx, dst, src, bytes))
 
 # `rng` of the reference signatures (src/abcdez_smc.jl:220, src/abcdez_mc.jl:104: `rng=Random.default_rng()`): the device stream
 # is a counter-based Philox4x32-10 keyed by 64 bits.  An AbstractRNG -- the reference's default included -- gives the key with one
@@ -163,7 +175,13 @@ d2h(e, dst, src, bytes) = check(ccall((:abcdez_memcpy_d2h, LIB), Cint, (Ptr{Cvoi
 philox_key(rng::Integer) = rng % UInt64
 philox_key(rng::AbstractRNG) = rand(rng, UInt64)
 
-function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
+# rank 0 of a multi-GPU run: the rendezvous id every rank passes to abcdesmc!(...; comm = (id = ..., rank = ..., world = ...))
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:abcdez_comm_unique_id, LIB), Cint, (Ptr{Cvoid}, Csize_t), id, 128)); id
+end
+
+function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int; comm=nothing)
     check_abi()
     fs = factors(prior); d = length(fs); ld = nextpow(2, d)
     data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d); mv = mvmaps(prior, ld)
@@ -181,9 +199,16 @@ function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int)
     end
     check(ccall((:abcdez_ctx_reserve, LIB), Cint, (Ptr{Cvoid}, Int64), ctx[], N))
     nw = cld(N, 32)
-    e = Engine(ctx[], N, ld, d, nb, [devalloc(8N * ld) for _ in 1:2], [devalloc(8N) for _ in 1:2], [devalloc(8N) for _ in 1:2],
+    rank, world = comm === nothing ? (0, 1) : (Int(comm.rank), Int(comm.world))
+    N % world == 0 || error("nparticles must be divisible by the number of ranks")
+    if comm !== nothing                              # every rank: join the communicator on this context's device
+        check(ccall((:abcdez_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint, Cint), ctx[], comm.id, length(comm.id), rank, world))
+    end
+    Np = N + 64 * world                              # sharded runs exchange chunks of the per-position arrays: room for `world` of them
+    e = Engine(ctx[], N, ld, d, nb, [devalloc(8N * ld) for _ in 1:2], [devalloc(8N) for _ in 1:2], [devalloc(8Np) for _ in 1:2],
                [devalloc(4nw) for _ in 1:2], nb > 0 ? [devalloc(8N) for _ in 1:2] : Ptr{Cvoid}[],
-               devalloc(8N), devalloc(N), devalloc(4N), devalloc(4N), devalloc(8N), devalloc(4N), 1, 1, 0, 0, N, N)
+               devalloc(8N), devalloc(N), devalloc(4N), devalloc(4N), devalloc(8N), devalloc(4N), 1, 1, 0, 0, N, N,
+               rank, world, world > 1 ? devalloc(Np) : C_NULL)
     z = zeros(UInt32, nw)                       # every position's current row is slot 1
     h2d(e, e.bits[1], z, 4nw); h2d(e, e.bits[2], z, 4nw)
     finalizer(free!, e)
@@ -191,7 +216,7 @@ end
 # releases the population and the context; safe to call twice (ADVICE r1: every run used to leak its arrays)
 function free!(e::Engine)
     e.ctx == C_NULL && return
-    foreach(devfree, vcat(e.slot, e.logpi, e.delta, e.bits, e.stamp, [e.wns, e.alive, e.inds, e.order, e.sorted, e.cnt]))
+    foreach(devfree, vcat(e.slot, e.logpi, e.delta, e.bits, e.stamp, [e.wns, e.alive, e.inds, e.order, e.sorted, e.cnt, e.flags]))
     ccall((:abcdez_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), e.ctx)
     e.ctx = C_NULL
 end
@@ -199,10 +224,16 @@ other(e) = 3 - e.cur
 bind_stamps!(e) = e.nb > 0 && check(ccall((:abcdez_ctx_set_stamps, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), e.ctx, e.stamp[e.cur], e.stamp[other(e)]))
 
 # ---- one ccall per reference function (include/abcdez_hip.h) --------------------------------
+allgather!(e, buf, piece_bytes) = check(ccall((:abcdez_comm_allgather, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), e.ctx, buf, piece_bytes))
 function init!(e)                                                                                         # init.jl:2-22
     bind_stamps!(e)
+    nl = e.N ÷ e.world                               # this rank draws the particles [rank nl, (rank + 1) nl) ...
     check(ccall((:abcdez_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64),
-                e.ctx, e.slot[1], e.logpi[e.cur], e.delta[e.cur], 0, e.N))
+                e.ctx, e.slot[1], e.logpi[e.cur], e.delta[e.cur], e.rank * nl, nl))
+    if e.world > 1                                   # ... and every rank ends up with the whole population (any particle may be a donor)
+        allgather!(e, e.slot[1], 8nl * e.ld); allgather!(e, e.logpi[e.cur], 8nl); allgather!(e, e.delta[e.cur], 8nl)
+        e.nb > 0 && allgather!(e, e.stamp[e.cur], 8nl)
+    end
 end
 function reset_weights!(e)                                                                                # smc:266-270: Wns = 1/N, alive = true
     w = fill(1.0 / e.N, e.N); a = ones(UInt8, e.N)
@@ -258,6 +289,18 @@ end
 # call: the test of :352 runs on the device between the sweeps -> (Σnaccs, Σnsims, Ki); Kmcmc ≤ 16 per call
 function smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min; next_prologue=nothing)
     nacc = zeros(Int64, Kmcmc); nsim = zeros(Int64, Kmcmc); done = Ref(Int32(0)); bind_stamps!(e)
+    if e.world > 1
+        # sharded by position: this rank sweeps its chunk of the alive prefix; flag all-gather, replay of the other ranks' accepted
+        # proposals, the test of smc:352 and the distance all-gather all happen inside this one call, on every rank alike
+        chunk = cld(cld(e.n_alive, e.world), 64) * 64
+        check(ccall((:abcdez_smc_sweeps_sharded, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                     Float64, Float64, Float64, UInt32, Int32, Float64, Ptr{Int64}, Ptr{Int64}, Ref{Int32}),
+                    e.ctx, e.bits[e.bc], e.bits[3 - e.bc], e.n_alive, chunk, e.slot[1], e.slot[2], e.logpi[e.cur], e.delta[e.cur], e.flags,
+                    ϵ, γ0, γσ, e.sweep, Kmcmc, Kmcmc_min, nacc, nsim, done))
+        e.sweep += done[]; isodd(done[]) && (e.bc = 3 - e.bc)
+        return (sum(nacc), sum(nsim), Int(done[]))
+    end
     # (α, ϵ_target) of the next prologue!: its quantile select is enqueued behind these sweeps (it only reads Δs; same results)
     next_prologue === nothing || check(ccall((:abcdez_smc_select_ahead, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Float64),
                                              e.ctx, e.delta[e.cur], e.alive, e.N, next_prologue[1], next_prologue[2]))
@@ -279,9 +322,17 @@ function download(e; packed::Bool)
         end
         src = packed ? rows : e.slot[e.cur]
         check(ccall((:abcdez_push_p, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), e.ctx, src, e.N, pushed))   # types.jl:20-23
-        th = Matrix{Float64}(undef, e.ld, e.N); d2h(e, th, pushed, sizeof(th))
-        Δ = Vector{Float64}(undef, e.N); W = Vector{Float64}(undef, e.N)
-        d2h(e, Δ, e.delta[e.cur], 8e.N); d2h(e, W, e.wns, 8e.N)
+        nrow = 8 * e.ld * e.N
+        stage = hostalloc(nrow + 16e.N)               # rows | Δ | Wns, pinned
+        th = Matrix{Float64}(undef, e.ld, e.N); Δ = Vector{Float64}(undef, e.N); W = Vector{Float64}(undef, e.N)
+        try
+            d2h_async(e, stage, pushed, nrow); d2h_async(e, stage + nrow, e.delta[e.cur], 8e.N); d2h_async(e, stage + nrow + 8e.N, e.wns, 8e.N)
+            check(ccall((:abcdez_sync, LIB), Cint, (Ptr{Cvoid},), e.ctx))
+            unsafe_copyto!(pointer(th), Ptr{Float64}(stage), e.ld * e.N)
+            unsafe_copyto!(pointer(Δ), Ptr{Float64}(stage + nrow), e.N); unsafe_copyto!(pointer(W), Ptr{Float64}(stage + nrow + 8e.N), e.N)
+        finally
+            hostfree(stage)
+        end
         blobs = fill(nothing, e.N)
         if e.nb > 0                                # rebuild the blobs from the stamps; the re-run distance must be the stored one
             w = Ref(Int32(0)); check(ccall((:abcdez_blob_width, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), e.ctx, w))
@@ -310,7 +361,8 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                    nparticles::Int=100, α=0.95, δess=0.5, nsims_max::Int=10^7, Kmcmc::Int=3, Kmcmc_min=1.0,
                    ABCk=ABCdeZ.IndicatorStrict0toϵ, facc_stop=0.0, facc_min=0.0, facc_tune=0.975,
                    verbose::Bool=true, verboseout::Bool=true, rng::Union{Integer,AbstractRNG}=Random.default_rng(),
-                   parallel::Bool=false)
+                   parallel::Bool=false, comm=nothing)
+    # comm = (id, rank, world): one of `world` processes, one GPU each (top of this file); every rank must pass the same integer `rng`
     # `varexternal` and `parallel` are accepted and ignored: the device simulator holds its own data (no per-task deepcopy,
     # smc:166-173) and the whole population always runs in parallel on the GPU (smc:237's executor has no counterpart)
     0.0 ≤ α < 1.0 || error("α must be in 0 <= α < 1")                                  # smc:223-235
@@ -326,7 +378,8 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
     nparticles_min = ceil(Int, 3 * length(prior) / (min(α, δess)))
     nparticles_min ≤ nparticles || error("nparticles must be at least $(nparticles_min)")
 
-    e = Engine(prior, dist!, ABCk, philox_key(rng), nparticles)
+    (comm === nothing || (Kmcmc ≤ 16 && rng isa Integer)) || error("comm: a sharded run needs Kmcmc <= 16 and the same integer rng on every rank")
+    e = Engine(prior, dist!, ABCk, philox_key(rng), nparticles; comm = comm)
     try
         init!(e)                                                                            # smc:242-252
         reset_weights!(e)                                                                   # smc:266-270

@@ -35,6 +35,12 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else "oracle"     # "oracle": CPU tensors; "hip": the product engine on cuda:0
     # "rccl1": the product engine in a ONE-rank RCCL group with the sharded code path forced on, so that a
     # single-GPU box runs the real collectives (in-place all_gather_into_tensor on device slices) end to end
+    # "rccl1_torch": the same with ABZ_COMM=torch -- the collectives issued by torch.distributed instead of by the library
+    if mode == "rccl1_torch":
+        os.environ["ABZ_COMM"] = "torch"
+    native = mode == "rccl1"
+    if mode == "rccl1_torch":
+        mode = "rccl1"
     dist.init_process_group("nccl" if mode == "rccl1" else "gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pg = dist.group.WORLD if (world > 1 or mode == "rccl1") else None
@@ -58,6 +64,8 @@ def main():
         r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
         assert r.engine.packed and r.engine.sharded_packed == (world > 1 or mode == "rccl1")
+        if mode == "rccl1":     # who issues the collectives: the library itself (abcdez_comm_*) or torch.distributed
+            assert r.engine._native_comm == native, (r.engine._native_comm, native)
         m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=25, verbose=False, rng=22,
                       engine=engine, process_group=pg)
         res, mres = r.engine.result(), m.engine.result()

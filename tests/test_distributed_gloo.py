@@ -92,14 +92,17 @@ def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
 
 
 @pytest.mark.gpu
-def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory):
+@pytest.mark.parametrize("mode", ["rccl1", "rccl1_torch"])
+def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory, mode):
     """The sharded code path (flag all-gather + replay, per-generation distance all-gather, abcdemc's row
     all-gathers, counter all-reduce) over the real RCCL backend in a group of one rank -- all a single-GPU box
-    can run of `nccl` -- must reproduce the single-process CPU-oracle result bit for bit."""
+    can run of `nccl` -- must reproduce the single-process CPU-oracle result bit for bit.  rccl1: the collectives are issued by
+    the LIBRARY on its own stream (abcdez_comm_*, abcdez_smc_sweeps_sharded: the whole sharded generation in one call);
+    rccl1_torch: by torch.distributed (ABZ_COMM=torch), as in rounds 2-4."""
     ref_dir = tmp_path_factory.mktemp("ref_oracle_rccl")
     run_world(1, ref_dir, "oracle")
-    hip_dir = tmp_path_factory.mktemp("hip_rccl1")
-    run_world(1, hip_dir, "rccl1", timeout=240)
+    hip_dir = tmp_path_factory.mktemp("hip_" + mode)
+    run_world(1, hip_dir, mode, timeout=240)
     for name in ("normal1d", "mvn8", "quad2d", "lv"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))

@@ -179,10 +179,21 @@ class ShimEngine:
             self.ck(self.lib.abcdez_packed_gather(self.ctx, self.bits[self.bc], self.N, self.slot[0], self.slot[1], rows))
         src = rows if packed else self.slot[self.cur]
         self.ck(self.lib.abcdez_push_p(self.ctx, src, self.N, pushed))
-        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, th.ctypes.data, pushed, th.nbytes))
         dl, w = np.empty(self.N), np.empty(self.N)
-        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, dl.ctypes.data, self.delta[self.cur], 8 * self.N))
-        self.ck(self.lib.abcdez_memcpy_d2h(self.ctx, w.ctypes.data, self.wns, 8 * self.N))
+        # the shim's download: page-locked staging memory, three copies enqueued back to back, one wait (julia/ABCdeZHIP.jl)
+        nrow = th.nbytes
+        stage = C.c_void_p()
+        self.ck(self.lib.abcdez_host_alloc(nrow + 16 * self.N, C.byref(stage)))
+        try:
+            self.ck(self.lib.abcdez_memcpy_d2h_async(self.ctx, stage.value, pushed, nrow))
+            self.ck(self.lib.abcdez_memcpy_d2h_async(self.ctx, stage.value + nrow, self.delta[self.cur], 8 * self.N))
+            self.ck(self.lib.abcdez_memcpy_d2h_async(self.ctx, stage.value + nrow + 8 * self.N, self.wns, 8 * self.N))
+            self.ck(self.lib.abcdez_sync(self.ctx))
+            C.memmove(th.ctypes.data, stage.value, nrow)
+            C.memmove(dl.ctypes.data, stage.value + nrow, 8 * self.N)
+            C.memmove(w.ctypes.data, stage.value + nrow + 8 * self.N, 8 * self.N)
+        finally:
+            self.lib.abcdez_host_free(stage)
         blobs = None
         if self.nb > 0:
             wd = C.c_int32()

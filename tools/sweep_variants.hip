@@ -112,11 +112,14 @@ int main(int argc, char** argv) {
   auto reset = [&]() { CK(hipMemcpy(logpi, logpi0, (size_t)N * 8, hipMemcpyDeviceToDevice)); };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
-  // eps with the target acceptance (bisection on variant 0; every distance starts out of the kernel's support)
+  // eps with the target acceptance (bisection on variant 0).  Every distance starts INSIDE the kernel's support (K(di) = 0, as for every
+  // alive particle of a real run): the prior ratio then takes part in the accept test, and the two-phase body skips the simulator
+  // for the proposals it has already rejected -- with distances outside the support (rounds 3-4: 1e9) every in-support proposal
+  // would be accepted on its distance alone and nothing could be skipped
   double lo = 5.0, hi = 14.0, acc = 0.0;
   for (int it = 0; it < 14; ++it) {
     a.eps = 0.5 * (lo + hi);
-    reset(); fill_f64<<<N / 256, 256>>>(delta, N, 1e9);
+    reset(); fill_f64<<<N / 256, 256>>>(delta, N, 0.0);
     const unsigned long long c0 = read_counter(cs, ABZ_C_NACC);
     variants[0].launch(&a, grid_of(variants[0]), 0); CK(hipDeviceSynchronize());
     acc = (double)(read_counter(cs, ABZ_C_NACC) - c0) / n_alive;
@@ -135,7 +138,7 @@ int main(int argc, char** argv) {
       }
     }
     for (int v = 0; v < nv; ++v) {
-      reset(); fill_f64<<<N / 256, 256>>>(delta, N, 1e9); CK(hipDeviceSynchronize());
+      reset(); fill_f64<<<N / 256, 256>>>(delta, N, 0.0); CK(hipDeviceSynchronize());
       const unsigned g = grid_of(variants[v]);
       CK(hipEventRecord(e0, 0));
       // variants named serp*: every other launch walks the prefix from its end (SmcPackedArgs.rev), as the library alternates them
