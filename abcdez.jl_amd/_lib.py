@@ -78,6 +78,8 @@ PROTOTYPES = {
     "abcdez_mc_generation_async": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _pf64, _i32, _f64, _f64,
                                    _u32, _pi64],
     "abcdez_mc_generation_wait": [_vp, _i64, _pi64, _pi64, _pf64, _pf64, _pf64],
+    "abcdez_mc_generation_sharded_async": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _pf64, _i32, _f64, _f64,
+                                           _u32, _pi64],
     "abcdez_comm_unique_id": [_vp, C.c_size_t],
     "abcdez_comm_init": [_vp, _vp, C.c_size_t, C.c_int, C.c_int],
     "abcdez_comm_destroy": [_vp],

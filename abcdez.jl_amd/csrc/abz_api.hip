@@ -414,10 +414,17 @@ static void ring_fold(abcdez_ctx* ctx, long long t) {
   if (ctx->ring_folded[slot]) return;
   const volatile unsigned long long* snap = ctx->h_ring + (size_t)slot * ABZ_RING_WORDS;
   const unsigned long long tg = snap[0], ts = snap[1];
-  ctx->ring_res[slot][0] = (long long)(ts - ctx->cnt_prev[ABZ_C_MCSIM]);
-  ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
-  ctx->cnt_prev[ABZ_C_MCSIM] = ts;
-  ctx->cnt_prev[ABZ_C_MCGT] = tg;
+  if (snap[7] != 0ull) {     /* a sharded generation: its counts over all ranks as they are; this GPU's slot totals keep the baselines */
+    ctx->ring_res[slot][0] = (long long)ts;
+    ctx->ring_res[slot][1] = (long long)tg;
+    ctx->cnt_prev[ABZ_C_MCSIM] = snap[9];
+    ctx->cnt_prev[ABZ_C_MCGT] = snap[8];
+  } else {
+    ctx->ring_res[slot][0] = (long long)(ts - ctx->cnt_prev[ABZ_C_MCSIM]);
+    ctx->ring_res[slot][1] = (long long)(tg - ctx->cnt_prev[ABZ_C_MCGT]);
+    ctx->cnt_prev[ABZ_C_MCSIM] = ts;
+    ctx->cnt_prev[ABZ_C_MCGT] = tg;
+  }
   /* at least 1 / 16 of the particles at or below eps_target after this generation: every later generation of the chain draws by
    * rejection (abz_ctx.h, mc_reject_known) */
   if (ctx->ring_chain[slot] == ctx->mc_chain && ctx->ring_res[slot][1] >= 0 &&
@@ -994,12 +1001,25 @@ int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const 
  * evaluated on the device with the host driver's operations; then the rank pass (do_rank) and the sweep.  A snapshot of
  * the counters and extrema is copied to pinned memory behind an event: abcdez_mc_generation_wait redeems the tickets in
  * the order they were issued (at most ABZ_MC_RING of them in flight). */
-int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
-                               double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta,
-                               uint32_t* cnt, double alpha, double eps_target, const double* lo_hi, int32_t do_rank,
-                               double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket) {
+} /* extern "C" */
+static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                                    double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta,
+                                    uint32_t* cnt, double alpha, double eps_target, const double* lo_hi, int32_t do_rank,
+                                    double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket, const bool sharded) {
   ABZ_REQUIRE(ctx && order && sorted_delta && cnt && theta && logpi && delta && ntheta && nlogpi && ndelta && ticket,
               "mc_generation_async: null argument");
+  /* sharded: this rank sweeps the particles [rank N / world, (rank + 1) N / world); the rank pass, the window and the snapshot run
+   * replicated on the whole population, which every rank holds (a better particle or a donor may be anybody, mc:23-32) */
+  int64_t i0 = 0, n_local = N;
+  if (sharded) {
+    ABZ_REQUIRE(ctx->comm, "mc_generation_sharded_async: no communicator (abcdez_comm_init)");
+    ABZ_REQUIRE(N % ctx->comm_world == 0, "mc_generation_sharded_async: nparticles must be divisible by the number of ranks");
+    n_local = N / ctx->comm_world; i0 = (int64_t)ctx->comm_rank * n_local;
+    /* the extrema a sweep leaves in its bank are THIS rank's: the window of a sharded chain comes from lo_hi (first generation) or
+     * from the snapshot kernel of the generation before, which holds the exchanged ones */
+    ABZ_REQUIRE(lo_hi || (ctx->mc_window_ready && ctx->mc_chain_sharded && ctx->mc_alpha == alpha && ctx->mc_eps_target == eps_target),
+                "mc_generation_sharded_async: the first generation of a chain (or after a change of alpha / eps_target) needs lo_hi");
+  }
   ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
@@ -1020,7 +1040,8 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   }
   /* a new chain: host-given extrema (the first generation of a run), other parameters, another population than the one the
    * generation before wrote (its outputs are this generation's inputs) */
-  if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N) {
+  if (lo_hi || ctx->mc_alpha != alpha || ctx->mc_eps_target != eps_target || ctx->mc_last_out != (const void*)delta || ctx->mc_last_N != N ||
+      ctx->mc_chain_sharded != sharded) {
     /* the driver counted these very distances against this eps_target (mc:133) and nothing has written them since: the
      * chain's first count is known here too, and with it whether its generations need rank passes at all */
     const auto& seen = ctx->mc_count_seen;
@@ -1058,14 +1079,20 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
       if (int r = abz_rank_prepare_impl(ctx, delta, N, 0.0, 0.0, order, sorted_delta, cnt, win, ctx->mc_tail_hint, ctx->mc_tail_bound)) return r;
     }
     if (int r = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta, 0.0, eps_target, gamma0,
-                                    gamma_sigma, 0u, (uint32_t)N, sweep_base, win, seq_dev, ctx->d_scal + ABZ_S_MC_NABOVE,
+                                    gamma_sigma, (uint32_t)i0, (uint32_t)n_local, sweep_base, win, seq_dev, ctx->d_scal + ABZ_S_MC_NABOVE,
                                     launch_rank ? 1 : 0)) return r;
+    if (sharded) {
+      /* this rank's counts / extrema / fail word -> the exchange words; the new rows, log-priors, distances (and blob stamps) of
+       * every rank's particles and those words travel as one group of collectives; the snapshot then folds GLOBAL values */
+      if (int r = abz_launch_mc_partial(ctx, ctx->mm_bank)) return r;
+      if (int r = abz_comm_mc_exchange(ctx, ntheta, nlogpi, ndelta, ctx->stamp_cur ? ctx->stamp_nxt : nullptr, n_local, ctx->h_model.ld)) return r;
+    }
     return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, launch_rank ? ctx->mc_rank_state : nullptr,
-                                  (uint32_t)N);
+                                  (uint32_t)N, sharded ? 1 : 0);
   };
   const long long ev_before = ctx->ev_tail;
   bool replayed = false;
-  if (ctx->graphs_on && ctx->stream != nullptr && !need_window && !timed_now) {      /* the legacy default stream cannot be captured */
+  if (ctx->graphs_on && ctx->stream != nullptr && !need_window && !timed_now && !sharded) {      /* the legacy default stream cannot be captured */
     abz_mc_graph_key key;
     memset(&key, 0, sizeof(key));
     key.theta = theta; key.logpi = logpi; key.delta = delta; key.ntheta = ntheta; key.nlogpi = nlogpi; key.ndelta = ndelta;
@@ -1132,10 +1159,27 @@ int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, 
   ctx->mc_last_out = (const void*)ndelta; ctx->mc_last_N = N;
   ctx->mc_window_ready = true; ctx->mc_alpha = alpha; ctx->mc_eps_target = eps_target;
   ctx->mm_bank = 1 - ctx->mm_bank;   /* the kernel reset the other bank for the next sweep */
-  ctx->mc_have_bank = true;
+  ctx->mc_have_bank = !sharded;      /* (a sharded sweep leaves this rank's extrema only) */
+  ctx->mc_chain_sharded = sharded;
   *ticket = (int64_t)ctx->mc_issued;
   ctx->mc_issued += 1;
   return 0;
+}
+extern "C" {
+int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                               double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta,
+                               uint32_t* cnt, double alpha, double eps_target, const double* lo_hi, int32_t do_rank,
+                               double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket) {
+  return mc_generation_async_impl(ctx, N, theta, logpi, delta, ntheta, nlogpi, ndelta, order, sorted_delta, cnt, alpha, eps_target, lo_hi,
+                                  do_rank, gamma0, gamma_sigma, sweep, ticket, false);
+}
+/* the same on a population sharded over the ranks of the context's communicator (abcdez_comm_init): include/abcdez_hip.h */
+int abcdez_mc_generation_sharded_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi, const double* delta,
+                                       double* ntheta, double* nlogpi, double* ndelta, uint32_t* order, double* sorted_delta,
+                                       uint32_t* cnt, double alpha, double eps_target, const double* lo_hi, int32_t do_rank,
+                                       double gamma0, double gamma_sigma, uint32_t sweep, int64_t* ticket) {
+  return mc_generation_async_impl(ctx, N, theta, logpi, delta, ntheta, nlogpi, ndelta, order, sorted_delta, cnt, alpha, eps_target, lo_hi,
+                                  do_rank, gamma0, gamma_sigma, sweep, ticket, true);
 }
 
 /* Results of the generation `ticket` (the oldest one not yet redeemed): nsim, #(new Ds > eps_target) (mc:156), extrema of the

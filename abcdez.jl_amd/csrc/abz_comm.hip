@@ -36,6 +36,24 @@
 
 static_assert(NCCL_UNIQUE_ID_BYTES == ABCDEZ_COMM_ID_BYTES, "abcdez_hip.h promises the hosts a 128-byte id");
 
+int abz_comm_mc_exchange(abcdez_ctx* ctx, double* ntheta, double* nlogpi, double* ndelta, uint64_t* nstamp, int64_t n_local, int ld) {
+  ABZ_REQUIRE(ctx->comm, "mc_generation_sharded_async: no communicator (abcdez_comm_init)");
+  ncclComm_t comm = (ncclComm_t)ctx->comm;
+  const size_t r = (size_t)ctx->comm_rank, nl = (size_t)n_local;
+  unsigned long long* part = ctx->d_scal + ABZ_S_MC_PART;
+  ABZ_NCCL_CHECK(ncclGroupStart());
+  ncclResult_t rc = ncclAllGather(ntheta + r * nl * (size_t)ld, ntheta, nl * (size_t)ld, ncclFloat64, comm, ctx->stream);
+  if (rc == ncclSuccess) rc = ncclAllGather(nlogpi + r * nl, nlogpi, nl, ncclFloat64, comm, ctx->stream);
+  if (rc == ncclSuccess) rc = ncclAllGather(ndelta + r * nl, ndelta, nl, ncclFloat64, comm, ctx->stream);
+  if (rc == ncclSuccess && nstamp) rc = ncclAllGather(nstamp + r * nl, nstamp, nl, ncclUint64, comm, ctx->stream);
+  if (rc == ncclSuccess) rc = ncclAllReduce(part, part, 2, ncclUint64, ncclSum, comm, ctx->stream);
+  if (rc == ncclSuccess) rc = ncclAllReduce(part + 2, part + 2, 3, ncclUint64, ncclMin, comm, ctx->stream);
+  const ncclResult_t re = ncclGroupEnd();
+  ABZ_NCCL_CHECK(rc);
+  ABZ_NCCL_CHECK(re);
+  return 0;
+}
+
 extern "C" {
 
 int abcdez_comm_unique_id(void* id_out, size_t bytes) {

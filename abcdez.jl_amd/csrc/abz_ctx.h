@@ -15,7 +15,10 @@
 
 #define ABZ_GROUP_MAX 16    /* sweeps per abcdez_smc_sweeps_packed call */
 #define ABZ_MC_RING 8       /* abcdemc generations in flight (abcdez_mc_generation_async) */
-#define ABZ_RING_WORDS 8    /* per generation: total #(Ds > eps_target), total nsim (cumulative), min key, max key, eps_pop, tail length, rank-pass error, ticket + 1 */
+/* per generation: [0] #(Ds > eps_target), [1] nsim -- cumulative totals of this GPU's counter slots, or, for a generation of a sharded
+ * population ([7] != 0), that generation's counts over ALL ranks --, [2] min key, [3] max key, [4] eps_pop, [5] tail length, [6] error
+ * word, [7] sharded, [8] [9] this GPU's cumulative slot totals (sharded generations: the host's baselines), [10] spare, [11] ticket + 1 */
+#define ABZ_RING_WORDS 12
 
 /* abcdez_smc_select_ahead: armed = start the next generation's select behind the next grouped sweeps; valid = it has been
  * enqueued for exactly these arguments and nothing has touched the distances / flags since */
@@ -115,6 +118,7 @@ struct abcdez_ctx {
   unsigned long long* h_ring = nullptr;           /* ABZ_MC_RING x ABZ_RING_WORDS u64, pinned + mapped: written BY a kernel */
   unsigned long long* d_ring = nullptr;           /* the same memory as the device sees it */
   bool ring_folded[ABZ_MC_RING] = {false};
+  bool mc_chain_sharded = false;                  /* the chain's generations sweep this rank's particles only (abcdez_mc_generation_sharded_async) */
   long long ring_res[ABZ_MC_RING][2] = {{0, 0}};  /* (nsim, #above target) once folded */
   long long ring_chain[ABZ_MC_RING] = {0};        /* which chain of generations the ticket belongs to (mc_chain when it was issued) */
   double ring_eps_target[ABZ_MC_RING] = {0.0};
@@ -249,7 +253,12 @@ enum {
    * ABZ_C_MCGT slots over the sweep before (their total at the last snapshot is kept next to it) */
   ABZ_S_MC_NABOVE = ABZ_S_MCW_EPS + 6, ABZ_S_MC_TGPREV = ABZ_S_MCW_EPS + 7,
   ABZ_S_MC_REJFAIL = ABZ_S_MCW_EPS + 8,   /* a sweep drawing by rejection ran out of trials: the population was not what the rule assumed */
-  ABZ_S_N = ABZ_S_MCW_EPS + 9
+  /* asynchronous generations of a SHARDED population (abcdez_mc_generation_sharded_async): this GPU's ABZ_C_MCSIM total at the last
+   * snapshot (TGPREV holds the ABZ_C_MCGT one) and the words the ranks exchange per generation -- [0] [1] this generation's counts
+   * (all-reduced by sum), [2] min key, [3] ~max key, [4] ~fail word (all-reduced by min), [5] [6] the local totals (not reduced) */
+  ABZ_S_MC_TSPREV = ABZ_S_MCW_EPS + 9,
+  ABZ_S_MC_PART = ABZ_S_MCW_EPS + 10,
+  ABZ_S_N = ABZ_S_MCW_EPS + 18
 };
 
 /* kernel launchers implemented across the .hip files */
@@ -276,7 +285,11 @@ int abz_launch_mc_swarm(abcdez_ctx*, const uint32_t*, const uint32_t*, uint32_t,
                         const unsigned long long* nabove_dev = nullptr, int rank_built = -1 /* -1: iff order and cnt are given */);
 int abz_launch_mc_window(abcdez_ctx*, int, double, double, double, double);
 int abz_launch_mc_snapshot(abcdez_ctx*, int bank, unsigned long long* d_ring, double alpha, double eps_target,
-                           const uint32_t* rank_state, uint32_t N);
+                           const uint32_t* rank_state, uint32_t N, int sharded = 0);
+int abz_launch_mc_partial(abcdez_ctx*, int bank);
+/* abz_comm.hip: what the ranks exchange after the own-range sweep of an abcdemc generation -- the new rows / log-priors / distances
+ * (/ blob stamps) of every rank's particles, in place, and the ABZ_S_MC_PART words -- as ONE group of collectives on the stream */
+int abz_comm_mc_exchange(abcdez_ctx*, double* ntheta, double* nlogpi, double* ndelta, uint64_t* nstamp, int64_t n_local, int ld);
 int abz_launch_mc_chain_start(abcdez_ctx*, const double* delta, int64_t N, double eps_target);
 /* which sorts a rank pass launches for a tail of the hinted / bounded length, and the grid of the long-tail kernels (a power of two
  * of wave-tiles: the kernels stride, so any grid is correct -- few distinct values keep the graph cache small) */

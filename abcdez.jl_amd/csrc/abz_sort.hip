@@ -433,7 +433,7 @@ int abz_launch_mc_window(abcdez_ctx* ctx, int bank, double lo, double hi, double
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long long* __restrict__ scal, int bank,
                                                                  unsigned long long* __restrict__ ring,
                                                                  double alpha, double eps_target, const uint32_t* __restrict__ rank_state,
-                                                                 uint32_t rank_limit, uint32_t N) {
+                                                                 uint32_t rank_limit, uint32_t N, int sharded) {
   /* which generation this is: counted on the device (the host's mc_issued when it enqueued this launch -- or when it replays
    * the graph this launch was captured into): ring slot and ticket follow from it */
   const unsigned long long gen = scal[ABZ_S_MCSEQ];
@@ -459,6 +459,15 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
   if (threadIdx.x == 0) {
     unsigned long long tg = 0, ts = 0;
     for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { tg += s_g[w]; ts += s_s[w]; }
+    out[7] = 0ull;
+    if (sharded) {
+      /* the sweep covered this rank's particles only: mc_partial_kernel folded its counts and extrema and the ranks have exchanged them
+       * (abz_comm_mc_exchange) -- this generation's counts over the WHOLE population, the global extrema, anybody's fail word */
+      const unsigned long long* part = scal + ABZ_S_MC_PART;
+      out[7] = 1ull; out[8] = part[5]; out[9] = part[6];
+      tg = part[0]; ts = part[1]; mn = part[2]; mx = ~part[3];
+      if (~part[4] != 0ull) scal[ABZ_S_MC_REJFAIL] = ~part[4];
+    }
     out[0] = tg; out[1] = ts; out[2] = mn; out[3] = mx;        /* wave 0 holds the bank's extrema */
     out[4] = scal[ABZ_S_MCW_EPS];
     out[5] = rank_state ? (unsigned long long)rank_state[MCR_ST_NTAIL] : ~0ull;   /* how many particles drew (sizes the next rank pass) */
@@ -475,20 +484,57 @@ __global__ __launch_bounds__(ABZ_CSLOTS) void mc_snapshot_kernel(unsigned long l
     if (rf == 1ull) out[6] = 2ull;
     else if (rf != 0ull && out[6] == 0ull) out[6] = 1ull;
     if (rf != 0ull) scal[ABZ_S_MC_REJFAIL] = 0ull;
-    /* ... and the next generation's: what this sweep added to the cumulative ABZ_C_MCGT slots */
-    scal[ABZ_S_MC_NABOVE] = tg - scal[ABZ_S_MC_TGPREV];
-    scal[ABZ_S_MC_TGPREV] = tg;
+    /* ... and the next generation's: what this sweep added to the cumulative ABZ_C_MCGT slots (sharded: all ranks' sweeps, mc_partial_kernel
+     * keeps the local baselines) */
+    if (sharded) scal[ABZ_S_MC_NABOVE] = tg;
+    else { scal[ABZ_S_MC_NABOVE] = tg - scal[ABZ_S_MC_TGPREV]; scal[ABZ_S_MC_TGPREV] = tg; }
     __threadfence_system();
     __hip_atomic_store(out + ABZ_RING_WORDS - 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     mc_window_write(scal, f64_from_order_key_dev(mn), f64_from_order_key_dev(mx), alpha, eps_target);
     scal[ABZ_S_MCSEQ] = seq;
   }
 }
+/* sharded generations: this rank's part of the reductions, made for the exchange -- counts of THIS sweep (growth of the local slot
+ * totals since the last snapshot), local extrema, local fail word (layout: abz_ctx.h, ABZ_S_MC_PART) */
+__global__ __launch_bounds__(ABZ_CSLOTS) void mc_partial_kernel(unsigned long long* __restrict__ scal, int bank) {
+  __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
+  const unsigned long long* cs = scal + ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE;
+  unsigned long long vg = cs[ABZ_C_MCGT], vs = cs[ABZ_C_MCSIM];
+  unsigned long long mn = ~0ull, mx = 0ull;
+  if (threadIdx.x < ABZ_MMSLOTS) {
+    const unsigned long long* m = scal + ABZ_S_MM0 + (size_t)bank * 2 * ABZ_MMSLOTS;
+    mn = m[2 * threadIdx.x]; mx = m[2 * threadIdx.x + 1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    vg += __shfl_xor(vg, o); vs += __shfl_xor(vs, o);
+    const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { s_g[threadIdx.x >> 6] = vg; s_s[threadIdx.x >> 6] = vs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tg = 0, ts = 0;
+    for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { tg += s_g[w]; ts += s_s[w]; }
+    unsigned long long* part = scal + ABZ_S_MC_PART;
+    part[0] = tg - scal[ABZ_S_MC_TGPREV]; part[1] = ts - scal[ABZ_S_MC_TSPREV];
+    part[2] = mn; part[3] = ~mx; part[4] = ~scal[ABZ_S_MC_REJFAIL];
+    part[5] = tg; part[6] = ts;
+    scal[ABZ_S_MC_TGPREV] = tg; scal[ABZ_S_MC_TSPREV] = ts;
+    scal[ABZ_S_MC_REJFAIL] = 0ull;          /* travels in part[4]; the snapshot kernel restores the reduced word */
+  }
+}
+int abz_launch_mc_partial(abcdez_ctx* ctx, int bank) {
+  hipLaunchKernelGGL(mc_partial_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank);
+  ABZ_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 int abz_launch_mc_snapshot(abcdez_ctx* ctx, int bank, unsigned long long* d_ring, double alpha,
-                           double eps_target, const uint32_t* rank_state, uint32_t N) {
+                           double eps_target, const uint32_t* rank_state, uint32_t N, int sharded) {
   static_assert(ABZ_MMSLOTS <= 64, "mc_snapshot_kernel reduces the bank in wave 0");
   hipLaunchKernelGGL(mc_snapshot_kernel, dim3(1), dim3(ABZ_CSLOTS), 0, ctx->stream, ctx->d_scal, bank, d_ring, alpha, eps_target, rank_state,
-                     ctx->mc_rank_limit, N);
+                     ctx->mc_rank_limit, N, sharded);
   ABZ_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -511,15 +557,17 @@ __global__ __launch_bounds__(ABZ_BLOCK) void mc_chain_count_kernel(const double*
   }
 }
 __global__ __launch_bounds__(ABZ_CSLOTS) void mc_chain_total_kernel(unsigned long long* __restrict__ scal) {
-  __shared__ unsigned long long s_g[ABZ_CSLOTS / 64];
+  __shared__ unsigned long long s_g[ABZ_CSLOTS / 64], s_s[ABZ_CSLOTS / 64];
   unsigned long long vg = scal[ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE + ABZ_C_MCGT];
-  for (int o = 32; o >= 1; o >>= 1) vg += __shfl_xor(vg, o);
-  if ((threadIdx.x & 63) == 0) s_g[threadIdx.x >> 6] = vg;
+  unsigned long long vs = scal[ABZ_S_CSLOT0 + (size_t)threadIdx.x * ABZ_CSTRIDE + ABZ_C_MCSIM];
+  for (int o = 32; o >= 1; o >>= 1) { vg += __shfl_xor(vg, o); vs += __shfl_xor(vs, o); }
+  if ((threadIdx.x & 63) == 0) { s_g[threadIdx.x >> 6] = vg; s_s[threadIdx.x >> 6] = vs; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long tg = 0;
-    for (int w = 0; w < ABZ_CSLOTS / 64; ++w) tg += s_g[w];
+    unsigned long long tg = 0, ts = 0;
+    for (int w = 0; w < ABZ_CSLOTS / 64; ++w) { tg += s_g[w]; ts += s_s[w]; }
     scal[ABZ_S_MC_TGPREV] = tg;
+    scal[ABZ_S_MC_TSPREV] = ts;          /* (sharded chains: mc_partial_kernel sends differences against both) */
   }
 }
 int abz_launch_mc_chain_start(abcdez_ctx* ctx, const double* delta, int64_t N, double eps_target) {

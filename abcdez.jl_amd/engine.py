@@ -354,6 +354,17 @@ class HipOps:
             C.byref(t)))
         return t.value
 
+    def mc_generation_sharded_async(self, cur, nxt, order, sorted_delta, cnt, alpha, eps_target, lo_hi, do_rank, gamma0, gsig, sweep):
+        """the same on a population sharded over the ranks of the library's communicator: own range swept, rows / reductions
+        exchanged by the library, no host synchronisation -> ticket (global results from mc_generation_wait)"""
+        t = C.c_int64()
+        lh = (C.c_double * 2)(*lo_hi) if lo_hi is not None else None
+        _lib.check(self.lib, self.lib.abcdez_mc_generation_sharded_async(
+            self.ctx, cur[1].numel(), _ptr(cur[0]), _ptr(cur[1]), _ptr(cur[2]), _ptr(nxt[0]), _ptr(nxt[1]), _ptr(nxt[2]),
+            _ptr(order), _ptr(sorted_delta), _ptr(cnt), alpha, eps_target, lh, 1 if do_rank else 0, gamma0, gsig, sweep,
+            C.byref(t)))
+        return t.value
+
     def mc_generation_wait(self, ticket):
         """-> (nsim, #(Ds > eps_target), min Ds, max Ds, eps_pop) of generation `ticket`; waits for that generation only"""
         nsim, ngt, lo, hi, ep = C.c_int64(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
@@ -694,6 +705,7 @@ class PopulationEngine:
     def init_population(self):
         self._stream()
         self.discard_select_ahead()
+        self._mc_sharded_chain = False
         if self._delta_work is not None:
             self._delta_work.wait()
             self._delta_work = None
@@ -1019,6 +1031,22 @@ class PopulationEngine:
             with _rng("mc_generation"):
                 t = self.ops.mc_generation_async(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, alpha,
                                                  eps_target, lo_hi, do_rank, gamma0, gsig, self.sweep)
+            self.sweep += 1
+            self._swap()
+            self._mc_pending.append(("ticket", t))
+            return
+        if self._native_comm and hasattr(self.ops, "mc_generation_sharded_async"):
+            # sharded over the library's communicator: nothing comes back to the host between the sweep, the exchange of the new
+            # rows and the reductions -- generations are issued ahead exactly as on one GPU
+            self._mc_arrays()
+            self._stream()
+            self._bind_stamps()
+            if lo_hi is None and not getattr(self, "_mc_sharded_chain", False):
+                lo_hi = self._mc_last if self._mc_last is not None else self.extrema()
+            with _rng("mc_generation_sharded"):
+                t = self.ops.mc_generation_sharded_async(self.state, self.other, self.order, self.sorted_delta, self.rank_cnt, alpha,
+                                                         eps_target, lo_hi, do_rank, gamma0, gsig, self.sweep)
+            self._mc_sharded_chain = True
             self.sweep += 1
             self._swap()
             self._mc_pending.append(("ticket", t))

@@ -350,6 +350,18 @@ ABCDEZ_API int abcdez_mc_generation_async(abcdez_ctx* ctx, int64_t N, const doub
                                           double gamma_sigma, uint32_t sweep, int64_t* ticket);
 ABCDEZ_API int abcdez_mc_generation_wait(abcdez_ctx* ctx, int64_t ticket, int64_t* nsim, int64_t* n_above_target,
                                          double* dmin, double* dmax, double* eps_pop);
+/* The same generation on a population SHARDED over the ranks of the context's communicator (abcdez_comm_init; N divisible by the
+ * number of ranks): rank r runs abcdemc_swarm! (src/abcdez_mc.jl:5-61) for the particles [r N / world, (r + 1) N / world) of the full
+ * arrays every rank holds; behind the sweep, still without a host synchronisation, the ranks exchange the new rows / log-priors /
+ * distances (/ blob stamps) in place and the generation's reductions (mc:146,156,163) in one group of RCCL collectives on the
+ * context's stream; rank pass, eps_pop (mc:147) and the rank-or-rejection rule run replicated on the exchanged population, so every
+ * rank takes the same decisions.  Tickets are redeemed with abcdez_mc_generation_wait, which returns the GLOBAL reductions on every
+ * rank.  The first generation of a chain needs lo_hi (a rank's own sweep only knows its own particles' extrema). */
+ABCDEZ_API int abcdez_mc_generation_sharded_async(abcdez_ctx* ctx, int64_t N, const double* theta, const double* logpi,
+                                                  const double* delta, double* ntheta, double* nlogpi, double* ndelta,
+                                                  uint32_t* order, double* sorted_delta, uint32_t* cnt, double alpha,
+                                                  double eps_target, const double* lo_hi, int32_t do_rank, double gamma0,
+                                                  double gamma_sigma, uint32_t sweep, int64_t* ticket);
 
 /* T2  push_p over the population (src/abcdez_types.jl:20-23; result P, smc:382, mc:166). */
 ABCDEZ_API int abcdez_push_p(abcdez_ctx* ctx, const double* theta, int64_t N, double* out);

@@ -21,3 +21,15 @@ timeout 300 $R/tools/sweep_variants 2965608 12 0.147 20 > $O/r05_sweep_variants_
 cat $O/r05_sweep_variants_two_phase_sustained.jsonl
 timeout 300 python3 $R/tools/time_result_download.py > $O/r05_result_download.json 2> $O/r05_result_download.err; cat $O/r05_result_download.json; tail -3 $O/r05_result_download.err
 bash $R/tools/r05_pmc_calibration.sh
+# the RCCL-behind-the-ABI paths on the one GPU (one-rank groups) + the sharded one-rank mc1d line
+timeout 900 python3 -m pytest $R/tests/test_distributed_gloo.py $R/tests/test_gpu_bench_contract.py $R/tests/test_gpu_shim_sequence.py -m gpu -x -q > $O/r05_b3_pytest.log 2>&1; tail -15 $O/r05_b3_pytest.log
+for c in "" "--force-collectives"; do
+  timeout 300 python3 $R/bench.py --config mc1d --no-cpu-baseline --no-whole-run --no-other-configs --no-pattern $c 2> $O/r05_mc1d_sharded$c.err | grep '^{' | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(json.dumps({'force_collectives': '$c' != '', 'value': d['value'], 'ms_per_step': d['ms_per_step']}))"
+done
+for c in "" "--force-collectives"; do
+  timeout 300 python3 $R/bench.py --config smc32 --no-cpu-baseline --no-whole-run --no-other-configs --no-pattern $c 2> $O/r05_smc32_sharded$c.err | grep '^{' | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(json.dumps({'force_collectives': '$c' != '', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'phases': d.get('sharded_phases_ms')}))"
+done
