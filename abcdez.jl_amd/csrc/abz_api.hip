@@ -1025,7 +1025,8 @@ static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* th
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
   ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0 && eps_target >= 0.0, "mc_generation_async: need 0 <= alpha <= 1 and eps_target >= 0");
   ABZ_REQUIRE(ctx->mc_issued - ctx->mc_waited < ABZ_MC_RING, "mc_generation_async: too many generations in flight (redeem a ticket first)");
-  ABZ_REQUIRE(lo_hi || ctx->mc_have_bank, "mc_generation_async: the first generation needs the population's extrema (lo_hi)");
+  ABZ_REQUIRE(lo_hi || ctx->mc_have_bank || (sharded && ctx->mc_window_ready),
+              "mc_generation_async: the first generation needs the population's extrema (lo_hi)");
   if (!ctx->h_ring) {
     ABZ_HIP_CHECK(hipHostMalloc((void**)&ctx->h_ring, (size_t)ABZ_MC_RING * ABZ_RING_WORDS * 8, hipHostMallocMapped | hipHostMallocCoherent));
     memset(ctx->h_ring, 0, (size_t)ABZ_MC_RING * ABZ_RING_WORDS * 8);

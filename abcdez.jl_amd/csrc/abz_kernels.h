@@ -231,9 +231,14 @@ __device__ inline void smc_swarm_packed_body_1p(const SmcPackedArgs& a) {
  *   phase 2, lane group k takes hand-over slot k: simulator + distance (smc:137) -> w -> accept (smc:145) -> row to the other slot.
  *            Wavefronts whose groups all lie beyond the number of survivors wait at the workgroup's barrier and issue nothing.
  * Same results bit for bit as the one-phase body (and the oracle, which simulates every proposal as the reference does). */
+#ifdef ABZ_EXPERIMENT_HAND_SLOTS   /* measurement builds only (tools/build_lib_variants.sh): fewer hand-over slots than positions -- NOT safe */
+#define ABZ_HAND_SLOTS(PB) ABZ_EXPERIMENT_HAND_SLOTS
+#else
+#define ABZ_HAND_SLOTS(PB) (PB)
+#endif
 template <int L, int C, int PB>
 struct SweepHand {
-  double tp[PB][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
+  double tp[ABZ_HAND_SLOTS(PB)][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
   double lp[PB], wl[PB], kdi[PB], logu[PB];
   uint32_t pos[PB];             /* position | own slot bit << 31 */
 };
@@ -308,8 +313,9 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
     unsigned int base = 0u;
     if (lane == 0u && mk) base = atomicAdd(&s_n, (unsigned)__popcll(mk));
     base = __shfl(base, 0, 64);
-    if (may) {
-      const int slot = (int)(base + (unsigned)__popcll(mk & ((1ull << (lane - (unsigned)j)) - 1ull)));
+    const int slot1 = (int)(base + (unsigned)__popcll(mk & ((1ull << (lane - (unsigned)j)) - 1ull)));
+    if (may && slot1 < ABZ_HAND_SLOTS(PB)) {
+      const int slot = slot1;
       double2* row = reinterpret_cast<double2*>(s_hand.tp[slot]);
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) { double2 t; t.x = tp[2 * m]; t.y = tp[2 * m + 1]; row[hand_unit<L, C>(slot, m, j)] = t; }
@@ -344,7 +350,16 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
       acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
       if (acc) {                                                  /* smc:146-150 */
+#ifdef ABZ_EXPERIMENT_NT_STORES     /* measurement builds only: the accepted row leaves with non-temporal stores */
+        {
+          typedef double d2v __attribute__((ext_vector_type(2)));
+          double* dst = (bs ? a.slot0 : a.slot1) + (size_t)rs * LD;
+#pragma unroll
+          for (int m = 0; m < C / 2; ++m) { d2v t; t.x = tq[2 * m]; t.y = tq[2 * m + 1]; __builtin_nontemporal_store(t, (d2v*)(dst + m * 2 * L + 2 * j)); }
+        }
+#else
         store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, j, tq);
+#endif
         if (j == 0) {
           const uint32_t t = rs - tile_base;
           atomicOr(&s_acc[t >> 5], 1u << (t & 31u));

@@ -26,7 +26,7 @@ t1 = time.perf_counter()
 t2 = time.perf_counter()
 res = r.engine.result()
 t3 = time.perf_counter()
-nbytes = sum(v.nbytes for v in res.values())
+nbytes = sum(v.nbytes for v in res.values() if v is not None) - (res["P"].nbytes if res["P"] is res["theta"] or res["P"].base is res["theta"] else 0)   # P aliases theta when no dimension is discrete
 print(json.dumps({"generations": r.iters, "updates": r.updates, "run_s_incl_download": t1 - t0, "download_s": t3 - t2,
                   "download_bytes": nbytes, "download_GBps": nbytes / (t3 - t2) / 1e9,
                   "updates_per_s_incl_download": r.updates / (t1 - t0),
