@@ -72,15 +72,19 @@ template <int SIM, int LD>
 struct ModelStage {
   static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
   static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
-  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);   /* 16-byte pieces per thread */
-  static_assert(sizeof(abz_tables) % (16 * ABZ_BLOCK) == 0, "table size must tile the block");
+  static constexpr int NU = (int)(sizeof(abz_tables) / 16);                /* 16-byte pieces of the tables (7 KB: 448) */
+  static constexpr int NT = (NU + ABZ_BLOCK - 1) / ABZ_BLOCK;              /* ... per thread; the last round is partial */
+  static_assert(sizeof(abz_tables) % 16 == 0, "the tables are staged in 16-byte pieces");
   uint64_t w[NW];
   double2 tb[NT];
   double y;
   __device__ inline void load(const HotModel& M) {
     const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+    for (int q = 0; q < NT; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (NU % ABZ_BLOCK == 0 || t < NU) tb[q] = tsrc[t];
+    }
     const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -95,7 +99,10 @@ struct ModelStage {
   __device__ inline void store(ModelLds<LD>& s) const {
     double2* tdst = reinterpret_cast<double2*>(&s.tab);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+    for (int q = 0; q < NT; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (NU % ABZ_BLOCK == 0 || t < NU) tdst[t] = tb[q];
+    }
     uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -108,17 +115,24 @@ struct ModelStage {
 
 /* the sampler tables alone (kernels that draw but neither evaluate the prior nor simulate) */
 struct TabStage {
-  static constexpr int NT = (int)(sizeof(abz_tables) / 16 / ABZ_BLOCK);
+  static constexpr int NU = (int)(sizeof(abz_tables) / 16);
+  static constexpr int NT = (NU + ABZ_BLOCK - 1) / ABZ_BLOCK;
   double2 tb[NT];
   __device__ inline void load(const HotModel& M) {
     const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) tb[q] = tsrc[threadIdx.x + q * ABZ_BLOCK];
+    for (int q = 0; q < NT; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (NU % ABZ_BLOCK == 0 || t < NU) tb[q] = tsrc[t];
+    }
   }
   __device__ inline void store(abz_tables& s) const {
     double2* tdst = reinterpret_cast<double2*>(&s);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) tdst[threadIdx.x + q * ABZ_BLOCK] = tb[q];
+    for (int q = 0; q < NT; ++q) {
+      const int t = threadIdx.x + q * ABZ_BLOCK;
+      if (NU % ABZ_BLOCK == 0 || t < NU) tdst[t] = tb[q];
+    }
   }
 };
 

@@ -239,9 +239,11 @@ __device__ inline void smc_swarm_packed_body_1p(const SmcPackedArgs& a) {
 template <int L, int C, int PB>
 struct SweepHand {
   double tp[ABZ_HAND_SLOTS(PB)][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
-  double lp[PB], wl[PB], kdi[PB], logu[PB];
-  uint32_t pos[PB];             /* position | own slot bit << 31 */
+  double wl[PB], kdi[PB], logu[PB];             /* lp - lpi, K(di), log(rand) of smc:140-145 (lp itself is re-evaluated in phase 2) */
+  uint8_t pos[PB];                              /* position inside the tile | own slot bit << 7 */
 };
+/* LDS of the two-phase d = 32 kernel: 7 KB sampler tables + 1.8 KB model + 16 KB rows + 1.6 KB scalars = 27,000 B -- six workgroups
+ * per CU (163,840 / 6 = 27,306), which is why the hand-over carries no more than it must */
 template <int L, int C>
 __device__ inline int hand_unit(int slot, int m, int j) {   /* 16-byte unit of (load m, lane j) inside hand-over row `slot` */
   constexpr int MM = C / 2;
@@ -258,7 +260,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
   constexpr int PB = ABZ_BLOCK / L;
   constexpr int GW = 64 / L;                        /* lane groups per wavefront */
-  static_assert(PB % 32 == 0 && L >= 2 && C >= 2 && (C & 1) == 0, "two-phase sweep: 2 <= lanes <= 8, an even number of components per lane");
+  static_assert(PB % 32 == 0 && PB <= 128 && L >= 2 && C >= 2 && (C & 1) == 0, "two-phase sweep: 2 <= lanes <= 8, an even number of components per lane");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;      /* serpentine order: smc_swarm_packed_body_1p */
@@ -271,9 +273,8 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
 
   __shared__ ModelLds<LD> s_model;
   __shared__ SweepHand<L, C, PB> s_hand;
-  __shared__ uint32_t s_acc[PB / 32];
+  __shared__ uint32_t s_acc[PB / 32], s_ins[PB / 32];    /* per position of the tile: accepted / in support (bit masks) */
   __shared__ uint32_t s_n;
-  __shared__ uint8_t s_flag[PB];
 
   /* ---------------- phase 1: order of issue = order of need (smc_swarm_packed_body_1p) */
   ModelStage<SIM, LD> stage;
@@ -285,7 +286,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   const uint32_t wa = a.bits[ra >> 5], wb = a.bits[rb >> 5];
   const double lpi = a.logpi[ri];
   const double dli = a.delta[ri];
-  if (threadIdx.x < PB / 32) s_acc[threadIdx.x] = 0u;
+  if (threadIdx.x < PB / 32) { s_acc[threadIdx.x] = 0u; s_ins[threadIdx.x] = 0u; }
   if (threadIdx.x == 0) s_n = 0u;
   const uint32_t bi = (wi >> (ri & 31u)) & 1u, ba = (wa >> (ra & 31u)) & 1u, bb = (wb >> (rb & 31u)) & 1u;
   double tp[C];
@@ -320,11 +321,11 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) { double2 t; t.x = tp[2 * m]; t.y = tp[2 * m + 1]; row[hand_unit<L, C>(slot, m, j)] = t; }
       if (j == 0) {
-        s_hand.lp[slot] = lp; s_hand.wl[slot] = wl; s_hand.kdi[slot] = kdi; s_hand.logu[slot] = log_u;
-        s_hand.pos[slot] = ri | (bi << 31);
+        s_hand.wl[slot] = wl; s_hand.kdi[slot] = kdi; s_hand.logu[slot] = log_u;
+        s_hand.pos[slot] = (uint8_t)((ri - tile_base) | (bi << 7));
       }
     }
-    if (active && j == 0 && a.flags) s_flag[threadIdx.x / L] = insupport ? 2 : 0;
+    if (active && j == 0 && insupport && a.flags) atomicOr(&s_ins[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
     /* nsims counts the in-support proposals (smc:138), simulated here or not */
     const unsigned nsim1 = (active && j == 0 && insupport) ? 1u : 0u;
     __syncthreads();                                              /* hand-over complete */
@@ -340,17 +341,17 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       double tq[C], pq[C];
 #pragma unroll
       for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>(slot, m, j)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
-      if constexpr (PLAIN) {
-#pragma unroll
-        for (int q = 0; q < C; ++q) pq[q] = tq[q];
-      } else group_push_p<L, C>(s_model.prior, j, tq, pq);
+      /* push_p (types.jl:20-23) and the log-prior again: the same function of the same row in the same lanes as in phase 1 -- the
+       * same bits -- for 45 instructions of the few wavefronts that get here, instead of 512 bytes of LDS in every workgroup */
+      const double lps = group_logprior<L, C, PLAIN>(s_model.prior, j, tq, pq, M.mv);
       const uint32_t pw = s_hand.pos[slot];
-      const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
+      const uint32_t rs = tile_base + (pw & 0x7Fu), bs = pw >> 7;
       const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
       const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
       acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
       if (acc) {                                                  /* smc:146-150 */
-#ifdef ABZ_EXPERIMENT_NT_STORES     /* measurement builds only: the accepted row leaves with non-temporal stores */
+#ifndef ABZ_SWEEP_PLAIN_STORES      /* the accepted row is not read again before the next sweep: non-temporal stores (-0.7 % on the
+                                     * sweep, profiles/r05_two_phase_ab2.jsonl; ABZ_SWEEP_PLAIN_STORES: the A/B build) */
         {
           typedef double d2v __attribute__((ext_vector_type(2)));
           double* dst = (bs ? a.slot0 : a.slot1) + (size_t)rs * LD;
@@ -363,19 +364,20 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
         if (j == 0) {
           const uint32_t t = rs - tile_base;
           atomicOr(&s_acc[t >> 5], 1u << (t & 31u));
-          a.logpi[rs] = s_hand.lp[slot]; a.delta[rs] = ds;
+          a.logpi[rs] = lps; a.delta[rs] = ds;
           if (a.stamp) a.stamp[rs] = abz_stamp(rs, a.sweep, 0);
-          if (a.flags) s_flag[t] |= 1;                            /* the position's only writer in this phase */
         }
       }
     }
-    block_count2((j == 0 && acc) ? 1u : 0u, nsim1, a.cslots, a.c_cls);      /* (its barrier publishes s_acc and s_flag) */
+    block_count2((j == 0 && acc) ? 1u : 0u, nsim1, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
   }
   if (threadIdx.x < PB / 32) {
     const uint32_t w = tile_base / 32u + threadIdx.x;
     if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w] ^ s_acc[threadIdx.x];
   }
-  if (a.flags && threadIdx.x < PB && tile_base + threadIdx.x < a.r_lo + a.n_work) a.flags[tile_base + threadIdx.x] = s_flag[threadIdx.x];
+  if (a.flags && threadIdx.x < PB && tile_base + threadIdx.x < a.r_lo + a.n_work)      /* sharded runs: bit 0 accepted, bit 1 simulated */
+    a.flags[tile_base + threadIdx.x] = (uint8_t)(((s_acc[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) |
+                                                 (((s_ins[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) << 1));
 }
 
 /* one-phase body for rows held by a single lane (every simulator but the d-dimensional Normal) and for the widest lane groups;

@@ -43,7 +43,7 @@ FP64_VALU_PEAK_ORIGIN = ("nominal: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flo
                          "fp32 VECTOR rate MI355X_MICROARCH.md lists (the guide gives no fp64 vector figure; its 78.6 'FP64 matrix' "
                          "entry is the same number); tools/valu_rate.hip measures 5.4 instead of 4 cycles per v_fma_f64 wave-instruction "
                          "under dense fp64, so the sustained rate of the part is ~0.74 of this peak (profiles/r02_valu_rate.jsonl)")
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def profile_json(name):
@@ -640,7 +640,8 @@ def run_config(args):
             },
             "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N),
         }
-        out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (around one of their sweeps, in turn)
+        out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (mode 3: around all their sweeps; mode 2: around one, in turn)
+        out["roofline"]["timing_mode"] = args.timing_mode if cfg["kind"] == "smc" and not eng.sharded_packed else 2
         if cfg["kind"] == "mc":
             out["config"]["timed_window"].update(unconverged_generations=gen.ranked, completion=gen.complete, max_distance=gen.hi)
             if hasattr(eng.ops, "mc_rank_stats"):

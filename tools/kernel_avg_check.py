@@ -31,8 +31,12 @@ n_launch = int(win.get("sweep_launches", steps * per_step))
 ran = int(win["sweeps"])
 window = durs[-n_launch:]               # every sweep dispatch of the timed steps
 worked = sorted(window)[len(window) - ran:] if ran <= len(window) else window      # drop the gated launches (they returned at once)
-# the bracketed launches: sweep (s mod per_step) of every stride-th step s
-timed = [window[st * per_step + (st % per_step)] for st in range(0, steps, stride) if st * per_step + (st % per_step) < len(window)][:n]
+# the bracketed launches.  Timing mode 3 (round 5: one pair around ALL the sweeps of every stride-th step): every sweep of those steps;
+# mode 2 (rounds 2-4): sweep (s mod per_step) of every stride-th step s
+if int(roof.get("timing_mode", 2)) == 3:
+    timed = [window[st * per_step + k] for st in range(0, steps, stride) for k in range(per_step) if st * per_step + k < len(window)][:n]
+else:
+    timed = [window[st * per_step + (st % per_step)] for st in range(0, steps, stride) if st * per_step + (st % per_step) < len(window)][:n]
 upl = win["updates"] / max(ran, 1)
 avg = sum(worked) / len(worked)
 b_read = roof.get("bytes_read_per_update")
