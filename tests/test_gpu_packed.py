@@ -217,6 +217,65 @@ def test_packed_lane_shapes(oracle, d, shapes):
             assert same(a, b), lanes
 
 
+def wide_models():
+    """rows spread over several lanes (the two-phase sweep, csrc/abz_kernels.h) with everything the d = 32 Normal-prior bench
+    workload does not touch: flat priors (nothing is rejected on the prior ratio: all 64 hand-over slots of a tile fill up),
+    bounded and discrete dimensions (out-of-support proposals, push_p), a correlated Normal prior"""
+    rng = np.random.default_rng(3)
+    Amat = rng.normal(size=(16, 16))
+    cov = Amat @ Amat.T / 16 + 0.5 * np.eye(16)
+    return {
+        "flat16": (A.Factored(*[A.Uniform(-4.0, 4.0) for _ in range(16)]), A.MVNormal(tuple([0.5] * 16)), (2, 4, 8)),
+        "mixed32": (A.Factored(*[(A.Normal(0.0, 1.0), A.Uniform(-2.5, 2.5), A.DiscreteUniform(-3, 3), A.Normal(0.5, 2.0))[k % 4]
+                                 for k in range(32)]), A.MVNormal(tuple([0.25 * (k % 5) for k in range(32)])), (4, 8)),
+        "mv16": (A.MvNormal(np.linspace(-0.5, 0.5, 16), cov), A.MVNormal(tuple([0.2] * 16)), (2, 4)),
+        "narrow_normal32": (A.Factored(*[A.Normal(0.0, 0.3) for _ in range(32)]), A.MVNormal(tuple([1.0] * 32)), (4,)),
+    }
+
+
+@pytest.mark.parametrize("name", list(wide_models()))
+@pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Epa0toϵ])
+def test_two_phase_sweep_on_wide_rows(oracle, name, abck):
+    """The two-phase sweep (phase 1: proposal, log-prior, the acceptance ratio with the kernel term at its maximum; phase 2: the
+    simulator for the proposals that may still be accepted, smc:137-145) against the oracle, which simulates every in-support
+    proposal as the reference does: counters (nsims counts in-support proposals, simulated or not), both row slots, slot bits,
+    log-priors, distances, weights and the flag bytes of a sharded sweep, bit for bit -- for flat priors (every proposal survives
+    phase 1), bounded / discrete dimensions, a correlated Normal, a prior so narrow that almost nothing survives, with an
+    indicator and an Epanechnikov kernel (K(di) != 0), in every lane shape the row width has."""
+    prior, sim, shapes = wide_models()[name]
+    spec = A.ModelSpec(prior, sim, seed=11, ABCk=abck)
+    d = spec.d
+    N = 1 << 13
+
+    def run(ops):
+        e = PopulationEngine(spec, N, ops=ops, storage="packed")
+        e.init_population(); e.reset_weights()
+        eps, eps_k, out = math.inf, math.inf, []
+        for _ in range(6):
+            eps = min(e.quantile_alive(0.85), eps)
+            _, ess, _ = e.smc_reweight(eps_k, eps)
+            if ess < 0.5 * N:
+                e.smc_resample()
+            n = e.alive_compact()
+            out += [e.smc_swarm(eps, 2.38 / math.sqrt(2 * d), 1e-5) for _ in range(2)]
+            eps_k = eps
+        # one more sweep of a sub-range with flag bytes, as a rank of a sharded run does it
+        fl = torch.zeros(N + PACKED_ALIGN, dtype=torch.uint8, device=e.device)
+        lo, hi = min(64, n), n
+        cur = e.buf[e.cur]
+        e.ops.smc_swarm_packed(e.bits[e.bc], e.bits[1 - e.bc], n, lo, hi, e.buf[0][0], e.buf[1][0], cur[1], cur[2], fl, eps,
+                               2.38 / math.sqrt(2 * d), 1e-5, e.sweep, want_counts=False)
+        return out, [t.cpu() for t in (e.buf[0][0], e.buf[1][0], cur[1], cur[2], e.wns, e.bits[1 - e.bc], fl[:n])]
+
+    ref = run(oracle.OracleOps(spec))
+    assert sum(c[1] for c in ref[0]) > 0
+    for lanes in shapes:
+        got = run(HipOps(spec, lanes=lanes))
+        assert got[0] == ref[0], (lanes, got[0], ref[0])
+        for k, (a, b) in enumerate(zip(got[1], ref[1])):
+            assert same(a, b), (lanes, k)
+
+
 @pytest.mark.parametrize("name", ["mvn32", "mvn3", "normal1d"])
 def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
     """what the ranks of a sharded run do, on one GPU: every "rank" sweeps its sub-range of the prefix on its own
