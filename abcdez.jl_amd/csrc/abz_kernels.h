@@ -242,8 +242,8 @@ struct SweepHand {
   double wl[PB], kdi[PB], logu[PB];             /* lp - lpi, K(di), log(rand) of smc:140-145 (lp itself is re-evaluated in phase 2) */
   uint8_t pos[PB];                              /* position inside the tile | own slot bit << 7 */
 };
-/* LDS of the two-phase d = 32 kernel: 7 KB sampler tables + 1.8 KB model + 16 KB rows + 1.6 KB scalars = 27,000 B -- six workgroups
- * per CU (163,840 / 6 = 27,306), which is why the hand-over carries no more than it must */
+/* LDS of the two-phase d = 32 kernel: 7 KB sampler tables + 1.8 KB model + 16 KB rows + 1.6 KB scalars = 27,000 B: room for six
+ * workgroups per CU (163,840 / 6 = 27,306) -- the hand-over carries no more than it must */
 template <int L, int C>
 __device__ inline int hand_unit(int slot, int m, int j) {   /* 16-byte unit of (load m, lane j) inside hand-over row `slot` */
   constexpr int MM = C / 2;
@@ -350,8 +350,8 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
       acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
       if (acc) {                                                  /* smc:146-150 */
-#ifndef ABZ_SWEEP_PLAIN_STORES      /* the accepted row is not read again before the next sweep: non-temporal stores (-0.7 % on the
-                                     * sweep, profiles/r05_two_phase_ab2.jsonl; ABZ_SWEEP_PLAIN_STORES: the A/B build) */
+#ifndef ABZ_SWEEP_PLAIN_STORES      /* the accepted row is not read again before the next sweep: non-temporal stores (-0.8 % / -1.8 % on
+                                     * the sweep on two boxes, profiles/r05_two_phase_ab2.jsonl, _ab3.jsonl; ABZ_SWEEP_PLAIN_STORES: the A/B build) */
         {
           typedef double d2v __attribute__((ext_vector_type(2)));
           double* dst = (bs ? a.slot0 : a.slot1) + (size_t)rs * LD;

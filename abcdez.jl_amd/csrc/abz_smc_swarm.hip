@@ -26,16 +26,10 @@ template <int SIM, int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
   smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
-/* The two-phase body of the 4 x 8 shape (d = 32, BASELINE configs[2]) fits 80 registers and 27,000 B of LDS: SIX workgroups per CU.
- * Only phase-1 wavefronts have loads in flight, so residency is what hides the memory latency of this kernel: 6 against 5 waves per
- * SIMD is -1.6 % on the sweep (profiles/r05_two_phase_ab2.jsonl).  The attribute sits on this instantiation alone -- on the generic
- * template it would make the compiler squeeze (or spill) every other shape. */
-#ifndef ABZ_SWEEP_WAVES
-template <int SIM>
-__global__ __launch_bounds__(ABZ_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void smc_swarm_packed_kernel_w6(const SmcPackedArgs a) {
-  smc_swarm_packed_body<SIM, 4, 8, true>(a);          /* all-Normal priors (PLAIN); the family dispatch of the others needs more registers */
-}
-#endif
+/* Occupancy of the two-phase 4 x 8 kernel (d = 32): 81 registers, 27,000 B of LDS -- five waves per SIMD as the compiler leaves it.
+ * Forcing six (-DABZ_SWEEP_WAVES=6: 80 registers, three dwords spilled in phase 2; the LDS budget allows it) was measured on two boxes
+ * of the pool: -1.6 % on one, +5.6 % on the other (profiles/r05_two_phase_ab2.jsonl, r05_two_phase_ab3.jsonl) -- more rows in flight
+ * is not uniformly better for random 256-byte reads, so the default stays. */
 template <int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcReplayPackedArgs a) {
   smc_replay_packed_body<L, C, PLAIN>(a);
@@ -65,14 +59,6 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {
-#ifndef ABZ_SWEEP_WAVES
-        if constexpr (S() == ABZ_SIM_MVN && LL() == 4 && CC() == 8) {
-          if (ctx->prior_plain) {
-            hipLaunchKernelGGL((smc_swarm_packed_kernel_w6<S()>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
-            return;
-          }
-        }
-#endif
         if (ctx->prior_plain)
           hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
         else
