@@ -81,9 +81,11 @@ struct ModelStage {
   __device__ inline void load(const HotModel& M) {
     const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
+    for (int q = 0; q < NT; ++q) {      /* every element is assigned (threads past the end re-read piece 0): a conditionally written
+                                         * array stays in scratch memory -- 16 bytes per lane out to HBM and back, measured as +128 B
+                                         * of fabric traffic per update (profiles/HISTORY.md, round 5) */
       const int t = threadIdx.x + q * ABZ_BLOCK;
-      if (NU % ABZ_BLOCK == 0 || t < NU) tb[q] = tsrc[t];
+      tb[q] = tsrc[(NU % ABZ_BLOCK == 0 || t < NU) ? t : 0];
     }
     const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
 #pragma unroll
@@ -121,9 +123,11 @@ struct TabStage {
   __device__ inline void load(const HotModel& M) {
     const double2* __restrict__ tsrc = reinterpret_cast<const double2*>(M.tables);
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
+    for (int q = 0; q < NT; ++q) {      /* every element is assigned (threads past the end re-read piece 0): a conditionally written
+                                         * array stays in scratch memory -- 16 bytes per lane out to HBM and back, measured as +128 B
+                                         * of fabric traffic per update (profiles/HISTORY.md, round 5) */
       const int t = threadIdx.x + q * ABZ_BLOCK;
-      if (NU % ABZ_BLOCK == 0 || t < NU) tb[q] = tsrc[t];
+      tb[q] = tsrc[(NU % ABZ_BLOCK == 0 || t < NU) ? t : 0];
     }
   }
   __device__ inline void store(abz_tables& s) const {
