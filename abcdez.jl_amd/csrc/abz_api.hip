@@ -457,8 +457,8 @@ static int read_counters(abcdez_ctx* ctx, int ran_limit = -1) {
 
 int abcdez_ctx_set_timing(abcdez_ctx* ctx, int on) {
   ABZ_REQUIRE(ctx, "set_timing: null context");
-  if (on && !ctx->ev[0])
-    for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreate(&e));
+  if (on && !ctx->ev[0])      /* timing only: no system-scope fence (cache write-back) when an event is recorded between two sweeps */
+    for (hipEvent_t& e : ctx->ev) ABZ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
   const int mode = on & 0xFF, stride = on >> 8;
   ABZ_REQUIRE(mode <= 3 && stride >= 0, "set_timing: on = mode (0, 1, 2, 3) + 256 * stride");
   ctx->timing = mode != 0;
