@@ -240,7 +240,7 @@ template <int L, int C, int PB>
 struct SweepHand {
   double tp[ABZ_HAND_SLOTS(PB)][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
   double wl[PB], kdi[PB], logu[PB];             /* lp - lpi, K(di), log(rand) of smc:140-145 (lp itself is re-evaluated in phase 2) */
-  uint8_t pos[PB];                              /* position inside the tile | own slot bit << 7 */
+  uint16_t pos[PB];                             /* position inside the tile | own slot bit << 15 */
 };
 /* LDS of the two-phase d = 32 kernel: 7 KB sampler tables + 1.8 KB model + 16 KB rows + 1.6 KB scalars = 27,000 B: room for six
  * workgroups per CU (163,840 / 6 = 27,306) -- the hand-over carries no more than it must */
@@ -260,7 +260,8 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
   constexpr int PB = ABZ_BLOCK / L;
   constexpr int GW = 64 / L;                        /* lane groups per wavefront */
-  static_assert(PB % 32 == 0 && PB <= 128 && L >= 2 && C >= 2 && (C & 1) == 0, "two-phase sweep: 2 <= lanes <= 8, an even number of components per lane");
+  static_assert(PB % 32 == 0 && L >= 1 && L <= 8 && C >= 2 && (C & 1) == 0 && !ABZ_ROWS_DOUBLE_BUFFERED(LD),
+                "two-phase sweep: 1 <= lanes <= 8, an even number of components per lane, rows of more than two doubles");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;      /* serpentine order: smc_swarm_packed_body_1p */
@@ -322,7 +323,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       for (int m = 0; m < C / 2; ++m) { double2 t; t.x = tp[2 * m]; t.y = tp[2 * m + 1]; row[hand_unit<L, C>(slot, m, j)] = t; }
       if (j == 0) {
         s_hand.wl[slot] = wl; s_hand.kdi[slot] = kdi; s_hand.logu[slot] = log_u;
-        s_hand.pos[slot] = (uint8_t)((ri - tile_base) | (bi << 7));
+        s_hand.pos[slot] = (uint16_t)((ri - tile_base) | (bi << 15));
       }
     }
     if (active && j == 0 && insupport && a.flags) atomicOr(&s_ins[(threadIdx.x / L) >> 5], 1u << ((threadIdx.x / L) & 31u));
@@ -345,7 +346,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
        * same bits -- for 45 instructions of the few wavefronts that get here, instead of 512 bytes of LDS in every workgroup */
       const double lps = group_logprior<L, C, PLAIN>(s_model.prior, j, tq, pq, M.mv);
       const uint32_t pw = s_hand.pos[slot];
-      const uint32_t rs = tile_base + (pw & 0x7Fu), bs = pw >> 7;
+      const uint32_t rs = tile_base + (pw & 0x7FFFu), bs = pw >> 15;
       const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
       const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
       acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
@@ -380,12 +381,15 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
                                                  (((s_ins[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) << 1));
 }
 
-/* one-phase body for rows held by a single lane (every simulator but the d-dimensional Normal) and for the widest lane groups;
- * two phases wherever a row is spread over 2, 4 or 8 lanes.  ABZ_SWEEP_ONE_PHASE forces the former (A/B measurements). */
+/* Two phases wherever a skipped simulation is worth a hand-over through LDS: rows spread over 2, 4 or 8 lanes (the d-dimensional
+ * Normal simulator: four Philox blocks and Box-Muller pairs per lane), and the Lotka-Volterra simulator (1500 RK4 steps per call; with
+ * its bounded prior half of the proposals and more leave the support, smc:135, and in the one-phase body their lanes idle through
+ * their wave-mates' simulations).  One phase for the rest: the cheap one-lane simulators, rows of one or two doubles (double-buffered),
+ * the widest lane groups.  ABZ_SWEEP_ONE_PHASE forces the one-phase body everywhere (A/B measurements). */
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
 #ifndef ABZ_SWEEP_ONE_PHASE
-  if constexpr (L >= 2 && L <= 8 && C >= 2 && C <= 8) smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
+  if constexpr ((L >= 2 && L <= 8 && C >= 2 && C <= 8) || (SIM == ABZ_SIM_LV && L == 1 && C == 4)) smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
   else
 #endif
     smc_swarm_packed_body_1p<SIM, L, C, PLAIN>(a);

@@ -230,6 +230,10 @@ def wide_models():
                                  for k in range(32)]), A.MVNormal(tuple([0.25 * (k % 5) for k in range(32)])), (4, 8)),
         "mv16": (A.MvNormal(np.linspace(-0.5, 0.5, 16), cov), A.MVNormal(tuple([0.2] * 16)), (2, 4)),
         "narrow_normal32": (A.Factored(*[A.Normal(0.0, 0.3) for _ in range(32)]), A.MVNormal(tuple([1.0] * 32)), (4,)),
+        # one lane per particle, two phases all the same: the simulator is 160 RK4 steps and most proposals leave the prior's box
+        "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
+               A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6, 0.9, 0.5),
+                                  dt=0.05, steps_per_obs=20), (1,)),
     }
 
 
