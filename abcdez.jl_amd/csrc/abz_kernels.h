@@ -384,12 +384,13 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
 /* Two phases wherever a skipped simulation is worth a hand-over through LDS: rows spread over 2, 4 or 8 lanes (the d-dimensional
  * Normal simulator: four Philox blocks and Box-Muller pairs per lane), and the Lotka-Volterra simulator (1500 RK4 steps per call; with
  * its bounded prior half of the proposals and more leave the support, smc:135, and in the one-phase body their lanes idle through
- * their wave-mates' simulations).  One phase for the rest: the cheap one-lane simulators, rows of one or two doubles (double-buffered),
- * the widest lane groups.  ABZ_SWEEP_ONE_PHASE forces the one-phase body everywhere (A/B measurements). */
+ * their wave-mates' simulations), and user-supplied simulators of 3 to 8 parameters (cost unknown, usually the bulk of the sweep).
+ * One phase for the rest: the cheap one-lane simulators, rows of one or two doubles (double-buffered), the widest lane groups.  ABZ_SWEEP_ONE_PHASE forces the one-phase body everywhere (A/B measurements). */
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
 #ifndef ABZ_SWEEP_ONE_PHASE
-  if constexpr ((L >= 2 && L <= 8 && C >= 2 && C <= 8) || (SIM == ABZ_SIM_LV && L == 1 && C == 4)) smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
+  if constexpr ((L >= 2 && L <= 8 && C >= 2 && C <= 8) || ((SIM == ABZ_SIM_LV || SIM == ABZ_SIM_USER) && L == 1 && (C == 4 || C == 8)))
+    smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
   else
 #endif
     smc_swarm_packed_body_1p<SIM, L, C, PLAIN>(a);

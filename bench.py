@@ -311,18 +311,22 @@ def lv_flops_per_update(sim):
     return (nobs - 1) * sim.steps_per_obs * 50 + nobs * 10
 
 
-def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 22):
+def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 22, sim_rate=1.0):
     avg_ms = kern_ms / max(launches, 1)
     upl = units / max(launches, 1)
     rate = upl / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
     if args_config == "lv":
+        # flops of the simulator calls that are MADE: the in-support proposals (sim_rate = nsims / updates of the timed window).  An
+        # out-of-support proposal (smc:135) costs no arithmetic -- in rounds 1-4 its lane idled through its wave-mates' simulations
+        # and the figure charged every update a full simulation (issue slots, not flops); the two-phase body packs the calls densely
         fl = lv_flops_per_update(cfg["sim"])
-        ach = fl * rate / 1e12
+        ach = fl * rate * sim_rate / 1e12
         return {"kernel": "smc_swarm_packed_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "peak_origin": FP64_VALU_PEAK_ORIGIN,
-                "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per update; the row traffic "
-                        "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl,
-                "rk4_steps_per_s": rate * (len(cfg["sim"].obs) // 2 - 1) * cfg["sim"].steps_per_obs,
+                "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per SIMULATED proposal (in support of "
+                        "the prior, smc:135-137); achieved = flops per simulation x simulations per second; the row traffic "
+                        "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl, "simulated_fraction_of_updates": sim_rate,
+                "rk4_steps_per_s": rate * sim_rate * (len(cfg["sim"].obs) // 2 - 1) * cfg["sim"].steps_per_obs,
                 "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches, "kernel_updates_per_s": rate}
     d = cfg["d"]
     if kind == "mc":
@@ -517,6 +521,7 @@ def run_config(args):
     tstride = 2 if cfg["kind"] == "smc" else 10
     eng.ops.set_timing((args.timing_mode if cfg["kind"] == "smc" and not eng.sharded_packed else 2) + 256 * tstride)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
+    n0 = getattr(gen, "nsims", 0)
     barrier()
     t0 = time.perf_counter()
     trace = [] if os.environ.get("ABZ_BENCH_TRACE_STEPS") else None       # diagnostic: per-step host times to stderr
@@ -638,7 +643,8 @@ def run_config(args):
                 "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
             },
-            "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N),
+            "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N,
+                                 sim_rate=((gen.nsims - n0) / max(updates, 1)) if cfg["kind"] == "smc" else 1.0),
         }
         out["roofline"]["timed_every_nth_step"] = tstride     # which steps carried the HIP-event pair (mode 3: around all their sweeps; mode 2: around one, in turn)
         out["roofline"]["timing_mode"] = args.timing_mode if cfg["kind"] == "smc" and not eng.sharded_packed else 2

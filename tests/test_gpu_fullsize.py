@@ -450,6 +450,51 @@ def test_user_simulator_equals_builtin(oracle, which):
     assert np.array_equal(m.engine.result()["theta"], cm["theta"])
 
 
+USER_LV = """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  const double a = th[0], b = th[1], c = th[2], e = th[3];
+  double x = p[0], y = p[1];
+  const double h = p[2], h2 = 0.5 * h, h6 = h / 6.0, sn = p[4];
+  const int steps = (int)p[3], nobs = n_data / 2;
+  double acc = 0.0;
+  for (int jo = 0; jo < nobs; ++jo) {
+    double z0, z1; rng.normal_pair(z0, z1);
+    const double ex = abz_fma(sn, z0, x) - data[2 * jo], ey = abz_fma(sn, z1, y) - data[2 * jo + 1];
+    acc = abz_fma(ex, ex, acc); acc = abz_fma(ey, ey, acc);
+    if (jo + 1 == nobs) break;
+    for (int s = 0; s < steps; ++s) {
+      const double k1x = x * abz_fma(-b, y, a), k1y = y * abz_fma(e, x, -c);
+      const double xa = abz_fma(h2, k1x, x), ya = abz_fma(h2, k1y, y);
+      const double k2x = xa * abz_fma(-b, ya, a), k2y = ya * abz_fma(e, xa, -c);
+      const double xb = abz_fma(h2, k2x, x), yb = abz_fma(h2, k2y, y);
+      const double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
+      const double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
+      const double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
+      x = abz_fma(h6, abz_fma(2.0, k2x, k1x) + abz_fma(2.0, k3x, k4x), x);
+      y = abz_fma(h6, abz_fma(2.0, k2y, k1y) + abz_fma(2.0, k3y, k4y), y);
+    }
+  }
+  return abz_sqrt(acc);
+}
+"""
+
+
+def test_user_simulator_of_four_parameters_runs_the_two_phase_sweep(oracle):
+    """a user simulator with 3 to 8 parameters takes the two-phase sweep (csrc/abz_kernels.h: the simulator runs only for proposals
+    that are in the prior's support and not already rejected on the prior ratio, densely packed): the Lotka-Volterra model restated
+    as HIP source must equal the built-in simulator -- hence the oracle, which simulates every in-support proposal -- bit for bit"""
+    obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6)
+    prior = A.Factored(*[A.Uniform(0.0, 2.0)] * 4)
+    builtin = A.LotkaVolterraRK4(obs, dt=0.05, steps_per_obs=10)
+    user = A.UserSimulator(USER_LV, params=(builtin.x0, builtin.y0, builtin.dt, float(builtin.steps_per_obs), builtin.noise), data=obs)
+    N, eps = 6000, 1.2
+    r = A.abcdesmc(prior, user, eps, None, nparticles=N, verbose=False, rng=17)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, builtin, seed=17), N, eps)
+    res = r.engine.result()
+    assert r.logZ == c["logZ"] and r.nsims == c["nsims"] and r.iters == c["iters"]
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"])
+
+
 def test_user_simulator_with_blobs(oracle):
     """a user simulator that also defines abz_user_blob: its blobs equal the built-in Normal1D simulator's"""
     src = """

@@ -1,0 +1,9 @@
+# Round 5: user simulators through the two-phase sweep (parity), the Lotka-Volterra profile set and the default bench line of the final tree
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+timeout 900 python3 -m pytest $R/tests -m gpu -x -q > $O/r05_b11_pytest.log 2>&1 || { tail -40 $O/r05_b11_pytest.log; exit 1; }
+tail -3 $O/r05_b11_pytest.log
+TAG=r05 CFG=lv PMC=0 bash $R/tools/profile_round.sh
+timeout 900 python3 $R/bench.py > $O/r05_bench_line.log 2>&1; grep '^{' $O/r05_bench_line.log | tail -1 > $O/r05_bench_line.json; python3 $R/tools/show_bench.py $O/r05_bench_line.json 2>/dev/null | cut -c1-250 | head -24
