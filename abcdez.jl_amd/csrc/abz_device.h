@@ -277,6 +277,47 @@ __device__ double abz_user_dist(const double* theta, int d, const double* data, 
 __device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data, const double* sim_p,
                               abz_user_rng& rng, double* blob, int n_blob);
 
+/* ---- Lotka-Volterra (ABZ_SIM_LV; BASELINE.json configs[3]): one observation and one interval of RK4 steps, shared by sim_dist and by
+ * the round-by-round second phase of the two-phase sweep (abz_kernels.h) -- the same operations in the same order either way */
+struct LvConst { double h, h2, h6, sn; int steps, nobs; };
+__device__ inline LvConst lv_const(const HotModel& M) {
+  LvConst k;
+  k.h = M.sim_p[2]; k.h2 = 0.5 * k.h; k.h6 = k.h / 6.0; k.sn = M.sim_p[4];
+  /* the trip count as an integer kernel argument (scalar register): taken from the f64 parameter it would be born in a vector
+   * register -- there is no scalar f64 -> i32 conversion -- and the compiler would keep the loop counter there, two of the loop's
+   * 32 vector instructions */
+  k.steps = M.sim_i[0]; k.nobs = M.n_data / 2;
+  return k;
+}
+/* observation jo: (x, y) + N(0, noise^2) against data[2 jo], data[2 jo + 1]; the squared errors join the running sum */
+template <bool BLOB>
+__device__ inline void lv_observe(const HotModel& M, const abz_tables* T, const LvConst& k, uint32_t i, uint32_t epoch, uint32_t purpose,
+                                  int jo, double x, double y, double& acc, double* blob) {
+  double z0, z1;
+  abz_normal_pair(abz_rng(M.seed, i, epoch, (uint32_t)jo, purpose), T, &z0, &z1);
+  const double ox = abz_fma(k.sn, z0, x), oy = abz_fma(k.sn, z1, y);
+  if constexpr (BLOB) { if (2 * jo + 1 < ABZ_MAX_BLOB) { blob[2 * jo] = ox; blob[2 * jo + 1] = oy; } }
+  const double ex = ox - M.data[2 * jo];
+  const double ey = oy - M.data[2 * jo + 1];
+  acc = abz_fma(ex, ex, acc);
+  acc = abz_fma(ey, ey, acc);
+}
+/* the RK4 steps between two observations */
+__device__ inline void lv_advance(const LvConst& k, double a, double b, double c, double e, double& x, double& y) {
+  const double h = k.h, h2 = k.h2, h6 = k.h6;
+  for (int s = 0; s < k.steps; ++s) {
+    const double k1x = x * abz_fma(-b, y, a), k1y = y * abz_fma(e, x, -c);
+    const double xa = abz_fma(h2, k1x, x), ya = abz_fma(h2, k1y, y);
+    const double k2x = xa * abz_fma(-b, ya, a), k2y = ya * abz_fma(e, xa, -c);
+    const double xb = abz_fma(h2, k2x, x), yb = abz_fma(h2, k2y, y);
+    const double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
+    const double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
+    const double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
+    x = abz_fma(h6, abz_fma(2.0, k2x, k1x) + abz_fma(2.0, k3x, k4x), x);   /* 2 k is exact: the same bits as (k1 + 2 k2) + (2 k3 + k4) */
+    y = abz_fma(h6, abz_fma(2.0, k2y, k1y) + abz_fma(2.0, k3y, k4y), y);
+  }
+}
+
 /* FULL: d == ld (no padding components), so the MVN simulator skips its `k < d` selects -- same values */
 template <int SIM, int L, int C, bool BLOB = false, bool FULL = false>
 __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j, const double (&th)[C],
@@ -359,37 +400,13 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     }
     return acc / (double)n;
   } else if constexpr (SIM == ABZ_SIM_LV) {
-    const double a = th[0], b = th[1], c = th[2], e = th[3];
+    const LvConst k = lv_const(M);
     double x = M.sim_p[0], y = M.sim_p[1];
-    const double h = M.sim_p[2], h2 = 0.5 * h, h6 = h / 6.0;
-    /* the trip count as an integer kernel argument (scalar register): taken from the f64 parameter it would be born in a vector
-     * register -- there is no scalar f64 -> i32 conversion -- and the compiler would keep the loop counter there, two of the loop's
-     * 32 vector instructions */
-    const int steps = M.sim_i[0];
-    const double sn = M.sim_p[4];
-    const int nobs = M.n_data / 2;
     double acc = 0.0;
-    for (int jo = 0; jo < nobs; ++jo) {
-      double z0, z1;
-      abz_normal_pair(abz_rng(seed, i, epoch, (uint32_t)jo, purpose), T, &z0, &z1);
-      const double ox = abz_fma(sn, z0, x), oy = abz_fma(sn, z1, y);
-      if constexpr (BLOB) { if (2 * jo + 1 < ABZ_MAX_BLOB) { blob[2 * jo] = ox; blob[2 * jo + 1] = oy; } }
-      const double ex = ox - M.data[2 * jo];
-      const double ey = oy - M.data[2 * jo + 1];
-      acc = abz_fma(ex, ex, acc);
-      acc = abz_fma(ey, ey, acc);
-      if (jo + 1 == nobs) break;
-      for (int s = 0; s < steps; ++s) {
-        const double k1x = x * abz_fma(-b, y, a), k1y = y * abz_fma(e, x, -c);
-        const double xa = abz_fma(h2, k1x, x), ya = abz_fma(h2, k1y, y);
-        const double k2x = xa * abz_fma(-b, ya, a), k2y = ya * abz_fma(e, xa, -c);
-        const double xb = abz_fma(h2, k2x, x), yb = abz_fma(h2, k2y, y);
-        const double k3x = xb * abz_fma(-b, yb, a), k3y = yb * abz_fma(e, xb, -c);
-        const double xc = abz_fma(h, k3x, x), yc = abz_fma(h, k3y, y);
-        const double k4x = xc * abz_fma(-b, yc, a), k4y = yc * abz_fma(e, xc, -c);
-        x = abz_fma(h6, abz_fma(2.0, k2x, k1x) + abz_fma(2.0, k3x, k4x), x);   /* 2 k is exact: the same bits as (k1 + 2 k2) + (2 k3 + k4) */
-        y = abz_fma(h6, abz_fma(2.0, k2y, k1y) + abz_fma(2.0, k3y, k4y), y);
-      }
+    for (int jo = 0; jo < k.nobs; ++jo) {
+      lv_observe<BLOB>(M, T, k, i, epoch, purpose, jo, x, y, acc, blob);
+      if (jo + 1 == k.nobs) break;
+      lv_advance(k, th[0], th[1], th[2], th[3], x, y);
     }
     return abz_sqrt(acc);
   } else if constexpr (SIM == ABZ_SIM_USER) {

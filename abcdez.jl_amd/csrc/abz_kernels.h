@@ -335,6 +335,80 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
     const unsigned n = s_n;
     const unsigned sg = threadIdx.x / L;
     bool acc = false;
+    if constexpr (SIM == ABZ_SIM_LV && L == 1) {
+      /* Lotka-Volterra: the distance is a running sum of squared errors over the observations (abz_device.h, lv_observe), so it
+       * only grows -- once it has passed eps^2 the proposal is rejected whatever the rest of the trajectory does (every ABC kernel
+       * is zero beyond eps, types.jl:26-73; K(dp) = -Inf makes w -Inf or NaN, smc:140-145), and the 100 RK4 steps to the next
+       * observation need not be made.  As with the skipped simulator calls this only pays when whole wavefronts stop, so phase 2 runs
+       * ROUND BY ROUND: one observation + one interval per round for the proposals still alive, which are re-packed into the
+       * leading lanes after every round.  State lives in LDS by hand-over slot; a proposal that survives every round has had
+       * exactly sim_dist's operations in sim_dist's order. */
+      __shared__ double s_lx[PB], s_ly[PB], s_lacc[PB];
+      __shared__ uint16_t s_list[2][PB];
+      __shared__ unsigned int s_live[3];
+      const LvConst k = lv_const(M);
+      /* certain rejection: acc >= bound > eps^2 (1 + 2^-41) => sqrt(acc) > eps for the strict and the non-strict kernels alike;
+       * eps = Inf or 0: never (bound NaN): dp = Inf is in the support of Indicator0toeps(Inf), dp = 0 in that of Indicator0toeps(0) */
+#ifdef ABZ_LV_NO_EARLY_EXIT            /* A/B builds: the same rounds, nobody leaves early */
+      const double bound = ABZ_NAN;
+#else
+      const double bound = (a.eps > 0.0 && a.eps < 1.0e300) ? (a.eps * a.eps) * (1.0 + 0x1p-40) : ABZ_NAN;
+#endif
+      if (threadIdx.x < n) { s_list[0][threadIdx.x] = (uint16_t)threadIdx.x; s_lx[threadIdx.x] = M.sim_p[0]; s_ly[threadIdx.x] = M.sim_p[1]; s_lacc[threadIdx.x] = 0.0; }
+      if (threadIdx.x < 3) s_live[threadIdx.x] = 0u;
+      __syncthreads();
+      unsigned n_live = n;
+      int cur = 0;
+      const unsigned lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
+      for (int jo = 0; jo < k.nobs; ++jo) {
+        if (wave0 < n_live) {                                      /* wave-uniform: this wavefront still has proposals */
+          const bool on = threadIdx.x < n_live;
+          const unsigned sl = s_list[cur][on ? threadIdx.x : 0u];  /* idle lanes of a working wave shadow the first proposal */
+          const double2* row = reinterpret_cast<const double2*>(s_hand.tp[sl]);
+          double tq[C], pq[C];
+#pragma unroll
+          for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>((int)sl, m, 0)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
+          group_push_p<L, C>(s_model.prior, 0, tq, pq);
+          double x = s_lx[sl], y = s_ly[sl], dsum = s_lacc[sl];
+          const uint32_t rs = tile_base + (s_hand.pos[sl] & 0x7FFFu);
+          lv_observe<false>(M, &s_model.tab, k, rs, a.sweep, ABZ_RNG_SIM, jo, x, y, dsum, nullptr);
+          const bool dead = dsum >= bound;                         /* (false for a NaN sum: it stays, and is rejected at the end) */
+          if (jo + 1 < k.nobs) lv_advance(k, pq[0], pq[1], pq[2], pq[3], x, y);
+          const bool keep = on && !dead;
+          if (keep) { s_lx[sl] = x; s_ly[sl] = y; s_lacc[sl] = dsum; }
+          const unsigned long long mk = __ballot(keep);
+          unsigned int base = 0u;
+          if (lane == 0u && mk) base = atomicAdd(&s_live[jo % 3], (unsigned)__popcll(mk));
+          base = __shfl(base, 0, 64);
+          if (keep) s_list[1 - cur][base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+        }
+        __syncthreads();
+        n_live = s_live[jo % 3];
+        if (threadIdx.x == 0) s_live[(jo + 2) % 3] = 0u;           /* the counter of the round after next (last read a round ago) */
+        cur = 1 - cur;
+      }
+      if (wave0 < n_live) {                                        /* the proposals whose distance stayed below the bound to the end */
+        const bool on = threadIdx.x < n_live;
+        const unsigned sl = s_list[cur][on ? threadIdx.x : 0u];
+        const double2* row = reinterpret_cast<const double2*>(s_hand.tp[sl]);
+        double tq[C], pq[C];
+#pragma unroll
+        for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>((int)sl, m, 0)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
+        const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+        const uint32_t pw = s_hand.pos[sl];
+        const uint32_t rs = tile_base + (pw & 0x7FFFu), bs = pw >> 15;
+        const double ds = abz_sqrt(s_lacc[sl]);                                                                    /* smc:137 */
+        const double w = (s_hand.wl[sl] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[sl];                  /* smc:140-141 */
+        acc = on && ((0.0 <= w) || (s_hand.logu[sl] < w));         /* smc:145 */
+        if (acc) {                                                 /* smc:146-150 */
+          store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, 0, tq);
+          const uint32_t t = rs - tile_base;
+          atomicOr(&s_acc[t >> 5], 1u << (t & 31u));
+          a.logpi[rs] = lps; a.delta[rs] = ds;
+          if (a.stamp) a.stamp[rs] = abz_stamp(rs, a.sweep, 0);
+        }
+      }
+    } else
     if ((threadIdx.x >> 6) * (unsigned)GW < n) {                  /* wave-uniform: this wavefront has at least one slot */
       const bool on = sg < n;
       const int slot = on ? (int)sg : 0;                          /* idle groups of a working wave shadow slot 0: shuffles stay converged */
