@@ -68,12 +68,12 @@ struct ModelLds {
 
 /* two phases so the global loads can be issued early (before the wave's dependent loads)
  * and the LDS writes + barrier placed right before the first use */
-template <int SIM, int LD>
+template <int SIM, int LD, int BLOCK = ABZ_BLOCK>
 struct ModelStage {
   static constexpr int W = LD * (int)(sizeof(abz_prior_dim) / 8);
-  static constexpr int NW = (W + ABZ_BLOCK - 1) / ABZ_BLOCK;
+  static constexpr int NW = (W + BLOCK - 1) / BLOCK;
   static constexpr int NU = (int)(sizeof(abz_tables) / 16);                /* 16-byte pieces of the tables (7 KB: 448) */
-  static constexpr int NT = (NU + ABZ_BLOCK - 1) / ABZ_BLOCK;              /* ... per thread; the last round is partial */
+  static constexpr int NT = (NU + BLOCK - 1) / BLOCK;              /* ... per thread; the last round is partial */
   static_assert(sizeof(abz_tables) % 16 == 0, "the tables are staged in 16-byte pieces");
   uint64_t w[NW];
   double2 tb[NT];
@@ -84,13 +84,13 @@ struct ModelStage {
     for (int q = 0; q < NT; ++q) {      /* every element is assigned (threads past the end re-read piece 0): a conditionally written
                                          * array stays in scratch memory -- 16 bytes per lane out to HBM and back, measured as +128 B
                                          * of fabric traffic per update (profiles/HISTORY.md, round 5) */
-      const int t = threadIdx.x + q * ABZ_BLOCK;
-      tb[q] = tsrc[(NU % ABZ_BLOCK == 0 || t < NU) ? t : 0];
+      const int t = threadIdx.x + q * BLOCK;
+      tb[q] = tsrc[(NU % BLOCK == 0 || t < NU) ? t : 0];
     }
     const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(M.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-      const int t = threadIdx.x + q * ABZ_BLOCK;
+      const int t = threadIdx.x + q * BLOCK;
       w[q] = t < W ? src[t] : 0ull;
     }
     y = 0.0;
@@ -102,13 +102,13 @@ struct ModelStage {
     double2* tdst = reinterpret_cast<double2*>(&s.tab);
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      const int t = threadIdx.x + q * ABZ_BLOCK;
-      if (NU % ABZ_BLOCK == 0 || t < NU) tdst[t] = tb[q];
+      const int t = threadIdx.x + q * BLOCK;
+      if (NU % BLOCK == 0 || t < NU) tdst[t] = tb[q];
     }
     uint64_t* dst = reinterpret_cast<uint64_t*>(s.prior);
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
-      const int t = threadIdx.x + q * ABZ_BLOCK;
+      const int t = threadIdx.x + q * BLOCK;
       if (t < W) dst[t] = w[q];
     }
     if ((int)threadIdx.x < LD) s.y[threadIdx.x] = y;
@@ -509,15 +509,17 @@ __device__ inline void particle_draws(const abz_tables* T, uint64_t seed, uint32
  * Same-address atomics serialise (10^5 of them on ONE address per launch were the bottleneck of the first build, ~15 ns
  * each); spread over 256 lines they overlap the kernel, and because the slots are cumulative nothing has to be zeroed or
  * reduced by another launch.  Ends with no barrier pending; must be reached by every thread of the block.       */
+template <int BLOCK = ABZ_BLOCK>
 __device__ inline void block_count2(unsigned int x, unsigned int y, unsigned long long* __restrict__ cslots, uint32_t cls) {
-  __shared__ unsigned int s_cnt[2][ABZ_BLOCK / 64];
+  __shared__ unsigned int s_cnt[2][BLOCK / 64];
 #pragma unroll
   for (int off = 32; off; off >>= 1) { x += __shfl_xor(x, off, 64); y += __shfl_xor(y, off, 64); }
   if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = x; s_cnt[1][threadIdx.x >> 6] = y; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long xs = (unsigned long long)s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-    const unsigned long long ys = (unsigned long long)s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    unsigned long long xs = 0, ys = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { xs += s_cnt[0][w]; ys += s_cnt[1][w]; }
     unsigned long long* s = cslots + (size_t)(blockIdx.x & (ABZ_CSLOTS - 1)) * ABZ_CSTRIDE + cls;
     if (xs) (void)__hip_atomic_fetch_add(s, xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ys) (void)__hip_atomic_fetch_add(s + 1, ys, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

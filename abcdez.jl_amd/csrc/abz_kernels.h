@@ -9,6 +9,9 @@
 
 #include "abz_device.h"
 
+#ifndef ABZ_LV_BLOCK
+#define ABZ_LV_BLOCK 512                                  /* threads per workgroup of the Lotka-Volterra sweep (abz_sweep_block) */
+#endif
 #define ABZ_REPLAY_PER 8                                  /* alive ranks per thread in the scan phase of the replay kernels */
 #define ABZ_REPLAY_CHUNK (ABZ_BLOCK * ABZ_REPLAY_PER)     /* alive ranks per block */
 
@@ -255,17 +258,17 @@ __device__ inline void group_push_p(const abz_prior_dim* pd, int j, const double
   for (int q = 0; q < C; ++q) pp[q] = abz_push_p(&pd[Lay<L, C>::comp(j, q / 2, q & 1)], p[q]);
 }
 
-template <int SIM, int L, int C, bool PLAIN = false>
+template <int SIM, int L, int C, bool PLAIN = false, int BLOCK = ABZ_BLOCK>
 __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   constexpr int LD = L * C;
-  constexpr int PB = ABZ_BLOCK / L;
+  constexpr int PB = BLOCK / L;
   constexpr int GW = 64 / L;                        /* lane groups per wavefront */
   static_assert(PB % 32 == 0 && L >= 1 && L <= 8 && C >= 2 && (C & 1) == 0 && !ABZ_ROWS_DOUBLE_BUFFERED(LD),
                 "two-phase sweep: 1 <= lanes <= 8, an even number of components per lane, rows of more than two doubles");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;      /* serpentine order: smc_swarm_packed_body_1p */
-  const uint32_t gid = tile * ABZ_BLOCK + threadIdx.x;
+  const uint32_t gid = tile * BLOCK + threadIdx.x;
   const uint32_t grp = gid / L;
   const int j = (int)(gid % L);
   const bool active = grp < a.n_work;
@@ -278,7 +281,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   __shared__ uint32_t s_n;
 
   /* ---------------- phase 1: order of issue = order of need (smc_swarm_packed_body_1p) */
-  ModelStage<SIM, LD> stage;
+  ModelStage<SIM, LD, BLOCK> stage;
   stage.load(M);
   const uint32_t wi = a.bits[ri >> 5];
   ParticleDraws<L> draws;
@@ -360,7 +363,14 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       unsigned n_live = n;
       int cur = 0;
       const unsigned lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
-      for (int jo = 0; jo < k.nobs; ++jo) {
+      /* ABZ_LV_ROUND observations (and the intervals behind them) per round: a round ends with a workgroup barrier, at which the
+       * working wavefronts wait for the slowest of them -- measured: 1 per round costs 4 % of the sweep where few proposals leave
+       * early (profiles/r05_lv_early_exit_ab.jsonl) */
+#ifndef ABZ_LV_ROUND
+#define ABZ_LV_ROUND 2
+#endif
+      int round = 0;
+      for (int jo0 = 0; jo0 < k.nobs; jo0 += ABZ_LV_ROUND, ++round) {
         if (wave0 < n_live) {                                      /* wave-uniform: this wavefront still has proposals */
           const bool on = threadIdx.x < n_live;
           const unsigned sl = s_list[cur][on ? threadIdx.x : 0u];  /* idle lanes of a working wave shadow the first proposal */
@@ -371,20 +381,23 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
           group_push_p<L, C>(s_model.prior, 0, tq, pq);
           double x = s_lx[sl], y = s_ly[sl], dsum = s_lacc[sl];
           const uint32_t rs = tile_base + (s_hand.pos[sl] & 0x7FFFu);
-          lv_observe<false>(M, &s_model.tab, k, rs, a.sweep, ABZ_RNG_SIM, jo, x, y, dsum, nullptr);
-          const bool dead = dsum >= bound;                         /* (false for a NaN sum: it stays, and is rejected at the end) */
-          if (jo + 1 < k.nobs) lv_advance(k, pq[0], pq[1], pq[2], pq[3], x, y);
+          bool dead = false;
+          for (int jo = jo0; jo < jo0 + ABZ_LV_ROUND && jo < k.nobs; ++jo) {
+            lv_observe<false>(M, &s_model.tab, k, rs, a.sweep, ABZ_RNG_SIM, jo, x, y, dsum, nullptr);
+            dead = dead || (dsum >= bound);                        /* (false for a NaN sum: it stays, and is rejected at the end) */
+            if (jo + 1 < k.nobs) lv_advance(k, pq[0], pq[1], pq[2], pq[3], x, y);
+          }
           const bool keep = on && !dead;
           if (keep) { s_lx[sl] = x; s_ly[sl] = y; s_lacc[sl] = dsum; }
           const unsigned long long mk = __ballot(keep);
           unsigned int base = 0u;
-          if (lane == 0u && mk) base = atomicAdd(&s_live[jo % 3], (unsigned)__popcll(mk));
+          if (lane == 0u && mk) base = atomicAdd(&s_live[round % 3], (unsigned)__popcll(mk));
           base = __shfl(base, 0, 64);
           if (keep) s_list[1 - cur][base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)sl;
         }
         __syncthreads();
-        n_live = s_live[jo % 3];
-        if (threadIdx.x == 0) s_live[(jo + 2) % 3] = 0u;           /* the counter of the round after next (last read a round ago) */
+        n_live = s_live[round % 3];
+        if (threadIdx.x == 0) s_live[(round + 2) % 3] = 0u;        /* the counter of the round after next (last read a round ago) */
         cur = 1 - cur;
       }
       if (wave0 < n_live) {                                        /* the proposals whose distance stayed below the bound to the end */
@@ -444,7 +457,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
         }
       }
     }
-    block_count2((j == 0 && acc) ? 1u : 0u, nsim1, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
+    block_count2<BLOCK>((j == 0 && acc) ? 1u : 0u, nsim1, a.cslots, a.c_cls);      /* (its barrier publishes s_acc) */
   }
   if (threadIdx.x < PB / 32) {
     const uint32_t w = tile_base / 32u + threadIdx.x;
@@ -460,11 +473,21 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
  * its bounded prior half of the proposals and more leave the support, smc:135, and in the one-phase body their lanes idle through
  * their wave-mates' simulations), and user-supplied simulators of 3 to 8 parameters (cost unknown, usually the bulk of the sweep).
  * One phase for the rest: the cheap one-lane simulators, rows of one or two doubles (double-buffered), the widest lane groups.  ABZ_SWEEP_ONE_PHASE forces the one-phase body everywhere (A/B measurements). */
+/* threads per workgroup of the sweep: 512 for the Lotka-Volterra simulator -- about a third of a tile's proposals reach phase 2, and
+ * 170 of 512 fill three wavefronts to 89 % where 85 of 256 fill two to 67 % (the simulator is all of that kernel's time) */
+template <int SIM, int L, int C>
+constexpr int abz_sweep_block() {
+#ifndef ABZ_SWEEP_ONE_PHASE
+  return (SIM == ABZ_SIM_LV && L == 1 && C == 4) ? ABZ_LV_BLOCK : ABZ_BLOCK;
+#else
+  return ABZ_BLOCK;
+#endif
+}
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
 #ifndef ABZ_SWEEP_ONE_PHASE
   if constexpr ((L >= 2 && L <= 8 && C >= 2 && C <= 8) || ((SIM == ABZ_SIM_LV || SIM == ABZ_SIM_USER) && L == 1 && (C == 4 || C == 8)))
-    smc_swarm_packed_body_2p<SIM, L, C, PLAIN>(a);
+    smc_swarm_packed_body_2p<SIM, L, C, PLAIN, abz_sweep_block<SIM, L, C>()>(a);
   else
 #endif
     smc_swarm_packed_body_1p<SIM, L, C, PLAIN>(a);

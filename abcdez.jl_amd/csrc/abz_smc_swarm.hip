@@ -23,7 +23,7 @@
 #define ABZ_SWEEP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ABZ_SWEEP_WAVES, ABZ_SWEEP_WAVES)))
 #endif
 template <int SIM, int L, int C, bool PLAIN>
-__global__ __launch_bounds__(ABZ_BLOCK) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
+__global__ __launch_bounds__((abz_sweep_block<SIM, L, C>())) ABZ_SWEEP_WAVES_ATTR void smc_swarm_packed_kernel(const SmcPackedArgs a) {
   smc_swarm_packed_body<SIM, L, C, PLAIN>(a);
 }
 /* Occupancy of the two-phase 4 x 8 kernel (d = 32): 81 registers, 27,000 B of LDS -- five waves per SIMD as the compiler leaves it.
@@ -51,7 +51,7 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   a.rev = ctx->serpentine ? (uint32_t)(ctx->sweep_launch_seq++ & 1) : 0u;
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
-  const unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+  unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
   const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
@@ -59,10 +59,12 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {
+        constexpr unsigned BLK = (unsigned)abz_sweep_block<S(), LL(), CC()>();       /* 256 threads, 512 for Lotka-Volterra */
+        const unsigned nb = (unsigned)(((uint64_t)a.n_work * (uint64_t)LL() + BLK - 1) / BLK);
         if (ctx->prior_plain)
-          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), true>), dim3(nb), dim3(BLK), 0, ctx->stream, a);
         else
-          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), false>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);
+          hipLaunchKernelGGL((smc_swarm_packed_kernel<S(), LL(), CC(), false>), dim3(nb), dim3(BLK), 0, ctx->stream, a);
       }
     });
   }
