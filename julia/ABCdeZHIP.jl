@@ -453,6 +453,17 @@ end
 function mc_generation_issue!(e, α, ϵ_target, γ0, γσ, lo_hi, do_rank::Bool)
     t = Ref(Int64(0)); o = other(e); bind_stamps!(e)
     lh = lo_hi === nothing ? C_NULL : pointer(lo_hi)
+    if e.world > 1
+        # sharded over the library's communicator: this rank sweeps its own particles, the library exchanges the new rows and the
+        # generation's reductions (one group of RCCL collectives on its stream); tickets and their results as on one GPU
+        GC.@preserve lo_hi check(ccall((:abcdez_mc_generation_sharded_async, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Float64, Float64, Ptr{Float64}, Int32, Float64, Float64, UInt32, Ref{Int64}),
+                e.ctx, e.N, e.slot[e.cur], e.logpi[e.cur], e.delta[e.cur], e.slot[o], e.logpi[o], e.delta[o], e.order, e.sorted, e.cnt,
+                α, ϵ_target, lh, do_rank ? 1 : 0, γ0, γσ, e.sweep, t))
+        e.sweep += 1; e.cur = o
+        return t[]
+    end
     GC.@preserve lo_hi check(ccall((:abcdez_mc_generation_async, LIB), Cint,
                 (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
                  Float64, Float64, Ptr{Float64}, Int32, Float64, Float64, UInt32, Ref{Int64}),
@@ -470,12 +481,14 @@ end
 
 function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
                   nparticles::Int=50, generations::Int=20, verbose=true, rng::Union{Integer,AbstractRNG}=Random.default_rng(),
-                  parallel::Bool=false)
+                  parallel::Bool=false, comm=nothing)
+    # comm = (id, rank, world): one of `world` processes, one GPU each (top of this file); every rank must pass the same integer `rng`
+    (comm === nothing || rng isa Integer) || error("comm: a sharded run needs the same integer rng on every rank")
     α = 0.0                                                                              # mc:107
     0.0 ≤ ϵ_target || error("ϵ_target must be non-negative")
     5 ≤ nparticles || error("nparticles must be at least 5")
     1 ≤ generations || error("generations must be at least 1")
-    e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, philox_key(rng), nparticles)
+    e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, philox_key(rng), nparticles; comm = comm)
     try
         init!(e)                                                                             # mc:117-125
         nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
