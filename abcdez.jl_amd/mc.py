@@ -34,8 +34,9 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
 
     spec = ModelSpec(prior, dist, seed=rng)
     eng = _make_engine(spec, nparticles, engine, process_group, storage="classic")
-    # the whole run on a stream of its own when the caller sits on the legacy default stream (engine.run_scope): generations
-    # are replayed as HIP graphs, which the default stream cannot capture
+    # the whole run on a stream of its own when the caller sits on the legacy default stream (engine.run_scope), which
+    # serialises with every other blocking stream of the process (and could not be captured when graph replay -- optional,
+    # off by default: measured slower -- is switched on)
     with (eng.run_scope() if hasattr(eng, "run_scope") else contextlib.nullcontext()):
         return _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α)
 

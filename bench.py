@@ -80,7 +80,7 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL, one rank per GPU (the contract); gloo = rehearsal of the N > 1 path on a box with fewer GPUs "
                         "than ranks: the ranks share the visible GPUs, collectives go through the host")
-    p.add_argument("--default-stream", action="store_true", help="diagnostic: run on the legacy default stream (no graph replay)")
+    p.add_argument("--default-stream", action="store_true", help="diagnostic: run on the legacy default stream")
     p.add_argument("--graphs", action="store_true", help="diagnostic: replay abcdemc generations as HIP graphs (off by default: measured slower)")
     p.add_argument("--timing-mode", type=int, default=3, choices=[2, 3],
                    help="abcdesmc kernel timing (abcdez_ctx_set_timing): 3 = one HIP-event pair around ALL the sweeps of every 2nd timed "
@@ -480,8 +480,8 @@ def run_config(args):
     device = local_rank if args.dist_backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
     if not args.default_stream:
-        # everything on a stream of its own: the legacy default stream cannot be captured (abcdemc generations are replayed as
-        # HIP graphs) and serialises with every other blocking stream of the process
+        # everything on a stream of its own: the legacy default stream serialises with every other blocking stream of the
+        # process (and cannot be captured when --graphs asks for graph replay of the abcdemc generations)
         torch.cuda.set_stream(torch.cuda.Stream(device))
     pg = None
     if world > 1 or args.force_collectives:
@@ -657,9 +657,9 @@ def run_config(args):
                     "rule": "by rejection once at least 1 / 16 of the particles lie at or below eps_target (include/abcdez_spec.h)"}
             gr = eng.ops.graph_stats()
             out["config"]["graph_replay"] = {"generations_replayed": gr[0], "graphs_captured": gr[1], "generations_stream_launched": gr[2],
-                                             "what": "one abcdemc generation (rank pass + sweep + snapshot, <= 15 dependent launches) is captured "
-                                                     "once per launch shape and replayed as a HIP graph; generations whose sweep carries the "
-                                                     "bench's event pair are enqueued launch by launch"}
+                                             "what": "off by default (measured slower than stream launches); with --graphs one abcdemc generation "
+                                                     "(rank pass + sweep + snapshot) is captured once per launch shape and replayed as a HIP "
+                                                     "graph, generations whose sweep carries the bench's event pair are enqueued launch by launch"}
         if whole is not None:
             out["whole_run"] = whole
             # the second half of BASELINE.json's metric ("posterior-mean & log-Z error vs ref"), from the whole run above
