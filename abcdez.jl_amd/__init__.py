@@ -14,8 +14,9 @@ from .kernels import (  # noqa: F401
     IndicatorStrict0toeps, IndicatorStrict0toϵ,
 )
 from .model import ModelSpec  # noqa: F401
-from .priors import (Beta, DiscreteUniform, Factored, MvNormal, NegativeBinomial, Normal, Product, Uniform,  # noqa: F401
-                     product_distribution, push_p)
+from .priors import (Beta, Binomial, Cauchy, Chisq, DiscreteUniform, Erlang, Exponential, Factored, Gamma, Geometric,  # noqa: F401
+                     InverseGamma, Laplace, Logistic, LogNormal, MvNormal, NegativeBinomial, Normal, Pareto, Poisson, Product,
+                     Rayleigh, TDist, TruncatedNormal, Uniform, Weibull, product_distribution, push_p, truncated)
 from .simulators import (  # noqa: F401
     DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, UserSimulator, WienerRMS,
 )

@@ -113,7 +113,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ABZ_REQUIRE(model->n_data >= 0 && (model->n_data == 0 || model->data), "ctx_create: data pointer missing");
   for (int k = 0; k < model->ld; ++k) {
     const int fam = model->prior[k].family;
-    ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_NEGBIN, "ctx_create: unknown prior family");
+    ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_LAST, "ctx_create: unknown prior family");
     ABZ_REQUIRE((k < model->d) == (fam != ABZ_PRIOR_PAD), "ctx_create: prior descriptor / d mismatch");
   }
   switch (model->sim_id) {

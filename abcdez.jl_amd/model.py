@@ -91,14 +91,23 @@ class ModelSpec:
         if self.n_blob > 64:
             raise ValueError(f"blobs of {self.n_blob} doubles exceed the supported maximum 64")
         self.discrete = tuple(bool(f.discrete) for f in factors)
-        self._desc = [f.descriptor() for f in factors]
+        # (family, discrete, p0, p1, c0, c1, reserved): the first three families compute c1 here
+        self._desc = [self._full_descriptor(f) for f in factors]
         if isinstance(prior, Product):
             # push_p broadcasts the whole product over the vector (types.jl:21): one rule for every component
             self.discrete = tuple(bool(prior.discrete) for _ in factors)
-            self._desc = [(fam, int(prior.discrete), p0, p1, c0) for (fam, _, p0, p1, c0) in self._desc]
-        self._c1 = [f.c1() if f.family == PRIOR_NEGBIN else None for f in factors]
+            self._desc = [(q[0], int(prior.discrete)) + tuple(q[2:]) for q in self._desc]
         # a correlated Normal prior (priors.MvNormal): [mu | L^-1 | L], host memory -- the library copies it to the device
         self.mv = prior.mv_maps(self.ld) if hasattr(prior, "mv_maps") else None
+
+    @staticmethod
+    def _full_descriptor(f):
+        q = tuple(f.descriptor())
+        if len(q) == 7:
+            return q
+        fam, disc, p0, p1, c0 = q
+        c1 = 1.0 / p1 if fam == PRIOR_NORMAL else (f.c1() if fam == PRIOR_NEGBIN else 0.0)
+        return (fam, disc, p0, p1, c0, c1, 0.0)
 
     def cstruct(self, data_ptr: Optional[int]) -> Model:
         m = Model()
@@ -111,12 +120,8 @@ class ModelSpec:
             m.sim_p[i] = params[i] if i < len(params) else 0.0
         m.data = data_ptr or None
         for k in range(MAX_D):
-            if k < self.d:
-                fam, disc, p0, p1, c0 = self._desc[k]
-            else:
-                fam, disc, p0, p1, c0 = PRIOR_PAD, 0, 0.0, 0.0, 0.0
+            fam, disc, p0, p1, c0, c1, reserved = self._desc[k] if k < self.d else (PRIOR_PAD, 0, 0.0, 0.0, 0.0, 0.0, 0.0)
             m.prior[k].family, m.prior[k].discrete = fam, disc
-            m.prior[k].p0, m.prior[k].p1, m.prior[k].c0 = p0, p1, c0
-            m.prior[k].c1 = 1.0 / p1 if fam == PRIOR_NORMAL else (self._c1[k] if fam == PRIOR_NEGBIN else 0.0)
+            m.prior[k].p0, m.prior[k].p1, m.prior[k].c0, m.prior[k].c1, m.prior[k].reserved = p0, p1, c0, c1, reserved
         m.mv = self.mv.ctypes.data if self.mv is not None else None
         return m

@@ -14,6 +14,8 @@ from typing import Sequence, Tuple, Union
 
 # family ids -- keep in sync with include/abcdez_spec.h (ABZ_PRIOR_*)
 PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM, PRIOR_BETA, PRIOR_NEGBIN = 0, 1, 2, 3, 4, 5
+(PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE, PRIOR_WEIBULL, PRIOR_INVGAMMA, PRIOR_TRUNCNORMAL,
+ PRIOR_LOGISTIC, PRIOR_TDIST, PRIOR_PARETO, PRIOR_POISSON, PRIOR_BINOMIAL) = range(6, 19)
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
@@ -188,6 +190,438 @@ class NegativeBinomial(UnivariateDistribution):
         return math.log1p(-self.p) if self.p < 1 else -math.inf
 
 
+# ---- further univariate families of Distributions.jl, in its parametrisations (the reference takes any `Distribution` as prior:
+# src/abcdez_smc.jl:165, 215; src/abcdez_mc.jl:102).  descriptor() = (family, discrete, p0, p1, c0, c1, reserved) as laid out in
+# include/abcdez_spec.h (ABZ_PRIOR_*); logpdf() here is the host mirror, the device and the oracle evaluate the header.
+
+class _Continuous(UnivariateDistribution):
+    def pdf(self, x: float) -> float:
+        return math.exp(self.logpdf(x))
+
+
+class _Counting(UnivariateDistribution):
+    discrete = True
+
+    def pdf(self, x) -> float:
+        return math.exp(self.logpdf(x))
+
+
+@dataclass(frozen=True)
+class Exponential(_Continuous):
+    """Exponential(θ): scale θ (mean θ), support x ≥ 0."""
+    theta: float = 1.0
+    family = PRIOR_EXPONENTIAL
+
+    def __post_init__(self):
+        if not (self.theta > 0 and math.isfinite(self.theta)):
+            raise ValueError("Exponential: need θ > 0")
+
+    def insupport(self, x) -> bool:
+        return 0.0 <= x < math.inf
+
+    def logpdf(self, x) -> float:
+        return -math.log(self.theta) - x / self.theta if self.insupport(x) else -math.inf
+
+    def rand(self, rng) -> float:
+        return float(rng.exponential(self.theta))
+
+    def descriptor(self):
+        return (PRIOR_EXPONENTIAL, 0, float(self.theta), 0.0, -math.log(self.theta), 1.0 / self.theta, 0.0)
+
+
+@dataclass(frozen=True)
+class Gamma(_Continuous):
+    """Gamma(α, θ): shape α, scale θ, support x ≥ 0."""
+    alpha: float = 1.0
+    theta: float = 1.0
+    family = PRIOR_GAMMA
+
+    def __post_init__(self):
+        if not (self.alpha > 0 and self.theta > 0 and math.isfinite(self.alpha) and math.isfinite(self.theta)):
+            raise ValueError("Gamma: need α, θ > 0")
+
+    def insupport(self, x) -> bool:
+        return 0.0 <= x < math.inf
+
+    def _c0(self) -> float:
+        return -math.lgamma(self.alpha) - self.alpha * math.log(self.theta)
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        a1 = self.alpha - 1.0
+        t1 = 0.0 if a1 == 0 else (a1 * math.log(x) if x > 0 else -math.inf * a1)
+        return t1 - x / self.theta + self._c0()
+
+    def rand(self, rng) -> float:
+        return float(rng.gamma(self.alpha, self.theta))
+
+    def descriptor(self):
+        return (PRIOR_GAMMA, 0, float(self.alpha), float(self.theta), self._c0(), 1.0 / self.theta, 0.0)
+
+
+def Chisq(nu: float) -> Gamma:
+    """Chisq(ν) = Gamma(ν/2, 2)"""
+    return Gamma(0.5 * nu, 2.0)
+
+
+def Erlang(k: int = 1, theta: float = 1.0) -> Gamma:
+    """Erlang(k, θ) = Gamma(k, θ) with an integer shape"""
+    if int(k) != k or k < 1:
+        raise ValueError("Erlang: the shape must be a positive integer")
+    return Gamma(float(k), theta)
+
+
+@dataclass(frozen=True)
+class LogNormal(_Continuous):
+    """LogNormal(μ, σ): log x ~ Normal(μ, σ), support x > 0."""
+    mu: float = 0.0
+    sigma: float = 1.0
+    family = PRIOR_LOGNORMAL
+
+    def __post_init__(self):
+        if not (self.sigma > 0 and math.isfinite(self.sigma) and math.isfinite(self.mu)):
+            raise ValueError("LogNormal: need σ > 0")
+
+    def insupport(self, x) -> bool:
+        return 0.0 < x < math.inf
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        lx = math.log(x)
+        z = (lx - self.mu) / self.sigma
+        return -0.5 * z * z - math.log(self.sigma) - _HALF_LOG_2PI - lx
+
+    def rand(self, rng) -> float:
+        return float(rng.lognormal(self.mu, self.sigma))
+
+    def descriptor(self):
+        return (PRIOR_LOGNORMAL, 0, float(self.mu), float(self.sigma), -math.log(self.sigma) - _HALF_LOG_2PI, 1.0 / self.sigma, 0.0)
+
+
+@dataclass(frozen=True)
+class Cauchy(_Continuous):
+    """Cauchy(μ, σ): location μ, scale σ."""
+    mu: float = 0.0
+    sigma: float = 1.0
+    family = PRIOR_CAUCHY
+
+    def __post_init__(self):
+        if not (self.sigma > 0 and math.isfinite(self.sigma) and math.isfinite(self.mu)):
+            raise ValueError("Cauchy: need σ > 0")
+
+    def insupport(self, x) -> bool:
+        return math.isfinite(x)
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        z = (x - self.mu) / self.sigma
+        return -math.log(math.pi * self.sigma) - math.log1p(z * z)
+
+    def rand(self, rng) -> float:
+        return self.mu + self.sigma * float(rng.standard_cauchy())
+
+    def descriptor(self):
+        return (PRIOR_CAUCHY, 0, float(self.mu), float(self.sigma), -math.log(math.pi * self.sigma), 1.0 / self.sigma, 0.0)
+
+
+@dataclass(frozen=True)
+class Laplace(_Continuous):
+    """Laplace(μ, θ): location μ, scale θ."""
+    mu: float = 0.0
+    theta: float = 1.0
+    family = PRIOR_LAPLACE
+
+    def __post_init__(self):
+        if not (self.theta > 0 and math.isfinite(self.theta) and math.isfinite(self.mu)):
+            raise ValueError("Laplace: need θ > 0")
+
+    def insupport(self, x) -> bool:
+        return math.isfinite(x)
+
+    def logpdf(self, x) -> float:
+        return -math.log(2.0 * self.theta) - abs(x - self.mu) / self.theta if self.insupport(x) else -math.inf
+
+    def rand(self, rng) -> float:
+        return float(rng.laplace(self.mu, self.theta))
+
+    def descriptor(self):
+        return (PRIOR_LAPLACE, 0, float(self.mu), float(self.theta), -math.log(2.0 * self.theta), 1.0 / self.theta, 0.0)
+
+
+@dataclass(frozen=True)
+class Weibull(_Continuous):
+    """Weibull(α, θ): shape α, scale θ, support x ≥ 0."""
+    alpha: float = 1.0
+    theta: float = 1.0
+    family = PRIOR_WEIBULL
+
+    def __post_init__(self):
+        if not (self.alpha > 0 and self.theta > 0 and math.isfinite(self.alpha) and math.isfinite(self.theta)):
+            raise ValueError("Weibull: need α, θ > 0")
+
+    def insupport(self, x) -> bool:
+        return 0.0 <= x < math.inf
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        a1 = self.alpha - 1.0
+        t = x / self.theta
+        t1 = 0.0 if a1 == 0 else (a1 * math.log(t) if t > 0 else -math.inf * a1)
+        return math.log(self.alpha / self.theta) + t1 - t ** self.alpha
+
+    def rand(self, rng) -> float:
+        return self.theta * float(rng.weibull(self.alpha))
+
+    def descriptor(self):
+        return (PRIOR_WEIBULL, 0, float(self.alpha), float(self.theta), math.log(self.alpha / self.theta), 1.0 / self.theta, 0.0)
+
+
+def Rayleigh(sigma: float = 1.0) -> Weibull:
+    """Rayleigh(σ) = Weibull(2, √2 σ)"""
+    return Weibull(2.0, math.sqrt(2.0) * sigma)
+
+
+@dataclass(frozen=True)
+class InverseGamma(_Continuous):
+    """InverseGamma(α, θ): shape α, scale θ, support x > 0."""
+    alpha: float = 1.0
+    theta: float = 1.0
+    family = PRIOR_INVGAMMA
+
+    def __post_init__(self):
+        if not (self.alpha > 0 and self.theta > 0 and math.isfinite(self.alpha) and math.isfinite(self.theta)):
+            raise ValueError("InverseGamma: need α, θ > 0")
+
+    def insupport(self, x) -> bool:
+        return 0.0 < x < math.inf
+
+    def _c0(self) -> float:
+        return self.alpha * math.log(self.theta) - math.lgamma(self.alpha)
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        return self._c0() - (self.alpha + 1.0) * math.log(x) - self.theta / x
+
+    def rand(self, rng) -> float:
+        return self.theta / float(rng.gamma(self.alpha, 1.0))
+
+    def descriptor(self):
+        return (PRIOR_INVGAMMA, 0, float(self.alpha), float(self.theta), self._c0(), 0.0, 0.0)
+
+
+def _norm_cdf_diff(a: float, b: float) -> float:
+    """Φ(b) − Φ(a) without cancellation in either tail"""
+    r2 = math.sqrt(2.0)
+    if a > 0:                              # right tail: difference of survival functions
+        return 0.5 * (math.erfc(a / r2) - math.erfc(b / r2))
+    if b < 0:
+        return 0.5 * (math.erfc(-b / r2) - math.erfc(-a / r2))
+    return 1.0 - 0.5 * math.erfc(-a / r2) - 0.5 * math.erfc(b / r2)
+
+
+@dataclass(frozen=True)
+class TruncatedNormal(_Continuous):
+    """``truncated(Normal(μ, σ), lo, hi)``: the Normal restricted to [lo, hi] (either bound may be infinite).  The initial
+    population is drawn by rejection from the parent Normal, so the interval must hold at least 1 % of its mass."""
+    mu: float = 0.0
+    sigma: float = 1.0
+    lo: float = -math.inf
+    hi: float = math.inf
+    family = PRIOR_TRUNCNORMAL
+
+    def __post_init__(self):
+        if not (self.sigma > 0 and math.isfinite(self.sigma) and math.isfinite(self.mu)):
+            raise ValueError("truncated(Normal): need σ > 0")
+        if not self.lo < self.hi:
+            raise ValueError("truncated(Normal): need lo < hi")
+        if self.mass() < 0.01:
+            raise ValueError(f"truncated(Normal): [lo, hi] holds {self.mass():.3g} of the Normal's mass; the device draws the initial "
+                             "population by rejection from the parent and needs at least 0.01")
+
+    def mass(self) -> float:
+        return _norm_cdf_diff((self.lo - self.mu) / self.sigma, (self.hi - self.mu) / self.sigma)
+
+    def insupport(self, x) -> bool:
+        return self.lo <= x <= self.hi and math.isfinite(x)
+
+    def _c0(self) -> float:
+        return -math.log(self.sigma) - _HALF_LOG_2PI - math.log(self.mass())
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        z = (x - self.mu) / self.sigma
+        return -0.5 * z * z + self._c0()
+
+    def rand(self, rng) -> float:
+        while True:
+            x = self.mu + self.sigma * float(rng.standard_normal())
+            if self.lo <= x <= self.hi:
+                return x
+
+    def descriptor(self):
+        return (PRIOR_TRUNCNORMAL, 0, float(self.mu), float(self.sigma), self._c0(), float(self.lo), float(self.hi))
+
+
+def truncated(dist, lower: float = None, upper: float = None):
+    """``truncated(d, lower, upper)`` of Distributions.jl for the one parent the device knows: a Normal."""
+    if type(dist) is not Normal:
+        raise TypeError("truncated(): only a Normal parent has a device descriptor")
+    return TruncatedNormal(dist.mu, dist.sigma, -math.inf if lower is None else float(lower), math.inf if upper is None else float(upper))
+
+
+@dataclass(frozen=True)
+class Logistic(_Continuous):
+    """Logistic(μ, θ): location μ, scale θ."""
+    mu: float = 0.0
+    theta: float = 1.0
+    family = PRIOR_LOGISTIC
+
+    def __post_init__(self):
+        if not (self.theta > 0 and math.isfinite(self.theta) and math.isfinite(self.mu)):
+            raise ValueError("Logistic: need θ > 0")
+
+    def insupport(self, x) -> bool:
+        return math.isfinite(x)
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        z = abs(x - self.mu) / self.theta
+        return -math.log(self.theta) - z - 2.0 * math.log1p(math.exp(-z))
+
+    def rand(self, rng) -> float:
+        return float(rng.logistic(self.mu, self.theta))
+
+    def descriptor(self):
+        return (PRIOR_LOGISTIC, 0, float(self.mu), float(self.theta), -math.log(self.theta), 1.0 / self.theta, 0.0)
+
+
+@dataclass(frozen=True)
+class TDist(_Continuous):
+    """TDist(ν): Student's t with ν degrees of freedom."""
+    nu: float = 1.0
+    family = PRIOR_TDIST
+
+    def __post_init__(self):
+        if not (self.nu > 0 and math.isfinite(self.nu)):
+            raise ValueError("TDist: need ν > 0")
+
+    def insupport(self, x) -> bool:
+        return math.isfinite(x)
+
+    def _c0(self) -> float:
+        return math.lgamma(0.5 * (self.nu + 1.0)) - math.lgamma(0.5 * self.nu) - 0.5 * math.log(self.nu * math.pi)
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        return self._c0() - 0.5 * (self.nu + 1.0) * math.log1p(x * x / self.nu)
+
+    def rand(self, rng) -> float:
+        return float(rng.standard_t(self.nu))
+
+    def descriptor(self):
+        return (PRIOR_TDIST, 0, float(self.nu), 0.5 * (self.nu + 1.0), self._c0(), 1.0 / self.nu, 0.0)
+
+
+@dataclass(frozen=True)
+class Pareto(_Continuous):
+    """Pareto(α, θ): shape α, scale θ, support x ≥ θ."""
+    alpha: float = 1.0
+    theta: float = 1.0
+    family = PRIOR_PARETO
+
+    def __post_init__(self):
+        if not (self.alpha > 0 and self.theta > 0 and math.isfinite(self.alpha) and math.isfinite(self.theta)):
+            raise ValueError("Pareto: need α, θ > 0")
+
+    def insupport(self, x) -> bool:
+        return self.theta <= x < math.inf
+
+    def _c0(self) -> float:
+        return math.log(self.alpha) + self.alpha * math.log(self.theta)
+
+    def logpdf(self, x) -> float:
+        return self._c0() - (self.alpha + 1.0) * math.log(x) if self.insupport(x) else -math.inf
+
+    def rand(self, rng) -> float:
+        return self.theta * (1.0 + float(rng.pareto(self.alpha)))
+
+    def descriptor(self):
+        return (PRIOR_PARETO, 0, float(self.alpha), float(self.theta), self._c0(), 0.0, 0.0)
+
+
+@dataclass(frozen=True)
+class Poisson(_Counting):
+    """Poisson(λ), λ ≤ 700 (the device draws the initial population by inversion from exp(−λ))."""
+    lam: float = 1.0
+    family = PRIOR_POISSON
+
+    def __post_init__(self):
+        if not 0 < self.lam <= 700:
+            raise ValueError("Poisson: need 0 < λ <= 700")
+
+    def insupport(self, x) -> bool:
+        return 0 <= x < 2.0 ** 52 and float(x) == _rint(float(x))
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        k = float(x)
+        return k * math.log(self.lam) - self.lam - math.lgamma(k + 1.0)
+
+    def rand(self, rng) -> int:
+        return int(rng.poisson(self.lam))
+
+    def descriptor(self):
+        return (PRIOR_POISSON, 1, float(self.lam), 0.0, -float(self.lam), math.log(self.lam), 0.0)
+
+
+@dataclass(frozen=True)
+class Binomial(_Counting):
+    """Binomial(n, p), 0 < p < 1, with n log(1 − min(p, 1 − p)) > −700 (inversion from the thinner end)."""
+    n: int = 1
+    p: float = 0.5
+    family = PRIOR_BINOMIAL
+
+    def __post_init__(self):
+        if int(self.n) != self.n or self.n < 1:
+            raise ValueError("Binomial: n must be a positive integer")
+        if not 0 < self.p < 1:
+            raise ValueError("Binomial: need 0 < p < 1 (a degenerate prior has no device descriptor)")
+        if self.n * math.log1p(-min(self.p, 1.0 - self.p)) <= -700:
+            raise ValueError("Binomial: n too large for the device's inversion sampler (n log(1 - min(p, 1 - p)) must stay above -700)")
+
+    def insupport(self, x) -> bool:
+        return 0 <= x <= self.n and float(x) == _rint(float(x))
+
+    def logpdf(self, x) -> float:
+        if not self.insupport(x):
+            return -math.inf
+        k, n = float(x), float(self.n)
+        return (math.lgamma(n + 1.0) - math.lgamma(k + 1.0) - math.lgamma(n - k + 1.0) + k * math.log(self.p)
+                + (n - k) * math.log1p(-self.p))
+
+    def rand(self, rng) -> int:
+        return int(rng.binomial(int(self.n), self.p))
+
+    def descriptor(self):
+        n = float(self.n)
+        return (PRIOR_BINOMIAL, 1, n, float(self.p), math.lgamma(n + 1.0) + n * math.log1p(-self.p),
+                math.log(self.p) - math.log1p(-self.p), 0.0)
+
+
+def Geometric(p: float = 0.5) -> NegativeBinomial:
+    """Geometric(p) = NegativeBinomial(1, p): failures before the first success"""
+    return NegativeBinomial(1.0, p)
+
+
 class Factored:
     """Product of independent univariate priors (src/abcdez_priors.jl:18-21).
 
@@ -320,7 +754,8 @@ def prior_factors(prior: Prior) -> Tuple[UnivariateDistribution, ...]:
         return prior.p
     if isinstance(prior, UnivariateDistribution):
         return (prior,)
-    raise TypeError(f"unsupported prior type {type(prior).__name__}; use Normal/Uniform/DiscreteUniform or Factored")
+    raise TypeError(f"unsupported prior type {type(prior).__name__}: the device knows the univariate families of "
+                    "abcdez_amd.priors (and Factored / product_distribution / MvNormal of them)")
 
 
 def prior_length(prior: Prior) -> int:

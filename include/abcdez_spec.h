@@ -358,8 +358,25 @@ enum {
   ABZ_PRIOR_UNIFORM = 2,    /* p0 = a, p1 = b (closed support), c0 = -log(b-a)      */
   ABZ_PRIOR_DUNIFORM = 3,   /* p0 = a, p1 = b integers, c0 = -log(b-a+1); discrete  */
   ABZ_PRIOR_BETA = 4,       /* p0 = alpha, p1 = beta, c0 = -log B(alpha, beta); support [0,1]       */
-  ABZ_PRIOR_NEGBIN = 5      /* p0 = r, p1 = p, c0 = r log p - lgamma(r), c1 = log(1-p); discrete k >= 0
+  ABZ_PRIOR_NEGBIN = 5,     /* p0 = r, p1 = p, c0 = r log p - lgamma(r), c1 = log(1-p); discrete k >= 0
                                (Distributions.NegativeBinomial: failures before the r-th success)   */
+  /* further univariate families of Distributions.jl in its parametrisations (`prior::Distribution`, smc:165, 215; mc:102):     */
+  ABZ_PRIOR_EXPONENTIAL = 6,  /* Exponential(theta): p0 = theta (scale), c0 = -log theta, c1 = 1/theta; x >= 0                  */
+  ABZ_PRIOR_GAMMA = 7,        /* Gamma(alpha, theta): p0 = alpha, p1 = theta, c0 = -lgamma(alpha) - alpha log theta, c1 = 1/theta */
+  ABZ_PRIOR_LOGNORMAL = 8,    /* LogNormal(mu, sigma): p0, p1, c0 = -log sigma - log(2 pi)/2, c1 = 1/sigma; x > 0               */
+  ABZ_PRIOR_CAUCHY = 9,       /* Cauchy(mu, sigma): p0, p1, c0 = -log(pi sigma), c1 = 1/sigma                                   */
+  ABZ_PRIOR_LAPLACE = 10,     /* Laplace(mu, theta): p0, p1, c0 = -log(2 theta), c1 = 1/theta                                   */
+  ABZ_PRIOR_WEIBULL = 11,     /* Weibull(alpha, theta): p0 = shape, p1 = scale, c0 = log(alpha / theta), c1 = 1/theta; x >= 0   */
+  ABZ_PRIOR_INVGAMMA = 12,    /* InverseGamma(alpha, theta): p0, p1, c0 = alpha log theta - lgamma(alpha); x > 0                */
+  ABZ_PRIOR_TRUNCNORMAL = 13, /* truncated(Normal(mu, sigma), lo, hi): p0 = mu, p1 = sigma, c1 = lo, reserved = hi (either may be
+                                 infinite), c0 = -log sigma - log(2 pi)/2 - log(Phi((hi-mu)/sigma) - Phi((lo-mu)/sigma))        */
+  ABZ_PRIOR_LOGISTIC = 14,    /* Logistic(mu, theta): p0, p1, c0 = -log theta, c1 = 1/theta                                     */
+  ABZ_PRIOR_TDIST = 15,       /* TDist(nu): p0 = nu, p1 = (nu+1)/2, c0 = lgamma((nu+1)/2) - lgamma(nu/2) - log(nu pi)/2, c1 = 1/nu */
+  ABZ_PRIOR_PARETO = 16,      /* Pareto(alpha, theta): p0 = shape, p1 = scale, c0 = log alpha + alpha log theta; x >= theta     */
+  ABZ_PRIOR_POISSON = 17,     /* Poisson(lambda): p0 = lambda, c0 = -lambda, c1 = log lambda; discrete k >= 0                    */
+  ABZ_PRIOR_BINOMIAL = 18,    /* Binomial(n, p), 0 < p < 1: p0 = n, p1 = p, c0 = lgamma(n+1) + n log(1-p), c1 = log p - log(1-p);
+                                 discrete 0 <= k <= n                                                                           */
+  ABZ_PRIOR_LAST = 18
 };
 
 typedef struct {    /* 48 bytes = three 16-byte loads */
@@ -389,18 +406,79 @@ ABZ_HD double abz_lgamma(double x) {
   return (lg + ser * xi) - abz_log(prod);
 }
 
-/* Beta / NegativeBinomial log-densities (the Socks problem of test/runtests.jl:425-491) */
+/* log-densities of the families beyond Normal / (Discrete)Uniform: Beta / NegativeBinomial (the Socks problem of
+ * test/runtests.jl:425-491) and the further Distributions.jl families above.  x is already push_p-cast. */
 ABZ_HD double abz_prior_logpdf_ext(const abz_prior_dim* pd, double x) {
-  if (pd->family == ABZ_PRIOR_BETA) {
-    if (!(x >= 0.0 && x <= 1.0)) return ABZ_NINF;
-    const double a1 = pd->p0 - 1.0, b1 = pd->p1 - 1.0;
-    const double t1 = a1 == 0.0 ? 0.0 : a1 * abz_log(x);
-    const double t2 = b1 == 0.0 ? 0.0 : b1 * abz_log(1.0 - x);
-    return (t1 + t2) + pd->c0;
+  const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
+  switch (pd->family) {
+    case ABZ_PRIOR_BETA: {
+      if (!(x >= 0.0 && x <= 1.0)) return ABZ_NINF;
+      const double a1 = p0 - 1.0, b1 = p1 - 1.0;
+      const double t1 = a1 == 0.0 ? 0.0 : a1 * abz_log(x);
+      const double t2 = b1 == 0.0 ? 0.0 : b1 * abz_log(1.0 - x);
+      return (t1 + t2) + c0;
+    }
+    case ABZ_PRIOR_NEGBIN:
+      if (!(x >= 0.0) || abz_rint(x) != x || x > 0x1p52) return ABZ_NINF;
+      return ((abz_lgamma(x + p0) - abz_lgamma(x + 1.0)) + c0) + x * c1;
+    default: break;
   }
-  /* ABZ_PRIOR_NEGBIN */
-  if (!(x >= 0.0) || abz_rint(x) != x || x > 0x1p52) return ABZ_NINF;
-  return ((abz_lgamma(x + pd->p0) - abz_lgamma(x + 1.0)) + pd->c0) + x * pd->c1;
+  if (!abz_isfinite(x)) return ABZ_NINF;          /* +-Inf carries no density in any family below; NaN is outside every support */
+  switch (pd->family) {
+    case ABZ_PRIOR_EXPONENTIAL:
+      return x >= 0.0 ? c0 - x * c1 : ABZ_NINF;
+    case ABZ_PRIOR_GAMMA: {
+      if (!(x >= 0.0)) return ABZ_NINF;
+      const double a1 = p0 - 1.0;
+      const double t1 = a1 == 0.0 ? 0.0 : a1 * abz_log(x);
+      return (t1 - x * c1) + c0;
+    }
+    case ABZ_PRIOR_LOGNORMAL: {
+      if (!(x > 0.0)) return ABZ_NINF;
+      const double lx = abz_log(x), z = (lx - p0) * c1;
+      return abz_fma(-0.5 * z, z, c0) - lx;
+    }
+    case ABZ_PRIOR_CAUCHY: {
+      const double z = (x - p0) * c1;
+      return c0 - abz_log(abz_fma(z, z, 1.0));
+    }
+    case ABZ_PRIOR_LAPLACE: {
+      const double t = x - p0;
+      return c0 - (t < 0.0 ? -t : t) * c1;
+    }
+    case ABZ_PRIOR_WEIBULL: {
+      if (!(x >= 0.0)) return ABZ_NINF;
+      const double a1 = p0 - 1.0, lt = abz_log(x * c1);
+      const double t1 = a1 == 0.0 ? 0.0 : a1 * lt;
+      return (c0 + t1) - abz_exp(p0 * lt);
+    }
+    case ABZ_PRIOR_INVGAMMA:
+      if (!(x > 0.0)) return ABZ_NINF;
+      return (c0 - (p0 + 1.0) * abz_log(x)) - p1 / x;
+    case ABZ_PRIOR_TRUNCNORMAL: {
+      if (!(x >= c1 && x <= pd->reserved)) return ABZ_NINF;
+      const double z = (x - p0) / p1;
+      return abz_fma(-0.5 * z, z, c0);
+    }
+    case ABZ_PRIOR_LOGISTIC: {
+      double z = (x - p0) * c1;
+      z = z < 0.0 ? -z : z;
+      return (c0 - z) - 2.0 * abz_log(1.0 + abz_exp(-z));
+    }
+    case ABZ_PRIOR_TDIST:
+      return c0 - p1 * abz_log(abz_fma(x * x, c1, 1.0));
+    case ABZ_PRIOR_PARETO:
+      if (!(x >= p1)) return ABZ_NINF;
+      return c0 - (p0 + 1.0) * abz_log(x);
+    case ABZ_PRIOR_POISSON:
+      if (!(x >= 0.0) || abz_rint(x) != x || x > 0x1p52) return ABZ_NINF;
+      return abz_fma(x, c1, c0) - abz_lgamma(x + 1.0);
+    case ABZ_PRIOR_BINOMIAL:
+      if (!(x >= 0.0 && x <= p0) || abz_rint(x) != x) return ABZ_NINF;
+      return ((c0 - abz_lgamma(x + 1.0)) - abz_lgamma((p0 - x) + 1.0)) + x * c1;
+    default:
+      return ABZ_NINF;
+  }
 }
 
 /* logpdf of one (already pushed) component; branch-free so a wave with mixed families
@@ -456,21 +534,103 @@ ABZ_HD double abz_gamma_draw(double shape, uint64_t seed, uint32_t i, uint32_t r
 ABZ_HD double abz_prior_draw_ext(const abz_prior_dim* pd, uint64_t seed, uint32_t i, uint32_t retry, uint32_t k,
                                  const abz_tables* T) {
   const uint32_t base = k * 4096u;
-  if (pd->family == ABZ_PRIOR_BETA) {
-    const double x = abz_gamma_draw(pd->p0, seed, i, retry, base, T);
-    const double y = abz_gamma_draw(pd->p1, seed, i, retry, base + 1024u, T);
-    return x / (x + y);
+  const double p0 = pd->p0, p1 = pd->p1;
+  switch (pd->family) {
+    case ABZ_PRIOR_BETA: {
+      const double x = abz_gamma_draw(p0, seed, i, retry, base, T);
+      const double y = abz_gamma_draw(p1, seed, i, retry, base + 1024u, T);
+      return x / (x + y);
+    }
+    case ABZ_PRIOR_NEGBIN: {
+      /* NegativeBinomial(r, p) by inversion: P(0) = p^r, P(k+1) = P(k) (k+r)/(k+1) (1-p) */
+      const double r = p0, q = 1.0 - p1;
+      const double u = abz_u01_co(abz_rng(seed, i, retry, base, ABZ_RNG_INIT_AUX).w0);
+      double P = abz_exp(r * abz_log(p1)), cum = P, kk = 0.0;
+      for (int it = 0; it < 100000 && u >= cum; ++it) {
+        P = P * ((kk + r) / (kk + 1.0)) * q;
+        kk += 1.0;
+        cum += P;
+      }
+      return kk;
+    }
+    default: break;
   }
-  /* NegativeBinomial(r, p) by inversion: P(0) = p^r, P(k+1) = P(k) (k+r)/(k+1) (1-p) */
-  const double r = pd->p0, q = 1.0 - pd->p1;
-  const double u = abz_u01_co(abz_rng(seed, i, retry, base, ABZ_RNG_INIT_AUX).w0);
-  double P = abz_exp(r * abz_log(pd->p1)), cum = P, kk = 0.0;
-  for (int it = 0; it < 100000 && u >= cum; ++it) {
-    P = P * ((kk + r) / (kk + 1.0)) * q;
-    kk += 1.0;
-    cum += P;
+  const abz_u64x2 w = abz_rng(seed, i, retry, base, ABZ_RNG_INIT_AUX);
+  switch (pd->family) {
+    case ABZ_PRIOR_EXPONENTIAL:                       /* inversion: -theta log U */
+      return -p0 * abz_log(abz_u01_open(w.w0));
+    case ABZ_PRIOR_GAMMA:
+      return p1 * abz_gamma_draw(p0, seed, i, retry, base, T);
+    case ABZ_PRIOR_LOGNORMAL: {
+      double z0, z1;
+      abz_normal_pair(w, T, &z0, &z1);
+      return abz_exp(abz_fma(p1, z0, p0));
+    }
+    case ABZ_PRIOR_CAUCHY: {                          /* the ratio of two independent standard normals */
+      double z0, z1;
+      abz_normal_pair(w, T, &z0, &z1);
+      return z1 == 0.0 ? p0 : abz_fma(p1, z0 / z1, p0);
+    }
+    case ABZ_PRIOR_LAPLACE: {                         /* an exponential with a random sign */
+      const double e = -abz_log(abz_u01_open(w.w0));
+      return (w.w1 >> 63) ? p0 - p1 * e : abz_fma(p1, e, p0);
+    }
+    case ABZ_PRIOR_WEIBULL: {                         /* theta E^(1/alpha), E exponential */
+      const double e = -abz_log(abz_u01_open(w.w0));
+      return p1 * abz_exp(abz_log(e) / p0);
+    }
+    case ABZ_PRIOR_INVGAMMA:
+      return p1 / abz_gamma_draw(p0, seed, i, retry, base, T);
+    case ABZ_PRIOR_TRUNCNORMAL: {                     /* rejection from the parent Normal; hosts refuse a mass below 1 % */
+      const double lo = pd->c1, hi = pd->reserved;
+      for (uint32_t a = 0; a < 4096u; ++a) {
+        double z0, z1;
+        abz_normal_pair(abz_rng(seed, i, retry, base + a, ABZ_RNG_INIT_AUX), T, &z0, &z1);
+        const double x0 = abz_fma(p1, z0, p0), x1 = abz_fma(p1, z1, p0);
+        if (x0 >= lo && x0 <= hi) return x0;
+        if (x1 >= lo && x1 <= hi) return x1;
+      }
+      return p0 < lo ? lo : (p0 > hi ? hi : p0);
+    }
+    case ABZ_PRIOR_LOGISTIC: {                        /* inversion: mu + theta log(U / (1 - U)) */
+      const double u = abz_u01_open(w.w0);
+      return abz_fma(p1, abz_log(u) - abz_log(1.0 - u), p0);
+    }
+    case ABZ_PRIOR_TDIST: {                           /* Z / sqrt(chi2_nu / nu), chi2_nu = 2 Gamma(nu / 2) */
+      double z0, z1;
+      abz_normal_pair(w, T, &z0, &z1);
+      const double g = abz_gamma_draw(0.5 * p0, seed, i, retry, base + 1024u, T);
+      return z0 * abz_sqrt(p0 / (2.0 * g));
+    }
+    case ABZ_PRIOR_PARETO:                            /* theta U^(-1/alpha) */
+      return p1 * abz_exp(-abz_log(abz_u01_open(w.w0)) / p0);
+    case ABZ_PRIOR_POISSON: {                         /* inversion from 0: P(0) = exp(-lambda), P(k+1) = P(k) lambda / (k+1) */
+      const double u = abz_u01_co(w.w0);
+      double P = abz_exp(pd->c0), cum = P, kk = 0.0;
+      for (int it = 0; it < 100000 && u >= cum; ++it) {
+        kk += 1.0;
+        P = P * (p0 / kk);
+        cum += P;
+        if (kk > p0 && P < 0x1p-70) break;            /* past the mode with terms that can no longer move the sum */
+      }
+      return kk;
+    }
+    case ABZ_PRIOR_BINOMIAL: {                        /* inversion from the thinner end: k successes or n - k */
+      const int flip = p1 > 0.5;
+      const double pp = flip ? 1.0 - p1 : p1, qq = 1.0 - pp, ratio = pp / qq;
+      const double u = abz_u01_co(w.w0);
+      double P = abz_exp(p0 * abz_log(qq)), cum = P, kk = 0.0;
+      for (int it = 0; it < 100000 && u >= cum && kk < p0; ++it) {
+        P = P * ((p0 - kk) / (kk + 1.0)) * ratio;
+        kk += 1.0;
+        cum += P;
+        if (kk > p0 * pp && P < 0x1p-70) break;
+      }
+      return flip ? p0 - kk : kk;
+    }
+    default:
+      return 0.0;
   }
-  return kk;
 }
 
 /* ------------------------------------------------------------------ ABC kernels (types.jl:26-73) */

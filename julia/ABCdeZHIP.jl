@@ -141,6 +141,42 @@ descriptor(p::Uniform) = AbzPriorDim(2, 0, p.a, p.b, -log(p.b - p.a), 0.0, 0.0)
 descriptor(p::DiscreteUniform) = AbzPriorDim(3, 1, p.a, p.b, -log(p.b - p.a + 1), 0.0, 0.0)
 descriptor(p::Beta) = AbzPriorDim(4, 0, p.α, p.β, -(lgam(p.α) + lgam(p.β) - lgam(p.α + p.β)), 0.0, 0.0)
 descriptor(p::NegativeBinomial) = AbzPriorDim(5, 1, p.r, p.p, p.r * log(p.p) - lgam(p.r), p.p < 1 ? log1p(-p.p) : -Inf, 0.0)
+# the further univariate families of Distributions.jl the device knows (include/abcdez_spec.h, ABZ_PRIOR_EXPONENTIAL ...), in
+# Distributions' own parametrisations; (family, discrete, p0, p1, c0, c1, reserved) as laid out there
+descriptor(p::Exponential) = (θ = scale(p); AbzPriorDim(6, 0, θ, 0.0, -log(θ), 1 / θ, 0.0))
+descriptor(p::Gamma) = ((α, θ) = params(p); AbzPriorDim(7, 0, α, θ, -lgam(α) - α * log(θ), 1 / θ, 0.0))
+descriptor(p::Chisq) = descriptor(Gamma(dof(p) / 2, 2.0))
+descriptor(p::Erlang) = descriptor(Gamma(Float64(shape(p)), scale(p)))
+descriptor(p::LogNormal) = ((μ, σ) = params(p); AbzPriorDim(8, 0, μ, σ, -log(σ) - 0.5 * log(2π), 1 / σ, 0.0))
+descriptor(p::Cauchy) = ((μ, σ) = params(p); AbzPriorDim(9, 0, μ, σ, -log(π * σ), 1 / σ, 0.0))
+descriptor(p::Laplace) = ((μ, θ) = params(p); AbzPriorDim(10, 0, μ, θ, -log(2θ), 1 / θ, 0.0))
+descriptor(p::Weibull) = ((α, θ) = params(p); AbzPriorDim(11, 0, α, θ, log(α / θ), 1 / θ, 0.0))
+descriptor(p::Rayleigh) = descriptor(Weibull(2.0, sqrt(2.0) * scale(p)))
+descriptor(p::InverseGamma) = ((α, θ) = params(p); AbzPriorDim(12, 0, α, θ, α * log(θ) - lgam(α), 0.0, 0.0))
+function descriptor(p::Truncated{<:Normal})                  # truncated(Normal(μ, σ), lo, hi); either bound may be missing
+    (μ, σ) = params(p.untruncated)
+    lo = p.lower === nothing ? -Inf : Float64(p.lower); hi = p.upper === nothing ? Inf : Float64(p.upper)
+    mass = cdf(p.untruncated, hi) - cdf(p.untruncated, lo)
+    mass >= 0.01 || error("truncated(Normal): [lo, hi] holds $mass of the Normal's mass; the device draws the initial " *
+                          "population by rejection from the parent and needs at least 0.01")
+    AbzPriorDim(13, 0, μ, σ, -log(σ) - 0.5 * log(2π) - log(mass), lo, hi)
+end
+descriptor(p::Logistic) = ((μ, θ) = params(p); AbzPriorDim(14, 0, μ, θ, -log(θ), 1 / θ, 0.0))
+descriptor(p::TDist) = (ν = dof(p); AbzPriorDim(15, 0, ν, (ν + 1) / 2, lgam((ν + 1) / 2) - lgam(ν / 2) - 0.5 * log(ν * π), 1 / ν, 0.0))
+descriptor(p::Pareto) = ((α, θ) = params(p); AbzPriorDim(16, 0, α, θ, log(α) + α * log(θ), 0.0, 0.0))
+function descriptor(p::Poisson)
+    λ = rate(p); 0 < λ <= 700 || error("Poisson: the device's inversion sampler needs 0 < λ <= 700")
+    AbzPriorDim(17, 1, λ, 0.0, -λ, log(λ), 0.0)
+end
+function descriptor(p::Binomial)
+    (n, q) = params(p)
+    0 < q < 1 || error("Binomial: a degenerate prior (p = 0 or 1) has no device descriptor")
+    n * log1p(-min(q, 1 - q)) > -700 || error("Binomial: n too large for the device's inversion sampler")
+    AbzPriorDim(18, 1, Float64(n), q, lgam(n + 1.0) + n * log1p(-q), log(q) - log1p(-q), 0.0)
+end
+descriptor(p::Geometric) = descriptor(NegativeBinomial(1.0, succprob(p)))
+descriptor(p) = error("no device descriptor for a prior of type $(typeof(p)): the univariate families of include/abcdez_spec.h " *
+                      "(ABZ_PRIOR_*), Factored / product_distribution of them and MvNormal are supported")
 kernelid(::Type{ABCdeZ.Indicator0toϵ}) = Int32(0);  kernelid(::Type{ABCdeZ.IndicatorStrict0toϵ}) = Int32(1)
 kernelid(::Type{ABCdeZ.Epa0toϵ}) = Int32(2);        kernelid(::Type{ABCdeZ.EpaStrict0toϵ}) = Int32(3)
 

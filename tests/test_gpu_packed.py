@@ -23,6 +23,10 @@ def models():
         "quad2d_inf": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.01),
         "normdu": (A.Factored(A.Normal(1, 0.5), A.DiscreteUniform(1, 10)), A.NormalTimesDU(5.5), 0.01),
         "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)), A.Socks(0, 11), 0.01),
+        # further Distributions.jl families (abcdez_spec.h, ABZ_PRIOR_EXPONENTIAL ...)
+        "further8": (A.Factored(A.Exponential(1.5), A.Gamma(2.5, 0.6), A.LogNormal(0.0, 0.5), A.Cauchy(1.0, 0.5), A.Poisson(2.0),
+                                A.Weibull(1.8, 1.2), A.TDist(4.0), A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0)),
+                     A.MVNormal(tuple([1.0] * 8)), 2.5),
     }
 
 
@@ -230,6 +234,13 @@ def wide_models():
                                  for k in range(32)]), A.MVNormal(tuple([0.25 * (k % 5) for k in range(32)])), (4, 8)),
         "mv16": (A.MvNormal(np.linspace(-0.5, 0.5, 16), cov), A.MVNormal(tuple([0.2] * 16)), (2, 4)),
         "narrow_normal32": (A.Factored(*[A.Normal(0.0, 0.3) for _ in range(32)]), A.MVNormal(tuple([1.0] * 32)), (4,)),
+        # the further Distributions.jl families: half lines, heavy tails, a truncation, counts -- out-of-support proposals on
+        # some components only, log-densities with logarithms and lgamma in both phases
+        "further16": (A.Factored(A.Exponential(1.5), A.Gamma(2.5, 0.6), A.LogNormal(0.0, 0.5), A.Cauchy(1.0, 0.5), A.Laplace(1.0, 1.0),
+                                 A.Weibull(1.8, 1.2), A.InverseGamma(3.0, 2.0), A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0),
+                                 A.Logistic(1.0, 0.5), A.TDist(4.0), A.Pareto(3.0, 0.5), A.Poisson(2.0), A.Binomial(6, 0.3),
+                                 A.Geometric(0.4), A.Chisq(2.0), A.Normal(1.0, 1.0)),
+                      A.MVNormal(tuple([1.0] * 16)), (2, 4, 8)),
         # one lane per particle, two phases all the same: the simulator is 160 RK4 steps and most proposals leave the prior's box
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6, 0.9, 0.5),
@@ -280,7 +291,7 @@ def test_two_phase_sweep_on_wide_rows(oracle, name, abck):
             assert same(a, b), (lanes, k)
 
 
-@pytest.mark.parametrize("name", ["mvn32", "mvn3", "normal1d"])
+@pytest.mark.parametrize("name", ["mvn32", "mvn3", "normal1d", "further8"])
 def test_packed_shard_sweep_plus_replay_equals_full_sweep(oracle, name):
     """what the ranks of a sharded run do, on one GPU: every "rank" sweeps its sub-range of the prefix on its own
     replica (flags out, no counters), the flags are merged, every rank replays the others' accepted proposals;

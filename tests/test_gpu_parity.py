@@ -29,6 +29,13 @@ def models():
         "mixture": (A.Uniform(-10, 10), A.Mixture01(0.0), 0.01),
         # test/runtests.jl:439-445: NegativeBinomial(mu 30, sd 15) x Beta(15, 2), rejection samplers at init
         "socks": (A.Factored(A.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), A.Beta(15, 2)), A.Socks(0, 11), 0.01),
+        # the further Distributions.jl families (abcdez_spec.h ABZ_PRIOR_EXPONENTIAL ...): one lane per particle, lane groups
+        "gamma1d": (A.Gamma(2.0, 1.5), A.Normal1D(3.0), 0.3),
+        "further8": (A.Factored(A.Exponential(1.5), A.Gamma(2.5, 0.6), A.LogNormal(0.0, 0.5), A.Cauchy(1.0, 0.5), A.Laplace(1.0, 1.0),
+                                A.Weibull(1.8, 1.2), A.InverseGamma(3.0, 2.0), A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0)),
+                     A.MVNormal(tuple([1.0] * 8)), 2.5),
+        "further5": (A.Factored(A.Logistic(1.0, 0.5), A.TDist(4.0), A.Pareto(3.0, 0.5), A.Poisson(2.0), A.Binomial(6, 0.3)),
+                     A.MVNormal((1.0, 0.5, 0.8, 2.0, 2.0)), 2.0),
     }
 
 
@@ -250,7 +257,7 @@ def test_stratified_resample_parity(oracle, N):
 
 
 # ---------------------------------------------------------------- S4
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac", "socks"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d_inf", "normdu", "dirac", "socks", "gamma1d", "further8", "further5"])
 def test_mc_sweep_parity(oracle, name):
     N = 5000
     spec, hip, orc, eps_target = engines(name, N, oracle=oracle, storage="classic")
@@ -494,7 +501,8 @@ def test_mc_generation_tickets_are_bounded_and_ordered(oracle):
 
 # ---------------------------------------------------------------- whole drivers, product vs C restatement
 @pytest.mark.parametrize("name,N", [("normal1d", 5000), ("uniform1d", 5000), ("mvn8", 4096), ("mvn32", 8192),
-                                    ("quad2d_inf", 500), ("normdu", 100), ("dirac", 100), ("socks", 3000)])
+                                    ("quad2d_inf", 500), ("normdu", 100), ("dirac", 100), ("socks", 3000), ("gamma1d", 3000),
+                                    ("further8", 4096), ("further5", 2000)])
 @pytest.mark.parametrize("abck", [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ])
 def test_abcdesmc_end_to_end_parity(oracle, name, N, abck):
     if name == "mvn32" and abck is not A.IndicatorStrict0toϵ:
@@ -527,7 +535,8 @@ def test_abcdesmc_reuses_the_select_enqueued_ahead():
 
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
                                          ("quad2d_inf", 500, 80), ("normal1d", 60000, 70), ("normal1d_tight", 60000, 60),
-                                         ("normal1d_tight", 3000, 60)])
+                                         ("normal1d_tight", 3000, 60), ("gamma1d", 3000, 40), ("further8", 2000, 40),
+                                         ("further5", 1500, 40)])
 def test_abcdemc_end_to_end_parity(oracle, name, N, gens):
     """(normal1d_tight: fewer than 1 / 16 of the particles at or below eps_target for the first generations, so the rank pass is
     seen launching both sorts, then -- once eps_pop == eps_target bounds the tail -- only the radix sort (N = 60000) or only the
@@ -734,12 +743,26 @@ def test_blobs_parity(oracle, name, N):
 
 
 # ---------------------------------------------------------------- randomized models: every d, mixed prior families
-def _random_model(seed):
+def _further_family(k, rng):
+    """one factor of the families beyond the five of the reference's tests, with random parameters"""
+    u = lambda a, b: float(rng.uniform(a, b))                                                        # noqa: E731
+    return [lambda: A.Exponential(u(0.3, 3.0)), lambda: A.Gamma(u(0.5, 5.0), u(0.3, 2.0)), lambda: A.LogNormal(u(-0.5, 0.5), u(0.2, 1.0)),
+            lambda: A.Cauchy(u(-1.0, 1.0), u(0.3, 2.0)), lambda: A.Laplace(u(-1.0, 1.0), u(0.3, 2.0)),
+            lambda: A.Weibull(u(0.7, 4.0), u(0.5, 3.0)), lambda: A.InverseGamma(u(1.5, 5.0), u(0.5, 3.0)),
+            lambda: A.truncated(A.Normal(u(-1.0, 1.0), u(0.5, 2.0)), u(-2.0, -0.2), None if rng.random() < 0.4 else u(0.5, 3.0)),
+            lambda: A.Logistic(u(-1.0, 1.0), u(0.3, 1.5)), lambda: A.TDist(u(1.0, 8.0)), lambda: A.Pareto(u(1.0, 4.0), u(0.2, 1.5)),
+            lambda: A.Poisson(u(0.5, 12.0)), lambda: A.Binomial(int(rng.integers(1, 40)), u(0.1, 0.9))][k]()
+
+
+def _random_model(seed, nfam=5):
     rng = np.random.default_rng(seed)
     d = int(rng.integers(1, 33))
     fams = []
     for _ in range(d):
-        k = int(rng.integers(0, 5))
+        k = int(rng.integers(0, nfam))
+        if k >= 5:
+            fams.append(_further_family(k - 5, rng))
+            continue
         if k == 0:
             fams.append(A.Normal(float(rng.normal(0.5, 1.0)), float(rng.uniform(0.3, 2.0))))
         elif k == 1:
@@ -758,12 +781,8 @@ def _random_model(seed):
     return d, prior, A.MVNormal(y, sigma=float(rng.uniform(0.5, 1.5)), blobs=bool(rng.random() < 0.5)), kern
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
-def test_random_models_end_to_end_parity(oracle, seed):
-    """40 seeded random models -- length(prior) 1..32 (every lane-group shape), all five prior families mixed, all
-    four ABC kernels, blobs on or off -- through the complete abcdesmc driver (row store) and a few abcdemc
-    generations (double buffer): HIP == oracle bit for bit."""
-    d, prior, sim, kern = _random_model(1000 + seed)
+def _random_model_case(oracle, seed, nfam):
+    d, prior, sim, kern = _random_model(1000 + seed, nfam)
     N = max(64, int(math.ceil(3 * d / 0.5)) + 40) * 8
     rng = np.random.default_rng(seed)
     # a target the population reaches in a handful of generations: the 30 % quantile of the initial distances
@@ -786,3 +805,18 @@ def test_random_models_end_to_end_parity(oracle, seed):
     mo = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=6, verbose=False, rng=seed + 2,
                    engine=oracle.oracle_engine)
     assert m.nsims == mo.nsims and np.array_equal(m.P, mo.P) and np.array_equal(m.C, mo.C)
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_models_end_to_end_parity(oracle, seed):
+    """40 seeded random models -- length(prior) 1..32 (every lane-group shape), all five prior families of the reference's tests
+    mixed, all four ABC kernels, blobs on or off -- through the complete abcdesmc driver (row store) and a few abcdemc
+    generations (double buffer): HIP == oracle bit for bit."""
+    _random_model_case(oracle, seed, 5)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 124)))
+def test_random_models_of_every_prior_family_end_to_end_parity(oracle, seed):
+    """the same with all 18 univariate families the device knows (`prior::Distribution`, src/abcdez_smc.jl:165): heavy tails,
+    half lines, truncations, counts -- their samplers at the initial population, their log-densities in every sweep"""
+    _random_model_case(oracle, seed, 18)

@@ -317,3 +317,33 @@ def test_public_wsample_stratified(oracle):
     assert inds.shape == (1000,) and (np.diff(inds) >= 0).all() and (w[inds] > 0).all()
     with pytest.raises(ValueError, match="Sum of weights"):
         A.wsample_stratified(w * 2, engine=eng)
+
+
+def test_prior_family_ids_agree_between_header_python_and_julia():
+    """include/abcdez_spec.h (ABZ_PRIOR_*), abcdez_amd/priors.py (PRIOR_*) and the descriptor() methods of julia/ABCdeZHIP.jl name
+    the same family with the same number and the same discrete flag"""
+    from abcdez_amd import priors
+
+    hdr = open(os.path.join(ROOT, "include", "abcdez_spec.h"), encoding="utf-8").read()
+    ids = {m.group(1): int(m.group(2)) for m in re.finditer(r"ABZ_PRIOR_(\w+) = (\d+)", hdr)}
+    last = ids.pop("LAST")
+    assert sorted(ids.values()) == list(range(last + 1))
+    for name, n in ids.items():
+        assert getattr(priors, "PRIOR_" + name) == n, name
+    jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    julia_name = {"NORMAL": "Normal", "UNIFORM": "Uniform", "DUNIFORM": "DiscreteUniform", "BETA": "Beta", "NEGBIN": "NegativeBinomial",
+                  "EXPONENTIAL": "Exponential", "GAMMA": "Gamma", "LOGNORMAL": "LogNormal", "CAUCHY": "Cauchy", "LAPLACE": "Laplace",
+                  "WEIBULL": "Weibull", "INVGAMMA": "InverseGamma", "TRUNCNORMAL": "Truncated{<:Normal}", "LOGISTIC": "Logistic",
+                  "TDIST": "TDist", "PARETO": "Pareto", "POISSON": "Poisson", "BINOMIAL": "Binomial"}
+    py_class = {"NORMAL": priors.Normal(), "UNIFORM": priors.Uniform(), "DUNIFORM": priors.DiscreteUniform(), "BETA": priors.Beta(),
+                "NEGBIN": priors.NegativeBinomial(), "EXPONENTIAL": priors.Exponential(), "GAMMA": priors.Gamma(),
+                "LOGNORMAL": priors.LogNormal(), "CAUCHY": priors.Cauchy(), "LAPLACE": priors.Laplace(), "WEIBULL": priors.Weibull(),
+                "INVGAMMA": priors.InverseGamma(), "TRUNCNORMAL": priors.TruncatedNormal(), "LOGISTIC": priors.Logistic(),
+                "TDIST": priors.TDist(), "PARETO": priors.Pareto(), "POISSON": priors.Poisson(), "BINOMIAL": priors.Binomial()}
+    assert set(julia_name) == set(ids) - {"PAD"}
+    for name, jn in julia_name.items():
+        at = jl.index("descriptor(p::%s)" % jn)
+        m = re.search(r"AbzPriorDim\((\d+), (\d),", jl[at:])
+        assert m and int(m.group(1)) == ids[name], (name, m and m.group(0))
+        d = py_class[name].descriptor()
+        assert d[0] == ids[name] and int(m.group(2)) == d[1] == int(py_class[name].discrete), name

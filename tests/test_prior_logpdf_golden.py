@@ -14,10 +14,24 @@ import abcdez_amd as A
 from abcdez_amd.model import ModelSpec
 
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prior_logpdf_scipy.json")))["cases"]
+def _num(v):
+    return math.inf if v == "inf" else (-math.inf if v == "-inf" else v)
+
+
 DISTS = {"Normal": A.Normal, "Uniform": A.Uniform, "DiscreteUniform": A.DiscreteUniform, "Beta": A.Beta,
-         "NegativeBinomial": A.NegativeBinomial}
-# abz_lgamma: < 3e-14 max(1, |lgamma|) (tests/test_spec_math.py); the NegativeBinomial pmf subtracts two such values
-TOL = {"Normal": 4e-15, "Uniform": 4e-16, "DiscreteUniform": 4e-16, "Beta": 2e-14, "NegativeBinomial": 2e-13}
+         "NegativeBinomial": A.NegativeBinomial,
+         # the further Distributions.jl families (`prior::Distribution`, src/abcdez_smc.jl:165)
+         "Exponential": A.Exponential, "Gamma": A.Gamma, "LogNormal": A.LogNormal, "Cauchy": A.Cauchy, "Laplace": A.Laplace,
+         "Weibull": A.Weibull, "InverseGamma": A.InverseGamma,
+         "TruncatedNormal": lambda mu, sg, lo, hi: A.truncated(A.Normal(mu, sg), _num(lo), _num(hi)),
+         "Logistic": A.Logistic, "TDist": A.TDist, "Pareto": A.Pareto, "Poisson": A.Poisson, "Binomial": A.Binomial}
+# abz_lgamma: < 3e-14 max(1, |lgamma|) (tests/test_spec_math.py); the NegativeBinomial / Binomial pmfs subtract two such values.
+# abz_log / abz_exp: < 1 ulp; a family that scales a logarithm (shape - 1, nu + 1, ...) scales its rounding error too.
+TOL = {"Normal": 4e-15, "Uniform": 4e-16, "DiscreteUniform": 4e-16, "Beta": 2e-14, "NegativeBinomial": 2e-13,
+       "Exponential": 4e-16, "Gamma": 2e-14, "LogNormal": 4e-15, "Cauchy": 4e-16, "Laplace": 4e-16, "Weibull": 4e-15,
+       "InverseGamma": 2e-14, "TruncatedNormal": 4e-15, "Logistic": 4e-16, "TDist": 2e-14, "Pareto": 4e-15, "Poisson": 2e-13,
+       "Binomial": 2e-13}
+COUNTS = ("NegativeBinomial", "Poisson", "Binomial")
 
 
 def want_of(c):
@@ -29,13 +43,15 @@ def groups():
     out = {}
     for c in GOLD:
         out.setdefault((c["family"], tuple(c["p"])), []).append(c)
-    return sorted(out.items())
+    return sorted(out.items(), key=lambda kv: (kv[0][0], str(kv[0][1])))
 
 
-def close(got, want, fam, x):
+def close(got, want, fam, x, p=()):
     if want == -math.inf:
         return got == -math.inf
-    scale = max(1.0, abs(want), abs(x) if fam == "NegativeBinomial" else 0.0)
+    scale = max(1.0, abs(want), abs(x) if fam in COUNTS else 0.0)
+    if fam == "Binomial":              # log C(n, k) as a difference of three lgamma values of size lgamma(n + 1)
+        scale = max(scale, math.lgamma(p[0] + 1.0))
     return abs(got - want) <= TOL[fam] * scale * 8
 
 
@@ -51,9 +67,9 @@ def test_oracle_prior_logpdf_equals_scipy(oracle, key, cases):
     pd = C.addressof(m.c.prior[0])
     for c in cases:
         got = L.orc_prior_logpdf1(pd, float(c["x"]))
-        assert close(got, want_of(c), fam, float(c["x"])), (fam, p, c["x"], got, want_of(c))
+        assert close(got, want_of(c), fam, float(c["x"]), p), (fam, p, c["x"], got, want_of(c))
         host = dist.logpdf(float(c["x"]))             # the Python host mirror agrees too
-        assert close(host, want_of(c), fam, float(c["x"])), (fam, p, c["x"], host)
+        assert close(host, want_of(c), fam, float(c["x"]), p), (fam, p, c["x"], host)
 
 
 @pytest.mark.gpu
@@ -80,5 +96,5 @@ def test_device_prior_logpdf_equals_oracle_and_scipy(oracle):
         for k, c in enumerate(cases):
             ref = L.orc_prior_logpdf1(C.addressof(m.c.prior[0]), float(c["x"]))
             assert np.float64(ref).view(np.int64) == got[k:k + 1].view(np.int64)[0], (fam, p, c["x"], got[k], ref)
-            assert close(float(got[k]), want_of(c), fam, float(c["x"]))
+            assert close(float(got[k]), want_of(c), fam, float(c["x"]), p)
         ops.close()

@@ -2,6 +2,7 @@
 references: published Philox known-answer vectors + a pure-Python Philox, and mpmath /
 numpy for the elementary functions.  CPU only."""
 import ctypes as C
+import math
 
 import mpmath
 import numpy as np
@@ -337,3 +338,85 @@ def test_beta_negbin_logpdf_and_samplers(oracle):
     exp = stats.nbinom.pmf(np.arange(100), nb.r, nb.p) * N
     keep = exp > 20
     assert stats.chisquare(obs[keep] * exp[keep].sum() / obs[keep].sum(), exp[keep]).pvalue > 1e-4
+
+
+FURTHER_FAMILIES = {
+    # name: (host prior, scipy frozen distribution)
+    "Exponential": lambda A: (A.Exponential(2.5), stats.expon(scale=2.5)),
+    "Gamma": lambda A: (A.Gamma(3.2, 0.7), stats.gamma(3.2, scale=0.7)),
+    "Gamma<1": lambda A: (A.Gamma(0.4, 2.0), stats.gamma(0.4, scale=2.0)),
+    "Chisq": lambda A: (A.Chisq(5.0), stats.chi2(5.0)),
+    "LogNormal": lambda A: (A.LogNormal(0.5, 0.8), stats.lognorm(s=0.8, scale=math.exp(0.5))),
+    "Cauchy": lambda A: (A.Cauchy(-1.0, 2.0), stats.cauchy(-1.0, 2.0)),
+    "Laplace": lambda A: (A.Laplace(1.0, 3.0), stats.laplace(1.0, 3.0)),
+    "Weibull": lambda A: (A.Weibull(1.7, 4.0), stats.weibull_min(1.7, scale=4.0)),
+    "Rayleigh": lambda A: (A.Rayleigh(1.5), stats.rayleigh(scale=1.5)),
+    "InverseGamma": lambda A: (A.InverseGamma(3.0, 2.0), stats.invgamma(3.0, scale=2.0)),
+    "truncated(Normal) one side": lambda A: (A.truncated(A.Normal(0.0, 2.0), 0.0, None), stats.truncnorm(0.0, np.inf, 0.0, 2.0)),
+    "truncated(Normal) tail": lambda A: (A.truncated(A.Normal(0.0, 1.0), 1.5, 4.0), stats.truncnorm(1.5, 4.0)),
+    "Logistic": lambda A: (A.Logistic(2.0, 0.5), stats.logistic(2.0, 0.5)),
+    "TDist": lambda A: (A.TDist(3.5), stats.t(3.5)),
+    "Pareto": lambda A: (A.Pareto(2.5, 1.5), stats.pareto(2.5, scale=1.5)),
+    "Poisson": lambda A: (A.Poisson(6.3), stats.poisson(6.3)),
+    "Poisson large": lambda A: (A.Poisson(400.0), stats.poisson(400.0)),
+    "Binomial": lambda A: (A.Binomial(30, 0.2), stats.binom(30, 0.2)),
+    "Binomial p>1/2": lambda A: (A.Binomial(500, 0.93), stats.binom(500, 0.93)),
+    "Geometric": lambda A: (A.Geometric(0.15), stats.geom(0.15, loc=-1)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FURTHER_FAMILIES))
+def test_further_prior_families_initial_population_follows_the_prior(oracle, name):
+    """the initial population is a sample from the prior (`rand(prior)`, src/abcdez_init.jl:8, smc:242): Kolmogorov-Smirnov
+    (continuous) / chi-square (counts) of the oracle's draws against scipy's distribution of the same parameters; every
+    draw inside the support with a finite log-density that equals the host mirror's"""
+    import abcdez_amd as A
+    from abcdez_amd.model import ModelSpec
+
+    prior, ref = FURTHER_FAMILIES[name](A)
+    N = 60000
+    spec = ModelSpec(prior, A.DiracSquare(1.5), seed=11)
+    eng = oracle.oracle_engine(spec, N)
+    eng.init_population()
+    x = eng.state[0].numpy()[:, 0].copy()
+    lp = eng.state[1].numpy().copy()
+    assert np.all(np.isfinite(x)) and np.all(np.isfinite(lp))
+    for j in range(0, N, 997):
+        assert prior.insupport(float(x[j]))
+        want = prior.logpdf(float(x[j]))
+        assert abs(lp[j] - want) <= 1e-12 * max(1.0, abs(want), math.lgamma(getattr(prior, "n", 0) + 1.0)), (name, x[j], lp[j], want)
+    if prior.discrete:
+        assert np.array_equal(x, np.rint(x))
+        k = x.astype(np.int64)
+        lo, hi = int(k.min()), int(k.max())
+        obs = np.bincount(k - lo, minlength=hi - lo + 1).astype(float)
+        exp = ref.pmf(np.arange(lo, hi + 1)) * N
+        keep = exp > 20
+        assert keep.sum() >= 5
+        assert stats.chisquare(obs[keep] * exp[keep].sum() / obs[keep].sum(), exp[keep]).pvalue > 1e-4, name
+        assert abs(k.mean() - ref.mean()) < 5 * ref.std() / math.sqrt(N)
+    else:
+        assert stats.kstest(x, ref.cdf).pvalue > 1e-3, name
+    # a second seed is a different sample
+    eng2 = oracle.oracle_engine(ModelSpec(prior, A.DiracSquare(1.5), seed=12), 64)
+    eng2.init_population()
+    assert not np.array_equal(eng2.state[0].numpy()[:, 0], x[:64])
+
+
+def test_further_prior_families_in_a_factored_prior_are_independent(oracle):
+    """components of a Factored prior draw from separate counter streams (one per component index): no correlation between
+    components of the same family, each marginal still its own law"""
+    import abcdez_amd as A
+    from abcdez_amd.model import ModelSpec
+
+    prior = A.Factored(A.Gamma(2.0, 1.0), A.Gamma(2.0, 1.0), A.Exponential(1.0), A.Exponential(1.0), A.TDist(5.0), A.LogNormal(0.0, 0.5),
+                       A.Poisson(3.0), A.Normal(0.0, 1.0))
+    N = 40000
+    spec = ModelSpec(prior, A.MVNormal((1.0,) * 8), seed=5)
+    eng = oracle.oracle_engine(spec, N)
+    eng.init_population()
+    th = eng.state[0].numpy()[:, :8]
+    c = np.corrcoef(th.T)
+    assert np.abs(c - np.eye(8)).max() < 0.03, c
+    assert stats.kstest(th[:, 1], stats.gamma(2.0).cdf).pvalue > 1e-3 and stats.kstest(th[:, 3], stats.expon().cdf).pvalue > 1e-3
+    assert stats.kstest(th[:, 4], stats.t(5.0).cdf).pvalue > 1e-3 and stats.kstest(th[:, 7], "norm").pvalue > 1e-3
