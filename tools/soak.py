@@ -26,6 +26,11 @@ cases = {
                                           rng=7, nsims_max=10 ** 12),
     "lv 2^18": lambda: A.abcdesmc(A.Factored(*[A.Uniform(0.0, 2.0)] * 4), lv, 1.0, None, nparticles=1 << 18, verbose=False, rng=9,
                                   nsims_max=10 ** 12),
+    "further families 2^20": lambda: A.abcdesmc(A.Factored(A.Exponential(1.5), A.Gamma(2.5, 0.6), A.LogNormal(0.0, 0.5), A.Cauchy(1.0, 0.5),
+                                                           A.Poisson(2.0), A.Weibull(1.8, 1.2), A.TDist(4.0),
+                                                           A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0)),
+                                                A.MVNormal((1.0,) * 8), 2.5, None, nparticles=1 << 20, verbose=False, rng=15,
+                                                nsims_max=10 ** 12),
     "epa 2^20": lambda: A.abcdesmc(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, None, nparticles=1 << 20, verbose=False, rng=11,
                                    ABCk=A.Epa0toϵ, nsims_max=10 ** 12),
 }
