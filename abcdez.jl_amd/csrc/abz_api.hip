@@ -51,6 +51,19 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
   return 0;
 }
 
+/* the hand-over list of the Lotka-Volterra sweep: [count | pad to 256 B | tp 32 B | wl 8 | kdi 8 | logu 8 | pos 4] per position */
+int abz_lv_hand_reserve(abcdez_ctx* ctx, size_t positions) {
+  if (positions <= ctx->lv_hand_cap) return 0;
+  ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->lv_hand) ABZ_HIP_CHECK(hipFree(ctx->lv_hand));
+  ctx->lv_hand = nullptr; ctx->lv_hand_cap = 0;
+  const size_t cap = abz_align(positions + positions / 8, 1024);
+  ABZ_HIP_CHECK(hipMalloc(&ctx->lv_hand, 256 + cap * 64));
+  ABZ_HIP_CHECK(hipMemset(ctx->lv_hand, 0, 256));              /* both counters zero: the invariant the sweeps keep */
+  ctx->lv_hand_cap = cap;
+  return 0;
+}
+
 static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 /* default lane-group shape: 8 components (64 contiguous bytes) per lane for the
@@ -241,6 +254,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->lv_hand) (void)hipFree(ctx->lv_hand);
   if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
   if (ctx->d_scal) (void)hipFree(ctx->d_scal);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
@@ -259,6 +273,7 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
   /* the largest user: the resampling (8 N of cumulative weights + tile sums) / the rank pass of abcdemc (12 N + its table) */
   int rc = abz_ws_reserve(ctx, (size_t)N * 16 + ((size_t)8 << 20));
   if (rc) return rc;
+  if (ctx->h_model.sim_id == ABZ_SIM_LV && (rc = abz_lv_hand_reserve(ctx, (size_t)N))) return rc;     /* no allocation inside the loop */
   /* The resampling's kernels run for the first time ~14 generations into a run; HIP loads a kernel's code on its first
    * launch (about 0.2 ms each), which would land in the middle of the loop: run them once here on a 64-particle dummy. */
   const int64_t n = 64;

@@ -85,6 +85,9 @@ struct abcdez_ctx {
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  void* lv_hand = nullptr;              /* Lotka-Volterra sweep: the list between its two launches (abz_kernels.h, LvHandList), 64 B per position */
+  size_t lv_hand_cap = 0;               /* positions the list has room for */
+  unsigned long long lv_seq = 0;        /* sweeps launched: parity picks the list counter (abz_smc_swarm.hip) */
   /* hiprtc-compiled kernels of a user-supplied simulator (abz_jit.hip), else null */
   void* user_module = nullptr;
   /* quantile select: its own histogram (left zeroed by every call) and the arrays the device-side window belongs to */
@@ -204,6 +207,7 @@ static inline unsigned abz_persistent_grid(abcdez_ctx* ctx, K kernel, uint64_t n
 
 /* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
+int abz_lv_hand_reserve(abcdez_ctx* ctx, size_t positions);
 
 static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

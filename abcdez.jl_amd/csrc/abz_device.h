@@ -56,6 +56,21 @@ __device__ inline void store_row(double* __restrict__ row, int j, const double (
   }
 }
 
+/* the same row through non-temporal stores: for rows nobody reads again soon */
+template <int L, int C>
+__device__ inline void store_row_nt(double* __restrict__ row, int j, const double (&v)[C]) {
+  if constexpr (C == 1) {
+    __builtin_nontemporal_store(v[0], row);
+  } else {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) {
+      d2v t; t.x = v[2 * m]; t.y = v[2 * m + 1];
+      __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(row + m * 2 * L + 2 * j));
+    }
+  }
+}
+
 /* The read-mostly model tables (prior descriptors, data vector) are staged in LDS once per
  * workgroup: every group of a block reads the same ld entries, so this turns ~10 dependent
  * global loads per component into broadcast LDS reads and keeps them out of the VGPR budget. */

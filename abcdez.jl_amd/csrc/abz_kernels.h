@@ -468,6 +468,201 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
                                                  (((s_ins[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) << 1));
 }
 
+/* ---- Lotka-Volterra (BASELINE configs[3]): the two phases as TWO KERNELS, the hand-over through global memory.
+ *
+ * Inside one kernel (above) a workgroup's phase 2 occupies only the wavefronts its own survivors fill -- a third of the tile's
+ * proposals at the start of a run, fewer later -- while the other wavefronts of the workgroup wait at its barriers: 1500 dependent RK4
+ * steps per proposal run at a third of the occupancy the registers allow.  Here phase 1 appends every proposal that may still be
+ * accepted to ONE list (64 bytes per record: the proposal row, lp - lpi, K(di), log(rand), the position), and phase 2 is a launch of
+ * its own over that list: every workgroup starts with all its lanes on a proposal.  Random numbers are addressed by position
+ * and every output is keyed by position, so the order of the list (an atomic counter's) changes nothing: the same bits as the one-kernel
+ * body, the one-phase body and the oracle.  Phase 1 leaves bits_out = bits and the flag bytes without the accepted bit; phase 2
+ * flips / sets them for the proposals it accepts. */
+struct LvHandList {
+  double* tp;               /* [cap][4] proposal rows */
+  double* wl;               /* lp - lpi */
+  double* kdi;              /* K(di) */
+  double* logu;             /* log(rand) of smc:145 */
+  uint32_t* pos;            /* position | own slot bit << 31 */
+  unsigned int* count;      /* records in the list: zero when phase 1 starts */
+  unsigned int* count_next; /* the counter of the NEXT sweep (the two alternate): phase 2 zeroes it, whether or not the sweep runs */
+};
+#ifndef ABZ_LV_BLOCK2
+#define ABZ_LV_BLOCK2 256   /* threads per workgroup of the second launch */
+#endif
+
+template <bool PLAIN, int BLOCK = ABZ_BLOCK>
+__device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandList& h) {
+  constexpr int L = 1, C = 4, LD = 4, PB = BLOCK;
+  const HotModel& M = a.hm;
+  if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
+  const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const uint32_t grp = tile * BLOCK + threadIdx.x;
+  const bool active = grp < a.n_work;
+  const uint32_t tile_base = a.r_lo + tile * (uint32_t)PB;
+  const uint32_t ri = a.r_lo + (active ? grp : 0u);
+
+  __shared__ ModelLds<LD> s_model;
+  __shared__ uint32_t s_ins[PB / 32];
+  __shared__ uint32_t s_n, s_base;
+
+  ModelStage<ABZ_SIM_LV, LD, BLOCK> stage;
+  stage.load(M);
+  const uint32_t wi = a.bits[ri >> 5];
+  ParticleDraws<L> draws;
+  uint32_t ra, rb;
+  draws.words(M.seed, ri, a.sweep, 0, a.n_alive, ri, &ra, &rb);
+  const uint32_t wa = a.bits[ra >> 5], wb = a.bits[rb >> 5];
+  const double lpi = a.logpi[ri];
+  const double dli = a.delta[ri];
+  if (threadIdx.x < PB / 32) s_ins[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) s_n = 0u;
+  const uint32_t bi = (wi >> (ri & 31u)) & 1u, ba = (wa >> (ra & 31u)) & 1u, bb = (wb >> (rb & 31u)) & 1u;
+  double tp[C], ti[C], ta[C], tb[C];
+  load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, 0, ti);
+  load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, 0, ta);
+  load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, 0, tb);
+  stage.store(s_model);
+  __syncthreads();                                                /* sampler + model tables staged; s_ins, s_n zeroed */
+  double g, log_u;
+  draws.finish(&s_model.tab, a.gamma0, a.gsig, &g, &log_u);
+#pragma unroll
+  for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                /* smc:128 */
+  double pp[C];
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, 0, tp, pp, M.mv);     /* smc:134 */
+  const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
+  const double kdi = kernel_logpdf_dev(M.abck, a.eps, dli);
+  const double wl = lp - lpi;
+  const double w_max = (wl + 0.0) - kdi;                          /* smc:140-141 with K(dp) at its maximum */
+  const bool may = active && insupport && ((0.0 <= w_max) || (log_u < w_max));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long mk = __ballot(may);
+  unsigned int base = 0u;
+  if (lane == 0u && mk) base = atomicAdd(&s_n, (unsigned)__popcll(mk));
+  base = __shfl(base, 0, 64);
+  const unsigned int local = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+  if (active && insupport && a.flags) atomicOr(&s_ins[threadIdx.x >> 5], 1u << (threadIdx.x & 31u));
+  const unsigned nsim1 = (active && insupport) ? 1u : 0u;         /* nsims counts the in-support proposals (smc:138) */
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_n ? atomicAdd(h.count, s_n) : 0u;          /* one reservation per workgroup */
+  __syncthreads();
+  if (may) {
+    const size_t r = (size_t)s_base + local;
+    double2* row = reinterpret_cast<double2*>(h.tp + r * LD);
+    double2 t0, t1;
+    t0.x = tp[0]; t0.y = tp[1]; t1.x = tp[2]; t1.y = tp[3];
+    row[0] = t0; row[1] = t1;
+    h.wl[r] = wl; h.kdi[r] = kdi; h.logu[r] = log_u;
+    h.pos[r] = ri | (bi << 31);
+  }
+  if (threadIdx.x < PB / 32) {                                    /* nothing accepted yet: the second launch flips the bits it accepts */
+    const uint32_t w = tile_base / 32u + threadIdx.x;
+    if (w * 32u < a.r_lo + a.n_work) a.bits_out[w] = a.bits[w];
+  }
+  if (a.flags && tile_base + threadIdx.x < a.r_lo + a.n_work)
+    a.flags[tile_base + threadIdx.x] = (uint8_t)(((s_ins[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) << 1);
+  block_count2<BLOCK>(0u, nsim1, a.cslots, a.c_cls);
+}
+
+template <bool PLAIN, int BLOCK = ABZ_LV_BLOCK2>
+__device__ inline void smc_lv_phase2_body(const SmcPackedArgs& a, const LvHandList& h) {
+  constexpr int L = 1, C = 4, LD = 4, PB = BLOCK;
+  const HotModel& M = a.hm;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *h.count_next = 0u;     /* last read by the sweep before this one; no memset launch */
+  if (a.stop && *a.stop) return;
+  const unsigned n_list = *h.count;
+  const unsigned c0 = blockIdx.x * (unsigned)PB;
+  if (c0 >= n_list) return;                                       /* workgroup-uniform: the grid covers the longest possible list */
+  const unsigned n = (n_list - c0 < (unsigned)PB) ? n_list - c0 : (unsigned)PB;
+
+  __shared__ ModelLds<LD> s_model;
+  __shared__ double s_tp[PB][C];
+  __shared__ double s_wl[PB], s_kdi[PB], s_logu[PB];
+  __shared__ uint32_t s_pos[PB];
+  __shared__ double s_lx[PB], s_ly[PB], s_lacc[PB];
+  __shared__ uint16_t s_list[2][PB];
+  __shared__ unsigned int s_live[3];
+
+  ModelStage<ABZ_SIM_LV, LD, BLOCK> stage;
+  stage.load(M);
+  if (threadIdx.x < n) {
+    const size_t r = (size_t)c0 + threadIdx.x;
+    const double2* row = reinterpret_cast<const double2*>(h.tp + r * LD);
+    const double2 t0 = row[0], t1 = row[1];
+    s_tp[threadIdx.x][0] = t0.x; s_tp[threadIdx.x][1] = t0.y; s_tp[threadIdx.x][2] = t1.x; s_tp[threadIdx.x][3] = t1.y;
+    s_wl[threadIdx.x] = h.wl[r]; s_kdi[threadIdx.x] = h.kdi[r]; s_logu[threadIdx.x] = h.logu[r];
+    s_pos[threadIdx.x] = h.pos[r];
+    s_list[0][threadIdx.x] = (uint16_t)threadIdx.x;
+    s_lx[threadIdx.x] = M.sim_p[0]; s_ly[threadIdx.x] = M.sim_p[1]; s_lacc[threadIdx.x] = 0.0;
+  }
+  if (threadIdx.x < 3) s_live[threadIdx.x] = 0u;
+  stage.store(s_model);
+  __syncthreads();
+
+  const LvConst k = lv_const(M);
+  /* certain rejection: see smc_swarm_packed_body_2p */
+#ifdef ABZ_LV_NO_EARLY_EXIT
+  const double bound = ABZ_NAN;
+#else
+  const double bound = (a.eps > 0.0 && a.eps < 1.0e300) ? (a.eps * a.eps) * (1.0 + 0x1p-40) : ABZ_NAN;
+#endif
+  unsigned n_live = n;
+  int cur = 0;
+  const unsigned lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
+  int round = 0;
+  for (int jo0 = 0; jo0 < k.nobs; jo0 += ABZ_LV_ROUND, ++round) {
+    if (wave0 < n_live) {                                         /* wave-uniform: this wavefront still has proposals */
+      const bool on = threadIdx.x < n_live;
+      const unsigned sl = s_list[cur][on ? threadIdx.x : 0u];     /* idle lanes of a working wave shadow the first proposal */
+      double tq[C], pq[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) tq[q] = s_tp[sl][q];
+      group_push_p<L, C>(s_model.prior, 0, tq, pq);
+      double x = s_lx[sl], y = s_ly[sl], dsum = s_lacc[sl];
+      const uint32_t rs = s_pos[sl] & 0x7FFFFFFFu;
+      bool dead = false;
+      for (int jo = jo0; jo < jo0 + ABZ_LV_ROUND && jo < k.nobs; ++jo) {
+        lv_observe<false>(M, &s_model.tab, k, rs, a.sweep, ABZ_RNG_SIM, jo, x, y, dsum, nullptr);
+        dead = dead || (dsum >= bound);                           /* (false for a NaN sum: it stays, and is rejected at the end) */
+        if (jo + 1 < k.nobs) lv_advance(k, pq[0], pq[1], pq[2], pq[3], x, y);
+      }
+      const bool keep = on && !dead;
+      if (keep) { s_lx[sl] = x; s_ly[sl] = y; s_lacc[sl] = dsum; }
+      const unsigned long long mk = __ballot(keep);
+      unsigned int base = 0u;
+      if (lane == 0u && mk) base = atomicAdd(&s_live[round % 3], (unsigned)__popcll(mk));
+      base = __shfl(base, 0, 64);
+      if (keep) s_list[1 - cur][base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)sl;
+    }
+    __syncthreads();
+    n_live = s_live[round % 3];
+    if (threadIdx.x == 0) s_live[(round + 2) % 3] = 0u;           /* the counter of the round after next (last read a round ago) */
+    cur = 1 - cur;
+  }
+  bool acc = false;
+  if (wave0 < n_live) {                                           /* the proposals whose distance stayed below the bound to the end */
+    const bool on = threadIdx.x < n_live;
+    const unsigned sl = s_list[cur][on ? threadIdx.x : 0u];
+    double tq[C], pq[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) tq[q] = s_tp[sl][q];
+    const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+    const uint32_t pw = s_pos[sl];
+    const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
+    const double ds = abz_sqrt(s_lacc[sl]);                                                        /* smc:137 */
+    const double w = (s_wl[sl] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_kdi[sl];                /* smc:140-141 */
+    acc = on && ((0.0 <= w) || (s_logu[sl] < w));                 /* smc:145 */
+    if (acc) {                                                    /* smc:146-150 */
+      store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, 0, tq);
+      atomicXor(&a.bits_out[rs >> 5], 1u << (rs & 31u));          /* phase 1 left bits_out = bits */
+      if (a.flags) a.flags[rs] = (uint8_t)3u;                     /* accepted | simulated (phase 1 wrote the second bit) */
+      a.logpi[rs] = lps; a.delta[rs] = ds;
+      if (a.stamp) a.stamp[rs] = abz_stamp(rs, a.sweep, 0);
+    }
+  }
+  block_count2<BLOCK>(acc ? 1u : 0u, 0u, a.cslots, a.c_cls);
+}
+
 /* Two phases wherever a skipped simulation is worth a hand-over through LDS: rows spread over 2, 4 or 8 lanes (the d-dimensional
  * Normal simulator: four Philox blocks and Box-Muller pairs per lane), and the Lotka-Volterra simulator (1500 RK4 steps per call; with
  * its bounded prior half of the proposals and more leave the support, smc:135, and in the one-phase body their lanes idle through

@@ -89,6 +89,16 @@ __device__ inline double tile_elem(const TileArgs& a, int64_t k, int& n_pos) {
   }
 }
 
+/* A/B builds (-DABZ_PROLOGUE_NT): the prologue's streaming reads of the distances as non-temporal loads -- do they displace rows the
+ * first sweep of the generation would have found in the last-level cache?  (profiles/HISTORY.md, round 5: no.) */
+__device__ inline double abz_ld_stream(const double* p) {
+#ifdef ABZ_PROLOGUE_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 template <int MODE>
 __global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
   __shared__ double s_w[4];
@@ -329,7 +339,13 @@ __global__ __launch_bounds__(ABZ_BLOCK) void ind_reweight_kernel(const double* _
     double d0 = 0.0, d1 = 0.0;
     uint8_t a0 = 0, a1 = 0;
     if (k + 1 < n) {
+#ifdef ABZ_PROLOGUE_NT
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      const d2v dv = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(delta + k));
+      double2 dd; dd.x = dv.x; dd.y = dv.y;
+#else
       const double2 dd = *reinterpret_cast<const double2*>(delta + k);
+#endif
       const uchar2 aa = *reinterpret_cast<const uchar2*>(alive + k);
       d0 = dd.x; d1 = dd.y; a0 = aa.x; a1 = aa.y;
     } else if (k < n) { d0 = delta[k]; a0 = alive[k]; }
@@ -599,8 +615,13 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_swap_kernel(const uint32_t* __
     double a[C], b[C];
     load_row<L, C>(rh, j, a);
     load_row<L, C>(rf, j, b);
+#ifdef ABZ_PART_SWAP_NT        /* A/B build: the moved rows leave through non-temporal stores */
+    store_row_nt<L, C>(rh, j, b);
+    store_row_nt<L, C>(rf, j, a);
+#else
     store_row<L, C>(rh, j, b);
     store_row<L, C>(rf, j, a);
+#endif
     if (j == 0) {
       double t;
       t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
@@ -903,7 +924,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void qs_minmax_kernel(const double* __re
   unsigned long long lo = ~0ull, hi = 0ull;
   const int64_t stride = (int64_t)gridDim.x * ABZ_BLOCK;
   for (int64_t k = (int64_t)blockIdx.x * ABZ_BLOCK + threadIdx.x; k < N; k += stride) {
-    const unsigned long long key = f64_order_key(delta[k]);
+    const unsigned long long key = f64_order_key(abz_ld_stream(delta + k));
     if (!alive || alive[k]) { lo = key < lo ? key : lo; hi = key > hi ? key : hi; }
   }
   block_minmax_u64(lo, hi);
@@ -961,13 +982,13 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_hist_kernel(const double* __res
     for (int u = 0; u < UM; ++u) {
       const int64_t k = k0 + u * stride;
       const bool in = k < kend;
-      key[u] = in ? f64_order_key(delta[k]) : 0ull;
+      key[u] = in ? f64_order_key(abz_ld_stream(delta + k)) : 0ull;
       al[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
     }
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       const int64_t k = t0 + u * stride;
-      tkey[u] = k < tend ? f64_order_key(delta[k]) : 0ull;
+      tkey[u] = k < tend ? f64_order_key(abz_ld_stream(delta + k)) : 0ull;
     }
 #pragma unroll
     for (int u = 0; u < UM; ++u) {
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
   for (int u = 0; u < 8; ++u) {
     const int64_t k = base + t + u * stride;
     const bool in = k < kend;
-    key[u] = in ? f64_order_key(delta[k]) : 0ull;
+    key[u] = in ? f64_order_key(abz_ld_stream(delta + k)) : 0ull;
     al[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
   }
   const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];      /* 2 consecutive bins per thread */
@@ -1083,7 +1104,7 @@ __global__ __launch_bounds__(ABZ_QS_FAT) void qs_compact_kernel(const double* __
     for (int u = 0; u < 8; ++u) {                                                           /* the next trip's loads */
       const int64_t k = nbase + t + u * stride;
       const bool in = k < kend;
-      nkey[u] = in ? f64_order_key(delta[k]) : 0ull;
+      nkey[u] = in ? f64_order_key(abz_ld_stream(delta + k)) : 0ull;
       nal[u] = in ? (alive ? alive[k] : (uint8_t)1) : (uint8_t)0;
     }
 #pragma unroll

@@ -30,6 +30,15 @@ __global__ __launch_bounds__((abz_sweep_block<SIM, L, C>())) ABZ_SWEEP_WAVES_ATT
  * Forcing six (-DABZ_SWEEP_WAVES=6: 80 registers, three dwords spilled in phase 2; the LDS budget allows it) was measured on two boxes
  * of the pool: -1.6 % on one, +5.6 % on the other (profiles/r05_two_phase_ab2.jsonl, r05_two_phase_ab3.jsonl) -- more rows in flight
  * is not uniformly better for random 256-byte reads, so the default stays. */
+/* Lotka-Volterra: the sweep as two launches with the hand-over list between them (abz_kernels.h, smc_lv_phase1_body) */
+template <bool PLAIN>
+__global__ __launch_bounds__(ABZ_BLOCK) void smc_lv_phase1_kernel(const SmcPackedArgs a, const LvHandList h) {
+  smc_lv_phase1_body<PLAIN, ABZ_BLOCK>(a, h);
+}
+template <bool PLAIN>
+__global__ __launch_bounds__(ABZ_LV_BLOCK2) void smc_lv_phase2_kernel(const SmcPackedArgs a, const LvHandList h) {
+  smc_lv_phase2_body<PLAIN, ABZ_LV_BLOCK2>(a, h);
+}
 template <int L, int C, bool PLAIN>
 __global__ __launch_bounds__(ABZ_BLOCK) void smc_replay_packed_kernel(const SmcReplayPackedArgs a) {
   smc_replay_packed_body<L, C, PLAIN>(a);
@@ -56,6 +65,29 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+#if !defined(ABZ_SWEEP_ONE_PHASE) && !defined(ABZ_LV_ONE_KERNEL)
+  } else if (ctx->h_model.sim_id == ABZ_SIM_LV && L == 1 && C == 4) {
+    /* two launches: phase 1 over the positions, phase 2 over the proposals it hands over -- every wavefront of the simulator full */
+    if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc;
+    LvHandList h;
+    char* base = (char*)ctx->lv_hand;
+    const size_t cap = ctx->lv_hand_cap;
+    const unsigned par = (unsigned)(ctx->lv_seq++ & 1ull);       /* two counters in turn: this sweep's is zero (abz_lv_hand_reserve, then the sweeps) */
+    h.count = (unsigned int*)base + par;
+    h.count_next = (unsigned int*)base + (1u - par);
+    h.tp = (double*)(base + 256);
+    h.wl = h.tp + cap * 4; h.kdi = h.wl + cap; h.logu = h.kdi + cap;
+    h.pos = (uint32_t*)(h.logu + cap);
+    const unsigned nb1 = (unsigned)(((uint64_t)a.n_work + ABZ_BLOCK - 1) / ABZ_BLOCK);
+    const unsigned nb2 = (unsigned)(((uint64_t)a.n_work + ABZ_LV_BLOCK2 - 1) / ABZ_LV_BLOCK2);
+    if (ctx->prior_plain) {
+      hipLaunchKernelGGL((smc_lv_phase1_kernel<true>), dim3(nb1), dim3(ABZ_BLOCK), 0, ctx->stream, a, h);
+      hipLaunchKernelGGL((smc_lv_phase2_kernel<true>), dim3(nb2), dim3(ABZ_LV_BLOCK2), 0, ctx->stream, a, h);
+    } else {
+      hipLaunchKernelGGL((smc_lv_phase1_kernel<false>), dim3(nb1), dim3(ABZ_BLOCK), 0, ctx->stream, a, h);
+      hipLaunchKernelGGL((smc_lv_phase2_kernel<false>), dim3(nb2), dim3(ABZ_LV_BLOCK2), 0, ctx->stream, a, h);
+    }
+#endif
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {

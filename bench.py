@@ -321,11 +321,14 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         # and the figure charged every update a full simulation (issue slots, not flops); the two-phase body packs the calls densely
         fl = lv_flops_per_update(cfg["sim"])
         ach = fl * rate * sim_rate / 1e12
-        return {"kernel": "smc_swarm_packed_kernel<ABZ_SIM_LV, 1, 4>", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
+        return {"kernel": "smc_lv_phase1_kernel + smc_lv_phase2_kernel (one sweep = two launches, both inside the event pair)", "bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": None, "peak_origin": FP64_VALU_PEAK_ORIGIN,
                 "note": "fp64 vector-ALU bound (no matrix work on this path): 1500 RK4 steps per SIMULATED proposal (in support of "
-                        "the prior, smc:135-137); achieved = flops per simulation x simulations per second; the row traffic "
-                        "(161 B per update) is 0.1 % of the launch", "flops_per_update": fl, "simulated_fraction_of_updates": sim_rate,
+                        "the prior, smc:135-137); achieved = flops per simulation x simulations per second (a simulation that leaves "
+                        "early on its running distance is charged in full: an upper bound of the arithmetic done); the row traffic "
+                        "(161 B per update + 128 B per handed-over proposal) is 0.1 % of the launch.  Late in a run every proposal is "
+                        "in support and runs to the end: the second launch then sustains 57 TFLOP/s = 0.73 of this peak, the "
+                        "rate v_fma_f64 sustains on the part (profiles/r05_lv_run_by_tenth.json)", "flops_per_update": fl, "simulated_fraction_of_updates": sim_rate,
                 "rk4_steps_per_s": rate * sim_rate * (len(cfg["sim"].obs) // 2 - 1) * cfg["sim"].steps_per_obs,
                 "updates_per_launch": upl, "avg_launch_ms": avg_ms, "launches": launches, "kernel_updates_per_s": rate}
     d = cfg["d"]

@@ -51,3 +51,16 @@ def test_the_d32_sweep_kernel_has_no_scratch_and_fits_its_occupancy():
     for other in ("_Z23smc_swarm_packed_kernelILi1ELi2ELi8ELb1EEv13SmcPackedArgs", "_Z23smc_swarm_packed_kernelILi1ELi8ELi8ELb1EEv13SmcPackedArgs",
                   "_Z23smc_swarm_packed_kernelILi1ELi4ELi4ELb1EEv13SmcPackedArgs"):
         assert int(rows[other]["ScratchSize [bytes/lane]"]) == 0, (other, rows[other])
+
+
+@pytest.mark.skipif(HIPCC is None, reason="needs hipcc")
+def test_the_lotka_volterra_sweep_is_two_launches_that_fill_the_simd():
+    """BASELINE configs[3]: the simulator launch (smc_lv_phase2_kernel) keeps five wavefronts per SIMD by registers and five
+    workgroups per CU by LDS, nothing in scratch -- late in a run it sustains the part's fp64 FMA rate"""
+    rows = resource_table("abz_smc_swarm.hip")
+    for plain in ("0", "1"):
+        p2 = rows["_Z20smc_lv_phase2_kernelILb%sEEv13SmcPackedArgs10LvHandList" % plain]
+        p1 = rows["_Z20smc_lv_phase1_kernelILb%sEEv13SmcPackedArgs10LvHandList" % plain]
+        for r in (p1, p2):
+            assert int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["VGPRs Spill"]) == 0, r
+        assert int(p2["Occupancy [waves/SIMD]"]) >= 5 and int(p2["LDS Size [bytes/block]"]) <= 163840 // 5, p2

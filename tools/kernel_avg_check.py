@@ -23,9 +23,15 @@ roof = doc["roofline"]
 win = doc["config"]["timed_window"]
 stride = int(roof.get("timed_every_nth_step", 1))
 steps = int(doc["steps"])
+# "a+b": a sweep made of two launches (Lotka-Volterra: smc_lv_phase1_kernel + smc_lv_phase2_kernel) -- the k-th launch of each, added
 with open(trace) as f:
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(f) if kernel in r["Kernel_Name"]))
-durs = [(e - s) / 1e6 for s, e in rows]
+    all_rows = list(csv.DictReader(f))
+parts = []
+for sub in kernel.split("+"):
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in all_rows if sub in r["Kernel_Name"]))
+    parts.append([(e - s) / 1e6 for s, e in rows])
+assert len({len(p) for p in parts}) == 1, [len(p) for p in parts]
+durs = [sum(v) for v in zip(*parts)]
 n = int(roof["launches"])
 n_launch = int(win.get("sweep_launches", steps * per_step))
 ran = int(win["sweeps"])

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${TAG:-r02}; CFG=${CFG:-smc32}
 case $CFG in
   smc32) MARK=qs_hist_kernel; LANES=0; LD=32; KERN=smc_swarm_packed_kernel;;
-  lv) MARK=qs_hist_kernel; LANES=0; LD=4; KERN=smc_swarm_packed_kernel;;
+  lv) MARK=qs_hist_kernel; LANES=0; LD=4; KERN=smc_lv_phase1+smc_lv_phase2;;     # one sweep = two launches (abz_kernels.h, smc_lv_phase1_body)
   evidence1d) MARK=qs_hist_kernel; LANES=0; LD=1; KERN=smc_swarm_packed_kernel;;
   mc1d) MARK=mc_swarm_kernel; LANES=0; LD=1; KERN=mc_swarm_kernel; PER_STEP=1;;
 esac

@@ -14,6 +14,7 @@ import json
 import sys
 
 trace, log, kernel = sys.argv[1:4]
+kernel = kernel.split("+")[-1]        # "a+b": a sweep of two launches (Lotka-Volterra) -- the window is found by the second one
 doc = json.loads([l for l in open(log) if l.startswith("{")][-1])
 win = doc["config"]["timed_window"]
 n_launch, ran = int(win["sweep_launches"]), int(win["sweeps"])
