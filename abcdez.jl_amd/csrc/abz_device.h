@@ -43,6 +43,20 @@ __device__ inline void load_row(const double* __restrict__ row, int j, double (&
     }
   }
 }
+/* the same row through non-temporal loads (A/B builds of the sweep: -DABZ_SWEEP_NT_LOADS) */
+template <int L, int C>
+__device__ inline void load_row_nt(const double* __restrict__ row, int j, double (&v)[C]) {
+  if constexpr (C == 1) {
+    v[0] = __builtin_nontemporal_load(row);
+  } else {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) {
+      const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(row + m * 2 * L + 2 * j));
+      v[2 * m] = t.x; v[2 * m + 1] = t.y;
+    }
+  }
+}
 template <int L, int C>
 __device__ inline void store_row(double* __restrict__ row, int j, const double (&v)[C]) {
   if constexpr (C == 1) {

@@ -281,6 +281,9 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   __shared__ uint32_t s_n;
 
   /* ---------------- phase 1: order of issue = order of need (smc_swarm_packed_body_1p) */
+#ifdef ABZ_SWEEP_PRIO
+  __builtin_amdgcn_s_setprio(ABZ_SWEEP_PRIO);
+#endif
   ModelStage<SIM, LD, BLOCK> stage;
   stage.load(M);
   const uint32_t wi = a.bits[ri >> 5];
@@ -296,9 +299,21 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   double tp[C];
   {
     double ti[C], ta[C], tb[C];
+#if defined(ABZ_SWEEP_NT_LOADS)          /* A/B builds: 1 = the own row, 2 = the donor rows, 3 = all three through non-temporal loads */
+    if constexpr ((ABZ_SWEEP_NT_LOADS & 1) != 0) load_row_nt<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+    else load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
+    if constexpr ((ABZ_SWEEP_NT_LOADS & 2) != 0) {
+      load_row_nt<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+      load_row_nt<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+    } else {
+      load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
+      load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+    }
+#else
     load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
     load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
     load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
+#endif
     stage.store(s_model);
     __syncthreads();                                              /* sampler + model tables staged; s_acc, s_n zeroed */
     double g, log_u;
@@ -333,6 +348,9 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
     /* nsims counts the in-support proposals (smc:138), simulated here or not */
     const unsigned nsim1 = (active && j == 0 && insupport) ? 1u : 0u;
     __syncthreads();                                              /* hand-over complete */
+#ifdef ABZ_SWEEP_PRIO                  /* A/B builds: wavefronts that still have their loads to issue go first */
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     /* ---------------- phase 2: lane group k takes slot k */
     const unsigned n = s_n;
