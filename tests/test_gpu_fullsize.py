@@ -125,6 +125,68 @@ def test_config4_lotka_volterra_full_size_properties_and_oracle_spot_checks(orac
     assert nsim_all < n                                                                 # bounded prior: some proposals fall outside
 
 
+def further_model():
+    """16 parameters over the further Distributions.jl families (include/abcdez_spec.h, ABZ_PRIOR_EXPONENTIAL ...), with scipy's
+    distribution of the same parameters next to each"""
+    from scipy import stats
+
+    fams = [(A.Exponential(1.5), stats.expon(scale=1.5)), (A.Gamma(2.5, 0.6), stats.gamma(2.5, scale=0.6)),
+            (A.LogNormal(0.0, 0.5), stats.lognorm(s=0.5)), (A.Cauchy(1.0, 0.5), stats.cauchy(1.0, 0.5)),
+            (A.Laplace(1.0, 1.0), stats.laplace(1.0, 1.0)), (A.Weibull(1.8, 1.2), stats.weibull_min(1.8, scale=1.2)),
+            (A.InverseGamma(3.0, 2.0), stats.invgamma(3.0, scale=2.0)),
+            (A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0), stats.truncnorm(-0.5, 1.5, 1.0, 2.0)),
+            (A.Logistic(1.0, 0.5), stats.logistic(1.0, 0.5)), (A.TDist(4.0), stats.t(4.0)), (A.Pareto(3.0, 0.5), stats.pareto(3.0, scale=0.5)),
+            (A.Poisson(2.0), stats.poisson(2.0)), (A.Binomial(6, 0.3), stats.binom(6, 0.3)), (A.Gamma(0.6, 2.0), stats.gamma(0.6, scale=2.0)),
+            (A.Beta(2.0, 3.0), stats.beta(2.0, 3.0)), (A.Normal(1.0, 1.0), stats.norm(1.0, 1.0))]
+    return fams, A.MVNormal(tuple([1.0] * 16))
+
+
+def test_further_prior_families_full_size(oracle):
+    """2^21 particles under a 16-parameter prior of the further families (`prior::Distribution`, src/abcdez_smc.jl:165): the device's
+    initial population -- inversion / ratio / Marsaglia-Tsang / rejection samplers at particle indices up to 2^21 -- follows every
+    marginal (Kolmogorov-Smirnov on 2 M draws; chi-square for the counts), first and last 2048 particles equal the oracle's bit for
+    bit; generations with the whole-population properties, and one sweep replayed by the oracle on three position ranges."""
+    from scipy import stats
+
+    fams, sim = further_model()
+    prior = A.Factored(*[f for f, _ in fams])
+    N, d = 1 << 21, 16
+    spec = A.ModelSpec(prior, sim, seed=23)
+    eng = PopulationEngine(spec, N, ops=HipOps(spec))
+    eng.init_population()
+    th0, lp0, dl0 = (t.cpu() for t in eng.state)
+    assert torch.isfinite(dl0).all() and torch.isfinite(lp0).all() and torch.isfinite(th0).all()
+    m = oracle.OracleModel(spec)
+    for i0 in (0, N - 2048):
+        oth, olp, odl = torch.zeros_like(th0), torch.zeros_like(lp0), torch.zeros_like(dl0)
+        assert oracle.lib().orc_init(m.ptr, oth.data_ptr(), olp.data_ptr(), odl.data_ptr(), i0, 2048) == 0
+        sl = slice(i0, i0 + 2048)
+        for a, b in ((oth, th0), (odl, dl0), (olp, lp0)):
+            assert torch.equal(a[sl].view(torch.int64), b[sl].view(torch.int64))
+    x = th0.numpy()
+    for k, (f, ref) in enumerate(fams):
+        col = x[:, k]
+        if f.discrete:
+            assert np.array_equal(col, np.rint(col))
+            kk = col.astype(np.int64)
+            obs = np.bincount(kk, minlength=40)[:40].astype(float)
+            exp = ref.pmf(np.arange(40)) * N
+            keep = exp > 50
+            assert stats.chisquare(obs[keep] * exp[keep].sum() / obs[keep].sum(), exp[keep]).pvalue > 1e-4, type(f).__name__
+        else:
+            assert stats.kstest(col, ref.cdf).pvalue > 1e-4, (type(f).__name__, k)
+    assert np.abs(np.corrcoef(x[:, :16].T) - np.eye(16)).max() < 0.01                   # one counter stream per component
+    eng.reset_weights()
+    loop = Loop(eng, d, 3.0)
+    chk = Checks(oracle, spec, deep=True)
+    for gen in range(3):
+        loop.generation(chk)
+    n = eng.n_alive
+    nacc_all, nsim_all = oracle_spot_check_of_a_packed_sweep(oracle, spec, eng, loop.eps, loop.g0,
+                                                             (0, (n // 2) // 64 * 64, (n - 8192) // 64 * 64))
+    assert nsim_all < n                       # half lines, a truncation, counts: some proposals leave the support
+
+
 def test_spec_vectors_on_gpu():
     """the committed oracle vectors (tests/golden/spec_vectors.json) reproduced by the HIP path"""
     gold = json.load(open(os.path.join(GOLD_DIR, "spec_vectors.json")))["abcdesmc_runs"]
