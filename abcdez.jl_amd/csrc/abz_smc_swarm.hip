@@ -61,14 +61,19 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
   unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
+#if !defined(ABZ_SWEEP_ONE_PHASE) && !defined(ABZ_LV_ONE_KERNEL)
+  const bool lv_split = ctx->h_model.sim_id == ABZ_SIM_LV && L == 1 && C == 4;
+  if (lv_split) { if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc; }      /* (a no-op after abcdez_ctx_reserve) */
+#else
+  const bool lv_split = false;
+#endif
   const int tk = abz_time_begin(ctx);
   bool ok = true;
   if (ctx->h_model.sim_id == ABZ_SIM_USER) {
     if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
 #if !defined(ABZ_SWEEP_ONE_PHASE) && !defined(ABZ_LV_ONE_KERNEL)
-  } else if (ctx->h_model.sim_id == ABZ_SIM_LV && L == 1 && C == 4) {
+  } else if (lv_split) {
     /* two launches: phase 1 over the positions, phase 2 over the proposals it hands over -- every wavefront of the simulator full */
-    if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc;
     LvHandList h;
     char* base = (char*)ctx->lv_hand;
     const size_t cap = ctx->lv_hand_cap;
