@@ -245,6 +245,11 @@ def wide_models():
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6, 0.9, 0.5),
                                   dt=0.05, steps_per_obs=20), (1,)),
+        # the same simulator under an all-Normal prior: the PLAIN instantiations of the two launches, and parameters that go
+        # negative -- trajectories that blow up (Inf / NaN running sums stay in their rounds and are rejected at the end)
+        "lv_normal_prior": (A.Factored(A.Normal(1.0, 0.5), A.Normal(0.4, 0.3), A.Normal(1.0, 0.5), A.Normal(0.3, 0.3)),
+                            A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6, 0.9, 0.5),
+                                               dt=0.05, steps_per_obs=20), (1,)),
     }
 
 
