@@ -27,6 +27,10 @@ def cases():
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6),
                                   dt=0.05, steps_per_obs=10, blobs=True), 1.2, 528),
+        # further prior families (include/abcdez_spec.h ABZ_PRIOR_EXPONENTIAL ...): the replicas rebuild the log-priors of the
+        # accepted rows themselves
+        "further5": (A.Factored(A.Gamma(2.5, 0.6), A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0), A.LogNormal(0.0, 0.5), A.Poisson(2.0),
+                                A.TDist(4.0)), A.MVNormal((1.0, 0.5, 0.8, 2.0, 0.3)), 2.0, 528),
     }
 
 

@@ -40,7 +40,7 @@ def runs(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "lv"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "lv", "further5"])
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_run_equals_single_process(runs, name, world):
     ref = np.load(os.path.join(runs[1], f"result_{name}_rank0.npz"))
@@ -81,7 +81,7 @@ def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
     run_world(1, ref_dir, "oracle")
     hip_dir = tmp_path_factory.mktemp(f"hip_world{world}")
     run_world(world, hip_dir, "hip", timeout=300)
-    for name in ("normal1d", "mvn8", "quad2d", "lv"):
+    for name in ("normal1d", "mvn8", "quad2d", "lv", "further5"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(world):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
@@ -103,7 +103,7 @@ def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory, mode):
     run_world(1, ref_dir, "oracle")
     hip_dir = tmp_path_factory.mktemp("hip_" + mode)
     run_world(1, hip_dir, mode, timeout=240)
-    for name in ("normal1d", "mvn8", "quad2d", "lv"):
+    for name in ("normal1d", "mvn8", "quad2d", "lv", "further5"):
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
         for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C") + \
