@@ -234,14 +234,9 @@ __device__ inline void smc_swarm_packed_body_1p(const SmcPackedArgs& a) {
  *   phase 2, lane group k takes hand-over slot k: simulator + distance (smc:137) -> w -> accept (smc:145) -> row to the other slot.
  *            Wavefronts whose groups all lie beyond the number of survivors wait at the workgroup's barrier and issue nothing.
  * Same results bit for bit as the one-phase body (and the oracle, which simulates every proposal as the reference does). */
-#ifdef ABZ_EXPERIMENT_HAND_SLOTS   /* measurement builds only (tools/build_lib_variants.sh): fewer hand-over slots than positions -- NOT safe */
-#define ABZ_HAND_SLOTS(PB) ABZ_EXPERIMENT_HAND_SLOTS
-#else
-#define ABZ_HAND_SLOTS(PB) (PB)
-#endif
 template <int L, int C, int PB>
 struct SweepHand {
-  double tp[ABZ_HAND_SLOTS(PB)][L * C];         /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
+  double tp[PB][L * C];                 /* proposal rows, 16-byte units swizzled by slot (hand_unit) */
   double wl[PB], kdi[PB], logu[PB];             /* lp - lpi, K(di), log(rand) of smc:140-145 (lp itself is re-evaluated in phase 2) */
   uint16_t pos[PB];                             /* position inside the tile | own slot bit << 15 */
 };
@@ -334,7 +329,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
     if (lane == 0u && mk) base = atomicAdd(&s_n, (unsigned)__popcll(mk));
     base = __shfl(base, 0, 64);
     const int slot1 = (int)(base + (unsigned)__popcll(mk & ((1ull << (lane - (unsigned)j)) - 1ull)));
-    if (may && slot1 < ABZ_HAND_SLOTS(PB)) {
+    if (may) {
       const int slot = slot1;
       double2* row = reinterpret_cast<double2*>(s_hand.tp[slot]);
 #pragma unroll
