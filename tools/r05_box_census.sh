@@ -1,5 +1,5 @@
 # Round 5: one more box of the pool -- which one, the default headline numbers, the arithmetic-free access pattern on the same GPU
-#   bash tools/r05_box_census.sh    (through gpurun; appends one line to gpurun_out/r05_box_census.jsonl)
+#   bash tools/r05_box_census.sh    (through gpurun; one line in gpurun_out/r05_box_census.jsonl per call: collect them on the calling side)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +12,7 @@ print(json.dumps({'host': '$HOST', 'gpu_unique_id': '$ID', 'value': d['value'], 
                   'pattern_ceiling_read_frac': pc.get('read_frac'), 'kernel_over_ceiling': pc.get('kernel_over_ceiling'),
                   'pattern_ceiling_single_launches_read_frac': (pc.get('updates_per_s_single_launches') or 0) * 785 / 8e12,
                   'kernel_over_ceiling_single_launches': pc.get('kernel_over_ceiling_single_launches'),
-                  'whole_run_s': ((d.get('whole_run') or {}).get('model') or {}).get('seconds')}))" | tee -a $O/r05_box_census.jsonl
+                  'whole_run_s': ((d.get('whole_run') or {}).get('model') or {}).get('seconds')}))" | tee $O/r05_box_census.jsonl
 # the same box: the sweep held to 4 / 6 wavefronts per SIMD against the shipped 5 (library variants, one run each, no pattern kernel)
 for lib in "" w4 w6; do
   L=$R/abcdez.jl_amd/lib/libabcdez_hip.so; [ -n "$lib" ] && L=$R/abcdez.jl_amd/lib/variants/libabcdez_hip_$lib.so
