@@ -1,5 +1,5 @@
 # Round 5, GPU call 29: wavefronts without a phase-2 slot leave the workgroup at once (-DABZ_EARLY_EXIT): parity of the variant build,
-# then same-box A/B against the shipped sweep
+# then same-box A/B against the shipped sweep.  (The knob was removed again after this call: measured, no change -- profiles/HISTORY.md.)
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
