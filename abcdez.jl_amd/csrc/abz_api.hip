@@ -51,14 +51,29 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
   return 0;
 }
 
-/* the hand-over list of the Lotka-Volterra sweep: [count | pad to 256 B | tp 32 B | wl 8 | kdi 8 | logu 8 | pos 4] per position */
+/* which models sweep in two launches (abz_kernels.h, smc_split_phase1_body): one lane per particle, rows of 4 or 8 doubles, a simulator
+ * that is the bulk of the sweep -- Lotka-Volterra, and user-supplied simulators (ABZ_USER_ONE_KERNEL=1 in the environment keeps those
+ * on the one-kernel two-phase body: the A/B switch, and the choice for a simulator cheaper than a launch and 100 bytes of traffic) */
+bool abz_sweep_in_two_launches(const abcdez_ctx* ctx) {
+#if defined(ABZ_SWEEP_ONE_PHASE)
+  return false;
+#else
+  if (ctx->L != 1) return false;
+#if !defined(ABZ_LV_ONE_KERNEL)
+  if (ctx->h_model.sim_id == ABZ_SIM_LV && ctx->C == 4) return true;
+#endif
+  return ctx->h_model.sim_id == ABZ_SIM_USER && (ctx->C == 4 || ctx->C == 8) && !ctx->user_one_kernel;
+#endif
+}
+
+/* the hand-over list of a two-launch sweep: [two counters | pad to 256 B | tp 8 ld B | wl 8 | kdi 8 | logu 8 | pos 4] per position */
 int abz_lv_hand_reserve(abcdez_ctx* ctx, size_t positions) {
   if (positions <= ctx->lv_hand_cap) return 0;
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->lv_hand) ABZ_HIP_CHECK(hipFree(ctx->lv_hand));
   ctx->lv_hand = nullptr; ctx->lv_hand_cap = 0;
   const size_t cap = abz_align(positions + positions / 8, 1024);
-  ABZ_HIP_CHECK(hipMalloc(&ctx->lv_hand, 256 + cap * 64));
+  ABZ_HIP_CHECK(hipMalloc(&ctx->lv_hand, 256 + cap * ((size_t)ctx->h_model.ld * 8 + 32)));
   ABZ_HIP_CHECK(hipMemset(ctx->lv_hand, 0, 256));              /* both counters zero: the invariant the sweeps keep */
   ctx->lv_hand_cap = cap;
   return 0;
@@ -169,6 +184,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ctx->device = device;
   if (const char* g = getenv("ABZ_GRAPHS")) ctx->graphs_on = !(g[0] == '0' && g[1] == 0) && g[0] != 0;
   if (const char* g = getenv("ABZ_SERPENTINE")) ctx->serpentine = !(g[0] == '0' && g[1] == 0);
+  if (const char* g = getenv("ABZ_USER_ONE_KERNEL")) ctx->user_one_kernel = !(g[0] == '0' && g[1] == 0) && g[0] != 0;
   ctx->h_model = *model;
   default_shape(*model, &ctx->L, &ctx->C);
   /* every dimension of the row a continuous Normal (d == ld, no padding): the sweeps run the two-instruction log-density
@@ -273,7 +289,7 @@ int abcdez_ctx_reserve(abcdez_ctx* ctx, int64_t N) {
   /* the largest user: the resampling (8 N of cumulative weights + tile sums) / the rank pass of abcdemc (12 N + its table) */
   int rc = abz_ws_reserve(ctx, (size_t)N * 16 + ((size_t)8 << 20));
   if (rc) return rc;
-  if (ctx->h_model.sim_id == ABZ_SIM_LV && (rc = abz_lv_hand_reserve(ctx, (size_t)N))) return rc;     /* no allocation inside the loop */
+  if (abz_sweep_in_two_launches(ctx) && (rc = abz_lv_hand_reserve(ctx, (size_t)N))) return rc;        /* no allocation inside the loop */
   /* The resampling's kernels run for the first time ~14 generations into a run; HIP loads a kernel's code on its first
    * launch (about 0.2 ms each), which would land in the middle of the loop: run them once here on a 64-particle dummy. */
   const int64_t n = 64;

@@ -85,9 +85,10 @@ struct abcdez_ctx {
   /* growable workspace */
   void* ws = nullptr;
   size_t ws_bytes = 0;
-  void* lv_hand = nullptr;              /* Lotka-Volterra sweep: the list between its two launches (abz_kernels.h, LvHandList), 64 B per position */
+  void* lv_hand = nullptr;              /* two-launch sweep (Lotka-Volterra, user simulators): the list between the launches (abz_kernels.h, LvHandList), 8 ld + 28 B per position */
   size_t lv_hand_cap = 0;               /* positions the list has room for */
   unsigned long long lv_seq = 0;        /* sweeps launched: parity picks the list counter (abz_smc_swarm.hip) */
+  bool user_one_kernel = false;         /* ABZ_USER_ONE_KERNEL=1: user simulators stay on the one-kernel two-phase sweep */
   /* hiprtc-compiled kernels of a user-supplied simulator (abz_jit.hip), else null */
   void* user_module = nullptr;
   /* quantile select: its own histogram (left zeroed by every call) and the arrays the device-side window belongs to */
@@ -208,6 +209,7 @@ static inline unsigned abz_persistent_grid(abcdez_ctx* ctx, K kernel, uint64_t n
 /* workspace: returns a device pointer to at least `bytes` (256-B aligned) */
 int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes);
 int abz_lv_hand_reserve(abcdez_ctx* ctx, size_t positions);
+bool abz_sweep_in_two_launches(const abcdez_ctx* ctx);
 
 static inline size_t abz_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -324,5 +326,7 @@ int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp
                          double* delta_out, uint32_t nbw);
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned ntiles);
 int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
+bool abz_jit_has_smc_split(abcdez_ctx*);
+int abz_jit_launch_smc_split(abcdez_ctx*, const void* args, const void* list, unsigned nblocks);
 
 #endif

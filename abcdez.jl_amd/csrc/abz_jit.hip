@@ -22,6 +22,7 @@
 struct AbzUserModule {
   hipModule_t mod = nullptr;
   hipFunction_t f_init = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
+  hipFunction_t f_p1 = nullptr, f_p2 = nullptr;     /* the sweep as two launches (rows of 4 or 8 doubles; abz_kernels.h, smc_split_phase1_body) */
 };
 
 /* the user kernels loop over tiles like the built-in ones (ABZ_TILE_LOOP): grid = what is resident at once */
@@ -60,6 +61,12 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
         "  smc_swarm_packed_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_mc(const McSwarmArgs a) {\n"
         "  mc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n";
+  const bool split = C == 4 || C == 8;               /* rows the two-launch sweep exists for */
+  if (split)
+    tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p1(const SmcPackedArgs a, const LvHandList h) {\n"
+          "  smc_split_phase1_body<ABZ_SIM_USER, ABZ_USER_C, false>(a, h);\n}\n"
+          "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
+          "  smc_split_phase2_body<ABZ_SIM_USER, ABZ_USER_C, false>(a, h);\n}\n";
   const bool has_blob = ctx->h_model.n_blob > 0;     /* then the source must also define abz_user_blob */
   if (has_blob)
     tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_blob_eval(const HotModel M, const double* theta, "
@@ -98,6 +105,10 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_mc, um->mod, "abz_user_mc"));
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_smcp, um->mod, "abz_user_smc_packed"));
   if (has_blob) ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_blob, um->mod, "abz_user_blob_eval"));
+  if (split) {
+    ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p1, um->mod, "abz_user_smc_p1"));
+    ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p2, um->mod, "abz_user_smc_p2"));
+  }
   return 0;
 }
 
@@ -138,5 +149,17 @@ int abz_jit_launch_smc_packed(abcdez_ctx* ctx, const void* args, unsigned nblock
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   void* params[] = {const_cast<void*>(args)};
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_smcp, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  return 0;
+}
+/* the sweep as two launches: phase 1 over the positions, phase 2 over the hand-over list (one workgroup per ABZ_BLOCK possible records) */
+bool abz_jit_has_smc_split(abcdez_ctx* ctx) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  return um && um->f_p1 && um->f_p2;
+}
+int abz_jit_launch_smc_split(abcdez_ctx* ctx, const void* args, const void* list, unsigned nblocks) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  void* params[] = {const_cast<void*>(args), const_cast<void*>(list)};
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_p1, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_p2, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
 }

@@ -492,7 +492,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
  * body, the one-phase body and the oracle.  Phase 1 leaves bits_out = bits and the flag bytes without the accepted bit; phase 2
  * flips / sets them for the proposals it accepts. */
 struct LvHandList {
-  double* tp;               /* [cap][4] proposal rows */
+  double* tp;               /* [cap][C] proposal rows (C = 4: Lotka-Volterra; 4 or 8: user-supplied simulators) */
   double* wl;               /* lp - lpi */
   double* kdi;              /* K(di) */
   double* logu;             /* log(rand) of smc:145 */
@@ -504,9 +504,11 @@ struct LvHandList {
 #define ABZ_LV_BLOCK2 256   /* threads per workgroup of the second launch */
 #endif
 
-template <bool PLAIN, int BLOCK = ABZ_BLOCK>
-__device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandList& h) {
-  constexpr int L = 1, C = 4, LD = 4, PB = BLOCK;
+/* phase 1 for any simulator that runs one lane per particle with rows of C = 4 or 8 doubles (Lotka-Volterra; user-supplied simulators) */
+template <int SIM, int C, bool PLAIN, int BLOCK = ABZ_BLOCK>
+__device__ inline void smc_split_phase1_body(const SmcPackedArgs& a, const LvHandList& h) {
+  constexpr int L = 1, LD = C, PB = BLOCK;
+  static_assert(C >= 2 && (C & 1) == 0 && !ABZ_ROWS_DOUBLE_BUFFERED(LD), "two-launch sweep: rows of 4 or 8 doubles");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -519,7 +521,7 @@ __device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandLi
   __shared__ uint32_t s_ins[PB / 32];
   __shared__ uint32_t s_n, s_base;
 
-  ModelStage<ABZ_SIM_LV, LD, BLOCK> stage;
+  ModelStage<SIM, LD, BLOCK> stage;
   stage.load(M);
   const uint32_t wi = a.bits[ri >> 5];
   ParticleDraws<L> draws;
@@ -562,9 +564,8 @@ __device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandLi
   if (may) {
     const size_t r = (size_t)s_base + local;
     double2* row = reinterpret_cast<double2*>(h.tp + r * LD);
-    double2 t0, t1;
-    t0.x = tp[0]; t0.y = tp[1]; t1.x = tp[2]; t1.y = tp[3];
-    row[0] = t0; row[1] = t1;
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) { double2 t; t.x = tp[2 * m]; t.y = tp[2 * m + 1]; row[m] = t; }
     h.wl[r] = wl; h.kdi[r] = kdi; h.logu[r] = log_u;
     h.pos[r] = ri | (bi << 31);
   }
@@ -575,6 +576,52 @@ __device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandLi
   if (a.flags && tile_base + threadIdx.x < a.r_lo + a.n_work)
     a.flags[tile_base + threadIdx.x] = (uint8_t)(((s_ins[threadIdx.x >> 5] >> (threadIdx.x & 31u)) & 1u) << 1);
   block_count2<BLOCK>(0u, nsim1, a.cslots, a.c_cls);
+}
+
+template <bool PLAIN, int BLOCK = ABZ_BLOCK>
+__device__ inline void smc_lv_phase1_body(const SmcPackedArgs& a, const LvHandList& h) {
+  smc_split_phase1_body<ABZ_SIM_LV, 4, PLAIN, BLOCK>(a, h);
+}
+
+/* phase 2 for a simulator whose distance is opaque (user-supplied, hiprtc): one lane per record of the list, the whole call, no rounds --
+ * what it gains over the one-kernel body is that every wavefront that simulates is full */
+template <int SIM, int C, bool PLAIN, int BLOCK = ABZ_BLOCK>
+__device__ inline void smc_split_phase2_body(const SmcPackedArgs& a, const LvHandList& h) {
+  constexpr int L = 1, LD = C;
+  const HotModel& M = a.hm;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *h.count_next = 0u;
+  if (a.stop && *a.stop) return;
+  const unsigned n_list = *h.count;
+  const unsigned c0 = blockIdx.x * (unsigned)BLOCK;
+  if (c0 >= n_list) return;                                       /* workgroup-uniform */
+  __shared__ ModelLds<LD> s_model;
+  ModelStage<SIM, LD, BLOCK> stage;
+  stage.load(M);
+  const bool on = c0 + threadIdx.x < n_list;
+  const size_t r = on ? (size_t)c0 + threadIdx.x : (size_t)c0;    /* lanes past the end shadow the chunk's first record */
+  double tq[C], pq[C];
+  {
+    const double2* row = reinterpret_cast<const double2*>(h.tp + r * LD);
+#pragma unroll
+    for (int m = 0; m < C / 2; ++m) { const double2 t = row[m]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
+  }
+  const double wl = h.wl[r], kdi = h.kdi[r], logu = h.logu[r];
+  const uint32_t pw = h.pos[r];
+  stage.store(s_model);
+  __syncthreads();
+  const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+  const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
+  const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, 0, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);     /* smc:137 */
+  const double w = (wl + kernel_logpdf_dev(M.abck, a.eps, ds)) - kdi;                                              /* smc:140-141 */
+  const bool acc = on && ((0.0 <= w) || (logu < w));              /* smc:145 */
+  if (acc) {                                                      /* smc:146-150 */
+    store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, 0, tq);
+    atomicXor(&a.bits_out[rs >> 5], 1u << (rs & 31u));            /* phase 1 left bits_out = bits */
+    if (a.flags) a.flags[rs] = (uint8_t)3u;
+    a.logpi[rs] = lps; a.delta[rs] = ds;
+    if (a.stamp) a.stamp[rs] = abz_stamp(rs, a.sweep, 0);
+  }
+  block_count2<BLOCK>(acc ? 1u : 0u, 0u, a.cslots, a.c_cls);
 }
 
 template <bool PLAIN, int BLOCK = ABZ_LV_BLOCK2>

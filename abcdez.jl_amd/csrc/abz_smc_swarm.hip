@@ -61,28 +61,28 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   const int L = ctx->L, C = ctx->C;
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
   unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
-#if !defined(ABZ_SWEEP_ONE_PHASE) && !defined(ABZ_LV_ONE_KERNEL)
-  const bool lv_split = ctx->h_model.sim_id == ABZ_SIM_LV && L == 1 && C == 4;
-  if (lv_split) { if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc; }      /* (a no-op after abcdez_ctx_reserve) */
-#else
-  const bool lv_split = false;
-#endif
-  const int tk = abz_time_begin(ctx);
-  bool ok = true;
-  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
-    if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
-#if !defined(ABZ_SWEEP_ONE_PHASE) && !defined(ABZ_LV_ONE_KERNEL)
-  } else if (lv_split) {
-    /* two launches: phase 1 over the positions, phase 2 over the proposals it hands over -- every wavefront of the simulator full */
-    LvHandList h;
+  /* two launches: phase 1 over the positions, phase 2 over the proposals it hands over -- every wavefront of the simulator full */
+  const bool split = abz_sweep_in_two_launches(ctx) && (ctx->h_model.sim_id != ABZ_SIM_USER || abz_jit_has_smc_split(ctx));
+  LvHandList h{};
+  if (split) {
+    if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc;      /* (a no-op after abcdez_ctx_reserve) */
     char* base = (char*)ctx->lv_hand;
     const size_t cap = ctx->lv_hand_cap;
     const unsigned par = (unsigned)(ctx->lv_seq++ & 1ull);       /* two counters in turn: this sweep's is zero (abz_lv_hand_reserve, then the sweeps) */
     h.count = (unsigned int*)base + par;
     h.count_next = (unsigned int*)base + (1u - par);
     h.tp = (double*)(base + 256);
-    h.wl = h.tp + cap * 4; h.kdi = h.wl + cap; h.logu = h.kdi + cap;
+    h.wl = h.tp + cap * (size_t)C; h.kdi = h.wl + cap; h.logu = h.kdi + cap;
     h.pos = (uint32_t*)(h.logu + cap);
+  }
+  const int tk = abz_time_begin(ctx);
+  bool ok = true;
+  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+    if (split) {
+      if (int rc = abz_jit_launch_smc_split(ctx, &a, &h, abz_grid((uint64_t)a.n_work))) return rc;
+    } else if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+  } else if (split) {
+    {
     const unsigned nb1 = (unsigned)(((uint64_t)a.n_work + ABZ_BLOCK - 1) / ABZ_BLOCK);
     const unsigned nb2 = (unsigned)(((uint64_t)a.n_work + ABZ_LV_BLOCK2 - 1) / ABZ_LV_BLOCK2);
     if (ctx->prior_plain) {
@@ -92,7 +92,7 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
       hipLaunchKernelGGL((smc_lv_phase1_kernel<false>), dim3(nb1), dim3(ABZ_BLOCK), 0, ctx->stream, a, h);
       hipLaunchKernelGGL((smc_lv_phase2_kernel<false>), dim3(nb2), dim3(ABZ_LV_BLOCK2), 0, ctx->stream, a, h);
     }
-#endif
+    }
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, L, C, [&](auto S, auto LL, auto CC) {
       if constexpr (LL() <= 8) {

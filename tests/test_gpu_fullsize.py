@@ -541,10 +541,14 @@ __device__ double abz_user_dist(const double* th, int d, const double* data, int
 """
 
 
-def test_user_simulator_of_four_parameters_runs_the_two_phase_sweep(oracle):
+@pytest.mark.parametrize("sweep", ["two launches", "one kernel"])
+def test_user_simulator_of_four_parameters_runs_the_two_phase_sweep(oracle, sweep, monkeypatch):
     """a user simulator with 3 to 8 parameters takes the two-phase sweep (csrc/abz_kernels.h: the simulator runs only for proposals
     that are in the prior's support and not already rejected on the prior ratio, densely packed): the Lotka-Volterra model restated
-    as HIP source must equal the built-in simulator -- hence the oracle, which simulates every in-support proposal -- bit for bit"""
+    as HIP source must equal the built-in simulator -- hence the oracle, which simulates every in-support proposal -- bit for bit.
+    Rows of 4 or 8 doubles sweep in two launches by default (phase 2 over a dense list of the surviving proposals);
+    ABZ_USER_ONE_KERNEL=1, read when the context is created, keeps the one-kernel body: both must give the same bits."""
+    monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "1" if sweep == "one kernel" else "0")
     obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6)
     prior = A.Factored(*[A.Uniform(0.0, 2.0)] * 4)
     builtin = A.LotkaVolterraRK4(obs, dt=0.05, steps_per_obs=10)
@@ -552,6 +556,43 @@ def test_user_simulator_of_four_parameters_runs_the_two_phase_sweep(oracle):
     N, eps = 6000, 1.2
     r = A.abcdesmc(prior, user, eps, None, nparticles=N, verbose=False, rng=17)
     c = oracle.run_abcdesmc(A.ModelSpec(prior, builtin, seed=17), N, eps)
+    res = r.engine.result()
+    assert r.logZ == c["logZ"] and r.nsims == c["nsims"] and r.iters == c["iters"]
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"])
+
+
+USER_MVN6 = """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  double sq[8];
+  for (int m = 0; m < 4; ++m) {
+    double z[2];
+    rng.normal_pair(z[0], z[1]);
+    for (int c = 0; c < 2; ++c) {
+      const int k = 2 * m + c;
+      double v = 0.0;
+      if (k < d) { const double x = abz_fma(p[0], z[c], th[k]); const double e = x - data[k]; v = e * e; }
+      sq[k] = v;
+    }
+  }
+  return abz_sqrt(abz_tree_sum_small(sq, 8));
+}
+"""
+
+
+@pytest.mark.parametrize("sweep", ["two launches", "one kernel"])
+def test_user_simulator_of_six_parameters_rows_of_eight_doubles(oracle, sweep, monkeypatch):
+    """rows of eight doubles (six parameters and two padding components), one lane per particle: the d-dimensional Normal simulator
+    restated as HIP source equals the built-in one -- the oracle -- bit for bit, in both forms of the sweep; a Gamma and a truncated
+    Normal among the priors (out-of-support proposals; the further prior families inside the run-time-compiled kernels)"""
+    monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "1" if sweep == "one kernel" else "0")
+    y = (1.0, 0.5, 0.8, 1.2, 0.3, 1.5)
+    prior = A.Factored(A.Normal(0, 2), A.Gamma(2.0, 1.0), A.Uniform(-2, 3), A.truncated(A.Normal(1.0, 2.0), 0.0, None), A.Normal(0, 1),
+                       A.LogNormal(0.0, 0.7))
+    builtin = A.MVNormal(y, sigma=0.8)
+    user = A.UserSimulator(USER_MVN6, params=(0.8,), data=y)
+    N, eps = 8000, 1.5
+    r = A.abcdesmc(prior, user, eps, None, nparticles=N, verbose=False, rng=19)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, builtin, seed=19), N, eps)
     res = r.engine.result()
     assert r.logZ == c["logZ"] and r.nsims == c["nsims"] and r.iters == c["iters"]
     assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"])
