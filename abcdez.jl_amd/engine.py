@@ -455,16 +455,8 @@ class PopulationEngine:
         # store, (logpi, delta) ping-pong at resamplings only.  Sharded packed runs exchange [r c, (r+1) c) pieces of
         # the per-position arrays: room for G chunks.
         self._npad = N + (self.world * PACKED_ALIGN if self.sharded_packed else 0)
-        arena = os.environ.get("ABZ_ARENA", "")
-        if arena and dev.type == "cuda":
-            # measurement knob (profiles/r05_smc32_arena_ab.json): the row slots and the per-position arrays carved out of ONE
-            # allocation at 2 MiB boundaries -- "lib": memory from abcdez_dev_alloc (what a host without a GPU array package
-            # uses, julia/ABCdeZHIP.jl), anything else: one torch allocation.  Results do not depend on it.
-            rows, full = self._carve_arena(arena, N, ld, self._npad)
-            self._full = [(full[2 * k], full[2 * k + 1]) for k in range(2)]
-        else:
-            rows = [torch.zeros((N, ld), **f64) for _ in range(2)]
-            self._full = [(torch.zeros(self._npad, **f64), torch.zeros(self._npad, **f64)) for _ in range(2)]
+        rows = [torch.zeros((N, ld), **f64) for _ in range(2)]
+        self._full = [(torch.zeros(self._npad, **f64), torch.zeros(self._npad, **f64)) for _ in range(2)]
         self.buf = [(rows[k], self._full[k][0][:N], self._full[k][1][:N]) for k in range(2)]
         self.cur = 0
         if self.packed:
@@ -490,35 +482,6 @@ class PopulationEngine:
         self.r_lo, self.r_hi = 0, N
         self.sweep = 0          # global sweep number = RNG epoch of the swarm kernels
         self.draw = 0           # resampling number = RNG epoch of the stratified draws
-
-    def _carve_arena(self, kind, N, ld, npad):
-        """two row slots f64[N][ld] + four per-position arrays f64[npad] from one allocation, each piece at a 2 MiB boundary"""
-        A2 = 2 << 20
-        up = lambda b: -(-b // A2) * A2
-        sizes = [up(N * ld * 8)] * 2 + [up(npad * 8)] * 4
-        total = sum(sizes) + A2
-        if kind == "lib":
-            ptr = C.c_void_p()
-            _lib.check(self.ops.lib, self.ops.lib.abcdez_dev_alloc(total, C.byref(ptr)))
-
-            class _Dev:
-                pass
-            d = _Dev()
-            d.__cuda_array_interface__ = {"shape": (total,), "typestr": "|u1", "data": (ptr.value, False), "version": 2}
-            base = torch.as_tensor(d, device=self.device)
-            self._arena_ptr = ptr            # released in close_arena(); the tensors must not outlive it
-        else:
-            base = torch.empty(total, dtype=torch.uint8, device=self.device)
-        off = (-base.data_ptr()) % A2
-        self._arena = base
-        out = []
-        for k, b in enumerate(sizes):
-            n = (N * ld) if k < 2 else npad
-            t = base[off:off + n * 8].view(torch.float64)
-            t.zero_()
-            out.append(t.view(N, ld) if k < 2 else t)
-            off += b
-        return out[:2], out[2:]
 
     def run_scope(self):
         """Context manager for a whole run: work on a side stream of this engine when the caller's current stream is the

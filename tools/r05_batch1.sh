@@ -24,6 +24,7 @@ cat $O/r05_serpentine_ab.jsonl
 timeout 300 $R/tools/sweep_variants 2965608 12 0.147 20 > $O/r05_sweep_variants_serpentine_sustained.jsonl 2> $O/r05_sweep_variants.err
 cat $O/r05_sweep_variants_serpentine_sustained.jsonl
 # --- allocation: torch's caching allocator (default) / one torch arena at 2 MiB boundaries / abcdez_dev_alloc
+#     (ABZ_ARENA: a knob of engine.py at the time of this call, removed at the end of the round -- it changed nothing)
 : > $O/r05_arena_ab.jsonl
 for rep in 1; do
   for a in "" torch lib ""; do
