@@ -77,6 +77,7 @@ struct abcdez_ctx {
   abz_ahead ahead;
   bool prior_plain = false;       /* all real dimensions continuous Normal priors (abz_api.hip)                 */
   /* device scalars + pinned host mirror */
+  void* d_block = nullptr;                /* ONE allocation behind d_scal, d_sync, d_model, d_tables, d_data, d_mv (abcdez_ctx_create) */
   unsigned long long* d_scal = nullptr;   /* ABZ_S_N x u64                      */
   unsigned int* d_sync = nullptr;         /* ABZ_SYNC_N tickets of "the last block to finish does X" kernels, zero between launches */
   unsigned long long* h_scal = nullptr;   /* pinned + mapped: ABZ_S_N words + the sequence word of abz_publish */
