@@ -82,6 +82,8 @@ PROTOTYPES = {
                                            _u32, _pi64],
     "abcdez_comm_unique_id": [_vp, C.c_size_t],
     "abcdez_comm_init": [_vp, _vp, C.c_size_t, C.c_int, C.c_int],
+    "abcdez_comm_init_host": [_vp, C.c_int, C.c_int, _vp, _vp, _vp],
+    "abcdez_comm_kind": [_vp, C.POINTER(_i32)],
     "abcdez_comm_destroy": [_vp],
     "abcdez_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
     "abcdez_comm_allgather": [_vp, _vp, _i64],
@@ -92,7 +94,10 @@ PROTOTYPES = {
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
-MIN_VERSION = 500      # abcdez_comm_*, abcdez_smc_sweeps_sharded, timing mode 3 (include/abcdez_hip.h)
+MIN_VERSION = 600      # abcdez_comm_init_host (host-supplied transport), lazily opened RCCL (include/abcdez_hip.h)
+# the callbacks of abcdez_comm_init_host (include/abcdez_hip.h): in-place all-gather / all-reduce on HOST memory
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _i32)
 # symbols with a non-status return type
 OTHER_SYMBOLS = ("abcdez_version", "abcdez_rng_rounds", "abcdez_last_error", "abcdez_abi_layout")
 

@@ -106,10 +106,11 @@ static inline void abz_population_written(abcdez_ctx* ctx) {
 extern "C" {
 
 /* 400: Philox4x32-10 again, abz_model.mv, group abort; 401: abcdemc's better particle by rejection;
- * 500: abcdez_comm_* and abcdez_smc_sweeps_sharded (RCCL behind the ABI), timing mode 3.  Hosts refuse a library older than the
+ * 500: abcdez_comm_* and abcdez_smc_sweeps_sharded (RCCL behind the ABI), timing mode 3; 600: abcdez_comm_init_host (a host-supplied
+ * transport under the same sharded entry points), librccl opened lazily.  Hosts refuse a library older than the
  * header they were written against (abcdez.jl_amd/_lib.py, julia/ABCdeZHIP.jl check_abi): a signature that grew an argument links
  * against an old binary without a diagnostic. */
-int abcdez_version(void) { return 500; }
+int abcdez_version(void) { return 600; }
 int abcdez_rng_rounds(void) { return ABZ_PHILOX_ROUNDS; }
 
 /* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
@@ -273,7 +274,7 @@ int abcdez_ctx_destroy(abcdez_ctx* ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->comm) (void)abcdez_comm_destroy(ctx);
+  if (ctx->comm_kind != ABZ_COMM_NONE) (void)abcdez_comm_destroy(ctx);
   for (abz_mc_graph& g : ctx->mc_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   ctx->mc_graphs.clear();
   abz_jit_destroy(ctx);
@@ -396,7 +397,17 @@ int abcdez_dev_free(void* ptr) {
 }
 int abcdez_memcpy_h2d(abcdez_ctx* ctx, void* dst, const void* src, size_t bytes) {
   ABZ_REQUIRE(ctx && dst && src, "memcpy_h2d: null argument");
-  abz_population_written(ctx);         /* the host writes device memory of its own choice -- possibly distances or flags */
+  /* the host writes device memory of its own choice: what the library remembers about distances or flags -- a select enqueued
+   * ahead, the window of the select, an abcdemc chain, a cached count -- is dropped iff the copy overlaps the arrays it describes
+   * (uploads of weights, bitmap words, rows leave it alone; abcdez_smc_select_discard says "written" without a copy) */
+  {
+    const char* lo = (const char*)dst; const char* hi = lo + bytes;
+    auto hits = [&](const void* a, size_t n) { return a && n && lo < (const char*)a + n && (const char*)a < hi; };
+    const bool mc_hit = hits(ctx->mc_last_out, (size_t)ctx->mc_last_N * 8) || hits(ctx->mc_count_seen.delta, (size_t)ctx->mc_count_seen.N * 8);
+    if (mc_hit || hits(ctx->ahead.delta, (size_t)ctx->ahead.N * 8) || hits(ctx->ahead.alive, (size_t)ctx->ahead.N)) abz_population_written(ctx);
+    /* the extrema a sweep left on the device and the window made from them describe the overwritten distances too */
+    if (mc_hit) { ctx->mc_window_ready = false; ctx->mc_have_bank = false; ctx->mc_count_seen.count = -1; }
+  }
   ABZ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   ABZ_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -511,7 +522,6 @@ int abcdez_ctx_get_timing(abcdez_ctx* ctx, double* swarm_ms, int64_t* launches, 
   return 0;
 }
 
-#define ABZ_MAX_N 0x7FFFFFFFll /* indices are 32-bit on the device */
 #define ABZ_PACKED_ALIGN 64      /* sub-ranges of the packed prefix own whole wave-rounds of the replay and whole bitmap words */
 
 /* ---- blobs (second return value of dist!): stamps carried with the distances, data rebuilt on demand ---- */
@@ -1048,7 +1058,8 @@ static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* th
    * replicated on the whole population, which every rank holds (a better particle or a donor may be anybody, mc:23-32) */
   int64_t i0 = 0, n_local = N;
   if (sharded) {
-    ABZ_REQUIRE(ctx->comm, "mc_generation_sharded_async: no communicator (abcdez_comm_init)");
+    ABZ_REQUIRE(ctx->comm_kind != ABZ_COMM_NONE, "mc_generation_sharded_async: no communicator (abcdez_comm_init / abcdez_comm_init_host)");
+    ABZ_REQUIRE(!ctx->comm_broken, "mc_generation_sharded_async: the communicator was aborted after a failure on this rank");
     ABZ_REQUIRE(N % ctx->comm_world == 0, "mc_generation_sharded_async: nparticles must be divisible by the number of ranks");
     n_local = N / ctx->comm_world; i0 = (int64_t)ctx->comm_rank * n_local;
     /* the extrema a sweep leaves in its bank are THIS rank's: the window of a sharded chain comes from lo_hi (first generation) or
@@ -1127,6 +1138,9 @@ static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* th
     return abz_launch_mc_snapshot(ctx, ctx->mm_bank, ctx->d_ring, alpha, eps_target, launch_rank ? ctx->mc_rank_state : nullptr,
                                   (uint32_t)N, sharded ? 1 : 0);
   };
+  /* a sharded generation is a collective call: what can fail on this rank alone -- the workspace of the rank pass -- is obtained
+   * before anything is enqueued (abz_comm.hip reserves its staging block before its first callback) */
+  if (sharded && launch_rank) { if ((rc = abz_ws_reserve(ctx, plan.ws_bytes))) return rc; }
   const long long ev_before = ctx->ev_tail;
   bool replayed = false;
   if (ctx->graphs_on && ctx->stream != nullptr && !need_window && !timed_now && !sharded) {      /* the legacy default stream cannot be captured */
@@ -1185,10 +1199,11 @@ static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* th
     ctx->n_graph_direct += 1;
     if (need_window) {
       rc = abz_launch_mc_window(ctx, lo_hi ? -1 : 1 - ctx->mm_bank, lo_hi ? lo_hi[0] : 0.0, lo_hi ? lo_hi[1] : 0.0, alpha, eps_target);
-      if (rc) { ctx->mc_seq_dirty = true; return rc; }
+      if (rc) { ctx->mc_seq_dirty = true; if (sharded) abz_comm_abort_after_failure(ctx); return rc; }
     }   /* else: the snapshot kernel of the generation before has already made this generation's eps_pop and window */
     rc = enqueue();
-    if (rc) { ctx->mc_seq_dirty = true; return rc; }
+    /* a sharded generation is a collective call: the peers are in (or on their way to) an exchange this rank will not make */
+    if (rc) { ctx->mc_seq_dirty = true; if (sharded) abz_comm_abort_after_failure(ctx); return rc; }
   }
   ctx->ring_timed[slot] = ctx->ev_tail != ev_before;
   ctx->ring_folded[slot] = false;

@@ -19,6 +19,8 @@
  * population ([7] != 0), that generation's counts over ALL ranks --, [2] min key, [3] max key, [4] eps_pop, [5] tail length, [6] error
  * word, [7] sharded, [8] [9] this GPU's cumulative slot totals (sharded generations: the host's baselines), [10] spare, [11] ticket + 1 */
 #define ABZ_RING_WORDS 12
+#define ABZ_MAX_N 0x7FFFFFFFll /* particle indices are 32-bit on the device */
+enum { ABZ_COMM_NONE = 0, ABZ_COMM_RCCL = 1, ABZ_COMM_HOST = 2 };   /* abcdez_comm_kind */
 
 /* abcdez_smc_select_ahead: armed = start the next generation's select behind the next grouped sweeps; valid = it has been
  * enqueued for exactly these arguments and nothing has touched the distances / flags since */
@@ -164,9 +166,18 @@ struct abcdez_ctx {
    * ABZ_SERPENTINE=0 in the environment keeps every launch front to back (same results; A/B measurements) */
   bool serpentine = true;
   long long sweep_launch_seq = 0;
-  /* multi-GPU (abz_comm.hip): the RCCL communicator of this context's rank (an ncclComm_t), null on a single GPU */
+  /* multi-GPU (abz_comm.hip): the transport of this context's rank -- RCCL (comm = an ncclComm_t) or the host's callbacks
+   * (abcdez_comm_init_host; hc_stage = the page-locked block the pieces travel through) --, none on a single GPU.  comm_broken: a
+   * sharded call failed on this rank between its collectives; every later collective returns an error (abz_comm_abort_after_failure) */
   void* comm = nullptr;
+  int comm_kind = ABZ_COMM_NONE;
+  bool comm_broken = false;
   int comm_rank = 0, comm_world = 1;
+  int (*hc_allgather)(void*, void*, int64_t) = nullptr;
+  int (*hc_allreduce)(void*, void*, int64_t, int32_t, int32_t) = nullptr;
+  void* hc_user = nullptr;
+  void* hc_stage = nullptr;
+  size_t hc_stage_bytes = 0;
 };
 
 void abz_set_error(const std::string& msg);
@@ -297,6 +308,7 @@ int abz_launch_mc_partial(abcdez_ctx*, int bank);
 /* abz_comm.hip: what the ranks exchange after the own-range sweep of an abcdemc generation -- the new rows / log-priors / distances
  * (/ blob stamps) of every rank's particles, in place, and the ABZ_S_MC_PART words -- as ONE group of collectives on the stream */
 int abz_comm_mc_exchange(abcdez_ctx*, double* ntheta, double* nlogpi, double* ndelta, uint64_t* nstamp, int64_t n_local, int ld);
+void abz_comm_abort_after_failure(abcdez_ctx*);
 int abz_launch_mc_chain_start(abcdez_ctx*, const double* delta, int64_t N, double eps_target);
 /* which sorts a rank pass launches for a tail of the hinted / bounded length, and the grid of the long-tail kernels (a power of two
  * of wave-tiles: the kernels stride, so any grid is correct -- few distinct values keep the graph cache small) */

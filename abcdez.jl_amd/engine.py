@@ -48,6 +48,38 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def pg_host_transport(pg, with_allreduce: bool = False):
+    """The callbacks of abcdez_comm_init_host over a torch.distributed process group whose backend moves HOST memory (gloo; an
+    MPI host would pass MPI.Allgather! here): ``allgather(address, piece_bytes)`` in place on the library's page-locked block,
+    and -- optionally -- ``allreduce(address, n, dtype, op)`` on 8-byte words (dtype 0 int64, 1 float64, 2 uint64; op 0 sum,
+    1 min, 2 max).  Without the second the library reduces in rank order itself (include/abcdez_hip.h)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+
+    def view(address, nbytes, dtype):
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(address))).view(dtype)
+
+    def allgather(address, piece):
+        t = view(address, piece * world, torch.uint8)
+        dist.all_gather_into_tensor(t, t[rank * piece:(rank + 1) * piece], group=pg)
+
+    def allreduce(address, n, dtype, op):
+        rop = (dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX)[op]
+        if dtype == 1:
+            dist.all_reduce(view(address, 8 * n, torch.float64), op=rop, group=pg)
+            return
+        t = view(address, 8 * n, torch.int64)
+        if dtype == 2 and op != 0:          # unsigned order through signed words: flip the top bit, reduce, flip it back
+            t ^= -0x8000000000000000
+            dist.all_reduce(t, op=rop, group=pg)
+            t ^= -0x8000000000000000
+        else:                               # (a sum wraps the same way in both)
+            dist.all_reduce(t, op=rop, group=pg)
+
+    return allgather, (allreduce if with_allreduce else None)
+
+
 class HipOps:
     """ctypes -> HIP kernels.  Tensors must live on this ops' CUDA(HIP) device."""
 
@@ -215,6 +247,37 @@ class HipOps:
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         _lib.check(self.lib, self.lib.abcdez_comm_init(self.ctx, unique_id, len(unique_id), rank, world))
 
+    def comm_init_host(self, rank: int, world: int, allgather, allreduce=None):
+        """the host-supplied transport (abcdez_comm_init_host): ``allgather(address, piece_bytes)`` gathers in place on HOST memory
+        (this rank's piece at address + rank * piece_bytes), ``allreduce(address, n, dtype, op)`` reduces n 8-byte words in place
+        (optional: without it the library all-gathers the words and reduces them in rank order).  Python callables; an
+        exception inside one is reported as a failed collective."""
+        def guard(fn, what):
+            def call(user, *args):
+                try:
+                    fn(*args)
+                    return 0
+                except BaseException as e:          # nothing may propagate through the C frames
+                    import sys
+                    print(f"[abcdez host transport] {what} failed: {e!r}", file=sys.stderr)
+                    return 1
+            return call
+        # the library keeps the function pointers for the life of the communicator: so must this object
+        self._host_cb = (_lib.HOST_ALLGATHER_FN(guard(allgather, "all-gather")),
+                         _lib.HOST_ALLREDUCE_FN(guard(allreduce, "all-reduce")) if allreduce is not None else None)
+        _lib.check(self.lib, self.lib.abcdez_comm_init_host(self.ctx, rank, world, C.cast(self._host_cb[0], C.c_void_p),
+                                                            C.cast(self._host_cb[1], C.c_void_p) if self._host_cb[1] else None, None))
+
+    def comm_kind(self) -> int:
+        """0: no communicator, 1: RCCL, 2: host transport"""
+        k = C.c_int32()
+        _lib.check(self.lib, self.lib.abcdez_comm_kind(self.ctx, C.byref(k)))
+        return k.value
+
+    def comm_destroy(self):
+        _lib.check(self.lib, self.lib.abcdez_comm_destroy(self.ctx))
+        self._host_cb = None
+
     def comm_rank(self):
         r, w = C.c_int32(), C.c_int32()
         rc = self.lib.abcdez_comm_rank(self.ctx, C.byref(r), C.byref(w))
@@ -227,7 +290,7 @@ class HipOps:
         _lib.check(self.lib, self.lib.abcdez_comm_allgather(self.ctx, _ptr(t), piece_elems * t.element_size()))
 
     def comm_allreduce(self, t, op: str = "sum"):
-        dt = {torch.int64: 0, torch.float64: 1}[t.dtype]
+        dt = {torch.int64: 0, torch.float64: 1, torch.uint64: 2}[t.dtype]
         _lib.check(self.lib, self.lib.abcdez_comm_allreduce(self.ctx, _ptr(t), t.numel(), dt, {"sum": 0, "min": 1, "max": 2}[op]))
 
     def smc_sweeps_sharded(self, bits_a, bits_b, n_alive, chunk, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig, sweep0,
@@ -429,20 +492,25 @@ class PopulationEngine:
         self.ops = ops if ops is not None else HipOps(spec, lanes=lanes)
         if hasattr(self.ops, "reserve"):
             self.ops.reserve(self.N)
-        # Collectives: RCCL issued BY THE LIBRARY on its own stream (abcdez_comm_*), whenever the group's backend is RCCL and
-        # the ops are the HIP library; torch.distributed itself only for other backends (gloo: the CPU tests, rehearsals on one
-        # GPU) and when ABZ_COMM=torch asks for it (A/B).  The rendezvous id travels through the process group once.
+        # Collectives of the HIP ops are issued BY THE LIBRARY (abcdez_comm_*, csrc/abz_comm.hip): RCCL on the library's own stream
+        # when the group's backend is RCCL (the rendezvous id travels through the process group once); for any other backend (gloo:
+        # ranks that share one GPU, hosts without RCCL) the library's host transport with this group's all-gather underneath
+        # (abcdez_comm_init_host; ABZ_HOST_ALLREDUCE=1 also hands it the group's all-reduce instead of the library's rank-order
+        # reduction).  torch.distributed's collectives are called by this file only for ops without a communicator of their own
+        # (the CPU oracle of the gloo tests).
         self._native_comm = False
-        if (self.pg is not None and self._backend == "nccl" and hasattr(self.ops, "comm_init")
-                and os.environ.get("ABZ_COMM", "native") != "torch"
-                and (self.world > 1 or force_collectives)):
+        if self.pg is not None and hasattr(self.ops, "comm_init") and (self.world > 1 or force_collectives):
             import torch.distributed as dist
 
-            idt = torch.zeros(128, dtype=torch.uint8, device=self.ops.device)
-            if self.rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(self.ops.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0), group=self.pg)
-            self.ops.comm_init(bytes(idt.cpu().numpy().tobytes()), self.rank, self.world)
+            if self._backend == "nccl":
+                idt = torch.zeros(128, dtype=torch.uint8, device=self.ops.device)
+                if self.rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(self.ops.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=dist.get_global_rank(self.pg, 0), group=self.pg)
+                self.ops.comm_init(bytes(idt.cpu().numpy().tobytes()), self.rank, self.world)
+            else:
+                ag, ar = pg_host_transport(self.pg, with_allreduce=os.environ.get("ABZ_HOST_ALLREDUCE", "0") == "1")
+                self.ops.comm_init_host(self.rank, self.world, ag, ar)
             self._native_comm = True
         dev = self.ops.device
         self.device = dev
@@ -557,11 +625,10 @@ class PopulationEngine:
             self.ops.comm_allgather(self._full[self.cur][1], self.chunk)
             self._delta_stale = False
             return True
-        if self._backend == "nccl" or self.device.type == "cpu":
-            t = self._full[self.cur][1]
-            self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
-                                                           t[self.rank * self.chunk:(self.rank + 1) * self.chunk],
-                                                           group=self.pg, async_op=True)
+        t = self._full[self.cur][1]    # (CPU tensors of an ops without a communicator: the oracle under gloo)
+        self._delta_work = dist.all_gather_into_tensor(t[:self.world * self.chunk],
+                                                       t[self.rank * self.chunk:(self.rank + 1) * self.chunk],
+                                                       group=self.pg, async_op=True)
 
     # ---- optional phase timing of the sharded packed sweep (bench.py's multi-GPU breakdown) ----
     def enable_phase_timing(self):
@@ -606,26 +673,18 @@ class PopulationEngine:
         self.cur = 1 - self.cur
 
     def _allgather_state(self, bufs):
-        """classic storage: exchange entries [lo, hi) of per-particle arrays (theta, logpi, delta, ...) -- one
-        all-gather per array.
-
-        RCCL ("nccl" backend): in place, straight between the device buffers over xGMI.
-        Any other backend (gloo in the CPU tests): CPU tensors in place; device tensors are
-        staged through host memory, so the path is deterministic on every rank."""
+        """classic storage: exchange entries [lo, hi) of per-particle arrays (theta, logpi, delta, ...) -- one in-place
+        all-gather per array: by the library for the HIP ops (RCCL over xGMI, or its host transport), by torch.distributed on
+        the CPU tensors of an ops without a communicator (the oracle under gloo)."""
         if not self._collectives:
             return
         import torch.distributed as dist
 
-        direct = self._backend == "nccl" or self.device.type == "cpu"
         for t in bufs:
             if self._native_comm:
                 self.ops.comm_allgather(t, t.numel() // self.world)
-            elif direct:
-                dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
             else:
-                host = torch.empty(t.shape, dtype=t.dtype)
-                dist.all_gather_into_tensor(host, t[self.lo:self.hi].cpu(), group=self.pg)
-                t.copy_(host)
+                dist.all_gather_into_tensor(t, t[self.lo:self.hi], group=self.pg)
 
     def _allgather_chunks(self, t):
         """sharded packed runs: rank r owns the positions [r chunk, (r + 1) chunk) of the prefix (chunk = a multiple of
@@ -635,20 +694,17 @@ class PopulationEngine:
         c, g = self.chunk, self.world
         if self._native_comm:
             self.ops.comm_allgather(t, c)
-        elif self._backend == "nccl" or self.device.type == "cpu":
-            dist.all_gather_into_tensor(t[:g * c], t[self.rank * c:(self.rank + 1) * c], group=self.pg)
         else:
-            host = torch.empty(g * c, dtype=t.dtype)
-            dist.all_gather_into_tensor(host, t[self.rank * c:(self.rank + 1) * c].cpu(), group=self.pg)
-            t[:g * c].copy_(host)
+            dist.all_gather_into_tensor(t[:g * c], t[self.rank * c:(self.rank + 1) * c], group=self.pg)
 
     def _allreduce_counts(self, *vals):
         if not self._collectives:
             return vals
         import torch.distributed as dist
 
-        t = torch.tensor(vals, dtype=torch.int64, device=self.device if self._backend == "nccl" else "cpu")
+        t = torch.tensor(vals, dtype=torch.int64, device=self.device if self._native_comm else "cpu")
         if self._native_comm:
+            self._stream()
             self.ops.comm_allreduce(t, "sum")
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
@@ -950,7 +1006,7 @@ class PopulationEngine:
         if self._collectives:
             import torch.distributed as dist
 
-            t = torch.tensor([lo, -hi], dtype=torch.float64, device=self.device if self._backend == "nccl" else "cpu")
+            t = torch.tensor([lo, -hi], dtype=torch.float64, device=self.device if self._native_comm else "cpu")
             if self._native_comm:
                 self.ops.comm_allreduce(t, "min")
             else:

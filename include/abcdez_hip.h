@@ -239,29 +239,53 @@ ABCDEZ_API int abcdez_smc_group_publish(abcdez_ctx* ctx);
  * drops the group's timing pairs and re-reads the counter baselines; a no-op when no group is open. */
 ABCDEZ_API int abcdez_smc_group_abort(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_smc_group_end(abcdez_ctx* ctx, int64_t* nacc, int64_t* nsim, int32_t* k_done);
-/* ---- Multi-GPU: the exchange steps behind the ABI (RCCL over xGMI on the context's own stream; csrc/abz_comm.hip).
+/* ---- Multi-GPU: the exchange steps behind the ABI (csrc/abz_comm.hip).
  * The reference parallelises its population loops over the threads of one process (`@floop ex for i in 1:nparticles`,
  * src/abcdez_smc.jl:110, src/abcdez_mc.jl:7, src/abcdez_init.jl:6; `parallel=true`, smc:237); here one process per GPU owns a
- * contiguous range of positions and what the threads share through memory is exchanged by collectives the LIBRARY issues.
+ * contiguous range of positions and what the threads share through memory is exchanged by collectives the LIBRARY issues, over one
+ * of two transports:
+ *   RCCL over xGMI on the context's own stream (comm_unique_id + comm_init).  librccl is opened lazily by the first of these calls:
+ *     the library itself loads on hosts without RCCL.
+ *   a HOST-SUPPLIED transport (comm_init_host): the library stages this rank's piece through page-locked host memory, waits for its
+ *     stream, calls the host's all-gather on HOST memory and copies the other ranks' pieces back -- the same in-place semantics at
+ *     the same points of the same entry points.  For hosts that exchange through MPI (`MPI.Allgather!`), for ranks sharing one GPU
+ *     (RCCL refuses that), for tests.
+ *
  *   comm_unique_id: rank 0 obtains the 128-byte rendezvous id; the host carries it to the other ranks (MPI.bcast, a file, torch's store).
- *   comm_init:      every rank, once per context: joins the communicator of `world` ranks on the context's device.
+ *   comm_init:      every rank, once per context: joins the RCCL communicator of `world` ranks on the context's device.
+ *   comm_init_host: every rank, once per context: `allgather(user, buf, piece_bytes)` works IN PLACE on host memory -- on entry this
+ *                   rank's piece lies at buf + rank * piece_bytes, on return buf holds all `world` pieces in rank order -- and returns
+ *                   0 or an error code; `allreduce(user, buf, n, dtype, op)` reduces n 8-byte elements in place (dtype / op as in
+ *                   comm_allreduce) and may be NULL: the library then all-gathers the words and reduces them in rank order itself
+ *                   (the same bits on every rank).  The callbacks are called on the calling thread, inside the library call that
+ *                   needs the exchange, and must be collective over the same `world` processes.
  *   comm_rank:      this context's (rank, world); returns 1 (and 0 of 1) when the context has no communicator.
+ *   comm_kind:      0 = none, 1 = RCCL, 2 = host transport.
  *   comm_allgather: in place over `world` pieces of piece_bytes each, rank r's piece at buf + r * piece_bytes; enqueued on the
- *                   context's stream (ordered with the kernels before and after it), does not wait.  Used for the rows / log-priors /
- *                   distances of the initial population (init.jl:2-22) and of abcdemc's sweeps (mc:140-155).
- *   comm_allreduce: in place over n elements; dtype 0 = int64, 1 = float64; op 0 = sum, 1 = min, 2 = max.
+ *                   context's stream (ordered with the kernels before and after it; RCCL: does not wait).  Used for the rows /
+ *                   log-priors / distances of the initial population (init.jl:2-22) and of abcdemc's sweeps (mc:140-155).
+ *   comm_allreduce: in place over n elements; dtype 0 = int64, 1 = float64, 2 = uint64; op 0 = sum, 1 = min, 2 = max.
  *   smc_sweeps_sharded: the sweeps of ONE generation (smc:336-353) on a population sharded by position -- the counterpart of
- *                   abcdez_smc_sweeps_packed for world > 1, one call and one host synchronisation per generation: k_max times
+ *                   abcdez_smc_sweeps_packed for world > 1, one call per generation (RCCL: one host synchronisation): k_max times
  *                   { sweep of the own chunk [rank chunk, (rank + 1) chunk) of the prefix -> all-gather of the flag bytes (1 B per
  *                   position) -> replay of the other ranks' accepted proposals + the device-side test of smc:352 }, read-back, and the
  *                   all-gather of the distance chunks behind it (8 B per position, once per generation).  chunk: a multiple of 64
  *                   with world * chunk >= n_alive; `flags` (u8) and `delta` need room for world * chunk entries.  Counters as in
- *                   abcdez_smc_sweeps_packed; every replica counts the same flags, so all ranks return the same k_done. */
+ *                   abcdez_smc_sweeps_packed; every replica counts the same flags, so all ranks return the same k_done.
+ * abcdez_smc_sweeps_sharded and abcdez_mc_generation_sharded_async are COLLECTIVE calls: every rank makes them with the same
+ * arguments.  What can fail on one rank alone is done before the call's first collective; a failure after it aborts the
+ * communicator (ncclCommAbort; a host transport is marked broken) so that the peers fail instead of waiting, and every later
+ * collective of the context returns an error until abcdez_comm_destroy + a new initialisation. */
 #define ABCDEZ_COMM_ID_BYTES 128
+typedef int (*abcdez_host_allgather_fn)(void* user, void* buf, int64_t piece_bytes);
+typedef int (*abcdez_host_allreduce_fn)(void* user, void* buf, int64_t n, int32_t dtype, int32_t op);
 ABCDEZ_API int abcdez_comm_unique_id(void* id_out, size_t bytes);
 ABCDEZ_API int abcdez_comm_init(abcdez_ctx* ctx, const void* unique_id, size_t bytes, int rank, int world);
+ABCDEZ_API int abcdez_comm_init_host(abcdez_ctx* ctx, int rank, int world, abcdez_host_allgather_fn allgather,
+                                     abcdez_host_allreduce_fn allreduce, void* user);
 ABCDEZ_API int abcdez_comm_destroy(abcdez_ctx* ctx);
 ABCDEZ_API int abcdez_comm_rank(abcdez_ctx* ctx, int32_t* rank, int32_t* world);
+ABCDEZ_API int abcdez_comm_kind(abcdez_ctx* ctx, int32_t* kind);
 ABCDEZ_API int abcdez_comm_allgather(abcdez_ctx* ctx, void* buf, int64_t piece_bytes);
 ABCDEZ_API int abcdez_comm_allreduce(abcdez_ctx* ctx, void* buf, int64_t n, int dtype, int op);
 ABCDEZ_API int abcdez_smc_sweeps_sharded(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b, int64_t n_alive, int64_t chunk,

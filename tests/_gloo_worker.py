@@ -23,6 +23,8 @@ def cases():
         "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 2016),     # blobs: stamps travel too
         "mvn8": (A.Factored(*[A.Normal(0, 1)] * 8), A.MVNormal((1.0,) * 8, blobs=True), 2.5, 1032),
         "quad2d": (A.Factored(A.Normal(0, 5), A.Normal(0, 5)), A.Quad2D(0.5), 0.05, 600),
+        # BASELINE.json configs[2] in miniature: the two-phase sweep on 256-byte rows (4 lanes x 8 components)
+        "mvn32": (A.Factored(*[A.Normal(0, 1)] * 32), A.MVNormal((1.0,) * 32), 7.5, 1056),
         # BASELINE.json configs[3] in miniature: Lotka-Volterra RK4, 4 x Uniform(0, 2) prior, 8 observations
         "lv": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                A.LotkaVolterraRK4((1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6),
@@ -36,20 +38,22 @@ def cases():
 
 def main():
     outdir = sys.argv[1]
-    mode = sys.argv[2] if len(sys.argv) > 2 else "oracle"     # "oracle": CPU tensors; "hip": the product engine on cuda:0
-    # "rccl1": the product engine in a ONE-rank RCCL group with the sharded code path forced on, so that a
-    # single-GPU box runs the real collectives (in-place all_gather_into_tensor on device slices) end to end
-    # "rccl1_torch": the same with ABZ_COMM=torch -- the collectives issued by torch.distributed instead of by the library
-    if mode == "rccl1_torch":
-        os.environ["ABZ_COMM"] = "torch"
-    native = mode == "rccl1"
-    if mode == "rccl1_torch":
-        mode = "rccl1"
+    # "oracle": the CPU oracle as compute backend, collectives by torch.distributed (gloo) on CPU tensors -- pins engine.py's host logic
+    # "hip" / "hip_ar": the product engine on cuda:0, every rank sharing the one GPU of the test box; the collectives are issued by the
+    #          LIBRARY (abcdez_smc_sweeps_sharded, abcdez_mc_generation_sharded_async, abcdez_comm_allgather) over its host transport
+    #          (abcdez_comm_init_host) with gloo's all-gather underneath; "hip_ar" also hands it gloo's all-reduce
+    # "rccl1": the product engine in a ONE-rank RCCL group with the sharded code path forced on, so that a single-GPU box runs the
+    #          real RCCL collectives end to end (RCCL refuses two ranks on one device)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "oracle"
+    names = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    if mode == "hip_ar":
+        os.environ["ABZ_HOST_ALLREDUCE"] = "1"
+        mode = "hip"
     dist.init_process_group("nccl" if mode == "rccl1" else "gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    pg = dist.group.WORLD if (world > 1 or mode == "rccl1") else None
+    pg = dist.group.WORLD if (world > 1 or mode in ("rccl1", "hip1")) else None
     engine = O.oracle_engine
-    if mode == "rccl1":
+    if mode in ("rccl1", "hip1"):       # hip1: the host transport in a group of one rank
         import functools
 
         import torch
@@ -61,17 +65,22 @@ def main():
         import torch
         from abcdez_amd.engine import HipEngine
 
-        torch.cuda.set_device(0)          # every rank shares the one GPU of the test box; collectives go through gloo
+        torch.cuda.set_device(0)          # every rank shares the one GPU of the test box
         engine = HipEngine
+    want_kind = {"rccl1": 1, "hip": 2 if world > 1 else 0, "hip1": 2}.get(mode)
     for name, (prior, sim, eps, N) in cases().items():
+        if names is not None and name not in names:
+            continue
         # default storage: packed population; sharded = accept-flag exchange + replay on the replicas
         r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=21, engine=engine,
                        process_group=pg)
-        assert r.engine.packed and r.engine.sharded_packed == (world > 1 or mode == "rccl1")
-        if mode == "rccl1":     # who issues the collectives: the library itself (abcdez_comm_*) or torch.distributed
-            assert r.engine._native_comm == native, (r.engine._native_comm, native)
+        assert r.engine.packed and r.engine.sharded_packed == (world > 1 or mode in ("rccl1", "hip1"))
+        if want_kind is not None:       # the collectives of the HIP ops are the library's own, over the transport the mode names
+            assert r.engine._native_comm == (want_kind != 0) and r.engine.ops.comm_kind() == want_kind, (mode, r.engine.ops.comm_kind())
         m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=25, verbose=False, rng=22,
                       engine=engine, process_group=pg)
+        if want_kind is not None:
+            assert m.engine.ops.comm_kind() == want_kind
         res, mres = r.engine.result(), m.engine.result()
         # every rank must hold the same full population after the all-gathers
         np.savez(os.path.join(outdir, f"result_{name}_rank{rank}.npz"), theta=res["theta"], C=res["C"], Wns=res["Wns"],

@@ -40,7 +40,7 @@ def runs(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "lv", "further5"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5"])
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_run_equals_single_process(runs, name, world):
     ref = np.load(os.path.join(runs[1], f"result_{name}_rank0.npz"))
@@ -70,43 +70,51 @@ def test_uneven_shard_is_rejected(oracle):
     assert (eng.lo, eng.hi, eng.world) == (0, 10, 1)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_engine_ranks_share_one_gpu(tmp_path_factory, world):
-    """The product engine (HIP kernels) sharded over 2 / 4 ranks that share the single GPU of the test box,
-    collectives over gloo: exercises i0 > 0, chunks of the alive prefix, chunk sweep + flag exchange + replay, the in-place
-    all-gathers on device tensors and the counters -- everything of the N > 1 path except RCCL itself -- and must
-    reproduce the single-process CPU-oracle result bit for bit."""
-    ref_dir = tmp_path_factory.mktemp("ref_oracle")
-    run_world(1, ref_dir, "oracle")
-    hip_dir = tmp_path_factory.mktemp(f"hip_world{world}")
-    run_world(world, hip_dir, "hip", timeout=300)
-    for name in ("normal1d", "mvn8", "quad2d", "lv", "further5"):
+NAMES = ("normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5")
+
+
+def compare_with_single_process_oracle(ref_dir, hip_dir, world, names=NAMES):
+    for name in names:
         ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
         for rank in range(world):
             got = np.load(os.path.join(hip_dir, f"result_{name}_rank{rank}.npz"))
+            assert int(got["world"]) == world
             for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C") + \
                     (("blobs", "mc_blobs") if "blobs" in ref.files else ()):
                 assert np.array_equal(ref[k], got[k], equal_nan=True), (name, rank, k)
             assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
+            assert int(ref["iters"]) == int(got["iters"]) and int(ref["mc_nsims"]) == int(got["mc_nsims"])
+
+
+@pytest.fixture(scope="module")
+def oracle_ref(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ref_oracle")
+    run_world(1, d, "oracle")
+    return d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rccl1", "rccl1_torch"])
-def test_sharded_code_path_over_rccl_one_rank(tmp_path_factory, mode):
-    """The sharded code path (flag all-gather + replay, per-generation distance all-gather, abcdemc's row
-    all-gathers, counter all-reduce) over the real RCCL backend in a group of one rank -- all a single-GPU box
-    can run of `nccl` -- must reproduce the single-process CPU-oracle result bit for bit.  rccl1: the collectives are issued by
-    the LIBRARY on its own stream (abcdez_comm_*, abcdez_smc_sweeps_sharded: the whole sharded generation in one call);
-    rccl1_torch: by torch.distributed (ABZ_COMM=torch), as in rounds 2-4."""
-    ref_dir = tmp_path_factory.mktemp("ref_oracle_rccl")
-    run_world(1, ref_dir, "oracle")
+@pytest.mark.parametrize("world,mode", [(2, "hip"), (4, "hip"), (2, "hip_ar"), (3, "hip")])
+def test_library_sharded_entry_points_with_world_gt_1_on_one_gpu(tmp_path_factory, oracle_ref, world, mode):
+    """The LIBRARY's multi-rank code with world > 1: 2 / 3 / 4 processes share the single GPU of the test box, each with a context of
+    its own, and every exchange is issued by libabcdez_hip.so itself -- abcdez_smc_sweeps_sharded (chunk sweep, flag all-gather at
+    flags + rank chunk, replay, device-side test of smc:352, distance all-gather), abcdez_mc_generation_sharded_async (rows at
+    ntheta + rank n_local ld, log-priors, distances, stamps, the seven exchange words) and abcdez_comm_allgather for the initial
+    population -- over the host transport (abcdez_comm_init_host) with gloo's all-gather underneath ("hip_ar": gloo's all-reduce
+    too instead of the library's rank-order reduction).  Every rank must reproduce the single-process CPU-oracle run bit for bit:
+    the same assertions as test_sharded_run_equals_single_process.  Replaces `@floop ex` of src/abcdez_smc.jl:110,237 and
+    src/abcdez_mc.jl:7,112."""
+    hip_dir = tmp_path_factory.mktemp(f"hip_world{world}_{mode}")
+    run_world(world, hip_dir, mode, timeout=420)
+    compare_with_single_process_oracle(oracle_ref, hip_dir, world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rccl1", "hip1"])
+def test_sharded_code_path_in_a_group_of_one_rank(tmp_path_factory, oracle_ref, mode):
+    """The sharded code path (flag all-gather + replay, per-generation distance all-gather, abcdemc's exchange) in a group of ONE
+    rank with the collectives forced on: rccl1 -- over the real RCCL backend (all a single-GPU box can run of it; librccl is
+    opened lazily by abcdez_comm_unique_id); hip1 -- over the host transport.  Bit-identical to the single-process CPU oracle."""
     hip_dir = tmp_path_factory.mktemp("hip_" + mode)
-    run_world(1, hip_dir, mode, timeout=240)
-    for name in ("normal1d", "mvn8", "quad2d", "lv", "further5"):
-        ref = np.load(os.path.join(ref_dir, f"result_{name}_rank0.npz"))
-        got = np.load(os.path.join(hip_dir, f"result_{name}_rank0.npz"))
-        for k in ("theta", "C", "Wns", "logpi", "eps_hist", "mc_theta", "mc_C") + \
-                (("blobs", "mc_blobs") if "blobs" in ref.files else ()):
-            assert np.array_equal(ref[k], got[k], equal_nan=True), (name, k)
-        assert float(ref["logZ"]) == float(got["logZ"]) and int(ref["nsims"]) == int(got["nsims"])
+    run_world(1, hip_dir, mode, timeout=300)
+    compare_with_single_process_oracle(oracle_ref, hip_dir, 1)
