@@ -20,6 +20,7 @@ _pi64, _pf64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
 PROTOTYPES = {
     "abcdez_ctx_create": [C.POINTER(Model), C.c_int, C.POINTER(_vp)],
     "abcdez_ctx_create_user": [C.POINTER(Model), C.c_char_p, C.c_int, C.POINTER(_vp)],
+    "abcdez_user_translation_unit": [C.POINTER(Model), C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t],
     "abcdez_ctx_destroy": [_vp],
     "abcdez_ctx_set_stream": [_vp, _vp],
     "abcdez_ctx_reserve": [_vp, _i64],

@@ -55,15 +55,9 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
  * that is the bulk of the sweep -- Lotka-Volterra, and user-supplied simulators (ABZ_USER_ONE_KERNEL=1 in the environment keeps those
  * on the one-kernel two-phase body: the A/B switch, and the choice for a simulator cheaper than a launch and 100 bytes of traffic) */
 bool abz_sweep_in_two_launches(const abcdez_ctx* ctx) {
-#if defined(ABZ_SWEEP_ONE_PHASE)
-  return false;
-#else
   if (ctx->L != 1) return false;
-#if !defined(ABZ_LV_ONE_KERNEL)
   if (ctx->h_model.sim_id == ABZ_SIM_LV && ctx->C == 4) return true;
-#endif
   return ctx->h_model.sim_id == ABZ_SIM_USER && (ctx->C == 4 || ctx->C == 8) && !ctx->user_one_kernel;
-#endif
 }
 
 /* the hand-over list of a two-launch sweep: [two counters | pad to 256 B | tp 8 ld B | wl 8 | kdi 8 | logu 8 | pos 4] per position */
@@ -87,6 +81,7 @@ static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
  * the whole row in one thread otherwise                                            */
 static void default_shape(const abz_model& m, int* L, int* C) {
   if (m.sim_id == ABZ_SIM_MVN && m.ld > 8) { *C = 8; *L = m.ld / 8; }
+  else if (m.sim_id == ABZ_SIM_USER && m.ld > 16) { *C = 8; *L = m.ld / 8; }     /* the cooperative form of a user simulator */
   else { *L = 1; *C = m.ld; }
 }
 
@@ -150,7 +145,9 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     case ABZ_SIM_MVN: ABZ_REQUIRE(model->n_data >= model->d, "mvn: needs d data values"); break;
     case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: ABZ_REQUIRE(model->d == 1, "simulator needs d = 1"); break;
     case ABZ_SIM_QUAD2D: case ABZ_SIM_NORMDU: ABZ_REQUIRE(model->d == 2, "simulator needs d = 2"); break;
-    case ABZ_SIM_USER: ABZ_REQUIRE(model->d <= 16, "user simulator: d must be <= 16 (whole row in one thread)"); break;
+    case ABZ_SIM_USER:     /* up to 16 parameters: the whole row in one thread (abz_user_dist); beyond: 8 per lane (abz_user_dist_lanes) */
+      ABZ_REQUIRE(model->n_blob == 0 || model->d <= 16, "user simulator: blobs need the whole row in one thread (d <= 16)");
+      break;
     case ABZ_SIM_SOCKS:
       ABZ_REQUIRE(model->d == 2 && model->sim_p[2] >= 1.0 && model->sim_p[2] <= 16.0, "socks: needs d = 2 and 1..16 picked socks");
       break;
@@ -365,7 +362,10 @@ int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes) {
   if (lanes <= 0) { default_shape(ctx->h_model, &ctx->L, &ctx->C); return 0; }
   const int ld = ctx->h_model.ld;
   ABZ_REQUIRE(is_pow2(lanes) && lanes <= 16 && ld % lanes == 0, "set_lanes: lanes must be a power of two <= 16 dividing ld");
-  ABZ_REQUIRE(lanes == 1 || ctx->h_model.sim_id == ABZ_SIM_MVN, "set_lanes: this simulator needs the whole row in one thread");
+  ABZ_REQUIRE(ctx->h_model.sim_id != ABZ_SIM_USER || lanes == ctx->L,
+              "set_lanes: the kernels of a user simulator were compiled for their lane-group shape when the context was created");
+  ABZ_REQUIRE(lanes == 1 || ctx->h_model.sim_id == ABZ_SIM_MVN || ctx->h_model.sim_id == ABZ_SIM_USER,
+              "set_lanes: this simulator needs the whole row in one thread");
   const int C = ld / lanes;
   ABZ_REQUIRE(lanes == 1 || C >= 2, "set_lanes: at least two components per lane");
   ctx->L = lanes; ctx->C = C;
@@ -549,6 +549,7 @@ int abcdez_blob_eval(abcdez_ctx* ctx, const double* theta, const uint64_t* stamp
   ABZ_REQUIRE(ctx && theta && stamp && blob && delta_out, "blob_eval: null argument");
   ABZ_REQUIRE(ctx->h_model.n_blob > 0, "blob_eval: the model was created with n_blob = 0");
   ABZ_REQUIRE(N >= 0 && N <= ABZ_MAX_N, "blob_eval: N out of range");
+  ABZ_REQUIRE_LANES(ctx, N, "blob_eval");
   const uint32_t nbw = (uint32_t)(ctx->h_model.sim_id == ABZ_SIM_MVN ? ctx->h_model.ld : ctx->h_model.n_blob);
   abz_population_written(ctx);         /* delta_out may be a distance array the library has state about */
   return abz_launch_blob_eval(ctx, theta, stamp, N, blob, delta_out, nbw);
@@ -558,6 +559,7 @@ int abcdez_init(abcdez_ctx* ctx, double* theta, double* logpi, double* delta, in
   ABZ_REQUIRE(ctx && theta && logpi && delta, "init: null argument");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(i0 >= 0 && n >= 0 && i0 + n <= ABZ_MAX_N, "init: range out of bounds");
+  ABZ_REQUIRE_LANES(ctx, n, "init");
   ABZ_HIP_CHECK(hipMemsetAsync(ctx->d_scal + ABZ_S_INITBAD, 0, 8, ctx->stream));
   int rc = abz_launch_init(ctx, theta, logpi, delta, i0, n);
   if (rc) return rc;
@@ -573,6 +575,7 @@ int abcdez_smc_partition(abcdez_ctx* ctx, uint8_t* alive, int64_t N, int64_t n_p
   ABZ_REQUIRE(ctx && alive && bits && bits_other && slot0 && slot1 && logpi && delta && wns, "smc_partition: null argument");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 0 <= n_new && n_new <= n_prev && n_prev <= N, "smc_partition: need 0 <= n_new <= n_prev <= N");
+  ABZ_REQUIRE_LANES(ctx, n_prev, "smc_partition");
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_partition: the two bit arrays / slots must differ");
   return abz_partition_impl(ctx, alive, N, n_prev, n_new, bits, bits_other, slot0, slot1, logpi, delta, wns, nullptr, 0.0);
 }
@@ -585,6 +588,7 @@ int abcdez_smc_prologue_packed(abcdez_ctx* ctx, double* delta, double* wns, uint
   ABZ_REQUIRE(ctx && delta && wns && alive && bits && bits_other && slot0 && slot1 && logpi && eps && wnorm && ess && n_alive &&
               partitioned, "smc_prologue_packed: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N && 1 <= n_prev && n_prev <= N, "smc_prologue_packed: need 1 <= n_prev <= N");
+  ABZ_REQUIRE_LANES(ctx, n_prev, "smc_prologue_packed");
   ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0, "smc_prologue_packed: alpha must be in [0, 1]");
   ABZ_REQUIRE(eps_k_old >= 0.0 && eps_target >= 0.0, "Expected ϵ ≥ 0.0");   /* types.jl:30 */
   ABZ_REQUIRE(bits != bits_other && slot0 != slot1, "smc_prologue_packed: the two bit arrays / slots must differ");
@@ -608,6 +612,7 @@ int abcdez_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bit
   ABZ_REQUIRE((nacc == nullptr) == (nsim == nullptr), "smc_swarm_packed: pass both counters or neither");
   /* the reference's donor loops (smc:119-126) never terminate with fewer than 3 alive particles */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE_LANES(ctx, n_alive, "smc_swarm_packed");
   ABZ_REQUIRE(0 <= r_lo && r_lo <= r_hi && r_hi <= n_alive, "smc_swarm_packed: position range out of bounds");
   ABZ_REQUIRE((r_lo % ABZ_PACKED_ALIGN == 0 || r_lo == n_alive) && (r_hi % ABZ_PACKED_ALIGN == 0 || r_hi == n_alive),
               "smc_swarm_packed: a sub-range must start and end at multiples of 64 positions (or at n_alive)");
@@ -692,6 +697,7 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
                              int32_t k_max, double kmcmc_min, int64_t* nacc, int64_t* nsim, int32_t* k_done) {
   ABZ_REQUIRE(ctx && bits_a && bits_b && slot0 && slot1 && logpi && delta && nacc && nsim && k_done, "smc_sweeps_packed: null argument");
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_swarm: needs at least 3 alive particles");
+  ABZ_REQUIRE_LANES(ctx, n_alive, "smc_sweeps_packed");
   ABZ_REQUIRE(1 <= k_max && k_max <= ABZ_GROUP_MAX, "smc_sweeps_packed: 1 <= k_max <= 16 sweeps per call");
   ABZ_REQUIRE(slot0 != slot1 && bits_a != bits_b, "smc_sweeps_packed: the two slots / bit arrays must differ");
   ABZ_REQUIRE(kmcmc_min >= 0.0, "smc_sweeps_packed: Kmcmc_min must not be negative");
@@ -779,6 +785,7 @@ int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bi
   ABZ_REQUIRE(ctx && bits && bits_out && slot0 && slot1 && logpi && flags && nacc && nsim, "smc_replay_packed: null argument");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N, "smc_replay_packed: needs at least 3 alive particles");
+  ABZ_REQUIRE_LANES(ctx, n_alive, "smc_replay_packed");
   ABZ_REQUIRE(0 <= skip_lo && skip_lo <= skip_hi && skip_hi <= n_alive, "smc_replay_packed: position range out of bounds");
   ABZ_REQUIRE((skip_lo % ABZ_PACKED_ALIGN == 0 || skip_lo == n_alive) && (skip_hi % ABZ_PACKED_ALIGN == 0 || skip_hi == n_alive),
               "smc_replay_packed: the own range must start and end at multiples of 64 positions (or at n_alive)");
@@ -807,6 +814,7 @@ int abcdez_smc_group_begin(abcdez_ctx* ctx, int64_t n_alive, double kmcmc_min) {
   ABZ_REQUIRE(ctx, "smc_group_begin: null context");
   ABZ_REQUIRE(ctx->grp_k < 0, "smc_group_begin: a group is already open");
   ABZ_REQUIRE(n_alive >= 3 && n_alive <= ABZ_MAX_N && kmcmc_min >= 0.0, "smc_group_begin: bad argument");
+  ABZ_REQUIRE_LANES(ctx, n_alive, "smc_group_begin");
   ctx->ahead = abz_ahead{};
   ctx->grp_k = 0; ctx->grp_n_alive = n_alive; ctx->grp_kmin = kmcmc_min; ctx->grp_pub = 0;
   ctx->grp_base_acc = ctx->cnt_prev[ABZ_C_RACC]; ctx->grp_base_sim = ctx->cnt_prev[ABZ_C_RSIM];
@@ -881,6 +889,7 @@ int abcdez_smc_resample_gather_packed(abcdez_ctx* ctx, const uint32_t* inds, int
               "smc_resample_gather_packed: null argument");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "smc_resample_gather_packed: N out of range");
+  ABZ_REQUIRE_LANES(ctx, N, "smc_resample_gather_packed");
   ABZ_REQUIRE(logpi != nlogpi && delta != ndelta && slot0 != slot1 && bits != bits_other,
               "smc_resample_gather_packed: in/out arrays must differ");
   ctx->w_uniform = true;                /* Wns .= 1/N (smc:102) */
@@ -892,6 +901,7 @@ int abcdez_packed_gather(abcdez_ctx* ctx, const uint32_t* bits, int64_t N, const
                          double* out) {
   ABZ_REQUIRE(ctx && bits && slot0 && slot1 && out, "packed_gather: null argument");
   ABZ_REQUIRE(N >= 1 && N <= ABZ_MAX_N, "packed_gather: N out of range");
+  ABZ_REQUIRE_LANES(ctx, N, "packed_gather");
   return abz_launch_packed_gather(ctx, bits, (uint32_t)N, slot0, slot1, out);
 }
 
@@ -988,6 +998,7 @@ int abcdez_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* cnt,
   ABZ_REQUIRE((order == nullptr) == (cnt == nullptr), "mc_swarm: pass both order and cnt (draws by rank) or neither (by rejection)");
   abz_population_written(ctx);          /* select enqueued ahead, abcdemc chain: they no longer describe the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE_LANES(ctx, N, "mc_swarm");
   ABZ_REQUIRE(i0 >= 0 && n_local >= 0 && i0 + n_local <= N, "mc_swarm: particle range out of bounds");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
   int rc = abz_launch_mc_swarm(ctx, order, cnt, (uint32_t)N, theta, logpi, delta, ntheta, nlogpi, ndelta,
@@ -1029,6 +1040,7 @@ int abcdez_mc_generation(abcdez_ctx* ctx, int64_t N, const double* theta, const 
                          uint32_t sweep, int64_t* nsim, int64_t* n_above_target, double* dmin, double* dmax_out) {
   ABZ_REQUIRE(ctx && order && sorted_delta && cnt && delta, "mc_generation: null argument");
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE_LANES(ctx, N, "mc_generation");
   ABZ_REQUIRE(n_above >= -1 && n_above <= N, "mc_generation: n_above = #(Ds > eps_target) of the distances read, or -1");
   if (n_above < 0) {                 /* the caller does not carry mc:156 of the generation before: count */
     if (int rc = abz_count_gt_impl(ctx, delta, N, eps_target, &n_above)) return rc;
@@ -1069,6 +1081,7 @@ static int mc_generation_async_impl(abcdez_ctx* ctx, int64_t N, const double* th
   }
   ctx->ahead = abz_ahead{};            /* anything enqueued ahead for the next prologue no longer describes the population */
   ABZ_REQUIRE(N >= 5 && N <= ABZ_MAX_N, "nparticles must be at least 5");   /* mc:109 */
+  ABZ_REQUIRE_LANES(ctx, N, "mc_generation_async");
   ABZ_REQUIRE(theta != ntheta && logpi != nlogpi && delta != ndelta, "mc_swarm: in/out arrays must differ (synchronous update)");
   ABZ_REQUIRE(alpha >= 0.0 && alpha <= 1.0 && eps_target >= 0.0, "mc_generation_async: need 0 <= alpha <= 1 and eps_target >= 0");
   ABZ_REQUIRE(ctx->mc_issued - ctx->mc_waited < ABZ_MC_RING, "mc_generation_async: too many generations in flight (redeem a ticket first)");

@@ -182,6 +182,20 @@ struct abcdez_ctx {
 
 void abz_set_error(const std::string& msg);
 
+/* Thread indices are 32-bit on the device (gid = tile * BLOCK + threadIdx.x in the sweep, init, gather, partition and replay bodies;
+ * L lanes of a wavefront own one particle): a launch over n particles must stay below 2^32 THREADS, which n <= ABZ_MAX_N alone
+ * does not guarantee (2^30 particles at 8 lanes wrap silently).  Checked by every entry point that launches lane-group kernels,
+ * before anything is enqueued. */
+#define ABZ_REQUIRE_LANES(ctx, n, who)                                                                                        \
+  do {                                                                                                                        \
+    if ((uint64_t)(n) * (uint64_t)(ctx)->L >= (1ull << 32)) {                                                                \
+      abz_set_error(std::string(who) + ": " + std::to_string((long long)(n)) + " particles x " + std::to_string((ctx)->L) +    \
+                    " lanes per particle is 2^32 threads or more -- thread indices are 32-bit on the device: use fewer lanes " \
+                    "(abcdez_ctx_set_lanes) or shard the population over more GPUs");                                          \
+      return -1;                                                                                                              \
+    }                                                                                                                         \
+  } while (0)
+
 #define ABZ_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
@@ -340,6 +354,7 @@ int abz_launch_blob_eval(abcdez_ctx*, const double* theta, const uint64_t* stamp
 int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned ntiles);
 int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
 bool abz_jit_has_smc_split(abcdez_ctx*);
+bool abz_jit_has_rounds(abcdez_ctx*);
 int abz_jit_launch_smc_split(abcdez_ctx*, const void* args, const void* list, unsigned nblocks);
 
 #endif

@@ -43,20 +43,6 @@ __device__ inline void load_row(const double* __restrict__ row, int j, double (&
     }
   }
 }
-/* the same row through non-temporal loads (A/B builds of the sweep: -DABZ_SWEEP_NT_LOADS) */
-template <int L, int C>
-__device__ inline void load_row_nt(const double* __restrict__ row, int j, double (&v)[C]) {
-  if constexpr (C == 1) {
-    v[0] = __builtin_nontemporal_load(row);
-  } else {
-    typedef double d2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int m = 0; m < C / 2; ++m) {
-      const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(row + m * 2 * L + 2 * j));
-      v[2 * m] = t.x; v[2 * m + 1] = t.y;
-    }
-  }
-}
 template <int L, int C>
 __device__ inline void store_row(double* __restrict__ row, int j, const double (&v)[C]) {
   if constexpr (C == 1) {
@@ -296,9 +282,38 @@ struct abz_user_rng {
   __device__ inline uint64_t bits() { return block().w0; }
   __device__ inline void normal_pair(double& z0, double& z1) { abz_normal_pair(block(), T, &z0, &z1); }
   __device__ inline double normal() { double a, b; normal_pair(a, b); return a; }
+  /* the same draws ADDRESSED by a sub-index instead of taken in sequence: what a cooperative simulator (below) uses, keyed by
+   * the component it draws for, so that its results do not depend on how many lanes share the row */
+  __device__ inline abz_u64x2 block_at(uint32_t s) const { return abz_rng(seed, i, epoch, s, purpose); }
+  __device__ inline double uniform_at(uint32_t s) const { return abz_u01_co(block_at(s).w0); }
+  __device__ inline void normal_pair_at(uint32_t s, double& z0, double& z1) const { abz_normal_pair(block_at(s), T, &z0, &z1); }
 };
+/* one thread sees the whole row: length(prior) <= 16 */
 __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data, const double* sim_p,
                                 abz_user_rng& rng);
+/* COOPERATIVE form, rows of 17 to 64 parameters: L lanes of a wavefront own one particle, as in the built-in d-dimensional Normal
+ * simulator.  Every lane of the group calls
+ *     abz_user_dist_lanes(theta, g, d, data, n_data, sim_p, rng)
+ * with ITS C = ABZ_USER_C components in theta[0 .. C) (push_p-cast); g.comp(q) is the index in the row of theta[q] (indices >= d are
+ * padding: theta = 0), g.sum(v) adds v[0 .. C) over all L x C entries of the group in one canonical tree -- the same value on every
+ * lane and for every L -- and the function returns the distance, the same value on every lane.  Draws are addressed
+ * (rng.normal_pair_at(k, ...), rng.uniform_at(k)): key them by component (g.comp(q) / 2 for a pair), never by lane.  ABZ_USER_L and
+ * ABZ_USER_C are compile-time constants of the translation unit. */
+struct abz_user_lanes {
+  int L, C, j;
+  __device__ inline int comp(int q) const { return C == 1 ? 0 : (q >> 1) * 2 * L + 2 * j + (q & 1); }
+  __device__ inline double sum(const double* v) const;
+};
+__device__ double abz_user_dist_lanes(const double* theta, const abz_user_lanes& g, int d, const double* data, int n_data,
+                                      const double* sim_p, abz_user_rng& rng);
+#if defined(ABZ_USER_L) && defined(ABZ_USER_C)     /* the run-time translation unit of a user simulator (abz_jit.hip) */
+__device__ inline double abz_user_lanes::sum(const double* v) const {
+  double x[ABZ_USER_C];
+#pragma unroll
+  for (int q = 0; q < ABZ_USER_C; ++q) x[q] = v[q];
+  return group_tree_sum<ABZ_USER_L, ABZ_USER_C>(x);
+}
+#endif
 
 /* ---- simulators = dist!(theta, ve); arithmetic fixed by abcdez_spec.h (ABZ_SIM_*) -- */
 /* BLOB = true additionally writes the simulated data behind the distance to blob[] (this lane's C entries in
@@ -439,7 +454,12 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     }
     return abz_sqrt(acc);
   } else if constexpr (SIM == ABZ_SIM_USER) {
-    static_assert(L == 1, "user simulators see the whole row in one thread");
+    if constexpr (L > 1) {       /* rows of 17 .. 64 parameters: the cooperative form, the row spread over the group's lanes */
+      static_assert(!BLOB, "user simulators on lane groups carry no blobs");
+      abz_user_rng rng{seed, i, epoch, purpose, 0u, T};
+      const abz_user_lanes g{L, C, j};
+      return abz_user_dist_lanes(th, g, M.d, M.data, M.n_data, M.sim_p, rng);
+    } else {
     abz_user_rng rng{seed, i, epoch, purpose, 0u, T};
 #ifdef ABZ_USER_HAS_BLOB
     if constexpr (BLOB) {       /* the user's blob function re-runs the simulation on a fresh copy of the same stream */
@@ -448,6 +468,7 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     }
 #endif
     return abz_user_dist(th, M.d, M.data, M.n_data, M.sim_p, rng);
+    }
   } else if constexpr (SIM == ABZ_SIM_SOCKS) {
     double ns = th[0];
     if (!(ns >= 0.0)) return ABZ_NAN;

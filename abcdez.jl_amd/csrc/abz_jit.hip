@@ -12,6 +12,8 @@
  */
 #include <hip/hiprtc.h>
 
+#include <string.h>
+
 #include <string>
 #include <vector>
 
@@ -23,6 +25,7 @@ struct AbzUserModule {
   hipModule_t mod = nullptr;
   hipFunction_t f_init = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
   hipFunction_t f_p1 = nullptr, f_p2 = nullptr;     /* the sweep as two launches (rows of 4 or 8 doubles; abz_kernels.h, smc_split_phase1_body) */
+  bool rounds = false;                              /* the second launch runs the staged form round by round (abz_user_rounds.h) */
 };
 
 /* the user kernels loop over tiles like the built-in ones (ABZ_TILE_LOOP): grid = what is resident at once */
@@ -49,29 +52,52 @@ static unsigned jit_grid(abcdez_ctx* ctx, hipFunction_t f, uint64_t ntiles) {
     }                                                                                      \
   } while (0)
 
-int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
-  const int C = ctx->h_model.ld;
-  std::string tu = "#include \"abz_kernels.h\"\n#line 1 \"user_simulator\"\n";
+/* The translation unit of a user simulator and the options it is compiled with: lane-group shape (L lanes x C components; the whole
+ * row in one thread up to 16 parameters -- abz_user_dist --, 8 components per lane beyond -- abz_user_dist_lanes), PLAIN (every dimension
+ * a continuous Normal: the two-instruction log-density of the built-in kernels), blobs.  A function of the model alone -- no device is
+ * touched --, so the CPU tests compile the very same text with hipcc (abcdez_user_translation_unit, tests/test_user_simulator_sources.py). */
+static int abz_jit_make_tu(int L, int C, bool plain, bool has_blob, const char* user_source, std::string& tu, std::vector<std::string>& defs) {
+  tu = "#include \"abz_kernels.h\"\n#line 1 \"user_simulator\"\n";
   tu += user_source;
-  tu += "\n#line 1 \"abz_user_entry\"\n";
+  /* behind the user's text, so that it sees the ABZ_USER_ROUNDS / ABZ_USER_STATE the text may define: the staged form's abz_user_dist and
+   * its round-by-round second launch */
+  tu += "\n#line 1 \"abz_user_entry\"\n#include \"abz_user_rounds.h\"\n";
   tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_init(const HotModel M, double* theta, "
         "double* logpi, double* delta, uint32_t i0, uint32_t n, unsigned long long* bad, uint64_t* stamp) {\n"
-        "  init_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad, stamp);\n}\n"
+        "  init_kernel_body<ABZ_SIM_USER, ABZ_USER_L, ABZ_USER_C>(M, theta, logpi, delta, i0, n, bad, stamp);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_packed(const SmcPackedArgs a) {\n"
-        "  smc_swarm_packed_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n"
+        "  smc_swarm_packed_body<ABZ_SIM_USER, ABZ_USER_L, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_mc(const McSwarmArgs a) {\n"
-        "  mc_swarm_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(a);\n}\n";
-  const bool split = C == 4 || C == 8;               /* rows the two-launch sweep exists for */
+        "  mc_swarm_kernel_body<ABZ_SIM_USER, ABZ_USER_L, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a);\n}\n";
+  const bool split = L == 1 && (C == 4 || C == 8);  /* rows the two-launch sweep exists for */
   if (split)
     tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p1(const SmcPackedArgs a, const LvHandList h) {\n"
-          "  smc_split_phase1_body<ABZ_SIM_USER, ABZ_USER_C, false>(a, h);\n}\n"
+          "  smc_split_phase1_body<ABZ_SIM_USER, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
+          "#ifdef ABZ_USER_ROUNDS\n"      /* the staged form: round by round, leavers dropped (abz_user_rounds.h) */
           "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
-          "  smc_split_phase2_body<ABZ_SIM_USER, ABZ_USER_C, false>(a, h);\n}\n";
-  const bool has_blob = ctx->h_model.n_blob > 0;     /* then the source must also define abz_user_blob */
+          "  smc_user_rounds_phase2_body<ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
+          "extern \"C\" __global__ void abz_user_has_rounds() {}\n"
+          "#else\n"
+          "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
+          "  smc_split_phase2_body<ABZ_SIM_USER, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
+          "#endif\n";
+  if (has_blob && L != 1) { abz_set_error("user simulator: blobs need the whole row in one thread (length(prior) <= 16)"); return -1; }
   if (has_blob)
     tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_blob_eval(const HotModel M, const double* theta, "
           "const uint64_t* stamp, uint32_t n, double* blob, double* delta_out, uint32_t nbw) {\n"
           "  blob_eval_kernel_body<ABZ_SIM_USER, 1, ABZ_USER_C>(M, theta, stamp, n, blob, delta_out, nbw);\n}\n";
+  defs = {"-DABZ_USER_C=" + std::to_string(C), "-DABZ_USER_L=" + std::to_string(L), std::string("-DABZ_USER_PLAIN=") + (plain ? "1" : "0")};
+  if (has_blob) defs.push_back("-DABZ_USER_HAS_BLOB=1");
+  return 0;
+}
+
+int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
+  const int L = ctx->L, C = ctx->C;
+  const bool split = L == 1 && (C == 4 || C == 8);
+  const bool has_blob = ctx->h_model.n_blob > 0;     /* then the source must also define abz_user_blob */
+  std::string tu;
+  std::vector<std::string> defs;
+  if (int rc = abz_jit_make_tu(L, C, ctx->prior_plain, has_blob, user_source, tu, defs)) return rc;
   hiprtcProgram prog;
   ABZ_RTC_CHECK(hiprtcCreateProgram(&prog, tu.c_str(), "abz_user.hip", abz_jit_n_headers, (const char**)abz_jit_header_sources,
                                     (const char**)abz_jit_header_names));
@@ -80,10 +106,9 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
   const size_t colon = arch.find(':');                 /* "gfx950:sramecc+:xnack-" -> "gfx950" */
   if (colon != std::string::npos) arch = arch.substr(0, colon);
-  const std::string defc = "-DABZ_USER_C=" + std::to_string(C);
-  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", defc.c_str(),
-                        "-DABZ_USER_HAS_BLOB=1"};
-  const hiprtcResult cr = hiprtcCompileProgram(prog, has_blob ? 7 : 6, opts);
+  std::vector<const char*> opts = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+  for (const std::string& d : defs) opts.push_back(d.c_str());
+  const hiprtcResult cr = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (cr != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
@@ -108,6 +133,9 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   if (split) {
     ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p1, um->mod, "abz_user_smc_p1"));
     ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p2, um->mod, "abz_user_smc_p2"));
+    hipFunction_t marker = nullptr;       /* present iff the source defined ABZ_USER_ROUNDS (the staged form) */
+    um->rounds = hipModuleGetFunction(&marker, um->mod, "abz_user_has_rounds") == hipSuccess;
+    (void)hipGetLastError();
   }
   return 0;
 }
@@ -125,7 +153,8 @@ int abz_jit_launch_init(abcdez_ctx* ctx, double* theta, double* logpi, double* d
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   HotModel M = ctx->hot;
   void* params[] = {&M, &theta, &logpi, &delta, &i0, &n, &bad, &stamp};
-  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, jit_grid(ctx, um->f_init, (n + ABZ_BLOCK - 1) / ABZ_BLOCK), 1, 1, ABZ_BLOCK, 1, 1,
+  const uint64_t tiles = ((uint64_t)n * (uint64_t)ctx->L + ABZ_BLOCK - 1) / ABZ_BLOCK;       /* L lanes per particle */
+  ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_init, jit_grid(ctx, um->f_init, tiles), 1, 1, ABZ_BLOCK, 1, 1,
                                       0, ctx->stream, params, nullptr));
   return 0;
 }
@@ -156,10 +185,34 @@ bool abz_jit_has_smc_split(abcdez_ctx* ctx) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   return um && um->f_p1 && um->f_p2;
 }
+bool abz_jit_has_rounds(abcdez_ctx* ctx) {
+  AbzUserModule* um = (AbzUserModule*)ctx->user_module;
+  return um && um->rounds;
+}
 int abz_jit_launch_smc_split(abcdez_ctx* ctx, const void* args, const void* list, unsigned nblocks) {
   AbzUserModule* um = (AbzUserModule*)ctx->user_module;
   void* params[] = {const_cast<void*>(args), const_cast<void*>(list)};
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_p1, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   ABZ_HIP_CHECK(hipModuleLaunchKernel(um->f_p2, nblocks, 1, 1, ABZ_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
   return 0;
+}
+
+/* Test hook (no device needed): the translation unit abcdez_ctx_create_user would hand to hiprtc for this model and source, and the -D
+ * options that go with it (one per line).  Returns the text's length, or a negative status. */
+extern "C" __attribute__((visibility("default"))) int abcdez_user_translation_unit(const abz_model* model, const char* user_source,
+                                                                                     char* tu_out, size_t tu_cap, char* opts_out, size_t opts_cap) {
+  if (!model || !user_source || !tu_out || !opts_out) { abz_set_error("user_translation_unit: null argument"); return -1; }
+  int L = 1, C = model->ld;
+  if (model->ld > 16) { C = 8; L = model->ld / 8; }           /* default_shape of abz_api.hip for ABZ_SIM_USER */
+  bool plain = model->d == model->ld && !model->mv;
+  for (int k = 0; k < model->d && plain; ++k) plain = model->prior[k].family == ABZ_PRIOR_NORMAL && !model->prior[k].discrete;
+  std::string tu;
+  std::vector<std::string> defs;
+  if (int rc = abz_jit_make_tu(L, C, plain, model->n_blob > 0, user_source, tu, defs)) return rc;
+  std::string o;
+  for (const std::string& d : defs) o += d + "\n";
+  if (tu.size() + 1 > tu_cap || o.size() + 1 > opts_cap) { abz_set_error("user_translation_unit: buffer too small"); return -1; }
+  memcpy(tu_out, tu.c_str(), tu.size() + 1);
+  memcpy(opts_out, o.c_str(), o.size() + 1);
+  return (int)tu.size();
 }

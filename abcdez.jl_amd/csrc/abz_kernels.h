@@ -9,9 +9,7 @@
 
 #include "abz_device.h"
 
-#ifndef ABZ_LV_BLOCK
 #define ABZ_LV_BLOCK 512                                  /* threads per workgroup of the Lotka-Volterra sweep (abz_sweep_block) */
-#endif
 #define ABZ_REPLAY_PER 8                                  /* alive ranks per thread in the scan phase of the replay kernels */
 #define ABZ_REPLAY_CHUNK (ABZ_BLOCK * ABZ_REPLAY_PER)     /* alive ranks per block */
 
@@ -276,9 +274,6 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   __shared__ uint32_t s_n;
 
   /* ---------------- phase 1: order of issue = order of need (smc_swarm_packed_body_1p) */
-#ifdef ABZ_SWEEP_PRIO
-  __builtin_amdgcn_s_setprio(ABZ_SWEEP_PRIO);
-#endif
   ModelStage<SIM, LD, BLOCK> stage;
   stage.load(M);
   const uint32_t wi = a.bits[ri >> 5];
@@ -294,21 +289,9 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
   double tp[C];
   {
     double ti[C], ta[C], tb[C];
-#if defined(ABZ_SWEEP_NT_LOADS)          /* A/B builds: 1 = the own row, 2 = the donor rows, 3 = all three through non-temporal loads */
-    if constexpr ((ABZ_SWEEP_NT_LOADS & 1) != 0) load_row_nt<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
-    else load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
-    if constexpr ((ABZ_SWEEP_NT_LOADS & 2) != 0) {
-      load_row_nt<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
-      load_row_nt<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
-    } else {
-      load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
-      load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
-    }
-#else
     load_row<L, C>((bi ? a.slot1 : a.slot0) + (size_t)ri * LD, j, ti);
     load_row<L, C>((ba ? a.slot1 : a.slot0) + (size_t)ra * LD, j, ta);
     load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
-#endif
     stage.store(s_model);
     __syncthreads();                                              /* sampler + model tables staged; s_acc, s_n zeroed */
     double g, log_u;
@@ -343,9 +326,6 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
     /* nsims counts the in-support proposals (smc:138), simulated here or not */
     const unsigned nsim1 = (active && j == 0 && insupport) ? 1u : 0u;
     __syncthreads();                                              /* hand-over complete */
-#ifdef ABZ_SWEEP_PRIO                  /* A/B builds: wavefronts that still have their loads to issue go first */
-    __builtin_amdgcn_s_setprio(0);
-#endif
 
     /* ---------------- phase 2: lane group k takes slot k */
     const unsigned n = s_n;
@@ -365,11 +345,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       const LvConst k = lv_const(M);
       /* certain rejection: acc >= bound > eps^2 (1 + 2^-41) => sqrt(acc) > eps for the strict and the non-strict kernels alike;
        * eps = Inf or 0: never (bound NaN): dp = Inf is in the support of Indicator0toeps(Inf), dp = 0 in that of Indicator0toeps(0) */
-#ifdef ABZ_LV_NO_EARLY_EXIT            /* A/B builds: the same rounds, nobody leaves early */
-      const double bound = ABZ_NAN;
-#else
       const double bound = (a.eps > 0.0 && a.eps < 1.0e300) ? (a.eps * a.eps) * (1.0 + 0x1p-40) : ABZ_NAN;
-#endif
       if (threadIdx.x < n) { s_list[0][threadIdx.x] = (uint16_t)threadIdx.x; s_lx[threadIdx.x] = M.sim_p[0]; s_ly[threadIdx.x] = M.sim_p[1]; s_lacc[threadIdx.x] = 0.0; }
       if (threadIdx.x < 3) s_live[threadIdx.x] = 0u;
       __syncthreads();
@@ -379,9 +355,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       /* ABZ_LV_ROUND observations (and the intervals behind them) per round: a round ends with a workgroup barrier, at which the
        * working wavefronts wait for the slowest of them -- measured: 1 per round costs 4 % of the sweep where few proposals leave
        * early (profiles/r05_lv_early_exit_ab.jsonl) */
-#ifndef ABZ_LV_ROUND
 #define ABZ_LV_ROUND 2
-#endif
       int round = 0;
       for (int jo0 = 0; jo0 < k.nobs; jo0 += ABZ_LV_ROUND, ++round) {
         if (wave0 < n_live) {                                      /* wave-uniform: this wavefront still has proposals */
@@ -451,17 +425,14 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       const double w = (s_hand.wl[slot] + kernel_logpdf_dev(M.abck, a.eps, ds)) - s_hand.kdi[slot];              /* smc:140-141 */
       acc = on && ((0.0 <= w) || (s_hand.logu[slot] < w));        /* smc:145 */
       if (acc) {                                                  /* smc:146-150 */
-#ifndef ABZ_SWEEP_PLAIN_STORES      /* the accepted row is not read again before the next sweep: non-temporal stores (-0.8 % / -1.8 % on
-                                     * the sweep on two boxes, profiles/r05_two_phase_ab2.jsonl, _ab3.jsonl; ABZ_SWEEP_PLAIN_STORES: the A/B build) */
+        /* the accepted row is not read again before the next sweep: non-temporal stores (-0.8 % / -1.8 % on the sweep on two boxes
+         * against plain stores, profiles/r05_two_phase_ab2.jsonl, _ab3.jsonl) */
         {
           typedef double d2v __attribute__((ext_vector_type(2)));
           double* dst = (bs ? a.slot0 : a.slot1) + (size_t)rs * LD;
 #pragma unroll
           for (int m = 0; m < C / 2; ++m) { d2v t; t.x = tq[2 * m]; t.y = tq[2 * m + 1]; __builtin_nontemporal_store(t, (d2v*)(dst + m * 2 * L + 2 * j)); }
         }
-#else
-        store_row<L, C>((bs ? a.slot0 : a.slot1) + (size_t)rs * LD, j, tq);
-#endif
         if (j == 0) {
           const uint32_t t = rs - tile_base;
           atomicOr(&s_acc[t >> 5], 1u << (t & 31u));
@@ -500,9 +471,7 @@ struct LvHandList {
   unsigned int* count;      /* records in the list: zero when phase 1 starts */
   unsigned int* count_next; /* the counter of the NEXT sweep (the two alternate): phase 2 zeroes it, whether or not the sweep runs */
 };
-#ifndef ABZ_LV_BLOCK2
 #define ABZ_LV_BLOCK2 256   /* threads per workgroup of the second launch */
-#endif
 
 /* phase 1 for any simulator that runs one lane per particle with rows of C = 4 or 8 doubles (Lotka-Volterra; user-supplied simulators) */
 template <int SIM, int C, bool PLAIN, int BLOCK = ABZ_BLOCK>
@@ -661,11 +630,7 @@ __device__ inline void smc_lv_phase2_body(const SmcPackedArgs& a, const LvHandLi
 
   const LvConst k = lv_const(M);
   /* certain rejection: see smc_swarm_packed_body_2p */
-#ifdef ABZ_LV_NO_EARLY_EXIT
-  const double bound = ABZ_NAN;
-#else
   const double bound = (a.eps > 0.0 && a.eps < 1.0e300) ? (a.eps * a.eps) * (1.0 + 0x1p-40) : ABZ_NAN;
-#endif
   unsigned n_live = n;
   int cur = 0;
   const unsigned lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
@@ -732,19 +697,13 @@ __device__ inline void smc_lv_phase2_body(const SmcPackedArgs& a, const LvHandLi
  * 170 of 512 fill three wavefronts to 89 % where 85 of 256 fill two to 67 % (the simulator is all of that kernel's time) */
 template <int SIM, int L, int C>
 constexpr int abz_sweep_block() {
-#ifndef ABZ_SWEEP_ONE_PHASE
   return (SIM == ABZ_SIM_LV && L == 1 && C == 4) ? ABZ_LV_BLOCK : ABZ_BLOCK;
-#else
-  return ABZ_BLOCK;
-#endif
 }
 template <int SIM, int L, int C, bool PLAIN = false>
 __device__ inline void smc_swarm_packed_body(const SmcPackedArgs& a) {
-#ifndef ABZ_SWEEP_ONE_PHASE
   if constexpr ((L >= 2 && L <= 8 && C >= 2 && C <= 8) || ((SIM == ABZ_SIM_LV || SIM == ABZ_SIM_USER) && L == 1 && (C == 4 || C == 8)))
     smc_swarm_packed_body_2p<SIM, L, C, PLAIN, abz_sweep_block<SIM, L, C>()>(a);
   else
-#endif
     smc_swarm_packed_body_1p<SIM, L, C, PLAIN>(a);
 }
 

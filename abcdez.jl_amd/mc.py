@@ -38,13 +38,14 @@ def abcdemc(prior, dist, ϵ_target, varexternal=None, *,
     # serialises with every other blocking stream of the process (and could not be captured when graph replay -- optional,
     # off by default: measured slower -- is switched on)
     with (eng.run_scope() if hasattr(eng, "run_scope") else contextlib.nullcontext()):
-        return _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α)
+        return _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α, parallel)
 
 
-def _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α):
-    if verbose:
-        log.info("Running abcdemc with engine %s: ϵ_target=%s nparticles=%d generations=%d seed=%d",
-                 type(eng).__name__, ϵ_target, nparticles, generations, spec.seed)
+def _abcdemc_run(eng, spec, prior, ϵ_target, nparticles, generations, verbose, resume, α, parallel=False):
+    if verbose:                                               # mc:113-114
+        log.info("Running abcdemc! with executor %s (%d rank(s))", type(getattr(eng, "ops", eng)).__name__, getattr(eng, "world", 1))
+        log.info("Running abcdemc! with ϵ_target=%s nparticles=%d generations=%d α=%s rng=%s parallel=%s", ϵ_target, nparticles,
+                 generations, α, spec.seed, parallel)
 
     if resume is None:
         eng.init_population()                                 # mc:117-125 (S1)

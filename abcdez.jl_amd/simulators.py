@@ -206,16 +206,39 @@ class Socks(DeviceSimulator):
 
 class UserSimulator(DeviceSimulator):
     """A simulator supplied as HIP source text -- the device counterpart of the reference's
-    ``dist!(θ, ve)`` closure.  ``source`` must define::
+    ``dist!(θ, ve)`` closure (src/abcdez_smc.jl:137).  Compiled with hiprtc when the engine is created.  ``source`` defines ONE of
+
+    * ``length(prior) <= 16`` -- the whole row in one thread::
 
         __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
                                         const double* sim_p, abz_user_rng& rng);
 
+    * ``17 <= length(prior) <= 64`` -- the row spread over L = ld / 8 lanes of a wavefront, every lane calling::
+
+        __device__ double abz_user_dist_lanes(const double* theta, const abz_user_lanes& g, int d, const double* data,
+                                              int n_data, const double* sim_p, abz_user_rng& rng);
+
+      with ITS ``ABZ_USER_C`` (= 8) components in ``theta``; ``g.comp(q)`` is the index in the row of ``theta[q]`` (indices ``>= d``
+      are padding), ``g.sum(v)`` adds ``v[0 .. C)`` over the whole group in one canonical tree (the same value on every lane and for
+      every lane count), and the function returns the distance on every lane.  Draws are addressed, not sequential:
+      ``rng.normal_pair_at(k, z0, z1)``, ``rng.uniform_at(k)`` -- key them by component (``g.comp(q) / 2`` for a pair), never by lane.
+
+    * the STAGED form (any ``length(prior) <= 16``; it pays off on rows of 3 .. 8 parameters, which sweep in two launches)::
+
+        #define ABZ_USER_ROUNDS 8      // the simulation in this many steps
+        #define ABZ_USER_STATE 3       // doubles carried between steps (<= 8, zero before round 0)
+        __device__ double abz_user_round(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+                                         abz_user_rng& rng, int round, double* state);
+
+      returning after every step a LOWER BOUND of the final distance that never decreases (the last round returns the distance):
+      a proposal whose bound has passed ϵ is rejected for certain and leaves the simulation early, as the built-in
+      Lotka–Volterra simulator's proposals do; results are bit for bit those of running every round (csrc/abz_user_rounds.h).
+
     ``theta`` arrives ``push_p``-cast; ``data`` / ``sim_p`` are the arrays given here (``varexternal``'s role);
     ``rng.uniform()``, ``rng.normal()``, ``rng.normal_pair(z0, z1)``, ``rng.bits()`` draw from the particle's
-    counter-based stream.  Compiled with hiprtc when the engine is created (length(prior) <= 16).
+    counter-based stream.
 
-    Blobs: with ``n_blob`` > 0 the source must also define::
+    Blobs (``length(prior) <= 16``): with ``n_blob`` > 0 the source must also define::
 
         __device__ void abz_user_blob(const double* theta, int d, const double* data, int n_data,
                                       const double* sim_p, abz_user_rng& rng, double* blob, int n_blob);
@@ -228,8 +251,9 @@ class UserSimulator(DeviceSimulator):
     ndim = None
 
     def __init__(self, source: str, params: Sequence[float] = (), data: Sequence[float] = (), n_blob: int = 0):
-        if "abz_user_dist" not in source:
-            raise ValueError("the source must define abz_user_dist")
+        if "abz_user_dist" not in source and "abz_user_round" not in source:
+            raise ValueError("the source must define abz_user_dist (rows of up to 16 parameters), abz_user_dist_lanes (17 .. 64) or "
+                             "abz_user_round (the staged form)")
         if not 0 <= int(n_blob) <= 64:
             raise ValueError("n_blob must be in 0..64")
         if n_blob and "abz_user_blob" not in source:

@@ -157,11 +157,11 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
 
     spec = ModelSpec(prior, dist, ABCk, seed=rng)
     eng = _make_engine(spec, nparticles, engine, process_group)
-    if verbose:
-        log.info("Running abcdesmc with engine %s: ϵ_target=%s nparticles=%d α=%s δess=%s nsims_max=%d Kmcmc=%d "
-                 "Kmcmc_min=%s ABCk=%s facc_stop=%s facc_min=%s facc_tune=%s seed=%d", type(eng).__name__,
-                 ϵ_target, nparticles, α, δess, nsims_max, Kmcmc, Kmcmc_min, ABCk.__name__, facc_stop, facc_min,
-                 facc_tune, spec.seed)
+    if verbose:                        # smc:238-239 (the executor of :237 has no counterpart: the engine named here runs the population)
+        log.info("Running abcdesmc! with executor %s (%d rank(s))", type(getattr(eng, "ops", eng)).__name__, getattr(eng, "world", 1))
+        log.info("Running abcdesmc! with ϵ_target=%s nparticles=%d α=%s δess=%s nsims_max=%d Kmcmc=%d Kmcmc_min=%s ABCk=%s "
+                 "facc_stop=%s facc_min=%s facc_tune=%s rng=%s parallel=%s verboseout=%s", ϵ_target, nparticles, α, δess, nsims_max,
+                 Kmcmc, Kmcmc_min, ABCk.__name__, facc_stop, facc_min, facc_tune, spec.seed, parallel, verboseout)
 
     ess_min = nparticles * δess        # smc:259
     γσ = 1e-5                          # smc:281
@@ -243,8 +243,9 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
             faccs.append(facc)
             γ0s.append(γ0)
             Kmcmcs.append(Ki)
-        if verbose:                    # smc:372
-            log.info("Finished run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
+        if verbose:                    # smc:372 -- range_ϵ = extrema(Δs) of THIS generation: one more small reduction, made for the log line only
+            log.info("Finished run: iteration=%d nsim=%d ϵ=%s range_ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, eng.extrema(), ess,
+                     facc, logZ)
         if n_alive < 3:                # smc:375
             warnings.warn("No alive particles")
             break
@@ -255,7 +256,7 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
         ranges_ϵ.append(eng.extrema())     # smc:364 for the last generation
 
     if verbose:                        # smc:379
-        log.info("Final run: iteration=%d nsim=%d ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, ess, facc, logZ)
+        log.info("Final run: iteration=%d nsim=%d ϵ=%s range_ϵ=%s ess=%s facc=%s logZ=%s", iters, nsims, ϵ, eng.extrema(), ess, facc, logZ)
 
     res = eng.result()                 # P is push_p-cast, smc:382
     out = Result(P=res["P"], Wns=res["Wns"], C=res["C"], ϵ=ϵ, logZ=logZ, blobs=res.get("blobs"))

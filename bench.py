@@ -43,6 +43,7 @@ FP64_VALU_PEAK_ORIGIN = ("nominal: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flo
                          "fp32 VECTOR rate MI355X_MICROARCH.md lists (the guide gives no fp64 vector figure; its 78.6 'FP64 matrix' "
                          "entry is the same number); tools/valu_rate.hip measures 5.4 instead of 4 cycles per v_fma_f64 wave-instruction "
                          "under dense fp64, so the sustained rate of the part is ~0.74 of this peak (profiles/r02_valu_rate.jsonl)")
+HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: measured float4 copy rate (79 % of spec); random 2,304-B rows gathered once: 5.7-5.8 TB/s
 PROFILE_TAG = "r05"
 
 
@@ -358,14 +359,42 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         "moved_bytes_per_update": b_moved, "moved_bytes_frac": to_gbs(b_moved) / HBM_PEAK_GBS,
         "acceptance_rate": acc_rate,
     }
+    if ld <= 2:
+        # Rows of one or two doubles: every random donor / base-particle read is an 8- or 16-byte access that leaves the L2 as ONE
+        # 128-byte line request (calibrated on a known stream, profiles/r05_pmc_gather_calibration.json) -- the sweep is bound by the
+        # rate at which the fabric fills lines (Infinity Cache + HBM behind it), not by the 41 algorithmic bytes of SURVEY.md 8d.
+        # achieved = line-fill bytes per update x kernel updates/s, with the line-fill bytes MEASURED where a counter file of this
+        # configuration is committed (TCC requests of the timed sweeps; the tables are partly L2-resident, so fewer than one fill
+        # per gather reaches the fabric) and the model 128 B x gathers + streamed bytes otherwise.
+        gathers = 3 if kind == "mc" else 2
+        streamed = 8 * ld + 17 + (12 if kind == "mc" else 0)
+        model = 128 * gathers + streamed
+        trn = profile_json(f"{PROFILE_TAG}_hbm_traffic_{args_config}.json")
+        fills = trn["total_bytes_per_update"] if trn and trn.get("ld") == ld else model
+        out["hbm_read_frac_algorithmic_bytes"] = out["frac"]
+        out["bound"] = "fabric-line-fills"
+        out["achieved"] = fills * rate / 1e9
+        out["frac"] = out["achieved"] / HBM_PEAK_GBS
+        out["frac_of_achievable"] = out["achieved"] / HBM_ACHIEVABLE_GBS
+        out["line_fill_bytes_per_update"] = fills
+        out["line_fill_bytes_per_update_model"] = model
+        out["line_fill_bytes_are"] = ("measured: fabric requests of the timed sweeps' dispatches (rocprofv3 --pmc, committed file below) per update"
+                                      if fills is not model else f"model: {gathers} random gathers x 128 B + {streamed} B streamed")
+        out["frac_is"] = (f"FABRIC LINE-FILL fraction: a random {8 * ld}-byte row read is one 128-byte line request (model: {gathers} gathers x 128 B + "
+                          f"{streamed} B streamed = {model} B per update); achieved = line-fill bytes per update x kernel updates/s against the 8 TB/s "
+                          "spec (the guide measures 7.4-8.6 TB/s for random rows of an Infinity-Cache-resident table, 6.0-6.3 TB/s from HBM); "
+                          "hbm_read_frac_algorithmic_bytes is SURVEY.md 8d's (24 ld + 17)-byte figure, the wrong ceiling for this access pattern")
     kc = profile_json(f"{PROFILE_TAG}_{args_config}_kernel_avg_check.json")
     if kc and kc.get("trace_avg_ms_timed_sweeps") and kc.get("updates_per_launch_timed_sweeps"):
         r_tr = kc["updates_per_launch_timed_sweeps"] / (kc["trace_avg_ms_timed_sweeps"] * 1e-3)
-        out["frac_trace"] = b_read * r_tr / 1e9 / HBM_PEAK_GBS
+        out["frac_trace"] = (out["line_fill_bytes_per_update"] if ld <= 2 else b_read) * r_tr / 1e9 / HBM_PEAK_GBS
         out["frac_trace_source"] = (f"NOT measured in this run: rocprofv3 --kernel-trace of this command on another box, average over EVERY sweep "
                                     f"that ran in the timed steps ({kc.get('timed_sweeps')} launches, {kc['trace_avg_ms_timed_sweeps']:.4f} ms, "
                                     f"{kc['updates_per_launch_timed_sweeps']:.0f} updates each; warm-up launches excluded), "
                                     f"profiles/{PROFILE_TAG}_{args_config}_kernel_avg_check.json")
+    # flat scalars next to frac: the same achieved bytes against the rate the part has been MEASURED to stream at
+    out["achievable_peak_gbs"] = HBM_ACHIEVABLE_GBS
+    out["frac_of_achievable"] = ach / HBM_ACHIEVABLE_GBS
     tr = profile_json(f"{PROFILE_TAG}_hbm_traffic_{args_config}.json")
     if tr and tr.get("ld") == ld:
         out["traffic"] = tr["total_bytes_per_update"] * upl
@@ -383,6 +412,12 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
         live = pattern_ceiling_live(int(round(upl)), int(round(100 * acc_rate)), positions) if PATTERN_LIVE else None
         pc = profile_json(f"{PROFILE_TAG}_pattern_ceiling.json")
         if live:
+            # flat (a nested object does not survive every consumer of this line): the arithmetic-free access pattern of the sweep,
+            # measured in this process on this GPU right after the timed window, and the kernel's rate over it
+            out["pattern_ceiling_read_frac"] = live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS
+            out["kernel_over_pattern"] = rate / live["particles_per_s"]
+            if live.get("best_single_launches"):
+                out["kernel_over_pattern_single_launches"] = rate / live["best_single_launches"]
             out["pattern_ceiling"] = {"updates_per_s": live["particles_per_s"], "read_frac": live["particles_per_s"] * b_read / 1e9 / HBM_PEAK_GBS,
                                       "kernel_over_ceiling": rate / live["particles_per_s"],
                                       "updates_per_s_single_launches": live.get("best_single_launches"),
@@ -404,12 +439,12 @@ def roofline(cfg, kind, ld, kern_ms, launches, units, acc_rate, positions=1 << 2
 PATTERN_LIVE = True
 TIMING_MODE = 3
 LAUNCHES_ARE = {
-    3: ("abcdesmc: ONE pair of HIP events on the library's stream around ALL the sweep launches of every 2nd timed generation "
-        "(abcdez_ctx_set_timing mode 3, stride 2): avg_launch_ms = elapsed / sweeps that ran.  The one-block group_check launches "
+    3: ("abcdesmc: ONE pair of HIP events on the library's stream around ALL the sweep launches of EVERY timed generation "
+        "(abcdez_ctx_set_timing mode 3, stride 1: every sweep of the timed steps is inside a pair): avg_launch_ms = elapsed / sweeps that ran.  The one-block group_check launches "
         "between the sweeps (~5 us each) are INSIDE the pair, so this is an upper bound of the sweep kernel's duration; the sweeps "
         "run back to back as they do un-instrumented (frac_trace: the rocprofv3 average of every sweep of the timed steps)"),
-    2: ("abcdesmc: ONE sweep of every 2nd timed generation between its own pair of HIP events on the library's stream -- the "
-        "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 2; a pair costs ~9 us of queue "
+    2: ("abcdesmc: ONE sweep of every timed generation between its own pair of HIP events on the library's stream -- the "
+        "generation's 1st, 2nd, 3rd sweep in rotation (abcdez_ctx_set_timing mode 2, stride 1; a pair costs ~9 us of queue "
         "time).  A bracketed launch starts on a drained queue, so this average is a few per cent ABOVE the un-instrumented "
         "kernel: frac_trace"),
 }
@@ -521,7 +556,7 @@ def run_config(args):
     # on a population the partition has just moved and is a few per cent slower than its siblings) / the sweep of every 4th
     # abcdemc generation: an event pair costs ~9 us of queue time (tools/launch_floor.hip) -- 0.6 % of an SMC generation, 7 % of
     # an abcdemc generation
-    tstride = 2 if cfg["kind"] == "smc" else 10
+    tstride = 1 if cfg["kind"] == "smc" else 10
     eng.ops.set_timing((args.timing_mode if cfg["kind"] == "smc" and not eng.sharded_packed else 2) + 256 * tstride)
     u0, s0, a0, r0 = gen.updates, gen.sweeps, getattr(gen, "naccs", 0), getattr(gen, "resamples", 0)
     n0 = getattr(gen, "nsims", 0)
@@ -645,6 +680,11 @@ def run_config(args):
                                  "rank pass (while max Ds > eps_target and fewer than 1 / 16 of the particles lie at or below it), one sweep with nsim / completion / extrema folded in (mc:140-161)",
                 "parallelism": (f"particle-shard x{world}, replicated packed population: per-sweep accept-flag all-gather + replay, "
                                 "per-generation distance all-gather") if world > 1 else "single GPU",
+                # who moves the bytes between the ranks: always the library's own sharded entry points (abcdez_smc_sweeps_sharded,
+                # abcdez_mc_generation_sharded_async) -- over RCCL / xGMI, or over its host transport when the ranks share GPUs
+                "collectives": {0: "none", 1: "libabcdez_hip.so over RCCL (xGMI), on the library's stream",
+                                2: "libabcdez_hip.so over its host transport (abcdez_comm_init_host; gloo all-gather underneath): a "
+                                   "rehearsal on fewer GPUs than ranks, not a scaling measurement"}[eng.ops.comm_kind()],
             },
             "roofline": roofline(cfg, cfg["kind"], ld, kern_ms, launches, units, acc_rate, positions=N,
                                  sim_rate=((gen.nsims - n0) / max(updates, 1)) if cfg["kind"] == "smc" else 1.0),
@@ -689,7 +729,8 @@ def run_config(args):
     return None, pg
 
 
-OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_trace", "peak_origin", "avg_launch_ms", "launches", "updates_per_launch",
+OTHER_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_is", "frac_of_achievable", "achievable_peak_gbs", "hbm_read_frac_algorithmic_bytes",
+              "line_fill_bytes_per_update", "line_fill_bytes_per_update_model", "line_fill_bytes_are", "frac_trace", "peak_origin", "avg_launch_ms", "launches", "updates_per_launch",
               "kernel_updates_per_s", "traffic", "traffic_over_moved_bytes", "traffic_source", "acceptance_rate", "flops_per_update",
               "rk4_steps_per_s", "bytes_read_per_update")
 

@@ -48,16 +48,31 @@ ABCDEZ_API const char* abcdez_last_error(void);
  * (src/abcdez_smc.jl:106-109, src/abcdez_mc.jl:5-6, src/abcdez_init.jl:2).
  * `model->data` is a HOST pointer here; it is copied to the device.             */
 ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx** out);
-/* The same with a user-supplied simulator (model->sim_id == ABZ_SIM_USER, d <= 16): `user_source` is HIP
- * source text defining
+/* The same with a user-supplied simulator (model->sim_id == ABZ_SIM_USER): `user_source` is HIP source text defining ONE of
+ *   d <= 16 -- the whole row in one thread:
  *     __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
  *                                     const double* sim_p, abz_user_rng& rng);
+ *   17 <= d <= 64 -- the row spread over L = ld / 8 lanes of a wavefront (as the built-in d-dimensional Normal simulator), every lane
+ *   of the group calling
+ *     __device__ double abz_user_dist_lanes(const double* theta, const abz_user_lanes& g, int d, const double* data, int n_data,
+ *                                           const double* sim_p, abz_user_rng& rng);
+ *   with ITS ABZ_USER_C = 8 components (g.comp(q) = index in the row; g.sum(v) = the canonical tree sum over the group; draws addressed
+ *   by component: rng.normal_pair_at(k, z0, z1), rng.uniform_at(k)) and returning the distance on every lane;
+ *   the STAGED form (d <= 16) -- #define ABZ_USER_ROUNDS / ABZ_USER_STATE and
+ *     __device__ double abz_user_round(const double* theta, int d, const double* data, int n_data, const double* sim_p,
+ *                                      abz_user_rng& rng, int round, double* state);
+ *   returning after every step a lower bound of the final distance that never decreases: proposals whose bound has passed eps leave
+ *   the simulation early (csrc/abz_user_rounds.h), results bit for bit those of running every round.
  * (theta push_p-cast; rng.uniform() / rng.normal() / rng.normal_pair(z0, z1) / rng.bits() hand out the
  * particle's Philox stream).  It is compiled with hiprtc for the device's architecture together with the
  * library's own kernel bodies; a compile error comes back as a negative status with the compiler log in
  * abcdez_last_error().  This is the device counterpart of the reference's dist!(theta, ve) closure
- * (src/abcdez_smc.jl:137, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17).                               */
+ * (src/abcdez_smc.jl:137,166-173, src/abcdez_mc.jl:45, src/abcdez_init.jl:10,17), for any length(prior) the library takes.  */
 ABCDEZ_API int abcdez_ctx_create_user(const abz_model* model, const char* user_source, int device, abcdez_ctx** out);
+/* Test hook, no device needed: the translation unit abcdez_ctx_create_user would compile for this model and source, and the -D options
+ * that go with it (one per line) -- so that a host without a GPU can check a simulator's source with hipcc.  Returns the text's length. */
+ABCDEZ_API int abcdez_user_translation_unit(const abz_model* model, const char* user_source, char* tu_out, size_t tu_cap,
+                                            char* opts_out, size_t opts_cap);
 ABCDEZ_API int abcdez_ctx_destroy(abcdez_ctx* ctx);
 /* Optional: size the context's internal workspace for populations of up to N particles now, so that no later call
  * (the first resampling, the first quantile) has to grow it -- growing synchronises the stream and reallocates. */

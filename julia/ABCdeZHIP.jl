@@ -19,7 +19,11 @@
 # stream, csrc/abz_comm.hip).  The host only carries the 128-byte rendezvous id from rank 0 to the others, e.g.
 #     id = rank == 0 ? comm_unique_id() : Vector{UInt8}(undef, 128);  MPI.Bcast!(id, 0, MPI.COMM_WORLD)
 #     r = abcdesmc!(prior, sim, ϵ, nothing; nparticles = N, rng = 1, comm = (id = id, rank = rank, world = world))
-# and every rank returns the same result, bit for bit what one GPU returns (random numbers are keyed by position).  Per sweep one
+# A host without RCCL (or with ranks that share GPUs) hands the library its own transport instead -- the library stages every
+# piece through page-locked host memory and calls back (abcdez_comm_init_host; no rendezvous id):
+#     ag!(buf::Vector{UInt8}, piece::Int) = MPI.Allgather!(MPI.IN_PLACE, MPI.UBuffer(buf, piece), MPI.COMM_WORLD)   # in place, rank order
+#     r = abcdesmc!(prior, sim, ϵ, nothing; nparticles = N, rng = 1, comm = (rank = rank, world = world, allgather! = ag!))
+# Either way every rank returns the same result, bit for bit what one GPU returns (random numbers are keyed by position).  Per sweep one
 # byte per alive position crosses the fabric, per generation the distances; abcdez_smc_sweeps_sharded is the whole sharded
 # generation in one ccall (abcdez_amd/engine.py drives the same entry points and is the tested reference for their order).
 module ABCdeZHIP
@@ -47,7 +51,7 @@ struct AbzModel
     mv::Ptr{Float64}                      # C_NULL, or [μ | L⁻¹ | L] of an MvNormal prior (include/abcdez_spec.h)
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
-const MIN_VERSION = 500        # abcdez_comm_*, abcdez_smc_sweeps_sharded (include/abcdez_hip.h)
+const MIN_VERSION = 600        # abcdez_comm_init_host, lazily opened RCCL (include/abcdez_hip.h)
 function check_abi()
     # an older library would link -- C has no signature check -- and misread arguments added since
     v = ccall((:abcdez_version, LIB), Cint, ())
@@ -83,8 +87,9 @@ LotkaVolterraRK4(obs; x0=1.0, y0=0.5, dt=0.01, steps_per_obs=100, noise=0.1, blo
     LotkaVolterraRK4(collect(Float64, obs), x0, y0, dt, steps_per_obs, noise, blobs)
 struct Socks <: DeviceSimulator; pairs::Float64; odd::Float64; n_picked::Int; blobs::Bool; end       # test/runtests.jl:427-437
 Socks(pairs, odd; n_picked=11, blobs=false) = Socks(pairs, odd, n_picked, blobs)
-# a device function given as HIP source text (abcdez_ctx_create_user): must define abz_user_dist, and abz_user_blob
-# when n_blob > 0 (INTEGRATION.md section 1)
+# a device function given as HIP source text (abcdez_ctx_create_user): defines abz_user_dist (length(prior) <= 16), abz_user_dist_lanes
+# (17 .. 64: the row spread over the lanes of a wavefront) or the staged abz_user_round (ABZ_USER_ROUNDS: proposals whose running lower
+# bound of the distance has passed ϵ leave the simulation early), and abz_user_blob when n_blob > 0 (INTEGRATION.md section 1)
 struct UserSimulator <: DeviceSimulator; source::String; params::Vector{Float64}; data::Vector{Float64}; n_blob::Int; end
 UserSimulator(source; params=Float64[], data=Float64[], n_blob=0) = UserSimulator(source, collect(Float64, params), collect(Float64, data), n_blob)
 
@@ -192,6 +197,24 @@ mutable struct Engine
     wns::Ptr{Cvoid}; alive::Ptr{Cvoid}; inds::Ptr{Cvoid}; order::Ptr{Cvoid}; sorted::Ptr{Cvoid}; cnt::Ptr{Cvoid}
     cur::Int; bc::Int; sweep::UInt32; draw::UInt32; n_alive::Int; n_prev::Int
     rank::Int; world::Int; flags::Ptr{Cvoid}        # multi-GPU: this process's rank, the number of ranks, one flag byte per position
+    transport::Any                                  # host transport (abcdez_comm_init_host): kept alive as long as the context
+end
+
+# the host-supplied transport of a sharded run: `allgather!(buf, piece)` gathers IN PLACE over `world` pieces of `piece` bytes of
+# host memory (this rank's piece at buf[rank * piece + 1 : (rank + 1) * piece] on entry), e.g. MPI.Allgather!(MPI.IN_PLACE, ...)
+mutable struct HostTransport
+    allgather!::Function
+    world::Int
+end
+function host_allgather_cb(user::Ptr{Cvoid}, buf::Ptr{UInt8}, piece::Int64)::Cint
+    t = unsafe_pointer_to_objref(user)::HostTransport
+    try
+        t.allgather!(unsafe_wrap(Array, buf, Int(piece) * t.world; own = false), Int(piece))
+        return Cint(0)
+    catch err                                       # nothing may unwind through the C frames: the library reports status -4
+        @error "ABCdeZHIP host transport: all-gather failed" err
+        return Cint(1)
+    end
 end
 
 devalloc(bytes) = (p = Ref{Ptr{Cvoid}}(); check(ccall((:abcdez_dev_alloc, LIB), Cint, (Csize_t, Ptr{Ptr{Cvoid}}), bytes, p)); p[])
@@ -237,14 +260,21 @@ function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int; comm=n
     nw = cld(N, 32)
     rank, world = comm === nothing ? (0, 1) : (Int(comm.rank), Int(comm.world))
     N % world == 0 || error("nparticles must be divisible by the number of ranks")
-    if comm !== nothing                              # every rank: join the communicator on this context's device
+    transport = nothing
+    if comm !== nothing && hasproperty(comm, :allgather!)     # the host's own transport (MPI ...): the library stages through pinned memory
+        transport = HostTransport(getproperty(comm, :allgather!), world)
+        cb = @cfunction(host_allgather_cb, Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64))
+        # no all-reduce callback: the library all-gathers the words and reduces them in rank order (the same bits on every rank)
+        check(ccall((:abcdez_comm_init_host, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    ctx[], rank, world, cb, C_NULL, pointer_from_objref(transport)))
+    elseif comm !== nothing                          # every rank: join the RCCL communicator on this context's device
         check(ccall((:abcdez_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint, Cint), ctx[], comm.id, length(comm.id), rank, world))
     end
     Np = N + 64 * world                              # sharded runs exchange chunks of the per-position arrays: room for `world` of them
     e = Engine(ctx[], N, ld, d, nb, [devalloc(8N * ld) for _ in 1:2], [devalloc(8N) for _ in 1:2], [devalloc(8Np) for _ in 1:2],
                [devalloc(4nw) for _ in 1:2], nb > 0 ? [devalloc(8N) for _ in 1:2] : Ptr{Cvoid}[],
                devalloc(8N), devalloc(N), devalloc(4N), devalloc(4N), devalloc(8N), devalloc(4N), 1, 1, 0, 0, N, N,
-               rank, world, world > 1 ? devalloc(Np) : C_NULL)
+               rank, world, world > 1 ? devalloc(Np) : C_NULL, transport)
     z = zeros(UInt32, nw)                       # every position's current row is slot 1
     h2d(e, e.bits[1], z, 4nw); h2d(e, e.bits[2], z, 4nw)
     finalizer(free!, e)
@@ -417,6 +447,9 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
     (comm === nothing || (Kmcmc ≤ 16 && rng isa Integer)) || error("comm: a sharded run needs Kmcmc <= 16 and the same integer rng on every rank")
     e = Engine(prior, dist!, ABCk, philox_key(rng), nparticles; comm = comm)
     try
+        # smc:238-239 (the executor of :237 has no counterpart: the population always runs in parallel on the device)
+        verbose && (@info("Running abcdesmc! with executor (libabcdez_hip.so on $(e.world) GPU rank(s)) ", typeof(dist!)))
+        verbose && (@info "Running abcdesmc! with" ϵ_target nparticles α δess nsims_max Kmcmc Kmcmc_min ABCk facc_stop facc_min facc_tune rng parallel verboseout)
         init!(e)                                                                            # smc:242-252
         reset_weights!(e)                                                                   # smc:266-270
         ϵ = Inf; ϵ_k = Inf; logZ = 0.0; ess = 0.0; nsims = 0; facc = 1.0; Ki = Kmcmc        # smc:255-276
@@ -448,12 +481,14 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
             end
             facc = naccs / (n_alive * Ki); ϵ_k = ϵ                                          # smc:357-360
             push!(ϵs, ϵ); push!(logZs, logZ); push!(esss, ess); push!(faccs, facc); push!(γ0s, γ0); push!(Kmcmcs, Ki)
-            verbose && (@info "Finished run:" iteration = iters nsim = nsims ϵ = ϵ ess = ess facc = facc logZ = logZ)
+            # smc:372 -- range_ϵ = extrema(Δs) of THIS generation is one more small reduction, made only for the log line
+            verbose && (@info "Finished run:" iteration = iters nsim = nsims ϵ = ϵ range_ϵ = extrema_dev(e) ess = ess facc = facc logZ = logZ)
             n_alive ≥ 3 || (@warn("No alive particles"); break)                             # smc:375
             (ϵ ≤ ϵ_target || nsims ≥ nsims_max || facc < facc_stop) && break                # smc:376
         end
         check(ccall((:abcdez_smc_select_discard, LIB), Cint, (Ptr{Cvoid},), e.ctx))        # the run ends: nothing is left armed
         push!(ranges_ϵ, extrema_dev(e))                                                     # smc:364 of the last generation
+        verbose && (@info "Final run:" iteration = iters nsim = nsims ϵ = ϵ range_ϵ = ranges_ϵ[end] ess = ess facc = facc logZ = logZ)   # smc:379
         P, Wns, Δs, blobs = download(e; packed=true)                                        # smc:382
         return verboseout ? (P = P, Wns = Wns, C = Δs, ϵ = ϵ, logZ = logZ, blobs = blobs, ϵs = ϵs, ranges_ϵ = ranges_ϵ,
                              logZs = logZs, esss = esss, faccs = faccs, γ0s = γ0s, Kmcmcs = Kmcmcs) :
@@ -526,6 +561,8 @@ function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
     1 ≤ generations || error("generations must be at least 1")
     e = Engine(prior, dist!, ABCdeZ.IndicatorStrict0toϵ, philox_key(rng), nparticles; comm = comm)
     try
+        verbose && (@info("Running abcdemc! with executor (libabcdez_hip.so on $(e.world) GPU rank(s)) ", typeof(dist!)))   # mc:113
+        verbose && (@info "Running abcdemc! with" ϵ_target nparticles generations α rng parallel)                           # mc:114
         init!(e)                                                                             # mc:117-125
         nsims = 0; γ0 = 2.38 / sqrt(2 * length(prior)); γσ = 1e-5; iters = 0                 # mc:128-131
         complete = 1 - count_gt(e, ϵ_target) / nparticles                                    # mc:133
@@ -548,6 +585,7 @@ function abcdemc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
         end
         while !isempty(tickets); collect!(); end
         conv = ϵ_h <= ϵ_target                                                               # mc:163
+        verbose && (@info "End:" completion = complete converged = conv nsim = nsims range_ϵ = (ϵ_l, ϵ_h))   # mc:164
         P, _, Δs, blobs = download(e; packed=false)                                          # mc:166
         return (P = P, C = Δs, reached_ϵ = conv, blobs = blobs)                              # mc:171
     finally

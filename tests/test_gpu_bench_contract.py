@@ -29,7 +29,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields(cfg, particles, ste
     roof, cpu = d["roofline"], d["cpu_baseline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
-    assert roof["bound"] in ("hbm", "valu") and 0 < roof["frac"] < 1.5 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["bound"] == {"smc32": "hbm", "lv": "valu", "mc1d": "fabric-line-fills", "evidence1d": "fabric-line-fills"}[cfg]
+    assert 0 < roof["frac"] < 1.5 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    if cfg == "smc32":       # the ceiling claim as flat scalars of the driver's line
+        for k in ("pattern_ceiling_read_frac", "kernel_over_pattern", "achievable_peak_gbs", "frac_of_achievable"):
+            assert isinstance(roof[k], float) and roof[k] > 0, k
+        assert roof["achievable_peak_gbs"] == 6290.0 and roof["timed_every_nth_step"] == 1
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["value"] > 0
@@ -56,7 +61,7 @@ def test_bench_two_ranks_print_one_line(cfg, particles):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
-    assert "x2" in d["config"]["parallelism"]
+    assert "x2" in d["config"]["parallelism"] and "host transport" in d["config"]["collectives"]
     if cfg == "smc32":
         assert d["config"]["particles_total"] == 2 * particles
         assert set(d["sharded_phases_ms"]) >= {"own_sweep", "flag_allgather", "replay"}
@@ -120,4 +125,4 @@ def test_bench_sharded_path_in_a_one_rank_rccl_group():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "sharded_phases_ms" in d
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "sharded_phases_ms" in d and "RCCL" in d["config"]["collectives"]

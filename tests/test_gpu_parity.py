@@ -719,6 +719,19 @@ def test_c_abi_error_paths():
     e16.init_population(); e16.reset_weights()
     with pytest.raises(_lib.AbcdezError, match="at most 8 lanes"):
         e16.smc_swarm(9.0, 0.3, 1e-5)
+    # 32-bit thread indices: 2^30 particles at 8 lanes per particle are 2^33 threads (the API's N <= 2^31 - 1 alone would let them
+    # through and gid = tile * BLOCK + threadIdx.x would wrap).  The check precedes every launch: no allocation of that size needed,
+    # the pointers are never dereferenced.
+    e8 = HipOps(spec32, lanes=8)
+    big, p = 1 << 30, s0.data_ptr()
+    for rc in (lib.abcdez_smc_swarm_packed(e8.ctx, p, p + 8, big, 0, big, p, p + 8, p, p, None, 5.0, 0.5, 1e-5, 0, None, None),
+               lib.abcdez_smc_sweeps_packed(e8.ctx, p, p + 8, big, p, p + 8, p, p, 5.0, 0.5, 1e-5, 0, 3, 1.0, nk, nk, C.byref(dn)),
+               lib.abcdez_init(e8.ctx, p, p, p, 0, big), lib.abcdez_smc_group_begin(e8.ctx, big, 1.0),
+               lib.abcdez_packed_gather(e8.ctx, p, big, p, p + 8, p),
+               lib.abcdez_smc_partition(e8.ctx, p, big, big, big, p, p + 8, p, p + 8, p, p, p)):
+        assert rc == -1 and b"2^32 threads" in lib.abcdez_last_error(), lib.abcdez_last_error()
+    assert lib.abcdez_ctx_set_lanes(e8.ctx, 2) == 0          # 2^31 threads: this check passes (the arrays are checked by their owner)
+    assert lib.abcdez_smc_group_begin(e8.ctx, big, 1.0) == 0 and lib.abcdez_smc_group_abort(e8.ctx) == 0
 
 
 # ---------------------------------------------------------------- blobs: stamps + rebuild, product vs C restatement

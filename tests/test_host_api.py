@@ -184,7 +184,9 @@ def _c_class(ctype):
            "int64_t*": {"Ptr{Int64}", "Ref{Int64}"}, "int32_t*": {"Ptr{Int32}", "Ref{Int32}", "Ref{Cint}", "Ptr{Cint}"},
            "abz_model*": {"Ref{AbzModel}", "Ptr{AbzModel}"}, "char*": {"Cstring"}}
     val = {"int64_t": {"Int64"}, "double": {"Float64"}, "uint32_t": {"UInt32"}, "int32_t": {"Int32", "Cint"},
-           "int": {"Cint", "Int32"}, "size_t": {"Csize_t"}}
+           "int": {"Cint", "Int32"}, "size_t": {"Csize_t"},
+           # function pointers of the host transport (typedefs of the header): a @cfunction pointer or C_NULL
+           "abcdez_host_allgather_fn": {"Ptr{Cvoid}"}, "abcdez_host_allreduce_fn": {"Ptr{Cvoid}"}}
     return (ptr if t.endswith("*") else val)[t]
 
 
@@ -205,7 +207,11 @@ def test_julia_shim_binds_only_exported_symbols_with_the_declared_types():
         assert len(types) == len(params), (name, types, params)
         for k, (jt, cp) in enumerate(zip(types, params)):
             assert jt in _c_class(cp), f"{name}: argument {k + 1} is `{cp}` in the header, bound as {jt}"
-    for need in ("abcdez_smc_prologue_packed", "abcdez_smc_swarm_packed", "abcdez_smc_resample_gather_packed",
+    # the callback the shim hands to abcdez_comm_init_host has the C signature of abcdez_host_allgather_fn
+    assert re.search(r"typedef int \(\*abcdez_host_allgather_fn\)\(void\* user, void\* buf, int64_t piece_bytes\);", hdr)
+    assert "@cfunction(host_allgather_cb, Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64))" in jl
+    for need in ("abcdez_comm_init_host", "abcdez_comm_init", "abcdez_smc_sweeps_sharded", "abcdez_mc_generation_sharded_async",
+                 "abcdez_smc_prologue_packed", "abcdez_smc_swarm_packed", "abcdez_smc_resample_gather_packed",
                  "abcdez_packed_gather", "abcdez_ctx_create_user", "abcdez_blob_eval", "abcdez_dev_free", "abcdez_rng_rounds"):
         assert any(c[0] == need for c in calls), need
 
@@ -226,6 +232,43 @@ def test_julia_shim_keeps_the_reference_signatures():
     for kw in ("nparticles::Int=50", "generations::Int=20", "verbose=true"):
         assert kw in mc, kw
     assert "philox_key(rng::AbstractRNG) = rand(rng, UInt64)" in jl and "using ABCdeZ, Distributions, LinearAlgebra, Random" in jl
+
+
+def test_verbose_lines_carry_the_reference_fields(oracle, caplog):
+    """src/abcdez_smc.jl:238-239,372,379 and src/abcdez_mc.jl:113-114,158,164: the `@info` lines of the reference -- a header with
+    every keyword, one line per generation with iteration / nsim / ϵ / range_ϵ / ess / facc / logZ, a final line; abcdemc:
+    completion / nsim / range_ϵ and the `End:` line -- in the Python drivers (logger `abcdez_amd`) and, statically, in the shim"""
+    import logging
+
+    import abcdez_amd as A
+    with caplog.at_level(logging.INFO, logger="abcdez_amd"):
+        A.abcdesmc(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.5, None, nparticles=300, verbose=True, rng=3, engine=oracle.oracle_engine)
+        A.abcdemc(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.5, None, nparticles=300, generations=6, verbose=True, rng=3,
+                  engine=oracle.oracle_engine)
+    text = [r.getMessage() for r in caplog.records]
+    head = next(t for t in text if t.startswith("Running abcdesmc! with ϵ_target"))
+    for f in ("ϵ_target", "nparticles", "α", "δess", "nsims_max", "Kmcmc", "Kmcmc_min", "ABCk", "facc_stop", "facc_min", "facc_tune", "rng",
+              "parallel", "verboseout"):
+        assert f + "=" in head, f
+    assert any(t.startswith("Running abcdesmc! with executor") for t in text)
+    gen = [t for t in text if t.startswith("Finished run: iteration=")]
+    assert gen and all(f in gen[0] for f in ("iteration=", "nsim=", "ϵ=", "range_ϵ=", "ess=", "facc=", "logZ="))
+    fin = next(t for t in text if t.startswith("Final run:"))
+    assert all(f in fin for f in ("iteration=", "nsim=", "ϵ=", "range_ϵ=", "ess=", "facc=", "logZ="))
+    mhead = next(t for t in text if t.startswith("Running abcdemc! with ϵ_target"))
+    assert all(f + "=" in mhead for f in ("ϵ_target", "nparticles", "generations", "α", "rng", "parallel"))
+    assert any(t.startswith("Running abcdemc! with executor") for t in text)
+    assert any(t.startswith("Finished run: completion=") and "nsim=" in t and "range_ϵ=" in t for t in text)
+    end = next(t for t in text if t.startswith("End:"))
+    assert all(f in end for f in ("completion=", "converged=", "nsim=", "range_ϵ="))
+    jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    for line in ('@info "Running abcdesmc! with" ϵ_target nparticles α δess nsims_max Kmcmc Kmcmc_min ABCk facc_stop facc_min facc_tune rng parallel verboseout',
+                 '@info "Finished run:" iteration = iters nsim = nsims ϵ = ϵ range_ϵ = extrema_dev(e) ess = ess facc = facc logZ = logZ',
+                 '@info "Final run:" iteration = iters nsim = nsims ϵ = ϵ range_ϵ = ranges_ϵ[end] ess = ess facc = facc logZ = logZ',
+                 '@info "Running abcdemc! with" ϵ_target nparticles generations α rng parallel',
+                 '@info "Finished run:" completion = ncomplete nsim = nsims range_ϵ = (ϵ_l, ϵ_h)',
+                 '@info "End:" completion = complete converged = conv nsim = nsims range_ϵ = (ϵ_l, ϵ_h)'):
+        assert line in jl, line
 
 
 def test_rng_argument_takes_a_key_or_a_generator():
