@@ -57,6 +57,15 @@ static unsigned jit_grid(abcdez_ctx* ctx, hipFunction_t f, uint64_t ntiles) {
  * a continuous Normal: the two-instruction log-density of the built-in kernels), blobs.  A function of the model alone -- no device is
  * touched --, so the CPU tests compile the very same text with hipcc (abcdez_user_translation_unit, tests/test_user_simulator_sources.py). */
 static int abz_jit_make_tu(int L, int C, bool plain, bool has_blob, const char* user_source, std::string& tu, std::vector<std::string>& defs) {
+  if (L > 1 && !strstr(user_source, "abz_user_dist_lanes")) {
+    abz_set_error("user simulator: rows of more than 16 parameters are spread over the lanes of a wavefront -- the source must define the "
+                  "cooperative form abz_user_dist_lanes (include/abcdez_hip.h)");
+    return -1;
+  }
+  if (L == 1 && !strstr(user_source, "abz_user_dist") && !strstr(user_source, "abz_user_round")) {
+    abz_set_error("user simulator: the source must define abz_user_dist (or the staged abz_user_round)");
+    return -1;
+  }
   tu = "#include \"abz_kernels.h\"\n#line 1 \"user_simulator\"\n";
   tu += user_source;
   /* behind the user's text, so that it sees the ABZ_USER_ROUNDS / ABZ_USER_STATE the text may define: the staged form's abz_user_dist and
