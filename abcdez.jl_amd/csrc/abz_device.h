@@ -111,6 +111,8 @@ struct ModelStage {
     y = 0.0;
     if constexpr (SIM == ABZ_SIM_MVN) {
       if ((int)threadIdx.x < LD && (int)threadIdx.x < M.d) y = M.data[threadIdx.x];
+    } else if constexpr (SIM == ABZ_SIM_USER) {       /* the first ld entries of the user's data: abz_user_lanes::y */
+      if ((int)threadIdx.x < LD && (int)threadIdx.x < M.n_data) y = M.data[threadIdx.x];
     }
   }
   __device__ inline void store(ModelLds<LD>& s) const {
@@ -295,12 +297,15 @@ __device__ double abz_user_dist(const double* theta, int d, const double* data, 
  * simulator.  Every lane of the group calls
  *     abz_user_dist_lanes(theta, g, d, data, n_data, sim_p, rng)
  * with ITS C = ABZ_USER_C components in theta[0 .. C) (push_p-cast); g.comp(q) is the index in the row of theta[q] (indices >= d are
- * padding: theta = 0), g.sum(v) adds v[0 .. C) over all L x C entries of the group in one canonical tree -- the same value on every
- * lane and for every L -- and the function returns the distance, the same value on every lane.  Draws are addressed
+ * padding: theta = 0), g.y[k] is data[k] for k < ld read from LDS instead of global memory, g.sum(v) adds v[0 .. C) over all L x C
+ * entries of the group in one canonical tree -- the same value on every lane and for every L -- and the function returns the
+ * distance, the same value on every lane.  Draws are addressed
  * (rng.normal_pair_at(k, ...), rng.uniform_at(k)): key them by component (g.comp(q) / 2 for a pair), never by lane.  ABZ_USER_L and
  * ABZ_USER_C are compile-time constants of the translation unit. */
 struct abz_user_lanes {
   int L, C, j;
+  const double* y;        /* the first ld entries of `data` (zero beyond n_data), staged in LDS by the library: y[comp(q)] is the datum that
+                           * belongs to theta[q] when the data vector is indexed like the parameters */
   __device__ inline int comp(int q) const { return C == 1 ? 0 : (q >> 1) * 2 * L + 2 * j + (q & 1); }
   __device__ inline double sum(const double* v) const;
 };
@@ -457,7 +462,7 @@ __device__ inline double sim_dist(const HotModel& M, const abz_tables* T, int j,
     if constexpr (L > 1) {       /* rows of 17 .. 64 parameters: the cooperative form, the row spread over the group's lanes */
       static_assert(!BLOB, "user simulators on lane groups carry no blobs");
       abz_user_rng rng{seed, i, epoch, purpose, 0u, T};
-      const abz_user_lanes g{L, C, j};
+      const abz_user_lanes g{L, C, j, y};
       return abz_user_dist_lanes(th, g, M.d, M.data, M.n_data, M.sim_p, rng);
     } else {
     abz_user_rng rng{seed, i, epoch, purpose, 0u, T};

@@ -14,12 +14,18 @@
 
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "abz_ctx.h"
 #include "abz_jit_sources.h"
 #include "abz_kernels.h"
+
+/* compiled code objects by (architecture, options, translation unit) */
+static std::mutex g_code_mutex;
+static std::unordered_map<std::string, std::vector<char>> g_code_cache;
 
 struct AbzUserModule {
   hipModule_t mod = nullptr;
@@ -107,14 +113,26 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   std::string tu;
   std::vector<std::string> defs;
   if (int rc = abz_jit_make_tu(L, C, ctx->prior_plain, has_blob, user_source, tu, defs)) return rc;
-  hiprtcProgram prog;
-  ABZ_RTC_CHECK(hiprtcCreateProgram(&prog, tu.c_str(), "abz_user.hip", abz_jit_n_headers, (const char**)abz_jit_header_sources,
-                                    (const char**)abz_jit_header_names));
   hipDeviceProp_t prop;
   ABZ_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
   std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
   const size_t colon = arch.find(':');                 /* "gfx950:sramecc+:xnack-" -> "gfx950" */
   if (colon != std::string::npos) arch = arch.substr(0, colon);
+  /* the same text for the same architecture and options is the same code object: a process that creates many contexts of one model
+   * (one per run, as both hosts do) compiles it once -- hiprtc takes 0.5-0.7 s per call (profiles/r06_user_lv_ab.jsonl) */
+  std::string key = arch;
+  for (const std::string& d : defs) key += " " + d;
+  key += "\n" + tu;
+  std::vector<char> code;
+  {
+    std::lock_guard<std::mutex> lock(g_code_mutex);
+    auto it = g_code_cache.find(key);
+    if (it != g_code_cache.end()) code = it->second;
+  }
+  if (code.empty()) {
+  hiprtcProgram prog;
+  ABZ_RTC_CHECK(hiprtcCreateProgram(&prog, tu.c_str(), "abz_user.hip", abz_jit_n_headers, (const char**)abz_jit_header_sources,
+                                    (const char**)abz_jit_header_names));
   std::vector<const char*> opts = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
   for (const std::string& d : defs) opts.push_back(d.c_str());
   const hiprtcResult cr = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
@@ -129,9 +147,13 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   }
   size_t cs = 0;
   ABZ_RTC_CHECK(hiprtcGetCodeSize(prog, &cs));
-  std::vector<char> code(cs);
+  code.resize(cs);
   ABZ_RTC_CHECK(hiprtcGetCode(prog, code.data()));
   hiprtcDestroyProgram(&prog);
+  std::lock_guard<std::mutex> lock(g_code_mutex);
+  if (g_code_cache.size() >= 32) g_code_cache.clear();          /* a host that keeps generating new sources: start over */
+  g_code_cache.emplace(key, code);
+  }
   AbzUserModule* um = new AbzUserModule();
   ctx->user_module = um;            /* owned by the context from here on: abz_jit_destroy releases it on any failure below */
   ABZ_HIP_CHECK(hipModuleLoadData(&um->mod, code.data()));

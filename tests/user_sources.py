@@ -17,7 +17,7 @@ __device__ double abz_user_dist_lanes(const double* th, const abz_user_lanes& g,
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       double v = 0.0;
-      if (k0 + c < d) { const double x = abz_fma(p[0], z[c], th[2 * m + c]); const double e = x - data[k0 + c]; v = e * e; }
+      if (k0 + c < d) { const double x = abz_fma(p[0], z[c], th[2 * m + c]); const double e = x - g.y[k0 + c]; v = e * e; }
       sq[2 * m + c] = v;
     }
   }
