@@ -15,7 +15,8 @@ template <int V> using IC = std::integral_constant<int, V>;
   X(ABZ_SIM_MVN, 1, 1) X(ABZ_SIM_MVN, 1, 2) X(ABZ_SIM_MVN, 1, 4) X(ABZ_SIM_MVN, 2, 2)    \
   X(ABZ_SIM_MVN, 2, 4) X(ABZ_SIM_MVN, 4, 2) X(ABZ_SIM_MVN, 4, 4) X(ABZ_SIM_MVN, 8, 2)    \
   X(ABZ_SIM_MVN, 8, 4) X(ABZ_SIM_MVN, 4, 8) X(ABZ_SIM_MVN, 16, 2) X(ABZ_SIM_MVN, 16, 4)  \
-  X(ABZ_SIM_MVN, 2, 16) X(ABZ_SIM_MVN, 1, 8) X(ABZ_SIM_MVN, 1, 16) X(ABZ_SIM_MVN, 4, 16) X(ABZ_SIM_MVN, 2, 8) X(ABZ_SIM_MVN, 8, 8)                                          \
+  X(ABZ_SIM_MVN, 2, 16) X(ABZ_SIM_MVN, 1, 8) X(ABZ_SIM_MVN, 1, 16) X(ABZ_SIM_MVN, 4, 16) X(ABZ_SIM_MVN, 2, 8) X(ABZ_SIM_MVN, 8, 8)  \
+  X(ABZ_SIM_MVN, 8, 16) X(ABZ_SIM_MVN, 8, 32)     /* rows of 128 and 256 doubles */                                      \
   X(ABZ_SIM_NORMAL1D, 1, 1) X(ABZ_SIM_DIRAC, 1, 1) X(ABZ_SIM_MIXTURE, 1, 1)              \
   X(ABZ_SIM_QUAD2D, 1, 2) X(ABZ_SIM_NORMDU, 1, 2) X(ABZ_SIM_WIENER, 1, 2)                \
   X(ABZ_SIM_LV, 1, 4) X(ABZ_SIM_SOCKS, 1, 2)
@@ -38,13 +39,14 @@ static inline bool abz_dispatch_lc(int L, int C, F&& f) {
 #define ABZ_Y(LL, CC) if (L == LL && C == CC) { f(IC<LL>{}, IC<CC>{}); return true; }
   ABZ_Y(1, 1) ABZ_Y(1, 2) ABZ_Y(1, 4) ABZ_Y(1, 8) ABZ_Y(1, 16) ABZ_Y(2, 2) ABZ_Y(2, 4) ABZ_Y(2, 8) ABZ_Y(2, 16)
   ABZ_Y(4, 2) ABZ_Y(4, 4) ABZ_Y(4, 8) ABZ_Y(4, 16) ABZ_Y(8, 2) ABZ_Y(8, 4) ABZ_Y(8, 8) ABZ_Y(16, 2) ABZ_Y(16, 4)
+  ABZ_Y(8, 16) ABZ_Y(8, 32)
 #undef ABZ_Y
   return false;
 }
 template <class F>
 static inline bool abz_dispatch_ld(int ld, F&& f) {
 #define ABZ_Z(V) if (ld == V) { f(IC<V>{}); return true; }
-  ABZ_Z(1) ABZ_Z(2) ABZ_Z(4) ABZ_Z(8) ABZ_Z(16) ABZ_Z(32) ABZ_Z(64)
+  ABZ_Z(1) ABZ_Z(2) ABZ_Z(4) ABZ_Z(8) ABZ_Z(16) ABZ_Z(32) ABZ_Z(64) ABZ_Z(128) ABZ_Z(256)
 #undef ABZ_Z
   return false;
 }

@@ -15,7 +15,7 @@ from .kernels import IndicatorStrict0toϵ, kernel_kind
 from .priors import Product, PRIOR_NEGBIN, PRIOR_NORMAL, PRIOR_PAD, Prior, prior_factors
 from .simulators import DeviceSimulator
 
-MAX_D = 64
+MAX_D = 256
 
 
 class PriorDim(C.Structure):

@@ -757,7 +757,7 @@ ABZ_HD double abz_tree_sum_small(const double* x, int p2) { /* p2 = power of two
  * What the reference passes as (prior, dist!, varexternal, rng) (smc:215, mc:102).
  * An arbitrary Julia closure cannot run on the device, so dist! is one of the
  * built-in simulators below, selected by id, with its constants in sim_p / data.   */
-#define ABZ_MAX_D 64
+#define ABZ_MAX_D 256    /* the reference has no upper limit on length(prior) (src/abcdez_smc.jl:234 is a lower bound on nparticles) */
 #define ABZ_DEAD 0xFFFFFFFFu
 
 enum {
@@ -790,8 +790,8 @@ enum {
    * socks without replacement (sequential uniform draws, Philox block t/2 word t%2 for pick t);
    * dist = |pairs picked - sim_p[0]| + |odd socks picked - sim_p[1]|                               */
   ABZ_SIM_SOCKS = 8,
-  /* user-supplied device function compiled at run time (abcdez_ctx_create_user); the whole row lives in
-   * one thread; d <= 16                                                                             */
+  /* user-supplied device function compiled at run time (abcdez_ctx_create_user): the whole row in one thread for d <= 16,
+   * spread over the lanes of a wavefront for 17 <= d <= 64 (include/abcdez_hip.h)                     */
   ABZ_SIM_USER = 9
 };
 

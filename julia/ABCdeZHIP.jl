@@ -47,7 +47,7 @@ struct AbzModel
     n_data::Int32; n_blob::Int32          # n_blob = 0: blobs off
     sim_p::NTuple{8,Float64}
     data::Ptr{Float64}
-    prior::NTuple{64,AbzPriorDim}
+    prior::NTuple{256,AbzPriorDim}
     mv::Ptr{Float64}                      # C_NULL, or [μ | L⁻¹ | L] of an MvNormal prior (include/abcdez_spec.h)
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
@@ -246,7 +246,7 @@ function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int; comm=n
     data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d); mv = mvmaps(prior, ld)
     m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), nb,
                  ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), isempty(data) ? C_NULL : pointer(data),
-                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 64),
+                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 256),
                  isempty(mv) ? C_NULL : pointer(mv))
     ctx = Ref{Ptr{Cvoid}}()
     GC.@preserve data mv begin

@@ -580,10 +580,11 @@ def test_tiny_populations_end_to_end(oracle, N):
         assert np.array_equal(m.engine.result()["theta"], cm["theta"])
 
 
-@pytest.mark.parametrize("d", [2, 3, 5, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("d", [2, 3, 5, 8, 16, 17, 40, 64, 65, 96, 128, 200, 256])
 def test_every_row_width(oracle, d):
-    """d = 1..64 maps to ld = next power of two with zero padding (PAD prior family): every lane-group shape
-    the library picks by default, mixed prior families across the components"""
+    """d = 1..256 maps to ld = next power of two with zero padding (PAD prior family): every lane-group shape
+    the library picks by default (beyond 64 parameters: 8 lanes of 16 or 32 components), mixed prior families across the
+    components.  The reference has no upper limit on length(prior): src/abcdez_smc.jl:165,234."""
     fams = [A.Normal(0.1 * k, 1.0 + 0.05 * k) if k % 3 else A.Uniform(-4.0, 4.0) for k in range(d)]
     prior = A.Factored(*fams)
     sim = A.MVNormal(tuple(0.3 + 0.01 * k for k in range(d)))
@@ -604,6 +605,30 @@ def test_every_row_width(oracle, d):
     assert (hip.state[0][:, d:] == 0).all()                 # padding components stay exactly zero
     hip.smc_resample(); orc.smc_resample()
     assert_state_equal(hip, orc, f"resample d={d}")
+
+
+@pytest.mark.parametrize("d", [128, 256])
+def test_wide_rows_end_to_end(oracle, d):
+    """rows of 128 and 256 doubles (8 lanes of 16 / 32 components): whole abcdesmc and abcdemc runs of the d-dimensional Normal
+    model, correlated prior included at d = 128, equal the oracle's bit for bit"""
+    y = tuple(1.0 + 0.002 * k for k in range(d))
+    if d == 128:
+        rng = np.random.default_rng(5)
+        Lm = np.tril(rng.normal(0, 0.05, (d, d)), -1) + np.diag(rng.uniform(0.8, 1.2, d))
+        prior = A.MvNormal(rng.normal(0, 0.2, d), Lm @ Lm.T)
+    else:
+        prior = A.Factored(*[A.Normal(0.0, 1.0 + 0.001 * k) if k % 5 else A.Uniform(-5.0, 5.0) for k in range(d)])
+    sim = A.MVNormal(y)
+    N, eps = 2048, 0.85 * math.sqrt(3.0 * d)
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=d, nsims_max=10 ** 9)
+    c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=d), N, eps, nsims_max=10 ** 9)
+    res = r.engine.result()
+    assert r.logZ == c["logZ"] and r.iters == c["iters"] and r.nsims == c["nsims"] and r.iters >= 5
+    assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"])
+    assert r.engine.ops.layout() == (d, 8, d // 8)
+    m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=d + 1)
+    cm = oracle.run_abcdemc(A.ModelSpec(prior, sim, seed=d + 1), N, eps, 12)
+    assert np.array_equal(m.engine.result()["theta"], cm["theta"]) and np.array_equal(m.engine.result()["C"], cm["C"])
 
 
 def test_run_that_ends_with_no_alive_particles(oracle):
