@@ -15,8 +15,8 @@ from .kernels import (  # noqa: F401
 )
 from .model import ModelSpec  # noqa: F401
 from .priors import (Beta, Binomial, Cauchy, Chisq, DiscreteUniform, Erlang, Exponential, Factored, Gamma, Geometric,  # noqa: F401
-                     InverseGamma, Laplace, Logistic, LogNormal, MvNormal, NegativeBinomial, Normal, Pareto, Poisson, Product,
-                     Rayleigh, TDist, TruncatedNormal, Uniform, Weibull, product_distribution, push_p, truncated)
+                     InverseGamma, Laplace, Logistic, LogNormal, MixtureModel, MvNormal, NegativeBinomial, Normal, Pareto, Poisson, Product,
+                     Rayleigh, TDist, Truncated, TruncatedNormal, Uniform, Weibull, prior_cdf, product_distribution, push_p, truncated)
 from .simulators import (  # noqa: F401
     DeviceSimulator, DiracSquare, LotkaVolterraRK4, Mixture01, MVNormal, Normal1D, NormalTimesDU, Quad2D, Socks, UserSimulator, WienerRMS,
 )

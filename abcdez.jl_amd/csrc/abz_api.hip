@@ -119,12 +119,82 @@ int abcdez_abi_layout(int32_t* out, int n) {
       (int32_t)sizeof(abz_model), (int32_t)offsetof(abz_model, d), (int32_t)offsetof(abz_model, ld),
       (int32_t)offsetof(abz_model, sim_id), (int32_t)offsetof(abz_model, abck), (int32_t)offsetof(abz_model, seed),
       (int32_t)offsetof(abz_model, n_data), (int32_t)offsetof(abz_model, n_blob), (int32_t)offsetof(abz_model, sim_p),
-      (int32_t)offsetof(abz_model, data), (int32_t)offsetof(abz_model, prior), (int32_t)offsetof(abz_model, mv)};
+      (int32_t)offsetof(abz_model, data), (int32_t)offsetof(abz_model, prior), (int32_t)offsetof(abz_model, mv),
+      (int32_t)offsetof(abz_model, ext), (int32_t)offsetof(abz_model, n_ext), (int32_t)offsetof(abz_model, reserved0)};
   const int m = (int)(sizeof(lay) / sizeof(lay[0]));
   for (int k = 0; k < m && k < n; ++k) out[k] = lay[k];
   return m;
 }
 const char* abcdez_last_error(void) { return g_err.c_str(); }
+
+/* Parameters of one prior descriptor: what the device's log-densities and samplers assume (the hosts check the same when the
+ * distribution object is made -- abcdez_amd/priors.py, julia/ABCdeZHIP.jl -- but a descriptor can also arrive through the bare C ABI).
+ * Inversion samplers start from exp(-lambda) / q^n, which must not underflow; the rejection samplers need an interval that holds at
+ * least 1 % of the parent's mass.  Returns an empty string when everything is in order. */
+static std::string prior_dim_problem(const abz_prior_dim& pd, const double* ext, int n_ext, bool nested) {
+  const double p0 = pd.p0, p1 = pd.p1;
+  auto pos = [](double v) { return v > 0.0 && v < 1.0e300; };
+  auto fin = [](double v) { return v == v && v > -1.0e300 && v < 1.0e300; };
+  switch (pd.family) {
+    case ABZ_PRIOR_PAD: return "";
+    case ABZ_PRIOR_NORMAL: return fin(p0) && pos(p1) ? "" : "Normal: need a finite mean and sigma > 0";
+    case ABZ_PRIOR_UNIFORM: return fin(p0) && fin(p1) && p0 < p1 ? "" : "Uniform: need a < b";
+    case ABZ_PRIOR_DUNIFORM: return fin(p0) && fin(p1) && p0 <= p1 && p0 == abz_rint(p0) && p1 == abz_rint(p1) ? "" : "DiscreteUniform: need integers a <= b";
+    case ABZ_PRIOR_BETA: return pos(p0) && pos(p1) ? "" : "Beta: need alpha, beta > 0";
+    case ABZ_PRIOR_NEGBIN: return pos(p0) && p1 > 0.0 && p1 <= 1.0 ? "" : "NegativeBinomial: need r > 0 and 0 < p <= 1";
+    case ABZ_PRIOR_EXPONENTIAL: return pos(p0) ? "" : "Exponential: need scale > 0";
+    case ABZ_PRIOR_GAMMA: case ABZ_PRIOR_INVGAMMA: case ABZ_PRIOR_WEIBULL: case ABZ_PRIOR_PARETO:
+      return pos(p0) && pos(p1) ? "" : "Gamma / InverseGamma / Weibull / Pareto: need shape > 0 and scale > 0";
+    case ABZ_PRIOR_LOGNORMAL: case ABZ_PRIOR_CAUCHY: case ABZ_PRIOR_LAPLACE: case ABZ_PRIOR_LOGISTIC:
+      return fin(p0) && pos(p1) ? "" : "LogNormal / Cauchy / Laplace / Logistic: need a finite location and scale > 0";
+    case ABZ_PRIOR_TDIST: return pos(p0) ? "" : "TDist: need nu > 0";
+    case ABZ_PRIOR_POISSON: return p0 > 0.0 && p0 <= 700.0 ? "" : "Poisson: need 0 < lambda <= 700 (the sampler inverts from exp(-lambda))";
+    case ABZ_PRIOR_BINOMIAL: {
+      if (!(p0 >= 1.0 && p0 == abz_rint(p0) && p0 < 4.0e15 && p1 > 0.0 && p1 < 1.0)) return "Binomial: need an integer n >= 1 and 0 < p < 1";
+      const double thin = p1 < 0.5 ? p1 : 1.0 - p1;
+      return p0 * log1p(-thin) > -700.0 ? "" : "Binomial: n log(1 - min(p, 1 - p)) must stay above -700 (the sampler inverts from q^n)";
+    }
+    case ABZ_PRIOR_TRUNCNORMAL: {
+      if (!(fin(p0) && pos(p1) && pd.c1 < pd.reserved)) return "truncated(Normal): need sigma > 0 and lo < hi";
+      const double logmass = -log(p1) - 0.91893853320467274178 - pd.c0;        /* c0 = -log sigma - log(2 pi)/2 - log mass */
+      return logmass >= log(0.01) - 1e-9 ? "" : "truncated(Normal): [lo, hi] must hold at least 1 % of the Normal's mass (rejection sampler)";
+    }
+    case ABZ_PRIOR_TRUNCATED: {
+      if (nested) return "a wrapper family inside a wrapper";
+      const double off = p0;
+      if (!ext || !(off >= 0.0 && off == abz_rint(off) && off + ABZ_EXT_TRUNC <= (double)n_ext)) return "truncated(...): record outside the ext table";
+      const double* rec = ext + (size_t)off;
+      if (!(rec[0] < rec[1])) return "truncated(...): need lo < hi";
+      if (!(rec[2] <= 1e-9 && rec[2] >= log(0.01) - 1e-9)) return "truncated(...): [lo, hi] must hold at least 1 % of the parent's mass (rejection sampler)";
+      abz_prior_dim par;
+      abz_ext_desc(rec + 3, &par);
+      if (par.family <= ABZ_PRIOR_PAD || par.family > ABZ_PRIOR_LAST) return "truncated(...): unknown parent family";
+      if ((par.discrete != 0) != (pd.discrete != 0)) return "truncated(...): the discrete flag must be the parent's";
+      return prior_dim_problem(par, ext, n_ext, true);
+    }
+    case ABZ_PRIOR_MIXTURE: {
+      if (nested) return "a wrapper family inside a wrapper";
+      const double K = p0, off = p1;
+      if (!(K >= 1.0 && K <= (double)ABZ_MAX_MIX && K == abz_rint(K))) return "MixtureModel: 1 .. 16 components";
+      if (!ext || !(off >= 0.0 && off == abz_rint(off) && off + K * ABZ_EXT_MIXC <= (double)n_ext)) return "MixtureModel: records outside the ext table";
+      const double* rec = ext + (size_t)off;
+      double prev = 0.0;
+      for (int j = 0; j < (int)K; ++j) {
+        const double* r = rec + (size_t)j * ABZ_EXT_MIXC;
+        if (!(r[0] <= 1e-12) || !(r[1] >= prev && r[1] <= 1.0 + 1e-9)) return "MixtureModel: weights must be positive and sum to 1";
+        prev = r[1];
+        abz_prior_dim c;
+        abz_ext_desc(r + 2, &c);
+        if (c.family <= ABZ_PRIOR_PAD || c.family > ABZ_PRIOR_LAST) return "MixtureModel: unknown component family";
+        if ((c.discrete != 0) != (pd.discrete != 0)) return "MixtureModel: the components must be all continuous or all discrete";
+        const std::string why = prior_dim_problem(c, ext, n_ext, true);
+        if (!why.empty()) return why;
+      }
+      return fabs(prev - 1.0) < 1e-9 ? "" : "MixtureModel: weights must sum to 1";
+    }
+    default: return "unknown prior family";
+  }
+}
 
 static int ctx_create_common(const abz_model* model, const char* user_source, int device, abcdez_ctx** out) {
   ABZ_REQUIRE(model && out, "ctx_create: null argument");
@@ -141,6 +211,13 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     ABZ_REQUIRE(fam >= ABZ_PRIOR_PAD && fam <= ABZ_PRIOR_LAST, "ctx_create: unknown prior family");
     ABZ_REQUIRE((k < model->d) == (fam != ABZ_PRIOR_PAD), "ctx_create: prior descriptor / d mismatch");
   }
+  ABZ_REQUIRE(model->n_ext >= 0 && model->n_ext <= (1 << 16) && (model->n_ext == 0) == (model->ext == nullptr),
+              "ctx_create: ext / n_ext mismatch (the records of truncated(...) / MixtureModel priors)");
+  for (int k = 0; k < model->d; ++k) {
+    const std::string why = prior_dim_problem(model->prior[k], model->ext, model->n_ext, false);
+    if (!why.empty()) { abz_set_error("ctx_create: prior factor " + std::to_string(k + 1) + ": " + why); return -1; }
+  }
+  ABZ_REQUIRE(!(model->mv && model->n_ext), "ctx_create: a correlated Normal prior has no wrapped factors");
   switch (model->sim_id) {
     case ABZ_SIM_NORMAL1D: ABZ_REQUIRE(model->d == 1 && model->n_data >= 1, "normal1d: needs d = 1 and one datum"); break;
     case ABZ_SIM_MVN: ABZ_REQUIRE(model->n_data >= model->d, "mvn: needs d data values"); break;
@@ -208,8 +285,9 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     const size_t b_model = abz_align(sizeof(abz_model), 256), b_tab = abz_align(sizeof(abz_tables), 256);
     const size_t b_data = abz_align((size_t)(model->n_data > 0 ? model->n_data : 0) * 8, 256);
     const size_t b_mv = model->mv ? abz_align(ABZ_MV_DOUBLES(model->ld) * 8, 256) : 0;
+    const size_t b_ext = model->n_ext > 0 ? abz_align((size_t)model->n_ext * 8, 256) : 0;
     char* base = nullptr;
-    ABZ_CTX_CHECK(hipMalloc((void**)&base, b_scal + b_sync + b_model + b_tab + b_data + b_mv + 256));
+    ABZ_CTX_CHECK(hipMalloc((void**)&base, b_scal + b_sync + b_model + b_tab + b_data + b_mv + b_ext + 256));
     ctx->d_block = base;
     ctx->d_scal = (unsigned long long*)base; base += b_scal;
     ctx->d_sync = (unsigned int*)base; base += b_sync;
@@ -217,7 +295,10 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     ctx->d_tables = (abz_tables*)base; base += b_tab;
     if (model->n_data > 0) { ctx->d_data = (double*)base; base += b_data; }
     if (model->mv) { ctx->d_mv = (double*)base; base += b_mv; }
+    if (model->n_ext > 0) { ctx->d_ext = (double*)base; base += b_ext; }
   }
+  if (model->n_ext > 0) ABZ_CTX_CHECK(hipMemcpy(ctx->d_ext, model->ext, (size_t)model->n_ext * 8, hipMemcpyHostToDevice));
+  ctx->h_model.ext = ctx->d_ext;
   if (model->n_data > 0) ABZ_CTX_CHECK(hipMemcpy(ctx->d_data, model->data, (size_t)model->n_data * 8, hipMemcpyHostToDevice));
   ctx->h_model.data = ctx->d_data;
   if (model->mv) {                   /* correlated Normal prior: [mu | W | L] travels to the device; no plain-Normal shortcut */
@@ -234,6 +315,7 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   }
   ctx->hot.tables = ctx->d_tables;
   ctx->hot.mv = ctx->d_mv;
+  ctx->hot.ext = ctx->d_ext;
   ctx->hot.seed = model->seed;
   ctx->hot.prior = (const abz_prior_dim*)((const char*)ctx->d_model + offsetof(abz_model, prior));
   ctx->hot.data = ctx->d_data;
@@ -251,7 +333,9 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
   ABZ_CTX_CHECK(hipHostMalloc((void**)&ctx->h_scal, (ABZ_S_N + 8) * 8, hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->h_scal, 0, (ABZ_S_N + 8) * 8);
   ABZ_CTX_CHECK(hipHostGetDevicePointer((void**)&ctx->h_scal_dev, ctx->h_scal, 0));
-  if (user_source) {
+  /* kernels compiled for this model at run time: a user-supplied simulator, or prior factors of the wrapper families (truncated(...),
+   * MixtureModel), whose log-densities the statically compiled sweeps do not carry (include/abcdez_spec.h, ABZ_PRIOR_WRAP) */
+  if (user_source || model->n_ext > 0) {
     const int rc = abz_jit_build(ctx, user_source);
     if (rc) { abcdez_ctx_destroy(ctx); return rc; }
   }
@@ -364,8 +448,9 @@ int abcdez_ctx_set_lanes(abcdez_ctx* ctx, int lanes) {
   if (lanes <= 0) { default_shape(ctx->h_model, &ctx->L, &ctx->C); return 0; }
   const int ld = ctx->h_model.ld;
   ABZ_REQUIRE(is_pow2(lanes) && lanes <= 16 && ld % lanes == 0, "set_lanes: lanes must be a power of two <= 16 dividing ld");
-  ABZ_REQUIRE(ctx->h_model.sim_id != ABZ_SIM_USER || lanes == ctx->L,
-              "set_lanes: the kernels of a user simulator were compiled for their lane-group shape when the context was created");
+  ABZ_REQUIRE(!ctx->user_module || lanes == ctx->L,
+              "set_lanes: the kernels of this model (a user simulator, or truncated(...) / MixtureModel priors) were compiled for their "
+              "lane-group shape when the context was created");
   ABZ_REQUIRE(lanes == 1 || ctx->h_model.sim_id == ABZ_SIM_MVN || ctx->h_model.sim_id == ABZ_SIM_USER,
               "set_lanes: this simulator needs the whole row in one thread");
   const int C = ld / lanes;

@@ -72,6 +72,7 @@ struct abcdez_ctx {
   abz_model* d_model = nullptr;
   double* d_data = nullptr;
   double* d_mv = nullptr;             /* maps of a correlated Normal prior (abz_model.mv), else null */
+  double* d_ext = nullptr;            /* records of the wrapper prior families (abz_model.ext), else null */
   abz_tables* d_tables = nullptr;
   int n_cu = 1;                       /* compute units of the device */
   std::unordered_map<const void*, int> occ;   /* kernel -> resident workgroups per CU (abz_persistent_grid) */
@@ -92,7 +93,8 @@ struct abcdez_ctx {
   size_t lv_hand_cap = 0;               /* positions the list has room for */
   unsigned long long lv_seq = 0;        /* sweeps launched: parity picks the list counter (abz_smc_swarm.hip) */
   bool user_one_kernel = false;         /* ABZ_USER_ONE_KERNEL=1: user simulators stay on the one-kernel two-phase sweep */
-  /* hiprtc-compiled kernels of a user-supplied simulator (abz_jit.hip), else null */
+  /* hiprtc-compiled kernels (abz_jit.hip): of a user-supplied simulator, or of a built-in one whose model has prior factors of the
+   * wrapper families (truncated(...), MixtureModel) -- the statically compiled sweeps do not carry those; else null */
   void* user_module = nullptr;
   /* quantile select: its own histogram (left zeroed by every call) and the arrays the device-side window belongs to */
   uint32_t* sel_hist = nullptr;
@@ -355,6 +357,9 @@ int abz_jit_launch_mc(abcdez_ctx*, const void* args, unsigned ntiles);
 int abz_jit_launch_smc_packed(abcdez_ctx*, const void* args, unsigned nblocks);
 bool abz_jit_has_smc_split(abcdez_ctx*);
 bool abz_jit_has_rounds(abcdez_ctx*);
+bool abz_jit_has_replay(abcdez_ctx*);
+int abz_jit_launch_replay(abcdez_ctx*, const void* args, unsigned nblocks);
+unsigned abz_jit_smc_block(abcdez_ctx*);
 int abz_jit_launch_smc_split(abcdez_ctx*, const void* args, const void* list, unsigned nblocks);
 
 #endif

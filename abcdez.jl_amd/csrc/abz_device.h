@@ -239,7 +239,8 @@ __device__ inline void group_lower_matvec(const double* __restrict__ mat, int j,
  * the whitened components z = W (theta - mu) (abcdez_spec.h) */
 template <int L, int C, bool PLAIN = false>
 __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entries */, int j, const double (&p)[C],
-                                        double (&pp)[C], const double* __restrict__ mv = nullptr) {
+                                        double (&pp)[C], const double* __restrict__ mv = nullptr,
+                                        const double* __restrict__ ext = nullptr /* records of the wrapper families, global memory */) {
   double lp[C];
   if constexpr (!PLAIN) {
     if (mv) {
@@ -265,7 +266,7 @@ __device__ inline double group_logprior(const abz_prior_dim* pd /* LDS, ld entri
       lp[q] = abz_fma(-0.5 * z, z, d->c0);
     } else {
       pp[q] = abz_push_p(d, p[q]);
-      lp[q] = abz_prior_logpdf1(d, pp[q]);
+      lp[q] = abz_prior_logpdf1x(d, pp[q], ext);
     }
   }
   return group_tree_sum<L, C>(lp);

@@ -14,6 +14,7 @@ struct HotModel {
   const double* data;           /* device, n_data values */
   const abz_tables* tables;     /* device copy of the sampler tables */
   const double* mv;             /* NULL, or [mu | W | L] of a correlated Normal prior (abcdez_spec.h), device memory */
+  const double* ext;            /* NULL, or the records of the wrapper prior families (truncated(...), MixtureModel), device memory */
   double sim_p[8];
   int32_t d, abck, n_data, n_blob;
   int32_t sim_i[2];             /* integer forms of simulator parameters: [0] = RK4 steps per observation (Lotka-Volterra, sim_p[3]) */

@@ -6,6 +6,7 @@
  * evaluate log-prior and first distance, and redraw while either is non-finite
  * (init.jl:14-20).  retry r of particle i uses RNG epoch r.
  */
+#define ABZ_PRIOR_WRAP 1        /* this translation unit's kernels evaluate the wrapper prior families too (include/abcdez_spec.h) */
 #include "abz_dispatch.h"
 #include "abz_kernels.h"
 

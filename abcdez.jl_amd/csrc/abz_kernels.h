@@ -47,7 +47,7 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
         double z0, z1;
         abz_normal_pair(w, &s_model.tab, &z0, &z1);
         th[0] = abz_prior_draw1(&pd[0], w.w0, z0);
-        if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_ext(&pd[0], seed, i, retry, 0u, &s_model.tab);
+        if (pd[0].family >= ABZ_PRIOR_BETA) th[0] = abz_prior_draw_extx(&pd[0], seed, i, retry, 0u, &s_model.tab, M.ext);
       } else {
 #pragma unroll
         for (int m = 0; m < C / 2; ++m) {
@@ -58,9 +58,9 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
           th[2 * m] = abz_prior_draw1(&pd[k], w.w0, z0);
           th[2 * m + 1] = abz_prior_draw1(&pd[k + 1], w.w1, z1);
           if (pd[k].family >= ABZ_PRIOR_BETA)
-            th[2 * m] = abz_prior_draw_ext(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab);
+            th[2 * m] = abz_prior_draw_extx(&pd[k], seed, i, retry, (uint32_t)k, &s_model.tab, M.ext);
           if (pd[k + 1].family >= ABZ_PRIOR_BETA)
-            th[2 * m + 1] = abz_prior_draw_ext(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab);
+            th[2 * m + 1] = abz_prior_draw_extx(&pd[k + 1], seed, i, retry, (uint32_t)(k + 1), &s_model.tab, M.ext);
         }
       }
       if (M.mv) {                     /* correlated Normal prior: the row drawn so far is z ~ N(0, I); theta = mu + L z */
@@ -74,7 +74,7 @@ __device__ inline void init_kernel_body(const HotModel& M, double* __restrict__ 
           th[q] = k < M.d ? M.mv[k] + th[q] : 0.0;
         }
       }
-      lp = group_logprior<L, C>(pd, j, th, pp, M.mv);
+      lp = group_logprior<L, C>(pd, j, th, pp, M.mv, M.ext);
       dl = ABZ_NAN;
       if (abz_isfinite(lp)) dl = sim_dist<SIM, L, C>(M, &s_model.tab, j, pp, s_model.y, i, retry, ABZ_RNG_INIT_SIM);   /* init.jl:9-13,17 */
       if (abz_isfinite(dl) && abz_isfinite(lp)) break;                                          /* init.jl:14 */
@@ -173,7 +173,7 @@ __device__ inline void smc_swarm_packed_body_1p(const SmcPackedArgs& a) {
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;
 
-  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv, M.ext);   /* smc:134 */
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   bool acc = false;
   double dp = dli;
@@ -299,7 +299,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;              /* smc:128 */
     double pp[C];
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);   /* smc:134 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv, M.ext);   /* smc:134 */
     const bool insupport = !(lp == ABZ_NINF);                     /* smc:135 */
     const double kdi = kernel_logpdf_dev(M.abck, a.eps, dli);
     const double wl = lp - lpi;
@@ -394,7 +394,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
         double tq[C], pq[C];
 #pragma unroll
         for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>((int)sl, m, 0)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
-        const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+        const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv, M.ext);
         const uint32_t pw = s_hand.pos[sl];
         const uint32_t rs = tile_base + (pw & 0x7FFFu), bs = pw >> 15;
         const double ds = abz_sqrt(s_lacc[sl]);                                                                    /* smc:137 */
@@ -418,7 +418,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
       for (int m = 0; m < C / 2; ++m) { const double2 t = row[hand_unit<L, C>(slot, m, j)]; tq[2 * m] = t.x; tq[2 * m + 1] = t.y; }
       /* push_p (types.jl:20-23) and the log-prior again: the same function of the same row in the same lanes as in phase 1 -- the
        * same bits -- for 45 instructions of the few wavefronts that get here, instead of 512 bytes of LDS in every workgroup */
-      const double lps = group_logprior<L, C, PLAIN>(s_model.prior, j, tq, pq, M.mv);
+      const double lps = group_logprior<L, C, PLAIN>(s_model.prior, j, tq, pq, M.mv, M.ext);
       const uint32_t pw = s_hand.pos[slot];
       const uint32_t rs = tile_base + (pw & 0x7FFFu), bs = pw >> 15;
       const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, j, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);   /* smc:137 */
@@ -513,7 +513,7 @@ __device__ inline void smc_split_phase1_body(const SmcPackedArgs& a, const LvHan
 #pragma unroll
   for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                /* smc:128 */
   double pp[C];
-  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, 0, tp, pp, M.mv);     /* smc:134 */
+  const double lp = group_logprior<L, C, PLAIN>(s_model.prior, 0, tp, pp, M.mv, M.ext);     /* smc:134 */
   const bool insupport = !(lp == ABZ_NINF);                       /* smc:135 */
   const double kdi = kernel_logpdf_dev(M.abck, a.eps, dli);
   const double wl = lp - lpi;
@@ -578,7 +578,7 @@ __device__ inline void smc_split_phase2_body(const SmcPackedArgs& a, const LvHan
   const uint32_t pw = h.pos[r];
   stage.store(s_model);
   __syncthreads();
-  const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+  const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv, M.ext);
   const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
   const double ds = sim_dist<SIM, L, C, false, PLAIN>(M, &s_model.tab, 0, pq, s_model.y, rs, a.sweep, ABZ_RNG_SIM);     /* smc:137 */
   const double w = (wl + kernel_logpdf_dev(M.abck, a.eps, ds)) - kdi;                                              /* smc:140-141 */
@@ -671,7 +671,7 @@ __device__ inline void smc_lv_phase2_body(const SmcPackedArgs& a, const LvHandLi
     double tq[C], pq[C];
 #pragma unroll
     for (int q = 0; q < C; ++q) tq[q] = s_tp[sl][q];
-    const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+    const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv, M.ext);
     const uint32_t pw = s_pos[sl];
     const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
     const double ds = abz_sqrt(s_lacc[sl]);                                                        /* smc:137 */
@@ -810,7 +810,7 @@ __device__ inline void smc_replay_packed_body(const SmcReplayPackedArgs& a) {
     load_row<L, C>((bb ? a.slot1 : a.slot0) + (size_t)rb * LD, j, tb);
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ti[q] + (ta[q] - tb[q]) * g;                       /* smc:128 */
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, a.hm.mv);      /* what the owner stored, smc:147 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, a.hm.mv, a.hm.ext);      /* what the owner stored, smc:147 */
     if (on) {
       store_row<L, C>((bi ? a.slot0 : a.slot1) + (size_t)ri * LD, j, tp);
       if (j == 0) {
@@ -923,7 +923,7 @@ __device__ inline void mc_swarm_kernel_body(const McSwarmArgs& a) {
 #pragma unroll
     for (int q = 0; q < C; ++q) tp[q] = ts[q] + (ta[q] - tb[q]) * g;
 
-    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv);        /* mc:41 */
+    const double lp = group_logprior<L, C, PLAIN>(s_model.prior, j, tp, pp, M.mv, M.ext);        /* mc:41 */
     const double w_prior = lp - lpi;                                        /* mc:42 */
     const double u = abz_u01_open(abz_rng(seed, i, sweep, 0, ABZ_RNG_ACCEPT).w0);
     double mn = w_prior < 0.0 ? w_prior : 0.0;
@@ -1009,7 +1009,7 @@ __device__ inline void blob_eval_kernel_body(const HotModel& M, const double* __
     if (s >= n) continue;                       /* whole groups leave together; no barrier inside the loop */
     double th[C], pp[C];
     load_row<L, C>(theta + (size_t)s * LD, j, th);
-    (void)group_logprior<L, C>(s_model.prior, j, th, pp, M.mv);  /* push_p (types.jl:20-23) */
+    (void)group_logprior<L, C>(s_model.prior, j, th, pp, M.mv, M.ext);  /* push_p (types.jl:20-23) */
     const uint64_t st = stamp[s];
     const uint32_t purpose = abz_stamp_is_init(st) ? (uint32_t)ABZ_RNG_INIT_SIM : (uint32_t)ABZ_RNG_SIM;
     if constexpr (SIM == ABZ_SIM_MVN) {

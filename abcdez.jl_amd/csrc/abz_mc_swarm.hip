@@ -39,7 +39,7 @@ int abz_launch_mc_swarm(abcdez_ctx* ctx, const uint32_t* order, const uint32_t* 
   a.stamp = ctx->stamp_cur; a.nstamp = ctx->stamp_cur ? ctx->stamp_nxt : nullptr;      /* blob stamps */
   bool ok = true;
   const int tk = abz_time_begin(ctx);
-  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+  if (ctx->user_module) {          /* kernels compiled for this model at run time (abz_jit.hip) */
     if (int rc = abz_jit_launch_mc(ctx, &a, ntiles)) return rc;
   } else {
     ok = abz_dispatch(ctx->h_model.sim_id, ctx->L, ctx->C, [&](auto S, auto LL, auto CC) {

@@ -7,6 +7,7 @@
  *   extrema / counts                                   (smc:286,364; mc:133,146,156,163)
  * All HBM-streaming, a few bytes per particle per generation.
  */
+#define ABZ_PRIOR_WRAP 1        /* this translation unit's kernels evaluate the wrapper prior families too (include/abcdez_spec.h) */
 #include <chrono>
 #include <sched.h>
 #include <string.h>
@@ -1689,7 +1690,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void math_eval_kernel(int fn, const abz_
     case 8: { double s, c; abz_sincos2pi_tab(x[i], T, &s, &c); y[i] = s; y2[i] = c; break; }
     case 9: y[i] = abz_sqrt_pn(x[i]); break;
     case 10: y[i] = abz_lgamma(x[i]); break;
-    case 11: y[i] = abz_prior_logpdf1(&M->prior[(int)y2[i]], x[i]); break;   /* log-density of prior factor y2[i] at x[i] */
+    case 11: y[i] = abz_prior_logpdf1x(&M->prior[(int)y2[i]], x[i], M->ext); break;   /* log-density of prior factor y2[i] at x[i] */
     default: y[i] = x[i] / y2[i]; break;
   }
 }

@@ -62,7 +62,8 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   if (L > 8) { abz_set_error("smc_swarm_packed: at most 8 lanes per particle (a block must cover whole bitmap words)"); return -3; }
   unsigned nblocks = abz_grid((uint64_t)a.n_work * (uint64_t)L);
   /* two launches: phase 1 over the positions, phase 2 over the proposals it hands over -- every wavefront of the simulator full */
-  const bool split = abz_sweep_in_two_launches(ctx) && (ctx->h_model.sim_id != ABZ_SIM_USER || abz_jit_has_smc_split(ctx));
+  const bool jit = ctx->user_module != nullptr;      /* this model's kernels were compiled at run time (abz_jit.hip) */
+  const bool split = abz_sweep_in_two_launches(ctx) && (!jit || abz_jit_has_smc_split(ctx));
   LvHandList h{};
   if (split) {
     if (int rc = abz_lv_hand_reserve(ctx, (size_t)a.n_work)) return rc;      /* (a no-op after abcdez_ctx_reserve) */
@@ -77,10 +78,14 @@ int abz_launch_smc_swarm_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t*
   }
   const int tk = abz_time_begin(ctx);
   bool ok = true;
-  if (ctx->h_model.sim_id == ABZ_SIM_USER) {
+  if (jit) {
     if (split) {
       if (int rc = abz_jit_launch_smc_split(ctx, &a, &h, abz_grid((uint64_t)a.n_work))) return rc;
-    } else if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+    } else {
+      const unsigned blk = abz_jit_smc_block(ctx);
+      nblocks = (unsigned)(((uint64_t)a.n_work * (uint64_t)L + blk - 1) / blk);
+      if (int rc = abz_jit_launch_smc_packed(ctx, &a, nblocks)) return rc;
+    }
   } else if (split) {
     {
     const unsigned nb1 = (unsigned)(((uint64_t)a.n_work + ABZ_BLOCK - 1) / ABZ_BLOCK);
@@ -149,6 +154,7 @@ int abz_launch_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t
   a.cslots = ctx->d_scal + ABZ_S_CSLOT0;
   a.gamma0 = gamma0; a.gsig = gsig; a.n_alive = n_alive; a.skip_lo = skip_lo; a.skip_hi = skip_hi; a.sweep = sweep;
   const unsigned nblocks = (unsigned)(((uint64_t)n_alive + ABZ_REPLAY_CHUNK - 1) / ABZ_REPLAY_CHUNK);
+  if (ctx->user_module && abz_jit_has_replay(ctx)) return abz_jit_launch_replay(ctx, &a, nblocks);
   bool ok = abz_dispatch_lc(ctx->L, ctx->C, [&](auto LL, auto CC) {
     if (ctx->prior_plain)
       hipLaunchKernelGGL((smc_replay_packed_kernel<LL(), CC(), true>), dim3(nblocks), dim3(ABZ_BLOCK), 0, ctx->stream, a);

@@ -120,7 +120,7 @@ __device__ inline void smc_user_rounds_phase2_body(const SmcPackedArgs& a, const
     double tq[C], pq[C];
 #pragma unroll
     for (int q = 0; q < C; ++q) tq[q] = s_tp[q][sl];
-    const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv);
+    const double lps = group_logprior<L, C, PLAIN>(s_model.prior, 0, tq, pq, M.mv, M.ext);
     const uint32_t pw = s_pos[sl];
     const uint32_t rs = pw & 0x7FFFFFFFu, bs = pw >> 31;
     const double ds = s_val[sl];                                                                    /* smc:137 */

@@ -43,6 +43,9 @@ class Model(C.Structure):
         ("data", C.c_void_p),
         ("prior", PriorDim * MAX_D),
         ("mv", C.c_void_p),
+        ("ext", C.c_void_p),
+        ("n_ext", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -91,8 +94,16 @@ class ModelSpec:
         if self.n_blob > 64:
             raise ValueError(f"blobs of {self.n_blob} doubles exceed the supported maximum 64")
         self.discrete = tuple(bool(f.discrete) for f in factors)
-        # (family, discrete, p0, p1, c0, c1, reserved): the first three families compute c1 here
-        self._desc = [self._full_descriptor(f) for f in factors]
+        # (family, discrete, p0, p1, c0, c1, reserved): the first three families compute c1 here.  The wrapper families
+        # (truncated(...), MixtureModel) keep their records in the model's ext table and point at them by offset.
+        ext, self._desc = [], []
+        for f in factors:
+            if hasattr(f, "ext_record"):
+                self._desc.append(tuple(f.descriptor_at(len(ext))))
+                ext += f.ext_record()
+            else:
+                self._desc.append(self._full_descriptor(f))
+        self.ext = np.ascontiguousarray(np.asarray(ext, dtype=np.float64)) if ext else None
         if isinstance(prior, Product):
             # push_p broadcasts the whole product over the vector (types.jl:21): one rule for every component
             self.discrete = tuple(bool(prior.discrete) for _ in factors)
@@ -124,4 +135,7 @@ class ModelSpec:
             m.prior[k].family, m.prior[k].discrete = fam, disc
             m.prior[k].p0, m.prior[k].p1, m.prior[k].c0, m.prior[k].c1, m.prior[k].reserved = p0, p1, c0, c1, reserved
         m.mv = self.mv.ctypes.data if self.mv is not None else None
+        m.ext = self.ext.ctypes.data if self.ext is not None else None
+        m.n_ext = int(self.ext.size) if self.ext is not None else 0
+        m.reserved0 = 0
         return m

@@ -16,6 +16,9 @@ from typing import Sequence, Tuple, Union
 PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM, PRIOR_BETA, PRIOR_NEGBIN = 0, 1, 2, 3, 4, 5
 (PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE, PRIOR_WEIBULL, PRIOR_INVGAMMA, PRIOR_TRUNCNORMAL,
  PRIOR_LOGISTIC, PRIOR_TDIST, PRIOR_PARETO, PRIOR_POISSON, PRIOR_BINOMIAL) = range(6, 19)
+# wrappers around the families above; their records live in the model's ext table (ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE)
+PRIOR_TRUNCATED, PRIOR_MIXTURE = 19, 20
+MAX_MIX = 16
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
 
@@ -469,10 +472,13 @@ class TruncatedNormal(_Continuous):
 
 
 def truncated(dist, lower: float = None, upper: float = None):
-    """``truncated(d, lower, upper)`` of Distributions.jl for the one parent the device knows: a Normal."""
-    if type(dist) is not Normal:
-        raise TypeError("truncated(): only a Normal parent has a device descriptor")
-    return TruncatedNormal(dist.mu, dist.sigma, -math.inf if lower is None else float(lower), math.inf if upper is None else float(upper))
+    """``truncated(d, lower, upper)`` of Distributions.jl: a Normal parent keeps its own family (ABZ_PRIOR_TRUNCNORMAL), any other
+    univariate family is wrapped (:class:`Truncated`, ABZ_PRIOR_TRUNCATED)."""
+    lo = -math.inf if lower is None else float(lower)
+    hi = math.inf if upper is None else float(upper)
+    if type(dist) is Normal:
+        return TruncatedNormal(dist.mu, dist.sigma, lo, hi)
+    return Truncated(dist, lo, hi)
 
 
 @dataclass(frozen=True)
@@ -620,6 +626,261 @@ class Binomial(_Counting):
 def Geometric(p: float = 0.5) -> NegativeBinomial:
     """Geometric(p) = NegativeBinomial(1, p): failures before the first success"""
     return NegativeBinomial(1.0, p)
+
+
+# ---- cumulative distribution functions (hosts only: the mass of a truncation interval; the device never evaluates a cdf) ----
+def _gammainc_p(a: float, x: float) -> float:
+    """regularised lower incomplete gamma P(a, x): series below a + 1, Lentz continued fraction of Q above"""
+    if x <= 0.0:
+        return 0.0
+    if math.isinf(x):
+        return 1.0
+    lg = a * math.log(x) - x - math.lgamma(a)
+    if x < a + 1.0:
+        ap, term, tot = a, 1.0 / a, 1.0 / a
+        for _ in range(2000):
+            ap += 1.0
+            term *= x / ap
+            tot += term
+            if abs(term) < abs(tot) * 1e-17:
+                break
+        return min(1.0, tot * math.exp(lg))
+    tiny = 1e-300
+    b = x + 1.0 - a
+    c, d = 1.0 / tiny, 1.0 / b
+    h = d
+    for i in range(1, 2000):
+        an = -i * (i - a)
+        b += 2.0
+        d = an * d + b
+        d = tiny if abs(d) < tiny else d
+        c = b + an / c
+        c = tiny if abs(c) < tiny else c
+        d = 1.0 / d
+        dl = d * c
+        h *= dl
+        if abs(dl - 1.0) < 1e-16:
+            break
+    return max(0.0, 1.0 - math.exp(lg) * h)
+
+
+def _betainc(a: float, b: float, x: float) -> float:
+    """regularised incomplete beta I_x(a, b) (Lentz continued fraction, with the symmetry that keeps it convergent)"""
+    if x <= 0.0:
+        return 0.0
+    if x >= 1.0:
+        return 1.0
+    lbt = math.lgamma(a + b) - math.lgamma(a) - math.lgamma(b) + a * math.log(x) + b * math.log1p(-x)
+
+    def cf(a, b, x):
+        tiny = 1e-300
+        qab, qap, qam = a + b, a + 1.0, a - 1.0
+        c, d = 1.0, 1.0 - qab * x / qap
+        d = tiny if abs(d) < tiny else d
+        d = 1.0 / d
+        h = d
+        for m in range(1, 3000):
+            m2 = 2 * m
+            aa = m * (b - m) * x / ((qam + m2) * (a + m2))
+            d = 1.0 + aa * d
+            d = tiny if abs(d) < tiny else d
+            c = 1.0 + aa / c
+            c = tiny if abs(c) < tiny else c
+            d = 1.0 / d
+            h *= d * c
+            aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2))
+            d = 1.0 + aa * d
+            d = tiny if abs(d) < tiny else d
+            c = 1.0 + aa / c
+            c = tiny if abs(c) < tiny else c
+            d = 1.0 / d
+            dl = d * c
+            h *= dl
+            if abs(dl - 1.0) < 1e-16:
+                break
+        return h
+    if x < (a + 1.0) / (a + b + 2.0):
+        return min(1.0, math.exp(lbt) * cf(a, b, x) / a)
+    return max(0.0, 1.0 - math.exp(lbt) * cf(b, a, 1.0 - x) / b)
+
+
+def _phi(z: float) -> float:
+    return 0.5 * math.erfc(-z / math.sqrt(2.0))
+
+
+def prior_cdf(dist, x: float) -> float:
+    """P(X <= x) of a univariate family of this module"""
+    x = float(x)
+    if math.isnan(x):
+        return math.nan
+    t = type(dist)
+    if t is Normal:
+        return _phi((x - dist.mu) / dist.sigma)
+    if t is Uniform:
+        return min(1.0, max(0.0, (x - dist.a) / (dist.b - dist.a)))
+    if t is DiscreteUniform:
+        return min(1.0, max(0.0, (math.floor(x) - dist.a + 1.0) / (dist.b - dist.a + 1.0)))
+    if t is Beta:
+        return _betainc(dist.alpha, dist.beta, x)
+    if t is NegativeBinomial:
+        return 0.0 if x < 0 else (1.0 if math.isinf(x) else _betainc(dist.r, math.floor(x) + 1.0, dist.p))
+    if t is Exponential:
+        return 0.0 if x <= 0 else -math.expm1(-x / dist.theta)
+    if t is Gamma:
+        return _gammainc_p(dist.alpha, x / dist.theta)
+    if t is LogNormal:
+        return 0.0 if x <= 0 else _phi((math.log(x) - dist.mu) / dist.sigma)
+    if t is Cauchy:
+        return 0.5 + math.atan((x - dist.mu) / dist.sigma) / math.pi
+    if t is Laplace:
+        z = (x - dist.mu) / dist.theta
+        return 0.5 * math.exp(z) if z < 0 else 1.0 - 0.5 * math.exp(-z)
+    if t is Weibull:
+        return 0.0 if x <= 0 else -math.expm1(-((x / dist.theta) ** dist.alpha))
+    if t is InverseGamma:
+        return 0.0 if x <= 0 else 1.0 - _gammainc_p(dist.alpha, dist.theta / x)
+    if t is TruncatedNormal:
+        lo = _phi((dist.lo - dist.mu) / dist.sigma)
+        return min(1.0, max(0.0, (_phi((x - dist.mu) / dist.sigma) - lo) / dist.mass()))
+    if t is Logistic:
+        z = (x - dist.mu) / dist.theta
+        return 1.0 / (1.0 + math.exp(-z)) if z >= 0 else math.exp(z) / (1.0 + math.exp(z))
+    if t is TDist:
+        if math.isinf(x):
+            return 1.0 if x > 0 else 0.0
+        tail = 0.5 * _betainc(0.5 * dist.nu, 0.5, dist.nu / (dist.nu + x * x))
+        return 1.0 - tail if x >= 0 else tail
+    if t is Pareto:
+        return 0.0 if x <= dist.theta else 1.0 - (dist.theta / x) ** dist.alpha
+    if t is Poisson:
+        return 0.0 if x < 0 else (1.0 if math.isinf(x) else 1.0 - _gammainc_p(math.floor(x) + 1.0, dist.lam))
+    if t is Binomial:
+        k = math.floor(x)
+        return 0.0 if k < 0 else (1.0 if k >= dist.n else _betainc(dist.n - k, k + 1.0, 1.0 - dist.p))
+    raise TypeError(f"no cdf for {t.__name__}")
+
+
+def _full7(f) -> tuple:
+    """(family, discrete, p0, p1, c0, c1, reserved) of a base family, as ModelSpec lays it out"""
+    q = tuple(f.descriptor())
+    if len(q) == 7:
+        return q
+    fam, disc, p0, p1, c0 = q
+    c1 = 1.0 / p1 if fam == PRIOR_NORMAL else (f.c1() if fam == PRIOR_NEGBIN else 0.0)
+    return (fam, disc, p0, p1, c0, c1, 0.0)
+
+
+class Truncated(UnivariateDistribution):
+    """``truncated(d, lo, hi)`` of Distributions.jl for ANY univariate family of this module (ABZ_PRIOR_TRUNCATED): the parent's
+    density inside [lo, hi] over the mass of the interval.  The device draws the initial population by rejection from the parent,
+    so the interval must hold at least 1 % of the parent's mass."""
+    family = PRIOR_TRUNCATED
+
+    def __init__(self, parent, lo: float = -math.inf, hi: float = math.inf):
+        if not isinstance(parent, UnivariateDistribution) or isinstance(parent, (Truncated, MixtureModel)):
+            raise TypeError("truncated(): the parent must be one of the base univariate families")
+        if not lo < hi:
+            raise ValueError("truncated(): need lower < upper")
+        self.parent, self.lo, self.hi = parent, float(lo), float(hi)
+        self.discrete = bool(parent.discrete)
+        below = prior_cdf(parent, math.ceil(self.lo) - 1.0 if self.discrete and math.isfinite(self.lo) else self.lo) if math.isfinite(self.lo) else 0.0
+        if not self.discrete and math.isfinite(self.lo):
+            below = prior_cdf(parent, self.lo)
+        above = prior_cdf(parent, self.hi) if math.isfinite(self.hi) else 1.0
+        self._mass = above - below
+        if not self._mass >= 0.01:
+            raise ValueError(f"truncated({type(parent).__name__}): [lo, hi] holds {self._mass:.3g} of the parent's mass; the device draws the "
+                             "initial population by rejection from the parent and needs at least 0.01")
+        self._logmass = math.log(self._mass)
+
+    def mass(self) -> float:
+        return self._mass
+
+    def insupport(self, x) -> bool:
+        return self.lo <= x <= self.hi and self.parent.insupport(x)
+
+    def logpdf(self, x) -> float:
+        return self.parent.logpdf(x) - self._logmass if self.insupport(x) else -math.inf
+
+    def pdf(self, x) -> float:
+        return math.exp(self.logpdf(x))
+
+    def rand(self, rng):
+        while True:
+            x = self.parent.rand(rng)
+            if self.lo <= x <= self.hi:
+                return x
+
+    def ext_record(self):
+        """[lo, hi, log mass, parent descriptor (7)] -- what the descriptor's p0 points at in abz_model.ext"""
+        return [self.lo, self.hi, self._logmass] + [float(v) for v in _full7(self.parent)]
+
+    def descriptor_at(self, offset: int):
+        return (PRIOR_TRUNCATED, int(self.discrete), float(offset), 0.0, 0.0, 0.0, 0.0)
+
+    def __repr__(self) -> str:
+        return f"truncated({self.parent!r}, {self.lo}, {self.hi})"
+
+
+class MixtureModel(UnivariateDistribution):
+    """``MixtureModel(components, weights)`` of Distributions.jl with univariate components of this module's base families, all
+    continuous or all discrete (ABZ_PRIOR_MIXTURE): logpdf = log-sum-exp of log w_j + logpdf_j; the initial population draws the
+    component by inversion of the cumulative weights, then from that component."""
+    family = PRIOR_MIXTURE
+
+    def __init__(self, components, weights=None):
+        comps = tuple(components)
+        if not 1 <= len(comps) <= MAX_MIX:
+            raise ValueError(f"MixtureModel: 1 .. {MAX_MIX} components")
+        for c in comps:
+            if not isinstance(c, UnivariateDistribution) or isinstance(c, (Truncated, MixtureModel)):
+                raise TypeError("MixtureModel: components must be base univariate families (no nesting)")
+        if len({bool(c.discrete) for c in comps}) != 1:
+            raise TypeError("MixtureModel: the components must be all continuous or all discrete (push_p has one rule per parameter)")
+        w = [1.0 / len(comps)] * len(comps) if weights is None else [float(v) for v in weights]
+        if len(w) != len(comps) or not all(v > 0 for v in w) or abs(sum(w) - 1.0) > 1e-9:
+            raise ValueError("MixtureModel: one positive weight per component, summing to 1")
+        tot = math.fsum(w)
+        self.components, self.weights = comps, tuple(v / tot for v in w)
+        self.discrete = bool(comps[0].discrete)
+
+    def insupport(self, x) -> bool:
+        return any(c.insupport(x) for c in self.components)
+
+    def logpdf(self, x) -> float:
+        t = [math.log(w) + c.logpdf(x) for w, c in zip(self.weights, self.components)]
+        m = max(t)
+        if m == -math.inf:
+            return -math.inf
+        acc = 0.0
+        for v in t:
+            acc += math.exp(v - m)
+        return m + math.log(acc)
+
+    def pdf(self, x) -> float:
+        return math.exp(self.logpdf(x))
+
+    def rand(self, rng):
+        u, cum = rng.random(), 0.0
+        for w, c in zip(self.weights, self.components):
+            cum += w
+            if u < cum:
+                return c.rand(rng)
+        return self.components[-1].rand(rng)
+
+    def ext_record(self):
+        """K records [log w_j, cumulative weight, component descriptor (7)]"""
+        out, cum = [], 0.0
+        for j, (w, c) in enumerate(zip(self.weights, self.components)):
+            cum = 1.0 if j == len(self.components) - 1 else cum + w
+            out += [math.log(w), cum] + [float(v) for v in _full7(c)]
+        return out
+
+    def descriptor_at(self, offset: int):
+        return (PRIOR_MIXTURE, int(self.discrete), float(len(self.components)), float(offset), 0.0, 0.0, 0.0)
+
+    def __repr__(self) -> str:
+        return f"MixtureModel({list(self.components)!r}, {list(self.weights)!r})"
 
 
 class Factored:

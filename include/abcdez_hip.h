@@ -39,8 +39,8 @@ ABCDEZ_API int abcdez_version(void);
  * run depends on it, so hosts store it in their checkpoints next to abcdez_version() and refuse to resume across a change. */
 ABCDEZ_API int abcdez_rng_rounds(void);
 /* Layout of the structs that cross the boundary: fills out[0 .. n) with { sizeof(abz_prior_dim), offsetof of its 7 fields
- * in declaration order, sizeof(abz_model), offsetof of its 11 fields in declaration order } and returns how many
- * values there are (20).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
+ * in declaration order, sizeof(abz_model), offsetof of its 14 fields in declaration order } and returns how many
+ * values there are (23).  Hosts that mirror the structs by hand assert this (julia/ABCdeZHIP.jl, tests/test_host_api.py). */
 ABCDEZ_API int abcdez_abi_layout(int32_t* out, int n);
 ABCDEZ_API const char* abcdez_last_error(void);
 

@@ -27,6 +27,16 @@
 #else
 #define ABZ_HD static inline
 #endif
+/* The WRAPPER prior families (ABZ_PRIOR_TRUNCATED, ABZ_PRIOR_MIXTURE) in DEVICE code are compiled only into translation units that
+ * ask for them (-DABZ_PRIOR_WRAP=1): inlined into every sweep kernel their loops cost the kernels of ALL non-Normal priors a third of
+ * their occupancy (94 -> 132 registers and scratch memory on the Lotka-Volterra sweep, measured).  The library compiles the sweep
+ * kernels of a model that has such factors at run time (csrc/abz_jit.hip), like those of a user-supplied simulator; its statically
+ * compiled initial-population and test-hook kernels carry them.  Host code (the oracle, the library's validation) always has them. */
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(ABZ_PRIOR_WRAP)
+#define ABZ_HAVE_PRIOR_WRAP 1
+#else
+#define ABZ_HAVE_PRIOR_WRAP 0
+#endif
 
 /* ------------------------------------------------------------------ bit casts */
 ABZ_HD uint64_t abz_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
@@ -376,8 +386,19 @@ enum {
   ABZ_PRIOR_POISSON = 17,     /* Poisson(lambda): p0 = lambda, c0 = -lambda, c1 = log lambda; discrete k >= 0                    */
   ABZ_PRIOR_BINOMIAL = 18,    /* Binomial(n, p), 0 < p < 1: p0 = n, p1 = p, c0 = lgamma(n+1) + n log(1-p), c1 = log p - log(1-p);
                                  discrete 0 <= k <= n                                                                           */
-  ABZ_PRIOR_LAST = 18
+  /* wrappers around the families above; their records live in the model's `ext` table (abz_model.ext, doubles):              */
+  ABZ_PRIOR_TRUNCATED = 19,   /* truncated(parent, lo, hi) of ANY univariate parent above: p0 = offset in ext of the record
+                                 [lo, hi, log(cdf(hi) - cdf(lo-)), parent descriptor (7 doubles)]; logpdf = parent's - log mass
+                                 inside [lo, hi], -Inf outside; `discrete` = the parent's                                        */
+  ABZ_PRIOR_MIXTURE = 20,     /* MixtureModel(components, weights) of univariate components: p0 = K, p1 = offset in ext of K
+                                 records [log w_j, cumulative weight, component descriptor (7 doubles)]; logpdf = log-sum-exp of
+                                 log w_j + logpdf_j; `discrete` = the components' (all alike)                                    */
+  ABZ_PRIOR_LAST = 20
 };
+#define ABZ_EXT_DESC 7        /* a descriptor stored as doubles: family, discrete, p0, p1, c0, c1, reserved */
+#define ABZ_EXT_TRUNC (3 + ABZ_EXT_DESC)
+#define ABZ_EXT_MIXC (2 + ABZ_EXT_DESC)
+#define ABZ_MAX_MIX 16        /* components per mixture */
 
 typedef struct {    /* 48 bytes = three 16-byte loads */
   int32_t family;
@@ -408,6 +429,62 @@ ABZ_HD double abz_lgamma(double x) {
 
 /* log-densities of the families beyond Normal / (Discrete)Uniform: Beta / NegativeBinomial (the Socks problem of
  * test/runtests.jl:425-491) and the further Distributions.jl families above.  x is already push_p-cast. */
+ABZ_HD double abz_prior_logpdf_ext(const abz_prior_dim* pd, double x);
+/* Normal / Uniform / DiscreteUniform / padding: branch-free so a wave with mixed families
+ * does not serialise.  Normal: z = (x - mu) * (1/sigma), -z^2/2 + c0.                     */
+ABZ_HD double abz_prior_logpdf_basic(const abz_prior_dim* pd, double x) {
+  const int fam = pd->family;
+  const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
+  const double z = (x - p0) * c1;
+  const double ln = abz_fma(-0.5 * z, z, c0);
+  int inr = (x >= p0) & (x <= p1);
+  if (fam == ABZ_PRIOR_DUNIFORM) inr &= (abz_rint(x) == x);
+  const double lu = inr ? c0 : ABZ_NINF;
+  return fam == ABZ_PRIOR_NORMAL ? ln : (fam == ABZ_PRIOR_PAD ? 0.0 : lu);
+}
+/* any base family -- what a wrapper's parent / component may be (no nesting: a wrapper inside a wrapper is NaN) */
+ABZ_HD double abz_prior_logpdf_base(const abz_prior_dim* pd, double x) {
+  if (pd->family >= ABZ_PRIOR_TRUNCATED) return ABZ_NAN;
+  return pd->family >= ABZ_PRIOR_BETA ? abz_prior_logpdf_ext(pd, x) : abz_prior_logpdf_basic(pd, x);
+}
+ABZ_HD void abz_ext_desc(const double* rec, abz_prior_dim* out) {
+  out->family = (int32_t)rec[0]; out->discrete = (int32_t)rec[1];
+  out->p0 = rec[2]; out->p1 = rec[3]; out->c0 = rec[4]; out->c1 = rec[5]; out->reserved = rec[6];
+}
+/* the wrapper families: ext = abz_model.ext (NULL: the model has none, and a wrapper descriptor is malformed) */
+ABZ_HD double abz_prior_logpdf_wrapped(const abz_prior_dim* pd, double x, const double* ext) {
+  if (!ext) return ABZ_NAN;
+  if (pd->family == ABZ_PRIOR_TRUNCATED) {
+    const double* rec = ext + (size_t)pd->p0;
+    if (!(x >= rec[0] && x <= rec[1])) return ABZ_NINF;
+    abz_prior_dim par;
+    abz_ext_desc(rec + 3, &par);
+    return abz_prior_logpdf_base(&par, x) - rec[2];
+  }
+  /* mixture: log-sum-exp around the largest term, terms added in component order.  Two passes over the components instead of an
+   * array of terms: a dynamically indexed local array would live in scratch memory on the device -- for every kernel that merely
+   * CONTAINS this branch */
+  const int K = (int)pd->p0;
+  const double* rec = ext + (size_t)pd->p1;
+  double m = ABZ_NINF;
+  int nan_term = 0;
+  for (int j = 0; j < K && j < ABZ_MAX_MIX; ++j) {
+    abz_prior_dim c;
+    abz_ext_desc(rec + (size_t)j * ABZ_EXT_MIXC + 2, &c);
+    const double t = rec[(size_t)j * ABZ_EXT_MIXC] + abz_prior_logpdf_base(&c, x);
+    if (t != t) nan_term = 1;
+    if (t > m) m = t;
+  }
+  if (nan_term) return ABZ_NAN;
+  if (!(m > ABZ_NINF)) return ABZ_NINF;                            /* outside every component's support */
+  double acc = 0.0;
+  for (int j = 0; j < K && j < ABZ_MAX_MIX; ++j) {
+    abz_prior_dim c;
+    abz_ext_desc(rec + (size_t)j * ABZ_EXT_MIXC + 2, &c);
+    acc += abz_exp((rec[(size_t)j * ABZ_EXT_MIXC] + abz_prior_logpdf_base(&c, x)) - m);
+  }
+  return m + abz_log(acc);
+}
 ABZ_HD double abz_prior_logpdf_ext(const abz_prior_dim* pd, double x) {
   const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
   switch (pd->family) {
@@ -481,19 +558,19 @@ ABZ_HD double abz_prior_logpdf_ext(const abz_prior_dim* pd, double x) {
   }
 }
 
-/* logpdf of one (already pushed) component; branch-free so a wave with mixed families
- * does not serialise.  Normal: z = (x - mu) * (1/sigma), -z^2/2 + c0.                     */
-ABZ_HD double abz_prior_logpdf1(const abz_prior_dim* pd, double x) {
+/* logpdf of one (already pushed) component */
+ABZ_HD double abz_prior_logpdf1x(const abz_prior_dim* pd, double x, const double* ext) {
   const int fam = pd->family;
+#if ABZ_HAVE_PRIOR_WRAP
+  if (fam >= ABZ_PRIOR_TRUNCATED) return abz_prior_logpdf_wrapped(pd, x, ext);
+#else
+  if (fam >= ABZ_PRIOR_TRUNCATED) return ABZ_NAN;       /* (a kernel compiled without the wrapper families is never launched on such a model) */
+#endif
   if (fam >= ABZ_PRIOR_BETA) return abz_prior_logpdf_ext(pd, x);
-  const double p0 = pd->p0, p1 = pd->p1, c0 = pd->c0, c1 = pd->c1;
-  const double z = (x - p0) * c1;
-  const double ln = abz_fma(-0.5 * z, z, c0);
-  int inr = (x >= p0) & (x <= p1);
-  if (fam == ABZ_PRIOR_DUNIFORM) inr &= (abz_rint(x) == x);
-  const double lu = inr ? c0 : ABZ_NINF;
-  return fam == ABZ_PRIOR_NORMAL ? ln : (fam == ABZ_PRIOR_PAD ? 0.0 : lu);
+  return abz_prior_logpdf_basic(pd, x);
 }
+/* a model without wrapper families (every caller that has no ext table at hand) */
+ABZ_HD double abz_prior_logpdf1(const abz_prior_dim* pd, double x) { return abz_prior_logpdf1x(pd, x, (const double*)0); }
 
 /* one prior draw for component pair (2m, 2m+1) uses one Philox block:
  *   normal: Box-Muller pair (z0 -> even component, z1 -> odd component)
@@ -631,6 +708,48 @@ ABZ_HD double abz_prior_draw_ext(const abz_prior_dim* pd, uint64_t seed, uint32_
     default:
       return 0.0;
   }
+}
+
+/* one draw of any BASE family with its random numbers taken at (epoch, component k, sub-index sub ...) of the purpose
+ * ABZ_RNG_INIT_AUX: what the wrapper families below draw their parents / components with */
+ABZ_HD double abz_prior_draw_base(const abz_prior_dim* pd, uint64_t seed, uint32_t i, uint32_t epoch, uint32_t k, uint32_t sub,
+                                  const abz_tables* T) {
+  if (pd->family >= ABZ_PRIOR_TRUNCATED) return ABZ_NAN;
+  if (pd->family >= ABZ_PRIOR_BETA) return abz_prior_draw_ext(pd, seed, i, epoch, k, T);
+  const abz_u64x2 w = abz_rng(seed, i, epoch, k * 4096u + sub, ABZ_RNG_INIT_AUX);
+  double z0, z1;
+  abz_normal_pair(w, T, &z0, &z1);
+  return abz_prior_draw1(pd, w.w0, z0);
+}
+/* truncated(parent, lo, hi): rejection from the parent (hosts refuse an interval holding less than 1 % of the parent's mass);
+ * attempt a draws at epoch retry | (a + 1) << 20 (the retry number of abcde_init! stays below 2^20).
+ * MixtureModel: the component by inversion of the cumulative weights with one uniform, then that component's own sampler. */
+ABZ_HD double abz_prior_draw_extx(const abz_prior_dim* pd, uint64_t seed, uint32_t i, uint32_t retry, uint32_t k,
+                                  const abz_tables* T, const double* ext) {
+  if (pd->family < ABZ_PRIOR_TRUNCATED) return abz_prior_draw_ext(pd, seed, i, retry, k, T);
+#if !ABZ_HAVE_PRIOR_WRAP
+  return ABZ_NAN;
+#else
+  if (!ext) return ABZ_NAN;
+  if (pd->family == ABZ_PRIOR_TRUNCATED) {
+    const double* rec = ext + (size_t)pd->p0;
+    abz_prior_dim par;
+    abz_ext_desc(rec + 3, &par);
+    for (uint32_t a = 0; a < 4095u; ++a) {
+      const double x = abz_prior_draw_base(&par, seed, i, retry | ((a + 1u) << 20), k, 3000u, T);
+      if (x >= rec[0] && x <= rec[1]) return x;
+    }
+    return abz_isfinite(rec[0]) ? rec[0] : rec[1];
+  }
+  const int K = (int)pd->p0;
+  const double* rec = ext + (size_t)pd->p1;
+  const double u = abz_u01_co(abz_rng(seed, i, retry, k * 4096u + 4000u, ABZ_RNG_INIT_AUX).w0);
+  int j = 0;
+  while (j + 1 < K && !(u < rec[(size_t)j * ABZ_EXT_MIXC + 1])) ++j;
+  abz_prior_dim c;
+  abz_ext_desc(rec + (size_t)j * ABZ_EXT_MIXC + 2, &c);
+  return abz_prior_draw_base(&c, seed, i, retry, k, 4001u, T);
+#endif
 }
 
 /* ------------------------------------------------------------------ ABC kernels (types.jl:26-73) */
@@ -833,6 +952,10 @@ typedef struct abz_model {
   abz_prior_dim prior[ABZ_MAX_D]; /* entries d..ld-1 are ABZ_PRIOR_PAD             */
   const double* mv;   /* NULL, or the maps of a correlated Normal prior (below): host memory for the oracle; the HIP library
                          copies them to the device at context creation                                                    */
+  const double* ext;  /* NULL, or n_ext doubles: the records of the wrapper families (ABZ_PRIOR_TRUNCATED / _MIXTURE); host memory
+                         for the oracle, copied to the device by the HIP library                                           */
+  int32_t n_ext;
+  int32_t reserved0;
 } abz_model;
 
 /* ---- a multivariate prior that is not a product (a Distributions.MvNormal in the `prior` position, src/abcdez_types.jl:16,21:

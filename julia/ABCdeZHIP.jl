@@ -49,6 +49,8 @@ struct AbzModel
     data::Ptr{Float64}
     prior::NTuple{256,AbzPriorDim}
     mv::Ptr{Float64}                      # C_NULL, or [μ | L⁻¹ | L] of an MvNormal prior (include/abcdez_spec.h)
+    ext::Ptr{Float64}                     # C_NULL, or the records of truncated(...) / MixtureModel factors (ABZ_PRIOR_TRUNCATED / _MIXTURE)
+    n_ext::Int32; reserved0::Int32
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
 const MIN_VERSION = 600        # abcdez_comm_init_host, lazily opened RCCL (include/abcdez_hip.h)
@@ -60,7 +62,7 @@ function check_abi()
     lay = Vector{Int32}(undef, 32)
     n = ccall((:abcdez_abi_layout, LIB), Cint, (Ptr{Int32}, Cint), lay, length(lay))
     mine = Int32[sizeof(AbzPriorDim), fieldoffset.(AbzPriorDim, 1:7)...,
-                 sizeof(AbzModel), fieldoffset.(AbzModel, 1:11)...]
+                 sizeof(AbzModel), fieldoffset.(AbzModel, 1:14)...]
     (n == length(mine) && lay[1:n] == mine) || error("ABCdeZHIP: struct layout differs from libabcdez_hip.so (abcdez_abi_layout)")
 end
 
@@ -180,8 +182,37 @@ function descriptor(p::Binomial)
     AbzPriorDim(18, 1, Float64(n), q, lgam(n + 1.0) + n * log1p(-q), log(q) - log1p(-q), 0.0)
 end
 descriptor(p::Geometric) = descriptor(NegativeBinomial(1.0, succprob(p)))
+# wrappers: truncated(d, lo, hi) of any other parent and MixtureModel of univariate components keep their records in the model's ext
+# table (include/abcdez_spec.h, ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE); the descriptor points at them by offset (0-based, in doubles)
+asdoubles(q::AbzPriorDim) = Float64[q.family, q.discrete, q.p0, q.p1, q.c0, q.c1, q.reserved]
+isbase(p) = !(p isa Truncated && !(p.untruncated isa Normal)) && !(p isa MixtureModel)
+function descriptor!(ext::Vector{Float64}, p::Truncated)
+    p.untruncated isa Normal && return descriptor(p)          # keeps its own family (13)
+    isbase(p.untruncated) || error("truncated(): the parent must be one of the base univariate families")
+    lo = p.lower === nothing ? -Inf : Float64(p.lower); hi = p.upper === nothing ? Inf : Float64(p.upper)
+    mass = exp(p.logtp)                                       # Distributions' own log(cdf(hi) - cdf(lo⁻))
+    mass >= 0.01 || error("truncated(): [lo, hi] holds $mass of the parent's mass; the device draws the initial population by " *
+                          "rejection from the parent and needs at least 0.01")
+    par = descriptor(p.untruncated); off = length(ext)
+    append!(ext, [lo, hi, p.logtp]); append!(ext, asdoubles(par))
+    AbzPriorDim(19, par.discrete, Float64(off), 0.0, 0.0, 0.0, 0.0)
+end
+function descriptor!(ext::Vector{Float64}, p::MixtureModel)
+    cs = components(p); w = probs(p); K = length(cs)
+    1 <= K <= 16 || error("MixtureModel: 1 .. 16 components")
+    all(isbase, cs) || error("MixtureModel: components must be base univariate families (no nesting)")
+    ds = descriptor.(cs)
+    all(q -> q.discrete == ds[1].discrete, ds) || error("MixtureModel: the components must be all continuous or all discrete")
+    off = length(ext); cum = 0.0
+    for j in 1:K
+        cum = j == K ? 1.0 : cum + w[j]
+        append!(ext, [log(w[j]), cum]); append!(ext, asdoubles(ds[j]))
+    end
+    AbzPriorDim(20, ds[1].discrete, Float64(K), Float64(off), 0.0, 0.0, 0.0)
+end
+descriptor!(ext::Vector{Float64}, p) = descriptor(p)
 descriptor(p) = error("no device descriptor for a prior of type $(typeof(p)): the univariate families of include/abcdez_spec.h " *
-                      "(ABZ_PRIOR_*), Factored / product_distribution of them and MvNormal are supported")
+                      "(ABZ_PRIOR_*), truncated(...) and MixtureModel of them, Factored / product_distribution of those and MvNormal are supported")
 kernelid(::Type{ABCdeZ.Indicator0toϵ}) = Int32(0);  kernelid(::Type{ABCdeZ.IndicatorStrict0toϵ}) = Int32(1)
 kernelid(::Type{ABCdeZ.Epa0toϵ}) = Int32(2);        kernelid(::Type{ABCdeZ.EpaStrict0toϵ}) = Int32(3)
 
@@ -244,12 +275,14 @@ function Engine(prior, sim::DeviceSimulator, ABCk, seed::Integer, N::Int; comm=n
     check_abi()
     fs = factors(prior); d = length(fs); ld = nextpow(2, d)
     data = simdata(sim); sp = simparams(sim); nb = nblob(sim, d); mv = mvmaps(prior, ld)
+    ext = Float64[]                                           # records of truncated(...) / MixtureModel factors
+    qs = [descriptor!(ext, fs[k]) for k in 1:d]
     m = AbzModel(d, ld, simid(sim), kernelid(ABCk), UInt64(seed), length(data), nb,
                  ntuple(i -> i <= length(sp) ? Float64(sp[i]) : 0.0, 8), isempty(data) ? C_NULL : pointer(data),
-                 ntuple(k -> k <= d ? (q = descriptor(fs[k]); AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 256),
-                 isempty(mv) ? C_NULL : pointer(mv))
+                 ntuple(k -> k <= d ? (q = qs[k]; AbzPriorDim(q.family, pushrule(prior, k, q.discrete), q.p0, q.p1, q.c0, q.c1, q.reserved)) : PAD, 256),
+                 isempty(mv) ? C_NULL : pointer(mv), isempty(ext) ? C_NULL : pointer(ext), Int32(length(ext)), Int32(0))
     ctx = Ref{Ptr{Cvoid}}()
-    GC.@preserve data mv begin
+    GC.@preserve data mv ext begin
         if sim isa UserSimulator
             check(ccall((:abcdez_ctx_create_user, LIB), Cint, (Ref{AbzModel}, Cstring, Cint, Ptr{Ptr{Cvoid}}), m, sim.source, 0, ctx))
         else

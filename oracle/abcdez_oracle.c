@@ -142,6 +142,10 @@ ORC_API uint64_t orc_weight_fix(double w, uint32_t n) { return abz_weight_fix(w,
 ORC_API double orc_u01(uint64_t w, int kind) { return kind == 1 ? abz_u01_open(w) : (kind == 2 ? abz_u01_52(w) : abz_u01_co(w)); }
 ORC_API uint32_t orc_randint(uint64_t w, uint32_t n) { return abz_randint(w, n); }
 ORC_API double orc_prior_logpdf1(const abz_prior_dim* pd, double x) { return abz_prior_logpdf1(pd, x); }
+/* the same for a factor of a MODEL (wrapper families read their records from the model's ext table) */
+ORC_API double orc_model_prior_logpdf(const abz_model* M, int k, double x) { return abz_prior_logpdf1x(&M->prior[k], x, M->ext); }
+/* one draw of factor k as abcde_init! makes it for particle i at retry `retry` (families beyond Normal / (Discrete)Uniform) */
+ORC_API double orc_model_prior_draw_ext(const abz_model* M, int k, uint32_t i, uint32_t retry) { return abz_prior_draw_extx(&M->prior[k], M->seed, i, retry, (uint32_t)k, ORC_T, M->ext); }
 ORC_API double orc_kernel_pdf(int kind, double eps, double x) { return abz_kernel_pdf(kind, eps, x); }
 ORC_API double orc_kernel_logpdf(int kind, double eps, double x) { return abz_kernel_logpdf(kind, eps, x); }
 
@@ -159,15 +163,15 @@ static const double* whitened(const abz_model* M, const double* pushed, double* 
 static double logprior_tree(const abz_model* M, const double* pushed) {
   double t[ABZ_MAX_D], zb[ABZ_MAX_D];
   const double* x = whitened(M, pushed, zb);
-  for (int k = 0; k < M->ld; ++k) t[k] = abz_prior_logpdf1(&M->prior[k], x[k]);
+  for (int k = 0; k < M->ld; ++k) t[k] = abz_prior_logpdf1x(&M->prior[k], x[k], M->ext);
   return abz_tree_sum_small(t, M->ld);
 }
 /* literal: left-to-right sum, priors.jl:41-45 */
 static double logprior_seq(const abz_model* M, const double* pushed) {
   double zb[ABZ_MAX_D];
   const double* x = whitened(M, pushed, zb);
-  double s = abz_prior_logpdf1(&M->prior[0], x[0]);
-  for (int k = 1; k < M->d; ++k) s += abz_prior_logpdf1(&M->prior[k], x[k]);
+  double s = abz_prior_logpdf1x(&M->prior[0], x[0], M->ext);
+  for (int k = 1; k < M->d; ++k) s += abz_prior_logpdf1x(&M->prior[k], x[k], M->ext);
   return s;
 }
 ORC_API void orc_push_p(const abz_model* M, const double* theta, int64_t n, double* out) {
@@ -356,7 +360,7 @@ static void draw_prior_row(const abz_model* M, uint32_t i, uint32_t retry, doubl
     if (2 * m + 1 < M->ld) th[2 * m + 1] = abz_prior_draw1(&M->prior[2 * m + 1], w.w1, z1);
     for (int c = 0; c < 2 && 2 * m + c < M->ld; ++c)
       if (M->prior[2 * m + c].family >= ABZ_PRIOR_BETA)
-        th[2 * m + c] = abz_prior_draw_ext(&M->prior[2 * m + c], M->seed, i, retry, (uint32_t)(2 * m + c), ORC_T);
+        th[2 * m + c] = abz_prior_draw_extx(&M->prior[2 * m + c], M->seed, i, retry, (uint32_t)(2 * m + c), ORC_T, M->ext);
   }
   if (M->mv) {                     /* correlated Normal prior: the row drawn so far is z ~ N(0, I); theta = mu + L z */
     double z[ABZ_MAX_D];

@@ -789,7 +789,14 @@ def _further_family(k, rng):
             lambda: A.Weibull(u(0.7, 4.0), u(0.5, 3.0)), lambda: A.InverseGamma(u(1.5, 5.0), u(0.5, 3.0)),
             lambda: A.truncated(A.Normal(u(-1.0, 1.0), u(0.5, 2.0)), u(-2.0, -0.2), None if rng.random() < 0.4 else u(0.5, 3.0)),
             lambda: A.Logistic(u(-1.0, 1.0), u(0.3, 1.5)), lambda: A.TDist(u(1.0, 8.0)), lambda: A.Pareto(u(1.0, 4.0), u(0.2, 1.5)),
-            lambda: A.Poisson(u(0.5, 12.0)), lambda: A.Binomial(int(rng.integers(1, 40)), u(0.1, 0.9))][k]()
+            lambda: A.Poisson(u(0.5, 12.0)), lambda: A.Binomial(int(rng.integers(1, 40)), u(0.1, 0.9)),
+            # the wrapper families (ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE): truncations of other parents, mixtures
+            lambda: A.truncated(A.Gamma(u(1.0, 4.0), u(0.5, 1.5)), u(0.2, 0.8), None if rng.random() < 0.5 else u(3.0, 8.0)),
+            lambda: A.truncated(A.Cauchy(u(-1.0, 1.0), u(0.5, 2.0)), u(-3.0, -1.0), u(1.0, 4.0)),
+            lambda: A.truncated(A.Poisson(u(2.0, 8.0)), int(rng.integers(0, 3)), int(rng.integers(6, 14))),
+            lambda: A.MixtureModel([A.Normal(u(-2.0, 0.0), u(0.3, 1.0)), A.Normal(u(0.5, 3.0), u(0.3, 1.5)), A.Laplace(u(-1.0, 1.0), u(0.5, 2.0))],
+                                   [0.25, 0.45, 0.30]),
+            lambda: A.MixtureModel([A.Poisson(u(0.5, 3.0)), A.Binomial(int(rng.integers(3, 20)), u(0.2, 0.8))], [0.35, 0.65])][k]()
 
 
 def _random_model(seed, nfam=5):
@@ -858,3 +865,11 @@ def test_random_models_of_every_prior_family_end_to_end_parity(oracle, seed):
     """the same with all 18 univariate families the device knows (`prior::Distribution`, src/abcdez_smc.jl:165): heavy tails,
     half lines, truncations, counts -- their samplers at the initial population, their log-densities in every sweep"""
     _random_model_case(oracle, seed, 18)
+
+
+@pytest.mark.parametrize("seed", list(range(200, 216)))
+def test_random_models_with_truncated_and_mixture_priors_end_to_end_parity(oracle, seed):
+    """and with the wrapper families among the factors -- truncated(d, lo, hi) of Gamma / Cauchy / Poisson parents, MixtureModel of
+    continuous and of counting components (records in the model's ext table): rejection and inversion samplers at the initial
+    population, log-sum-exp densities in every sweep, replayed log-priors -- HIP == oracle bit for bit"""
+    _random_model_case(oracle, seed, 23)

@@ -23,7 +23,7 @@ class ShimEngine:
         self.lib = _lib.load()
         self.spec = A.ModelSpec(prior, sim, ABCk, seed=seed)
         lay = (C.c_int32 * 32)()                                    # check_abi()
-        assert self.lib.abcdez_abi_layout(lay, 32) == 20
+        assert self.lib.abcdez_abi_layout(lay, 32) == 23
         self._data = np.ascontiguousarray(self.spec.data, dtype=np.float64)
         m = self.spec.cstruct(self._data.ctypes.data if self._data.size else None)
         ctx = C.c_void_p()

@@ -132,7 +132,7 @@ def test_abi_layout_of_the_hand_mirrored_structs():
     n = lib.abcdez_abi_layout(out, 32)
     mine = [ctypes.sizeof(PriorDim)] + [getattr(PriorDim, f).offset for f, _ in PriorDim._fields_] + \
            [ctypes.sizeof(Model)] + [getattr(Model, f).offset for f, _ in Model._fields_]
-    assert n == len(mine) == 20 and list(out[:n]) == mine
+    assert n == len(mine) == 23 and list(out[:n]) == mine
     jl = open(os.path.join(ROOT, "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
     body = lambda name: re.search(r"struct %s\n(.*?)\nend" % name, jl, re.S).group(1)
     fields = lambda name: re.findall(r"(\w+)::", re.sub(r"#.*", "", body(name)))
@@ -383,7 +383,13 @@ def test_prior_family_ids_agree_between_header_python_and_julia():
                 "LOGNORMAL": priors.LogNormal(), "CAUCHY": priors.Cauchy(), "LAPLACE": priors.Laplace(), "WEIBULL": priors.Weibull(),
                 "INVGAMMA": priors.InverseGamma(), "TRUNCNORMAL": priors.TruncatedNormal(), "LOGISTIC": priors.Logistic(),
                 "TDIST": priors.TDist(), "PARETO": priors.Pareto(), "POISSON": priors.Poisson(), "BINOMIAL": priors.Binomial()}
-    assert set(julia_name) == set(ids) - {"PAD"}
+    assert set(julia_name) == set(ids) - {"PAD", "TRUNCATED", "MIXTURE"}
+    # the wrapper families: their descriptors point into the ext table (descriptor! in the shim, descriptor_at here)
+    tr, mx = priors.truncated(priors.Gamma(2.0, 1.0), 0.5, 4.0), priors.MixtureModel([priors.Normal(), priors.Laplace()], [0.3, 0.7])
+    assert tr.descriptor_at(5)[:3] == (ids["TRUNCATED"], 0, 5.0) and mx.descriptor_at(7)[:4] == (ids["MIXTURE"], 0, 2.0, 7.0)
+    assert len(tr.ext_record()) == 3 + 7 and len(mx.ext_record()) == 2 * (2 + 7)
+    assert "AbzPriorDim(19, par.discrete, Float64(off), 0.0, 0.0, 0.0, 0.0)" in jl and "AbzPriorDim(20, ds[1].discrete, Float64(K), Float64(off)" in jl
+    assert re.search(r"#define ABZ_EXT_TRUNC \(3 \+ ABZ_EXT_DESC\)", hdr) and re.search(r"#define ABZ_EXT_MIXC \(2 \+ ABZ_EXT_DESC\)", hdr)
     for name, jn in julia_name.items():
         at = jl.index("descriptor(p::%s)" % jn)
         m = re.search(r"AbzPriorDim\((\d+), (\d),", jl[at:])

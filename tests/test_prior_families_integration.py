@@ -33,7 +33,41 @@ CASES = {
     "Poisson": (lambda: A.Poisson(4.0), stats.poisson(4.0), True),
     "Binomial": (lambda: A.Binomial(12, 0.3), stats.binom(12, 0.3), True),
     "Geometric": (lambda: A.Geometric(0.25), stats.geom(0.25, loc=-1), True),
+    # the wrapper families (include/abcdez_spec.h: ABZ_PRIOR_TRUNCATED, ABZ_PRIOR_MIXTURE): truncated(d, lo, hi) of a parent other
+    # than Normal, MixtureModel of univariate components -- continuous and counting
+    "truncated(Gamma)": (lambda: A.truncated(A.Gamma(2.0, 1.5), 1.0, 6.0), None, False),
+    "truncated(Cauchy)": (lambda: A.truncated(A.Cauchy(0.0, 2.0), -1.0, None), None, False),
+    "truncated(Poisson)": (lambda: A.truncated(A.Poisson(4.0), 2, 9), None, True),
+    "MixtureModel(Normal, Normal, Laplace)": (lambda: A.MixtureModel([A.Normal(-1.0, 0.5), A.Normal(2.5, 1.0), A.Laplace(0.0, 2.0)],
+                                                                     [0.2, 0.5, 0.3]), None, False),
+    "MixtureModel(Poisson, Binomial)": (lambda: A.MixtureModel([A.Poisson(2.0), A.Binomial(12, 0.4)], [0.4, 0.6]), None, True),
 }
+
+
+class Wrapped:
+    """scipy-backed reference of a wrapper prior: pdf / pmf / support built from scipy's distributions of the parents"""
+
+    def __init__(self, name):
+        g, c, po = stats.gamma(2.0, scale=1.5), stats.cauchy(0.0, 2.0), stats.poisson(4.0)
+        if name == "truncated(Gamma)":
+            z = g.cdf(6.0) - g.cdf(1.0)
+            self.f, self.sup = (lambda t: np.where((t >= 1.0) & (t <= 6.0), g.pdf(t) / z, 0.0)), (1.0, 6.0)
+        elif name == "truncated(Cauchy)":
+            z = 1.0 - c.cdf(-1.0)
+            self.f, self.sup = (lambda t: np.where(t >= -1.0, c.pdf(t) / z, 0.0)), (-1.0, np.inf)
+        elif name == "truncated(Poisson)":
+            z = po.cdf(9) - po.cdf(1)
+            self.f, self.sup = (lambda k: np.where((k >= 2) & (k <= 9), po.pmf(k) / z, 0.0)), (2, 9)
+        elif name.startswith("MixtureModel(Normal"):
+            self.f = lambda t: 0.2 * stats.norm(-1.0, 0.5).pdf(t) + 0.5 * stats.norm(2.5, 1.0).pdf(t) + 0.3 * stats.laplace(0.0, 2.0).pdf(t)
+            self.sup = (-np.inf, np.inf)
+        else:
+            self.f, self.sup = (lambda k: 0.4 * stats.poisson(2.0).pmf(k) + 0.6 * stats.binom(12, 0.4).pmf(k)), (0, np.inf)
+
+    pdf = pmf = lambda self, t: self.f(np.asarray(t, dtype=float))
+
+    def support(self):
+        return self.sup
 
 
 def exact(ref, discrete):
@@ -69,6 +103,7 @@ def run_mc(oracle, backend, prior, **kw):
 @pytest.mark.parametrize("name", list(CASES))
 def test_evidence_and_posterior_mean_under_each_prior_family(oracle, backend, name):
     make, ref, discrete = CASES[name]
+    ref = ref if ref is not None else Wrapped(name)
     Z, mean = exact(ref, discrete)
     prior = make()
     r = run_smc(oracle, backend, prior, nparticles=8000, rng=21)
@@ -88,8 +123,16 @@ def test_evidence_and_posterior_mean_under_each_prior_family(oracle, backend, na
 def test_unsupported_priors_are_refused_loudly():
     with pytest.raises(ValueError, match="at least 0.01"):
         A.truncated(A.Normal(0.0, 1.0), 4.0, 5.0)
-    with pytest.raises(TypeError, match="only a Normal parent"):
-        A.truncated(A.Gamma(2.0, 1.0), 0.0, 1.0)
+    with pytest.raises(ValueError, match="at least 0.01"):                 # any parent: the rejection sampler's limit
+        A.truncated(A.Gamma(2.0, 1.0), 30.0, 40.0)
+    with pytest.raises(TypeError, match="base univariate families"):       # no wrapper inside a wrapper
+        A.truncated(A.truncated(A.Gamma(2.0, 1.0), 0.5, 3.0), 1.0, 2.0)
+    with pytest.raises(TypeError, match="no nesting"):
+        A.MixtureModel([A.truncated(A.Gamma(2.0, 1.0), 0.5, 3.0), A.Normal()])
+    with pytest.raises(TypeError, match="all continuous or all discrete"):
+        A.MixtureModel([A.Poisson(2.0), A.Normal()])
+    with pytest.raises(ValueError, match="summing to 1"):
+        A.MixtureModel([A.Normal(), A.Normal(1.0, 2.0)], [0.5, 0.6])
     with pytest.raises(ValueError, match="700"):
         A.Poisson(1e4)
     with pytest.raises(ValueError, match="0 < p < 1"):
