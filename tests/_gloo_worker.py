@@ -33,6 +33,10 @@ def cases():
         # accepted rows themselves
         "further5": (A.Factored(A.Gamma(2.5, 0.6), A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0), A.LogNormal(0.0, 0.5), A.Poisson(2.0),
                                 A.TDist(4.0)), A.MVNormal((1.0, 0.5, 0.8, 2.0, 0.3)), 2.0, 528),
+        # the wrapper families (ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE): the HIP engine compiles this model's sweep, REPLAY and abcdemc
+        # kernels at run time (csrc/abz_jit.hip); the replicas rebuild log-sum-exp log-priors
+        "wrapped4": (A.Factored(A.truncated(A.Gamma(2.0, 1.0), 0.3, 5.0), A.MixtureModel([A.Normal(-1.0, 0.5), A.Laplace(1.0, 1.5)], [0.4, 0.6]),
+                                A.Normal(0.5, 1.0), A.truncated(A.Poisson(4.0), 1, 9)), A.MVNormal((1.0, 0.5, 0.8, 3.0)), 1.5, 528),
     }
 
 
