@@ -14,7 +14,7 @@ from .kernels import (  # noqa: F401
     IndicatorStrict0toeps, IndicatorStrict0toϵ,
 )
 from .model import ModelSpec  # noqa: F401
-from .priors import (Beta, Binomial, Cauchy, Chisq, DiscreteUniform, Erlang, Exponential, Factored, Gamma, Geometric,  # noqa: F401
+from .priors import (Affine, Beta, Binomial, Cauchy, Chisq, DiscreteUniform, Erlang, Exponential, Factored, Gamma, Geometric,  # noqa: F401
                      InverseGamma, Laplace, Logistic, LogNormal, MixtureModel, MvNormal, NegativeBinomial, Normal, Pareto, Poisson, Product,
                      Rayleigh, TDist, Truncated, TruncatedNormal, Uniform, Weibull, prior_cdf, product_distribution, push_p, truncated)
 from .simulators import (  # noqa: F401

@@ -172,6 +172,19 @@ static std::string prior_dim_problem(const abz_prior_dim& pd, const double* ext,
       if ((par.discrete != 0) != (pd.discrete != 0)) return "truncated(...): the discrete flag must be the parent's";
       return prior_dim_problem(par, ext, n_ext, true);
     }
+    case ABZ_PRIOR_AFFINE: {
+      if (nested) return "a wrapper family inside a wrapper";
+      const double off = p0;
+      if (!ext || !(off >= 0.0 && off == abz_rint(off) && off + ABZ_EXT_AFFINE <= (double)n_ext)) return "mu + sigma * d: record outside the ext table";
+      const double* rec = ext + (size_t)off;
+      if (!(fin(rec[0]) && pos(rec[1]) && fabs(rec[2] * rec[1] - 1.0) < 1e-12 && fabs(rec[3] - log(rec[1])) < 1e-12))
+        return "mu + sigma * d: need a finite mu, sigma > 0 and the record's 1 / sigma and log sigma to match";
+      abz_prior_dim par;
+      abz_ext_desc(rec + 4, &par);
+      if (par.family <= ABZ_PRIOR_PAD || par.family > ABZ_PRIOR_LAST) return "mu + sigma * d: unknown parent family";
+      if (par.discrete || pd.discrete) return "mu + sigma * d: the parent must be continuous";
+      return prior_dim_problem(par, ext, n_ext, true);
+    }
     case ABZ_PRIOR_MIXTURE: {
       if (nested) return "a wrapper family inside a wrapper";
       const double K = p0, off = p1;

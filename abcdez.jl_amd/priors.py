@@ -17,7 +17,7 @@ PRIOR_PAD, PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_DUNIFORM, PRIOR_BETA, PRIOR_NEGBIN
 (PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL, PRIOR_CAUCHY, PRIOR_LAPLACE, PRIOR_WEIBULL, PRIOR_INVGAMMA, PRIOR_TRUNCNORMAL,
  PRIOR_LOGISTIC, PRIOR_TDIST, PRIOR_PARETO, PRIOR_POISSON, PRIOR_BINOMIAL) = range(6, 19)
 # wrappers around the families above; their records live in the model's ext table (ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE)
-PRIOR_TRUNCATED, PRIOR_MIXTURE = 19, 20
+PRIOR_TRUNCATED, PRIOR_MIXTURE, PRIOR_AFFINE = 19, 20, 21
 MAX_MIX = 16
 
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
@@ -777,7 +777,7 @@ class Truncated(UnivariateDistribution):
     family = PRIOR_TRUNCATED
 
     def __init__(self, parent, lo: float = -math.inf, hi: float = math.inf):
-        if not isinstance(parent, UnivariateDistribution) or isinstance(parent, (Truncated, MixtureModel)):
+        if not isinstance(parent, UnivariateDistribution) or isinstance(parent, (Truncated, MixtureModel, Affine)):
             raise TypeError("truncated(): the parent must be one of the base univariate families")
         if not lo < hi:
             raise ValueError("truncated(): need lower < upper")
@@ -822,6 +822,42 @@ class Truncated(UnivariateDistribution):
         return f"truncated({self.parent!r}, {self.lo}, {self.hi})"
 
 
+class Affine(UnivariateDistribution):
+    """``μ + σ * d`` of Distributions.jl (``LocationScale`` / ``AffineDistribution``) for a continuous base family d and σ > 0
+    (ABZ_PRIOR_AFFINE): logpdf(x) = d.logpdf((x − μ) / σ) − log σ; the initial population draws μ + σ · (a draw of d)."""
+    family = PRIOR_AFFINE
+    discrete = False
+
+    def __init__(self, parent, mu: float = 0.0, sigma: float = 1.0):
+        if not isinstance(parent, UnivariateDistribution) or isinstance(parent, (Truncated, MixtureModel, Affine)) or parent.discrete:
+            raise TypeError("Affine: the parent must be one of the continuous base univariate families")
+        if not (sigma > 0 and math.isfinite(sigma) and math.isfinite(mu)):
+            raise ValueError("Affine: need a finite μ and σ > 0")
+        self.parent, self.mu, self.sigma = parent, float(mu), float(sigma)
+
+    def insupport(self, x) -> bool:
+        return self.parent.insupport((x - self.mu) / self.sigma)
+
+    def logpdf(self, x) -> float:
+        return self.parent.logpdf((x - self.mu) * (1.0 / self.sigma)) - math.log(self.sigma)
+
+    def pdf(self, x) -> float:
+        return math.exp(self.logpdf(x))
+
+    def rand(self, rng):
+        return self.mu + self.sigma * self.parent.rand(rng)
+
+    def ext_record(self):
+        """[μ, σ, 1 / σ, log σ, parent descriptor (7)]"""
+        return [self.mu, self.sigma, 1.0 / self.sigma, math.log(self.sigma)] + [float(v) for v in _full7(self.parent)]
+
+    def descriptor_at(self, offset: int):
+        return (PRIOR_AFFINE, 0, float(offset), 0.0, 0.0, 0.0, 0.0)
+
+    def __repr__(self) -> str:
+        return f"{self.mu} + {self.sigma} * {self.parent!r}"
+
+
 class MixtureModel(UnivariateDistribution):
     """``MixtureModel(components, weights)`` of Distributions.jl with univariate components of this module's base families, all
     continuous or all discrete (ABZ_PRIOR_MIXTURE): logpdf = log-sum-exp of log w_j + logpdf_j; the initial population draws the
@@ -833,7 +869,7 @@ class MixtureModel(UnivariateDistribution):
         if not 1 <= len(comps) <= MAX_MIX:
             raise ValueError(f"MixtureModel: 1 .. {MAX_MIX} components")
         for c in comps:
-            if not isinstance(c, UnivariateDistribution) or isinstance(c, (Truncated, MixtureModel)):
+            if not isinstance(c, UnivariateDistribution) or isinstance(c, (Truncated, MixtureModel, Affine)):
                 raise TypeError("MixtureModel: components must be base univariate families (no nesting)")
         if len({bool(c.discrete) for c in comps}) != 1:
             raise TypeError("MixtureModel: the components must be all continuous or all discrete (push_p has one rule per parameter)")

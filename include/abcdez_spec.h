@@ -393,11 +393,15 @@ enum {
   ABZ_PRIOR_MIXTURE = 20,     /* MixtureModel(components, weights) of univariate components: p0 = K, p1 = offset in ext of K
                                  records [log w_j, cumulative weight, component descriptor (7 doubles)]; logpdf = log-sum-exp of
                                  log w_j + logpdf_j; `discrete` = the components' (all alike)                                    */
-  ABZ_PRIOR_LAST = 20
+  ABZ_PRIOR_AFFINE = 21,      /* mu + sigma * parent (Distributions' `d * sigma + mu`, LocationScale / AffineDistribution) of a continuous
+                                 parent, sigma > 0: p0 = offset in ext of [mu, sigma, 1 / sigma, log sigma, parent descriptor (7)];
+                                 logpdf(x) = parent((x - mu) / sigma) - log sigma                                                */
+  ABZ_PRIOR_LAST = 21
 };
 #define ABZ_EXT_DESC 7        /* a descriptor stored as doubles: family, discrete, p0, p1, c0, c1, reserved */
 #define ABZ_EXT_TRUNC (3 + ABZ_EXT_DESC)
 #define ABZ_EXT_MIXC (2 + ABZ_EXT_DESC)
+#define ABZ_EXT_AFFINE (4 + ABZ_EXT_DESC)
 #define ABZ_MAX_MIX 16        /* components per mixture */
 
 typedef struct {    /* 48 bytes = three 16-byte loads */
@@ -460,6 +464,12 @@ ABZ_HD double abz_prior_logpdf_wrapped(const abz_prior_dim* pd, double x, const 
     abz_prior_dim par;
     abz_ext_desc(rec + 3, &par);
     return abz_prior_logpdf_base(&par, x) - rec[2];
+  }
+  if (pd->family == ABZ_PRIOR_AFFINE) {
+    const double* rec = ext + (size_t)pd->p0;
+    abz_prior_dim par;
+    abz_ext_desc(rec + 4, &par);
+    return abz_prior_logpdf_base(&par, (x - rec[0]) * rec[2]) - rec[3];
   }
   /* mixture: log-sum-exp around the largest term, terms added in component order.  Two passes over the components instead of an
    * array of terms: a dynamically indexed local array would live in scratch memory on the device -- for every kernel that merely
@@ -740,6 +750,12 @@ ABZ_HD double abz_prior_draw_extx(const abz_prior_dim* pd, uint64_t seed, uint32
       if (x >= rec[0] && x <= rec[1]) return x;
     }
     return abz_isfinite(rec[0]) ? rec[0] : rec[1];
+  }
+  if (pd->family == ABZ_PRIOR_AFFINE) {
+    const double* rec = ext + (size_t)pd->p0;
+    abz_prior_dim par;
+    abz_ext_desc(rec + 4, &par);
+    return abz_fma(rec[1], abz_prior_draw_base(&par, seed, i, retry, k, 3000u, T), rec[0]);
   }
   const int K = (int)pd->p0;
   const double* rec = ext + (size_t)pd->p1;

@@ -185,7 +185,7 @@ descriptor(p::Geometric) = descriptor(NegativeBinomial(1.0, succprob(p)))
 # wrappers: truncated(d, lo, hi) of any other parent and MixtureModel of univariate components keep their records in the model's ext
 # table (include/abcdez_spec.h, ABZ_PRIOR_TRUNCATED / ABZ_PRIOR_MIXTURE); the descriptor points at them by offset (0-based, in doubles)
 asdoubles(q::AbzPriorDim) = Float64[q.family, q.discrete, q.p0, q.p1, q.c0, q.c1, q.reserved]
-isbase(p) = !(p isa Truncated && !(p.untruncated isa Normal)) && !(p isa MixtureModel)
+isbase(p) = !(p isa Truncated && !(p.untruncated isa Normal)) && !(p isa MixtureModel) && !(p isa Distributions.AffineDistribution)
 function descriptor!(ext::Vector{Float64}, p::Truncated)
     p.untruncated isa Normal && return descriptor(p)          # keeps its own family (13)
     isbase(p.untruncated) || error("truncated(): the parent must be one of the base univariate families")
@@ -209,6 +209,16 @@ function descriptor!(ext::Vector{Float64}, p::MixtureModel)
         append!(ext, [log(w[j]), cum]); append!(ext, asdoubles(ds[j]))
     end
     AbzPriorDim(20, ds[1].discrete, Float64(K), Float64(off), 0.0, 0.0, 0.0)
+end
+# μ + σ * d (Distributions.LocationScale / AffineDistribution) of a continuous base family, σ > 0: family 21
+function descriptor!(ext::Vector{Float64}, p::Distributions.AffineDistribution)
+    μ, σ, ρ = Float64(p.μ), Float64(p.σ), p.ρ
+    (σ > 0 && isfinite(σ) && isfinite(μ)) || error("μ + σ * d: need a finite μ and σ > 0")
+    (isbase(ρ) && !(ρ isa Distributions.AffineDistribution) && ρ isa ContinuousUnivariateDistribution) ||
+        error("μ + σ * d: the parent must be one of the continuous base univariate families")
+    off = length(ext)
+    append!(ext, [μ, σ, 1 / σ, log(σ)]); append!(ext, asdoubles(descriptor(ρ)))
+    AbzPriorDim(21, 0, Float64(off), 0.0, 0.0, 0.0, 0.0)
 end
 descriptor!(ext::Vector{Float64}, p) = descriptor(p)
 descriptor(p) = error("no device descriptor for a prior of type $(typeof(p)): the univariate families of include/abcdez_spec.h " *

@@ -30,6 +30,10 @@ TRUNCATED = [  # (parent, params, lo, hi) -- None = unbounded
     ("Beta", [2.0, 3.0], 0.1, 0.7), ("Uniform", [-1.0, 3.0], 0.0, 2.0), ("Poisson", [4.0], 2, 9), ("Binomial", [12, 0.3], 1, 6),
     ("NegativeBinomial", [4.6, 0.13], 5, 60), ("DiscreteUniform", [1, 10], 3, 7),
 ]
+AFFINE = [  # (parent, params, mu, sigma): mu + sigma * parent
+    ("TDist", [4.0], 1.0, 2.0), ("Gamma", [2.5, 0.6], -1.0, 3.0), ("Beta", [2.0, 3.0], 10.0, 5.0), ("Logistic", [0.0, 1.0], 2.0, 0.25),
+    ("Exponential", [1.0], 0.5, 0.1),
+]
 MIXTURES = [  # ([(family, params), ...], weights)
     ([("Normal", [-1.0, 0.5]), ("Normal", [2.0, 1.0]), ("Laplace", [0.0, 2.0])], [0.2, 0.5, 0.3]),
     ([("Gamma", [2.0, 1.0]), ("Exponential", [0.5])], [0.6, 0.4]),
@@ -69,6 +73,13 @@ for fam, p, lo, hi in TRUNCATED:
         lp = logpmf_or_pdf(ref, fam, x) - math.log(mass) if inside else -math.inf
         pts.append({"x": x, "logpdf": enc(lp if np.isfinite(lp) else -math.inf)})
     cases.append({"kind": "truncated", "parent": fam, "p": p, "lo": lo, "hi": hi, "mass": float(mass), "points": pts})
+for fam, p, mu, sg in AFFINE:
+    ref = PARENTS[fam](*p)
+    pts = []
+    for x in points(mu - 3.0 * sg, mu + 6.0 * sg, False):
+        lp = float(ref.logpdf((x - mu) / sg)) - math.log(sg)
+        pts.append({"x": x, "logpdf": enc(lp if np.isfinite(lp) else -math.inf)})
+    cases.append({"kind": "affine", "parent": fam, "p": p, "mu": mu, "sigma": sg, "points": pts})
 for comps, w in MIXTURES:
     disc = comps[0][0] in DISCRETE
     pts = []

@@ -796,7 +796,8 @@ def _further_family(k, rng):
             lambda: A.truncated(A.Poisson(u(2.0, 8.0)), int(rng.integers(0, 3)), int(rng.integers(6, 14))),
             lambda: A.MixtureModel([A.Normal(u(-2.0, 0.0), u(0.3, 1.0)), A.Normal(u(0.5, 3.0), u(0.3, 1.5)), A.Laplace(u(-1.0, 1.0), u(0.5, 2.0))],
                                    [0.25, 0.45, 0.30]),
-            lambda: A.MixtureModel([A.Poisson(u(0.5, 3.0)), A.Binomial(int(rng.integers(3, 20)), u(0.2, 0.8))], [0.35, 0.65])][k]()
+            lambda: A.MixtureModel([A.Poisson(u(0.5, 3.0)), A.Binomial(int(rng.integers(3, 20)), u(0.2, 0.8))], [0.35, 0.65]),
+            lambda: A.Affine(A.TDist(u(2.0, 8.0)), u(-1.0, 2.0), u(0.3, 2.5)), lambda: A.Affine(A.Beta(u(1.0, 4.0), u(1.0, 4.0)), u(-2.0, 0.0), u(2.0, 6.0))][k]()
 
 
 def _random_model(seed, nfam=5):
@@ -870,6 +871,6 @@ def test_random_models_of_every_prior_family_end_to_end_parity(oracle, seed):
 @pytest.mark.parametrize("seed", list(range(200, 216)))
 def test_random_models_with_truncated_and_mixture_priors_end_to_end_parity(oracle, seed):
     """and with the wrapper families among the factors -- truncated(d, lo, hi) of Gamma / Cauchy / Poisson parents, MixtureModel of
-    continuous and of counting components (records in the model's ext table): rejection and inversion samplers at the initial
+    continuous and of counting components, mu + sigma * d of a TDist / Beta (records in the model's ext table): rejection and inversion samplers at the initial
     population, log-sum-exp densities in every sweep, replayed log-priors -- HIP == oracle bit for bit"""
-    _random_model_case(oracle, seed, 23)
+    _random_model_case(oracle, seed, 25)

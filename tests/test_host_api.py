@@ -383,7 +383,10 @@ def test_prior_family_ids_agree_between_header_python_and_julia():
                 "LOGNORMAL": priors.LogNormal(), "CAUCHY": priors.Cauchy(), "LAPLACE": priors.Laplace(), "WEIBULL": priors.Weibull(),
                 "INVGAMMA": priors.InverseGamma(), "TRUNCNORMAL": priors.TruncatedNormal(), "LOGISTIC": priors.Logistic(),
                 "TDIST": priors.TDist(), "PARETO": priors.Pareto(), "POISSON": priors.Poisson(), "BINOMIAL": priors.Binomial()}
-    assert set(julia_name) == set(ids) - {"PAD", "TRUNCATED", "MIXTURE"}
+    assert set(julia_name) == set(ids) - {"PAD", "TRUNCATED", "MIXTURE", "AFFINE"}
+    af = priors.Affine(priors.TDist(4.0), 1.0, 2.0)
+    assert af.descriptor_at(3)[:3] == (ids["AFFINE"], 0, 3.0) and len(af.ext_record()) == 4 + 7
+    assert "AbzPriorDim(21, 0, Float64(off), 0.0, 0.0, 0.0, 0.0)" in jl and re.search(r"#define ABZ_EXT_AFFINE \(4 \+ ABZ_EXT_DESC\)", hdr)
     # the wrapper families: their descriptors point into the ext table (descriptor! in the shim, descriptor_at here)
     tr, mx = priors.truncated(priors.Gamma(2.0, 1.0), 0.5, 4.0), priors.MixtureModel([priors.Normal(), priors.Laplace()], [0.3, 0.7])
     assert tr.descriptor_at(5)[:3] == (ids["TRUNCATED"], 0, 5.0) and mx.descriptor_at(7)[:4] == (ids["MIXTURE"], 0, 2.0, 7.0)

@@ -41,6 +41,7 @@ CASES = {
     "MixtureModel(Normal, Normal, Laplace)": (lambda: A.MixtureModel([A.Normal(-1.0, 0.5), A.Normal(2.5, 1.0), A.Laplace(0.0, 2.0)],
                                                                      [0.2, 0.5, 0.3]), None, False),
     "MixtureModel(Poisson, Binomial)": (lambda: A.MixtureModel([A.Poisson(2.0), A.Binomial(12, 0.4)], [0.4, 0.6]), None, True),
+    "2 + 1.5 * TDist": (lambda: A.Affine(A.TDist(3.0), 2.0, 1.5), stats.t(3.0, loc=2.0, scale=1.5), False),
 }
 
 

@@ -28,12 +28,16 @@ FAM = {"Gamma": A.Gamma, "Cauchy": A.Cauchy, "Exponential": A.Exponential, "LogN
 def build(case):
     if case["kind"] == "truncated":
         return A.truncated(FAM[case["parent"]](*case["p"]), case["lo"], case["hi"])
+    if case["kind"] == "affine":
+        return A.Affine(FAM[case["parent"]](*case["p"]), case["mu"], case["sigma"])
     return A.MixtureModel([FAM[f](*p) for f, p in case["components"]], case["weights"])
 
 
 def label(case):
     if case["kind"] == "truncated":
         return f"truncated({case['parent']}{tuple(case['p'])}, {case['lo']}, {case['hi']})"
+    if case["kind"] == "affine":
+        return f"{case['mu']} + {case['sigma']} * {case['parent']}{tuple(case['p'])}"
     return "MixtureModel(" + ", ".join(f for f, _ in case["components"]) + ")"
 
 
@@ -62,7 +66,7 @@ def test_logpdf_of_wrapper_families_equals_scipy(oracle, case):
         assert abs(dist.mass() - case["mass"]) < 1e-14, (dist.mass(), case["mass"])       # the host's own cdfs (abcdez_amd/priors.py)
     # the wrapped factor in the middle of a model: offsets into the ext table are not all zero
     spec = ModelSpec(A.Factored(A.truncated(A.Gamma(2.0, 1.0), 0.5, 4.0), dist, A.Normal(0, 1)), A.MVNormal((1.0, 1.0, 1.0)))
-    assert spec.ext is not None and spec._desc[1][0] in (19, 20)
+    assert spec.ext is not None and spec._desc[1][0] in (19, 20, 21)
     m = oracle.OracleModel(spec)
     f = model_logpdf(oracle)
     for pt in case["points"]:
@@ -120,6 +124,8 @@ def test_samplers_of_wrapper_families_follow_their_laws(oracle):
     assert np.array_equal(k, np.rint(k)) and k.min() >= 2 and k.max() <= 9
     exp = po.pmf(np.arange(2, 10)) / (po.cdf(9) - po.cdf(1)) * k.size
     assert stats.chisquare(np.bincount(k.astype(int), minlength=10)[2:10], exp).pvalue > 1e-3
+    x = draws(oracle, A.Affine(A.TDist(4.0), 1.0, 2.0))                        # mu + sigma * d: the parent's sampler, moved and scaled
+    assert stats.kstest(x, stats.t(4.0, loc=1.0, scale=2.0).cdf).pvalue > 1e-3
     mix = A.MixtureModel([A.Normal(-1.0, 0.5), A.Normal(2.0, 1.0), A.Laplace(0.0, 2.0)], [0.2, 0.5, 0.3])
     x = draws(oracle, mix)
     cdf = lambda t: 0.2 * stats.norm(-1, 0.5).cdf(t) + 0.5 * stats.norm(2, 1).cdf(t) + 0.3 * stats.laplace(0, 2).cdf(t)       # noqa: E731
@@ -173,13 +179,17 @@ def test_c_abi_validates_wrapper_records_and_family_parameters():
     bad(tr, lambda cm, ext: ext.__setitem__(3, 19.0), "inside a wrapper")
     bad(tr, lambda cm, ext: ext.__setitem__(3 + 3, -2.0), "scale > 0")                          # the PARENT's parameters are checked too
     bad(tr, lambda cm, ext: setattr(cm, "ext", None), "ext / n_ext mismatch")
+    af = A.Affine(A.TDist(4.0), 1.0, 2.0)
+    bad(af, lambda cm, ext: ext.__setitem__(1, -2.0), "sigma > 0")
+    bad(af, lambda cm, ext: ext.__setitem__(2, 0.7), "to match")
+    bad(af, lambda cm, ext: ext.__setitem__(4 + 1, 1.0), "must be continuous")
     mx = A.MixtureModel([A.Normal(0, 1), A.Laplace(1.0, 2.0)], [0.3, 0.7])
     bad(mx, setp("p0", 17.0), "1 .. 16 components")
     bad(mx, lambda cm, ext: ext.__setitem__(9 + 1, 0.9), "sum to 1")
     bad(mx, lambda cm, ext: ext.__setitem__(2 + 1, 1.0), "all continuous or all discrete")      # a component that claims to be discrete
     bad(mx, lambda cm, ext: ext.__setitem__(9 + 2, 20.0), "inside a wrapper")
     # a well-formed model passes the validation and fails later only for want of a device (or succeeds on a GPU box)
-    rc, msg = create(A.Factored(tr, mx, A.Poisson(3.0)))
+    rc, msg = create(A.Factored(tr, mx, A.Poisson(3.0), af))
     assert rc == 0 or "prior factor" not in msg, msg
     if rc == 0:
         lib.abcdez_ctx_destroy(ctx)

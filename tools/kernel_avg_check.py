@@ -45,7 +45,8 @@ else:
     timed = [window[st * per_step + (st % per_step)] for st in range(0, steps, stride) if st * per_step + (st % per_step) < len(window)][:n]
 upl = win["updates"] / max(ran, 1)
 avg = sum(worked) / len(worked)
-b_read = roof.get("bytes_read_per_update")
+# the bytes `roofline.frac` counts: SURVEY 8d's algorithmic reads, or -- rows of one or two doubles -- the fabric line fills
+b_read = roof.get("line_fill_bytes_per_update") or roof.get("bytes_read_per_update")
 out = {
     "kernel": kernel, "same_run": True, "command_steps_warmup": [steps, int(doc["warmup"])],
     "bench_hip_events_avg_launch_ms": roof["avg_launch_ms"], "bench_launches": n, "timed_every_nth_step": stride,
