@@ -90,15 +90,9 @@ __device__ inline double tile_elem(const TileArgs& a, int64_t k, int& n_pos) {
   }
 }
 
-/* A/B builds (-DABZ_PROLOGUE_NT): the prologue's streaming reads of the distances as non-temporal loads -- do they displace rows the
- * first sweep of the generation would have found in the last-level cache?  (profiles/HISTORY.md, round 5: no.) */
-__device__ inline double abz_ld_stream(const double* p) {
-#ifdef ABZ_PROLOGUE_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
+/* the prologue's streaming reads of the distances (as non-temporal loads they change nothing: the first sweep of a generation is not
+ * slower for rows these passes displaced, profiles/HISTORY.md round 5) */
+__device__ inline double abz_ld_stream(const double* p) { return *p; }
 
 template <int MODE>
 __global__ __launch_bounds__(ABZ_BLOCK) void tile_sum_kernel(const TileArgs a) {
@@ -340,13 +334,7 @@ __global__ __launch_bounds__(ABZ_BLOCK) void ind_reweight_kernel(const double* _
     double d0 = 0.0, d1 = 0.0;
     uint8_t a0 = 0, a1 = 0;
     if (k + 1 < n) {
-#ifdef ABZ_PROLOGUE_NT
-      typedef double d2v __attribute__((ext_vector_type(2)));
-      const d2v dv = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(delta + k));
-      double2 dd; dd.x = dv.x; dd.y = dv.y;
-#else
       const double2 dd = *reinterpret_cast<const double2*>(delta + k);
-#endif
       const uchar2 aa = *reinterpret_cast<const uchar2*>(alive + k);
       d0 = dd.x; d1 = dd.y; a0 = aa.x; a1 = aa.y;
     } else if (k < n) { d0 = delta[k]; a0 = alive[k]; }
@@ -616,13 +604,8 @@ __global__ __launch_bounds__(ABZ_BLOCK) void part_swap_kernel(const uint32_t* __
     double a[C], b[C];
     load_row<L, C>(rh, j, a);
     load_row<L, C>(rf, j, b);
-#ifdef ABZ_PART_SWAP_NT        /* A/B build: the moved rows leave through non-temporal stores */
-    store_row_nt<L, C>(rh, j, b);
-    store_row_nt<L, C>(rf, j, a);
-#else
-    store_row<L, C>(rh, j, b);
+    store_row<L, C>(rh, j, b);          /* (non-temporal stores here: no difference, profiles/HISTORY.md round 5) */
     store_row<L, C>(rf, j, a);
-#endif
     if (j == 0) {
       double t;
       t = logpi[h]; logpi[h] = logpi[f]; logpi[f] = t;
@@ -894,9 +877,7 @@ int abz_stratified_impl(abcdez_ctx* ctx, const double* wns, int64_t N, uint32_t 
 #define ABZ_QS_GRID 256
 #define ABZ_QS_CAP 12288            /* keys a block of pass 2 stages in LDS (96 KB; one fat block per CU) */
 #define ABZ_QS_LDSKEYS 4096
-#ifndef ABZ_QS_FINAL_THREADS
 #define ABZ_QS_FINAL_THREADS 1024    /* threads of the finishing block of the select */
-#endif
 
 __device__ inline int qs_shift(unsigned long long klo, unsigned long long khi) {
   if (khi <= klo) return 0;
