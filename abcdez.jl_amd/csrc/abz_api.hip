@@ -82,6 +82,7 @@ static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 static void default_shape(const abz_model& m, int* L, int* C) {
   if (m.sim_id == ABZ_SIM_MVN && m.ld > 64) { *L = 8; *C = m.ld / 8; }           /* rows of 128 / 256 doubles: 16 / 32 components per lane */
   else if (m.sim_id == ABZ_SIM_MVN && m.ld > 8) { *C = 8; *L = m.ld / 8; }
+  else if (m.sim_id == ABZ_SIM_USER && m.ld > 64) { *L = 8; *C = m.ld / 8; }     /* the cooperative form on rows of 128 / 256 doubles */
   else if (m.sim_id == ABZ_SIM_USER && m.ld > 16) { *C = 8; *L = m.ld / 8; }     /* the cooperative form of a user simulator */
   else { *L = 1; *C = m.ld; }
 }
@@ -237,7 +238,6 @@ static int ctx_create_common(const abz_model* model, const char* user_source, in
     case ABZ_SIM_DIRAC: case ABZ_SIM_MIXTURE: ABZ_REQUIRE(model->d == 1, "simulator needs d = 1"); break;
     case ABZ_SIM_QUAD2D: case ABZ_SIM_NORMDU: ABZ_REQUIRE(model->d == 2, "simulator needs d = 2"); break;
     case ABZ_SIM_USER:     /* up to 16 parameters: the whole row in one thread (abz_user_dist); beyond: 8 per lane (abz_user_dist_lanes) */
-      ABZ_REQUIRE(model->d <= 64, "user simulator: length(prior) must be <= 64 (8 components on each of at most 8 lanes)");
       ABZ_REQUIRE(model->n_blob == 0 || model->d <= 16, "user simulator: blobs need the whole row in one thread (d <= 16)");
       break;
     case ABZ_SIM_SOCKS:

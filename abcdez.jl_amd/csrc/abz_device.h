@@ -294,7 +294,7 @@ struct abz_user_rng {
 /* one thread sees the whole row: length(prior) <= 16 */
 __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data, const double* sim_p,
                                 abz_user_rng& rng);
-/* COOPERATIVE form, rows of 17 to 64 parameters: L lanes of a wavefront own one particle, as in the built-in d-dimensional Normal
+/* COOPERATIVE form, rows of 17 to 256 parameters: L lanes of a wavefront own one particle, as in the built-in d-dimensional Normal
  * simulator.  Every lane of the group calls
  *     abz_user_dist_lanes(theta, g, d, data, n_data, sim_p, rng)
  * with ITS C = ABZ_USER_C components in theta[0 .. C) (push_p-cast); g.comp(q) is the index in the row of theta[q] (indices >= d are

@@ -270,7 +270,8 @@ extern "C" __attribute__((visibility("default"))) int abcdez_user_translation_un
                                                                                      char* tu_out, size_t tu_cap, char* opts_out, size_t opts_cap) {
   if (!model || !tu_out || !opts_out || (model->sim_id == ABZ_SIM_USER && !user_source)) { abz_set_error("user_translation_unit: null argument"); return -1; }
   int L = 1, C = model->ld;                                   /* default_shape of abz_api.hip */
-  if (model->sim_id == ABZ_SIM_USER && model->ld > 16) { C = 8; L = model->ld / 8; }
+  if (model->sim_id == ABZ_SIM_USER && model->ld > 64) { L = 8; C = model->ld / 8; }
+  else if (model->sim_id == ABZ_SIM_USER && model->ld > 16) { C = 8; L = model->ld / 8; }
   if (model->sim_id == ABZ_SIM_MVN && model->ld > 64) { L = 8; C = model->ld / 8; }
   else if (model->sim_id == ABZ_SIM_MVN && model->ld > 8) { C = 8; L = model->ld / 8; }
   bool plain = model->d == model->ld && !model->mv;

@@ -213,12 +213,13 @@ class UserSimulator(DeviceSimulator):
         __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
                                         const double* sim_p, abz_user_rng& rng);
 
-    * ``17 <= length(prior) <= 64`` -- the row spread over L = ld / 8 lanes of a wavefront, every lane calling::
+    * ``17 <= length(prior) <= 256`` -- the row spread over the lanes of a wavefront (8 components on each of 4 or 8 lanes up to 64
+      parameters, 16 or 32 components on each of 8 lanes beyond), every lane calling::
 
         __device__ double abz_user_dist_lanes(const double* theta, const abz_user_lanes& g, int d, const double* data,
                                               int n_data, const double* sim_p, abz_user_rng& rng);
 
-      with ITS ``ABZ_USER_C`` (= 8) components in ``theta``; ``g.comp(q)`` is the index in the row of ``theta[q]`` (indices ``>= d``
+      with ITS ``ABZ_USER_C`` components in ``theta``; ``g.comp(q)`` is the index in the row of ``theta[q]`` (indices ``>= d``
       are padding), ``g.sum(v)`` adds ``v[0 .. C)`` over the whole group in one canonical tree (the same value on every lane and for
       every lane count), and the function returns the distance on every lane.  Draws are addressed, not sequential:
       ``rng.normal_pair_at(k, z0, z1)``, ``rng.uniform_at(k)`` -- key them by component (``g.comp(q) / 2`` for a pair), never by lane.

@@ -52,11 +52,12 @@ ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx*
  *   d <= 16 -- the whole row in one thread:
  *     __device__ double abz_user_dist(const double* theta, int d, const double* data, int n_data,
  *                                     const double* sim_p, abz_user_rng& rng);
- *   17 <= d <= 64 -- the row spread over L = ld / 8 lanes of a wavefront (as the built-in d-dimensional Normal simulator), every lane
+ *   17 <= d <= 256 -- the row spread over the lanes of a wavefront (as the built-in d-dimensional Normal simulator: 8 components on each
+ *   of 4 or 8 lanes up to 64 parameters, 16 or 32 components on each of 8 lanes beyond), every lane
  *   of the group calling
  *     __device__ double abz_user_dist_lanes(const double* theta, const abz_user_lanes& g, int d, const double* data, int n_data,
  *                                           const double* sim_p, abz_user_rng& rng);
- *   with ITS ABZ_USER_C = 8 components (g.comp(q) = index in the row; g.sum(v) = the canonical tree sum over the group; draws addressed
+ *   with ITS ABZ_USER_C components (g.comp(q) = index in the row; g.sum(v) = the canonical tree sum over the group; draws addressed
  *   by component: rng.normal_pair_at(k, z0, z1), rng.uniform_at(k)) and returning the distance on every lane;
  *   the STAGED form (d <= 16) -- #define ABZ_USER_ROUNDS / ABZ_USER_STATE and
  *     __device__ double abz_user_round(const double* theta, int d, const double* data, int n_data, const double* sim_p,

@@ -926,7 +926,7 @@ enum {
    * dist = |pairs picked - sim_p[0]| + |odd socks picked - sim_p[1]|                               */
   ABZ_SIM_SOCKS = 8,
   /* user-supplied device function compiled at run time (abcdez_ctx_create_user): the whole row in one thread for d <= 16,
-   * spread over the lanes of a wavefront for 17 <= d <= 64 (include/abcdez_hip.h)                     */
+   * spread over the lanes of a wavefront beyond (include/abcdez_hip.h)                     */
   ABZ_SIM_USER = 9
 };
 

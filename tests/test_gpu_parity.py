@@ -611,7 +611,7 @@ def test_every_row_width(oracle, d):
 def test_wide_rows_end_to_end(oracle, d):
     """rows of 128 and 256 doubles (8 lanes of 16 / 32 components): whole abcdesmc and abcdemc runs of the d-dimensional Normal
     model, correlated prior included at d = 128, equal the oracle's bit for bit"""
-    y = tuple(1.0 + 0.002 * k for k in range(d))
+    y = tuple(1.0 for k in range(d))
     if d == 128:
         rng = np.random.default_rng(5)
         Lm = np.tril(rng.normal(0, 0.05, (d, d)), -1) + np.diag(rng.uniform(0.8, 1.2, d))
@@ -619,11 +619,12 @@ def test_wide_rows_end_to_end(oracle, d):
     else:
         prior = A.Factored(*[A.Normal(0.0, 1.0 + 0.001 * k) if k % 5 else A.Uniform(-5.0, 5.0) for k in range(d)])
     sim = A.MVNormal(y)
-    N, eps = 2048, 0.85 * math.sqrt(3.0 * d)
+    N, eps = 2048, 0.93 * math.sqrt(3.0 * d)
     r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=d, nsims_max=10 ** 9)
     c = oracle.run_abcdesmc(A.ModelSpec(prior, sim, seed=d), N, eps, nsims_max=10 ** 9)
     res = r.engine.result()
     assert r.logZ == c["logZ"] and r.iters == c["iters"] and r.nsims == c["nsims"] and r.iters >= 5
+    assert int((r.Wns > 0).sum()) > 100 and math.isfinite(r.logZ)          # a run that got somewhere
     assert np.array_equal(res["theta"], c["theta"]) and np.array_equal(res["C"], c["C"]) and np.array_equal(res["Wns"], c["Wns"])
     assert r.engine.ops.layout() == (d, 8, d // 8)
     m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=12, verbose=False, rng=d + 1)

@@ -41,6 +41,10 @@ CASES = {
                            {"-DABZ_USER_L=4", "-DABZ_USER_C=8", "-DABZ_USER_PLAIN=0"}, None),
     "mvn64_lanes": (A.Factored(*[A.Normal(0, 1)] * 64), A.UserSimulator(USER_MVN_LANES, params=(1.0,), data=(1.0,) * 64),
                     {"-DABZ_USER_L=8", "-DABZ_USER_C=8", "-DABZ_USER_PLAIN=1"}, None),
+    "mvn200_lanes": (A.Factored(*[A.Normal(0, 1)] * 200), A.UserSimulator(USER_MVN_LANES, params=(1.0,), data=(1.0,) * 200),
+                     {"-DABZ_USER_L=8", "-DABZ_USER_C=32", "-DABZ_USER_PLAIN=0"}, None),
+    "mvn128_lanes": (A.Factored(*[A.Normal(0, 1)] * 128), A.UserSimulator(USER_MVN_LANES, params=(1.0,), data=(1.0,) * 128),
+                     {"-DABZ_USER_L=8", "-DABZ_USER_C=16", "-DABZ_USER_PLAIN=1"}, None),
     "lv_rounds": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4),
                   A.UserSimulator(USER_LV_ROUNDS % {"rounds": 8}, params=(1.0, 0.5, 0.01, 100.0, 0.1), data=(1.0, 0.5) * 16),
                   {"-DABZ_USER_L=1", "-DABZ_USER_C=4", "-DABZ_USER_PLAIN=0"}, "smc_user_rounds_phase2_body"),
