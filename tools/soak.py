@@ -16,6 +16,9 @@ import torch
 
 import abcdez_amd as A
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from user_sources import USER_MVN_LANES
+
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 g = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lv_data.json")))
 lv = A.LotkaVolterraRK4(tuple(g["obs"]), x0=g["x0"], y0=g["y0"], dt=g["dt"], steps_per_obs=g["steps_per_obs"], noise=g["noise"])
@@ -31,6 +34,12 @@ cases = {
                                                            A.truncated(A.Normal(1.0, 2.0), 0.0, 4.0)),
                                                 A.MVNormal((1.0,) * 8), 2.5, None, nparticles=1 << 20, verbose=False, rng=15,
                                                 nsims_max=10 ** 12),
+    # round 6: kernels compiled at run time -- wrapper priors under a built-in simulator, a user simulator in the cooperative form
+    "wrapped priors 2^20": lambda: A.abcdesmc(A.Factored(A.truncated(A.Gamma(2.0, 1.0), 0.3, 5.0), A.MixtureModel([A.Normal(-1.0, 0.5), A.Laplace(1.0, 1.5)], [0.4, 0.6]),
+                                                         A.Affine(A.TDist(4.0), 0.5, 1.5), A.truncated(A.Poisson(4.0), 1, 9)),
+                                              A.MVNormal((1.0, 0.5, 0.8, 3.0)), 1.0, None, nparticles=1 << 20, verbose=False, rng=17, nsims_max=10 ** 12),
+    "user lanes d=32 2^20": lambda: A.abcdesmc(A.Factored(*[A.Normal(0, 1)] * 32), A.UserSimulator(USER_MVN_LANES, params=(1.0,), data=(1.0,) * 32), 6.5, None,
+                                               nparticles=1 << 20, verbose=False, rng=19, nsims_max=10 ** 12),
     "epa 2^20": lambda: A.abcdesmc(A.Normal(0, math.sqrt(10)), A.Normal1D(3.0), 0.3, None, nparticles=1 << 20, verbose=False, rng=11,
                                    ABCk=A.Epa0toϵ, nsims_max=10 ** 12),
 }
