@@ -533,6 +533,43 @@ def test_abcdesmc_reuses_the_select_enqueued_ahead():
     assert reused >= (2 * r.iters) // 3, (reused, inline, r.iters)
 
 
+def test_host_uploads_invalidate_only_what_they_overwrite():
+    """abcdez_memcpy_h2d (the Julia shim's uploads): a copy into arrays the library holds no state about -- weights, bitmap
+    words -- leaves a select enqueued ahead in place; a copy that overlaps the distances it was made from discards it.  Either way the
+    results are those of a run without the copies (the discarded select is redone)."""
+    import ctypes as C
+
+    prior, sim, eps_t = models()["mvn8"]
+    spec = A.ModelSpec(prior, sim, seed=5)
+    g0 = 2.38 / math.sqrt(2 * spec.d)
+
+    def run(upload):
+        e = PopulationEngine(spec, 8192, ops=HipOps(spec))
+        e.init_population(); e.reset_weights()
+        eps, eps_k, out = math.inf, math.inf, []
+        for gen in range(4):
+            eps, wnorm, ess, n_alive, _ = e.smc_prologue(0.9, eps, eps_t, eps_k, 0.0)
+            e.alive_compact()
+            cnt = e.smc_sweeps(eps, g0, 1e-5, 2, 9.0, next_prologue=(0.9, eps_t))
+            eps_k = eps
+            torch.cuda.synchronize()
+            if upload == "weights":                        # 64 doubles of the weights, rewritten with their own values
+                host = e.wns[:64].cpu().numpy().copy()
+                _lib.check(e.ops.lib, e.ops.lib.abcdez_memcpy_h2d(e.ops.ctx, e.wns.data_ptr(), host.ctypes.data, host.nbytes))
+            elif upload == "distances":                    # the same for the distances the select ahead was made from
+                host = e.delta[:64].cpu().numpy().copy()
+                _lib.check(e.ops.lib, e.ops.lib.abcdez_memcpy_h2d(e.ops.ctx, e.delta.data_ptr(), host.ctypes.data, host.nbytes))
+            out.append((eps, wnorm, n_alive, tuple(cnt[0])))
+        return out, e.ops.smc_select_stats()
+
+    base, (reused0, inline0) = run(None)
+    same_w, (reused_w, inline_w) = run("weights")
+    same_d, (reused_d, inline_d) = run("distances")
+    assert base == same_w == same_d
+    assert (reused0, inline0) == (3, 1) and (reused_w, inline_w) == (3, 1)          # untouched: every later prologue finds its select
+    assert reused_d == 0 and inline_d == 4                                          # discarded every time, redone inline
+
+
 @pytest.mark.parametrize("name,N,gens", [("normal1d", 5000, 60), ("mvn8", 2000, 40), ("normdu", 100, 100),
                                          ("quad2d_inf", 500, 80), ("normal1d", 60000, 70), ("normal1d_tight", 60000, 60),
                                          ("normal1d_tight", 3000, 60), ("gamma1d", 3000, 40), ("further8", 2000, 40),
