@@ -54,6 +54,9 @@ PROTOTYPES = {
     "abcdez_mc_rank_stats": [_vp, _pi64, _pi64, _pi64],
     "abcdez_smc_sweeps_packed": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _u32, _i32, _f64, _pi64, _pi64,
                                  C.POINTER(_i32)],
+    "abcdez_smc_generation_packed": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _f64, _f64, _f64,
+                                     _u32, _u32, _i32, _f64, _i32, _pf64, _pf64, _pf64, _pi64, C.POINTER(_i32), C.POINTER(_i32), _pf64, _pi64,
+                                     _pi64, _pi64, C.POINTER(_i32), _pf64, _pf64],
     "abcdez_smc_replay_packed": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32, _pi64, _pi64],
     "abcdez_smc_group_begin": [_vp, _i64, _f64],
     "abcdez_smc_group_replay": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _u32],
@@ -95,7 +98,7 @@ PROTOTYPES = {
     "abcdez_math_eval": [_vp, C.c_int, _vp, _vp, _vp, _i64],
     "abcdez_draws_eval": [_vp, C.c_int, _i64, _i64, _i64, _u32, _f64, _f64, _vp, _vp, _vp, _vp],
 }
-MIN_VERSION = 600      # abcdez_comm_init_host (host-supplied transport), lazily opened RCCL (include/abcdez_hip.h)
+MIN_VERSION = 610      # abcdez_comm_init_host, abz_model.ext (wrapper priors), abcdez_smc_generation_packed (include/abcdez_hip.h)
 # the callbacks of abcdez_comm_init_host (include/abcdez_hip.h): in-place all-gather / all-reduce on HOST memory
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64)
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _i32)

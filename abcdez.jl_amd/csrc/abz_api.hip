@@ -104,10 +104,10 @@ extern "C" {
 
 /* 400: Philox4x32-10 again, abz_model.mv, group abort; 401: abcdemc's better particle by rejection;
  * 500: abcdez_comm_* and abcdez_smc_sweeps_sharded (RCCL behind the ABI), timing mode 3; 600: abcdez_comm_init_host (a host-supplied
- * transport under the same sharded entry points), librccl opened lazily.  Hosts refuse a library older than the
+ * transport under the same sharded entry points), librccl opened lazily; 610: abcdez_smc_generation_packed, abz_model.ext.  Hosts refuse a library older than the
  * header they were written against (abcdez.jl_amd/_lib.py, julia/ABCdeZHIP.jl check_abi): a signature that grew an argument links
  * against an old binary without a diagnostic. */
-int abcdez_version(void) { return 600; }
+int abcdez_version(void) { return 610; }
 int abcdez_rng_rounds(void) { return ABZ_PHILOX_ROUNDS; }
 
 /* sizeof / offsetof of the two structs that cross the boundary, so that a host that mirrors them by hand (the Julia
@@ -877,6 +877,54 @@ int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint32_t* bits_b
     return -1;
   }
   return 0;
+}
+
+/* ONE generation of abcdesmc!'s loop body (smc:301-353) on an unsharded packed population in ONE call: the prologue (eps of smc:301,
+ * weights, ESS, extrema, partition), the resampling when ESS < ess_min (smc:323-326), the Kmcmc sweeps behind the device-side test of
+ * smc:352 -- the entry points above, composed, with the two decisions between them (resample or not, sweep or not) taken HERE in a few
+ * hundred nanoseconds instead of in the host language between three calls.  Nothing new happens on the device; what changes is how long
+ * the queue stands empty while an interpreter walks from one call to the next (the partition and the select ahead hide ~50 us each,
+ * and a Python host needs most of that).  `bits_cur` names the current slot of every position, (logpi_cur, delta_cur) is the current
+ * pair; a resampling gathers into the other pair, which is the current one afterwards (`resampled` tells the host to swap its names).
+ * select_ahead: arm the next generation's select behind these sweeps (abcdez_smc_select_ahead with the same alpha, eps_target). */
+int abcdez_smc_generation_packed(abcdez_ctx* ctx, int64_t N, int64_t n_prev, uint32_t* bits_cur, uint32_t* bits_oth, double* slot0,
+                                 double* slot1, double* logpi_cur, double* delta_cur, double* logpi_oth, double* delta_oth, double* wns,
+                                 uint8_t* alive, uint32_t* inds, double alpha, double eps_prev, double eps_target, double eps_k_old,
+                                 double ess_min, double gamma0, double gamma_sigma, uint32_t sweep0, uint32_t draw, int32_t k_max,
+                                 double kmcmc_min, int32_t select_ahead, double* eps, double* wnorm, double* ess, int64_t* n_alive,
+                                 int32_t* partitioned, int32_t* resampled, double* ess_resampled, int64_t* n_swept, int64_t* nacc,
+                                 int64_t* nsim, int32_t* k_done, double* dmin, double* dmax) {
+  ABZ_REQUIRE(ctx && logpi_oth && delta_oth && inds && eps && wnorm && ess && n_alive && partitioned && resampled && ess_resampled &&
+              n_swept && nacc && nsim && k_done, "smc_generation_packed: null argument");
+  ABZ_REQUIRE(logpi_cur != logpi_oth && delta_cur != delta_oth, "smc_generation_packed: the two (logpi, delta) pairs must differ");
+  ABZ_REQUIRE(1 <= k_max && k_max <= ABZ_GROUP_MAX && kmcmc_min >= 0.0, "smc_generation_packed: 1 <= Kmcmc <= 16 sweeps per call, Kmcmc_min >= 0");
+  ABZ_REQUIRE(ctx->comm_kind == ABZ_COMM_NONE || ctx->comm_world == 1, "smc_generation_packed: an unsharded population (sharded: abcdez_smc_sweeps_sharded)");
+  *resampled = 0; *ess_resampled = 0.0; *k_done = 0; *n_swept = 0;
+  for (int k = 0; k < k_max; ++k) { nacc[k] = 0; nsim[k] = 0; }
+  int rc = abcdez_smc_prologue_packed(ctx, delta_cur, wns, alive, N, n_prev, alpha, eps_prev, eps_target, eps_k_old, ess_min, bits_cur,
+                                      bits_oth, slot0, slot1, logpi_cur, eps, nullptr, wnorm, ess, n_alive, partitioned, dmin, dmax);
+  if (rc) return rc;
+  int64_t n = *n_alive;
+  double* lp = logpi_cur;
+  double* dl = delta_cur;
+  if (n > 0 && *ess < ess_min) {                                           /* smc:323-326 */
+    rc = abcdez_wsample_stratified(ctx, wns, N, draw, inds);
+    if (rc == 0) rc = abcdez_smc_resample_gather_packed(ctx, inds, N, bits_cur, bits_oth, slot0, slot1, logpi_cur, delta_cur, logpi_oth, delta_oth, wns, alive);
+    if (rc) return rc;
+    if (ctx->stamp_cur) { uint64_t* t = ctx->stamp_cur; ctx->stamp_cur = ctx->stamp_nxt; ctx->stamp_nxt = t; }   /* the stamps were gathered with the distances */
+    rc = abcdez_get_ess(ctx, wns, N, ess_resampled);                        /* what the drivers record after a resampling (smc:325) */
+    if (rc) return rc;
+    *resampled = 1;
+    n = N; lp = logpi_oth; dl = delta_oth;
+  }
+  *n_swept = n;
+  if (n < 3) return 0;                                                      /* the donor draws need three alive particles (smc:119-126) */
+  if (select_ahead && *eps > eps_target) {                                  /* (at eps_target this is the run's last generation) */
+    rc = abcdez_smc_select_ahead(ctx, dl, alive, N, alpha, eps_target);
+    if (rc) return rc;
+  }
+  return abcdez_smc_sweeps_packed(ctx, bits_cur, bits_oth, n, slot0, slot1, lp, dl, *eps, gamma0, gamma_sigma, sweep0, k_max, kmcmc_min, nacc,
+                                  nsim, k_done);
 }
 
 int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive, int64_t skip_lo,

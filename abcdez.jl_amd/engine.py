@@ -190,6 +190,23 @@ class HipOps:
             C.byref(ess), C.byref(na), C.byref(part), C.byref(lo), C.byref(hi)))
         return eps.value, wnorm.value, ess.value, na.value, bool(part.value), lo.value, hi.value
 
+    def smc_generation_packed(self, n_prev, bits_cur, bits_oth, slot0, slot1, cur, oth, wns, alive, inds, alpha, eps_prev, eps_target,
+                              eps_k, ess_min, gamma0, gsig, sweep0, draw, k_max, kmcmc_min, select_ahead):
+        """one generation of smc:301-353 in ONE library call (abcdez_smc_generation_packed): prologue, the resampling when
+        ESS < ess_min, the sweeps.  cur / oth = the (logpi, delta) pairs -> dict of everything the driver needs"""
+        eps, wnorm, ess, essr, lo, hi = (C.c_double() for _ in range(6))
+        na, ns = C.c_int64(), C.c_int64()
+        part, res, done = C.c_int32(), C.c_int32(), C.c_int32()
+        nacc, nsim = (C.c_int64 * k_max)(), (C.c_int64 * k_max)()
+        _lib.check(self.lib, self.lib.abcdez_smc_generation_packed(
+            self.ctx, wns.numel(), n_prev, _ptr(bits_cur), _ptr(bits_oth), _ptr(slot0), _ptr(slot1), _ptr(cur[0]), _ptr(cur[1]),
+            _ptr(oth[0]), _ptr(oth[1]), _ptr(wns), _ptr(alive), _ptr(inds), alpha, eps_prev, eps_target, eps_k, ess_min, gamma0, gsig,
+            sweep0, draw, k_max, kmcmc_min, 1 if select_ahead else 0, C.byref(eps), C.byref(wnorm), C.byref(ess), C.byref(na),
+            C.byref(part), C.byref(res), C.byref(essr), C.byref(ns), nacc, nsim, C.byref(done), C.byref(lo), C.byref(hi)))
+        return dict(eps=eps.value, wnorm=wnorm.value, ess=ess.value, n_alive=na.value, partitioned=bool(part.value),
+                    resampled=bool(res.value), ess_resampled=essr.value, n_swept=ns.value, naccs=list(nacc[:done.value]),
+                    nsims=list(nsim[:done.value]), Ki=done.value, range=(lo.value, hi.value))
+
     def smc_swarm_packed(self, bits, bits_out, n_alive, r_lo, r_hi, slot0, slot1, logpi, delta, flags, eps, gamma0, gsig,
                          sweep, want_counts=True):
         """want_counts=False: no host synchronisation (the replay reports the sweep's global counters)"""
@@ -902,6 +919,56 @@ class PopulationEngine:
             if sum(naccs) / self.n_alive >= Kmcmc_min:   # smc:352
                 break
         return naccs, nsims, len(naccs)
+
+    def smc_generation(self, alpha: float, eps_prev: float, eps_target: float, eps_k: float, ess_min: float, gamma0: float, gsig: float,
+                       Kmcmc: int, Kmcmc_min: float, select_ahead: bool = True):
+        """The loop body of abcdesmc! between `iters += 1` and the acceptance fraction (smc:301-353): new eps, weights, evidence
+        increment, ESS; the resampling when ESS < ess_min (smc:323-326); the Kmcmc sweeps with their early exit (smc:336-353).
+        -> dict(eps, wnorm, ess (after a resampling: of the resampled weights, smc:325), n_alive (the count the sweeps ran on), naccs,
+        nsims, Ki, range = extrema(Ds) of the generation before, resampled).
+        On an unsharded HIP population ONE library call (abcdez_smc_generation_packed): the two decisions between prologue,
+        resampling and sweeps are taken inside the library instead of in this interpreter, which otherwise walks from call to call
+        while the device queue stands empty.  Otherwise (sharded runs, the CPU oracle) the same steps through the methods above."""
+        self._need_packed("smc_generation")
+        fused = (not self.sharded_packed and hasattr(self.ops, "smc_generation_packed") and Kmcmc <= self.ops.SWEEPS_MAX
+                 and Kmcmc_min >= 0.0 and os.environ.get("ABZ_GENERATION_STEPWISE", "0") != "1")
+        if fused:
+            self._stream()
+            self._sync_delta()
+            self._bind_stamps()
+            cur, oth = self.buf[self.cur], self.buf[1 - self.cur]
+            with _rng("generation"):
+                g = self.ops.smc_generation_packed(self.n_prev, self.bits[self.bc], self.bits[1 - self.bc], self.buf[0][0], self.buf[1][0],
+                                                   (cur[1], cur[2]), (oth[1], oth[2]), self.wns, self.alive, self.inds, alpha, eps_prev,
+                                                   eps_target, eps_k, ess_min, gamma0, gsig, self.sweep, self.draw, Kmcmc, Kmcmc_min,
+                                                   select_ahead)
+            self.n_alive = g["n_alive"]
+            if g["partitioned"]:
+                self.n_prev = g["n_alive"]
+            if g["resampled"]:                     # the other (logpi, delta, stamp) arrays are the current ones now
+                self.draw += 1
+                self._swap()
+                self.n_alive = self.n_prev = self.N
+                g["ess"] = g["ess_resampled"]
+            self.r_lo, self.r_hi = 0, self.n_alive
+            self.sweep += g["Ki"]
+            if g["Ki"] & 1:
+                self.bc = 1 - self.bc
+            g["n_alive"] = g["n_swept"]
+            return g
+        eps, wnorm, ess, n_alive, rng_prev = self.smc_prologue(alpha, eps_prev, eps_target, eps_k, ess_min)
+        resampled = n_alive > 0 and ess < ess_min
+        if resampled:                              # smc:323-326
+            self.smc_resample()
+            ess = self.get_ess()
+            n_alive = self.N
+        naccs, nsims, Ki = [], [], 0
+        if n_alive >= 3:                           # donor draws need three alive particles (smc:119-126)
+            self.alive_compact()
+            naccs, nsims, Ki = self.smc_sweeps(eps, gamma0, gsig, Kmcmc, Kmcmc_min,
+                                               next_prologue=(alpha, eps_target) if select_ahead and eps > eps_target else None)
+        return dict(eps=eps, wnorm=wnorm, ess=ess, n_alive=n_alive, naccs=list(naccs), nsims=list(nsims), Ki=Ki, range=rng_prev,
+                    resampled=resampled)
 
     def _smc_sweeps_sharded_group(self, eps, gamma0, gsig, Kmcmc, Kmcmc_min):
         """sharded population: all Kmcmc sweeps enqueued back to back -- own range, flag all-gather, replay + the device-side

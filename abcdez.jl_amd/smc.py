@@ -205,35 +205,28 @@ def abcdesmc(prior, dist, ϵ_target, varexternal=None, *,
 
     while iters < max_iters:           # smc:295
         iters += 1
-        # new ϵ target ϵ = max(min(quantile(Δs[alive], α), ϵ), ϵ_target) (smc:301; S9: the order statistics come from
-        # the device, the schedule stays here: ϵ and ϵ_target go in, the new ϵ comes back); target weights,
-        # normalisation, alive mask: smc:305-311 (S5) and ESS smc:323 (S6).  One engine call -- on the packed HIP
-        # population one host synchronisation; it also returns extrema(Δs) of the generation that just ended (smc:364)
-        ϵ, wnorm, ess, n_alive, range_prev = eng.smc_prologue(α, ϵ, ϵ_target, ϵ_k, ess_min)
+        if facc < facc_min:            # smc:320 (depends on the generation before only: tuned ahead of the engine's one call)
+            γ0 *= facc_tune
+        # smc:301-353 in ONE engine call -- on the unsharded HIP population one library call (abcdez_smc_generation_packed):
+        #   new ϵ = max(min(quantile(Δs[alive], α), ϵ), ϵ_target) (smc:301; S9: the order statistics come from the device, the schedule
+        #   stays here: ϵ and ϵ_target go in, the new ϵ comes back); target weights, normalisation, alive mask smc:305-311 (S5), ESS
+        #   smc:323 (S6), extrema(Δs) of the generation that just ended (smc:364)                        [one host synchronisation]
+        #   resampling when ess < ess_min, smc:323-326 (S7, S8)
+        #   for i in 1:Kmcmc: sweep; naccs, nsims; (naccs / n_alive >= Kmcmc_min) && (Ki = i; break), smc:336-353 (S2, S3), the test
+        #   of :352 on the device between the sweeps                                                      [one host synchronisation]
+        # Unless this is known to be the last generation the engine may start the next generation's quantile select behind the
+        # sweeps (it only reads Δs; its arguments will be α and ϵ_target)
+        g = eng.smc_generation(α, ϵ, ϵ_target, ϵ_k, ess_min, γ0, γσ, Kmcmc, Kmcmc_min, select_ahead=iters < max_iters)
+        ϵ, wnorm, ess, n_alive, range_prev = g["eps"], g["wnorm"], g["ess"], g["n_alive"], g["range"]
         if verboseout and iters > 1 and len(ranges_ϵ) < len(ϵs):
             ranges_ϵ.append(range_prev)
         ABCk(ϵ)
         # evidence, smc:315
         logZ += math.log(wnorm) if wnorm > 0.0 else (-math.inf if wnorm == 0.0 else math.nan)
-        naccs = 0                      # smc:318
-        Ki = Kmcmc
-        if facc < facc_min:            # smc:320
-            γ0 *= facc_tune
-        if n_alive > 0 and ess < ess_min:   # smc:323-326 (S7, S8)
-            eng.smc_resample()
-            ess = eng.get_ess()
-            n_alive = nparticles
-        if n_alive >= 3:               # donor draws need three alive particles (smc:119-126)
-            eng.alive_compact()
-            # for i in 1:Kmcmc: sweep; naccs, nsims; (naccs / n_alive >= Kmcmc_min) && (Ki = i; break)   smc:336-353 (S2, S3)
-            # -- one engine call; on the HIP population the test of :352 runs on the device between the sweeps
-            # (next_prologue: unless this is known to be the last generation, the engine may start the next generation's
-            # quantile select behind these sweeps -- it only reads Δs; the values it will be asked for are α and ϵ_target)
-            naccs_i, nsims_i, Ki = eng.smc_sweeps(ϵ, γ0, γσ, Kmcmc, Kmcmc_min,
-                                                   next_prologue=(α, ϵ_target) if ϵ > ϵ_target and iters < max_iters else None)
-            naccs += sum(naccs_i)
-            nsims += sum(nsims_i)
-            updates += n_alive * Ki
+        naccs = sum(g["naccs"])        # smc:318, :345
+        Ki = g["Ki"] if g["Ki"] else Kmcmc
+        nsims += sum(g["nsims"])
+        updates += n_alive * g["Ki"]
         facc = naccs / (n_alive * Ki) if n_alive > 0 else math.nan   # smc:357
         ϵ_k = ϵ                        # smc:360
         if verboseout:                 # smc:362-370; ranges_ϵ gets this generation's extrema from the next prologue

@@ -112,21 +112,17 @@ class Generation:
 
     def step(self):
         e = self.e
-        # smc:301 (eps), smc:305-311 (reweight), ESS, and extrema(Ds) of the generation that just ended (smc:364)
-        self.eps, wnorm, ess, n_alive, self.range = e.smc_prologue(self.alpha, self.eps, self.eps_target, self.eps_k,
-                                                                   e.N * self.delta_ess)
-        self.logZ += math.log(wnorm)                                                       # smc:315
-        if ess < e.N * self.delta_ess:                                                     # smc:323-326
-            e.smc_resample()
-            n_alive = e.N
-            self.resamples += 1
-        e.alive_compact()
-        naccs_i, nsims_i, Ki = e.smc_sweeps(self.eps, self.gamma0, 1e-5, self.Kmcmc, self.Kmcmc_min,     # smc:336-353
-                                            next_prologue=(self.alpha, self.eps_target) if self.eps > self.eps_target else None)
-        self.naccs += sum(naccs_i)
-        self.nsims += sum(nsims_i)
-        self.updates += n_alive * Ki
-        self.sweeps += Ki
+        # smc:301 (eps), smc:305-311 (reweight), ESS, extrema(Ds) of the generation that just ended (smc:364); the resampling when
+        # ESS < N delta_ess (smc:323-326); the Kmcmc sweeps (smc:336-353) -- one engine call, on one GPU one library call
+        g = e.smc_generation(self.alpha, self.eps, self.eps_target, self.eps_k, e.N * self.delta_ess, self.gamma0, 1e-5, self.Kmcmc,
+                             self.Kmcmc_min)
+        self.eps, self.range = g["eps"], g["range"]
+        self.logZ += math.log(g["wnorm"])                                                  # smc:315
+        self.resamples += 1 if g["resampled"] else 0
+        self.naccs += sum(g["naccs"])
+        self.nsims += sum(g["nsims"])
+        self.updates += g["n_alive"] * g["Ki"]
+        self.sweeps += g["Ki"]
         self.eps_k = self.eps
         self.generations += 1
 

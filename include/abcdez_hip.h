@@ -235,6 +235,21 @@ ABCDEZ_API int abcdez_smc_sweeps_packed(abcdez_ctx* ctx, uint32_t* bits_a, uint3
                                         double* slot0, double* slot1, double* logpi, double* delta, double eps,
                                         double gamma0, double gamma_sigma, uint32_t sweep0, int32_t k_max,
                                         double kmcmc_min, int64_t* nacc, int64_t* nsim, int32_t* k_done);
+/* ONE generation of the loop body of abcdesmc! (src/abcdez_smc.jl:301-353) in one call: abcdez_smc_prologue_packed, then -- when
+ * ESS < ess_min, smc:323-326 -- abcdez_wsample_stratified + abcdez_smc_resample_gather_packed (+ abcdez_get_ess of the uniform weights,
+ * what the drivers record), then abcdez_smc_sweeps_packed on the population that results; the two decisions between them are taken inside
+ * the call.  (bits_cur, logpi_cur, delta_cur) name the current state; after a resampling (*resampled = 1) the OTHER (logpi, delta) pair is
+ * the current one and the host swaps its names (the bitmaps keep theirs; k_done odd flips them as after abcdez_smc_sweeps_packed).
+ * Outputs: eps, wnorm, ess, n_alive, partitioned, dmin / dmax as abcdez_smc_prologue_packed; n_swept = the alive count the sweeps ran on
+ * (N after a resampling; no sweeps below 3); nacc[k], nsim[k], k_done as abcdez_smc_sweeps_packed.  An unsharded population only. */
+ABCDEZ_API int abcdez_smc_generation_packed(abcdez_ctx* ctx, int64_t N, int64_t n_prev, uint32_t* bits_cur, uint32_t* bits_oth,
+                                            double* slot0, double* slot1, double* logpi_cur, double* delta_cur, double* logpi_oth,
+                                            double* delta_oth, double* wns, uint8_t* alive, uint32_t* inds, double alpha,
+                                            double eps_prev, double eps_target, double eps_k_old, double ess_min, double gamma0,
+                                            double gamma_sigma, uint32_t sweep0, uint32_t draw, int32_t k_max, double kmcmc_min,
+                                            int32_t select_ahead, double* eps, double* wnorm, double* ess, int64_t* n_alive,
+                                            int32_t* partitioned, int32_t* resampled, double* ess_resampled, int64_t* n_swept,
+                                            int64_t* nacc, int64_t* nsim, int32_t* k_done, double* dmin, double* dmax);
 ABCDEZ_API int abcdez_smc_replay_packed(abcdez_ctx* ctx, const uint32_t* bits, uint32_t* bits_out, int64_t n_alive,
                                         int64_t skip_lo, int64_t skip_hi, double* slot0, double* slot1, double* logpi,
                                         const uint8_t* flags, double gamma0, double gamma_sigma, uint32_t sweep,
