@@ -17,7 +17,13 @@ import abcdez_amd as A
 from oracle import oracle as O
 
 
-def cases():
+def cases(hip: bool = False):
+    """hip: the product engine runs the case (a user-supplied simulator is compiled from its source); otherwise the CPU oracle runs the
+    built-in simulator that source restates -- the results must be the same bits"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from user_sources import USER_MVN_LANES
+
+    y20 = tuple(1.0 + 0.02 * k for k in range(20))
     return {
         # population sizes divisible by 1, 2, 3, 4 and 8 ranks
         "normal1d": (A.Normal(0, math.sqrt(10)), A.Normal1D(3.0, blobs=True), 0.3, 2016),     # blobs: stamps travel too
@@ -37,6 +43,10 @@ def cases():
         # kernels at run time (csrc/abz_jit.hip); the replicas rebuild log-sum-exp log-priors
         "wrapped4": (A.Factored(A.truncated(A.Gamma(2.0, 1.0), 0.3, 5.0), A.MixtureModel([A.Normal(-1.0, 0.5), A.Laplace(1.0, 1.5)], [0.4, 0.6]),
                                 A.Normal(0.5, 1.0), A.truncated(A.Poisson(4.0), 1, 9)), A.MVNormal((1.0, 0.5, 0.8, 3.0)), 1.5, 528),
+        # a USER-SUPPLIED simulator in the cooperative form (20 parameters on 4 lanes of 8 components, 12 padding components): sweep,
+        # replay and abcdemc kernels compiled at run time from the user's source; the oracle runs the built-in simulator it restates
+        "user_mvn20": (A.Factored(*([A.Normal(0, 1)] * 18 + [A.Gamma(2.0, 1.0), A.Uniform(-3, 4)])),
+                       A.UserSimulator(USER_MVN_LANES, params=(1.0,), data=y20) if hip else A.MVNormal(y20), 6.2, 528),
     }
 
 
@@ -72,7 +82,7 @@ def main():
         torch.cuda.set_device(0)          # every rank shares the one GPU of the test box
         engine = HipEngine
     want_kind = {"rccl1": 1, "hip": 2 if world > 1 else 0, "hip1": 2}.get(mode)
-    for name, (prior, sim, eps, N) in cases().items():
+    for name, (prior, sim, eps, N) in cases(hip=mode in ("hip", "hip1", "rccl1")).items():
         if names is not None and name not in names:
             continue
         # default storage: packed population; sharded = accept-flag exchange + replay on the replicas

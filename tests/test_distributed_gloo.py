@@ -40,7 +40,7 @@ def runs(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5", "wrapped4"])
+@pytest.mark.parametrize("name", ["normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5", "wrapped4", "user_mvn20"])
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_sharded_run_equals_single_process(runs, name, world):
     ref = np.load(os.path.join(runs[1], f"result_{name}_rank0.npz"))
@@ -70,7 +70,7 @@ def test_uneven_shard_is_rejected(oracle):
     assert (eng.lo, eng.hi, eng.world) == (0, 10, 1)
 
 
-NAMES = ("normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5", "wrapped4")
+NAMES = ("normal1d", "mvn8", "quad2d", "mvn32", "lv", "further5", "wrapped4", "user_mvn20")
 
 
 def compare_with_single_process_oracle(ref_dir, hip_dir, world, names=NAMES):
