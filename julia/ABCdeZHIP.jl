@@ -53,7 +53,7 @@ struct AbzModel
     n_ext::Int32; reserved0::Int32
 end
 # the library reports sizeof / offsetof of both structs; a mismatch is a build mix-up, not a run-time condition
-const MIN_VERSION = 600        # abcdez_comm_init_host, lazily opened RCCL (include/abcdez_hip.h)
+const MIN_VERSION = 610        # abz_model.ext (wrapper priors), abcdez_comm_init_host, abcdez_smc_generation_packed (include/abcdez_hip.h)
 function check_abi()
     # an older library would link -- C has no signature check -- and misread arguments added since
     v = ccall((:abcdez_version, LIB), Cint, ())
@@ -421,6 +421,30 @@ function smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min; next_prologue=nothing)
     e.sweep += done[]; isodd(done[]) && (e.bc = 3 - e.bc)
     (sum(nacc), sum(nsim), Int(done[]))
 end
+# the loop body of smc:301-353 on an unsharded population in ONE call (abcdez_smc_generation_packed): prologue!, the resample! of
+# smc:323-326 when ESS < ess_min, smc_sweeps! with the next generation's select armed -- the two decisions in between are taken
+# inside the library.  -> (ϵ, wnorm, ess, n_alive the sweeps ran on, Σnaccs, Σnsims, Ki, extrema(Δs) of the generation before)
+function generation!(e, α, ϵ, ϵ_target, ϵ_k, ess_min, γ0, γσ, Kmcmc, Kmcmc_min)
+    bind_stamps!(e); o = other(e)
+    ϵn = Ref(0.0); wnorm = Ref(0.0); ess = Ref(0.0); essr = Ref(0.0); lo = Ref(0.0); hi = Ref(0.0)
+    na = Ref(Int64(0)); ns = Ref(Int64(0)); part = Ref(Int32(0)); res = Ref(Int32(0)); done = Ref(Int32(0))
+    nacc = zeros(Int64, Kmcmc); nsim = zeros(Int64, Kmcmc)
+    check(ccall((:abcdez_smc_generation_packed, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Float64, Float64, Float64, Float64, UInt32, UInt32,
+                 Int32, Float64, Int32, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}, Ref{Int32}, Ref{Int32}, Ref{Float64},
+                 Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Ref{Int32}, Ref{Float64}, Ref{Float64}),
+                e.ctx, e.N, e.n_prev, e.bits[e.bc], e.bits[3 - e.bc], e.slot[1], e.slot[2], e.logpi[e.cur], e.delta[e.cur],
+                e.logpi[o], e.delta[o], e.wns, e.alive, e.inds, α, ϵ, ϵ_target, ϵ_k, ess_min, γ0, γσ, e.sweep, e.draw,
+                Kmcmc, Kmcmc_min, 1, ϵn, wnorm, ess, na, part, res, essr, ns, nacc, nsim, done, lo, hi))
+    e.n_alive = na[]
+    part[] != 0 && (e.n_prev = e.n_alive)
+    if res[] != 0                                # the other (logpi, Δ, stamp) arrays are the current ones now (smc:85-104)
+        e.draw += 1; e.cur = o; e.n_alive = e.n_prev = e.N
+    end
+    e.sweep += done[]; isodd(done[]) && (e.bc = 3 - e.bc)
+    (ϵn[], wnorm[], res[] != 0 ? essr[] : ess[], Int(ns[]), sum(nacc), sum(nsim), Int(done[]), (lo[], hi[]))
+end
 # P (push_p-cast, smc:382 / mc:166), Wns, C and -- with blobs on -- the simulated data behind every distance
 function download(e; packed::Bool)
     rows = devalloc(8 * e.N * e.ld); pushed = devalloc(8 * e.N * e.ld)
@@ -502,26 +526,31 @@ function abcdesmc!(prior, dist!::DeviceSimulator, ϵ_target, varexternal;
         iters = 0
         while true                                                                          # smc:295
             iters += 1
-            ϵ, wnorm, ess, n_alive, range_prev = prologue!(e, α, ϵ, ϵ_target, ϵ_k, ess_min) # smc:301-311, :323
+            naccs = 0; Ki = Kmcmc
+            facc < facc_min && (γ0 *= facc_tune)                                            # smc:320 (γ0 is only read by the sweeps)
+            if e.world == 1 && Kmcmc ≤ 16                                                   # smc:301-353 in one call
+                ϵ, wnorm, ess, n_alive, naccs, nsim, Kdone, range_prev = generation!(e, α, ϵ, ϵ_target, ϵ_k, ess_min, γ0, γσ, Kmcmc, Kmcmc_min)
+                n_alive ≥ 3 && (Ki = Kdone)
+                nsims += nsim
+            else
+                ϵ, wnorm, ess, n_alive, range_prev = prologue!(e, α, ϵ, ϵ_target, ϵ_k, ess_min) # smc:301-311, :323
+                if n_alive > 0 && ess < ess_min                                             # smc:323-326
+                    resample!(e); ess = get_ess(e); n_alive = nparticles
+                end
+                if n_alive ≥ 3 && Kmcmc ≤ 16
+                    naccs, nsim, Ki = smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min)           # smc:336-353, one (collective) call
+                    nsims += nsim
+                elseif n_alive ≥ 3
+                    for i in 1:Kmcmc                                                        # smc:336-353
+                        nacc, nsim = smc_swarm!(e, ϵ, γ0, γσ)
+                        naccs += nacc; nsims += nsim
+                        (naccs / n_alive ≥ Kmcmc_min) && (Ki = i; break)                    # smc:352
+                    end
+                end
+            end
             iters > 1 && push!(ranges_ϵ, range_prev)                                        # smc:364 of the generation before
             ABCk(ϵ)
             logZ += log(wnorm)                                                              # smc:315
-            naccs = 0; Ki = Kmcmc
-            facc < facc_min && (γ0 *= facc_tune)                                            # smc:320
-            if n_alive > 0 && ess < ess_min                                                 # smc:323-326
-                resample!(e); ess = get_ess(e); n_alive = nparticles
-            end
-            if n_alive ≥ 3 && Kmcmc ≤ 16
-                naccs, nsim, Ki = smc_sweeps!(e, ϵ, γ0, γσ, Kmcmc, Kmcmc_min;               # smc:336-353, one call
-                                              next_prologue = ϵ > ϵ_target ? (α, ϵ_target) : nothing)
-                nsims += nsim
-            elseif n_alive ≥ 3
-                for i in 1:Kmcmc                                                            # smc:336-353
-                    nacc, nsim = smc_swarm!(e, ϵ, γ0, γσ)
-                    naccs += nacc; nsims += nsim
-                    (naccs / n_alive ≥ Kmcmc_min) && (Ki = i; break)                        # smc:352
-                end
-            end
             facc = naccs / (n_alive * Ki); ϵ_k = ϵ                                          # smc:357-360
             push!(ϵs, ϵ); push!(logZs, logZ); push!(esss, ess); push!(faccs, facc); push!(γ0s, γ0); push!(Kmcmcs, Ki)
             # smc:372 -- range_ϵ = extrema(Δs) of THIS generation is one more small reduction, made only for the log line
