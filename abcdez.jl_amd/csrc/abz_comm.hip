@@ -35,6 +35,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "abz_ctx.h"
 #include "../../include/abcdez_hip.h"
 
@@ -77,6 +79,8 @@ bool abz_sym(F& f, const char* name) {
 }
 
 int abz_rccl_load() {
+  static std::mutex once;                                     /* contexts of several host threads may come here together */
+  std::lock_guard<std::mutex> hold(once);
   if (R.handle && R.GroupEnd) return 0;
   if (!R.tried) {
     R.tried = true;
