@@ -51,13 +51,13 @@ int abz_ws_reserve(abcdez_ctx* ctx, size_t bytes) {
   return 0;
 }
 
-/* which models sweep in two launches (abz_kernels.h, smc_split_phase1_body): one lane per particle, rows of 4 or 8 doubles, a simulator
+/* which models sweep in two launches (abz_kernels.h, smc_split_phase1_body): one lane per particle, rows of 4, 8 or 16 doubles, a simulator
  * that is the bulk of the sweep -- Lotka-Volterra, and user-supplied simulators (ABZ_USER_ONE_KERNEL=1 in the environment keeps those
  * on the one-kernel two-phase body: the A/B switch, and the choice for a simulator cheaper than a launch and 100 bytes of traffic) */
 bool abz_sweep_in_two_launches(const abcdez_ctx* ctx) {
   if (ctx->L != 1) return false;
   if (ctx->h_model.sim_id == ABZ_SIM_LV && ctx->C == 4) return true;
-  return ctx->h_model.sim_id == ABZ_SIM_USER && (ctx->C == 4 || ctx->C == 8) && !ctx->user_one_kernel;
+  return ctx->h_model.sim_id == ABZ_SIM_USER && (ctx->C == 4 || ctx->C == 8 || ctx->C == 16) && !ctx->user_one_kernel;
 }
 
 /* the hand-over list of a two-launch sweep: [two counters | pad to 256 B | tp 8 ld B | wl 8 | kdi 8 | logu 8 | pos 4] per position */

@@ -30,7 +30,7 @@ static std::unordered_map<std::string, std::vector<char>> g_code_cache;
 struct AbzUserModule {
   hipModule_t mod = nullptr;
   hipFunction_t f_init = nullptr, f_smcp = nullptr, f_mc = nullptr, f_blob = nullptr;
-  hipFunction_t f_p1 = nullptr, f_p2 = nullptr;     /* the sweep as two launches (rows of 4 or 8 doubles; abz_kernels.h, smc_split_phase1_body) */
+  hipFunction_t f_p1 = nullptr, f_p2 = nullptr;     /* the sweep as two launches (rows of 4, 8 or 16 doubles; abz_kernels.h, smc_split_phase1_body) */
   hipFunction_t f_replay = nullptr;                 /* replay of a sharded sweep on the replicas (it evaluates the accepted rows' log-priors) */
   unsigned block_smc = ABZ_BLOCK, block_p2 = ABZ_BLOCK;
   bool rounds = false;                              /* the second launch runs the staged form round by round (abz_user_rounds.h) */
@@ -64,6 +64,15 @@ static unsigned jit_grid(abcdez_ctx* ctx, hipFunction_t f, uint64_t ntiles) {
  * row in one thread up to 16 parameters -- abz_user_dist --, 8 components per lane beyond -- abz_user_dist_lanes), PLAIN (every dimension
  * a continuous Normal: the two-instruction log-density of the built-in kernels), blobs.  A function of the model alone -- no device is
  * touched --, so the CPU tests compile the very same text with hipcc (abcdez_user_translation_unit, tests/test_user_simulator_sources.py). */
+/* the shapes the two-launch sweep exists for: one lane per particle; a user-supplied simulator on rows of 4, 8 or 16 doubles (3 to 16
+ * parameters), the built-in Lotka-Volterra simulator on rows of 4 */
+static bool abz_jit_split_shape(int sim_id, int L, int C) {
+  return L == 1 && ((sim_id == ABZ_SIM_USER && (C == 4 || C == 8 || C == 16)) || (sim_id == ABZ_SIM_LV && C == 4));
+}
+/* threads per workgroup of a user simulator's second launch: the staged form keeps a workgroup's proposals and their carried state in
+ * LDS (abz_user_rounds.h: 8 C + 8 ABZ_USER_STATE + 44 bytes per proposal), which at 16 doubles per row fits for 128 of them */
+static unsigned abz_jit_user_p2_block(int C) { return C == 16 ? 128u : (unsigned)ABZ_BLOCK; }
+
 static int abz_jit_make_tu(int sim_id, int L, int C, bool plain, bool has_blob, bool wrap, const char* user_source, std::string& tu,
                            std::vector<std::string>& defs) {
   const bool user = sim_id == ABZ_SIM_USER;
@@ -97,17 +106,17 @@ static int abz_jit_make_tu(int sim_id, int L, int C, bool plain, bool has_blob, 
         "  mc_swarm_kernel_body<ABZ_JIT_SIM, ABZ_USER_L, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a);\n}\n"
         "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_replay(const SmcReplayPackedArgs a) {\n"
         "  smc_replay_packed_body<ABZ_USER_L, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a);\n}\n";
-  const bool split = L == 1 && ((user && (C == 4 || C == 8)) || (sim_id == ABZ_SIM_LV && C == 4));  /* rows the two-launch sweep exists for */
+  const bool split = abz_jit_split_shape(sim_id, L, C);
   if (split && user)
     tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p1(const SmcPackedArgs a, const LvHandList h) {\n"
           "  smc_split_phase1_body<ABZ_SIM_USER, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
           "#ifdef ABZ_USER_ROUNDS\n"      /* the staged form: round by round, leavers dropped (abz_user_rounds.h) */
-          "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
-          "  smc_user_rounds_phase2_body<ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
+          "extern \"C\" __global__ __launch_bounds__(ABZ_USER_P2_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
+          "  smc_user_rounds_phase2_body<ABZ_USER_C, ABZ_USER_PLAIN != 0, ABZ_USER_P2_BLOCK>(a, h);\n}\n"
           "extern \"C\" __global__ void abz_user_has_rounds() {}\n"
           "#else\n"
-          "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
-          "  smc_split_phase2_body<ABZ_SIM_USER, ABZ_USER_C, ABZ_USER_PLAIN != 0>(a, h);\n}\n"
+          "extern \"C\" __global__ __launch_bounds__(ABZ_USER_P2_BLOCK) void abz_user_smc_p2(const SmcPackedArgs a, const LvHandList h) {\n"
+          "  smc_split_phase2_body<ABZ_SIM_USER, ABZ_USER_C, ABZ_USER_PLAIN != 0, ABZ_USER_P2_BLOCK>(a, h);\n}\n"
           "#endif\n";
   if (split && !user)                    /* the built-in Lotka-Volterra simulator: its own two launches (rounds with early exit) */
     tu += "extern \"C\" __global__ __launch_bounds__(ABZ_BLOCK) void abz_user_smc_p1(const SmcPackedArgs a, const LvHandList h) {\n"
@@ -123,13 +132,14 @@ static int abz_jit_make_tu(int sim_id, int L, int C, bool plain, bool has_blob, 
           "-DABZ_JIT_SIM=" + std::to_string(sim_id)};
   if (has_blob && user) defs.push_back("-DABZ_USER_HAS_BLOB=1");
   if (wrap) defs.push_back("-DABZ_PRIOR_WRAP=1");
+  if (split && user) defs.push_back("-DABZ_USER_P2_BLOCK=" + std::to_string(abz_jit_user_p2_block(C)));
   return 0;
 }
 
 int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   const int L = ctx->L, C = ctx->C, sim_id = ctx->h_model.sim_id;
   const bool user = sim_id == ABZ_SIM_USER;
-  const bool split = L == 1 && ((user && (C == 4 || C == 8)) || (sim_id == ABZ_SIM_LV && C == 4));
+  const bool split = abz_jit_split_shape(sim_id, L, C);
   const bool has_blob = ctx->h_model.n_blob > 0;     /* then a user source must also define abz_user_blob */
   std::string tu;
   std::vector<std::string> defs;
@@ -184,7 +194,7 @@ int abz_jit_build(abcdez_ctx* ctx, const char* user_source) {
   ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_replay, um->mod, "abz_user_replay"));
   if (has_blob && user) ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_blob, um->mod, "abz_user_blob_eval"));
   um->block_smc = (sim_id == ABZ_SIM_LV && L == 1 && C == 4) ? ABZ_LV_BLOCK : ABZ_BLOCK;      /* abz_sweep_block of the one-kernel body */
-  um->block_p2 = user ? ABZ_BLOCK : ABZ_LV_BLOCK2;
+  um->block_p2 = user ? abz_jit_user_p2_block(C) : (unsigned)ABZ_LV_BLOCK2;
   if (split) {
     ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p1, um->mod, "abz_user_smc_p1"));
     ABZ_HIP_CHECK(hipModuleGetFunction(&um->f_p2, um->mod, "abz_user_smc_p2"));

@@ -463,7 +463,7 @@ __device__ inline void smc_swarm_packed_body_2p(const SmcPackedArgs& a) {
  * body, the one-phase body and the oracle.  Phase 1 leaves bits_out = bits and the flag bytes without the accepted bit; phase 2
  * flips / sets them for the proposals it accepts. */
 struct LvHandList {
-  double* tp;               /* [cap][C] proposal rows (C = 4: Lotka-Volterra; 4 or 8: user-supplied simulators) */
+  double* tp;               /* [cap][C] proposal rows (C = 4: Lotka-Volterra; 4, 8 or 16: user-supplied simulators) */
   double* wl;               /* lp - lpi */
   double* kdi;              /* K(di) */
   double* logu;             /* log(rand) of smc:145 */
@@ -473,11 +473,11 @@ struct LvHandList {
 };
 #define ABZ_LV_BLOCK2 256   /* threads per workgroup of the second launch */
 
-/* phase 1 for any simulator that runs one lane per particle with rows of C = 4 or 8 doubles (Lotka-Volterra; user-supplied simulators) */
+/* phase 1 for any simulator that runs one lane per particle with rows of C = 4, 8 or 16 doubles (Lotka-Volterra; user-supplied simulators) */
 template <int SIM, int C, bool PLAIN, int BLOCK = ABZ_BLOCK>
 __device__ inline void smc_split_phase1_body(const SmcPackedArgs& a, const LvHandList& h) {
   constexpr int L = 1, LD = C, PB = BLOCK;
-  static_assert(C >= 2 && (C & 1) == 0 && !ABZ_ROWS_DOUBLE_BUFFERED(LD), "two-launch sweep: rows of 4 or 8 doubles");
+  static_assert(C >= 2 && (C & 1) == 0 && !ABZ_ROWS_DOUBLE_BUFFERED(LD), "two-launch sweep: rows of 4, 8 or 16 doubles");
   const HotModel& M = a.hm;
   if (a.stop && *a.stop) return;                    /* grid-uniform: written by the kernel before this one */
   const uint32_t tile = a.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -691,7 +691,7 @@ __device__ inline void smc_lv_phase2_body(const SmcPackedArgs& a, const LvHandLi
 /* Two phases wherever a skipped simulation is worth a hand-over through LDS: rows spread over 2, 4 or 8 lanes (the d-dimensional
  * Normal simulator: four Philox blocks and Box-Muller pairs per lane), and the Lotka-Volterra simulator (1500 RK4 steps per call; with
  * its bounded prior half of the proposals and more leave the support, smc:135, and in the one-phase body their lanes idle through
- * their wave-mates' simulations), and user-supplied simulators of 3 to 8 parameters (cost unknown, usually the bulk of the sweep).
+ * their wave-mates' simulations), and user-supplied simulators of 3 to 8 parameters (cost unknown, usually the bulk of the sweep; in two LAUNCHES, the default for them, up to 16 parameters).
  * One phase for the rest: the cheap one-lane simulators, rows of one or two doubles (double-buffered), the widest lane groups.  ABZ_SWEEP_ONE_PHASE forces the one-phase body everywhere (A/B measurements). */
 /* threads per workgroup of the sweep: 512 for the Lotka-Volterra simulator -- about a third of a tile's proposals reach phase 2, and
  * 170 of 512 fill three wavefronts to 89 % where 85 of 256 fill two to 67 % (the simulator is all of that kernel's time) */

@@ -10,7 +10,7 @@
  * abz_user_round advances the simulation by one step and returns a LOWER BOUND of the final distance that never decreases from one
  * round to the next; what the last round returns IS the distance.  rng continues where the round before left it.
  *
- * What the library does with it (abz_kernels.h, the two-launch sweep of rows of 4 or 8 doubles): the second launch runs the proposals
+ * What the library does with it (abz_kernels.h, the two-launch sweep of rows of 4, 8 or 16 doubles): the second launch runs the proposals
  * round by round, as the built-in Lotka-Volterra simulator does; a proposal whose bound has passed eps is rejected for certain -- every
  * ABC kernel is zero beyond eps (src/abcdez_types.jl:26-73), so smc:140-145 reject it whatever the remaining rounds would return --,
  * leaves, and the proposals still in flight are re-packed into the leading lanes.  The accepted population is bit for bit what the

@@ -14,7 +14,7 @@ import abcdez_amd as A
 from abcdez_amd import _lib
 from abcdez_amd.engine import HipOps, PopulationEngine
 
-from user_sources import USER_LV_ROUNDS, USER_MVN_LANES
+from user_sources import USER_LV_ROUNDS, USER_MVN16, USER_MVN_LANES, USER_SEQ16, USER_SEQ16_ROUNDS
 
 pytestmark = pytest.mark.gpu
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
@@ -99,3 +99,57 @@ def test_staged_form_limits_are_compile_errors():
     with pytest.raises(_lib.AbcdezError, match="ABZ_USER_STATE"):
         A.abcdesmc(prior, A.UserSimulator(src.replace("#define ABZ_USER_STATE 3", "#define ABZ_USER_STATE 9"), params=params, data=obs), 1.2, None,
                    nparticles=1024, verbose=False, rng=1)
+
+
+# ---- 9 to 16 parameters: one lane per particle on rows of 16 doubles; the sweep in two launches (the second one 128 threads wide) ----
+def prior_12():
+    return A.Factored(A.Normal(0, 2), A.Gamma(2.0, 1.0), A.Uniform(-2, 3), A.truncated(A.Normal(1.0, 2.0), 0.0, None), A.Normal(0, 1),
+                      A.LogNormal(0.0, 0.7), *[A.Normal(0.5, 1.5)] * 6)
+
+
+Y12 = (1.0, 0.5, 0.8, 1.2, 0.3, 1.5, 0.2, 0.9, 1.1, 0.4, 0.7, 0.6)
+
+
+@pytest.mark.parametrize("d", [9, 12, 16])
+@pytest.mark.parametrize("sweep", ["two launches", "one kernel"])
+def test_user_simulator_of_nine_to_sixteen_parameters_equals_the_builtin(oracle, sweep, d, monkeypatch):
+    """the d-dimensional Normal simulator restated as one opaque abz_user_dist over a row of 16 doubles (d = 16: no padding
+    component) equals the built-in one -- the oracle -- bit for bit: in the two-launch sweep (phase 2 over the dense list of the
+    proposals that can still be accepted) and inside the one-kernel body (ABZ_USER_ONE_KERNEL=1); abcdemc and the initial
+    population with it"""
+    monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "1" if sweep == "one kernel" else "0")
+    factors = (prior_12().p + (A.Normal(0, 1),) * 4)[:d]
+    y = (Y12 + (0.9, 0.1, 1.3, 0.5))[:d]
+    prior = A.Factored(*factors)
+    run_both(prior, A.UserSimulator(USER_MVN16, params=(0.8,), data=y), A.MVNormal(y, sigma=0.8), 6000, 0.62 * math.sqrt(d), oracle, seed=29,
+             generations=10)
+
+
+def _whole_run(prior, sim, N, eps, seed, **kw):
+    r = A.abcdesmc(prior, sim, eps, None, nparticles=N, verbose=False, rng=seed, nsims_max=10 ** 10, **kw)
+    res = r.engine.result()
+    m = A.abcdemc(prior, sim, eps, None, nparticles=N, generations=8, verbose=False, rng=seed + 1)
+    mres = m.engine.result()
+    return (r.logZ, r.nsims, r.iters, res["theta"].copy(), res["C"].copy(), res["Wns"].copy(), mres["theta"].copy(), mres["C"].copy())
+
+
+@pytest.mark.parametrize("kernel", ["indicator", "epanechnikov"])
+def test_staged_form_on_rows_of_sixteen_doubles(kernel, monkeypatch):
+    """ONE model of 12 parameters in the opaque and in the staged form (squared errors accumulated pair by pair: 1, 2, 4 or 8 rounds
+    over the 8 pairs).  The anchor is the opaque form inside the one-kernel body -- the only path such a model had before the
+    two-launch sweep took rows of 16 doubles; the opaque form in two launches and every staged form (proposals leaving after the
+    round in which their running sum passes eps, survivors re-packed; 128 proposals per workgroup) must reproduce its whole run:
+    evidence, counters, every particle, distance and weight, abcdemc's population."""
+    prior = prior_12()
+    kw = dict(ABCk=A.Epa0toϵ) if kernel == "epanechnikov" else {}
+    N, eps, seed = 6000, 2.3, 31
+    monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "1")
+    anchor = _whole_run(prior, A.UserSimulator(USER_SEQ16, params=(0.8,), data=Y12), N, eps, seed, **kw)
+    assert anchor[2] > 5 and np.isfinite(anchor[0])
+    monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "0")
+    forms = [USER_SEQ16] + [USER_SEQ16_ROUNDS % {"rounds": r} for r in (1, 2, 4, 8)]
+    for src in forms:
+        got = _whole_run(prior, A.UserSimulator(src, params=(0.8,), data=Y12), N, eps, seed, **kw)
+        assert got[:3] == anchor[:3], (src[:60], got[:3], anchor[:3])
+        for a, b in zip(got[3:], anchor[3:]):
+            assert np.array_equal(a, b)

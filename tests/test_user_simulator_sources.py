@@ -14,7 +14,7 @@ import pytest
 import abcdez_amd as A
 from abcdez_amd import _lib
 
-from user_sources import USER_LV, USER_LV_ROUNDS, USER_MVN_LANES
+from user_sources import USER_MVN16, USER_SEQ16, USER_SEQ16_ROUNDS, USER_LV, USER_LV_ROUNDS, USER_MVN_LANES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
@@ -50,6 +50,12 @@ CASES = {
                   {"-DABZ_USER_L=1", "-DABZ_USER_C=4", "-DABZ_USER_PLAIN=0"}, "smc_user_rounds_phase2_body"),
     "lv_opaque": (A.Factored(*[A.Uniform(0.0, 2.0)] * 4), A.UserSimulator(USER_LV, params=(1.0, 0.5, 0.01, 100.0, 0.1), data=(1.0, 0.5) * 16),
                   {"-DABZ_USER_L=1", "-DABZ_USER_C=4", "-DABZ_USER_PLAIN=0"}, "smc_split_phase2_body"),
+    # 9 to 16 parameters: one lane per particle on rows of 16 doubles, the sweep in two launches, the second one 128 threads wide
+    "mvn12_opaque": (A.Factored(*[A.Normal(0, 1)] * 12), A.UserSimulator(USER_MVN16, params=(1.0,), data=(1.0,) * 12),
+                     {"-DABZ_USER_L=1", "-DABZ_USER_C=16", "-DABZ_USER_P2_BLOCK=128"}, "smc_split_phase2_body"),
+    "seq12_rounds": (A.Factored(*([A.Normal(0, 1)] * 11 + [A.Gamma(2.0, 1.0)])),
+                     A.UserSimulator(USER_SEQ16_ROUNDS % {"rounds": 4}, params=(1.0,), data=(1.0,) * 12),
+                     {"-DABZ_USER_L=1", "-DABZ_USER_C=16", "-DABZ_USER_PLAIN=0", "-DABZ_USER_P2_BLOCK=128"}, "smc_user_rounds_phase2_body"),
     # BUILT-IN simulators whose model has prior factors of the wrapper families (truncated(...), MixtureModel): the statically compiled
     # sweeps do not carry those log-densities (include/abcdez_spec.h, ABZ_PRIOR_WRAP), so the library compiles this model's sweep,
     # replay and abcdemc kernels at run time with -DABZ_PRIOR_WRAP=1

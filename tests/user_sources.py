@@ -87,3 +87,58 @@ __device__ double abz_user_dist(const double* th, int d, const double* data, int
   return abz_sqrt(acc);
 }
 """
+
+# 9 to 16 parameters, one lane per particle (rows of 16 doubles).  USER_MVN16 is the d-dimensional Normal simulator again (tree sum of
+# the squared errors: equal to the built-in, whatever lane shape that runs in).  USER_SEQ16 / USER_SEQ16_ROUNDS are ONE model in the
+# opaque and in the staged form: the squared errors accumulated pair by pair in order -- a running sum that only grows, so its square
+# root after any number of pairs is a lower bound of the distance.
+USER_MVN16 = """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  double sq[16];
+  for (int m = 0; m < 8; ++m) {
+    double z[2];
+    rng.normal_pair(z[0], z[1]);
+    for (int c = 0; c < 2; ++c) {
+      const int k = 2 * m + c;
+      double v = 0.0;
+      if (k < d) { const double x = abz_fma(p[0], z[c], th[k]); const double e = x - data[k]; v = e * e; }
+      sq[k] = v;
+    }
+  }
+  return abz_sqrt(abz_tree_sum_small(sq, 16));
+}
+"""
+
+_SEQ16_PAIR = """
+__device__ inline double seq16_pair(const double* th, int d, const double* data, const double* p, abz_user_rng& rng, int m, double acc) {
+  double z[2];
+  rng.normal_pair(z[0], z[1]);
+  for (int c = 0; c < 2; ++c) {
+    const int k = 2 * m + c;
+    if (k < d) { const double e = abz_fma(p[0], z[c], th[k]) - data[k]; acc = abz_fma(e, e, acc); }
+  }
+  return acc;
+}
+"""
+
+USER_SEQ16 = _SEQ16_PAIR + """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  double acc = 0.0;
+  for (int m = 0; m < 8; ++m) acc = seq16_pair(th, d, data, p, rng, m, acc);
+  return abz_sqrt(acc);
+}
+"""
+
+USER_SEQ16_ROUNDS = """
+#define ABZ_USER_ROUNDS %(rounds)d
+#define ABZ_USER_STATE 1
+""" + _SEQ16_PAIR + """
+__device__ double abz_user_round(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng,
+                                 int round, double* st) {
+  const int per = 8 / ABZ_USER_ROUNDS;
+  double acc = st[0];
+  for (int m = round * per; m < (round + 1) * per; ++m) acc = seq16_pair(th, d, data, p, rng, m, acc);
+  st[0] = acc;
+  return abz_sqrt(acc);
+}
+"""
