@@ -64,6 +64,9 @@ ABCDEZ_API int abcdez_ctx_create(const abz_model* model, int device, abcdez_ctx*
  *                                      abz_user_rng& rng, int round, double* state);
  *   returning after every step a lower bound of the final distance that never decreases: proposals whose bound has passed eps leave
  *   the simulation early (csrc/abz_user_rounds.h), results bit for bit those of running every round.
+ *   With 3 to 16 parameters (rows of 4, 8 or 16 doubles) either one-thread form sweeps in TWO launches: the simulator runs in a launch of
+ *   its own over the dense list of the proposals the prior ratio has not already rejected (that is where the staged form's early exit
+ *   acts); ABZ_USER_ONE_KERNEL=1 in the environment keeps it inside the sweep kernel.
  * (theta push_p-cast; rng.uniform() / rng.normal() / rng.normal_pair(z0, z1) / rng.bits() hand out the
  * particle's Philox stream).  It is compiled with hiprtc for the device's architecture together with the
  * library's own kernel bodies; a compile error comes back as a negative status with the compiler log in

@@ -546,7 +546,7 @@ def test_user_simulator_of_four_parameters_runs_the_two_phase_sweep(oracle, swee
     """a user simulator with 3 to 8 parameters takes the two-phase sweep (csrc/abz_kernels.h: the simulator runs only for proposals
     that are in the prior's support and not already rejected on the prior ratio, densely packed): the Lotka-Volterra model restated
     as HIP source must equal the built-in simulator -- hence the oracle, which simulates every in-support proposal -- bit for bit.
-    Rows of 4 or 8 doubles sweep in two launches by default (phase 2 over a dense list of the surviving proposals);
+    Rows of 4, 8 (and 16: tests/test_gpu_user_simulators.py) doubles sweep in two launches by default (phase 2 over a dense list of the surviving proposals);
     ABZ_USER_ONE_KERNEL=1, read when the context is created, keeps the one-kernel body: both must give the same bits."""
     monkeypatch.setenv("ABZ_USER_ONE_KERNEL", "1" if sweep == "one kernel" else "0")
     obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6)
