@@ -90,7 +90,7 @@ LotkaVolterraRK4(obs; x0=1.0, y0=0.5, dt=0.01, steps_per_obs=100, noise=0.1, blo
 struct Socks <: DeviceSimulator; pairs::Float64; odd::Float64; n_picked::Int; blobs::Bool; end       # test/runtests.jl:427-437
 Socks(pairs, odd; n_picked=11, blobs=false) = Socks(pairs, odd, n_picked, blobs)
 # a device function given as HIP source text (abcdez_ctx_create_user): defines abz_user_dist (length(prior) <= 16), abz_user_dist_lanes
-# (17 .. 64: the row spread over the lanes of a wavefront) or the staged abz_user_round (ABZ_USER_ROUNDS: proposals whose running lower
+# (17 .. 256: the row spread over the lanes of a wavefront) or the staged abz_user_round (ABZ_USER_ROUNDS: proposals whose running lower
 # bound of the distance has passed ϵ leave the simulation early), and abz_user_blob when n_blob > 0 (INTEGRATION.md section 1)
 struct UserSimulator <: DeviceSimulator; source::String; params::Vector{Float64}; data::Vector{Float64}; n_blob::Int; end
 UserSimulator(source; params=Float64[], data=Float64[], n_blob=0) = UserSimulator(source, collect(Float64, params), collect(Float64, data), n_blob)

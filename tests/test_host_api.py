@@ -399,3 +399,32 @@ def test_prior_family_ids_agree_between_header_python_and_julia():
         assert m and int(m.group(1)) == ids[name], (name, m and m.group(0))
         d = py_class[name].descriptor()
         assert d[0] == ids[name] and int(m.group(2)) == d[1] == int(py_class[name].discrete), name
+
+
+def test_shim_block_structure_balances():
+    """no Julia here to parse julia/ABCdeZHIP.jl: at least every block opener (function, if, for, while, try, struct, let, begin, do,
+    module, `abstract type`) must meet its `end`, function definitions must sit directly inside the module, and the module must close on
+    the last line -- what an edit that drops or doubles an `end` breaks first"""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "julia", "ABCdeZHIP.jl"), encoding="utf-8").read()
+    stack = []
+    opener = re.compile(r"(?<![\w.:@])(abstract type|function|if|for|while|try|struct|let|begin|do|quote|module|macro|end)(?![\w!])")
+    for no, line in enumerate(src.splitlines(), 1):
+        code = re.sub(r"#.*$", "", re.sub(r'"(?:\\.|[^"\\])*"', '""', line))
+        for m in opener.finditer(code):
+            pre, tok = code[:m.start()], m.group(1)
+            in_brackets = pre.count("[") - pre.count("]") > 0
+            in_call = pre.count("(") - pre.count(")") > 0
+            if tok == "end":
+                if in_brackets:
+                    continue                      # a[end]
+                assert stack, f"line {no}: `end` without an opener"
+                stack.pop()
+            elif tok in ("for", "if") and (in_brackets or in_call):
+                continue                          # comprehension / generator
+            else:
+                if tok == "function" and not line.startswith(" "):
+                    assert [t for t, _ in stack] == ["module"], f"line {no}: a top-level function inside {stack}"
+                stack.append((tok, no))
+    assert not stack, f"unclosed blocks: {stack}"
+    assert src.rstrip().splitlines()[-1].startswith("end")
