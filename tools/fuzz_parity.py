@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Differential campaign: random models and random driver settings through the HIP library and through the CPU oracle, whole runs
+compared bit for bit.  Wider than the seeded cases of tests/test_gpu_parity.py (which this reuses the prior generator of): population
+sizes that are not multiples of anything, Kmcmc beyond the 16 sweeps one library call takes, every early-exit / tuning / stopping
+keyword of src/abcdez_smc.jl:215-235, targets the population cannot reach, a few abcdemc generations of the same model.  One JSON line per case; exit
+status 1 at the first difference (the case's seed reproduces it: --first SEED --cases 1).
+
+    python tools/fuzz_parity.py --cases 400 --first 0 > gpurun_out/fuzz.jsonl
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import abcdez_amd as A                                   # noqa: E402
+from oracle import oracle as O                           # noqa: E402  (the checker; tools are test infrastructure)
+from test_gpu_parity import _further_family              # noqa: E402
+
+
+def random_prior(rng, d, nfam):
+    fams = []
+    for _ in range(d):
+        k = int(rng.integers(0, nfam))
+        if k >= 5:
+            fams.append(_further_family(k - 5, rng))
+        elif k == 0:
+            fams.append(A.Normal(float(rng.normal(0.5, 1.0)), float(rng.uniform(0.3, 2.0))))
+        elif k == 1:
+            a = float(rng.uniform(-3, 1))
+            fams.append(A.Uniform(a, a + float(rng.uniform(1.0, 5.0))))
+        elif k == 2:
+            a = int(rng.integers(-3, 2))
+            fams.append(A.DiscreteUniform(a, a + int(rng.integers(1, 6))))
+        elif k == 3:
+            fams.append(A.Beta(float(rng.uniform(0.6, 4.0)), float(rng.uniform(0.6, 4.0))))
+        else:
+            fams.append(A.NegativeBinomial(float(rng.uniform(0.7, 6.0)), float(rng.uniform(0.2, 0.8))))
+    return fams[0] if d == 1 and rng.random() < 0.5 else A.Factored(*fams)
+
+
+def random_case(seed):
+    rng = np.random.default_rng(50_000 + seed)
+    u = rng.random()
+    d = int(rng.integers(1, 5)) if u < 0.15 else int(rng.integers(1, 49)) if u < 0.9 else int(rng.integers(65, 141))
+    nfam = [5, 18, 25][int(rng.integers(0, 3))] if d <= 48 else 5          # (wide rows: the reference's five families, as the suite)
+    sim_kind = "mvn"
+    if d == 1 and rng.random() < 0.5:
+        sim_kind = "normal1d"
+    elif d == 4 and rng.random() < 0.5:
+        sim_kind = "lv"
+    if sim_kind == "lv":
+        prior = A.Factored(*[A.Uniform(0.0, float(rng.uniform(1.5, 2.5))) for _ in range(4)])
+        obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6)
+        sim = A.LotkaVolterraRK4(obs, dt=0.05, steps_per_obs=int(rng.integers(4, 12)), blobs=bool(rng.random() < 0.3))
+    elif sim_kind == "normal1d":
+        prior = random_prior(rng, 1, nfam)
+        sim = A.Normal1D(float(rng.normal(1.0, 1.0)), blobs=bool(rng.random() < 0.3))
+    else:
+        prior = random_prior(rng, d, nfam)
+        y = tuple(float(v) for v in rng.normal(1.0, 0.5, d))
+        sim = A.MVNormal(y, sigma=float(rng.uniform(0.5, 1.5)), blobs=bool(rng.random() < 0.3) and d <= 64)
+    kern = [A.IndicatorStrict0toϵ, A.Indicator0toϵ, A.Epa0toϵ, A.EpaStrict0toϵ][int(rng.integers(0, 4))]
+    α = float(rng.uniform(0.3, 0.97))
+    δess = float(rng.uniform(0.1, 0.9))
+    n_min = int(math.ceil(3 * d / min(α, δess)))
+    N = n_min + int(rng.integers(0, 3000)) if rng.random() < 0.9 else n_min + int(rng.integers(3000, 20000))
+    Kmcmc = int(rng.integers(1, 7)) if rng.random() < 0.93 else int(rng.integers(17, 21))
+    Kmcmc_min = [1.0, 1.0, 0.3, 0.1, float("inf"), 0.0, 2.5][int(rng.integers(0, 7))]
+    facc_min = [0.0, 0.0, 0.3, 0.6][int(rng.integers(0, 4))]
+    facc_stop = [0.0, 0.0, 0.0, 0.05, 0.2][int(rng.integers(0, 5))]
+    if not Kmcmc_min > facc_min:                         # the reference only warns (smc:233); keep the log quiet
+        facc_min = 0.0
+    q = [0.3, 0.3, 0.3, 0.05, 0.6, 0.0][int(rng.integers(0, 6))]     # 0.0: a target below every distance (the run ends some other way)
+    nsims_max = 10 ** 8 if rng.random() < 0.8 else int(N * rng.uniform(1.0, 8.0))
+    return dict(seed=seed, d=d, nfam=nfam, sim=sim_kind, prior=prior, simulator=sim, ABCk=kern, N=N, q=q,
+                smc=dict(α=α, δess=δess, Kmcmc=Kmcmc, Kmcmc_min=Kmcmc_min, facc_min=facc_min, facc_stop=facc_stop,
+                         facc_tune=float(rng.uniform(0.8, 0.99)), nsims_max=nsims_max),
+                mc=dict(generations=int(rng.integers(2, 12))))
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def run_case(c):
+    prior, sim, kern, N = c["prior"], c["simulator"], c["ABCk"], c["N"]
+    seed = c["seed"]
+    probe = O.oracle_engine(A.ModelSpec(prior, sim, kern, seed=seed + 1), N)
+    probe.init_population()
+    eps = probe.quantile_alive(c["q"]) if c["q"] > 0 else 0.0
+    kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=30, **c["smc"])
+    selftest = os.environ.get("ABZ_FUZZ_SELFTEST") == "1"       # both sides the oracle: checks this script where there is no GPU
+    hip = dict(engine=O.oracle_engine) if selftest else {}
+    r = A.abcdesmc(prior, sim, eps, None, **hip, **kw)
+    o = A.abcdesmc(prior, sim, eps, None, engine=O.oracle_engine, **kw)
+    assert selftest or type(r.engine.ops).__name__ == "HipOps"
+    bad = []
+    if not (r.iters == o.iters and r.nsims == o.nsims):
+        bad.append(("iters/nsims", (r.iters, r.nsims), (o.iters, o.nsims)))
+    if not (r.logZ == o.logZ or (math.isnan(r.logZ) and math.isnan(o.logZ))):
+        bad.append(("logZ", r.logZ, o.logZ))
+    for k in ("ϵs", "esss", "faccs", "γ0s", "Kmcmcs", "logZs"):
+        if not same(getattr(r, k), getattr(o, k)):
+            bad.append((k, list(getattr(r, k))[-3:], list(getattr(o, k))[-3:]))
+    if not same(np.array(r.ranges_ϵ), np.array(o.ranges_ϵ)):
+        bad.append(("ranges_ϵ",))
+    for k in ("P", "Wns", "C"):
+        if not same(getattr(r, k), getattr(o, k)):
+            bad.append((k,))
+    if sim.blobs and not same(r.blobs, o.blobs):
+        bad.append(("blobs",))
+    mkw = dict(nparticles=N, verbose=False, rng=seed + 2, **c["mc"])
+    m = A.abcdemc(prior, sim, eps, None, **hip, **mkw)
+    mo = A.abcdemc(prior, sim, eps, None, engine=O.oracle_engine, **mkw)
+    if not (m.nsims == mo.nsims and same(m.P, mo.P) and same(m.C, mo.C) and m.reached_ϵ == mo.reached_ϵ):
+        bad.append(("abcdemc", m.nsims, mo.nsims))
+    if sim.blobs and not same(m.blobs, mo.blobs):
+        bad.append(("abcdemc blobs",))
+    return dict(eps=eps, iters=r.iters, nsims=r.nsims, logZ=r.logZ, resamples=int(sum(1 for a, b in zip(r.esss[1:], r.esss[2:]) if b > a)),
+                alive_end=int(np.count_nonzero(np.asarray(r.Wns) > 0)), mc_nsims=m.nsims), bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--seconds", type=float, default=0.0, help="stop starting new cases after this many seconds (0: run them all)")
+    args = ap.parse_args()
+    O.build()
+    t0 = time.time()
+    n_bad = 0
+    for seed in range(args.first, args.first + args.cases):
+        if args.seconds and time.time() - t0 > args.seconds:
+            break
+        c = random_case(seed)
+        head = dict(seed=seed, d=c["d"], families=c["nfam"], sim=c["sim"], kernel=c["ABCk"].__name__, N=c["N"], q=c["q"],
+                    blobs=bool(c["simulator"].blobs), **{k: v for k, v in c["smc"].items()}, mc=c["mc"])
+        t = time.time()
+        try:
+            info, bad = run_case(c)
+        except Exception as e:                          # a refusal both sides share is not a difference; anything else is reported
+            info, bad = dict(error=f"{type(e).__name__}: {e}"[:300]), [("exception",)]
+        head.update(info, seconds=round(time.time() - t, 2), same=not bad)
+        if bad:
+            head["differences"] = [str(b)[:200] for b in bad]
+            n_bad += 1
+        print(json.dumps(head, ensure_ascii=False), flush=True)
+        if bad:
+            break
+    print(json.dumps(dict(summary=True, first=args.first, ran=seed - args.first + (0 if n_bad == 0 and args.seconds and time.time() - t0 > args.seconds else 1),
+                          different=n_bad, seconds=round(time.time() - t0, 1))), flush=True)
+    sys.exit(1 if n_bad else 0)
+
+
+if __name__ == "__main__":
+    main()
