@@ -46,7 +46,7 @@ def random_prior(rng, d, nfam):
     return fams[0] if d == 1 and rng.random() < 0.5 else A.Factored(*fams)
 
 
-def random_case(seed):
+def random_case(seed, big=False):
     rng = np.random.default_rng(50_000 + seed)
     u = rng.random()
     d = int(rng.integers(1, 5)) if u < 0.15 else int(rng.integers(1, 49)) if u < 0.9 else int(rng.integers(65, 141))
@@ -72,6 +72,8 @@ def random_case(seed):
     δess = float(rng.uniform(0.1, 0.9))
     n_min = int(math.ceil(3 * d / min(α, δess)))
     N = n_min + int(rng.integers(0, 3000)) if rng.random() < 0.9 else n_min + int(rng.integers(3000, 20000))
+    if big:                                             # populations of many workgroups: multi-block scans, lists, the radix rank pass
+        N = n_min + int(rng.integers(50_000, 600_000))
     Kmcmc = int(rng.integers(1, 7)) if rng.random() < 0.93 else int(rng.integers(17, 21))
     Kmcmc_min = [1.0, 1.0, 0.3, 0.1, float("inf"), 0.0, 2.5][int(rng.integers(0, 7))]
     facc_min = [0.0, 0.0, 0.3, 0.6][int(rng.integers(0, 4))]
@@ -96,7 +98,7 @@ def run_case(c):
     probe = O.oracle_engine(A.ModelSpec(prior, sim, kern, seed=seed + 1), N)
     probe.init_population()
     eps = probe.quantile_alive(c["q"]) if c["q"] > 0 else 0.0
-    kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=30, **c["smc"])
+    kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=c.get("max_iters", 30), **c["smc"])
     selftest = os.environ.get("ABZ_FUZZ_SELFTEST") == "1"       # both sides the oracle: checks this script where there is no GPU
     hip = dict(engine=O.oracle_engine) if selftest else {}
     r = A.abcdesmc(prior, sim, eps, None, **hip, **kw)
@@ -133,6 +135,7 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop starting new cases after this many seconds (0: run them all)")
+    ap.add_argument("--big", action="store_true", help="populations of 50,000 to 600,000 particles, rows up to 48 parameters, at most 8 generations")
     args = ap.parse_args()
     O.build()
     t0 = time.time()
@@ -140,7 +143,10 @@ def main():
     for seed in range(args.first, args.first + args.cases):
         if args.seconds and time.time() - t0 > args.seconds:
             break
-        c = random_case(seed)
+        c = random_case(seed, big=args.big)
+        if args.big:
+            c["max_iters"] = 8
+            c["mc"]["generations"] = min(c["mc"]["generations"], 4)
         head = dict(seed=seed, d=c["d"], families=c["nfam"], sim=c["sim"], kernel=c["ABCk"].__name__, N=c["N"], q=c["q"],
                     blobs=bool(c["simulator"].blobs), **{k: v for k, v in c["smc"].items()}, mc=c["mc"])
         t = time.time()
