@@ -33,6 +33,8 @@ import time
 # window: idle OpenMP workers must sleep, not spin, or they compete with the thread that polls the GPU's read-backs.
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# RCCL between processes (the driver launches the ranks itself under torch.distributed.run): this driver stack only has dmabuf IPC
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
