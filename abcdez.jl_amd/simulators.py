@@ -224,7 +224,7 @@ class UserSimulator(DeviceSimulator):
       every lane count), and the function returns the distance on every lane.  Draws are addressed, not sequential:
       ``rng.normal_pair_at(k, z0, z1)``, ``rng.uniform_at(k)`` -- key them by component (``g.comp(q) / 2`` for a pair), never by lane.
 
-    * the STAGED form (any ``length(prior) <= 16``; it pays off on rows of 3 .. 8 parameters, which sweep in two launches)::
+    * the STAGED form (any ``length(prior) <= 16``; it pays off from 3 parameters on: those rows sweep in two launches)::
 
         #define ABZ_USER_ROUNDS 8      // the simulation in this many steps
         #define ABZ_USER_STATE 3       // doubles carried between steps (<= 8, zero before round 0)
@@ -253,7 +253,7 @@ class UserSimulator(DeviceSimulator):
 
     def __init__(self, source: str, params: Sequence[float] = (), data: Sequence[float] = (), n_blob: int = 0):
         if "abz_user_dist" not in source and "abz_user_round" not in source:
-            raise ValueError("the source must define abz_user_dist (rows of up to 16 parameters), abz_user_dist_lanes (17 .. 64) or "
+            raise ValueError("the source must define abz_user_dist (rows of up to 16 parameters), abz_user_dist_lanes (17 .. 256) or "
                              "abz_user_round (the staged form)")
         if not 0 <= int(n_blob) <= 64:
             raise ValueError("n_blob must be in 0..64")

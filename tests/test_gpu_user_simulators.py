@@ -153,3 +153,20 @@ def test_staged_form_on_rows_of_sixteen_doubles(kernel, monkeypatch):
         assert got[:3] == anchor[:3], (src[:60], got[:3], anchor[:3])
         for a, b in zip(got[3:], anchor[3:]):
             assert np.array_equal(a, b)
+
+
+def test_user_simulator_example_script():
+    """examples/user_simulator.py: an SIR epidemic written by a user in the staged form recovers the parameters its data were generated
+    at, and equals the same model written as one opaque call bit for bit"""
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "user_simulator.py")
+    spec = importlib.util.spec_from_file_location("user_simulator_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r, mean, sd, truth = mod.main(20000, verbose=False)
+    o, _, _, _ = mod.main(20000, source=mod.SIR_OPAQUE, verbose=False)
+    assert r.ϵ == 0.08 and r.iters > 20
+    assert np.all(np.abs(mean - np.array(truth)) < 2.5 * sd), (mean, sd)
+    assert sd[0] < 0.2 and sd[1] < 0.06                                  # the data are informative: far narrower than the priors
+    assert r.logZ == o.logZ and r.nsims == o.nsims and np.array_equal(np.array(r.P), np.array(o.P)) and np.array_equal(r.Wns, o.Wns)
