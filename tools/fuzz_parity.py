@@ -88,6 +88,40 @@ def random_case(seed, big=False):
                 mc=dict(generations=int(rng.integers(2, 12))))
 
 
+# the d-dimensional Normal simulator as a USER would write it, one thread per row of LD = 4, 8 or 16 doubles (3 to 16 parameters);
+# wider rows take tests/user_sources.py's cooperative form
+USER_MVN_ROW = """
+__device__ double abz_user_dist(const double* th, int d, const double* data, int n_data, const double* p, abz_user_rng& rng) {
+  double sq[%(ld)d];
+  for (int m = 0; m < %(ld)d / 2; ++m) {
+    double z[2];
+    rng.normal_pair(z[0], z[1]);
+    for (int c = 0; c < 2; ++c) {
+      const int k = 2 * m + c;
+      double v = 0.0;
+      if (k < d) { const double x = abz_fma(p[0], z[c], th[k]); const double e = x - data[k]; v = e * e; }
+      sq[k] = v;
+    }
+  }
+  return abz_sqrt(abz_tree_sum_small(sq, %(ld)d));
+}
+"""
+
+
+def user_form_of(sim, d, rng):
+    """the built-in d-dimensional Normal simulator restated as user-supplied source (None: no user form for this case)"""
+    if type(sim).__name__ != "MVNormal" or d < 3 or sim.blobs:
+        return None
+    from user_sources import USER_MVN_LANES
+
+    y, sigma = tuple(sim.data()), sim.params()[0]
+    if d <= 16:
+        ld = 4 if d <= 4 else 8 if d <= 8 else 16
+        os.environ["ABZ_USER_ONE_KERNEL"] = "1" if rng.random() < 0.3 else "0"       # read when the context is created
+        return A.UserSimulator(USER_MVN_ROW % {"ld": ld}, params=(sigma,), data=y)
+    return A.UserSimulator(USER_MVN_LANES, params=(sigma,), data=y)
+
+
 def same(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
@@ -101,7 +135,8 @@ def run_case(c):
     kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=c.get("max_iters", 30), **c["smc"])
     selftest = os.environ.get("ABZ_FUZZ_SELFTEST") == "1"       # both sides the oracle: checks this script where there is no GPU
     hip = dict(engine=O.oracle_engine) if selftest else {}
-    r = A.abcdesmc(prior, sim, eps, None, **hip, **kw)
+    hip_sim = (None if selftest else c.get("user_sim")) or sim      # (the oracle always runs the built-in simulator the source restates)
+    r = A.abcdesmc(prior, hip_sim, eps, None, **hip, **kw)
     o = A.abcdesmc(prior, sim, eps, None, engine=O.oracle_engine, **kw)
     assert selftest or type(r.engine.ops).__name__ == "HipOps"
     bad = []
@@ -120,7 +155,7 @@ def run_case(c):
     if sim.blobs and not same(r.blobs, o.blobs):
         bad.append(("blobs",))
     mkw = dict(nparticles=N, verbose=False, rng=seed + 2, **c["mc"])
-    m = A.abcdemc(prior, sim, eps, None, **hip, **mkw)
+    m = A.abcdemc(prior, hip_sim, eps, None, **hip, **mkw)
     mo = A.abcdemc(prior, sim, eps, None, engine=O.oracle_engine, **mkw)
     if not (m.nsims == mo.nsims and same(m.P, mo.P) and same(m.C, mo.C) and m.reached_ϵ == mo.reached_ϵ):
         bad.append(("abcdemc", m.nsims, mo.nsims))
@@ -135,6 +170,8 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop starting new cases after this many seconds (0: run them all)")
+    ap.add_argument("--user", action="store_true", help="the library runs the Normal simulator as USER-SUPPLIED source (run-time compiled: one thread per "
+                    "row up to 16 parameters, in two launches or inside the sweep kernel; the cooperative form beyond), the oracle the built-in")
     ap.add_argument("--big", action="store_true", help="populations of 50,000 to 600,000 particles, rows up to 48 parameters, at most 8 generations")
     args = ap.parse_args()
     O.build()
@@ -147,8 +184,15 @@ def main():
         if args.big:
             c["max_iters"] = 8
             c["mc"]["generations"] = min(c["mc"]["generations"], 4)
+        if args.user:
+            if c["sim"] == "mvn" and c["simulator"].blobs:
+                c["simulator"] = A.MVNormal(tuple(c["simulator"].data()), sigma=c["simulator"].params()[0])
+            c["user_sim"] = user_form_of(c["simulator"], c["d"], np.random.default_rng(seed))
+            if c["user_sim"] is None:
+                continue
         head = dict(seed=seed, d=c["d"], families=c["nfam"], sim=c["sim"], kernel=c["ABCk"].__name__, N=c["N"], q=c["q"],
-                    blobs=bool(c["simulator"].blobs), **{k: v for k, v in c["smc"].items()}, mc=c["mc"])
+                    blobs=bool(c["simulator"].blobs), **{k: v for k, v in c["smc"].items()}, mc=c["mc"],
+                    **({"user_one_kernel": os.environ.get("ABZ_USER_ONE_KERNEL", "0")} if args.user else {}))
         t = time.time()
         try:
             info, bad = run_case(c)
