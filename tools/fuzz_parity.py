@@ -161,6 +161,24 @@ def run_case(c):
         bad.append(("abcdemc", m.nsims, mo.nsims))
     if sim.blobs and not same(m.blobs, mo.blobs):
         bad.append(("abcdemc blobs",))
+    if c.get("resume") and not selftest:
+        # interrupted and continued (max_iters / resume=checkpoint, a few abcdemc generations then the rest): the same bits as the
+        # uninterrupted run of the library
+        rs = np.random.default_rng(seed + 5)
+        if r.iters >= 2:
+            k = int(rs.integers(1, r.iters))
+            part = A.abcdesmc(prior, hip_sim, eps, None, **{**kw, "max_iters": k})
+            cont = A.abcdesmc(prior, hip_sim, eps, None, resume=part.checkpoint(), **kw)
+            if not (cont.iters == r.iters and cont.nsims == r.nsims and (cont.logZ == r.logZ or math.isnan(r.logZ)) and same(cont.P, r.P)
+                    and same(cont.Wns, r.Wns) and same(cont.C, r.C) and same(cont.ϵs, r.ϵs) and same(cont.esss, r.esss)):
+                bad.append(("abcdesmc resumed after %d of %d generations" % (k, r.iters),))
+        G = mkw["generations"]
+        if G >= 2:
+            g1 = int(rs.integers(1, G))
+            part = A.abcdemc(prior, hip_sim, eps, None, **{**mkw, "generations": g1})
+            cont = A.abcdemc(prior, hip_sim, eps, None, resume=part.checkpoint(), **mkw)
+            if not (cont.nsims == m.nsims and same(cont.P, m.P) and same(cont.C, m.C)):
+                bad.append(("abcdemc resumed after %d of %d generations" % (g1, G),))
     return dict(eps=eps, iters=r.iters, nsims=r.nsims, logZ=r.logZ, resamples=int(sum(1 for a, b in zip(r.esss[1:], r.esss[2:]) if b > a)),
                 alive_end=int(np.count_nonzero(np.asarray(r.Wns) > 0)), mc_nsims=m.nsims), bad
 
@@ -172,6 +190,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0, help="stop starting new cases after this many seconds (0: run them all)")
     ap.add_argument("--user", action="store_true", help="the library runs the Normal simulator as USER-SUPPLIED source (run-time compiled: one thread per "
                     "row up to 16 parameters, in two launches or inside the sweep kernel; the cooperative form beyond), the oracle the built-in")
+    ap.add_argument("--resume", action="store_true", help="also interrupt every run at a random generation and continue it from its checkpoint")
     ap.add_argument("--big", action="store_true", help="populations of 50,000 to 600,000 particles, rows up to 48 parameters, at most 8 generations")
     args = ap.parse_args()
     O.build()
@@ -184,6 +203,7 @@ def main():
         if args.big:
             c["max_iters"] = 8
             c["mc"]["generations"] = min(c["mc"]["generations"], 4)
+        c["resume"] = args.resume
         if args.user:
             if c["sim"] == "mvn" and c["simulator"].blobs:
                 c["simulator"] = A.MVNormal(tuple(c["simulator"].data()), sigma=c["simulator"].params()[0])
