@@ -46,9 +46,9 @@ def random_prior(rng, d, nfam):
     return fams[0] if d == 1 and rng.random() < 0.5 else A.Factored(*fams)
 
 
-def random_case(seed, big=False):
+def random_case(seed, big=False, small=False):
     rng = np.random.default_rng(50_000 + seed)
-    u = rng.random()
+    u = rng.random() * (0.15 if small else 1.0)         # small: 1 to 4 parameters only -- the test problems of test/runtests.jl
     d = int(rng.integers(1, 5)) if u < 0.15 else int(rng.integers(1, 49)) if u < 0.9 else int(rng.integers(65, 141))
     nfam = [5, 18, 25][int(rng.integers(0, 3))] if d <= 48 else 5          # (wide rows: the reference's five families, as the suite)
     sim_kind = "mvn"
@@ -56,7 +56,28 @@ def random_case(seed, big=False):
         sim_kind = "normal1d"
     elif d == 4 and rng.random() < 0.5:
         sim_kind = "lv"
-    if sim_kind == "lv":
+    elif d <= 2 and rng.random() < 0.6:                  # the other test problems of test/runtests.jl, their own priors perturbed
+        sim_kind = [["dirac", "mixture01"], ["quad2d", "normdu", "wiener", "socks"]][d - 1][int(rng.integers(0, 2 if d == 1 else 4))]
+    if sim_kind in ("dirac", "mixture01", "quad2d", "normdu", "wiener", "socks"):
+        b = bool(rng.random() < 0.3)
+        u = lambda lo, hi: float(rng.uniform(lo, hi))                                   # noqa: E731
+        if sim_kind == "dirac":
+            prior, sim = A.Normal(u(0.8, 1.2), u(0.15, 0.4)), A.DiracSquare(u(1.3, 2.5), blobs=b)
+        elif sim_kind == "mixture01":
+            prior, sim = A.Uniform(-10.0, u(5.0, 10.0)), A.Mixture01(u(-1.0, 1.0), blobs=b)
+        elif sim_kind == "quad2d":
+            prior, sim = A.Factored(A.Normal(0, u(2.0, 5.0)), A.Normal(0, u(2.0, 5.0))), A.Quad2D([0.0, 0.1, 0.5][int(rng.integers(0, 3))], blobs=b)
+        elif sim_kind == "normdu":
+            prior, sim = A.Factored(A.Normal(1, u(0.3, 0.8)), A.DiscreteUniform(1, int(rng.integers(4, 12)))), A.NormalTimesDU(u(3.0, 8.0), blobs=b)
+        elif sim_kind == "wiener":
+            mu, sg = u(0.2, 0.8), u(0.5, 2.0)
+            tdata = tuple(math.sqrt(mu * mu * t * t + sg * sg * t) for t in range(int(rng.integers(5, 30))))
+            prior, sim = A.Factored(A.Uniform(0, 1), A.Uniform(0, 4)), A.WienerRMS(tdata, blobs=b)
+        else:
+            r_ = u(3.0, 7.0)
+            prior = A.Factored(A.NegativeBinomial(r_, r_ / (u(20.0, 40.0) + r_)), A.Beta(u(8.0, 20.0), u(1.5, 4.0)))
+            sim = A.Socks(float(rng.integers(0, 3)), float(rng.integers(7, 12)), blobs=b)
+    elif sim_kind == "lv":
         prior = A.Factored(*[A.Uniform(0.0, float(rng.uniform(1.5, 2.5))) for _ in range(4)])
         obs = (1.0, 0.5, 1.46, 0.43, 1.77, 0.62, 1.52, 1.13, 0.95, 1.31, 0.66, 1.09, 0.61, 0.79, 0.75, 0.6)
         sim = A.LotkaVolterraRK4(obs, dt=0.05, steps_per_obs=int(rng.integers(4, 12)), blobs=bool(rng.random() < 0.3))
@@ -191,6 +212,7 @@ def main():
     ap.add_argument("--user", action="store_true", help="the library runs the Normal simulator as USER-SUPPLIED source (run-time compiled: one thread per "
                     "row up to 16 parameters, in two launches or inside the sweep kernel; the cooperative form beyond), the oracle the built-in")
     ap.add_argument("--resume", action="store_true", help="also interrupt every run at a random generation and continue it from its checkpoint")
+    ap.add_argument("--small", action="store_true", help="1 to 4 parameters only: the built-in simulators of the reference's test problems")
     ap.add_argument("--big", action="store_true", help="populations of 50,000 to 600,000 particles, rows up to 48 parameters, at most 8 generations")
     args = ap.parse_args()
     O.build()
@@ -199,7 +221,7 @@ def main():
     for seed in range(args.first, args.first + args.cases):
         if args.seconds and time.time() - t0 > args.seconds:
             break
-        c = random_case(seed, big=args.big)
+        c = random_case(seed, big=args.big, small=args.small)
         if args.big:
             c["max_iters"] = 8
             c["mc"]["generations"] = min(c["mc"]["generations"], 4)
