@@ -4,6 +4,7 @@ result fields, and the C-ABI surface (library loads, exports every declared symb
 loudly without a GPU).  CPU only -- no compute call goes to the HIP library here."""
 import ctypes
 import inspect
+import json
 import math
 import os
 import re
@@ -428,3 +429,19 @@ def test_shim_block_structure_balances():
                 stack.append((tok, no))
     assert not stack, f"unclosed blocks: {stack}"
     assert src.rstrip().splitlines()[-1].startswith("end")
+
+
+def test_differential_campaign_tool_runs_its_cases():
+    """tools/fuzz_parity.py (the differential campaign of profiles/r06_fuzz_parity_summary.json) with the oracle on both sides: the case
+    generator, the driver keywords it exercises and its comparison code stay runnable where there is no GPU"""
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, ABZ_FUZZ_SELFTEST="1")
+    for extra in ([], ["--small"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "12", "--first", "7000", *extra],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        last = json.loads(r.stdout.strip().splitlines()[-1])
+        assert last["summary"] and last["ran"] == 12 and last["different"] == 0
