@@ -25,7 +25,7 @@ import torch.distributed as dist                         # noqa: E402
 
 import abcdez_amd as A                                   # noqa: E402
 from abcdez_amd.engine import HipEngine                  # noqa: E402
-from fuzz_parity import random_case, same                # noqa: E402
+from fuzz_parity import random_case, same, user_form_of                # noqa: E402
 
 
 def main():
@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seconds", type=float, default=0.0)
+    ap.add_argument("--big", action="store_true", help="populations of 50,000 to 600,000 particles (chunks of many workgroups), at most 8 generations")
+    ap.add_argument("--user", action="store_true", help="the Normal simulator as user-supplied source (run-time compiled sweep / replay / abcdemc kernels)")
     args = ap.parse_args()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -45,10 +47,19 @@ def main():
         dist.broadcast(stop, src=0)                      # every rank leaves the loop at the same case
         if int(stop):
             break
-        c = random_case(seed)
+        c = random_case(seed, big=args.big)
+        if args.big:
+            c["mc"]["generations"] = min(c["mc"]["generations"], 4)
+        if args.user:
+            if c["sim"] == "mvn" and c["simulator"].blobs:
+                c["simulator"] = A.MVNormal(tuple(c["simulator"].data()), sigma=c["simulator"].params()[0])
+            usim = user_form_of(c["simulator"], c["d"], np.random.default_rng(seed))
+            if usim is None:
+                continue
+            c["simulator"] = usim
         prior, sim, kern = c["prior"], c["simulator"], c["ABCk"]
         N = -(-c["N"] // 12) * 12                        # divisible by worlds of 1, 2, 3 and 4 ranks
-        kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=30, **c["smc"])
+        kw = dict(nparticles=N, verbose=False, rng=seed + 1, ABCk=kern, max_iters=8 if args.big else 30, **c["smc"])
         # the target: a quantile of the initial distances, taken from the unsharded engine (the same on every rank)
         probe = HipEngine(A.ModelSpec(prior, sim, kern, seed=seed + 1), N)
         probe.init_population()
